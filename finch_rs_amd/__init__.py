@@ -1,0 +1,9 @@
+"""finch_rs_amd -- MI355X-native MinHash sketching engine behind finch's sketching interface.
+
+Only the hot path of onecodex/finch-rs lives here: hand-written gfx950 kernels +
+the C ABI (csrc/, include/finch_hip.h) and the host-side mirror of the reference's interface for
+that path.  Importing this package never falls back to a CPU implementation.
+"""
+from ._lib import FinchHipError, SO_PATH, load  # noqa: F401
+from .sketch_schemes import (DeviceBuffer, FinchError, HipSketcher, KmerCount, SketchParams,  # noqa: F401
+                             device_count)

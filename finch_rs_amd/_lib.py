@@ -1,0 +1,80 @@
+"""ctypes loader of libfinch_hip.so (the C ABI in include/finch_hip.h).
+
+The product path has no CPU implementation: if the HIP library is missing or no device is usable,
+everything here fails loudly instead of falling back."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libfinch_hip.so")
+
+FH_OK = 0
+FH_ERR_INVALID, FH_ERR_NO_DEVICE, FH_ERR_HIP, FH_ERR_STATE, FH_ERR_CAPACITY, FH_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+KIND_MASH, KIND_SCALED = 0, 1
+
+
+class FhParams(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("k", C.c_uint32), ("size", C.c_uint64), ("seed", C.c_uint64),
+                ("scale", C.c_double), ("max_launch", C.c_uint64), ("hash_mask", C.c_uint64)]
+
+
+class FinchHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("finch_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+# every symbol include/finch_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_U64P, _U32P, _U8P = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+SYMBOLS = {
+    "fh_device_count": (C.c_int, []),
+    "fh_last_error": (C.c_char_p, []),
+    "fh_abi_version": (C.c_int, []),
+    "fh_new": (_P, [C.POINTER(FhParams), C.c_int]),
+    "fh_free": (None, [_P]),
+    "fh_reset": (C.c_int, [_P]),
+    "fh_set_stream_offset": (C.c_int, [_P, C.c_uint64]),
+    "fh_push_block": (C.c_int, [_P, _P, C.c_uint64]),
+    "fh_push_device": (C.c_int, [_P, _P, C.c_uint64]),
+    "fh_sync": (C.c_int, [_P]),
+    "fh_finish": (C.c_int, [_P, _U64P, _U64P]),
+    "fh_copy_out": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "fh_merge": (C.c_int, [_P, _P]),
+    "fh_merge_arrays": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, C.c_uint64]),
+    "fh_set_profiling": (C.c_int, [_P, C.c_int]),
+    "fh_kernel_time": (C.c_int, [_P, C.POINTER(C.c_double), _U64P, _U64P]),
+    "fh_device_alloc": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(_P)]),
+    "fh_device_free": (C.c_int, [C.c_int, _P]),
+    "fh_copy_to_device": (C.c_int, [C.c_int, _P, _P, C.c_uint64]),
+    "fh_copy_from_device": (C.c_int, [C.c_int, _P, _P, C.c_uint64]),
+    "fh_synth_genome_host": (C.c_int, [_P, C.c_uint64, C.c_uint64]),
+    "fh_synth_genome_device": (C.c_int, [C.c_int, _P, C.c_uint64, C.c_uint64]),
+    "fh_synth_reads_host": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64,
+                                      C.c_uint32, C.c_uint32]),
+    "fh_synth_reads_device": (C.c_int, [C.c_int, _P, _P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64,
+                                        C.c_uint32, C.c_uint32]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libfinch_hip.so and bind every declared symbol.  Raises if the library is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise FinchHipError(FH_ERR_NO_DEVICE, "%s not built -- run `python finch_rs_amd/csrc/build.py` "
+                                "(or __graft_entry__.build())" % SO_PATH)
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != FH_OK:
+        raise FinchHipError(rc, (load().fh_last_error() or b"").decode(errors="replace"))

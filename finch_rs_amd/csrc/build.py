@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Build libfinch_hip.so for gfx950 (hipcc cross-compiles without a GPU).
+
+    python finch_rs_amd/csrc/build.py [--force]
+
+The hot kernel (fh_k2.hip) is compiled as FH_NPARTS translation units in parallel, one per share of
+K = 1..32; everything is linked into finch_rs_amd/libfinch_hip.so (in-tree, travels with the repo).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, "libfinch_hip.so")
+OBJ = os.path.join(HERE, "obj")
+NPARTS = 4
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2.hip", "fh_kernels.hip", "fh_api.hip",
+           os.path.join("..", "..", "include", "finch_hip.h")]
+
+
+def _newest_src():
+    return max(os.path.getmtime(os.path.join(HERE, s)) for s in SOURCES)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, cwd=HERE, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= _newest_src():
+        return OUT
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    for part in range(NPARTS):
+        jobs.append([HIPCC] + FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2.hip", "-o", os.path.join(OBJ, "fh_k2_%d.o" % part)])
+    jobs.append([HIPCC] + FLAGS + ["-c", "fh_kernels.hip", "-o", os.path.join(OBJ, "fh_kernels.o")])
+    jobs.append([HIPCC] + FLAGS + ["-c", "fh_api.hip", "-o", os.path.join(OBJ, "fh_api.o")])
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        outs = list(ex.map(_run, jobs))
+    if verbose:
+        for o in outs:
+            if o.strip():
+                print(o)
+    objs = [j[-1] for j in jobs]
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

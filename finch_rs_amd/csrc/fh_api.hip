@@ -1,0 +1,683 @@
+// fh_api.hip -- host side of the C ABI declared in include/finch_hip.h.
+//
+// One handle = one device + one HIP stream + the device-resident sketch state (fh_device.h).
+// The host only stages bytes, sizes launches and copies the final <= n records back; every
+// per-base operation of the reference's process()/push() (mash.rs:34-80) runs in fh_kernels.hip.
+// There is deliberately no CPU implementation of the sketching path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/finch_hip.h"
+#include "fh_core.h"
+#include "fh_device.h"
+#include "fh_kernels.h"
+
+using namespace fh;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(FH_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+constexpr uint64_t DEFAULT_MAX_LAUNCH = 64ull << 20; // k-mer start positions per launch
+constexpr uint64_t FIRST_LAUNCH = 4096;
+constexpr uint32_t CLOG_CAP = 4096;
+constexpr uint64_t STAGE_BYTES = 64ull << 20;
+constexpr int N_STAGE = 2;
+
+struct ResultRec {
+    uint64_t hash;
+    uint32_t count, extra;
+    uint64_t kmer; // m-form
+    uint64_t pos;
+};
+
+} // namespace
+
+struct fh_sketcher {
+    fh_params p{};
+    int device = 0;
+    uint64_t max_hash = 0; // scaled
+    uint64_t max_launch = 0;
+    hipStream_t stream = nullptr;
+
+    // device state
+    Entry *table = nullptr;
+    uint32_t cap = 0;
+    uint32_t *live = nullptr;
+    uint32_t live_cap = 0;
+    uint32_t *dead = nullptr; // slots dropped from the live list (garbage to clear on reset)
+    uint32_t dead_cap = 0;
+    Ctl *ctl = nullptr;
+    CollRec *clog = nullptr;
+    // gather outputs (device), capacity SMALL_MAX
+    uint64_t *o_hash = nullptr, *o_kmer = nullptr, *o_pos = nullptr;
+    uint32_t *o_count = nullptr, *o_extra = nullptr;
+    // staging
+    uint8_t *h_stage[N_STAGE] = {nullptr, nullptr};
+    uint8_t *d_stage[N_STAGE] = {nullptr, nullptr};
+    hipEvent_t stage_done[N_STAGE] = {nullptr, nullptr};
+    bool stage_busy[N_STAGE] = {false, false};
+    int stage_next = 0;
+    Ctl *h_ctl = nullptr; // pinned
+
+    // host bookkeeping
+    uint64_t stream_off = 0;     // stream coordinate of the next byte
+    uint64_t positions_done = 0; // k-mer start positions processed since reset
+    uint32_t trigger = 0;
+    bool open_loop = false;      // threshold tight enough that launches need no host feedback
+    uint64_t last_tau = ~0ull;   // as of the last status readback
+    uint32_t last_live = 0;
+    bool finished = false;
+    bool dirty = false; // device table holds entries from this run
+
+    // profiling
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
+    double prof_ms = 0.0;
+    uint64_t prof_launches = 0, prof_positions = 0;
+
+    // finished result (host), ascending by hash
+    std::vector<ResultRec> res;
+    uint64_t total_kmers = 0;
+};
+
+namespace {
+
+uint64_t scaled_max_hash(double scale) {
+    // scaled.rs:23,31 : iscale = (1. / scale) as u64 (saturating cast) ; max_hash = u64::MAX / iscale
+    double inv = 1.0 / scale;
+    uint64_t iscale;
+    if (!(inv == inv) || inv <= 0.0) iscale = 0;
+    else if (inv >= 18446744073709551616.0) iscale = UINT64_MAX;
+    else iscale = (uint64_t)inv;
+    return iscale ? UINT64_MAX / iscale : UINT64_MAX;
+}
+
+uint64_t initial_tau(const fh_sketcher *s) {
+    if (s->p.kind == FH_KIND_SCALED && s->p.size == 0) return s->max_hash;
+    return EMPTY64;
+}
+
+int set_device(const fh_sketcher *s) {
+    HIP_TRY(hipSetDevice(s->device));
+    return FH_OK;
+}
+
+int init_state(fh_sketcher *s) {
+    HIP_TRY(launch_init_ctl(s->ctl, initial_tau(s), s->stream));
+    s->stream_off = 0;
+    s->positions_done = 0;
+    s->open_loop = false;
+    s->last_tau = initial_tau(s);
+    s->last_live = 0;
+    s->finished = false;
+    s->dirty = false;
+    s->res.clear();
+    s->total_kmers = 0;
+    s->prof_used = 0;
+    s->prof_ms = 0.0;
+    s->prof_launches = 0;
+    s->prof_positions = 0;
+    return FH_OK;
+}
+
+double admit_rate(uint64_t tau) { return tau == EMPTY64 ? 1.0 : ((double)tau + 1.0) / 18446744073709551616.0; }
+
+// Warm-up is closed-loop: while the admit threshold is loose, a launch may insert up to one new hash
+// per position, so its size is chosen from the threshold read back after the previous launch such that
+// the live set stays inside what the in-LDS prune can sort.  tau only ever decreases, so once a
+// maximum-size launch is safe it stays safe and launches go open-loop (no host feedback).
+uint64_t next_launch_size(const fh_sketcher *s) {
+    if (s->open_loop) return s->max_launch;
+    const double room = (double)(SMALL_MAX - std::min<uint32_t>(s->last_live, SMALL_MAX));
+    double P = 0.5 * room / admit_rate(s->last_tau);
+    if (P > (double)s->max_launch) P = (double)s->max_launch;
+    uint64_t Pi = ((uint64_t)P / TILE_POS) * TILE_POS;
+    return std::max<uint64_t>(Pi, TILE_POS);
+}
+
+int check_ctl(fh_sketcher *s);
+
+int collect_profile(fh_sketcher *s) {
+    for (size_t i = 0; i < s->prof_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->prof_events[i].first, s->prof_events[i].second));
+        s->prof_ms += ms;
+    }
+    s->prof_used = 0;
+    return FH_OK;
+}
+
+// sketch [0,len) of a device-resident packed stream whose first byte has stream coordinate base_pos
+int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos) {
+    if (len < s->p.k) return FH_OK;
+    const uint64_t n_pos = len - s->p.k + 1; // windows that fit
+    uint64_t pos = 0;
+    hipDeviceProp_t *prop = nullptr;
+    (void)prop;
+    while (pos < n_pos) {
+        const uint64_t P = next_launch_size(s);
+        const uint64_t end = std::min<uint64_t>(n_pos, pos + P);
+        SketchArgs a{};
+        a.seq = d_seq;
+        a.len_total = len;
+        a.p_begin = pos;
+        a.p_end = end;
+        a.base_pos = base_pos;
+        a.seed = s->p.seed;
+        a.hash_mask = s->p.hash_mask ? s->p.hash_mask : ~0ull;
+        a.table = s->table;
+        a.cap = s->cap;
+        a.live = s->live;
+        a.live_cap = s->live_cap;
+        a.ctl = s->ctl;
+        a.clog = s->clog;
+        a.clog_cap = CLOG_CAP;
+        const uint64_t tiles = (end - pos + TILE_POS - 1) / TILE_POS;
+        a.tiles_total = (uint32_t)tiles;
+        const uint64_t max_waves = 256ull * 16; // 4 workgroups of 4 waves per CU
+        uint64_t waves = std::min<uint64_t>(tiles, max_waves);
+        a.tiles_per_wave = (uint32_t)((tiles + waves - 1) / waves);
+        waves = (tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
+        const int blocks = (int)((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (s->profiling) {
+            if (s->prof_used == s->prof_events.size()) {
+                hipEvent_t a0, a1;
+                HIP_TRY(hipEventCreate(&a0));
+                HIP_TRY(hipEventCreate(&a1));
+                s->prof_events.emplace_back(a0, a1);
+            }
+            e0 = s->prof_events[s->prof_used].first;
+            e1 = s->prof_events[s->prof_used].second;
+            s->prof_used++;
+            HIP_TRY(hipEventRecord(e0, s->stream));
+        }
+        HIP_TRY(launch_k2((int)s->p.k, a, blocks, s->stream));
+        if (s->profiling) {
+            HIP_TRY(hipEventRecord(e1, s->stream));
+            s->prof_launches++;
+            s->prof_positions += end - pos;
+        }
+        HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size, s->max_hash,
+                                   s->trigger, s->open_loop ? 0u : 1u, s->stream));
+        s->positions_done += end - pos;
+        s->dirty = true;
+        pos = end;
+        if (!s->open_loop) {
+            if (int rc = check_ctl(s)) return rc;
+            s->last_tau = s->h_ctl->tau;
+            s->last_live = s->h_ctl->n_live;
+            const double room = (double)(SMALL_MAX - std::min<uint64_t>(std::max<uint64_t>(s->p.size, s->last_live), SMALL_MAX));
+            if ((double)s->max_launch * admit_rate(s->last_tau) <= 0.25 * room) s->open_loop = true;
+        }
+    }
+    return FH_OK;
+}
+
+int check_ctl(fh_sketcher *s) {
+    HIP_TRY(hipMemcpyAsync(s->h_ctl, s->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->h_ctl->overflow == 1) return fail(FH_ERR_CAPACITY, "device hash table capacity exceeded");
+    if (s->h_ctl->overflow == 2) return fail(FH_ERR_CAPACITY, "hash collision log capacity exceeded");
+    if (s->h_ctl->need_big || s->h_ctl->launches_skipped)
+        return fail(FH_ERR_UNSUPPORTED,
+                    "sketch needs more than %d live hashes on the device; this build only has the in-LDS "
+                    "bottom-n selection (kmers_to_sketch too large)",
+                    SMALL_MAX);
+    return FH_OK;
+}
+
+void select_final(const fh_sketcher *s, std::vector<ResultRec> &v) {
+    // v ascending by hash and distinct.  mash.rs:57-60 / scaled.rs:41-58 net effect.
+    if (s->p.kind == FH_KIND_MASH) {
+        if (v.size() > s->p.size) v.resize(s->p.size);
+    } else {
+        size_t n_le = 0;
+        while (n_le < v.size() && v[n_le].hash <= s->max_hash) ++n_le;
+        size_t keep = std::max<size_t>(n_le, std::min<size_t>(v.size(), s->p.size));
+        v.resize(keep);
+    }
+}
+
+void kmer_ascii(uint64_t m, int k, uint8_t *out) {
+    for (int b = 0; b < k; ++b) out[b] = (uint8_t) "ACGT"[(m >> (2 * (k - 1 - b))) & 3u];
+}
+
+uint64_t ascii_kmer(const uint8_t *in, int k) {
+    uint64_t m = 0;
+    for (int b = 0; b < k; ++b) {
+        const uint8_t c = in[b];
+        const uint64_t code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3;
+        m = (m << 2) | code;
+    }
+    return m;
+}
+
+uint32_t sat_add(uint32_t a, uint32_t b) {
+    const uint32_t r = a + b;
+    return r < a ? UINT32_MAX : r;
+}
+
+} // namespace
+
+extern "C" {
+
+int fh_abi_version(void) { return 1; }
+
+const char *fh_last_error(void) { return g_err.c_str(); }
+
+int fh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+fh_sketcher *fh_new(const fh_params *params, int device) {
+    if (!params) {
+        fail(FH_ERR_INVALID, "params is NULL");
+        return nullptr;
+    }
+    if (params->k < 1 || params->k > 32) {
+        fail(FH_ERR_UNSUPPORTED, "kmer_length %u outside the device range 1..32", params->k);
+        return nullptr;
+    }
+    if (params->kind != FH_KIND_MASH && params->kind != FH_KIND_SCALED) {
+        fail(FH_ERR_INVALID, "unknown sketch kind %u", params->kind);
+        return nullptr;
+    }
+    if (params->kind == FH_KIND_SCALED && !(params->scale > 0.0 && params->scale <= 1.0)) {
+        fail(FH_ERR_INVALID, "scale must be in (0, 1]");
+        return nullptr;
+    }
+    int ndev = fh_device_count();
+    if (ndev <= 0 || device < 0 || device >= ndev) {
+        fail(FH_ERR_NO_DEVICE, "no usable HIP device (requested %d of %d)", device, ndev);
+        return nullptr;
+    }
+    fh_sketcher *s = new fh_sketcher();
+    s->p = *params;
+    s->device = device;
+    s->max_hash = params->kind == FH_KIND_SCALED ? scaled_max_hash(params->scale) : 0;
+    s->max_launch = params->max_launch ? params->max_launch : DEFAULT_MAX_LAUNCH;
+    s->max_launch = std::max<uint64_t>((s->max_launch / TILE_POS) * TILE_POS, FIRST_LAUNCH);
+    if (s->max_launch > (1ull << 30)) s->max_launch = 1ull << 30;
+    // prune when the live list has doubled (or is about to outgrow the in-LDS sort)
+    {
+        uint64_t n = params->size;
+        uint64_t t = std::min<uint64_t>(2 * n, (n + SMALL_MAX) / 2);
+        if (params->kind == FH_KIND_SCALED) t = std::min<uint64_t>(t, SMALL_MAX / 2);
+        s->trigger = (uint32_t)std::min<uint64_t>(t, SMALL_MAX - 1);
+    }
+    auto bail = [&](const char *what, hipError_t e) -> fh_sketcher * {
+        fail(FH_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+        fh_free(s);
+        return nullptr;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    // worst case a launch inserts one new hash per position: size the table so that it can never fill
+    const uint64_t live_cap = s->max_launch + SMALL_MAX + 64;
+    const uint64_t cap = 2 * live_cap;
+    if (cap >= (1ull << 32)) {
+        fail(FH_ERR_INVALID, "max_launch too large");
+        fh_free(s);
+        return nullptr;
+    }
+    s->cap = (uint32_t)cap;
+    s->live_cap = (uint32_t)live_cap;
+    if ((e = hipMalloc(&s->table, cap * sizeof(Entry))) != hipSuccess) return bail("hipMalloc(table)", e);
+    if ((e = hipMalloc(&s->live, live_cap * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(live)", e);
+    s->dead_cap = 4u << 20;
+    if ((e = hipMalloc(&s->dead, (size_t)s->dead_cap * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(dead)", e);
+    if ((e = hipMalloc(&s->ctl, sizeof(Ctl))) != hipSuccess) return bail("hipMalloc(ctl)", e);
+    if ((e = hipMalloc(&s->clog, CLOG_CAP * sizeof(CollRec))) != hipSuccess) return bail("hipMalloc(clog)", e);
+    if ((e = hipMalloc(&s->o_hash, SMALL_MAX * 8)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&s->o_kmer, SMALL_MAX * 8)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&s->o_pos, SMALL_MAX * 8)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&s->o_count, SMALL_MAX * 4)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc(&s->o_extra, SMALL_MAX * 4)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipHostMalloc(&s->h_ctl, sizeof(Ctl), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    if ((e = launch_fill_table(s->table, cap, s->stream)) != hipSuccess) return bail("fill_table", e);
+    if (init_state(s) != FH_OK) {
+        fh_free(s);
+        return nullptr;
+    }
+    if ((e = hipStreamSynchronize(s->stream)) != hipSuccess) return bail("hipStreamSynchronize", e);
+    return s;
+}
+
+void fh_free(fh_sketcher *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (auto &pe : s->prof_events) {
+        (void)hipEventDestroy(pe.first);
+        (void)hipEventDestroy(pe.second);
+    }
+    for (int i = 0; i < N_STAGE; ++i) {
+        if (s->h_stage[i]) (void)hipHostFree(s->h_stage[i]);
+        if (s->d_stage[i]) (void)hipFree(s->d_stage[i]);
+        if (s->stage_done[i]) (void)hipEventDestroy(s->stage_done[i]);
+    }
+    if (s->h_ctl) (void)hipHostFree(s->h_ctl);
+    (void)hipFree(s->table);
+    (void)hipFree(s->live);
+    (void)hipFree(s->dead);
+    (void)hipFree(s->ctl);
+    (void)hipFree(s->clog);
+    (void)hipFree(s->o_hash);
+    (void)hipFree(s->o_kmer);
+    (void)hipFree(s->o_pos);
+    (void)hipFree(s->o_count);
+    (void)hipFree(s->o_extra);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+int fh_reset(fh_sketcher *s) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (int rc = set_device(s)) return rc;
+    if (s->dirty) {
+        // clear only the slots this run touched (live + dropped); fall back to a full refill if the
+        // dropped-slot list overflowed
+        HIP_TRY(launch_clear_slots(s->table, s->cap, s->live, s->dead, s->ctl, s->stream));
+    }
+    return init_state(s);
+}
+
+int fh_set_stream_offset(fh_sketcher *s, uint64_t offset) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    s->stream_off = offset;
+    return FH_OK;
+}
+
+int fh_push_device(fh_sketcher *s, const void *dev_bytes, uint64_t len) {
+    if (!s || (!dev_bytes && len)) return fail(FH_ERR_INVALID, "null argument");
+    if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    if (((uintptr_t)dev_bytes & 15u) != 0) return fail(FH_ERR_INVALID, "device block must be 16-byte aligned");
+    if (int rc = set_device(s)) return rc;
+    int rc = sketch_device_range(s, (const uint8_t *)dev_bytes, len, s->stream_off);
+    s->stream_off += len;
+    return rc;
+}
+
+int fh_push_block(fh_sketcher *s, const uint8_t *bytes, uint64_t len) {
+    if (!s || (!bytes && len)) return fail(FH_ERR_INVALID, "null argument");
+    if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    if (int rc = set_device(s)) return rc;
+    for (int i = 0; i < N_STAGE; ++i) {
+        if (!s->h_stage[i]) {
+            HIP_TRY(hipHostMalloc((void **)&s->h_stage[i], STAGE_BYTES + 64, hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void **)&s->d_stage[i], STAGE_BYTES + 64));
+            HIP_TRY(hipEventCreateWithFlags(&s->stage_done[i], hipEventDisableTiming));
+        }
+    }
+    // normalize(false) drops whitespace (needletail; mash.rs:73): strip it while staging so that device
+    // positions are contiguous.  k-mers may span staging slices of one block: carry K-1 bytes over.
+    const uint32_t K = s->p.k;
+    uint8_t carry[32];
+    uint32_t carry_len = 0;
+    uint64_t in = 0;
+    while (in < len) {
+        const int b = s->stage_next;
+        if (s->stage_busy[b]) {
+            HIP_TRY(hipEventSynchronize(s->stage_done[b]));
+            s->stage_busy[b] = false;
+        }
+        uint8_t *dst = s->h_stage[b];
+        uint64_t m = 0;
+        memcpy(dst, carry, carry_len);
+        m = carry_len;
+        while (in < len && m < STAGE_BYTES) {
+            const uint8_t c = bytes[in++];
+            if (c == ' ' || c == '\t' || c == '\r' || c == '\n') continue;
+            dst[m++] = c;
+        }
+        const uint64_t fresh = m - carry_len;
+        const uint64_t base = s->stream_off - carry_len;
+        HIP_TRY(hipMemcpyAsync(s->d_stage[b], dst, m, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+        s->stage_busy[b] = true;
+        if (int rc = sketch_device_range(s, s->d_stage[b], m, base)) return rc;
+        s->stream_off += fresh;
+        // the next H2D into d_stage[b] is stream-ordered after these kernels
+        carry_len = (uint32_t)std::min<uint64_t>(K - 1, m);
+        memcpy(carry, dst + m - carry_len, carry_len);
+        s->stage_next = (b + 1) % N_STAGE;
+    }
+    return FH_OK;
+}
+
+int fh_sync(fh_sketcher *s) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (int rc = set_device(s)) return rc;
+    if (int rc = check_ctl(s)) return rc;
+    return collect_profile(s);
+}
+
+int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (int rc = set_device(s)) return rc;
+    if (!s->finished) {
+        HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size, s->max_hash,
+                                   0u, 1u, s->stream));
+        HIP_TRY(launch_gather(s->table, s->live, s->ctl, (int)s->p.k, s->o_hash, s->o_count, s->o_extra, s->o_kmer,
+                              s->o_pos, SMALL_MAX, s->stream));
+        if (int rc = check_ctl(s)) return rc;
+        if (int rc = collect_profile(s)) return rc;
+        const Ctl c = *s->h_ctl;
+        const uint32_t n = c.n_live;
+        std::vector<uint64_t> hh(n), kk(n), pp(n);
+        std::vector<uint32_t> cc(n), ee(n);
+        if (n) {
+            HIP_TRY(hipMemcpyAsync(hh.data(), s->o_hash, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(kk.data(), s->o_kmer, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(pp.data(), s->o_pos, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(cc.data(), s->o_count, n * 4ull, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(ee.data(), s->o_extra, n * 4ull, hipMemcpyDeviceToHost, s->stream));
+        }
+        std::vector<CollRec> coll(std::min<uint32_t>(c.n_coll, CLOG_CAP));
+        if (!coll.empty())
+            HIP_TRY(hipMemcpyAsync(coll.data(), s->clog, coll.size() * sizeof(CollRec), hipMemcpyDeviceToHost, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        s->res.resize(n);
+        for (uint32_t i = 0; i < n; ++i) s->res[i] = ResultRec{hh[i], cc[i], ee[i], kk[i], pp[i]};
+        // the hash value that cannot be a table key, if it occurred (it sorts last)
+        if (c.sp_count) {
+            ResultRec r{EMPTY64, (uint32_t)std::min<uint64_t>(c.sp_count, UINT32_MAX),
+                        (uint32_t)std::min<uint64_t>(c.sp_extra, UINT32_MAX), c.sp_kmer, c.sp_pos};
+            s->res.push_back(r);
+        }
+        select_final(s, s->res);
+        // 64-bit hash collisions between distinct k-mers: the reference keeps the bytes of the first
+        // occurrence (mash.rs:52-56).  Occurrences whose k-mer differed from the slot's were logged.
+        for (const CollRec &cr : coll) {
+            auto it = std::lower_bound(s->res.begin(), s->res.end(), cr.hash,
+                                       [](const ResultRec &r, uint64_t h) { return r.hash < h; });
+            if (it != s->res.end() && it->hash == cr.hash && it->pos == cr.pos) it->kmer = cr.kmer;
+        }
+        s->total_kmers = c.total_kmers;
+        s->finished = true;
+    }
+    if (n_out) *n_out = s->res.size();
+    if (total_kmers) *total_kmers = s->total_kmers;
+    return FH_OK;
+}
+
+int fh_copy_out(fh_sketcher *s, uint64_t *hashes, uint32_t *counts, uint32_t *extra_counts, uint8_t *kmers,
+                uint64_t *first_pos) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (!s->finished) return fail(FH_ERR_STATE, "fh_copy_out before fh_finish");
+    const int k = (int)s->p.k;
+    for (size_t i = 0; i < s->res.size(); ++i) {
+        const ResultRec &r = s->res[i];
+        if (hashes) hashes[i] = r.hash;
+        if (counts) counts[i] = r.count;
+        if (extra_counts) extra_counts[i] = r.extra;
+        if (kmers) kmer_ascii(r.kmer, k, kmers + i * (size_t)k);
+        if (first_pos) first_pos[i] = r.pos;
+    }
+    return FH_OK;
+}
+
+int fh_merge_arrays(fh_sketcher *dst, uint64_t n, const uint64_t *hashes, const uint32_t *counts,
+                    const uint32_t *extra_counts, const uint8_t *kmers, const uint64_t *first_pos,
+                    uint64_t total_kmers) {
+    if (!dst || (n && (!hashes || !counts || !extra_counts || !kmers || !first_pos)))
+        return fail(FH_ERR_INVALID, "null argument");
+    if (!dst->finished) return fail(FH_ERR_STATE, "fh_merge: dst not finished");
+    const int k = (int)dst->p.k;
+    std::vector<ResultRec> out;
+    out.reserve(dst->res.size() + n);
+    size_t i = 0;
+    uint64_t j = 0;
+    while (i < dst->res.size() || j < n) {
+        if (j > 0 && j < n && hashes[j] <= hashes[j - 1]) return fail(FH_ERR_INVALID, "fh_merge: src not ascending");
+        if (j >= n || (i < dst->res.size() && dst->res[i].hash < hashes[j])) {
+            out.push_back(dst->res[i++]);
+        } else {
+            ResultRec r{hashes[j], counts[j], extra_counts[j], ascii_kmer(kmers + j * (size_t)k, k), first_pos[j]};
+            if (i < dst->res.size() && dst->res[i].hash == r.hash) {
+                const ResultRec &d = dst->res[i++];
+                r.count = sat_add(r.count, d.count);
+                r.extra = sat_add(r.extra, d.extra);
+                if (d.pos < r.pos) {
+                    r.pos = d.pos;
+                    r.kmer = d.kmer;
+                }
+            }
+            out.push_back(r);
+            ++j;
+        }
+    }
+    select_final(dst, out);
+    dst->res.swap(out);
+    dst->total_kmers += total_kmers;
+    return FH_OK;
+}
+
+int fh_merge(fh_sketcher *dst, const fh_sketcher *src) {
+    if (!dst || !src) return fail(FH_ERR_INVALID, "null handle");
+    if (!src->finished) return fail(FH_ERR_STATE, "fh_merge: src not finished");
+    if (dst->p.k != src->p.k || dst->p.kind != src->p.kind || dst->p.seed != src->p.seed || dst->p.size != src->p.size)
+        return fail(FH_ERR_INVALID, "fh_merge: incompatible sketch parameters");
+    const size_t n = src->res.size();
+    const int k = (int)src->p.k;
+    std::vector<uint64_t> hh(n), pp(n);
+    std::vector<uint32_t> cc(n), ee(n);
+    std::vector<uint8_t> km(n * (size_t)k + 1);
+    for (size_t i = 0; i < n; ++i) {
+        hh[i] = src->res[i].hash;
+        cc[i] = src->res[i].count;
+        ee[i] = src->res[i].extra;
+        pp[i] = src->res[i].pos;
+        kmer_ascii(src->res[i].kmer, k, km.data() + i * (size_t)k);
+    }
+    return fh_merge_arrays(dst, n, hh.data(), cc.data(), ee.data(), km.data(), pp.data(), src->total_kmers);
+}
+
+int fh_set_profiling(fh_sketcher *s, int enable) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    s->profiling = enable != 0;
+    return FH_OK;
+}
+
+int fh_kernel_time(fh_sketcher *s, double *total_ms, uint64_t *launches, uint64_t *positions) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (int rc = set_device(s)) return rc;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (int rc = collect_profile(s)) return rc;
+    if (total_ms) *total_ms = s->prof_ms;
+    if (launches) *launches = s->prof_launches;
+    if (positions) *positions = s->prof_positions;
+    return FH_OK;
+}
+
+int fh_device_alloc(int device, uint64_t bytes, void **out) {
+    if (!out) return fail(FH_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
+    return FH_OK;
+}
+
+int fh_device_free(int device, void *p) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(p));
+    return FH_OK;
+}
+
+int fh_copy_to_device(int device, void *dst, const void *src, uint64_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return FH_OK;
+}
+
+int fh_copy_from_device(int device, void *dst, const void *src, uint64_t bytes) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return FH_OK;
+}
+
+int fh_synth_genome_host(uint8_t *out, uint64_t len, uint64_t seed) {
+    if (!out && len) return fail(FH_ERR_INVALID, "null argument");
+    for (uint64_t i = 0; i < len; ++i) out[i] = synth_genome_base(seed, i);
+    return FH_OK;
+}
+
+int fh_synth_genome_device(int device, void *dev_out, uint64_t len, uint64_t seed) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(launch_synth_genome((uint8_t *)dev_out, len, seed, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return FH_OK;
+}
+
+int fh_synth_reads_host(uint8_t *out, const uint8_t *genome, uint64_t genome_len, uint64_t first_read,
+                        uint64_t n_reads, uint32_t read_len, uint64_t seed, uint32_t sub_ppm, uint32_t n_ppm) {
+    if ((!out || !genome) && n_reads) return fail(FH_ERR_INVALID, "null argument");
+    if (genome_len < read_len) return fail(FH_ERR_INVALID, "genome shorter than a read");
+    const uint64_t rec = (uint64_t)read_len + 1;
+    for (uint64_t r = 0; r < n_reads; ++r)
+        for (uint32_t j = 0; j <= read_len; ++j)
+            out[r * rec + j] = synth_read_byte(genome, genome_len, first_read + r, j, read_len, seed, sub_ppm, n_ppm);
+    return FH_OK;
+}
+
+int fh_synth_reads_device(int device, void *dev_out, const void *dev_genome, uint64_t genome_len,
+                          uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t seed,
+                          uint32_t sub_ppm, uint32_t n_ppm) {
+    if (genome_len < read_len) return fail(FH_ERR_INVALID, "genome shorter than a read");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(launch_synth_reads((uint8_t *)dev_out, (const uint8_t *)dev_genome, genome_len, first_read, n_reads,
+                               read_len, seed, sub_ppm, n_ppm, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return FH_OK;
+}
+
+} // extern "C"

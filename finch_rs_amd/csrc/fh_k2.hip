@@ -1,0 +1,209 @@
+// fh_k2.hip -- the hot kernel of the finch sketching path, hand-written for gfx950 (CDNA4, wave64).
+//
+//   k2_sketch<K>   replaces, per k-mer start position, the reference's
+//                  normalize -> reverse_complement -> canonical_kmers -> hash_f -> push admit test
+//                  (mash.rs:67-80, 34-42; hashing.rs:10-12).  Integer-ALU bound (the 64-bit multiplies of
+//                  murmur3); algorithmic HBM traffic is 1 byte per position.
+//
+// Wave-level structure (one wavefront = one independent worker, no workgroup barriers in the loop):
+//   * a wave owns a contiguous range of 2048-position tiles; lane l owns positions [32l, 32l+32) of a tile;
+//   * phase A: every lane loads ITS 32 bytes (2 x global_load_dwordx4, coalesced 2 KiB per wave), classifies
+//     them to 2-bit codes + good bits with packed byte arithmetic and stores them in a wave-private LDS
+//     ring (2 tiles deep) -- so the (K-1)-base halo of lane l is simply lane l+1's LDS words, and the
+//     halo of lane 63 is lane 0 of the next tile, which the ring already holds (classified once, used twice);
+//   * phase B: the lane rolls the forward window in two forms (see fh_core.h), picks the canonical word,
+//     hashes it with the LUT-based murmur3 (tables in LDS, built once per workgroup), compares with tau and
+//     takes the (rare) upsert path with device-scope atomics on the HBM table.
+//
+// This file is compiled FH_NPARTS times (-DFH_PART=i), each translation unit instantiating the kernel for
+// its share of K = 1..32, so that the build parallelises.
+#include <hip/hip_runtime.h>
+
+#include "fh_core.h"
+#include "fh_device.h"
+#include "fh_kernels.h"
+
+#ifndef FH_PART
+#error "compile with -DFH_PART=<0..FH_NPARTS-1>"
+#endif
+
+namespace fh {
+
+// ------------------------------------------------------------------------------------------------
+// rare path: one k-mer occurrence with hash <= tau
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void log_collision(const SketchArgs &a, u64 h, u64 kmer, u64 pos) {
+    u32 i = atomicAdd(&a.ctl->n_coll, 1u);
+    if (i < a.clog_cap) {
+        a.clog[i].hash = h;
+        a.clog[i].kmer = kmer;
+        a.clog[i].pos = pos;
+    } else {
+        atomicExch(&a.ctl->overflow, 2u);
+    }
+}
+
+__device__ __noinline__ void upsert(const SketchArgs &a, u64 h, u64 kmer, u64 pos, u32 strand) {
+    typedef unsigned long long ull;
+    if (h == EMPTY64) { // the one value that cannot be a table key
+        atomicAdd((ull *)&a.ctl->sp_count, 1ull);
+        if (strand) atomicAdd((ull *)&a.ctl->sp_extra, 1ull);
+        atomicMin((ull *)&a.ctl->sp_pos, (ull)pos);
+        ull oldk = atomicCAS((ull *)&a.ctl->sp_kmer, (ull)EMPTY64, (ull)kmer);
+        if (oldk != EMPTY64 && oldk != kmer) log_collision(a, h, kmer, pos);
+        return;
+    }
+    // admitted hashes are tiny numbers (<= tau) but their low bits are still uniform
+    u32 key32 = (u32)h ^ (u32)(h >> 32) * 0x9E3779B1u;
+    u32 slot = (u32)(((u64)key32 * (u64)a.cap) >> 32);
+    int probe = 0;
+    for (; probe < MAX_PROBE; ++probe) {
+        ull old = atomicCAS((ull *)&a.table[slot].hash, (ull)EMPTY64, (ull)h);
+        if (old == EMPTY64) {
+            u32 idx = atomicAdd(&a.ctl->n_live, 1u);
+            if (idx < a.live_cap) a.live[idx] = slot;
+            else atomicExch(&a.ctl->overflow, 1u);
+            break;
+        }
+        if (old == h) break;
+        slot = (slot + 1u == a.cap) ? 0u : slot + 1u;
+    }
+    if (probe == MAX_PROBE) {
+        atomicExch(&a.ctl->overflow, 1u);
+        return;
+    }
+    Entry *e = &a.table[slot];
+    atomicAdd((ull *)&e->count, 1ull);
+    if (strand) atomicAdd((ull *)&e->extra, 1ull);
+    atomicMin((ull *)&e->pos, (ull)pos);
+    ull oldk = atomicCAS((ull *)&e->kmer, (ull)EMPTY64, (ull)kmer);
+    if (oldk != EMPTY64 && oldk != kmer) log_collision(a, h, kmer, pos);
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase A: classify the lane's own 32 bytes of tile `t` into the wave's LDS ring
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 load_chunk_guarded(const uint8_t *seq, u64 off, u64 len) {
+    if (off + 16 <= len) return *reinterpret_cast<const uint4 *>(seq + off);
+    uint4 r = make_uint4(0u, 0u, 0u, 0u); // bytes past the end read as 0 => k-mer breakers
+    if (off < len) {
+        u32 w[4] = {0u, 0u, 0u, 0u};
+        const u32 n = (u32)(len - off);
+        for (u32 i = 0; i < n; ++i) w[i >> 2] |= (u32)seq[off + i] << (8 * (i & 3));
+        r = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    return r;
+}
+
+__device__ __forceinline__ void classify_tile(const SketchArgs &a, u64 tile, int lane, u32 *codes_ring,
+                                              u32 *good_ring) {
+    const u64 off = a.p_begin + tile * (u64)TILE_POS + (u64)lane * LANE_POS;
+    const uint4 c0 = load_chunk_guarded(a.seq, off, a.len_total);
+    const uint4 c1 = load_chunk_guarded(a.seq, off + 16, a.len_total);
+    u32 q0, g0, q1, g1;
+    classify_chunk(c0.x, c0.y, c0.z, c0.w, q0, g0);
+    classify_chunk(c1.x, c1.y, c1.z, c1.w, q1, g1);
+    const u32 par = (u32)(tile & 1u);
+    *reinterpret_cast<uint2 *>(&codes_ring[par * 128u + 2u * (u32)lane]) = make_uint2(q0, q1);
+    good_ring[par * 64u + (u32)lane] = g0 | (g1 << 16);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2
+// ------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k2_sketch(const SketchArgs a) {
+    __shared__ __attribute__((aligned(16))) u64 sT1[256];
+    __shared__ __attribute__((aligned(16))) u64 sT2[256];
+    __shared__ __attribute__((aligned(16))) u64 sTP[64];
+    __shared__ __attribute__((aligned(16))) u32 sCodes[WAVES_PER_BLOCK][256];
+    __shared__ __attribute__((aligned(16))) u32 sGood[WAVES_PER_BLOCK][128];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    sT1[tid] = lut_entry((u32)tid, 4, MURMUR_C1);
+    sT2[tid] = lut_entry((u32)tid, 4, MURMUR_C2);
+    constexpr int PNB = partial_nb(K);
+    if (tid < 64) sTP[tid] = (PNB != 0 && tid < (1 << (2 * PNB))) ? lut_entry((u32)tid, PNB, partial_const(K)) : 0ull;
+    __syncthreads();
+
+    if (__hip_atomic_load(&a.ctl->need_big, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        // the table needs a prune this build's in-stream path could not do: do not add to it
+        if (blockIdx.x == 0 && tid == 0) atomicAdd(&a.ctl->launches_skipped, 1u);
+        return;
+    }
+    const u64 tau = __hip_atomic_load(&a.ctl->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    const u32 gw = blockIdx.x * WAVES_PER_BLOCK + (u32)wave;
+    const u64 t0 = (u64)gw * a.tiles_per_wave;
+    u64 t1 = t0 + a.tiles_per_wave;
+    if (t1 > a.tiles_total) t1 = a.tiles_total;
+    if (t0 >= t1) return;
+
+    u32 *codes_ring = sCodes[wave];
+    u32 *good_ring = sGood[wave];
+    u32 nvalid = 0;
+
+    classify_tile(a, t0, lane, codes_ring, good_ring);
+    for (u64 t = t0; t < t1; ++t) {
+        classify_tile(a, t + 1, lane, codes_ring, good_ring); // also provides the halo of lane 63
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const u32 par = (u32)(t & 1u);
+        const uint2 own = *reinterpret_cast<const uint2 *>(&codes_ring[par * 128u + 2u * (u32)lane]);
+        const uint2 nbr = *reinterpret_cast<const uint2 *>(&codes_ring[(par * 128u + 2u * (u32)lane + 2u) & 255u]);
+        const u32 g_own = good_ring[par * 64u + (u32)lane];
+        const u32 g_nbr = good_ring[(par * 64u + (u32)lane + 1u) & 127u];
+        const u64 clo = (u64)own.x | ((u64)own.y << 32);
+        const u64 chi = (u64)nbr.x | ((u64)nbr.y << 32);
+        const u64 g64 = (u64)g_own | ((u64)g_nbr << 32);
+
+        Roll<K> roll;
+        roll.init(clo, g_own);
+
+        const u64 lane_pos0 = a.p_begin + t * (u64)TILE_POS + (u64)lane * LANE_POS; // first start position
+        const u32 limit = (a.p_end > lane_pos0) ? (u32)((a.p_end - lane_pos0) < 32 ? (a.p_end - lane_pos0) : 32) : 0u;
+
+#pragma unroll
+        for (int j = 0; j < LANE_POS; ++j) {
+            const int bi = j + K - 1;
+            const u32 c = (bi < 32) ? ((u32)(clo >> (2 * bi)) & 3u) : ((u32)(chi >> (2 * (bi - 32))) & 3u);
+            const u32 g = (u32)(g64 >> bi) & 1u;
+            roll.push(c, g);
+            const bool ok = roll.valid() && ((u32)j < limit);
+            bool is_rc;
+            const u64 cm = roll.canonical(is_rc);
+            const u64 h = murmur_h1_lut<K>(cm, a.seed, sT1, sT2, sTP) & a.hash_mask;
+            nvalid += (u32)__popcll(__ballot(ok));
+            if (ok && h <= tau) upsert(a, h, cm, a.base_pos + lane_pos0 + (u64)j, is_rc ? 1u : 0u);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && nvalid) atomicAdd((unsigned long long *)&a.ctl->total_kmers, (unsigned long long)nvalid);
+}
+
+template <int K>
+static hipError_t launch_k2_t(const SketchArgs &a, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL(k2_sketch<K>, dim3(blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+constexpr int PART_LO = FH_PART * (32 / FH_NPARTS) + 1;
+constexpr int PART_HI = (FH_PART + 1) * (32 / FH_NPARTS);
+
+template <int K>
+static hipError_t launch_k2_dispatch(int k, const SketchArgs &a, int blocks, hipStream_t st) {
+    if (k == K) return launch_k2_t<K>(a, blocks, st);
+    if constexpr (K > PART_LO) return launch_k2_dispatch<K - 1>(k, a, blocks, st);
+    return hipErrorInvalidValue;
+}
+
+#define FH_CAT2(a, b) a##b
+#define FH_CAT(a, b) FH_CAT2(a, b)
+hipError_t FH_CAT(launch_k2_part, FH_PART)(int k, const SketchArgs &a, int blocks, hipStream_t st) {
+    if (k < PART_LO || k > PART_HI) return hipErrorInvalidValue;
+    return launch_k2_dispatch<PART_HI>(k, a, blocks, st);
+}
+
+} // namespace fh

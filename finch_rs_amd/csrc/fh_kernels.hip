@@ -1,0 +1,268 @@
+// fh_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the finch sketching hot path.
+//
+//   k3_prune_small   bottom-n selection: replaces the heap eviction of push (mash.rs:57-60 /
+//                    scaled.rs:54-58) by sorting the live hashes of the device table in LDS, publishing
+//                    the new admit threshold tau and leaving the live list sorted (== to_vec order).
+//   k4_gather        to_vec (mash.rs:86-102): materialise (hash, count, extra, kmer bytes, first_pos).
+//   fill/clear/synth support kernels.
+//
+// (the hot kernel k2_sketch<K> lives in fh_k2.hip)
+#include <hip/hip_runtime.h>
+
+#include "fh_core.h"
+#include "fh_device.h"
+#include "fh_kernels.h"
+
+namespace fh {
+
+hipError_t launch_k2(int k, const SketchArgs &a, int blocks, hipStream_t st) {
+    static_assert(FH_NPARTS == 4, "dispatcher below is written for 4 parts");
+    if (k < 1 || k > 32) return hipErrorInvalidValue;
+    switch ((k - 1) / (32 / FH_NPARTS)) {
+    case 0: return launch_k2_part0(k, a, blocks, st);
+    case 1: return launch_k2_part1(k, a, blocks, st);
+    case 2: return launch_k2_part2(k, a, blocks, st);
+    default: return launch_k2_part3(k, a, blocks, st);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 (small): single workgroup, bitonic sort of the live hashes in LDS
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k3_prune_small(Entry *table, u32 *live, u32 *dead, u32 dead_cap, Ctl *ctl,
+                                                       u32 kind, u64 size, u64 max_hash, u32 trigger, u32 force) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u64 *keys = reinterpret_cast<u64 *>(smem);
+    u32 *slots = reinterpret_cast<u32 *>(smem + (size_t)SMALL_MAX * 8);
+    const u32 tid = threadIdx.x, nthr = blockDim.x;
+    const u32 M = ctl->n_live;
+    if (ctl->need_big) return;
+    if (!force && M <= trigger) return;
+    if (M > (u32)SMALL_MAX) {
+        if (tid == 0) ctl->need_big = 1u;
+        return;
+    }
+    u32 N = 1;
+    while (N < M) N <<= 1;
+    for (u32 i = tid; i < N; i += nthr) {
+        if (i < M) {
+            const u32 s = live[i];
+            keys[i] = table[s].hash;
+            slots[i] = s;
+        } else {
+            keys[i] = EMPTY64;
+            slots[i] = 0xFFFFFFFFu;
+        }
+    }
+    __syncthreads();
+    for (u32 kk = 2; kk <= N; kk <<= 1) {
+        for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+            for (u32 i = tid; i < N; i += nthr) {
+                const u32 ixj = i ^ jj;
+                if (ixj > i) {
+                    const bool up = (i & kk) == 0;
+                    const u64 a = keys[i], b = keys[ixj];
+                    if ((a > b) == up) {
+                        keys[i] = b;
+                        keys[ixj] = a;
+                        const u32 sa = slots[i];
+                        slots[i] = slots[ixj];
+                        slots[ixj] = sa;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // choose how many entries stay live and the new admit threshold
+    u32 keep;
+    u64 tau;
+    if (kind == 0u) { // mash.rs:37-60 : bottom-`size` distinct hashes
+        if ((u64)M >= size) {
+            keep = (u32)size;
+            tau = size ? keys[size - 1] : 0ull;
+        } else {
+            keep = M;
+            tau = EMPTY64;
+        }
+    } else { // scaled.rs:41-58 : everything <= max_hash, padded with the smallest others up to `size`
+        // count of keys <= max_hash by binary search (keys sorted, M real keys)
+        u32 lo = 0, hi = M;
+        while (lo < hi) {
+            const u32 mid = (lo + hi) >> 1;
+            if (keys[mid] <= max_hash) lo = mid + 1;
+            else hi = mid;
+        }
+        const u32 n_le = lo;
+        if ((u64)n_le >= size) {
+            keep = n_le;
+            tau = max_hash;
+        } else if ((u64)M >= size) {
+            keep = (u32)size;
+            tau = keys[size - 1];
+        } else {
+            keep = M;
+            tau = (size != 0) ? EMPTY64 : max_hash;
+        }
+    }
+    for (u32 i = tid; i < keep; i += nthr) live[i] = slots[i];
+    // remember the dropped slots so that fh_reset can clear them without sweeping the whole table
+    const u32 nd0 = ctl->n_dead;
+    const u32 ndrop = M - keep;
+    if (nd0 <= dead_cap && ndrop <= dead_cap - nd0) {
+        for (u32 i = tid; i < ndrop; i += nthr) dead[nd0 + i] = slots[keep + i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ctl->n_live = keep;
+        ctl->tau = tau;
+        ctl->sorted = 1u;
+        ctl->n_dead = (nd0 <= dead_cap && ndrop <= dead_cap - nd0) ? nd0 + ndrop : 0xFFFFFFFFu; // overflow marker
+    }
+}
+
+hipError_t launch_prune_small(Entry *table, u32 *live, u32 *dead, u32 dead_cap, Ctl *ctl, u32 kind, u64 size,
+                              u64 max_hash, u32 trigger, u32 force, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)SMALL_MAX * 12;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k3_prune_small),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k3_prune_small, dim3(1), dim3(1024), lds, st, table, live, dead, dead_cap, ctl, kind, size,
+                       max_hash, trigger, force);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: to_vec
+// ------------------------------------------------------------------------------------------------
+__global__ void k4_gather(const Entry *table, const u32 *live, const Ctl *ctl, int k, u64 *o_hash, u32 *o_count,
+                          u32 *o_extra, u64 *o_kmer, u64 *o_pos, u32 cap_out) {
+    const u32 n = ctl->n_live < cap_out ? ctl->n_live : cap_out;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Entry e = table[live[i]];
+        o_hash[i] = e.hash;
+        o_count[i] = e.count > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)e.count;
+        o_extra[i] = e.extra > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)e.extra;
+        o_kmer[i] = e.kmer;
+        o_pos[i] = e.pos;
+    }
+    (void)k;
+}
+
+hipError_t launch_gather(const Entry *table, const u32 *live, const Ctl *ctl, int k, u64 *o_hash, u32 *o_count,
+                         u32 *o_extra, u64 *o_kmer, u64 *o_pos, u32 cap_out, hipStream_t st) {
+    hipLaunchKernelGGL(k4_gather, dim3(64), dim3(256), 0, st, table, live, ctl, k, o_hash, o_count, o_extra, o_kmer,
+                       o_pos, cap_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// table maintenance
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fill_table(Entry *table, u64 cap) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += stride) {
+        Entry e;
+        e.hash = EMPTY64;
+        e.kmer = EMPTY64;
+        e.pos = EMPTY64;
+        e.count = 0;
+        e.extra = 0;
+        table[i] = e;
+    }
+}
+
+hipError_t launch_fill_table(Entry *table, u64 cap, hipStream_t st) {
+    hipLaunchKernelGGL(k_fill_table, dim3(2048), dim3(256), 0, st, table, cap);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ void clear_entry(Entry *e) {
+    e->hash = EMPTY64;
+    e->kmer = EMPTY64;
+    e->pos = EMPTY64;
+    e->count = 0;
+    e->extra = 0;
+}
+
+// reset support: clear exactly the slots this run touched; a full sweep only if the dropped-slot list overflowed
+__global__ void k_clear_slots(Entry *table, u64 cap, const u32 *live, const u32 *dead, const Ctl *ctl) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 t0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 nl = ctl->n_live, nd = ctl->n_dead;
+    if (nd == 0xFFFFFFFFu) {
+        for (u64 i = t0; i < cap; i += stride) clear_entry(&table[i]);
+        return;
+    }
+    for (u64 i = t0; i < nl; i += stride) clear_entry(&table[live[i]]);
+    for (u64 i = t0; i < nd; i += stride) clear_entry(&table[dead[i]]);
+}
+
+hipError_t launch_clear_slots(Entry *table, u64 cap, const u32 *live, const u32 *dead, const Ctl *ctl, hipStream_t st) {
+    hipLaunchKernelGGL(k_clear_slots, dim3(1024), dim3(256), 0, st, table, cap, live, dead, ctl);
+    return hipGetLastError();
+}
+
+__global__ void k_init_ctl(Ctl *ctl, u64 tau0) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        Ctl c;
+        c.tau = tau0;
+        c.total_kmers = 0;
+        c.n_live = 0;
+        c.overflow = 0;
+        c.n_coll = 0;
+        c.need_big = 0;
+        c.sorted = 1;
+        c.launches_skipped = 0;
+        c.n_dead = 0;
+        c.pad0 = 0;
+        c.sp_count = 0;
+        c.sp_extra = 0;
+        c.sp_pos = EMPTY64;
+        c.sp_kmer = EMPTY64;
+        *ctl = c;
+    }
+}
+
+hipError_t launch_init_ctl(Ctl *ctl, u64 tau0, hipStream_t st) {
+    hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, st, ctl, tau0);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic inputs (not part of the timed path)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_synth_genome(uint8_t *out, u64 len, u64 seed) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += stride) out[i] = synth_genome_base(seed, i);
+}
+
+__global__ void k_synth_reads(uint8_t *out, const uint8_t *genome, u64 genome_len, u64 first_read, u64 n_reads,
+                              u32 read_len, u64 seed, u32 sub_ppm, u32 n_ppm) {
+    const u64 rec = (u64)read_len + 1;
+    const u64 total = n_reads * rec;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const u64 r = i / rec;
+        const u32 j = (u32)(i - r * rec);
+        out[i] = synth_read_byte(genome, genome_len, first_read + r, j, read_len, seed, sub_ppm, n_ppm);
+    }
+}
+
+hipError_t launch_synth_genome(uint8_t *out, u64 len, u64 seed, hipStream_t st) {
+    hipLaunchKernelGGL(k_synth_genome, dim3(1024), dim3(256), 0, st, out, len, seed);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_reads(uint8_t *out, const uint8_t *genome, u64 genome_len, u64 first_read, u64 n_reads,
+                              u32 read_len, u64 seed, u32 sub_ppm, u32 n_ppm, hipStream_t st) {
+    hipLaunchKernelGGL(k_synth_reads, dim3(4096), dim3(256), 0, st, out, genome, genome_len, first_read, n_reads,
+                       read_len, seed, sub_ppm, n_ppm);
+    return hipGetLastError();
+}
+
+} // namespace fh

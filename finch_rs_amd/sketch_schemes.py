@@ -1,0 +1,243 @@
+"""Host-side mirror of finch's sketch-scheme interface for the accelerated path.
+
+Mirrors lib/src/sketch_schemes/mod.rs of the reference: `KmerCount` (16-22), `trait SketchScheme`
+(24-51: process / total_bases_and_kmers / to_vec / parameters), `SketchParams` (54-128:
+create_sketcher, process_post_filter, k, hash_info, expected_size).  The sketchers are thin handles
+on the MI355X engine behind the C ABI (include/finch_hip.h); there is no CPU implementation here.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import FhParams, FinchHipError, KIND_MASH, KIND_SCALED, check
+
+KC_DTYPE = np.dtype([("hash", "<u8"), ("count", "<u4"), ("extra_count", "<u4")])
+
+
+class FinchError(Exception):
+    """errors.rs: FinchError::Message"""
+
+
+@dataclass
+class KmerCount:
+    """mod.rs:16-22"""
+    hash: int
+    kmer: bytes
+    count: int
+    extra_count: int
+    label: Optional[bytes] = None
+
+
+@dataclass
+class SketchParams:
+    """mod.rs:54-71.  kind: 'mash' | 'scaled' (AllCounts is not on the accelerated path)."""
+    kind: str = "mash"
+    kmers_to_sketch: int = 1000
+    final_size: int = 1000
+    no_strict: bool = False
+    kmer_length: int = 21
+    hash_seed: int = 0
+    scale: float = 0.001
+
+    @staticmethod
+    def default():
+        return SketchParams()  # mod.rs:73-83
+
+    @staticmethod
+    def mash(kmers_to_sketch=1000, final_size=1000, no_strict=False, kmer_length=21, hash_seed=0):
+        return SketchParams("mash", kmers_to_sketch, final_size, no_strict, kmer_length, hash_seed)
+
+    @staticmethod
+    def scaled(kmers_to_sketch, kmer_length, scale, hash_seed=0):
+        return SketchParams("scaled", kmers_to_sketch, kmers_to_sketch, False, kmer_length, hash_seed, scale)
+
+    def k(self) -> int:
+        return self.kmer_length
+
+    def hash_info(self):  # mod.rs:138-146
+        return ("MurmurHash3_x64_128", 64, self.hash_seed, self.scale if self.kind == "scaled" else None)
+
+    def expected_size(self) -> int:  # mod.rs:148-156
+        return self.final_size if self.kind == "mash" else self.kmers_to_sketch
+
+    def create_sketcher(self, device: int = 0, **kw) -> "HipSketcher":
+        """mod.rs:86-113 -> the device engine"""
+        if self.kind == "mash":
+            return HipSketcher(KIND_MASH, self.kmers_to_sketch, self.kmer_length, self.hash_seed, device=device, **kw)
+        if self.kind == "scaled":
+            return HipSketcher(KIND_SCALED, self.kmers_to_sketch, self.kmer_length, self.hash_seed, self.scale,
+                               device=device, **kw)
+        raise FinchError("sketch type %r is not on the accelerated path" % self.kind)
+
+    def process_post_filter(self, kmers: List[KmerCount], name: str) -> List[KmerCount]:
+        """mod.rs:115-128: Mash only -- truncate(final_size); error unless no_strict"""
+        if self.kind == "mash":
+            kmers = kmers[: self.final_size]
+            if not self.no_strict and len(kmers) < self.final_size:
+                raise FinchError("%s had too few kmers (%d) to sketch" % (name, len(kmers)))
+        return kmers
+
+
+class HipSketcher:
+    """`impl SketchScheme` over the C ABI: MashSketcher (mash.rs) / ScaledSketcher (scaled.rs) on the GPU."""
+
+    def __init__(self, kind: int, size: int, kmer_length: int, seed: int, scale: float = 0.001, device: int = 0,
+                 max_launch: int = 0, hash_mask: int = 0):
+        self._L = _lib.load()
+        self.kind, self.size, self.kmer_length, self.seed, self.scale = kind, size, kmer_length, seed, scale
+        self.device = device
+        p = FhParams(kind, kmer_length, size, seed, scale, max_launch, hash_mask)
+        self._h = self._L.fh_new(C.byref(p), device)
+        if not self._h:
+            raise FinchHipError(-1, (self._L.fh_last_error() or b"").decode(errors="replace"))
+        self.total_bases = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fh_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # --- trait SketchScheme ---
+    def process(self, seq) -> None:
+        """process(&mut self, seq): one record's raw sequence() bytes (mash.rs:67-80)"""
+        b = bytes(seq)
+        self.total_bases += len(b)
+        block = b + b"\x00"
+        check(self._L.fh_push_block(self._h, C.cast(C.c_char_p(block), C.c_void_p), len(block)))
+
+    def push_block(self, block) -> None:
+        """several records at once: sequences separated/terminated by a breaker byte (0)"""
+        a = np.ascontiguousarray(np.frombuffer(block, dtype=np.uint8) if not isinstance(block, np.ndarray) else block)
+        check(self._L.fh_push_block(self._h, a.ctypes.data_as(C.c_void_p), a.size))
+
+    def push_device(self, dev_ptr: int, nbytes: int) -> None:
+        check(self._L.fh_push_device(self._h, C.c_void_p(dev_ptr), nbytes))
+
+    def set_stream_offset(self, off: int) -> None:
+        check(self._L.fh_set_stream_offset(self._h, off))
+
+    def reset(self) -> None:
+        check(self._L.fh_reset(self._h))
+        self.total_bases = 0
+
+    def sync(self) -> None:
+        check(self._L.fh_sync(self._h))
+
+    def finish(self) -> Tuple[int, int]:
+        n, tk = C.c_uint64(), C.c_uint64()
+        check(self._L.fh_finish(self._h, C.byref(n), C.byref(tk)))
+        return n.value, tk.value
+
+    def total_bases_and_kmers(self) -> Tuple[int, int]:
+        """mash.rs:82-84 (total_bases is a host counter; see include/finch_hip.h)"""
+        return self.total_bases, self.finish()[1]
+
+    def to_arrays(self):
+        """-> (structured [hash,count,extra_count], kmers uint8 [n,k], first_pos uint64 [n]) ascending by hash"""
+        n, _ = self.finish()
+        hs = np.zeros(n, dtype=np.uint64)
+        cs = np.zeros(n, dtype=np.uint32)
+        es = np.zeros(n, dtype=np.uint32)
+        km = np.zeros((n, self.kmer_length), dtype=np.uint8)
+        ps = np.zeros(n, dtype=np.uint64)
+        check(self._L.fh_copy_out(self._h, hs.ctypes.data_as(C.c_void_p), cs.ctypes.data_as(C.c_void_p),
+                                  es.ctypes.data_as(C.c_void_p), km.ctypes.data_as(C.c_void_p),
+                                  ps.ctypes.data_as(C.c_void_p)))
+        kc = np.zeros(n, dtype=KC_DTYPE)
+        kc["hash"], kc["count"], kc["extra_count"] = hs, cs, es
+        return kc, km, ps
+
+    def to_vec(self) -> List[KmerCount]:
+        """mash.rs:86-102"""
+        kc, km, _ = self.to_arrays()
+        return [KmerCount(int(kc["hash"][i]), bytes(km[i]), int(kc["count"][i]), int(kc["extra_count"][i]))
+                for i in range(len(kc))]
+
+    def parameters(self) -> SketchParams:
+        """mash.rs:104-112 / scaled.rs:102-109"""
+        if self.kind == KIND_MASH:
+            return SketchParams("mash", self.size, self.size, False, self.kmer_length, self.seed)
+        return SketchParams("scaled", self.size, self.size, False, self.kmer_length, self.seed, self.scale)
+
+    def merge(self, other: "HipSketcher") -> None:
+        check(self._L.fh_merge(self._h, other._h))
+
+    def merge_arrays(self, kc, km, first_pos, total_kmers: int) -> None:
+        hs = np.ascontiguousarray(kc["hash"], dtype=np.uint64)
+        cs = np.ascontiguousarray(kc["count"], dtype=np.uint32)
+        es = np.ascontiguousarray(kc["extra_count"], dtype=np.uint32)
+        km = np.ascontiguousarray(km, dtype=np.uint8)
+        ps = np.ascontiguousarray(first_pos, dtype=np.uint64)
+        check(self._L.fh_merge_arrays(self._h, len(hs), hs.ctypes.data_as(C.c_void_p), cs.ctypes.data_as(C.c_void_p),
+                                      es.ctypes.data_as(C.c_void_p), km.ctypes.data_as(C.c_void_p),
+                                      ps.ctypes.data_as(C.c_void_p), total_kmers))
+
+    # --- measurement ---
+    def set_profiling(self, on: bool) -> None:
+        check(self._L.fh_set_profiling(self._h, 1 if on else 0))
+
+    def kernel_time(self):
+        ms, n, pos = C.c_double(), C.c_uint64(), C.c_uint64()
+        check(self._L.fh_kernel_time(self._h, C.byref(ms), C.byref(n), C.byref(pos)))
+        return ms.value, n.value, pos.value
+
+
+class DeviceBuffer:
+    """device memory through the C ABI (no torch needed)"""
+
+    def __init__(self, nbytes: int, device: int = 0):
+        self._L = _lib.load()
+        self.device, self.nbytes = device, nbytes
+        p = C.c_void_p()
+        check(self._L.fh_device_alloc(device, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray, offset: int = 0):
+        a = np.ascontiguousarray(arr)
+        check(self._L.fh_copy_to_device(self.device, C.c_void_p(self.ptr + offset), a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def download(self, nbytes: int, offset: int = 0) -> np.ndarray:
+        out = np.zeros(nbytes, dtype=np.uint8)
+        check(self._L.fh_copy_from_device(self.device, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + offset), nbytes))
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self._L.fh_device_free(self.device, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    __del__ = free
+
+
+def synth_genome_host(length: int, seed: int) -> np.ndarray:
+    out = np.zeros(length, dtype=np.uint8)
+    check(_lib.load().fh_synth_genome_host(out.ctypes.data_as(C.c_void_p), length, seed))
+    return out
+
+
+def synth_reads_host(genome: np.ndarray, first_read: int, n_reads: int, read_len: int, seed: int, sub_ppm: int,
+                     n_ppm: int) -> np.ndarray:
+    out = np.zeros(n_reads * (read_len + 1), dtype=np.uint8)
+    g = np.ascontiguousarray(genome, dtype=np.uint8)
+    check(_lib.load().fh_synth_reads_host(out.ctypes.data_as(C.c_void_p), g.ctypes.data_as(C.c_void_p), g.size,
+                                          first_read, n_reads, read_len, seed, sub_ppm, n_ppm))
+    return out
+
+
+def synth_genome_device(buf: DeviceBuffer, length: int, seed: int):
+    check(_lib.load().fh_synth_genome_device(buf.device, C.c_void_p(buf.ptr), length, seed))
+
+
+def synth_reads_device(out: DeviceBuffer, genome: DeviceBuffer, genome_len: int, first_read: int, n_reads: int,
+                       read_len: int, seed: int, sub_ppm: int, n_ppm: int, out_offset: int = 0):
+    check(_lib.load().fh_synth_reads_device(out.device, C.c_void_p(out.ptr + out_offset), C.c_void_p(genome.ptr),
+                                            genome_len, first_read, n_reads, read_len, seed, sub_ppm, n_ppm))
+
+
+def device_count() -> int:
+    return _lib.load().fh_device_count()

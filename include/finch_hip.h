@@ -1,0 +1,141 @@
+/*
+ * finch_hip.h -- C ABI of libfinch_hip.so, the MI355X (gfx950) MinHash sketching engine that sits
+ * behind finch's sketching interface.
+ *
+ * This is the drop-in boundary for exactly one path of onecodex/finch-rs (citations relative to the
+ * reference tree):
+ *
+ *     finch::sketch_files()                      lib/src/lib.rs:29-49
+ *       -> sketch_stream()                       lib/src/lib.rs:51-94
+ *         -> SketchScheme::process()             lib/src/sketch_schemes/mash.rs:67-80, scaled.rs:65-78
+ *           -> MashSketcher/ScaledSketcher::push mash.rs:34-63, scaled.rs:37-61
+ *         -> total_bases_and_kmers(), to_vec()   mash.rs:82-102, scaled.rs:80-100
+ *
+ * A Rust `impl SketchScheme for HipSketcher` binds these symbols 1:1:
+ *     SketchParams::create_sketcher()  (mod.rs:86-113)  -> fh_new
+ *     SketchScheme::process()                          -> fh_push_block (record bytes + 1 breaker byte)
+ *     SketchScheme::total_bases_and_kmers()            -> fh_finish (total_kmers; total_bases is a host counter)
+ *     SketchScheme::to_vec()                           -> fh_finish + fh_copy_out (ascending hash)
+ *     drop                                             -> fh_free
+ *
+ * Plain C: pointers and sizes only, no exceptions cross the boundary.  Every function returns
+ * FH_OK (0) or a negative FH_ERR_* code; fh_last_error() returns a thread-local message.
+ * A handle owns one device, its HIP streams and all device memory; a handle is NOT thread-safe,
+ * different handles are independent (one per file / per rayon worker / per GPU).
+ * There is no CPU fallback: if no HIP device is usable, fh_new fails with FH_ERR_NO_DEVICE.
+ */
+#ifndef FINCH_HIP_H
+#define FINCH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FH_OK 0
+#define FH_ERR_INVALID (-1)     /* bad argument (k outside 1..32, null pointer, ...) */
+#define FH_ERR_NO_DEVICE (-2)   /* no usable HIP device / device index out of range */
+#define FH_ERR_HIP (-3)         /* a HIP runtime call failed (message has the HIP error string) */
+#define FH_ERR_STATE (-4)       /* call not valid in the handle's current state */
+#define FH_ERR_CAPACITY (-5)    /* device table / collision log capacity exceeded */
+#define FH_ERR_UNSUPPORTED (-6) /* valid request this build cannot serve on the device */
+
+#define FH_KIND_MASH 0   /* SketchParams::Mash   (mod.rs:55-61)  -> MashSketcher::new(size, k, seed)          */
+#define FH_KIND_SCALED 1 /* SketchParams::Scaled (mod.rs:62-67)  -> ScaledSketcher::new(size, scale, k, seed) */
+
+/* POD mirror of the sketcher constructor arguments (mash.rs:21, scaled.rs:22). */
+typedef struct fh_params {
+    uint32_t kind;        /* FH_KIND_MASH | FH_KIND_SCALED */
+    uint32_t k;           /* kmer_length, 1..32 on the device */
+    uint64_t size;        /* kmers_to_sketch */
+    uint64_t seed;        /* hash_seed */
+    double scale;         /* scaled only; max_hash = u64::MAX / ((1/scale) as u64) */
+    uint64_t max_launch;  /* 0 = default; max k-mer start positions per kernel launch (sizes the device table) */
+    uint64_t hash_mask;   /* 0 = none (all bits); test hook: AND every hash with this mask (forces collisions) */
+} fh_params;
+
+typedef struct fh_sketcher fh_sketcher;
+
+/* number of visible HIP devices (0 if none / runtime unusable) */
+int fh_device_count(void);
+const char *fh_last_error(void);
+/* library/ABI version, bumped on any signature change */
+int fh_abi_version(void);
+
+/* create_sketcher: allocate the device-resident sketch state on `device`. NULL on error. */
+fh_sketcher *fh_new(const fh_params *params, int device);
+void fh_free(fh_sketcher *s);
+/* forget everything pushed so far (state as after fh_new); keeps device memory */
+int fh_reset(fh_sketcher *s);
+
+/* Global stream coordinate of the next pushed byte.  Only matters for sharded inputs: it makes
+ * "first occurrence" (which k-mer bytes are retained on a 64-bit hash collision, mash.rs:52-56)
+ * well defined across shards.  Default 0; advanced automatically by pushes. */
+int fh_set_stream_offset(fh_sketcher *s, uint64_t offset);
+
+/* process(): push one block of *sequence bytes* (host memory).  The block holds whole records, raw /
+ * un-normalised, each record followed by one breaker byte (any byte that is not whitespace and not in
+ * ACGTUacgtu, e.g. '\0').  The library performs normalize(false) (whitespace skipped, case folded, U->T,
+ * everything else breaks k-mers), reverse-complement, canonical k-mers, murmurhash3_x64_128 and the
+ * bottom-n / scaled admission on the device.  k-mers never span two pushed blocks.
+ * Asynchronous: returns once the bytes are staged; the caller may reuse `bytes` immediately. */
+int fh_push_block(fh_sketcher *s, const uint8_t *bytes, uint64_t len);
+
+/* Same for a block that is already resident in this device's HBM (16-byte aligned, no whitespace
+ * bytes: the packed stream produced by fh_push_block's staging or by fh_synth_reads_device).
+ * The memory must stay valid until fh_finish/fh_sync returns. */
+int fh_push_device(fh_sketcher *s, const void *dev_bytes, uint64_t len);
+
+/* wait for all pushed work; surfaces deferred device errors */
+int fh_sync(fh_sketcher *s);
+
+/* to_vec() part 1: finalise (bottom-n select + sort ascending) and report the sizes.
+ * n_out = number of retained hashes, total_kmers = number of valid k-mers pushed (mash.rs:35). */
+int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers);
+/* to_vec() part 2: copy the sketch out, ascending by hash.  Any pointer may be NULL.
+ * counts/extra are saturated at u32::MAX (mash.rs:46-49).  kmers receives n_out*k ASCII bytes
+ * (uppercase canonical k-mer of the first occurrence).  first_pos = stream coordinate of that occurrence. */
+int fh_copy_out(fh_sketcher *s, uint64_t *hashes, uint32_t *counts, uint32_t *extra_counts, uint8_t *kmers,
+                uint64_t *first_pos);
+
+/* Host-side merge of partial sketches (multi-GPU read-block sharding): union, counts
+ * summed (saturating), k-mer of the smallest first_pos, re-select per kind.  Both must be finished.
+ * After the call dst holds the merged sketch (fh_copy_out works on it); dst's total_kmers += src's. */
+int fh_merge(fh_sketcher *dst, const fh_sketcher *src);
+/* Same, from raw arrays (a partial sketch received from another process). */
+int fh_merge_arrays(fh_sketcher *dst, uint64_t n, const uint64_t *hashes, const uint32_t *counts,
+                    const uint32_t *extra_counts, const uint8_t *kmers, const uint64_t *first_pos,
+                    uint64_t total_kmers);
+
+/* --- measurement support (bench.py) --- */
+/* when enabled, every sketch-kernel launch is bracketed by HIP events on the handle's stream */
+int fh_set_profiling(fh_sketcher *s, int enable);
+/* sum of event-measured durations (ms) and number of sketch-kernel launches since the last reset,
+ * and the k-mer start positions those launches covered */
+int fh_kernel_time(fh_sketcher *s, double *total_ms, uint64_t *launches, uint64_t *positions);
+
+/* --- device memory helpers so callers need no HIP/torch binding (tests, bench) --- */
+int fh_device_alloc(int device, uint64_t bytes, void **out);
+int fh_device_free(int device, void *p);
+int fh_copy_to_device(int device, void *dst, const void *src, uint64_t bytes);
+int fh_copy_from_device(int device, void *dst, const void *src, uint64_t bytes);
+
+/* --- synthetic inputs: counter-based, identical on host and device --- */
+/* genome: `len` uniform ACGT bytes */
+int fh_synth_genome_host(uint8_t *out, uint64_t len, uint64_t seed);
+int fh_synth_genome_device(int device, void *dev_out, uint64_t len, uint64_t seed);
+/* reads [first_read, first_read+n_reads): each read_len bases sampled from the genome (random start and
+ * strand, per-base substitution and N rates as parts-per-million) followed by one '\0' breaker byte.
+ * out receives n_reads*(read_len+1) bytes. */
+int fh_synth_reads_host(uint8_t *out, const uint8_t *genome, uint64_t genome_len, uint64_t first_read,
+                        uint64_t n_reads, uint32_t read_len, uint64_t seed, uint32_t sub_ppm, uint32_t n_ppm);
+int fh_synth_reads_device(int device, void *dev_out, const void *dev_genome, uint64_t genome_len,
+                          uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t seed,
+                          uint32_t sub_ppm, uint32_t n_ppm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FINCH_HIP_H */

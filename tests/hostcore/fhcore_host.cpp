@@ -1,0 +1,76 @@
+// Host build of the per-lane kernel arithmetic (finch_rs_amd/csrc/fh_core.h) for logic tests on a
+// GPU-less machine.  Test infrastructure: it is NOT part of libfinch_hip.so and nothing in the
+// product path calls it.  It walks a byte stream exactly the way one lane of the sketch kernel does
+// (32 start positions per lane segment, classification of 16-byte chunks, state initialised from the
+// first K-1 bases, LUT-based murmur3) and reports per-position results.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../finch_rs_amd/csrc/fh_core.h"
+
+using namespace fh;
+
+template <int K>
+static int run(const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hashes, uint8_t *valid, uint8_t *isrc,
+               uint64_t *canon) {
+    std::vector<uint8_t> buf(((len + 31) / 32) * 32 + 64, 0);
+    memcpy(buf.data(), seq, len);
+    std::vector<u64> T1(256), T2(256), TP(64, 0);
+    for (u32 q = 0; q < 256; ++q) {
+        T1[q] = lut_entry(q, 4, MURMUR_C1);
+        T2[q] = lut_entry(q, 4, MURMUR_C2);
+    }
+    const int pnb = partial_nb(K);
+    for (u32 q = 0; q < (1u << (2 * pnb)); ++q)
+        if (pnb) TP[q] = lut_entry(q, pnb, partial_const(K));
+    for (uint64_t s = 0; s < len; s += 32) {
+        u32 cw[4], gw[4];
+        for (int c = 0; c < 4; ++c) {
+            u32 d[4];
+            memcpy(d, buf.data() + s + 16 * c, 16);
+            classify_chunk(d[0], d[1], d[2], d[3], cw[c], gw[c]);
+        }
+        const u64 clo = (u64)cw[0] | ((u64)cw[1] << 32), chi = (u64)cw[2] | ((u64)cw[3] << 32);
+        const u64 g64 = (u64)gw[0] | ((u64)gw[1] << 16) | ((u64)gw[2] << 32) | ((u64)gw[3] << 48);
+        Roll<K> roll;
+        roll.init(clo, (u32)g64);
+        for (int j = 0; j < 32; ++j) {
+            const int bi = j + K - 1;
+            const u32 c = (u32)(((bi < 32) ? (clo >> (2 * bi)) : (chi >> (2 * (bi - 32)))) & 3u);
+            const u32 g = (u32)((g64 >> bi) & 1u);
+            roll.push(c, g);
+            const uint64_t p = s + j;
+            if (p >= len) break;
+            bool rc;
+            const u64 cm = roll.canonical(rc);
+            valid[p] = roll.valid() ? 1 : 0;
+            isrc[p] = rc ? 1 : 0;
+            canon[p] = cm;
+            hashes[p] = murmur_h1_lut<K>(cm, seed, T1.data(), T2.data(), TP.data());
+        }
+    }
+    return 0;
+}
+
+template <int K>
+static int dispatch(int k, const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hashes, uint8_t *valid,
+                    uint8_t *isrc, uint64_t *canon) {
+    if (k == K) return run<K>(seq, len, seed, hashes, valid, isrc, canon);
+    if constexpr (K > 1) return dispatch<K - 1>(k, seq, len, seed, hashes, valid, isrc, canon);
+    return -1;
+}
+
+extern "C" int fhcore_positions(const uint8_t *seq, uint64_t len, int k, uint64_t seed, uint64_t *hashes,
+                                uint8_t *valid, uint8_t *isrc, uint64_t *canon) {
+    if (k < 1 || k > 32) return -1;
+    return dispatch<32>(k, seq, len, seed, hashes, valid, isrc, canon);
+}
+
+extern "C" void fhcore_synth(uint8_t *genome, uint64_t glen, uint8_t *reads, uint64_t first, uint64_t n, uint32_t rl,
+                             uint64_t seed, uint32_t sub_ppm, uint32_t n_ppm) {
+    for (uint64_t i = 0; i < glen; ++i) genome[i] = synth_genome_base(seed, i);
+    for (uint64_t r = 0; r < n; ++r)
+        for (uint32_t j = 0; j <= rl; ++j)
+            reads[r * (rl + 1) + j] = synth_read_byte(genome, glen, first + r, j, rl, seed, sub_ppm, n_ppm);
+}

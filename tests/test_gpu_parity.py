@@ -1,0 +1,232 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle: bit-exact hashes, counts,
+extra_counts and retained k-mer bytes.  Needs a real MI355X: run with `-m gpu`."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import finch_rs_amd as F
+from finch_rs_amd import sketch_schemes as S
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _kmers(km):
+    return [bytes(r).decode() for r in km]
+
+
+def assert_same(hip: F.HipSketcher, ora: O.OracleSketcher, ctx=""):
+    kc, km, _ = hip.to_arrays()
+    okc, okm = ora.to_vec()
+    assert len(kc) == len(okc), (ctx, len(kc), len(okc))
+    assert np.array_equal(kc["hash"], okc["hash"]), ctx
+    assert np.array_equal(kc["count"], okc["count"]), ctx
+    assert np.array_equal(kc["extra_count"], okc["extra_count"]), ctx
+    assert np.array_equal(km, okm), ctx
+    assert hip.finish()[1] == ora.total_bases_and_kmers()[1], ctx
+
+
+def random_reads(rng, n_reads, lo=0, hi=200, p_n=0.01, p_lower=0.05, genome=None):
+    out = []
+    for _ in range(n_reads):
+        L = int(rng.integers(lo, hi + 1))
+        if genome is not None and L > 0:
+            st = int(rng.integers(0, len(genome) - L))
+            r = genome[st:st + L].copy()
+        else:
+            r = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L)
+        m = rng.random(L)
+        r[m < p_n] = ord("N")
+        low = (m > 1 - p_lower)
+        r[low] = r[low] | 0x20
+        out.append(bytes(r))
+    return out
+
+
+@pytest.fixture(scope="module")
+def vec(golden_dir):
+    with open(os.path.join(golden_dir, "reference_vectors.json")) as f:
+        return json.load(f)
+
+
+def fasta_records(data: bytes):
+    """raw sequence() slices of a FASTA file as needletail yields them (newlines inside)"""
+    recs = []
+    for chunk in data.split(b">")[1:]:
+        nl = chunk.index(b"\n")
+        recs.append(chunk[nl + 1:].rstrip(b"\r\n"))
+    return recs
+
+
+@pytest.mark.parametrize("kind", ["mash", "scaled"])
+def test_cli_golden_kmers(vec, golden_dir, kind):
+    # cli/tests/test_cli.rs:80-149
+    v = vec["test_cli_rs_99_143"]
+    data = open(os.path.join(golden_dir, v["file"]), "rb").read()
+    params = (F.SketchParams.mash(v["n"], v["n"], False, v["k"], v["seed"]) if kind == "mash"
+              else F.SketchParams.scaled(v["n"], v["k"], v["scale"], v["seed"]))
+    sk = params.create_sketcher()
+    for rec in fasta_records(data):
+        sk.process(rec)
+    kc, km, _ = sk.to_arrays()
+    assert _kmers(km)[:10] == v["kmers"]
+    assert [int(h) for h in kc["hash"][:10]] == [
+        933085113509804, 8582128962097342, 12581283643378369, 13388215406653903, 59671498055219043,
+        85163822212241463, 196329111101504065, 240583695071237384, 241465901919730030, 256930375650047524]
+    assert [int(c) for c in kc["count"][:10]] == [1, 1, 1, 1, 1, 1, 2, 1, 1, 2]
+    assert [int(c) for c in kc["extra_count"][:10]] == [0, 0, 1, 1, 1, 1, 2, 1, 1, 0]
+    assert sk.total_bases_and_kmers() == (134 + 136 + 135, 339)
+
+
+def test_longer_sequence_hashes(vec):
+    # mash.rs:136-154
+    v = vec["mash_rs_141_153"]
+    sk = F.SketchParams.mash(100, 100, True, v["k"], v["seed"]).create_sketcher()
+    sk.process(v["sequence"].encode())
+    kc, _, _ = sk.to_arrays()
+    assert [str(int(h)) for h in kc["hash"]] == v["hashes"]
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 8, 11, 15, 16, 17, 20, 21, 24, 27, 31, 32])
+def test_random_reads_all_k(k):
+    rng = np.random.default_rng(1000 + k)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=20000)
+    reads = random_reads(rng, 400, 0, 180, genome=genome)
+    seed = 0 if k % 2 else 42
+    n = 64
+    sk = F.SketchParams.mash(n, n, True, k, seed).create_sketcher()
+    ora = O.OracleSketcher(O.MASH, n, k, seed)
+    for r in reads:
+        sk.process(r)
+        ora.process(r)
+    assert_same(sk, ora, "k=%d" % k)
+    assert sk.total_bases == ora.total_bases_and_kmers()[0]
+
+
+@pytest.mark.parametrize("n", [0, 1, 10, 1000, 3000])
+def test_sizes(n):
+    rng = np.random.default_rng(5 + n)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=300000)
+    reads = random_reads(rng, 3000, 30, 160, genome=genome)
+    block = b"".join(r + b"\x00" for r in reads)
+    sk = F.SketchParams.mash(n, n, True, 21, 0).create_sketcher()
+    sk.push_block(block)
+    ora = O.OracleSketcher(O.MASH, n, 21, 0)
+    ora.process_packed(block, 0)
+    assert_same(sk, ora, "n=%d" % n)
+
+
+def test_fewer_distinct_than_n_and_empty_inputs():
+    sk = F.SketchParams.mash(1000, 1000, True, 21, 0).create_sketcher()
+    ora = O.OracleSketcher(O.MASH, 1000, 21, 0)
+    for r in [b"", b"ACGT", b"N" * 50, b"ACGTACGTACGTACGTACGTACGTACGT" * 3, b"acgtacgtacgtacgtacgtaNgtacgtacgtacgtacgtacgtacgtacgtttt"]:
+        sk.process(r)
+        ora.process(r)
+    assert_same(sk, ora)
+    sk2 = F.SketchParams.mash(10, 10, True, 21, 0).create_sketcher()
+    assert sk2.to_vec() == [] and sk2.total_bases_and_kmers() == (0, 0)
+
+
+def test_whitespace_skipped_and_breakers():
+    a = F.SketchParams.mash(100, 100, True, 5, 0).create_sketcher()
+    b = O.OracleSketcher(O.MASH, 100, 5, 0)
+    for r in [b"ACGTT\nGCAAT\r\nCCGA", b"AC GT\tTGCA-ATC.CGA~TTGACA", b"ACGUUGCAuuACGRYACGTAC"]:
+        a.process(r)
+        b.process(r)
+    assert_same(a, b)
+
+
+@pytest.mark.parametrize("size,scale", [(0, 0.01), (50, 0.001), (3, 1.0), (200, 0.05)])
+def test_scaled(size, scale):
+    rng = np.random.default_rng(77)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=50000)
+    reads = random_reads(rng, 600, 30, 160, genome=genome)
+    k = 15
+    sk = F.SketchParams.scaled(size, k, scale, 0).create_sketcher()
+    ora = O.OracleSketcher(O.SCALED, size, k, 0, scale)
+    for r in reads:
+        sk.process(r)
+        ora.process(r)
+    assert_same(sk, ora, "scaled %d %g" % (size, scale))
+
+
+def test_synth_generator_host_equals_device():
+    gl, nr, rl, seed = 100000, 5000, 150, 20250620
+    g_host = S.synth_genome_host(gl, seed)
+    r_host = S.synth_reads_host(g_host, 17, nr, rl, seed, 10000, 500)
+    dg = F.DeviceBuffer(gl)
+    dr = F.DeviceBuffer(nr * (rl + 1))
+    S.synth_genome_device(dg, gl, seed)
+    S.synth_reads_device(dr, dg, gl, 17, nr, rl, seed, 10000, 500)
+    assert np.array_equal(dg.download(gl), g_host)
+    assert np.array_equal(dr.download(nr * (rl + 1)), r_host)
+    assert set(np.unique(r_host)) <= set(b"ACGTN\x00")
+    assert 0.0002 < np.mean(r_host == ord("N")) < 0.001
+
+
+@pytest.mark.parametrize("k,n", [(21, 1000), (31, 2000)])
+def test_resident_stream_vs_oracle(k, n):
+    """the bench path: synthetic 150 bp reads generated in HBM, sketched with fh_push_device"""
+    gl, nr, rl, seed = 500000, 200000, 150, 20250620
+    dg = F.DeviceBuffer(gl)
+    nbytes = nr * (rl + 1)
+    dr = F.DeviceBuffer(nbytes + 64)
+    S.synth_genome_device(dg, gl, seed)
+    S.synth_reads_device(dr, dg, gl, 0, nr, rl, seed, 10000, 500)
+    sk = F.SketchParams.mash(n, n, True, k, 0).create_sketcher(max_launch=4 << 20)
+    sk.push_device(dr.ptr, nbytes)
+    host = dr.download(nbytes)
+    ora = O.OracleSketcher(O.MASH, n, k, 0)
+    ora.process_packed(host, 0)
+    assert_same(sk, ora, "resident k=%d" % k)
+    # reset + re-run gives the same answer (fh_reset clears exactly what was touched)
+    kc1 = sk.to_arrays()
+    sk.reset()
+    sk.push_device(dr.ptr, nbytes)
+    kc2 = sk.to_arrays()
+    assert all(np.array_equal(a, b) for a, b in zip(kc1, kc2))
+
+
+def test_sharded_merge_equals_whole():
+    """global sketch == merge of read-block shard sketches"""
+    gl, nr, rl, seed = 300000, 120000, 150, 7
+    g = S.synth_genome_host(gl, seed)
+    reads = S.synth_reads_host(g, 0, nr, rl, seed, 10000, 500)
+    rec = rl + 1
+    whole = F.SketchParams.mash(500, 500, True, 21, 0).create_sketcher()
+    whole.push_block(reads)
+    parts = []
+    cuts = [0, 30000, 30001, 90000, nr]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        p = F.SketchParams.mash(500, 500, True, 21, 0).create_sketcher()
+        p.set_stream_offset(a * rec)
+        p.push_block(reads[a * rec:b * rec])
+        p.finish()
+        parts.append(p)
+    merged = parts[0]
+    for p in parts[1:]:
+        merged.merge(p)
+    a, b = whole.to_arrays(), merged.to_arrays()
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert whole.finish()[1] == merged.finish()[1]
+    ora = O.OracleSketcher(O.MASH, 500, 21, 0)
+    ora.process_packed(reads, 0)
+    assert_same(merged, ora)
+
+
+def test_hash_collisions_keep_first_kmer():
+    """64-bit collisions between distinct k-mers, forced with the hash_mask test hook:
+    counts are summed and the k-mer bytes of the FIRST occurrence are kept (mash.rs:45-56)."""
+    rng = np.random.default_rng(3)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=40000)
+    reads = random_reads(rng, 500, 50, 150, genome=genome)
+    block = b"".join(r + b"\x00" for r in reads)
+    mask = 0xFFF
+    sk = F.SketchParams.mash(300, 300, True, 21, 0).create_sketcher(hash_mask=mask)
+    sk.push_block(block)
+    ora = O.OracleSketcher(O.MASH, 300, 21, 0)
+    ora.set_hash_mask(mask)
+    ora.process_packed(block, 0)
+    assert_same(sk, ora, "masked")

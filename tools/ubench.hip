@@ -1,0 +1,212 @@
+// ubench.hip -- VALU instruction-rate micro-benchmarks for gfx950 (feeds DESIGN.md's cost model of k2).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/ubench.hip -o tools/ubench ; run on the GPU box.
+// Each kernel issues ITER x 8 x UNROLL independent instances of one instruction on 8 register chains.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                            \
+    do {                                                                                    \
+        hipError_t e = (x);                                                                 \
+        if (e != hipSuccess) {                                                              \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__);    \
+            exit(1);                                                                        \
+        }                                                                                   \
+    } while (0)
+
+constexpr int ITER = 2000;
+constexpr int REP = 8; // instructions per chain per iteration
+
+#define DEF_KERNEL32(NAME, ASM)                                                             \
+    __global__ __launch_bounds__(256) void NAME(unsigned *out, unsigned seed) {             \
+        unsigned a0 = threadIdx.x + seed, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3; \
+        unsigned a4 = a0 * 11 + 4, a5 = a0 * 13 + 5, a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;    \
+        unsigned b = seed | 0x9E3779B1u, c = seed ^ 0x85EBCA6Bu;                            \
+        for (int i = 0; i < ITER; ++i) {                                                    \
+            _Pragma("unroll") for (int r = 0; r < REP; ++r) {                               \
+                asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)        \
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5),  \
+                               "+v"(a6), "+v"(a7)                                           \
+                             : "v"(b), "v"(c));                                             \
+            }                                                                               \
+        }                                                                                   \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7; \
+    }
+
+#define A_MUL_LO(n) "v_mul_lo_u32 %" #n ", %" #n ", %8\n"
+#define A_MUL_HI(n) "v_mul_hi_u32 %" #n ", %" #n ", %8\n"
+#define A_MUL_U24(n) "v_mul_u32_u24 %" #n ", %" #n ", %8\n"
+#define A_MAD_U24(n) "v_mad_u32_u24 %" #n ", %" #n ", %8, %9\n"
+#define A_XOR(n) "v_xor_b32 %" #n ", %" #n ", %8\n"
+#define A_ADD(n) "v_add_u32 %" #n ", %" #n ", %8\n"
+#define A_ADD3(n) "v_add3_u32 %" #n ", %" #n ", %8, %9\n"
+#define A_ALIGNBIT(n) "v_alignbit_b32 %" #n ", %" #n ", %8, 13\n"
+#define A_PERM(n) "v_perm_b32 %" #n ", %" #n ", %8, %9\n"
+#define A_BFE(n) "v_bfe_u32 %" #n ", %" #n ", 3, 9\n"
+#define A_LSHL_OR(n) "v_lshl_or_b32 %" #n ", %" #n ", 2, %8\n"
+#define A_AND_OR(n) "v_and_or_b32 %" #n ", %" #n ", %8, %9\n"
+#define A_XAD(n) "v_xad_u32 %" #n ", %" #n ", %8, %9\n"
+#define A_BITOP3(n) "v_bitop3_b32 %" #n ", %" #n ", %8, %9 bitop3:0x96\n"
+#define A_CNDMASK(n) "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+#define A_BFREV(n) "v_bfrev_b32 %" #n ", %" #n "\n"
+#define A_ADDCO(n) "v_add_co_u32 %" #n ", vcc, %" #n ", %8\n"
+#define A_ADDC(n) "v_addc_co_u32 %" #n ", vcc, %" #n ", %8, vcc\n"
+
+DEF_KERNEL32(k_mul_lo, A_MUL_LO)
+DEF_KERNEL32(k_mul_hi, A_MUL_HI)
+DEF_KERNEL32(k_mul_u24, A_MUL_U24)
+DEF_KERNEL32(k_mad_u24, A_MAD_U24)
+DEF_KERNEL32(k_xor, A_XOR)
+DEF_KERNEL32(k_add, A_ADD)
+DEF_KERNEL32(k_add3, A_ADD3)
+DEF_KERNEL32(k_alignbit, A_ALIGNBIT)
+DEF_KERNEL32(k_perm, A_PERM)
+DEF_KERNEL32(k_bfe, A_BFE)
+DEF_KERNEL32(k_lshl_or, A_LSHL_OR)
+DEF_KERNEL32(k_and_or, A_AND_OR)
+DEF_KERNEL32(k_xad, A_XAD)
+DEF_KERNEL32(k_bitop3, A_BITOP3)
+DEF_KERNEL32(k_cndmask, A_CNDMASK)
+DEF_KERNEL32(k_bfrev, A_BFREV)
+DEF_KERNEL32(k_addco, A_ADDCO)
+DEF_KERNEL32(k_addc, A_ADDC)
+
+// 64-bit register-pair instructions
+#define DEF_KERNEL64(NAME, ASM)                                                             \
+    __global__ __launch_bounds__(256) void NAME(unsigned *out, unsigned seed) {             \
+        unsigned long long a0 = threadIdx.x + seed, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3; \
+        unsigned long long a4 = a0 * 11 + 4, a5 = a0 * 13 + 5, a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;    \
+        unsigned b = seed | 0x9E3779B1u;                                                    \
+        unsigned long long c = ((unsigned long long)seed << 32) ^ 0x85EBCA6B12345ull;       \
+        for (int i = 0; i < ITER; ++i) {                                                    \
+            _Pragma("unroll") for (int r = 0; r < REP; ++r) {                               \
+                asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)        \
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5),  \
+                               "+v"(a6), "+v"(a7)                                           \
+                             : "v"(b), "v"(c));                                             \
+            }                                                                               \
+        }                                                                                   \
+        unsigned long long x = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                       \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)x ^ (unsigned)(x >> 32);     \
+    }
+
+// v_mad_u64_u32 D(64), vcc-like sdst, S0(32), S1(32), S2(64):  D = S0*S1 + S2
+#define A_MAD64(n) "v_mad_u64_u32 %" #n ", s[4:5], %8, %8, %" #n "\n"
+#define A_LSHL64(n) "v_lshlrev_b64 %" #n ", 3, %" #n "\n"
+#define A_LSHR64(n) "v_lshrrev_b64 %" #n ", 3, %" #n "\n"
+#define A_LSHLADD64(n) "v_lshl_add_u64 %" #n ", %" #n ", 2, %9\n"
+#define A_CMPLT64(n) "v_cmp_lt_u64 vcc, %" #n ", %9\n"
+#define A_MULF64(n) "v_mul_f64 %" #n ", %" #n ", %9\n"
+#define A_PKADD(n) "v_pk_add_u16 %" #n ", %" #n ", %9\n"
+
+DEF_KERNEL64(k_mad64, A_MAD64)
+DEF_KERNEL64(k_lshl64, A_LSHL64)
+DEF_KERNEL64(k_lshr64, A_LSHR64)
+DEF_KERNEL64(k_lshladd64, A_LSHLADD64)
+DEF_KERNEL64(k_cmplt64, A_CMPLT64)
+
+// compiler-generated 64-bit multiply by a constant, 4 chains
+__global__ __launch_bounds__(256) void k_mul64c(unsigned *out, unsigned seed) {
+    unsigned long long a0 = threadIdx.x + seed, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3;
+    unsigned long long a4 = a0 * 11 + 4, a5 = a0 * 13 + 5, a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;
+    for (int i = 0; i < ITER; ++i) {
+#pragma unroll
+        for (int r = 0; r < REP; ++r) {
+            a0 *= 0x87c37b91114253d5ULL; a1 *= 0x87c37b91114253d5ULL; a2 *= 0x87c37b91114253d5ULL; a3 *= 0x87c37b91114253d5ULL;
+            a4 *= 0x87c37b91114253d5ULL; a5 *= 0x87c37b91114253d5ULL; a6 *= 0x87c37b91114253d5ULL; a7 *= 0x87c37b91114253d5ULL;
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        }
+    }
+    unsigned long long x = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)x ^ (unsigned)(x >> 32);
+}
+
+// random ds_read_b64 / b32 from a 2 KiB table
+template <int WIDE>
+__global__ __launch_bounds__(256) void k_lds_lut(unsigned *out, unsigned seed) {
+    __shared__ unsigned long long T[256];
+    T[threadIdx.x] = threadIdx.x * 0x9E3779B97F4A7C15ull + seed;
+    __syncthreads();
+    unsigned idx0 = threadIdx.x * 2654435761u + seed, idx1 = idx0 * 3 + 1, idx2 = idx0 * 5 + 7, idx3 = idx0 * 7 + 11;
+    unsigned long long acc = 0;
+    for (int i = 0; i < ITER; ++i) {
+#pragma unroll
+        for (int r = 0; r < REP; ++r) {
+            if (WIDE) {
+                acc += T[(idx0 >> 7) & 255]; acc ^= T[(idx1 >> 9) & 255]; acc += T[(idx2 >> 11) & 255]; acc ^= T[(idx3 >> 13) & 255];
+            } else {
+                const unsigned *T32 = (const unsigned *)T;
+                acc += T32[2 * ((idx0 >> 7) & 255)]; acc ^= T32[2 * ((idx1 >> 9) & 255)];
+                acc += T32[2 * ((idx2 >> 11) & 255)]; acc ^= T32[2 * ((idx3 >> 13) & 255)];
+            }
+            idx0 = idx0 * 1664525u + 1013904223u + (unsigned)acc; idx1 += idx0; idx2 ^= idx1; idx3 += idx2;
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)acc ^ (unsigned)(acc >> 32);
+}
+
+typedef void (*kern_t)(unsigned *, unsigned);
+
+static void run(const char *name, kern_t k, double inst_per_thread, unsigned *d_out, int blocks, double clk_ghz) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d_out, 1u);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int t = 0; t < 3; ++t) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d_out, 2u + t);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    const double waves = (double)blocks * 4;
+    const double wave_inst = waves * inst_per_thread;
+    const double per_s = wave_inst / (best * 1e-3);
+    // cycles per wave-instruction per SIMD at the given clock (1024 SIMDs)
+    const double cyc = clk_ghz * 1e9 * 1024.0 / per_s;
+    printf("%-14s %8.3f ms  %8.2f G wave-inst/s  ~%5.2f cyc/inst/SIMD @%.2f GHz\n", name, best, per_s * 1e-9, cyc, clk_ghz);
+}
+
+int main(int argc, char **argv) {
+    double clk = argc > 1 ? atof(argv[1]) : 2.4;
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s  CUs=%d  clock=%d kHz\n", prop.name, prop.multiProcessorCount, prop.clockRate);
+    const int blocks = prop.multiProcessorCount * 8; // 8 blocks x 4 waves = 32 waves/CU
+    unsigned *d_out;
+    CHECK(hipMalloc(&d_out, (size_t)blocks * 256 * 4));
+    const double n32 = (double)ITER * REP * 8;
+    run("v_xor_b32", k_xor, n32, d_out, blocks, clk);
+    run("v_add_u32", k_add, n32, d_out, blocks, clk);
+    run("v_add3_u32", k_add3, n32, d_out, blocks, clk);
+    run("v_alignbit", k_alignbit, n32, d_out, blocks, clk);
+    run("v_perm_b32", k_perm, n32, d_out, blocks, clk);
+    run("v_bfe_u32", k_bfe, n32, d_out, blocks, clk);
+    run("v_lshl_or", k_lshl_or, n32, d_out, blocks, clk);
+    run("v_and_or", k_and_or, n32, d_out, blocks, clk);
+    run("v_xad_u32", k_xad, n32, d_out, blocks, clk);
+    run("v_bitop3", k_bitop3, n32, d_out, blocks, clk);
+    run("v_cndmask", k_cndmask, n32, d_out, blocks, clk);
+    run("v_bfrev", k_bfrev, n32, d_out, blocks, clk);
+    run("v_add_co", k_addco, n32, d_out, blocks, clk);
+    run("v_addc_co", k_addc, n32, d_out, blocks, clk);
+    run("v_mul_u32_u24", k_mul_u24, n32, d_out, blocks, clk);
+    run("v_mad_u32_u24", k_mad_u24, n32, d_out, blocks, clk);
+    run("v_mul_lo_u32", k_mul_lo, n32, d_out, blocks, clk);
+    run("v_mul_hi_u32", k_mul_hi, n32, d_out, blocks, clk);
+    run("v_mad_u64_u32", k_mad64, n32, d_out, blocks, clk);
+    run("v_lshlrev_b64", k_lshl64, n32, d_out, blocks, clk);
+    run("v_lshrrev_b64", k_lshr64, n32, d_out, blocks, clk);
+    run("v_lshl_add_u64", k_lshladd64, n32, d_out, blocks, clk);
+    run("v_cmp_lt_u64", k_cmplt64, n32, d_out, blocks, clk);
+    run("mul64 by const", k_mul64c, n32, d_out, blocks, clk);
+    run("lds lut b64 x4", k_lds_lut<1>, (double)ITER * REP * 4, d_out, blocks, clk);
+    run("lds lut b32 x4", k_lds_lut<0>, (double)ITER * REP * 4, d_out, blocks, clk);
+    return 0;
+}
