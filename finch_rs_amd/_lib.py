@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libfinch_hip.so")
+SO_PATH = os.environ.get("FH_LIB", os.path.join(_HERE, "libfinch_hip.so"))
 
 FH_OK = 0
 FH_ERR_INVALID, FH_ERR_NO_DEVICE, FH_ERR_HIP, FH_ERR_STATE, FH_ERR_CAPACITY, FH_ERR_UNSUPPORTED = -1, -2, -3, -4, -5, -6

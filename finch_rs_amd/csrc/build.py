@@ -18,6 +18,8 @@ OBJ = os.path.join(HERE, "obj")
 NPARTS = 4
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("FH_EXTRA_FLAGS", "").split()
+OUT = os.environ.get("FH_OUT", OUT)
 
 SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2.hip", "fh_kernels.hip", "fh_api.hip",
            os.path.join("..", "..", "include", "finch_hip.h")]

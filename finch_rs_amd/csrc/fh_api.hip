@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -199,7 +200,11 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
         a.clog_cap = CLOG_CAP;
         const uint64_t tiles = (end - pos + TILE_POS - 1) / TILE_POS;
         a.tiles_total = (uint32_t)tiles;
-        const uint64_t max_waves = 256ull * 16; // 4 workgroups of 4 waves per CU
+        static const uint64_t waves_per_cu = [] {
+            const char *e = getenv("FH_WAVES_PER_CU"); // tuning knob
+            return e ? (uint64_t)atoi(e) : 16ull;
+        }();
+        const uint64_t max_waves = 256ull * waves_per_cu;
         uint64_t waves = std::min<uint64_t>(tiles, max_waves);
         a.tiles_per_wave = (uint32_t)((tiles + waves - 1) / waves);
         waves = (tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;

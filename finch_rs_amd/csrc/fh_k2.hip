@@ -165,7 +165,10 @@ __global__ __launch_bounds__(256) void k2_sketch(const SketchArgs a) {
         const u64 lane_pos0 = a.p_begin + t * (u64)TILE_POS + (u64)lane * LANE_POS; // first start position
         const u32 limit = (a.p_end > lane_pos0) ? (u32)((a.p_end - lane_pos0) < 32 ? (a.p_end - lane_pos0) : 32) : 0u;
 
-#pragma unroll
+#ifndef FH_UNROLL
+#define FH_UNROLL 32
+#endif
+#pragma unroll FH_UNROLL
         for (int j = 0; j < LANE_POS; ++j) {
             const int bi = j + K - 1;
             const u32 c = (bi < 32) ? ((u32)(clo >> (2 * bi)) & 3u) : ((u32)(chi >> (2 * (bi - 32))) & 3u);

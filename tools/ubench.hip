@@ -54,6 +54,52 @@ constexpr int REP = 8; // instructions per chain per iteration
 #define A_ADDCO(n) "v_add_co_u32 %" #n ", vcc, %" #n ", %8\n"
 #define A_ADDC(n) "v_addc_co_u32 %" #n ", vcc, %" #n ", %8, vcc\n"
 
+#define A_AND(n) "v_and_b32 %" #n ", %" #n ", %8\n"
+#define A_OR(n) "v_or_b32 %" #n ", %" #n ", %8\n"
+#define A_SUB(n) "v_sub_u32 %" #n ", %" #n ", %8\n"
+#define A_LSHL(n) "v_lshlrev_b32 %" #n ", 5, %" #n "\n"
+#define A_LSHR(n) "v_lshrrev_b32 %" #n ", 5, %" #n "\n"
+#define A_LSHLV(n) "v_lshlrev_b32 %" #n ", %8, %" #n "\n"
+#define A_NOT(n) "v_not_b32 %" #n ", %" #n "\n"
+#define A_MOV(n) "v_mov_b32 %" #n ", %8\n"
+#define A_XORLIT(n) "v_xor_b32 %" #n ", 0x12345678, %" #n "\n"
+#define A_ANDLIT(n) "v_and_b32 %" #n ", 0x0f0f0f0f, %" #n "\n"
+#define A_MIN(n) "v_min_u32 %" #n ", %" #n ", %8\n"
+#define A_FMA(n) "v_fma_f32 %" #n ", %" #n ", %8, %9\n"
+#define A_FMAC(n) "v_fmac_f32 %" #n ", %8, %9\n"
+#define A_MULF(n) "v_mul_f32 %" #n ", %" #n ", %8\n"
+#define A_ADDF(n) "v_add_f32 %" #n ", %" #n ", %8\n"
+#define A_CMPCND(n) "v_cmp_lt_u32 vcc, %" #n ", %8\nv_cndmask_b32 %" #n ", %" #n ", %9, vcc\n"
+#define A_CMP32(n) "v_cmp_lt_u32 vcc, %" #n ", %8\n"
+#define A_XOR_MUL(n) "v_xor_b32 %" #n ", %" #n ", %8\nv_mul_lo_u32 %" #n ", %" #n ", %9\n"
+#define A_XOR_ALIGN(n) "v_xor_b32 %" #n ", %" #n ", %8\nv_alignbit_b32 %" #n ", %" #n ", %9, 7\n"
+#define A_MUL_ALIGN(n) "v_mul_lo_u32 %" #n ", %" #n ", %8\nv_alignbit_b32 %" #n ", %" #n ", %9, 7\n"
+#define A_XOR_ADD(n) "v_xor_b32 %" #n ", %" #n ", %8\nv_add_u32 %" #n ", %" #n ", %9\n"
+#define A_SDWA(n) "v_add_u32_sdwa %" #n ", %" #n ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n"
+#define A_DPP(n) "v_mov_b32_dpp %" #n ", %" #n " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+DEF_KERNEL32(k_and, A_AND)
+DEF_KERNEL32(k_or, A_OR)
+DEF_KERNEL32(k_sub, A_SUB)
+DEF_KERNEL32(k_lshl, A_LSHL)
+DEF_KERNEL32(k_lshr, A_LSHR)
+DEF_KERNEL32(k_lshlv, A_LSHLV)
+DEF_KERNEL32(k_not, A_NOT)
+DEF_KERNEL32(k_mov, A_MOV)
+DEF_KERNEL32(k_xorlit, A_XORLIT)
+DEF_KERNEL32(k_andlit, A_ANDLIT)
+DEF_KERNEL32(k_min, A_MIN)
+DEF_KERNEL32(k_fma, A_FMA)
+DEF_KERNEL32(k_fmac, A_FMAC)
+DEF_KERNEL32(k_mulf, A_MULF)
+DEF_KERNEL32(k_addf, A_ADDF)
+DEF_KERNEL32(k_cmpcnd, A_CMPCND)
+DEF_KERNEL32(k_cmp32, A_CMP32)
+DEF_KERNEL32(k_xor_mul, A_XOR_MUL)
+DEF_KERNEL32(k_xor_align, A_XOR_ALIGN)
+DEF_KERNEL32(k_mul_align, A_MUL_ALIGN)
+DEF_KERNEL32(k_xor_add, A_XOR_ADD)
+DEF_KERNEL32(k_sdwa, A_SDWA)
+DEF_KERNEL32(k_dpp, A_DPP)
 DEF_KERNEL32(k_mul_lo, A_MUL_LO)
 DEF_KERNEL32(k_mul_hi, A_MUL_HI)
 DEF_KERNEL32(k_mul_u24, A_MUL_U24)
@@ -147,6 +193,14 @@ __global__ __launch_bounds__(256) void k_lds_lut(unsigned *out, unsigned seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)acc ^ (unsigned)(acc >> 32);
 }
 
+// wall clock vs shader clock: a kernel that spins on s_memtime for a fixed number of ticks
+__global__ void k_clock(unsigned long long *out, unsigned long long ticks) {
+    unsigned long long t0 = __builtin_readcyclecounter();
+    unsigned long long t = t0;
+    while (t - t0 < ticks) t = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t - t0;
+}
+
 typedef void (*kern_t)(unsigned *, unsigned);
 
 static void run(const char *name, kern_t k, double inst_per_thread, unsigned *d_out, int blocks, double clk_ghz) {
@@ -181,7 +235,56 @@ int main(int argc, char **argv) {
     const int blocks = prop.multiProcessorCount * 8; // 8 blocks x 4 waves = 32 waves/CU
     unsigned *d_out;
     CHECK(hipMalloc(&d_out, (size_t)blocks * 256 * 4));
+    {
+        unsigned long long *d_t;
+        CHECK(hipMalloc(&d_t, 8));
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        for (int rep = 0; rep < 2; ++rep) {
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_clock, dim3(1), dim3(64), 0, 0, d_t, 100000000ull);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            unsigned long long t;
+            CHECK(hipMemcpy(&t, d_t, 8, hipMemcpyDeviceToHost));
+            printf("s_memtime: %llu ticks in %.3f ms => %.1f MHz tick rate\n", t, ms, t / (ms * 1e3));
+        }
+    }
     const double n32 = (double)ITER * REP * 8;
+    run("v_and_b32", k_and, n32, d_out, blocks, clk);
+    run("v_or_b32", k_or, n32, d_out, blocks, clk);
+    run("v_sub_u32", k_sub, n32, d_out, blocks, clk);
+    run("v_lshlrev_b32 i", k_lshl, n32, d_out, blocks, clk);
+    run("v_lshrrev_b32 i", k_lshr, n32, d_out, blocks, clk);
+    run("v_lshlrev_b32 v", k_lshlv, n32, d_out, blocks, clk);
+    run("v_not_b32", k_not, n32, d_out, blocks, clk);
+    run("v_mov_b32", k_mov, n32, d_out, blocks, clk);
+    run("v_xor lit", k_xorlit, n32, d_out, blocks, clk);
+    run("v_and lit", k_andlit, n32, d_out, blocks, clk);
+    run("v_min_u32", k_min, n32, d_out, blocks, clk);
+    run("v_fma_f32", k_fma, n32, d_out, blocks, clk);
+    run("v_fmac_f32", k_fmac, n32, d_out, blocks, clk);
+    run("v_mul_f32", k_mulf, n32, d_out, blocks, clk);
+    run("v_add_f32", k_addf, n32, d_out, blocks, clk);
+    run("cmp+cndmask x2", k_cmpcnd, 2 * n32, d_out, blocks, clk);
+    run("v_cmp_lt_u32", k_cmp32, n32, d_out, blocks, clk);
+    run("xor+mul_lo x2", k_xor_mul, 2 * n32, d_out, blocks, clk);
+    run("xor+alignbit x2", k_xor_align, 2 * n32, d_out, blocks, clk);
+    run("mul+alignbit x2", k_mul_align, 2 * n32, d_out, blocks, clk);
+    run("xor+add x2", k_xor_add, 2 * n32, d_out, blocks, clk);
+    run("v_add_sdwa", k_sdwa, n32, d_out, blocks, clk);
+    run("v_mov_dpp", k_dpp, n32, d_out, blocks, clk);
+    // occupancy sweep on two representative instructions
+    for (int bpc = 1; bpc <= 8; bpc *= 2) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "xor @%d blk/CU", bpc);
+        run(nm, k_xor, n32, d_out, prop.multiProcessorCount * bpc, clk);
+        snprintf(nm, sizeof nm, "mul_lo @%d blk/CU", bpc);
+        run(nm, k_mul_lo, n32, d_out, prop.multiProcessorCount * bpc, clk);
+    }
     run("v_xor_b32", k_xor, n32, d_out, blocks, clk);
     run("v_add_u32", k_add, n32, d_out, blocks, clk);
     run("v_add3_u32", k_add3, n32, d_out, blocks, clk);
