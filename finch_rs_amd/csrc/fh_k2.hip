@@ -32,7 +32,17 @@ namespace fh {
 // ------------------------------------------------------------------------------------------------
 // rare path: one k-mer occurrence with hash <= tau
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void log_collision(const SketchArgs &a, u64 h, u64 kmer, u64 pos) {
+// (all arguments by value: a by-reference SketchArgs would force every wave to spill the 128-byte
+//  argument block to scratch at kernel entry)
+struct TableRef {
+    Entry *table;
+    u32 *live;
+    Ctl *ctl;
+    CollRec *clog;
+    u32 cap, live_cap, clog_cap;
+};
+
+__device__ __forceinline__ void log_collision(const TableRef a, u64 h, u64 kmer, u64 pos) {
     u32 i = atomicAdd(&a.ctl->n_coll, 1u);
     if (i < a.clog_cap) {
         a.clog[i].hash = h;
@@ -43,8 +53,10 @@ __device__ __forceinline__ void log_collision(const SketchArgs &a, u64 h, u64 km
     }
 }
 
-__device__ __noinline__ void upsert(const SketchArgs &a, u64 h, u64 kmer, u64 pos, u32 strand) {
+__device__ __noinline__ void upsert(Entry *table, u32 *live, Ctl *ctl, CollRec *clog, u32 cap, u32 live_cap,
+                                    u32 clog_cap, u64 h, u64 kmer, u64 pos, u32 strand) {
     typedef unsigned long long ull;
+    const TableRef a{table, live, ctl, clog, cap, live_cap, clog_cap};
     if (h == EMPTY64) { // the one value that cannot be a table key
         atomicAdd((ull *)&a.ctl->sp_count, 1ull);
         if (strand) atomicAdd((ull *)&a.ctl->sp_extra, 1ull);
@@ -111,7 +123,7 @@ __device__ __forceinline__ void classify_tile(const SketchArgs &a, u64 tile, int
 // ------------------------------------------------------------------------------------------------
 // K2
 // ------------------------------------------------------------------------------------------------
-template <int K>
+template <int K, bool MASKED>
 __global__ __launch_bounds__(256) void k2_sketch(const SketchArgs a) {
     __shared__ __attribute__((aligned(16))) u64 sT1[256];
     __shared__ __attribute__((aligned(16))) u64 sT2[256];
@@ -176,10 +188,24 @@ __global__ __launch_bounds__(256) void k2_sketch(const SketchArgs a) {
             roll.push(c, g);
             const bool ok = roll.valid() && ((u32)j < limit);
             bool is_rc;
+#if defined(FH_ABL_NOWINDOW)
+            is_rc = false;
+            const u64 cm = clo + (u64)j * 0x12345ull + g64; // ablation: no rolling / canonical selection
+#else
             const u64 cm = roll.canonical(is_rc);
-            const u64 h = murmur_h1_lut<K>(cm, a.seed, sT1, sT2, sTP) & a.hash_mask;
+#endif
+#if defined(FH_ABL_NOHASH)
+            u64 h = cm * 0x9E3779B97F4A7C15ull; // ablation: one multiply instead of murmur3
+#elif defined(FH_ABL_NOLDS)
+            u64 h = murmur_h1_lut<K>(cm, a.seed, (const u64 *)nullptr, (const u64 *)nullptr, (const u64 *)nullptr);
+#else
+            u64 h = murmur_h1_lut<K>(cm, a.seed, sT1, sT2, sTP);
+#endif
+            if (MASKED) h &= a.hash_mask; // test hook only
             nvalid += (u32)__popcll(__ballot(ok));
-            if (ok && h <= tau) upsert(a, h, cm, a.base_pos + lane_pos0 + (u64)j, is_rc ? 1u : 0u);
+            if (ok && h <= tau)
+                upsert(a.table, a.live, a.ctl, a.clog, a.cap, a.live_cap, a.clog_cap, h, cm,
+                       a.base_pos + lane_pos0 + (u64)j, is_rc ? 1u : 0u);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -188,7 +214,8 @@ __global__ __launch_bounds__(256) void k2_sketch(const SketchArgs a) {
 
 template <int K>
 static hipError_t launch_k2_t(const SketchArgs &a, int blocks, hipStream_t st) {
-    hipLaunchKernelGGL(k2_sketch<K>, dim3(blocks), dim3(256), 0, st, a);
+    if (a.hash_mask == ~0ull) hipLaunchKernelGGL((k2_sketch<K, false>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k2_sketch<K, true>), dim3(blocks), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
