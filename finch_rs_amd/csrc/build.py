@@ -21,7 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 FLAGS += os.environ.get("FH_EXTRA_FLAGS", "").split()
 OUT = os.environ.get("FH_OUT", OUT)
 
-SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2.hip", "fh_kernels.hip", "fh_api.hip",
+SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2.hip", "fh_kernels.hip", "fh_big.hip", "fh_api.hip",
            os.path.join("..", "..", "include", "finch_hip.h")]
 
 
@@ -44,6 +44,7 @@ def build(force=False, verbose=False):
     for part in range(NPARTS):
         jobs.append([HIPCC] + FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2.hip", "-o", os.path.join(OBJ, "fh_k2_%d.o" % part)])
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_kernels.hip", "-o", os.path.join(OBJ, "fh_kernels.o")])
+    jobs.append([HIPCC] + FLAGS + ["-c", "fh_big.hip", "-o", os.path.join(OBJ, "fh_big.o")])
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_api.hip", "-o", os.path.join(OBJ, "fh_api.o")])
     with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
         outs = list(ex.map(_run, jobs))

@@ -44,7 +44,8 @@ int fail(int code, const char *fmt, ...) {
 
 constexpr uint64_t DEFAULT_MAX_LAUNCH = 64ull << 20; // k-mer start positions per launch
 constexpr uint64_t FIRST_LAUNCH = 4096;
-constexpr uint32_t CLOG_CAP = 4096;
+constexpr uint64_t SMALL_N_MAX = 3000; // largest kmers_to_sketch served by the in-LDS selection alone
+constexpr uint32_t CLOG_CAP = 65536;
 constexpr uint64_t STAGE_BYTES = 64ull << 20;
 constexpr int N_STAGE = 2;
 
@@ -73,9 +74,24 @@ struct fh_sketcher {
     uint32_t dead_cap = 0;
     Ctl *ctl = nullptr;
     CollRec *clog = nullptr;
-    // gather outputs (device), capacity SMALL_MAX
+    // gather outputs (device), capacity out_cap (grown on demand)
     uint64_t *o_hash = nullptr, *o_kmer = nullptr, *o_pos = nullptr;
     uint32_t *o_count = nullptr, *o_extra = nullptr;
+    uint32_t out_cap = 0;
+    // device-wide selection (fh_big.hip), allocated on first use
+    bool big_mode = false;        // live sets beyond the in-LDS sort (large kmers_to_sketch, scaled)
+    uint64_t live_target = 0;     // prune when the live list reaches this
+    uint64_t *keys_a = nullptr, *keys_b = nullptr;
+    uint32_t *slots_a = nullptr, *slots_b = nullptr, *keep_dev = nullptr;
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    uint32_t big_cap = 0;
+    uint64_t n_big_prunes = 0;
+    // lagged status ring for open-loop launches
+    Ctl *h_ring[2] = {nullptr, nullptr};
+    hipEvent_t ring_ev[2] = {nullptr, nullptr};
+    bool ring_used[2] = {false, false};
+    uint64_t launch_idx = 0;
     // staging
     uint8_t *h_stage[N_STAGE] = {nullptr, nullptr};
     uint8_t *d_stage[N_STAGE] = {nullptr, nullptr};
@@ -135,6 +151,9 @@ int init_state(fh_sketcher *s) {
     s->open_loop = false;
     s->last_tau = initial_tau(s);
     s->last_live = 0;
+    s->ring_used[0] = s->ring_used[1] = false;
+    s->launch_idx = 0;
+    s->live_target = s->big_mode ? std::max<uint64_t>(4 * s->p.size, 1ull << 16) : (uint64_t)SMALL_MAX;
     s->finished = false;
     s->dirty = false;
     s->res.clear();
@@ -154,7 +173,7 @@ double admit_rate(uint64_t tau) { return tau == EMPTY64 ? 1.0 : ((double)tau + 1
 // maximum-size launch is safe it stays safe and launches go open-loop (no host feedback).
 uint64_t next_launch_size(const fh_sketcher *s) {
     if (s->open_loop) return s->max_launch;
-    const double room = (double)(SMALL_MAX - std::min<uint32_t>(s->last_live, SMALL_MAX));
+    const double room = (double)s->live_target - (double)std::min<uint64_t>(s->last_live, s->live_target);
     double P = 0.5 * room / admit_rate(s->last_tau);
     if (P > (double)s->max_launch) P = (double)s->max_launch;
     uint64_t Pi = ((uint64_t)P / TILE_POS) * TILE_POS;
@@ -162,6 +181,8 @@ uint64_t next_launch_size(const fh_sketcher *s) {
 }
 
 int check_ctl(fh_sketcher *s);
+int big_prune(fh_sketcher *s);
+int grow_table(fh_sketcher *s, uint64_t new_live_cap);
 
 int collect_profile(fh_sketcher *s) {
     for (size_t i = 0; i < s->prof_used; ++i) {
@@ -229,18 +250,39 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
             s->prof_launches++;
             s->prof_positions += end - pos;
         }
-        HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size, s->max_hash,
-                                   s->trigger, s->open_loop ? 0u : 1u, s->stream));
+        if (!s->big_mode)
+            HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size,
+                                       s->max_hash, s->trigger, s->open_loop ? 0u : 1u, s->stream));
         s->positions_done += end - pos;
         s->dirty = true;
         pos = end;
         if (!s->open_loop) {
+            // closed loop: read the status back before sizing the next launch
             if (int rc = check_ctl(s)) return rc;
             s->last_tau = s->h_ctl->tau;
             s->last_live = s->h_ctl->n_live;
-            const double room = (double)(SMALL_MAX - std::min<uint64_t>(std::max<uint64_t>(s->p.size, s->last_live), SMALL_MAX));
+            if (s->h_ctl->need_big || (s->big_mode && 4 * (uint64_t)s->last_live >= 3 * s->live_target))
+                if (int rc = big_prune(s)) return rc;
+            const double room = (double)s->live_target - (double)std::min<uint64_t>(std::max<uint64_t>(s->p.size, s->last_live), s->live_target);
             if ((double)s->max_launch * admit_rate(s->last_tau) <= 0.25 * room) s->open_loop = true;
+        } else {
+            // open loop: inspect the status of the launch before the previous one (long finished), so the
+            // GPU never idles; capacity covers two maximum launches beyond live_target
+            const int slot = (int)(s->launch_idx & 1);
+            if (s->ring_used[slot]) {
+                HIP_TRY(hipEventSynchronize(s->ring_ev[slot]));
+                const Ctl &c = *s->h_ring[slot];
+                if (c.overflow) return fail(FH_ERR_CAPACITY, "device hash table capacity exceeded");
+                s->last_tau = c.tau;
+                s->last_live = c.n_live;
+                if (c.need_big || (s->big_mode && c.n_live >= s->live_target))
+                    if (int rc = big_prune(s)) return rc;
+            }
+            HIP_TRY(hipMemcpyAsync(s->h_ring[slot], s->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipEventRecord(s->ring_ev[slot], s->stream));
+            s->ring_used[slot] = true;
         }
+        s->launch_idx++;
     }
     return FH_OK;
 }
@@ -250,11 +292,90 @@ int check_ctl(fh_sketcher *s) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->h_ctl->overflow == 1) return fail(FH_ERR_CAPACITY, "device hash table capacity exceeded");
     if (s->h_ctl->overflow == 2) return fail(FH_ERR_CAPACITY, "hash collision log capacity exceeded");
-    if (s->h_ctl->need_big || s->h_ctl->launches_skipped)
-        return fail(FH_ERR_UNSUPPORTED,
-                    "sketch needs more than %d live hashes on the device; this build only has the in-LDS "
-                    "bottom-n selection (kmers_to_sketch too large)",
-                    SMALL_MAX);
+    return FH_OK;
+}
+
+int ensure_big_buffers(fh_sketcher *s, uint32_t M) {
+    if (M <= s->big_cap) return FH_OK;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->keys_a) { (void)hipFree(s->keys_a); (void)hipFree(s->keys_b); (void)hipFree(s->slots_a); (void)hipFree(s->slots_b); (void)hipFree(s->sort_tmp); }
+    s->keys_a = s->keys_b = nullptr; s->slots_a = s->slots_b = nullptr; s->sort_tmp = nullptr;
+    const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)M + M / 2 + 1024, s->live_cap);
+    HIP_TRY(hipMalloc(&s->keys_a, (size_t)cap * 8));
+    HIP_TRY(hipMalloc(&s->keys_b, (size_t)cap * 8));
+    HIP_TRY(hipMalloc(&s->slots_a, (size_t)cap * 4));
+    HIP_TRY(hipMalloc(&s->slots_b, (size_t)cap * 4));
+    HIP_TRY(big_sort_tmp_bytes(cap, &s->sort_tmp_bytes));
+    HIP_TRY(hipMalloc(&s->sort_tmp, s->sort_tmp_bytes ? s->sort_tmp_bytes : 16));
+    if (!s->keep_dev) HIP_TRY(hipMalloc(&s->keep_dev, 16));
+    s->big_cap = cap;
+    return FH_OK;
+}
+
+// device-wide bottom-n selection (fh_big.hip); host-driven because it runs a handful of times per stream
+int big_prune(fh_sketcher *s) {
+    if (int rc = check_ctl(s)) return rc;
+    const uint32_t M = s->h_ctl->n_live;
+    if (int rc = ensure_big_buffers(s, M)) return rc;
+    HIP_TRY(launch_big_prune(s->table, s->live, s->dead, s->dead_cap, s->ctl, M, s->h_ctl->n_dead, s->p.kind, s->p.size,
+                             s->max_hash, s->keys_a, s->keys_b, s->slots_a, s->slots_b, s->sort_tmp, s->sort_tmp_bytes,
+                             s->keep_dev, s->stream));
+    if (M == 0) {
+        // nothing to sort; still clear the flag
+        uint32_t zero = 0;
+        HIP_TRY(hipMemcpyAsync(&s->ctl->need_big, &zero, 4, hipMemcpyHostToDevice, s->stream));
+    }
+    if (int rc = check_ctl(s)) return rc;
+    s->last_tau = s->h_ctl->tau;
+    s->last_live = s->h_ctl->n_live;
+    s->n_big_prunes++;
+    // scaled sketches keep everything <= max_hash: the live set itself grows with the input
+    if (2 * (uint64_t)s->last_live > s->live_target) {
+        s->live_target = 2 * (uint64_t)s->last_live;
+        const uint64_t need = s->live_target + 2 * s->max_launch + 64;
+        if (need > s->live_cap)
+            if (int rc = grow_table(s, need + need / 2)) return rc;
+    }
+    return FH_OK;
+}
+
+int grow_table(fh_sketcher *s, uint64_t new_live_cap) {
+    const uint64_t new_cap = 2 * new_live_cap;
+    if (new_cap >= (1ull << 32)) return fail(FH_ERR_CAPACITY, "sketch state would exceed 2^32 table slots");
+    Entry *nt = nullptr;
+    uint32_t *nl = nullptr, *nd = nullptr;
+    HIP_TRY(hipMalloc(&nt, new_cap * sizeof(Entry)));
+    HIP_TRY(hipMalloc(&nl, new_live_cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&nd, new_live_cap * sizeof(uint32_t)));
+    HIP_TRY(launch_fill_table(nt, new_cap, s->stream));
+    HIP_TRY(launch_rehash(s->table, s->live, s->last_live, nt, (uint32_t)new_cap, nl, s->ctl, s->stream));
+    uint32_t zero = 0;
+    HIP_TRY(hipMemcpyAsync(&s->ctl->n_dead, &zero, 4, hipMemcpyHostToDevice, s->stream)); // garbage stayed behind
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    (void)hipFree(s->table);
+    (void)hipFree(s->live);
+    (void)hipFree(s->dead);
+    s->table = nt;
+    s->live = nl;
+    s->dead = nd;
+    s->cap = (uint32_t)new_cap;
+    s->live_cap = (uint32_t)new_live_cap;
+    s->dead_cap = (uint32_t)new_live_cap;
+    return check_ctl(s);
+}
+
+int ensure_out(fh_sketcher *s, uint32_t n) {
+    if (n <= s->out_cap) return FH_OK;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    (void)hipFree(s->o_hash); (void)hipFree(s->o_kmer); (void)hipFree(s->o_pos); (void)hipFree(s->o_count); (void)hipFree(s->o_extra);
+    s->o_hash = s->o_kmer = s->o_pos = nullptr; s->o_count = s->o_extra = nullptr;
+    const uint32_t cap = std::max<uint32_t>(n, (uint32_t)SMALL_MAX);
+    HIP_TRY(hipMalloc(&s->o_hash, (size_t)cap * 8));
+    HIP_TRY(hipMalloc(&s->o_kmer, (size_t)cap * 8));
+    HIP_TRY(hipMalloc(&s->o_pos, (size_t)cap * 8));
+    HIP_TRY(hipMalloc(&s->o_count, (size_t)cap * 4));
+    HIP_TRY(hipMalloc(&s->o_extra, (size_t)cap * 4));
+    s->out_cap = cap;
     return FH_OK;
 }
 
@@ -347,8 +468,11 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-    // worst case a launch inserts one new hash per position: size the table so that it can never fill
-    const uint64_t live_cap = s->max_launch + SMALL_MAX + 64;
+    s->big_mode = params->kind == FH_KIND_SCALED || params->size > SMALL_N_MAX;
+    s->live_target = s->big_mode ? std::max<uint64_t>(4 * params->size, 1ull << 16) : (uint64_t)SMALL_MAX;
+    // worst case a launch inserts one new hash per position, and open-loop status lags by one launch:
+    // size the table so that it can never fill
+    const uint64_t live_cap = s->live_target + 2 * s->max_launch + 64;
     const uint64_t cap = 2 * live_cap;
     if (cap >= (1ull << 32)) {
         fail(FH_ERR_INVALID, "max_launch too large");
@@ -359,16 +483,15 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
     s->live_cap = (uint32_t)live_cap;
     if ((e = hipMalloc(&s->table, cap * sizeof(Entry))) != hipSuccess) return bail("hipMalloc(table)", e);
     if ((e = hipMalloc(&s->live, live_cap * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(live)", e);
-    s->dead_cap = 4u << 20;
+    s->dead_cap = (uint32_t)live_cap;
     if ((e = hipMalloc(&s->dead, (size_t)s->dead_cap * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(dead)", e);
     if ((e = hipMalloc(&s->ctl, sizeof(Ctl))) != hipSuccess) return bail("hipMalloc(ctl)", e);
     if ((e = hipMalloc(&s->clog, CLOG_CAP * sizeof(CollRec))) != hipSuccess) return bail("hipMalloc(clog)", e);
-    if ((e = hipMalloc(&s->o_hash, SMALL_MAX * 8)) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc(&s->o_kmer, SMALL_MAX * 8)) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc(&s->o_pos, SMALL_MAX * 8)) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc(&s->o_count, SMALL_MAX * 4)) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc(&s->o_extra, SMALL_MAX * 4)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipHostMalloc(&s->h_ctl, sizeof(Ctl), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    for (int i = 0; i < 2; ++i) {
+        if ((e = hipHostMalloc(&s->h_ring[i], sizeof(Ctl), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+        if ((e = hipEventCreateWithFlags(&s->ring_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    }
     if ((e = launch_fill_table(s->table, cap, s->stream)) != hipSuccess) return bail("fill_table", e);
     if (init_state(s) != FH_OK) {
         fh_free(s);
@@ -392,6 +515,16 @@ void fh_free(fh_sketcher *s) {
         if (s->stage_done[i]) (void)hipEventDestroy(s->stage_done[i]);
     }
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
+    for (int i = 0; i < 2; ++i) {
+        if (s->h_ring[i]) (void)hipHostFree(s->h_ring[i]);
+        if (s->ring_ev[i]) (void)hipEventDestroy(s->ring_ev[i]);
+    }
+    (void)hipFree(s->keys_a);
+    (void)hipFree(s->keys_b);
+    (void)hipFree(s->slots_a);
+    (void)hipFree(s->slots_b);
+    (void)hipFree(s->sort_tmp);
+    (void)hipFree(s->keep_dev);
     (void)hipFree(s->table);
     (void)hipFree(s->live);
     (void)hipFree(s->dead);
@@ -491,10 +624,17 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (int rc = set_device(s)) return rc;
     if (!s->finished) {
-        HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size, s->max_hash,
-                                   0u, 1u, s->stream));
+        if (int rc = check_ctl(s)) return rc;
+        if (!s->big_mode && s->h_ctl->n_live <= (uint32_t)SMALL_MAX && !s->h_ctl->need_big) {
+            HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size,
+                                       s->max_hash, 0u, 1u, s->stream));
+            if (int rc = check_ctl(s)) return rc;
+        } else {
+            if (int rc = big_prune(s)) return rc;
+        }
+        if (int rc = ensure_out(s, s->h_ctl->n_live)) return rc;
         HIP_TRY(launch_gather(s->table, s->live, s->ctl, (int)s->p.k, s->o_hash, s->o_count, s->o_extra, s->o_kmer,
-                              s->o_pos, SMALL_MAX, s->stream));
+                              s->o_pos, s->out_cap, s->stream));
         if (int rc = check_ctl(s)) return rc;
         if (int rc = collect_profile(s)) return rc;
         const Ctl c = *s->h_ctl;

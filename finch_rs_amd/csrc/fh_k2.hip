@@ -138,11 +138,6 @@ __global__ __launch_bounds__(256) void k2_sketch(const SketchArgs a) {
     if (tid < 64) sTP[tid] = (PNB != 0 && tid < (1 << (2 * PNB))) ? lut_entry((u32)tid, PNB, partial_const(K)) : 0ull;
     __syncthreads();
 
-    if (__hip_atomic_load(&a.ctl->need_big, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-        // the table needs a prune this build's in-stream path could not do: do not add to it
-        if (blockIdx.x == 0 && tid == 0) atomicAdd(&a.ctl->launches_skipped, 1u);
-        return;
-    }
     const u64 tau = __hip_atomic_load(&a.ctl->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     const u32 gw = blockIdx.x * WAVES_PER_BLOCK + (u32)wave;

@@ -20,6 +20,14 @@ hipError_t launch_clear_slots(Entry *table, uint64_t cap, const uint32_t *live, 
 hipError_t launch_gather(const Entry *table, const uint32_t *live, const Ctl *ctl, int k, uint64_t *o_hash,
                          uint32_t *o_count, uint32_t *o_extra, uint64_t *o_kmer, uint64_t *o_pos, uint32_t cap_out,
                          hipStream_t st);
+// fh_big.hip
+hipError_t big_sort_tmp_bytes(uint32_t M, size_t *bytes);
+hipError_t launch_big_prune(Entry *table, uint32_t *live, uint32_t *dead, uint32_t dead_cap, Ctl *ctl, uint32_t M,
+                            uint32_t n_dead_now, uint32_t kind, uint64_t size, uint64_t max_hash, uint64_t *keys_a,
+                            uint64_t *keys_b, uint32_t *slots_a, uint32_t *slots_b, void *tmp, size_t tmp_bytes,
+                            uint32_t *keep_dev, hipStream_t st);
+hipError_t launch_rehash(const Entry *src, const uint32_t *src_live, uint32_t M, Entry *dst, uint32_t dst_cap,
+                         uint32_t *dst_live, Ctl *ctl, hipStream_t st);
 hipError_t launch_fill_table(Entry *table, uint64_t cap, hipStream_t st);
 hipError_t launch_init_ctl(Ctl *ctl, uint64_t tau0, hipStream_t st);
 hipError_t launch_synth_genome(uint8_t *out, uint64_t len, uint64_t seed, hipStream_t st);

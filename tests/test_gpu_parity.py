@@ -152,6 +152,33 @@ def test_scaled(size, scale):
     assert_same(sk, ora, "scaled %d %g" % (size, scale))
 
 
+@pytest.mark.parametrize("n,k", [(3001, 21), (20000, 31), (250000, 21)])
+def test_large_sketch_sizes_device_wide_selection(n, k):
+    """kmers_to_sketch beyond the in-LDS selection (the CLI's oversketch x200 regime, cli.rs:187-192)"""
+    gl, nr, rl, seed = 400000, 60000, 150, 11
+    g = S.synth_genome_host(gl, seed)
+    reads = S.synth_reads_host(g, 0, nr, rl, seed, 10000, 500)
+    sk = F.SketchParams.mash(n, n, True, k, 0).create_sketcher(max_launch=1 << 20)
+    sk.push_block(reads)
+    ora = O.OracleSketcher(O.MASH, n, k, 0)
+    ora.process_packed(reads, 0)
+    assert_same(sk, ora, "n=%d" % n)
+
+
+def test_scaled_unbounded_growth():
+    """scale=1 keeps every distinct k-mer: the device table has to grow with the input (scaled.rs:118-138)"""
+    gl, nr, rl, seed = 200000, 8000, 150, 5
+    g = S.synth_genome_host(gl, seed)
+    reads = S.synth_reads_host(g, 0, nr, rl, seed, 10000, 500)
+    for size, scale in [(3, 1.0), (100, 0.25)]:
+        sk = F.SketchParams.scaled(size, 21, scale, 0).create_sketcher(max_launch=8192)
+        sk.push_block(reads)
+        ora = O.OracleSketcher(O.SCALED, size, 21, 0, scale)
+        ora.process_packed(reads, 0)
+        assert_same(sk, ora, "scaled growth %g" % scale)
+        assert len(sk.to_arrays()[0]) > 100000 * scale
+
+
 def test_synth_generator_host_equals_device():
     gl, nr, rl, seed = 100000, 5000, 150, 20250620
     g_host = S.synth_genome_host(gl, seed)
@@ -223,10 +250,20 @@ def test_hash_collisions_keep_first_kmer():
     genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=40000)
     reads = random_reads(rng, 500, 50, 150, genome=genome)
     block = b"".join(r + b"\x00" for r in reads)
-    mask = 0xFFF
-    sk = F.SketchParams.mash(300, 300, True, 21, 0).create_sketcher(hash_mask=mask)
-    sk.push_block(block)
-    ora = O.OracleSketcher(O.MASH, 300, 21, 0)
-    ora.set_hash_mask(mask)
-    ora.process_packed(block, 0)
-    assert_same(sk, ora, "masked")
+    n_coll_members = 0
+    for mask in (0xFFFFF, 0x3FFFF):
+        sk = F.SketchParams.mash(300, 300, True, 21, 0).create_sketcher(hash_mask=mask)
+        sk.push_block(block)
+        ora = O.OracleSketcher(O.MASH, 300, 21, 0)
+        ora.set_hash_mask(mask)
+        ora.process_packed(block, 0)
+        assert_same(sk, ora, "masked %x" % mask)
+        # make sure the case is actually exercised: some retained hash stands for >1 distinct k-mer
+        full = O.OracleSketcher(O.MASH, 10**6, 21, 0)
+        full.process_packed(block, 0)
+        fk, _ = full.to_vec()
+        masked = fk["hash"] & np.uint64(mask)
+        vals, cnt = np.unique(masked, return_counts=True)
+        dup = set(vals[cnt > 1].tolist())
+        n_coll_members += sum(1 for h in ora.to_vec()[0]["hash"].tolist() if h in dup)
+    assert n_coll_members > 0
