@@ -46,7 +46,11 @@ constexpr uint64_t DEFAULT_MAX_LAUNCH = 64ull << 20; // k-mer start positions pe
 constexpr uint64_t FIRST_LAUNCH = 4096;
 constexpr uint64_t SMALL_N_MAX = 3000; // largest kmers_to_sketch served by the in-LDS selection alone
 constexpr uint32_t CLOG_CAP = 65536;
-constexpr uint64_t STAGE_BYTES = 64ull << 20;
+const uint64_t STAGE_BYTES = [] {
+    const char *e = getenv("FH_STAGE_BYTES"); // test knob: force blocks to span staging slices
+    const uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
+    return v >= 4096 ? v : (64ull << 20);
+}();
 constexpr int N_STAGE = 2;
 
 struct ResultRec {
@@ -98,6 +102,8 @@ struct fh_sketcher {
     hipEvent_t stage_done[N_STAGE] = {nullptr, nullptr};
     bool stage_busy[N_STAGE] = {false, false};
     int stage_next = 0;
+    uint8_t carry[32] = {0}; // last K-1 staged bytes: k-mers span staging slices (and FH_PUSH_CONTINUE pushes)
+    uint32_t carry_len = 0;
     Ctl *h_ctl = nullptr; // pinned
 
     // host bookkeeping
@@ -153,6 +159,7 @@ int init_state(fh_sketcher *s) {
     s->last_live = 0;
     s->ring_used[0] = s->ring_used[1] = false;
     s->launch_idx = 0;
+    s->carry_len = 0;
     s->live_target = s->big_mode ? std::max<uint64_t>(4 * s->p.size, 1ull << 16) : (uint64_t)SMALL_MAX;
     s->finished = false;
     s->dirty = false;
@@ -199,8 +206,6 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
     if (len < s->p.k) return FH_OK;
     const uint64_t n_pos = len - s->p.k + 1; // windows that fit
     uint64_t pos = 0;
-    hipDeviceProp_t *prop = nullptr;
-    (void)prop;
     while (pos < n_pos) {
         const uint64_t P = next_launch_size(s);
         const uint64_t end = std::min<uint64_t>(n_pos, pos + P);
@@ -566,7 +571,36 @@ int fh_push_device(fh_sketcher *s, const void *dev_bytes, uint64_t len) {
     return rc;
 }
 
-int fh_push_block(fh_sketcher *s, const uint8_t *bytes, uint64_t len) {
+// copy `n` bytes dropping ' ', '\t', '\r', '\n' (what normalize(false) removes); 8 bytes at a time when clean
+static inline uint64_t strip_copy(uint8_t *dst, const uint8_t *src, uint64_t n, uint64_t dst_room, uint64_t *consumed) {
+    uint64_t i = 0, m = 0;
+    while (i + 8 <= n && m + 8 <= dst_room) {
+        uint64_t x;
+        memcpy(&x, src + i, 8);
+        // any byte < 0x21 ?
+        if (((x - 0x2121212121212121ull) & ~x & 0x8080808080808080ull) == 0) {
+            memcpy(dst + m, &x, 8);
+            m += 8;
+            i += 8;
+        } else {
+            for (int j = 0; j < 8; ++j) {
+                const uint8_t c = src[i + j];
+                if (c == ' ' || c == '\t' || c == '\r' || c == '\n') continue;
+                dst[m++] = c;
+            }
+            i += 8;
+        }
+    }
+    while (i < n && m < dst_room) {
+        const uint8_t c = src[i++];
+        if (c == ' ' || c == '\t' || c == '\r' || c == '\n') continue;
+        dst[m++] = c;
+    }
+    *consumed = i;
+    return m;
+}
+
+int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_t flags) {
     if (!s || (!bytes && len)) return fail(FH_ERR_INVALID, "null argument");
     if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
     if (int rc = set_device(s)) return rc;
@@ -580,8 +614,7 @@ int fh_push_block(fh_sketcher *s, const uint8_t *bytes, uint64_t len) {
     // normalize(false) drops whitespace (needletail; mash.rs:73): strip it while staging so that device
     // positions are contiguous.  k-mers may span staging slices of one block: carry K-1 bytes over.
     const uint32_t K = s->p.k;
-    uint8_t carry[32];
-    uint32_t carry_len = 0;
+    if (!(flags & FH_PUSH_CONTINUE)) s->carry_len = 0;
     uint64_t in = 0;
     while (in < len) {
         const int b = s->stage_next;
@@ -590,28 +623,29 @@ int fh_push_block(fh_sketcher *s, const uint8_t *bytes, uint64_t len) {
             s->stage_busy[b] = false;
         }
         uint8_t *dst = s->h_stage[b];
-        uint64_t m = 0;
-        memcpy(dst, carry, carry_len);
-        m = carry_len;
-        while (in < len && m < STAGE_BYTES) {
-            const uint8_t c = bytes[in++];
-            if (c == ' ' || c == '\t' || c == '\r' || c == '\n') continue;
-            dst[m++] = c;
-        }
-        const uint64_t fresh = m - carry_len;
+        const uint32_t carry_len = s->carry_len;
+        memcpy(dst, s->carry, carry_len);
+        uint64_t consumed = 0;
+        const uint64_t fresh = strip_copy(dst + carry_len, bytes + in, len - in, STAGE_BYTES - carry_len, &consumed);
+        in += consumed;
+        const uint64_t m = carry_len + fresh;
         const uint64_t base = s->stream_off - carry_len;
-        HIP_TRY(hipMemcpyAsync(s->d_stage[b], dst, m, hipMemcpyHostToDevice, s->stream));
-        HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
-        s->stage_busy[b] = true;
-        if (int rc = sketch_device_range(s, s->d_stage[b], m, base)) return rc;
-        s->stream_off += fresh;
-        // the next H2D into d_stage[b] is stream-ordered after these kernels
-        carry_len = (uint32_t)std::min<uint64_t>(K - 1, m);
-        memcpy(carry, dst + m - carry_len, carry_len);
-        s->stage_next = (b + 1) % N_STAGE;
+        if (fresh) {
+            HIP_TRY(hipMemcpyAsync(s->d_stage[b], dst, m, hipMemcpyHostToDevice, s->stream));
+            HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+            s->stage_busy[b] = true;
+            if (int rc = sketch_device_range(s, s->d_stage[b], m, base)) return rc;
+            s->stream_off += fresh;
+            // the next H2D into d_stage[b] is stream-ordered after these kernels
+            s->carry_len = (uint32_t)std::min<uint64_t>(K - 1, m);
+            memcpy(s->carry, dst + m - s->carry_len, s->carry_len);
+            s->stage_next = (b + 1) % N_STAGE;
+        }
     }
     return FH_OK;
 }
+
+int fh_push_block(fh_sketcher *s, const uint8_t *bytes, uint64_t len) { return fh_push_block_ex(s, bytes, len, 0u); }
 
 int fh_sync(fh_sketcher *s) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");

@@ -1,0 +1,898 @@
+// fh_host.cpp -- host-side mirror of finch's library entry points for the accelerated path
+// (C ABI in include/finch_host.h).  Everything per-base happens on the device through the fh_* ABI;
+// this file parses FASTA/FASTQ, stages record bytes, applies the O(n) filters and serialises.
+//
+// Reference items mirrored (relative to the finch-rs tree) are cited at each function.
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <charconv>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/finch_hip.h"
+#include "../../include/finch_host.h"
+
+namespace finch {
+
+thread_local std::string g_host_err;
+
+static int hfail(int code, const char *fmt, ...) {
+    char buf[768];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_host_err = buf;
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------------
+// data model: KmerCount (sketch_schemes/mod.rs:16-22), FilterParams (filtering.rs:11-16),
+// SketchParams (mod.rs:54-71), Sketch (serialization/mod.rs:46-55)
+// ---------------------------------------------------------------------------------------------
+struct KmerCount {
+    uint64_t hash;
+    std::string kmer;
+    uint32_t count, extra_count;
+};
+
+struct Sketch {
+    std::string name;
+    uint64_t seq_length = 0, num_valid_kmers = 0;
+    std::string comment;
+    std::vector<KmerCount> hashes;
+    finch_filter_params filter_params{};
+    finch_sketch_params sketch_params{};
+};
+
+// statistics.rs:30-47
+static std::vector<uint64_t> hist(const std::vector<KmerCount> &sketch) {
+    uint64_t max_count = 0;
+    for (const auto &k : sketch) max_count = std::max<uint64_t>(max_count, k.count);
+    std::vector<uint64_t> counts(max_count, 0);
+    for (const auto &k : sketch) counts[k.count - 1] += 1;
+    return counts;
+}
+
+// filtering.rs:154-195
+static uint32_t guess_filter_threshold(const std::vector<KmerCount> &sketch, double filter_level) {
+    const std::vector<uint64_t> hist_data = hist(sketch);
+    uint64_t total = 0;
+    for (size_t i = 0; i < hist_data.size(); ++i) total += (uint64_t)(i + 1) * hist_data[i];
+    const double total_counts = (double)total;
+    const double cutoff_amt = filter_level * total_counts;
+    size_t wgt_cutoff = 0;
+    uint64_t cum_count = 0;
+    for (uint64_t count : hist_data) {
+        cum_count += (uint64_t)wgt_cutoff * count;
+        if ((double)cum_count > cutoff_amt) break;
+        wgt_cutoff += 1;
+    }
+    if (wgt_cutoff == 0) return 1;
+    const size_t win_size = std::max<size_t>(1, wgt_cutoff / 20);
+    uint64_t sum = 0;
+    for (size_t i = 0; i < win_size; ++i) sum += hist_data[i];
+    uint64_t lowest_val = sum;
+    size_t lowest_idx = win_size - 1;
+    for (size_t i = 0, j = win_size; j < wgt_cutoff; ++i, ++j) {
+        if (sum <= lowest_val) {
+            lowest_val = sum;
+            lowest_idx = j;
+        }
+        sum -= hist_data[i];
+        sum += hist_data[j];
+    }
+    return (uint32_t)lowest_idx + 1;
+}
+
+// filtering.rs:413-432
+static std::vector<KmerCount> filter_strands(const std::vector<KmerCount> &sketch, double ratio_cutoff) {
+    std::vector<KmerCount> filtered;
+    for (const auto &kmer : sketch) {
+        if (kmer.count < 16) {
+            filtered.push_back(kmer);
+            continue;
+        }
+        const uint32_t lowest = std::min(kmer.extra_count, kmer.count - kmer.extra_count);
+        if (((double)lowest / (double)kmer.count) >= ratio_cutoff) filtered.push_back(kmer);
+    }
+    return filtered;
+}
+
+// filtering.rs:329-343
+static std::vector<KmerCount> filter_abundance(const std::vector<KmerCount> &sketch, bool has_lo, uint32_t lo, bool has_hi,
+                                               uint32_t hi) {
+    const uint32_t lo_t = has_lo ? lo : 0u, hi_t = has_hi ? hi : UINT32_MAX;
+    std::vector<KmerCount> filtered;
+    for (const auto &kmer : sketch)
+        if (lo_t <= kmer.count && kmer.count <= hi_t) filtered.push_back(kmer);
+    return filtered;
+}
+
+// FilterParams::filter_counts (filtering.rs:60-87); updates `fp` like the reference updates self
+static std::vector<KmerCount> filter_counts(finch_filter_params &fp, const std::vector<KmerCount> &hashes) {
+    const bool filter_on = fp.filter_on == 1;
+    std::vector<KmerCount> filtered = hashes;
+    if (filter_on && fp.strand_filter > 0.0) filtered = filter_strands(filtered, fp.strand_filter);
+    if (filter_on && fp.err_filter > 0.0) {
+        const uint32_t cutoff = guess_filter_threshold(filtered, fp.err_filter);
+        if (fp.has_abun_lo) {
+            if (cutoff > fp.abun_lo) fp.abun_lo = cutoff;
+        } else {
+            fp.has_abun_lo = 1;
+            fp.abun_lo = cutoff;
+        }
+    }
+    if (filter_on && (fp.has_abun_lo || fp.has_abun_hi))
+        filtered = filter_abundance(filtered, fp.has_abun_lo, fp.abun_lo, fp.has_abun_hi, fp.abun_hi);
+    return filtered;
+}
+
+// SketchParams::process_post_filter (mod.rs:115-128)
+static int process_post_filter(const finch_sketch_params &sp, std::vector<KmerCount> &kmers, const std::string &name) {
+    if (sp.kind == 0) {
+        if (kmers.size() > sp.final_size) kmers.resize(sp.final_size);
+        if (!sp.no_strict && kmers.size() < sp.final_size)
+            return hfail(FH_ERR_INVALID, "%s had too few kmers (%zu) to sketch", name.c_str(), kmers.size());
+    }
+    return FH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// byte sources: plain memory / FILE*, optionally through zlib (needletail sniffs 1F 8B)
+// ---------------------------------------------------------------------------------------------
+struct ByteSource {
+    virtual ~ByteSource() {}
+    virtual size_t read(uint8_t *dst, size_t cap) = 0; // 0 = EOF
+    virtual bool failed() const { return false; }
+};
+
+struct MemSource : ByteSource {
+    const uint8_t *p;
+    size_t n, off = 0;
+    MemSource(const uint8_t *p_, size_t n_) : p(p_), n(n_) {}
+    size_t read(uint8_t *dst, size_t cap) override {
+        const size_t m = std::min(cap, n - off);
+        memcpy(dst, p + off, m);
+        off += m;
+        return m;
+    }
+};
+
+struct FileSource : ByteSource {
+    FILE *f;
+    bool own;
+    FileSource(FILE *f_, bool own_) : f(f_), own(own_) {}
+    ~FileSource() override {
+        if (own && f) fclose(f);
+    }
+    size_t read(uint8_t *dst, size_t cap) override { return fread(dst, 1, cap, f); }
+};
+
+// prepends already-consumed sniff bytes
+struct PrefixedSource : ByteSource {
+    std::vector<uint8_t> prefix;
+    size_t off = 0;
+    std::unique_ptr<ByteSource> inner;
+    size_t read(uint8_t *dst, size_t cap) override {
+        if (off < prefix.size()) {
+            const size_t m = std::min(cap, prefix.size() - off);
+            memcpy(dst, prefix.data() + off, m);
+            off += m;
+            return m;
+        }
+        return inner->read(dst, cap);
+    }
+};
+
+struct GzSource : ByteSource {
+    std::unique_ptr<ByteSource> inner;
+    z_stream zs{};
+    std::vector<uint8_t> inbuf;
+    bool eof = false, bad = false, init = false;
+    explicit GzSource(std::unique_ptr<ByteSource> in) : inner(std::move(in)), inbuf(1 << 20) {
+        init = inflateInit2(&zs, 15 + 32) == Z_OK; // gzip/zlib auto-detect
+        bad = !init;
+    }
+    ~GzSource() override {
+        if (init) inflateEnd(&zs);
+    }
+    bool failed() const override { return bad; }
+    size_t read(uint8_t *dst, size_t cap) override {
+        if (eof || bad) return 0;
+        zs.next_out = dst;
+        zs.avail_out = (uInt)std::min<size_t>(cap, 1u << 30);
+        while (zs.avail_out > 0) {
+            if (zs.avail_in == 0) {
+                const size_t got = inner->read(inbuf.data(), inbuf.size());
+                if (got == 0) {
+                    eof = true;
+                    break;
+                }
+                zs.next_in = inbuf.data();
+                zs.avail_in = (uInt)got;
+            }
+            const int rc = inflate(&zs, Z_NO_FLUSH);
+            if (rc == Z_STREAM_END) {
+                // concatenated gzip members (bgzip) continue with a fresh header
+                if (zs.avail_in == 0) {
+                    const size_t got = inner->read(inbuf.data(), inbuf.size());
+                    if (got == 0) {
+                        eof = true;
+                        break;
+                    }
+                    zs.next_in = inbuf.data();
+                    zs.avail_in = (uInt)got;
+                }
+                inflateReset(&zs);
+                continue;
+            }
+            if (rc != Z_OK && rc != Z_BUF_ERROR) {
+                bad = true;
+                break;
+            }
+        }
+        return (size_t)(zs.next_out - dst);
+    }
+};
+
+// needletail parse_fastx_reader: sniff two magic bytes (lib.rs:60)
+static int open_source(std::unique_ptr<ByteSource> raw, std::unique_ptr<ByteSource> &out) {
+    auto pre = std::make_unique<PrefixedSource>();
+    pre->prefix.resize(2);
+    size_t got = 0;
+    while (got < 2) {
+        const size_t g = raw->read(pre->prefix.data() + got, 2 - got);
+        if (g == 0) break;
+        got += g;
+    }
+    pre->prefix.resize(got);
+    const bool gz = got == 2 && pre->prefix[0] == 0x1F && pre->prefix[1] == 0x8B;
+    const bool bz = got == 2 && pre->prefix[0] == 0x42 && pre->prefix[1] == 0x5A;
+    const bool xz = got == 2 && pre->prefix[0] == 0xFD && pre->prefix[1] == 0x37;
+    pre->inner = std::move(raw);
+    if (bz || xz)
+        return hfail(FH_ERR_UNSUPPORTED, "%s-compressed input: no %s development files in this build", bz ? "bzip2" : "xz",
+                     bz ? "libbz2" : "liblzma");
+    if (gz) out = std::make_unique<GzSource>(std::move(pre));
+    else out = std::move(pre);
+    return FH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// record sink: either the device sketcher or a counter (finch_fastx_scan)
+// ---------------------------------------------------------------------------------------------
+struct RecordSink {
+    virtual ~RecordSink() {}
+    // a piece of the current record's sequence() bytes; `raw_len` is what total_bases counts for it
+    virtual int piece(const uint8_t *p, size_t n) = 0;
+    virtual int end_record() = 0;
+};
+
+struct CountSink : RecordSink {
+    uint64_t records = 0;
+    int piece(const uint8_t *, size_t) override { return FH_OK; }
+    int end_record() override {
+        records++;
+        return FH_OK;
+    }
+};
+
+// SketchScheme::process (mash.rs:67-80) over the C ABI: record bytes + one breaker byte, batched into
+// blocks; records longer than a block continue with FH_PUSH_CONTINUE
+struct DeviceSink : RecordSink {
+    fh_sketcher *h;
+    std::vector<uint8_t> block;
+    size_t cap;
+    bool continuing = false; // the block starts inside a record that an earlier flush cut
+    bool in_record = false;
+    static size_t default_cap() {
+        const char *e = getenv("FINCH_BLOCK_BYTES"); // test knob: force records to span blocks
+        const size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0;
+        return v ? v : (32u << 20);
+    }
+    explicit DeviceSink(fh_sketcher *h_) : h(h_), cap(default_cap()) { block.reserve(cap + 4096); }
+    int flush() {
+        if (block.empty()) return FH_OK;
+        const int rc = fh_push_block_ex(h, block.data(), block.size(), continuing ? FH_PUSH_CONTINUE : 0u);
+        if (rc != FH_OK) return hfail(rc, "%s", fh_last_error());
+        block.clear();
+        continuing = in_record;
+        return FH_OK;
+    }
+    int piece(const uint8_t *p, size_t n) override {
+        in_record = true;
+        while (n) {
+            const size_t room = cap - block.size();
+            const size_t m = std::min(room, n);
+            block.insert(block.end(), p, p + m);
+            p += m;
+            n -= m;
+            if (block.size() >= cap)
+                if (int rc = flush()) return rc;
+        }
+        return FH_OK;
+    }
+    int end_record() override {
+        block.push_back(0);
+        in_record = false;
+        if (block.size() >= cap) return flush();
+        return FH_OK;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// FASTX reader restating needletail 0.5.0 (lib.rs:60-68): first byte '>' => FASTA (multi-line),
+// '@' => FASTQ (4-line records, equal-length seq/qual, CR trimmed).  sequence() of a FASTA record is the
+// raw slice from after the header line to the end of the last sequence line (internal newlines included,
+// the final newline and a CR before it excluded) -- that length is what total_bases counts (mash.rs:72).
+// ---------------------------------------------------------------------------------------------
+struct FastxStats {
+    uint64_t n_records = 0, total_bases = 0;
+    int format = 0; // 1 FASTA, 2 FASTQ
+};
+
+static int parse_fastx(ByteSource &src, RecordSink &sink, FastxStats &st) {
+    std::vector<uint8_t> buf(8u << 20);
+    size_t lo = 0, hi = 0; // valid bytes [lo, hi)
+    bool eof = false;
+    auto refill = [&]() -> bool { // returns false if nothing more could be read
+        if (eof) return false;
+        if (lo > 0) {
+            memmove(buf.data(), buf.data() + lo, hi - lo);
+            hi -= lo;
+            lo = 0;
+        }
+        if (hi == buf.size()) buf.resize(buf.size() * 2);
+        const size_t got = src.read(buf.data() + hi, buf.size() - hi);
+        if (got == 0) {
+            eof = true;
+            return false;
+        }
+        hi += got;
+        return true;
+    };
+    refill();
+    if (src.failed()) return hfail(FH_ERR_INVALID, "corrupt compressed stream");
+    if (hi == 0) return hfail(FH_ERR_INVALID, "empty input: not a FASTA/FASTQ file");
+    if (buf[0] == '>') {
+        st.format = 1;
+        // line-oriented state machine over the buffered stream
+        enum { HEADER, SEQ } state = HEADER;
+        bool at_line_start = true, have_record = false;
+        uint64_t raw_len = 0;        // bytes of the current record's sequence region so far
+        uint8_t prev = 0, last = 0;  // its last two bytes
+        auto close_record = [&]() -> int {
+            uint64_t trim = 0;
+            if (raw_len >= 1 && last == '\n') {
+                trim = 1;
+                if (raw_len >= 2 && prev == '\r') trim = 2;
+            } else if (raw_len >= 1 && last == '\r') {
+                trim = 1;
+            }
+            st.total_bases += raw_len - trim;
+            st.n_records++;
+            return sink.end_record();
+        };
+        for (;;) {
+            if (lo == hi && !refill()) break;
+            if (at_line_start && buf[lo] == '>') {
+                if (have_record)
+                    if (int rc = close_record()) return rc;
+                have_record = true;
+                raw_len = 0;
+                prev = last = 0;
+                state = HEADER;
+            }
+            const uint8_t *nl = (const uint8_t *)memchr(buf.data() + lo, '\n', hi - lo);
+            const size_t end = nl ? (size_t)(nl - buf.data()) : hi; // [lo,end): (part of) a line, newline excluded
+            if (state == SEQ) {
+                const size_t n = end - lo;
+                if (n) {
+                    if (int rc = sink.piece(buf.data() + lo, n)) return rc; // a CR goes along; the device side drops it
+                    raw_len += n;
+                    prev = n >= 2 ? buf[end - 2] : last;
+                    last = buf[end - 1];
+                }
+                if (nl) {
+                    raw_len += 1;
+                    prev = last;
+                    last = '\n';
+                }
+            }
+            if (nl) {
+                lo = end + 1;
+                at_line_start = true;
+                if (state == HEADER) state = SEQ;
+            } else {
+                lo = hi;
+                at_line_start = false;
+            }
+        }
+        if (src.failed()) return hfail(FH_ERR_INVALID, "corrupt compressed stream");
+        if (have_record)
+            if (int rc = close_record()) return rc;
+        return FH_OK;
+    }
+    if (buf[0] != '@') return hfail(FH_ERR_INVALID, "not a FASTA/FASTQ file (first byte 0x%02x)", buf[0]);
+    st.format = 2;
+    for (;;) {
+        // skip blank lines between records / at EOF
+        for (;;) {
+            if (lo == hi && !refill()) break;
+            if (lo < hi && (buf[lo] == '\n' || buf[lo] == '\r')) ++lo;
+            else break;
+        }
+        if (lo == hi) break;
+        // the four line ends of the record (the last one may be EOF); refill() keeps [lo,hi) and sets lo = 0
+        size_t ends[4];
+        bool at_eof = false;
+        for (;;) {
+            int found = 0;
+            size_t scan = lo;
+            while (found < 4 && scan < hi) {
+                const uint8_t *nl = (const uint8_t *)memchr(buf.data() + scan, '\n', hi - scan);
+                if (!nl) break;
+                ends[found++] = (size_t)(nl - buf.data());
+                scan = ends[found - 1] + 1;
+            }
+            if (found == 4) break;
+            if (at_eof) {
+                if (found == 3) {
+                    ends[3] = hi; // last line without a newline
+                    break;
+                }
+                return hfail(FH_ERR_INVALID, "truncated FASTQ record");
+            }
+            if (!refill()) at_eof = true; // refill may have moved [lo,hi): rescan either way
+        }
+        const size_t h0 = lo, s0 = ends[0] + 1, p0 = ends[1] + 1, q0 = ends[2] + 1;
+        if (buf[h0] != '@') return hfail(FH_ERR_INVALID, "invalid FASTQ record: expected '@'");
+        if (p0 >= hi || buf[p0] != '+') return hfail(FH_ERR_INVALID, "invalid FASTQ record: expected '+'");
+        size_t s1 = ends[1], q1 = ends[3];
+        if (s1 > s0 && buf[s1 - 1] == '\r') --s1;
+        if (q1 > q0 && buf[q1 - 1] == '\r') --q1;
+        if (s1 - s0 != q1 - q0) return hfail(FH_ERR_INVALID, "invalid FASTQ record: sequence and quality lengths differ");
+        if (s1 > s0)
+            if (int rc = sink.piece(buf.data() + s0, s1 - s0)) return rc;
+        st.total_bases += s1 - s0;
+        st.n_records++;
+        if (int rc = sink.end_record()) return rc;
+        lo = std::min(hi, ends[3] + 1);
+    }
+    if (src.failed()) return hfail(FH_ERR_INVALID, "corrupt compressed stream");
+    return FH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sketch_stream (lib.rs:51-94)
+// ---------------------------------------------------------------------------------------------
+static fh_params to_fh(const finch_sketch_params &sp, uint64_t max_launch) {
+    fh_params p{};
+    p.kind = sp.kind;
+    p.k = sp.kmer_length;
+    p.size = sp.kmers_to_sketch;
+    p.seed = sp.hash_seed;
+    p.scale = sp.scale;
+    p.max_launch = max_launch;
+    p.hash_mask = 0;
+    return p;
+}
+
+static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &name, const finch_sketch_params &sp,
+                         const finch_filter_params &filters, fh_sketcher *h, Sketch &out) {
+    std::unique_ptr<ByteSource> src;
+    if (int rc = open_source(std::move(raw), src)) return rc;
+    if (int rc = fh_reset(h)) return hfail(rc, "%s", fh_last_error());
+    DeviceSink sink(h);
+    FastxStats st;
+    if (int rc = parse_fastx(*src, sink, st)) return rc;
+    if (int rc = sink.flush()) return rc;
+    finch_filter_params fp = filters;
+    // lib.rs:70-76: filtering defaults to off for FASTA, on for FASTQ
+    if (fp.filter_on < 0) fp.filter_on = st.format == 2 ? 1 : 0;
+    uint64_t n = 0, total_kmers = 0;
+    if (int rc = fh_finish(h, &n, &total_kmers)) return hfail(rc, "%s", fh_last_error());
+    const uint32_t k = sp.kmer_length;
+    std::vector<uint64_t> hs(n);
+    std::vector<uint32_t> cs(n), es(n);
+    std::vector<uint8_t> km(n * (size_t)k + 1);
+    if (int rc = fh_copy_out(h, hs.data(), cs.data(), es.data(), km.data(), nullptr)) return hfail(rc, "%s", fh_last_error());
+    std::vector<KmerCount> hashes(n);
+    for (uint64_t i = 0; i < n; ++i)
+        hashes[i] = KmerCount{hs[i], std::string((const char *)km.data() + i * k, k), cs[i], es[i]};
+    std::vector<KmerCount> filtered = filter_counts(fp, hashes);          // lib.rs:82
+    if (int rc = process_post_filter(sp, filtered, name)) return rc;      // lib.rs:83
+    out.name = name;
+    out.seq_length = st.total_bases;
+    out.num_valid_kmers = total_kmers;
+    out.comment = "";
+    out.hashes.swap(filtered);
+    out.filter_params = fp;
+    out.sketch_params = sp;
+    return FH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// .sk (Mash-JSON) writer: MultiSketch::from_sketches + serde_json (json.rs:64-89,141-158,199-218)
+// ---------------------------------------------------------------------------------------------
+static void json_escape(std::string &o, const std::string &s) {
+    o.push_back('"');
+    for (unsigned char c : s) {
+        switch (c) {
+        case '"': o += "\\\""; break;
+        case '\\': o += "\\\\"; break;
+        case '\n': o += "\\n"; break;
+        case '\r': o += "\\r"; break;
+        case '\t': o += "\\t"; break;
+        case '\b': o += "\\b"; break;
+        case '\f': o += "\\f"; break;
+        default:
+            if (c < 0x20) {
+                char b[8];
+                snprintf(b, sizeof b, "\\u%04x", c);
+                o += b;
+            } else o.push_back((char)c);
+        }
+    }
+    o.push_back('"');
+}
+
+// shortest round-trip digits
+static void shortest_digits(double v, std::string &digits, int &exp10) {
+    char b[64];
+    auto r = std::to_chars(b, b + sizeof b, v, std::chars_format::scientific);
+    std::string s(b, r.ptr); // d.ddddde[+-]XX
+    const size_t e = s.find('e');
+    std::string mant = s.substr(0, e);
+    exp10 = atoi(s.c_str() + e + 1);
+    digits.clear();
+    for (char c : mant)
+        if (c != '.' && c != '-') digits.push_back(c);
+}
+
+// Rust `f64::to_string()` (Display): never scientific, shortest digits (filtering.rs:96-99)
+static std::string rust_display_f64(double v) {
+    if (v == 0.0) return "0";
+    std::string d;
+    int e;
+    shortest_digits(std::fabs(v), d, e);
+    std::string o = v < 0 ? "-" : "";
+    const int nd = (int)d.size();
+    if (e >= nd - 1) { // integer
+        o += d;
+        o.append((size_t)(e - (nd - 1)), '0');
+    } else if (e >= 0) {
+        o += d.substr(0, (size_t)e + 1) + "." + d.substr((size_t)e + 1);
+    } else {
+        o += "0.";
+        o.append((size_t)(-e - 1), '0');
+        o += d;
+    }
+    return o;
+}
+
+// serde_json f64 (ryu): fixed for 1e-5 <= |v| < 1e16 (always with a fractional part), else scientific
+static std::string json_f64(double v) {
+    if (v == 0.0) return "0.0";
+    std::string d;
+    int e;
+    shortest_digits(std::fabs(v), d, e);
+    std::string o = v < 0 ? "-" : "";
+    const int nd = (int)d.size();
+    if (e >= -5 && e < 16) {
+        if (e >= nd - 1) {
+            o += d;
+            o.append((size_t)(e - (nd - 1)), '0');
+            o += ".0";
+        } else if (e >= 0) {
+            o += d.substr(0, (size_t)e + 1) + "." + d.substr((size_t)e + 1);
+        } else {
+            o += "0.";
+            o.append((size_t)(-e - 1), '0');
+            o += d;
+        }
+    } else {
+        o += d.substr(0, 1);
+        if (nd > 1) o += "." + d.substr(1);
+        o += "e" + std::to_string(e);
+    }
+    return o;
+}
+
+// FilterParams::to_serialized (filtering.rs:89-108); the reference's HashMap has no defined key order
+static void json_filters(std::string &o, const finch_filter_params &fp) {
+    o.push_back('{');
+    if (fp.filter_on == 1) {
+        bool first = true;
+        auto kv = [&](const char *k, const std::string &v) {
+            if (!first) o.push_back(',');
+            first = false;
+            o += "\"";
+            o += k;
+            o += "\":\"" + v + "\"";
+        };
+        if (fp.strand_filter > 0.0) kv("strandFilter", rust_display_f64(fp.strand_filter));
+        if (fp.err_filter > 0.0) kv("errFilter", rust_display_f64(fp.err_filter));
+        if (fp.has_abun_lo) kv("minCopies", std::to_string(fp.abun_lo));
+        if (fp.has_abun_hi) kv("maxCopies", std::to_string(fp.abun_hi));
+    }
+    o.push_back('}');
+}
+
+static int to_json(const std::vector<Sketch> &sketches, std::string &o) {
+    if (sketches.empty()) return hfail(FH_ERR_INVALID, "no sketches to serialise");
+    // SketchParams::from_sketches (mod.rs:158-180): all sketches must be compatible with the first
+    const finch_sketch_params &sp = sketches[0].sketch_params;
+    for (size_t i = 1; i < sketches.size(); ++i) {
+        const finch_sketch_params &q = sketches[i].sketch_params;
+        if (q.kmer_length != sp.kmer_length)
+            return hfail(FH_ERR_INVALID, "First sketch has k %u, but sketch %zu has k %u", sp.kmer_length, i + 1, q.kmer_length);
+        if (q.hash_seed != sp.hash_seed)
+            return hfail(FH_ERR_INVALID, "First sketch has hash seed %llu, but sketch %zu has hash seed %llu",
+                         (unsigned long long)sp.hash_seed, i + 1, (unsigned long long)q.hash_seed);
+    }
+    const uint64_t expected = sp.kind == 0 ? sp.final_size : sp.kmers_to_sketch; // mod.rs:148-156
+    o.clear();
+    o += "{\"kmer\":" + std::to_string(sp.kmer_length);
+    o += ",\"alphabet\":\"ACGT\",\"preserveCase\":false,\"canonical\":true";
+    o += ",\"sketchSize\":" + std::to_string((uint32_t)expected);
+    o += ",\"hashType\":\"MurmurHash3_x64_128\",\"hashBits\":64";
+    o += ",\"hashSeed\":" + std::to_string(sp.hash_seed);
+    o += ",\"scale\":" + (sp.kind == 1 ? json_f64(sp.scale) : std::string("null"));
+    o += ",\"sketches\":[";
+    for (size_t i = 0; i < sketches.size(); ++i) {
+        const Sketch &s = sketches[i];
+        if (i) o.push_back(',');
+        o += "{\"name\":";
+        json_escape(o, s.name);
+        o += ",\"seqLength\":" + std::to_string(s.seq_length);
+        o += ",\"numValidKmers\":" + std::to_string(s.num_valid_kmers);
+        o += ",\"comment\":";
+        json_escape(o, s.comment);
+        o += ",\"filters\":";
+        json_filters(o, s.filter_params);
+        o += ",\"hashes\":[";
+        for (size_t j = 0; j < s.hashes.size(); ++j) {
+            if (j) o.push_back(',');
+            o += "\"" + std::to_string(s.hashes[j].hash) + "\"";
+        }
+        o += "],\"kmers\":[";
+        for (size_t j = 0; j < s.hashes.size(); ++j) {
+            if (j) o.push_back(',');
+            json_escape(o, s.hashes[j].kmer);
+        }
+        o += "],\"counts\":[";
+        for (size_t j = 0; j < s.hashes.size(); ++j) {
+            if (j) o.push_back(',');
+            o += std::to_string(s.hashes[j].count);
+        }
+        o += "]}";
+    }
+    o += "]}";
+    return FH_OK;
+}
+
+} // namespace finch
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+using namespace finch;
+
+struct finch_sketches {
+    std::vector<Sketch> v;
+};
+
+extern "C" {
+
+const char *finch_last_error(void) { return g_host_err.c_str(); }
+
+void finch_default_sketch_params(finch_sketch_params *out) {
+    if (!out) return;
+    memset(out, 0, sizeof *out);
+    out->kind = 0;
+    out->kmers_to_sketch = 1000;
+    out->final_size = 1000;
+    out->no_strict = 0;
+    out->kmer_length = 21;
+    out->hash_seed = 0;
+    out->scale = 0.001;
+}
+
+void finch_default_filter_params(finch_filter_params *out) {
+    if (!out) return;
+    memset(out, 0, sizeof *out);
+    out->filter_on = 0; // Some(false)
+}
+
+static uint64_t env_max_launch() {
+    const char *e = getenv("FINCH_MAX_LAUNCH");
+    return e ? strtoull(e, nullptr, 10) : 0;
+}
+
+int finch_sketch_buffer(const uint8_t *data, uint64_t len, const char *name, const finch_sketch_params *sp,
+                        const finch_filter_params *filters, int device, finch_sketches **out) {
+    if ((!data && len) || !sp || !filters || !out) return hfail(FH_ERR_INVALID, "null argument");
+    fh_params p = to_fh(*sp, env_max_launch());
+    fh_sketcher *h = fh_new(&p, device);
+    if (!h) return hfail(FH_ERR_NO_DEVICE, "%s", fh_last_error());
+    auto res = std::make_unique<finch_sketches>();
+    res->v.resize(1);
+    const int rc = sketch_stream(std::make_unique<MemSource>(data, (size_t)len), name ? name : "", *sp, *filters, h, res->v[0]);
+    fh_free(h);
+    if (rc != FH_OK) return rc;
+    *out = res.release();
+    return FH_OK;
+}
+
+int finch_sketch_files(const char *const *filenames, uint32_t n_files, const finch_sketch_params *sp,
+                       const finch_filter_params *filters, const int *devices, uint32_t n_devices, uint32_t n_threads,
+                       finch_sketches **out) {
+    if (!filenames || !sp || !filters || !out) return hfail(FH_ERR_INVALID, "null argument");
+    std::vector<int> devs;
+    if (devices && n_devices) devs.assign(devices, devices + n_devices);
+    else devs.push_back(0);
+    if (n_threads == 0) n_threads = (uint32_t)devs.size();
+    n_threads = std::max<uint32_t>(1, std::min<uint32_t>(n_threads, std::max<uint32_t>(n_files, 1)));
+    auto res = std::make_unique<finch_sketches>();
+    res->v.resize(n_files);
+    std::atomic<uint32_t> next{0};
+    std::mutex err_mu;
+    int first_err_code = FH_OK;
+    uint32_t first_err_idx = UINT32_MAX;
+    std::string first_err_msg;
+    // lib.rs:34-36: par_iter over the files; here one worker = one device sketcher reused across its files
+    const uint64_t ml = env_max_launch() ? env_max_launch() : (n_files > 1 ? (16ull << 20) : 0ull);
+    auto worker = [&](uint32_t w) {
+        fh_params p = to_fh(*sp, ml);
+        fh_sketcher *h = nullptr;
+        for (;;) {
+            const uint32_t i = next.fetch_add(1);
+            if (i >= n_files) break;
+            int rc = FH_OK;
+            std::string msg;
+            if (!h) {
+                h = fh_new(&p, devs[w % devs.size()]);
+                if (!h) {
+                    rc = FH_ERR_NO_DEVICE;
+                    msg = fh_last_error();
+                }
+            }
+            if (rc == FH_OK) {
+                const std::string fn = filenames[i];
+                FILE *f = fn == "-" ? stdin : fopen(fn.c_str(), "rb");
+                if (!f) {
+                    rc = FH_ERR_INVALID;
+                    msg = fn + ": " + strerror(errno) + " (os error " + std::to_string(errno) + ")";
+                } else {
+                    rc = sketch_stream(std::make_unique<FileSource>(f, f != stdin), fn, *sp, *filters, h, res->v[i]);
+                    if (rc != FH_OK) msg = g_host_err;
+                }
+            }
+            if (rc != FH_OK) {
+                std::lock_guard<std::mutex> g(err_mu);
+                if (i < first_err_idx) {
+                    first_err_idx = i;
+                    first_err_code = rc;
+                    first_err_msg = msg;
+                }
+            }
+        }
+        if (h) fh_free(h);
+    };
+    std::vector<std::thread> th;
+    for (uint32_t w = 0; w < n_threads; ++w) th.emplace_back(worker, w);
+    for (auto &t : th) t.join();
+    if (first_err_code != FH_OK) return hfail(first_err_code, "%s", first_err_msg.c_str());
+    *out = res.release();
+    return FH_OK;
+}
+
+void finch_sketches_free(finch_sketches *s) { delete s; }
+uint32_t finch_sketches_len(const finch_sketches *s) { return s ? (uint32_t)s->v.size() : 0; }
+const char *finch_sketch_name(const finch_sketches *s, uint32_t i) { return (s && i < s->v.size()) ? s->v[i].name.c_str() : ""; }
+uint64_t finch_sketch_seq_length(const finch_sketches *s, uint32_t i) { return (s && i < s->v.size()) ? s->v[i].seq_length : 0; }
+uint64_t finch_sketch_num_valid_kmers(const finch_sketches *s, uint32_t i) {
+    return (s && i < s->v.size()) ? s->v[i].num_valid_kmers : 0;
+}
+uint64_t finch_sketch_n_hashes(const finch_sketches *s, uint32_t i) { return (s && i < s->v.size()) ? s->v[i].hashes.size() : 0; }
+
+int finch_sketch_filter_params(const finch_sketches *s, uint32_t i, finch_filter_params *out) {
+    if (!s || i >= s->v.size() || !out) return hfail(FH_ERR_INVALID, "bad argument");
+    *out = s->v[i].filter_params;
+    return FH_OK;
+}
+
+int finch_sketch_copy(const finch_sketches *s, uint32_t i, uint64_t *hashes, uint32_t *counts, uint32_t *extra_counts,
+                      uint8_t *kmers) {
+    if (!s || i >= s->v.size()) return hfail(FH_ERR_INVALID, "bad argument");
+    const Sketch &sk = s->v[i];
+    const size_t k = sk.sketch_params.kmer_length;
+    for (size_t j = 0; j < sk.hashes.size(); ++j) {
+        if (hashes) hashes[j] = sk.hashes[j].hash;
+        if (counts) counts[j] = sk.hashes[j].count;
+        if (extra_counts) extra_counts[j] = sk.hashes[j].extra_count;
+        if (kmers) memcpy(kmers + j * k, sk.hashes[j].kmer.data(), std::min(k, sk.hashes[j].kmer.size()));
+    }
+    return FH_OK;
+}
+
+int finch_sketches_to_json(const finch_sketches *s, char **out, uint64_t *len) {
+    if (!s || !out) return hfail(FH_ERR_INVALID, "null argument");
+    std::string o;
+    if (int rc = to_json(s->v, o)) return rc;
+    char *p = (char *)malloc(o.size() + 1);
+    if (!p) return hfail(FH_ERR_INVALID, "out of memory");
+    memcpy(p, o.data(), o.size());
+    p[o.size()] = 0;
+    *out = p;
+    if (len) *len = o.size();
+    return FH_OK;
+}
+
+void finch_free_string(char *p) { free(p); }
+
+int finch_sketches_from_arrays(const char *name, uint64_t seq_length, uint64_t num_valid_kmers, uint64_t n,
+                               const uint64_t *hashes, const uint32_t *counts, const uint32_t *extra_counts,
+                               const uint8_t *kmers, const finch_sketch_params *sp, const finch_filter_params *filters,
+                               finch_sketches **out) {
+    if (!sp || !filters || !out || (n && (!hashes || !counts || !extra_counts))) return hfail(FH_ERR_INVALID, "null argument");
+    auto res = std::make_unique<finch_sketches>();
+    res->v.resize(1);
+    Sketch &s = res->v[0];
+    s.name = name ? name : "";
+    s.seq_length = seq_length;
+    s.num_valid_kmers = num_valid_kmers;
+    s.sketch_params = *sp;
+    s.filter_params = *filters;
+    const size_t k = sp->kmer_length;
+    s.hashes.resize(n);
+    for (uint64_t i = 0; i < n; ++i)
+        s.hashes[i] = KmerCount{hashes[i], kmers ? std::string((const char *)kmers + i * k, k) : std::string(), counts[i],
+                                extra_counts[i]};
+    *out = res.release();
+    return FH_OK;
+}
+
+int finch_apply_filters(finch_sketches *s, uint32_t i, finch_filter_params *filters) {
+    if (!s || i >= s->v.size() || !filters) return hfail(FH_ERR_INVALID, "bad argument");
+    Sketch &sk = s->v[i];
+    std::vector<KmerCount> f = filter_counts(*filters, sk.hashes);
+    if (int rc = process_post_filter(sk.sketch_params, f, sk.name)) return rc;
+    sk.hashes.swap(f);
+    sk.filter_params = *filters;
+    return FH_OK;
+}
+
+uint32_t finch_guess_filter_threshold(const uint32_t *counts, uint64_t n, double filter_level) {
+    std::vector<KmerCount> v(n);
+    for (uint64_t i = 0; i < n; ++i) v[i] = KmerCount{i, std::string(), counts[i], 0};
+    return guess_filter_threshold(v, filter_level);
+}
+
+int finch_fastx_scan(const uint8_t *data, uint64_t len, uint64_t *n_records, uint64_t *total_bases, int *format) {
+    if (!data && len) return hfail(FH_ERR_INVALID, "null argument");
+    std::unique_ptr<ByteSource> src;
+    if (int rc = open_source(std::make_unique<MemSource>(data, (size_t)len), src)) return rc;
+    CountSink sink;
+    FastxStats st;
+    if (int rc = parse_fastx(*src, sink, st)) return rc;
+    if (n_records) *n_records = st.n_records;
+    if (total_bases) *total_bases = st.total_bases;
+    if (format) *format = st.format;
+    return FH_OK;
+}
+
+} // extern "C"

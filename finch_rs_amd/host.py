@@ -1,0 +1,201 @@
+"""Python binding of the C++ host layer (include/finch_host.h): finch::sketch_files / sketch_stream,
+FilterParams, the `.sk` (Mash-JSON) writer -- mirrors lib/src/lib.rs:29-94 of the reference."""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import FinchHipError
+from .sketch_schemes import KC_DTYPE, FinchError, KmerCount, SketchParams
+
+
+class CSketchParams(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("kmer_length", C.c_uint32), ("kmers_to_sketch", C.c_uint64),
+                ("final_size", C.c_uint64), ("no_strict", C.c_uint32), ("pad", C.c_uint32),
+                ("hash_seed", C.c_uint64), ("scale", C.c_double)]
+
+
+class CFilterParams(C.Structure):
+    _fields_ = [("filter_on", C.c_int32), ("has_abun_lo", C.c_uint32), ("abun_lo", C.c_uint32),
+                ("has_abun_hi", C.c_uint32), ("abun_hi", C.c_uint32), ("pad", C.c_uint32),
+                ("err_filter", C.c_double), ("strand_filter", C.c_double)]
+
+
+@dataclass
+class FilterParams:
+    """filtering.rs:11-16"""
+    filter_on: Optional[bool] = False
+    abun_filter: Tuple[Optional[int], Optional[int]] = (None, None)
+    err_filter: float = 0.0
+    strand_filter: float = 0.0
+
+    def to_c(self) -> CFilterParams:
+        lo, hi = self.abun_filter
+        return CFilterParams(-1 if self.filter_on is None else int(bool(self.filter_on)), lo is not None, lo or 0,
+                             hi is not None, hi or 0, 0, self.err_filter, self.strand_filter)
+
+    @staticmethod
+    def from_c(c: CFilterParams) -> "FilterParams":
+        return FilterParams(None if c.filter_on < 0 else bool(c.filter_on),
+                            (c.abun_lo if c.has_abun_lo else None, c.abun_hi if c.has_abun_hi else None),
+                            c.err_filter, c.strand_filter)
+
+
+@dataclass
+class Sketch:
+    """serialization/mod.rs:46-55"""
+    name: str
+    seq_length: int
+    num_valid_kmers: int
+    comment: str
+    hashes: List[KmerCount]
+    filter_params: FilterParams
+    sketch_params: SketchParams
+    arrays: tuple = field(default=None, repr=False)  # (structured [hash,count,extra_count], kmers uint8[n,k])
+
+
+_P = C.c_void_p
+_SYMS = {
+    "finch_last_error": (C.c_char_p, []),
+    "finch_default_sketch_params": (None, [C.POINTER(CSketchParams)]),
+    "finch_default_filter_params": (None, [C.POINTER(CFilterParams)]),
+    "finch_sketch_files": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(CSketchParams), C.POINTER(CFilterParams),
+                                     C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "finch_sketch_buffer": (C.c_int, [_P, C.c_uint64, C.c_char_p, C.POINTER(CSketchParams), C.POINTER(CFilterParams),
+                                      C.c_int, C.POINTER(_P)]),
+    "finch_sketches_free": (None, [_P]),
+    "finch_sketches_len": (C.c_uint32, [_P]),
+    "finch_sketch_name": (C.c_char_p, [_P, C.c_uint32]),
+    "finch_sketch_seq_length": (C.c_uint64, [_P, C.c_uint32]),
+    "finch_sketch_num_valid_kmers": (C.c_uint64, [_P, C.c_uint32]),
+    "finch_sketch_n_hashes": (C.c_uint64, [_P, C.c_uint32]),
+    "finch_sketch_filter_params": (C.c_int, [_P, C.c_uint32, C.POINTER(CFilterParams)]),
+    "finch_sketch_copy": (C.c_int, [_P, C.c_uint32, _P, _P, _P, _P]),
+    "finch_sketches_to_json": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "finch_free_string": (None, [_P]),
+    "finch_sketches_from_arrays": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, _P, _P, _P, _P,
+                                             C.POINTER(CSketchParams), C.POINTER(CFilterParams), C.POINTER(_P)]),
+    "finch_apply_filters": (C.c_int, [_P, C.c_uint32, C.POINTER(CFilterParams)]),
+    "finch_guess_filter_threshold": (C.c_uint32, [_P, C.c_uint64, C.c_double]),
+    "finch_fastx_scan": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+}
+_bound = None
+
+
+def lib():
+    global _bound
+    if _bound is None:
+        L = _lib.load()
+        for name, (res, args) in _SYMS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _bound = L
+    return _bound
+
+
+def _check(rc):
+    if rc != 0:
+        msg = (lib().finch_last_error() or b"").decode(errors="replace")
+        if rc == _lib.FH_ERR_INVALID:
+            raise FinchError(msg)
+        raise FinchHipError(rc, msg)
+
+
+def _params_c(p: SketchParams) -> CSketchParams:
+    kind = {"mash": 0, "scaled": 1}[p.kind]
+    return CSketchParams(kind, p.kmer_length, p.kmers_to_sketch, p.final_size, int(p.no_strict), 0, p.hash_seed, p.scale)
+
+
+class Sketches:
+    """owning wrapper of a finch_sketches*"""
+
+    def __init__(self, ptr, params: SketchParams):
+        self._p, self.params = ptr, params
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().finch_sketches_free(self._p)
+            self._p = None
+
+    def __len__(self):
+        return lib().finch_sketches_len(self._p)
+
+    def sketch(self, i: int) -> Sketch:
+        L = lib()
+        n = L.finch_sketch_n_hashes(self._p, i)
+        k = self.params.kmer_length
+        hs, cs, es = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        km = np.zeros((n, k), np.uint8)
+        _check(L.finch_sketch_copy(self._p, i, hs.ctypes.data, cs.ctypes.data, es.ctypes.data, km.ctypes.data))
+        fp = CFilterParams()
+        _check(L.finch_sketch_filter_params(self._p, i, C.byref(fp)))
+        kc = np.zeros(n, dtype=KC_DTYPE)
+        kc["hash"], kc["count"], kc["extra_count"] = hs, cs, es
+        hashes = [KmerCount(int(hs[j]), bytes(km[j]), int(cs[j]), int(es[j])) for j in range(n)]
+        return Sketch(L.finch_sketch_name(self._p, i).decode(), L.finch_sketch_seq_length(self._p, i),
+                      L.finch_sketch_num_valid_kmers(self._p, i), "", hashes, FilterParams.from_c(fp), self.params,
+                      (kc, km))
+
+    def to_list(self) -> List[Sketch]:
+        return [self.sketch(i) for i in range(len(self))]
+
+    def to_json(self) -> str:
+        out, n = _P(), C.c_uint64()
+        _check(lib().finch_sketches_to_json(self._p, C.byref(out), C.byref(n)))
+        try:
+            return C.string_at(out.value, n.value).decode()
+        finally:
+            lib().finch_free_string(out)
+
+    def apply_filters(self, i: int, filters: FilterParams) -> FilterParams:
+        c = filters.to_c()
+        _check(lib().finch_apply_filters(self._p, i, C.byref(c)))
+        return FilterParams.from_c(c)
+
+
+def sketch_files(filenames: Sequence[str], sketch_params: SketchParams, filters: FilterParams,
+                 devices: Optional[Sequence[int]] = None, n_threads: int = 0) -> Sketches:
+    """finch::sketch_files (lib.rs:29-49)"""
+    arr = (C.c_char_p * len(filenames))(*[f.encode() for f in filenames])
+    devs = list(devices) if devices else [0]
+    darr = (C.c_int * len(devs))(*devs)
+    sp, fp = _params_c(sketch_params), filters.to_c()
+    out = _P()
+    _check(lib().finch_sketch_files(arr, len(filenames), C.byref(sp), C.byref(fp), darr, len(devs), n_threads, C.byref(out)))
+    return Sketches(out, sketch_params)
+
+
+def sketch_stream(data: bytes, name: str, sketch_params: SketchParams, filters: FilterParams, device: int = 0) -> Sketches:
+    """finch::sketch_stream (lib.rs:51-94) over an in-memory file image"""
+    sp, fp = _params_c(sketch_params), filters.to_c()
+    out = _P()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    _check(lib().finch_sketch_buffer(buf.ctypes.data, len(data), name.encode(), C.byref(sp), C.byref(fp), device, C.byref(out)))
+    return Sketches(out, sketch_params)
+
+
+def sketches_from_arrays(name, seq_length, num_valid_kmers, kc, km, sketch_params: SketchParams, filters: FilterParams) -> Sketches:
+    hs = np.ascontiguousarray(kc["hash"], np.uint64)
+    cs = np.ascontiguousarray(kc["count"], np.uint32)
+    es = np.ascontiguousarray(kc["extra_count"], np.uint32)
+    km = np.ascontiguousarray(km, np.uint8)
+    sp, fp = _params_c(sketch_params), filters.to_c()
+    out = _P()
+    _check(lib().finch_sketches_from_arrays(name.encode(), seq_length, num_valid_kmers, len(hs), hs.ctypes.data, cs.ctypes.data,
+                                            es.ctypes.data, km.ctypes.data if km.size else None, C.byref(sp), C.byref(fp),
+                                            C.byref(out)))
+    return Sketches(out, sketch_params)
+
+
+def guess_filter_threshold(counts, level: float) -> int:
+    a = np.ascontiguousarray(counts, np.uint32)
+    return lib().finch_guess_filter_threshold(a.ctypes.data, len(a), level)
+
+
+def fastx_scan(data: bytes):
+    n, tb, fmt = C.c_uint64(), C.c_uint64(), C.c_int()
+    buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+    _check(lib().finch_fastx_scan(buf.ctypes.data, len(data), C.byref(n), C.byref(tb), C.byref(fmt)))
+    return n.value, tb.value, fmt.value

@@ -82,6 +82,10 @@ int fh_set_stream_offset(fh_sketcher *s, uint64_t offset);
  * bottom-n / scaled admission on the device.  k-mers never span two pushed blocks.
  * Asynchronous: returns once the bytes are staged; the caller may reuse `bytes` immediately. */
 int fh_push_block(fh_sketcher *s, const uint8_t *bytes, uint64_t len);
+/* Same with flags.  FH_PUSH_CONTINUE: this block continues the record the previous push ended in (a
+ * record longer than the caller's buffer, e.g. a chromosome): k-mers span the boundary of the two pushes. */
+#define FH_PUSH_CONTINUE 1u
+int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_t flags);
 
 /* Same for a block that is already resident in this device's HBM (16-byte aligned, no whitespace
  * bytes: the packed stream produced by fh_push_block's staging or by fh_synth_reads_device).

@@ -1,0 +1,106 @@
+/*
+ * finch_host.h -- host-side mirror of finch's library entry points for the accelerated path, exported
+ * by libfinch_hip.so next to the device ABI (finch_hip.h).  C++ implementation (the reference is
+ * compiled code; no Rust toolchain in this image), C linkage so that any host language can bind it.
+ *
+ * Reference items mirrored (relative to the finch-rs tree):
+ *   finch_sketch_files      finch::sketch_files        lib/src/lib.rs:29-49   (one Sketch per file, input order;
+ *                                                       rayon par_iter over files -> worker threads, each with its
+ *                                                       own device sketcher; files are mapped round-robin to GPUs)
+ *   finch_sketch_buffer     finch::sketch_stream       lib/src/lib.rs:51-94   (in-memory FASTA/FASTQ[.gz] image)
+ *   FASTX reading           needletail 0.5.0 parse_fastx_reader (lib.rs:60-68): gz sniffed by magic bytes,
+ *                           '>' FASTA (multi-line), '@' FASTQ (4-line records)
+ *   filtering               FilterParams::filter_counts lib/src/filtering.rs:60-87 (strand -> err -> abundance)
+ *   post filter             SketchParams::process_post_filter lib/src/sketch_schemes/mod.rs:115-128
+ *   .sk writer              MultiSketch / JsonSketch   lib/src/serialization/json.rs:64-89,141-158,199-218
+ *
+ * The per-base work (normalize, canonical k-mers, murmur3, bottom-n) is done by the device engine; this
+ * layer parses, stages, filters (O(n) on <= n records) and serialises.
+ */
+#ifndef FINCH_HOST_H
+#define FINCH_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* SketchParams (mod.rs:54-71); AllCounts is not on the accelerated path */
+typedef struct finch_sketch_params {
+    uint32_t kind;            /* 0 = Mash, 1 = Scaled */
+    uint32_t kmer_length;
+    uint64_t kmers_to_sketch;
+    uint64_t final_size;      /* Mash only */
+    uint32_t no_strict;       /* Mash only */
+    uint32_t pad;
+    uint64_t hash_seed;
+    double scale;             /* Scaled only */
+} finch_sketch_params;
+
+/* FilterParams (filtering.rs:11-16) */
+typedef struct finch_filter_params {
+    int32_t filter_on;        /* -1 = None, 0 = Some(false), 1 = Some(true) */
+    uint32_t has_abun_lo, abun_lo;
+    uint32_t has_abun_hi, abun_hi;
+    uint32_t pad;
+    double err_filter;
+    double strand_filter;
+} finch_filter_params;
+
+/* Vec<Sketch> (serialization/mod.rs:46-55) */
+typedef struct finch_sketches finch_sketches;
+
+const char *finch_last_error(void);
+
+/* SketchParams::default() (mod.rs:73-83) and FilterParams::default() (filtering.rs:136-145) */
+void finch_default_sketch_params(finch_sketch_params *out);
+void finch_default_filter_params(finch_filter_params *out);
+
+/* sketch_files: `devices` lists the HIP devices to use (NULL/0 = device 0); n_threads = worker threads
+ * (0 = one per device).  "-" reads stdin.  Returns 0 or a negative FH_ERR_* code (message via
+ * finch_last_error; the first failing file wins, as in the reference's collect()). */
+int finch_sketch_files(const char *const *filenames, uint32_t n_files, const finch_sketch_params *sketch_params,
+                       const finch_filter_params *filters, const int *devices, uint32_t n_devices, uint32_t n_threads,
+                       finch_sketches **out);
+/* sketch_stream over an in-memory file image */
+int finch_sketch_buffer(const uint8_t *data, uint64_t len, const char *name, const finch_sketch_params *sketch_params,
+                        const finch_filter_params *filters, int device, finch_sketches **out);
+void finch_sketches_free(finch_sketches *s);
+
+uint32_t finch_sketches_len(const finch_sketches *s);
+const char *finch_sketch_name(const finch_sketches *s, uint32_t i);
+uint64_t finch_sketch_seq_length(const finch_sketches *s, uint32_t i);
+uint64_t finch_sketch_num_valid_kmers(const finch_sketches *s, uint32_t i);
+uint64_t finch_sketch_n_hashes(const finch_sketches *s, uint32_t i);
+/* the (possibly updated) filter params of sketch i (lib.rs:70-76, filtering.rs:69-80) */
+int finch_sketch_filter_params(const finch_sketches *s, uint32_t i, finch_filter_params *out);
+/* hashes ascending; kmers = n*k ASCII bytes; any pointer may be NULL */
+int finch_sketch_copy(const finch_sketches *s, uint32_t i, uint64_t *hashes, uint32_t *counts, uint32_t *extra_counts,
+                      uint8_t *kmers);
+
+/* MultiSketch::from_sketches + serde_json::to_string (the `.sk` format).  *out is malloc'ed; free with
+ * finch_free_string. */
+int finch_sketches_to_json(const finch_sketches *s, char **out, uint64_t *len);
+void finch_free_string(char *p);
+
+/* ---- pieces that need no GPU (unit-testable on the host) ---- */
+/* Build a one-sketch result from arrays (to exercise filtering / serialisation without a device). */
+int finch_sketches_from_arrays(const char *name, uint64_t seq_length, uint64_t num_valid_kmers, uint64_t n,
+                               const uint64_t *hashes, const uint32_t *counts, const uint32_t *extra_counts,
+                               const uint8_t *kmers, const finch_sketch_params *sketch_params,
+                               const finch_filter_params *filters, finch_sketches **out);
+/* filter_counts (filtering.rs:60-87) + process_post_filter (mod.rs:115-128) applied in place to sketch i;
+ * `filters` is updated exactly as the reference updates its FilterParams. */
+int finch_apply_filters(finch_sketches *s, uint32_t i, finch_filter_params *filters);
+/* guess_filter_threshold (filtering.rs:154-195) */
+uint32_t finch_guess_filter_threshold(const uint32_t *counts, uint64_t n, double filter_level);
+/* FASTX scan only: number of records, sum of sequence() lengths (what total_bases counts, mash.rs:72) and
+ * the format of the first record (1 FASTA, 2 FASTQ).  gz images are inflated first. */
+int finch_fastx_scan(const uint8_t *data, uint64_t len, uint64_t *n_records, uint64_t *total_bases, int *format);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FINCH_HOST_H */

@@ -1,0 +1,136 @@
+"""GPU tests of the host layer: finch::sketch_files / sketch_stream through the C++ mirror, against the
+reference's CLI golden vectors and the oracle's own sketch_stream.  Run with -m gpu."""
+import gzip
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from finch_rs_amd import host as H
+from finch_rs_amd import sketch_schemes as S
+from finch_rs_amd.sketch_schemes import FinchError, SketchParams
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_sketch(data: bytes, kind, size, k, seed=0, scale=0.001):
+    o = O.OracleSketcher(kind, size, k, seed, scale)
+    fmt = o.sketch_stream(data)
+    return o, fmt
+
+
+def same(sk: H.Sketch, o: O.OracleSketcher, n=None):
+    okc, okm = o.to_vec()
+    if n is not None:
+        okc, okm = okc[:n], okm[:n]
+    assert np.array_equal(sk.arrays[0], okc) and np.array_equal(sk.arrays[1], okm)
+    assert (sk.seq_length, sk.num_valid_kmers) == o.total_bases_and_kmers()
+
+
+def test_cli_golden_through_sketch_files(golden_dir):
+    # cli/tests/test_cli.rs:20-149 ("finch sketch --n-hashes 10 tests/data/query.fa -O"): the CLI oversketches
+    # x200 (cli.rs:187-192) and FASTA input leaves filtering off (lib.rs:70-76)
+    path = os.path.join(golden_dir, "query.fa")
+    vec = json.load(open(os.path.join(golden_dir, "reference_vectors.json")))["test_cli_rs_99_143"]
+    res = H.sketch_files([path], SketchParams.mash(10 * 200, 10, False, 21, 0), H.FilterParams(None, (None, None), 1.0 * 21 / 100, 1.0))
+    sk = res.sketch(0)
+    assert [h.kmer.decode() for h in sk.hashes] == vec["kmers"]
+    assert sk.name == path and sk.seq_length == 405 and sk.num_valid_kmers == 339
+    assert sk.filter_params.filter_on is False
+    d = json.loads(res.to_json())
+    assert (d["kmer"], d["alphabet"], d["sketchSize"], d["hashSeed"]) == (21, "ACGT", 10, 0)
+    assert d["sketches"][0]["kmers"] == vec["kmers"] and len(d["sketches"][0]["hashes"]) == 10
+    res2 = H.sketch_files([path], SketchParams.scaled(10, 21, 0.001, 0), H.FilterParams(None))
+    assert [h.kmer.decode() for h in res2.sketch(0).hashes][:10] == vec["kmers"]
+
+
+def make_fastq(n_reads, seed=3, rl=150, gl=100000):
+    g = S.synth_genome_host(gl, seed)
+    reads = S.synth_reads_host(g, 0, n_reads, rl, seed, 10000, 500).reshape(n_reads, rl + 1)[:, :rl]
+    return b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(reads[i]), b"I" * rl) for i in range(n_reads)), g
+
+
+def test_fastq_defaults_to_filtering_and_matches_oracle(tmp_path):
+    fq, _ = make_fastq(20000)
+    params = SketchParams.mash(2000, 100, False, 21, 0)
+    filt = H.FilterParams(None, (None, None), 0.21, 0.1)
+    p = tmp_path / "reads.fastq"
+    p.write_bytes(fq)
+    pz = tmp_path / "reads.fastq.gz"
+    pz.write_bytes(gzip.compress(fq, 1))
+    res = H.sketch_files([str(p), str(pz)], params, filt, n_threads=2)
+    o, fmt = oracle_sketch(fq, O.MASH, 2000, 21)
+    assert fmt == 2
+    okc, okm = o.to_vec()
+    a, ak = O.filter_strands(okc, okm, 0.1)
+    cutoff = O.guess_filter_threshold(a, 0.21)
+    b, bk = O.filter_abundance(a, ak, cutoff, None)
+    for i in range(2):
+        sk = res.sketch(i)
+        assert sk.filter_params.filter_on is True and sk.filter_params.abun_filter == (cutoff, None)
+        assert np.array_equal(sk.arrays[0], b[:100]) and np.array_equal(sk.arrays[1], bk[:100])
+        assert (sk.seq_length, sk.num_valid_kmers) == o.total_bases_and_kmers()
+    assert [res.sketch(i).name for i in range(2)] == [str(p), str(pz)]
+
+
+def test_errors(tmp_path):
+    with pytest.raises(FinchError, match="No such file or directory"):
+        H.sketch_files([str(tmp_path / "nope.fa")], SketchParams.default(), H.FilterParams(False))
+    p = tmp_path / "tiny.fa"
+    p.write_bytes(b">a\nACGTACGTACGTACGTACGTACGTA\n")
+    with pytest.raises(FinchError, match=r"had too few kmers \(\d+\) to sketch"):
+        H.sketch_files([str(p)], SketchParams.default(), H.FilterParams(False))
+    assert len(H.sketch_files([str(p)], SketchParams.mash(1000, 1000, True, 21, 0), H.FilterParams(False)).sketch(0).hashes) > 0
+
+
+def test_batch_of_fastas_one_sketch_per_file_in_order(tmp_path):
+    rng = np.random.default_rng(4)
+    paths, datas = [], []
+    for i in range(12):
+        L = int(rng.integers(20000, 200000))
+        seq = bytes(S.synth_genome_host(L, 100 + i))
+        data = b">g%d\n" % i + b"\n".join(seq[j:j + 70] for j in range(0, L, 70)) + b"\n"
+        p = tmp_path / ("g%02d.fa" % i)
+        p.write_bytes(data)
+        paths.append(str(p))
+        datas.append(data)
+    res = H.sketch_files(paths, SketchParams.default(), H.FilterParams(None), n_threads=4)
+    assert len(res) == 12
+    for i in range(12):
+        o, fmt = oracle_sketch(datas[i], O.MASH, 1000, 21)
+        sk = res.sketch(i)
+        assert sk.name == paths[i]
+        same(sk, o)
+
+
+def _run_child(code, env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", code], env=e, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    return r.stdout
+
+
+def test_long_records_span_blocks_and_staging_slices():
+    """a record longer than the host block / the staging slice: k-mers must span the cuts
+    (FH_PUSH_CONTINUE + the K-1 byte carry).  Tiny buffers are forced through env knobs in a child process."""
+    code = r'''
+import numpy as np
+from finch_rs_amd import host as H, sketch_schemes as S
+from oracle import oracle as O
+seq = bytes(S.synth_genome_host(300000, 9))
+data = b">chr1 long\n" + b"\n".join(seq[j:j+61] for j in range(0, len(seq), 61)) + b"\n>chr2\n" + seq[1000:9000] + b"\nNNNN\n" + seq[:500] + b"\n"
+res = H.sketch_stream(data, "mem", S.SketchParams.mash(500, 500, False, 31, 0), H.FilterParams(False))
+o = O.OracleSketcher(O.MASH, 500, 31, 0); o.sketch_stream(data)
+okc, okm = o.to_vec(); sk = res.sketch(0)
+assert np.array_equal(sk.arrays[0], okc) and np.array_equal(sk.arrays[1], okm)
+assert (sk.seq_length, sk.num_valid_kmers) == o.total_bases_and_kmers()
+print("child ok")
+'''
+    for env in [{"FINCH_BLOCK_BYTES": "1000"}, {"FH_STAGE_BYTES": "4096"}, {"FINCH_BLOCK_BYTES": "7777", "FH_STAGE_BYTES": "5000"}]:
+        assert "child ok" in _run_child(code, env)

@@ -1,0 +1,138 @@
+"""CPU tests of the C++ host layer (include/finch_host.h): FASTX reader vs the oracle's parser, the
+filters vs the reference's known answers (filtering.rs tests) and the oracle, and the `.sk` writer."""
+import gzip
+import json
+
+import numpy as np
+import pytest
+
+from finch_rs_amd import host as H
+from finch_rs_amd.sketch_schemes import FinchError, KC_DTYPE, SketchParams
+from oracle import oracle as O
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    import __graft_entry__ as G
+    G.build()
+
+
+def oracle_scan(data: bytes):
+    s = O.OracleSketcher(O.MASH, 10, 21, 0)
+    fmt = s.sketch_stream(data)
+    return s.total_bases_and_kmers()[0], fmt
+
+
+FASTA_CASES = [
+    b">a\nACGT\n",
+    b">a\nACGT",
+    b">a desc\nACGT\nTTGA\n>b\nAC\nGT\n\n",
+    b">a\r\nACGT\r\nTT\r\n>b\r\nGG\r\n",
+    b">only header\n",
+    b">a\nAC GT\tNN\n>b\n\n>c\nA\n",
+]
+
+
+@pytest.mark.parametrize("data", FASTA_CASES)
+def test_fasta_scan_matches_oracle(data):
+    n, tb, fmt = H.fastx_scan(data)
+    otb, ofmt = oracle_scan(data)
+    assert fmt == 1 and ofmt == 1
+    assert tb == otb
+    assert n == data.count(b">")
+
+
+def test_fastq_scan_and_errors(golden_dir):
+    fq = b"@r1\nACGT\n+\nIIII\n@r2 x\nAC\n+r2\nII\n@r3\n\n+\n\n"
+    n, tb, fmt = H.fastx_scan(fq)
+    assert (n, tb, fmt) == (3, 6, 2)
+    assert oracle_scan(fq) == (6, 2)
+    n, tb, fmt = H.fastx_scan(b"@r1\r\nACGT\r\n+\r\nIIII\r\n@r2\nAC\n+\nII")  # CRLF and no final newline
+    assert (n, tb) == (2, 6)
+    assert H.fastx_scan(gzip.compress(fq)) == (3, 6, 2)
+    for bad in [b"@r1\nACGT\n+\nIII\n", b"@r1\nACGT\nIIII\n+\n", b"@r1\nACGT\n", b"xyz", b""]:
+        with pytest.raises(FinchError):
+            H.fastx_scan(bad)
+    data = open(golden_dir + "/query.fa", "rb").read()
+    assert H.fastx_scan(data) == (3, 134 + 136 + 135, 1)
+
+
+def test_big_records_cross_buffer_refills():
+    rng = np.random.default_rng(0)
+    seq = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=20_000_000))
+    lines = b"\n".join(seq[i:i + 70] for i in range(0, len(seq), 70))
+    data = b">chr\n" + lines + b"\n>small\nACGT\n"
+    n, tb, fmt = H.fastx_scan(data)
+    assert n == 2 and fmt == 1
+    assert tb == len(lines) + 4
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, seq[i * 150:(i + 1) * 150], b"I" * 150) for i in range(100000))
+    assert H.fastx_scan(fq) == (100000, 15_000_000, 2)
+
+
+def kc_of(counts, extras=None):
+    kc = np.zeros(len(counts), dtype=KC_DTYPE)
+    kc["hash"] = np.arange(1, len(counts) + 1)
+    kc["count"] = counts
+    kc["extra_count"] = extras if extras is not None else 0
+    return kc
+
+
+def test_guess_filter_threshold_reference_known_answers():
+    # lib/src/filtering.rs:197-327
+    cases = [([], 0.2, 1), ([1], 0.2, 1), ([1, 1], 0.2, 1), ([1, 9], 0.2, 8), ([1, 10, 10, 9], 0.1, 8),
+             ([1, 1, 2, 4], 0.1, 1), ([2], 1.0, 2)]
+    for counts, level, want in cases:
+        assert H.guess_filter_threshold(counts, level) == want
+        assert O.guess_filter_threshold(kc_of(counts), level) == want
+
+
+def test_filter_counts_matches_oracle_and_updates_params():
+    rng = np.random.default_rng(9)
+    n = 5000
+    counts = np.concatenate([rng.poisson(1.2, n // 2) + 1, rng.poisson(40, n - n // 2) + 1]).astype(np.uint32)
+    extras = (counts * rng.random(n)).astype(np.uint32)
+    kc = kc_of(counts, extras)
+    kc["hash"] = np.sort(rng.integers(1, 2**62, n).astype(np.uint64))
+    km = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(n, 21))
+    params = SketchParams.mash(n, 1000, True, 21, 0)
+    sk = H.sketches_from_arrays("x", 1, 2, kc, km, params, H.FilterParams(False))
+    fp = sk.apply_filters(0, H.FilterParams(True, (None, None), 0.31, 0.1))
+    got = sk.sketch(0)
+    # oracle: strand -> err threshold -> abundance -> truncate(final_size)
+    a, ak = O.filter_strands(kc, km, 0.1)
+    cutoff = O.guess_filter_threshold(a, 0.31)
+    b, bk = O.filter_abundance(a, ak, cutoff, None)
+    assert fp.abun_filter == (cutoff, None) and fp.filter_on is True
+    assert np.array_equal(got.arrays[0], b[:1000]) and np.array_equal(got.arrays[1], bk[:1000])
+    # filtering off: untouched apart from the truncate
+    sk2 = H.sketches_from_arrays("x", 1, 2, kc, km, params, H.FilterParams(False))
+    sk2.apply_filters(0, H.FilterParams(False, (None, None), 0.31, 0.1))
+    assert np.array_equal(sk2.sketch(0).arrays[0], kc[:1000])
+    # strict: too few kmers -> the reference's error text (mod.rs:123-125)
+    sk3 = H.sketches_from_arrays("reads.fq", 1, 2, kc[:10], km[:10], SketchParams.mash(100, 100, False, 21, 0), H.FilterParams(False))
+    with pytest.raises(FinchError, match=r"reads.fq had too few kmers \(10\) to sketch"):
+        sk3.apply_filters(0, H.FilterParams(False))
+
+
+def test_sk_json_writer_format():
+    kc = kc_of([3, 1], [1, 0])
+    kc["hash"] = [12345678901234567890, 18446744073709551615]
+    km = np.frombuffer(b"ACGTA" + b"TTTTT", np.uint8).reshape(2, 5)
+    p = SketchParams.mash(2, 2, False, 5, 42)
+    sk = H.sketches_from_arrays('we"ird\\name\n', 100, 96, kc, km, p, H.FilterParams(True, (2, None), 0.25, 0.1))
+    js = sk.to_json()
+    # serialization/json.rs:64-89,141-158 field order, hashes as strings, extra_count not serialised
+    assert js == ('{"kmer":5,"alphabet":"ACGT","preserveCase":false,"canonical":true,"sketchSize":2,'
+                  '"hashType":"MurmurHash3_x64_128","hashBits":64,"hashSeed":42,"scale":null,"sketches":['
+                  '{"name":"we\\"ird\\\\name\\n","seqLength":100,"numValidKmers":96,"comment":"",'
+                  '"filters":{"strandFilter":"0.1","errFilter":"0.25","minCopies":"2"},'
+                  '"hashes":["12345678901234567890","18446744073709551615"],"kmers":["ACGTA","TTTTT"],"counts":[3,1]}]}')
+    d = json.loads(js)
+    assert d["sketches"][0]["name"] == 'we"ird\\name\n'
+    p2 = SketchParams.scaled(7, 5, 0.001, 0)
+    js2 = H.sketches_from_arrays("s", 1, 1, kc, km, p2, H.FilterParams(False)).to_json()
+    d2 = json.loads(js2)
+    assert '"scale":0.001,' in js2 and d2["sketchSize"] == 7 and d2["sketches"][0]["filters"] == {}
+    for scale, txt in [(1.0, "1.0"), (0.5, "0.5"), (1e-7, "1e-7"), (0.00123, "0.00123")]:
+        assert ('"scale":%s,' % txt) in H.sketches_from_arrays("s", 1, 1, kc, km, SketchParams.scaled(7, 5, scale, 0),
+                                                              H.FilterParams(False)).to_json()
