@@ -57,6 +57,7 @@ def main():
     import torch
     import finch_rs_amd as F
     from finch_rs_amd import sketch_schemes as S
+    from finch_rs_amd import sharding as SH
 
     if not torch.cuda.is_available() or F.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libfinch_hip has no CPU path")
@@ -97,38 +98,11 @@ def main():
         kc, km, pos = sk.to_arrays()
         tk = sk.finish()[1]
         if dist is not None:
-            # partial sketches are <= n records: ship them to rank 0 and merge on the host (O(N*n))
-            n = len(kc)
-            pad = args.n
-            buf = torch.zeros(2 + pad * (4 + (args.k + 7) // 8 + 1), dtype=torch.int64)
-            payload = np.zeros(buf.numel(), dtype=np.int64)
-            payload[0], payload[1] = n, tk
-            off = 2
-            payload[off:off + n] = kc["hash"].view(np.int64); off += pad
-            payload[off:off + n] = kc["count"].astype(np.int64); off += pad
-            payload[off:off + n] = kc["extra_count"].astype(np.int64); off += pad
-            payload[off:off + n] = pos.view(np.int64); off += pad
-            kmw = (args.k + 7) // 8
-            kmp = np.zeros((pad, kmw * 8), dtype=np.uint8)
-            kmp[:n, :args.k] = km
-            payload[off:off + pad * kmw] = kmp.view(np.int64).reshape(-1)
-            t = torch.from_numpy(payload).cuda()
-            outs = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
-            dist.gather(t, outs, dst=0)
+            # partial sketches are <= n records: ship them to rank 0 (one small fixed-size tensor per rank)
+            # and merge on the host, O(N*n) -- finch_rs_amd/sharding.py
+            merged = SH.gather_and_merge(dist, params, (kc, km, pos, tk), args.n, device="cuda")
             if rank == 0:
-                for r in range(1, world):
-                    p = outs[r].cpu().numpy()
-                    m, tkr = int(p[0]), int(p[1])
-                    o = 2
-                    hs = p[o:o + m].view(np.uint64); o += pad
-                    cs = p[o:o + m].astype(np.uint32); o += pad
-                    es = p[o:o + m].astype(np.uint32); o += pad
-                    ps = p[o:o + m].view(np.uint64); o += pad
-                    kmr = p[o:o + pad * kmw].view(np.uint8).reshape(pad, kmw * 8)[:m, :args.k]
-                    kcr = np.zeros(m, dtype=S.KC_DTYPE)
-                    kcr["hash"], kcr["count"], kcr["extra_count"] = hs, cs, es
-                    sk.merge_arrays(kcr, kmr, ps, tkr)
-                gathered = sk.to_arrays()
+                gathered = merged[:3]
         else:
             gathered = (kc, km, pos)
 

@@ -43,6 +43,9 @@ SYMBOLS = {
     "fh_copy_out": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "fh_merge": (C.c_int, [_P, _P]),
     "fh_merge_arrays": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, C.c_uint64]),
+    "fh_merge_partials": (C.c_int, [C.c_uint32, C.c_uint64, C.c_double, C.c_uint32,
+                                    C.c_uint64, _P, _P, _P, _P, _P, C.c_uint64, _P, _P, _P, _P, _P,
+                                    _U64P, _P, _P, _P, _P, _P]),
     "fh_set_profiling": (C.c_int, [_P, C.c_int]),
     "fh_kernel_time": (C.c_int, [_P, C.POINTER(C.c_double), _U64P, _U64P]),
     "fh_device_alloc": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(_P)]),

@@ -384,16 +384,48 @@ int ensure_out(fh_sketcher *s, uint32_t n) {
     return FH_OK;
 }
 
-void select_final(const fh_sketcher *s, std::vector<ResultRec> &v) {
+uint32_t sat_add(uint32_t a, uint32_t b);
+
+void select_final_p(uint32_t kind, uint64_t size, uint64_t max_hash, std::vector<ResultRec> &v) {
     // v ascending by hash and distinct.  mash.rs:57-60 / scaled.rs:41-58 net effect.
-    if (s->p.kind == FH_KIND_MASH) {
-        if (v.size() > s->p.size) v.resize(s->p.size);
+    if (kind == FH_KIND_MASH) {
+        if (v.size() > size) v.resize(size);
     } else {
         size_t n_le = 0;
-        while (n_le < v.size() && v[n_le].hash <= s->max_hash) ++n_le;
-        size_t keep = std::max<size_t>(n_le, std::min<size_t>(v.size(), s->p.size));
+        while (n_le < v.size() && v[n_le].hash <= max_hash) ++n_le;
+        size_t keep = std::max<size_t>(n_le, std::min<size_t>(v.size(), size));
         v.resize(keep);
     }
+}
+
+void select_final(const fh_sketcher *s, std::vector<ResultRec> &v) { select_final_p(s->p.kind, s->p.size, s->max_hash, v); }
+
+// union of two ascending partial sketches: counts summed (saturating, mash.rs:46-49), k-mer of the smaller
+// first position (mash.rs:52-56 keeps the first occurrence's bytes)
+int merge_sorted(const std::vector<ResultRec> &a, const std::vector<ResultRec> &b, std::vector<ResultRec> &out) {
+    out.clear();
+    out.reserve(a.size() + b.size());
+    size_t i = 0, j = 0;
+    while (i < a.size() || j < b.size()) {
+        if (i > 0 && i < a.size() && a[i].hash <= a[i - 1].hash) return fail(FH_ERR_INVALID, "merge: input not ascending");
+        if (j > 0 && j < b.size() && b[j].hash <= b[j - 1].hash) return fail(FH_ERR_INVALID, "merge: input not ascending");
+        if (j >= b.size() || (i < a.size() && a[i].hash < b[j].hash)) out.push_back(a[i++]);
+        else if (i >= a.size() || b[j].hash < a[i].hash) out.push_back(b[j++]);
+        else {
+            ResultRec r = a[i];
+            const ResultRec &d = b[j];
+            r.count = sat_add(r.count, d.count);
+            r.extra = sat_add(r.extra, d.extra);
+            if (d.pos < r.pos) {
+                r.pos = d.pos;
+                r.kmer = d.kmer;
+            }
+            out.push_back(r);
+            ++i;
+            ++j;
+        }
+    }
+    return FH_OK;
 }
 
 void kmer_ascii(uint64_t m, int k, uint8_t *out) {
@@ -733,32 +765,40 @@ int fh_merge_arrays(fh_sketcher *dst, uint64_t n, const uint64_t *hashes, const 
         return fail(FH_ERR_INVALID, "null argument");
     if (!dst->finished) return fail(FH_ERR_STATE, "fh_merge: dst not finished");
     const int k = (int)dst->p.k;
-    std::vector<ResultRec> out;
-    out.reserve(dst->res.size() + n);
-    size_t i = 0;
-    uint64_t j = 0;
-    while (i < dst->res.size() || j < n) {
-        if (j > 0 && j < n && hashes[j] <= hashes[j - 1]) return fail(FH_ERR_INVALID, "fh_merge: src not ascending");
-        if (j >= n || (i < dst->res.size() && dst->res[i].hash < hashes[j])) {
-            out.push_back(dst->res[i++]);
-        } else {
-            ResultRec r{hashes[j], counts[j], extra_counts[j], ascii_kmer(kmers + j * (size_t)k, k), first_pos[j]};
-            if (i < dst->res.size() && dst->res[i].hash == r.hash) {
-                const ResultRec &d = dst->res[i++];
-                r.count = sat_add(r.count, d.count);
-                r.extra = sat_add(r.extra, d.extra);
-                if (d.pos < r.pos) {
-                    r.pos = d.pos;
-                    r.kmer = d.kmer;
-                }
-            }
-            out.push_back(r);
-            ++j;
-        }
-    }
+    std::vector<ResultRec> src(n), out;
+    for (uint64_t j = 0; j < n; ++j)
+        src[j] = ResultRec{hashes[j], counts[j], extra_counts[j], ascii_kmer(kmers + j * (size_t)k, k), first_pos[j]};
+    if (int rc = merge_sorted(dst->res, src, out)) return rc;
     select_final(dst, out);
     dst->res.swap(out);
     dst->total_kmers += total_kmers;
+    return FH_OK;
+}
+
+int fh_merge_partials(uint32_t kind, uint64_t size, double scale, uint32_t k, uint64_t nA, const uint64_t *hashesA,
+                      const uint32_t *countsA, const uint32_t *extraA, const uint8_t *kmersA, const uint64_t *posA,
+                      uint64_t nB, const uint64_t *hashesB, const uint32_t *countsB, const uint32_t *extraB,
+                      const uint8_t *kmersB, const uint64_t *posB, uint64_t *n_out, uint64_t *out_hashes,
+                      uint32_t *out_counts, uint32_t *out_extra, uint8_t *out_kmers, uint64_t *out_pos) {
+    if (!n_out || k < 1 || k > 32 || (kind != FH_KIND_MASH && kind != FH_KIND_SCALED))
+        return fail(FH_ERR_INVALID, "bad argument");
+    if ((nA && (!hashesA || !countsA || !extraA || !kmersA || !posA)) || (nB && (!hashesB || !countsB || !extraB || !kmersB || !posB)))
+        return fail(FH_ERR_INVALID, "null argument");
+    std::vector<ResultRec> a(nA), b(nB), out;
+    for (uint64_t j = 0; j < nA; ++j)
+        a[j] = ResultRec{hashesA[j], countsA[j], extraA[j], ascii_kmer(kmersA + j * (size_t)k, (int)k), posA[j]};
+    for (uint64_t j = 0; j < nB; ++j)
+        b[j] = ResultRec{hashesB[j], countsB[j], extraB[j], ascii_kmer(kmersB + j * (size_t)k, (int)k), posB[j]};
+    if (int rc = merge_sorted(a, b, out)) return rc;
+    select_final_p(kind, size, kind == FH_KIND_SCALED ? scaled_max_hash(scale) : 0, out);
+    *n_out = out.size();
+    for (size_t j = 0; j < out.size(); ++j) {
+        if (out_hashes) out_hashes[j] = out[j].hash;
+        if (out_counts) out_counts[j] = out[j].count;
+        if (out_extra) out_extra[j] = out[j].extra;
+        if (out_kmers) kmer_ascii(out[j].kmer, (int)k, out_kmers + j * (size_t)k);
+        if (out_pos) out_pos[j] = out[j].pos;
+    }
     return FH_OK;
 }
 

@@ -113,6 +113,15 @@ int fh_merge_arrays(fh_sketcher *dst, uint64_t n, const uint64_t *hashes, const 
                     const uint32_t *extra_counts, const uint8_t *kmers, const uint64_t *first_pos,
                     uint64_t total_kmers);
 
+/* Handle-free form of the same merge (pure host code, no device needed): merges partial sketch B into
+ * partial sketch A.  out_* must hold nA+nB records; *n_out receives the merged count.  `scale` is only
+ * read for FH_KIND_SCALED. */
+int fh_merge_partials(uint32_t kind, uint64_t size, double scale, uint32_t k, uint64_t nA, const uint64_t *hashesA,
+                      const uint32_t *countsA, const uint32_t *extraA, const uint8_t *kmersA, const uint64_t *posA,
+                      uint64_t nB, const uint64_t *hashesB, const uint32_t *countsB, const uint32_t *extraB,
+                      const uint8_t *kmersB, const uint64_t *posB, uint64_t *n_out, uint64_t *out_hashes,
+                      uint32_t *out_counts, uint32_t *out_extra, uint8_t *out_kmers, uint64_t *out_pos);
+
 /* --- measurement support (bench.py) --- */
 /* when enabled, every sketch-kernel launch is bracketed by HIP events on the handle's stream */
 int fh_set_profiling(fh_sketcher *s, int enable);

@@ -1,0 +1,103 @@
+"""N>1 path on CPU: two processes over gloo shard one read set by read blocks, gather their partial
+sketches to rank 0 and merge on the host (finch_rs_amd/sharding.py + fh_merge_partials).  There is no
+GPU here, so each rank's sketcher is the oracle standing in for the device engine; what is under test
+is the sharding arithmetic, the wire format and the merge, against the oracle run on the whole input."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["FH_ROOT"])
+from finch_rs_amd import sharding as SH
+from finch_rs_amd import sketch_schemes as S
+from oracle import oracle as O
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+kind = os.environ["FH_KIND"]
+n, k, nr, rl, seed = 300, 21, 6001, 100, 5
+params = S.SketchParams.mash(n, n, True, k, 0) if kind == "mash" else S.SketchParams.scaled(n, k, 0.002, 0)
+g = S.synth_genome_host(50000, seed)
+lo, hi = SH.shard_bounds(nr, rank, world)
+reads = S.synth_reads_host(g, lo, hi - lo, rl, seed, 10000, 500)
+o = O.OracleSketcher(O.MASH if kind == "mash" else O.SCALED, n, k, 0, 0.002)
+o.process_packed(reads, 0)
+kc, km = o.to_vec()
+# the oracle has no positions: any value consistent with stream order works for distinct k-mers
+pos = np.full(len(kc), lo * (rl + 1), dtype=np.uint64)
+pad = 4096
+merged = SH.gather_and_merge(dist, params, (kc, km, pos, o.total_bases_and_kmers()[1]), pad)
+if rank == 0:
+    whole = S.synth_reads_host(g, 0, nr, rl, seed, 10000, 500)
+    w = O.OracleSketcher(O.MASH if kind == "mash" else O.SCALED, n, k, 0, 0.002)
+    w.process_packed(whole, 0)
+    wkc, wkm = w.to_vec()
+    assert np.array_equal(merged[0], wkc), "hash/count mismatch"
+    assert np.array_equal(merged[1], wkm), "kmer mismatch"
+    assert merged[3] == w.total_bases_and_kmers()[1]
+    print("MERGE_OK", len(wkc))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("kind", ["mash", "scaled"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_shard_gather_merge(kind, world):
+    import __graft_entry__ as G
+    G.build()
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FH_ROOT=ROOT, FH_KIND=kind)
+        procs.append(subprocess.Popen([sys.executable, "-c", CHILD], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert "MERGE_OK" in outs[0]
+
+
+def test_shard_bounds_cover_everything():
+    from finch_rs_amd import sharding as SH
+    for n in [0, 1, 7, 8, 333333334]:
+        for w in [1, 2, 3, 8]:
+            b = [SH.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def test_pack_unpack_roundtrip():
+    from finch_rs_amd import sharding as SH
+    from finch_rs_amd.sketch_schemes import KC_DTYPE
+    rng = np.random.default_rng(1)
+    for k in [5, 21, 31, 32]:
+        n = 37
+        kc = np.zeros(n, dtype=KC_DTYPE)
+        kc["hash"] = np.sort(rng.integers(0, 2**63, n).astype(np.uint64)) * np.uint64(2) + np.uint64(1)
+        kc["count"] = rng.integers(1, 2**32 - 1, n)
+        kc["extra_count"] = rng.integers(0, 2**31, n)
+        km = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(n, k))
+        pos = rng.integers(0, 2**62, n).astype(np.uint64)
+        p = SH.pack_partial(kc, km, pos, 123456789012, 64, k)
+        kc2, km2, pos2, tk = SH.unpack_partial(p, 64, k)
+        assert np.array_equal(kc, kc2) and np.array_equal(km, km2) and np.array_equal(pos, pos2) and tk == 123456789012
