@@ -216,47 +216,189 @@ FH_HD u64 murmur_h1_lut(u64 cm, u64 seed, const u64 *T1, const u64 *T2, const u6
 }
 
 // ---- rolling window state of one lane ----
+// Fm  : m-form of the forward window (bottom aligned, masked)
+// Rcm : m-form of the reverse complement of the window == l-form of the complemented codes, which rolls
+//       by (x >> 2) | (cbar << 2(K-1)) with no mask (the oldest digit falls off the bottom)
 template <int K>
 struct Roll {
-    u64 Fm; // m-form of the forward window
-    u64 F;  // l-form of the forward window
-    u32 run; // number of consecutive good bases ending at the newest base
+    u64 Fm;
+    u64 Rcm;
 
-    // state after the first K-1 bases of the lane segment; s64 = l-form code stream (bases 0..31),
-    // good = good bits of bases 0..31
-    FH_HDM void init(u64 s64, u32 good) {
+    // state after the first K-1 bases of the lane segment; s64 = l-form code stream of bases 0..31
+    FH_HDM void init(u64 s64) {
         if (K == 1) {
-            Fm = 0; F = 0; run = 0;
+            Fm = 0;
+            Rcm = 0;
             return;
         }
         const u64 mask = kmask(K);
-        F = (s64 << 2) & mask;
-        // keep bases 0..K-2, pair-reverse, align so that base K-2 is digit 0
-        u64 low = (K - 1 >= 32) ? s64 : (s64 & ((1ULL << (2 * (K - 1))) - 1ULL));
+        Rcm = ((~s64) << 2) & mask;
+        const u64 low = s64 & ((1ULL << (2 * (K - 1))) - 1ULL); // K-1 <= 31
         Fm = pairrev64(low) >> (64 - 2 * (K - 1));
-        u32 bad = ~good & (u32)((1ULL << (K - 1)) - 1ULL);
-        if (bad == 0) run = K - 1;
-        else {
-            const int msb = 31 - __builtin_clz(bad);
-            run = (u32)(K - 2 - msb);
-        }
     }
-    // roll in one base (code c, good bit g)
-    FH_HDM void push(u32 c, u32 g) {
+    // roll in one base (code c)
+    FH_HDM void push(u32 c) {
         const u64 mask = kmask(K);
         Fm = ((Fm << 2) | c) & mask;
-        F = (F >> 2) | ((u64)c << (2 * (K - 1)));
-        run = (run + 1u) * g;
+        Rcm = (Rcm >> 2) | ((u64)(c ^ 3u) << (2 * (K - 1)));
     }
-    FH_HDM bool valid() const { return run >= (u32)K; }
     // canonical m-form and strand (true = reverse complement retained), canonical_kmers semantics:
     // (fwd < rc) ? fwd : rc   -- ties (even-k palindromes) report rc
     FH_HDM u64 canonical(bool &is_rc) const {
-        const u64 rcm = ~F & kmask(K);
-        is_rc = !(Fm < rcm);
-        return is_rc ? rcm : Fm;
+        is_rc = !(Fm < Rcm);
+        return is_rc ? Rcm : Fm;
     }
 };
+
+// bit j of the result: the K-base window starting at base j lies entirely in good bases (g64 bit b = base
+// b is one of ACGT).  Log-doubling AND of shifted masks; runs once per lane per tile.
+template <int K>
+FH_HD u32 window_valid_mask(u64 g64) {
+    u64 A[6]; // A[p][j] = AND of 2^p consecutive good bits starting at j
+    A[0] = g64;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int p = 1; p < 6; ++p) A[p] = A[p - 1] & (A[p - 1] >> (1 << (p - 1)));
+    u64 W = ~0ULL;
+    int off = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int p = 5; p >= 0; --p) {
+        if (K & (1 << p)) {
+            W &= (A[p] >> off);
+            off += (1 << p);
+        }
+    }
+    return (u32)W;
+}
+
+// ---- 32-bit split lookup tables for the LUT murmur (device layout: u32 T[4][256] + partial tables) ----
+// TQ[0] = lo(ascii4*c1), TQ[1] = hi(ascii4*c1), TQ[2] = lo(ascii4*c2), TQ[3] = hi(ascii4*c2)
+// TP[0] = lo(ascii_nb*cp), TP[1] = hi(ascii_nb*cp)  (64 entries each, nb = K & 3)
+struct U64H {
+    u32 lo, hi;
+};
+
+FH_HD U64H make64(u64 x) { return U64H{(u32)x, (u32)(x >> 32)}; }
+FH_HD u64 join64(U64H x) { return ((u64)x.hi << 32) | x.lo; }
+
+FH_HD u32 alignbit_b32(u32 hi, u32 lo, u32 sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (u32)(((((u64)hi) << 32) | lo) >> (sh & 31));
+#endif
+}
+
+template <int R>
+FH_HD U64H rotl64h(U64H x) {
+    if (R == 32) return U64H{x.hi, x.lo};
+    if (R < 32) return U64H{alignbit_b32(x.lo, x.hi, 32 - R), alignbit_b32(x.hi, x.lo, 32 - R)};
+    return U64H{alignbit_b32(x.hi, x.lo, 64 - R), alignbit_b32(x.lo, x.hi, 64 - R)};
+}
+
+// 64-bit add / (x*5 + c) on the device as single v_lshl_add_u64 instructions
+FH_HD u64 add64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 r;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a + b;
+#endif
+}
+
+FH_HD u64 mul5_add(u64 h, u64 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 t, r;
+    asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(t) : "v"(h));
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(t), "s"(c));
+    return r;
+#else
+    return h * 5 + c;
+#endif
+}
+
+FH_HD u64 mul64c(U64H a, u64 C) {
+    const u32 cl = (u32)C, ch = (u32)(C >> 32);
+    u64 p = (u64)a.lo * cl;
+    const u32 cross = a.lo * ch + a.hi * cl;
+    return p + ((u64)cross << 32);
+}
+
+// murmurhash3_x64_128(ascii(canonical k-mer), seed).0 from the m-form canonical word, 32-bit split tables.
+// SEED0: compile-time knowledge that seed == 0 (the default; drops three 64-bit ops).
+template <int K, bool SEED0>
+FH_HD u64 murmur_h1_fast(u64 cm, u64 seed, const u32 *TQ, const u32 *TP) {
+    constexpr int NB = K / 16, TAIL = K & 15, NG = (K + 3) / 4;
+    const u32 cml = (u32)cm, cmh = (u32)(cm >> 32);
+    u32 wl[2 * NB + 2], wh[2 * NB + 2];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 2 * NB + 2; ++i) wl[i] = wh[i] = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int g = 0; g < NG; ++g) {
+        const GroupGeom gg = group_geom(K, g);
+        // byte offset (index * 4) of the group in a 32-bit table
+        const int sh = gg.shift - 2; // want ((cm >> shift) & m) << 2
+        const u32 fm = ((1u << (2 * gg.nb)) - 1u) << 2;
+        u32 idx4;
+        if (sh >= 32) idx4 = (cmh >> (sh - 32)) & fm;
+        else if (sh >= 0 && sh + 2 * gg.nb + 2 <= 32) idx4 = (cml >> sh) & fm;
+        else if (sh >= 0) idx4 = alignbit_b32(cmh, cml, (u32)sh) & fm;
+        else idx4 = (cml << (-sh)) & fm;
+        const u32 *T = (gg.nb == 4) ? (TQ + (gg.is_k2 ? 512 : 0)) : TP;
+        const u32 hi_off = (gg.nb == 4) ? 256u : 64u;
+        const u32 plo = *(const u32 *)((const char *)T + idx4);
+        if (gg.hi) {
+            wh[gg.word] += plo;
+        } else {
+            const u32 phi = *(const u32 *)((const char *)(T + hi_off) + idx4);
+            wl[gg.word] += plo; // at most one lo-half group per word: no carry
+            wh[gg.word] += phi;
+        }
+    }
+    u64 h1 = seed, h2 = seed;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int b = 0; b < NB; ++b) {
+        u64 k1 = mul64c(rotl64h<31>(U64H{wl[2 * b], wh[2 * b]}), MURMUR_C2);
+        if (SEED0 && b == 0) h1 = k1;
+        else h1 ^= k1;
+        h1 = join64(rotl64h<27>(make64(h1)));
+        if (!(SEED0 && b == 0)) h1 = add64(h1, h2);
+        h1 = mul5_add(h1, 0x52dce729ULL);
+        u64 k2 = mul64c(rotl64h<33>(U64H{wl[2 * b + 1], wh[2 * b + 1]}), MURMUR_C1);
+        if (SEED0 && b == 0) h2 = k2;
+        else h2 ^= k2;
+        h2 = join64(rotl64h<31>(make64(h2)));
+        h2 = add64(h2, h1);
+        h2 = mul5_add(h2, 0x38495ab5ULL);
+    }
+    if (TAIL > 8) {
+        u64 k2 = mul64c(rotl64h<33>(U64H{wl[2 * NB + 1], wh[2 * NB + 1]}), MURMUR_C1);
+        if (SEED0 && NB == 0) h2 = k2;
+        else h2 ^= k2;
+    }
+    if (TAIL > 0) {
+        u64 k1 = mul64c(rotl64h<31>(U64H{wl[2 * NB], wh[2 * NB]}), MURMUR_C2);
+        if (SEED0 && NB == 0) h1 = k1;
+        else h1 ^= k1;
+    }
+    h1 ^= (u64)K;
+    h2 ^= (u64)K;
+    h1 = add64(h1, h2);
+    h2 = add64(h2, h1);
+    h1 = fmix64(h1);
+    h2 = fmix64(h2);
+    return add64(h1, h2);
+}
 
 // ---- synthetic data generator : splitmix64 counter RNG ----
 FH_HD u64 splitmix64(u64 x) {

@@ -27,7 +27,13 @@
 #error "compile with -DFH_PART=<0..FH_NPARTS-1>"
 #endif
 
+#ifndef FH_UNROLL
+#define FH_UNROLL 32
+#endif
+
 namespace fh {
+
+constexpr int UNROLL_J = FH_UNROLL;
 
 // ------------------------------------------------------------------------------------------------
 // rare path: one k-mer occurrence with hash <= tau
@@ -123,19 +129,27 @@ __device__ __forceinline__ void classify_tile(const SketchArgs &a, u64 tile, int
 // ------------------------------------------------------------------------------------------------
 // K2
 // ------------------------------------------------------------------------------------------------
-template <int K, bool MASKED>
+template <int K, bool MASKED, bool SEED0>
 __global__ __launch_bounds__(256) void k2_sketch(const SketchArgs a) {
-    __shared__ __attribute__((aligned(16))) u64 sT1[256];
-    __shared__ __attribute__((aligned(16))) u64 sT2[256];
-    __shared__ __attribute__((aligned(16))) u64 sTP[64];
+    __shared__ __attribute__((aligned(16))) u32 sTQ[1024];  // lo/hi(ascii4*c1), lo/hi(ascii4*c2)
+    __shared__ __attribute__((aligned(16))) u32 sTP[128];   // lo/hi(partial group * its constant)
     __shared__ __attribute__((aligned(16))) u32 sCodes[WAVES_PER_BLOCK][256];
     __shared__ __attribute__((aligned(16))) u32 sGood[WAVES_PER_BLOCK][128];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    sT1[tid] = lut_entry((u32)tid, 4, MURMUR_C1);
-    sT2[tid] = lut_entry((u32)tid, 4, MURMUR_C2);
-    constexpr int PNB = partial_nb(K);
-    if (tid < 64) sTP[tid] = (PNB != 0 && tid < (1 << (2 * PNB))) ? lut_entry((u32)tid, PNB, partial_const(K)) : 0ull;
+    {
+        const u64 e1 = lut_entry((u32)tid, 4, MURMUR_C1), e2 = lut_entry((u32)tid, 4, MURMUR_C2);
+        sTQ[tid] = (u32)e1;
+        sTQ[256 + tid] = (u32)(e1 >> 32);
+        sTQ[512 + tid] = (u32)e2;
+        sTQ[768 + tid] = (u32)(e2 >> 32);
+        constexpr int PNB = partial_nb(K);
+        if (tid < 64) {
+            const u64 ep = (PNB != 0 && tid < (1 << (2 * PNB))) ? lut_entry((u32)tid, PNB, partial_const(K)) : 0ull;
+            sTP[tid] = (u32)ep;
+            sTP[64 + tid] = (u32)(ep >> 32);
+        }
+    }
     __syncthreads();
 
     const u64 tau = __hip_atomic_load(&a.ctl->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(256) void k2_sketch(const SketchArgs a) {
 
     u32 *codes_ring = sCodes[wave];
     u32 *good_ring = sGood[wave];
-    u32 nvalid = 0;
+    u32 nvalid = 0; // per lane
 
     classify_tile(a, t0, lane, codes_ring, good_ring);
     for (u64 t = t0; t < t1; ++t) {
@@ -166,51 +180,43 @@ __global__ __launch_bounds__(256) void k2_sketch(const SketchArgs a) {
         const u64 chi = (u64)nbr.x | ((u64)nbr.y << 32);
         const u64 g64 = (u64)g_own | ((u64)g_nbr << 32);
 
-        Roll<K> roll;
-        roll.init(clo, g_own);
-
-        const u64 lane_pos0 = a.p_begin + t * (u64)TILE_POS + (u64)lane * LANE_POS; // first start position
+        // which of the lane's 32 start positions carry a k-mer: all K bases good and inside [p_begin, p_end)
+        const u64 lane_pos0 = a.p_begin + t * (u64)TILE_POS + (u64)lane * LANE_POS;
         const u32 limit = (a.p_end > lane_pos0) ? (u32)((a.p_end - lane_pos0) < 32 ? (a.p_end - lane_pos0) : 32) : 0u;
+        const u32 W = window_valid_mask<K>(g64) & (limit >= 32u ? 0xFFFFFFFFu : ((1u << limit) - 1u));
+        nvalid += (u32)__popc(W);
 
-#ifndef FH_UNROLL
-#define FH_UNROLL 32
-#endif
-#pragma unroll FH_UNROLL
+        Roll<K> roll;
+        roll.init(clo);
+
+#pragma unroll(UNROLL_J)
         for (int j = 0; j < LANE_POS; ++j) {
             const int bi = j + K - 1;
             const u32 c = (bi < 32) ? ((u32)(clo >> (2 * bi)) & 3u) : ((u32)(chi >> (2 * (bi - 32))) & 3u);
-            const u32 g = (u32)(g64 >> bi) & 1u;
-            roll.push(c, g);
-            const bool ok = roll.valid() && ((u32)j < limit);
+            roll.push(c);
             bool is_rc;
-#if defined(FH_ABL_NOWINDOW)
-            is_rc = false;
-            const u64 cm = clo + (u64)j * 0x12345ull + g64; // ablation: no rolling / canonical selection
-#else
             const u64 cm = roll.canonical(is_rc);
-#endif
-#if defined(FH_ABL_NOHASH)
-            u64 h = cm * 0x9E3779B97F4A7C15ull; // ablation: one multiply instead of murmur3
-#elif defined(FH_ABL_NOLDS)
-            u64 h = murmur_h1_lut<K>(cm, a.seed, (const u64 *)nullptr, (const u64 *)nullptr, (const u64 *)nullptr);
-#else
-            u64 h = murmur_h1_lut<K>(cm, a.seed, sT1, sT2, sTP);
-#endif
+            u64 h = murmur_h1_fast<K, SEED0>(cm, a.seed, sTQ, sTP);
             if (MASKED) h &= a.hash_mask; // test hook only
-            nvalid += (u32)__popcll(__ballot(ok));
-            if (ok && h <= tau)
-                upsert(a.table, a.live, a.ctl, a.clog, a.cap, a.live_cap, a.clog_cap, h, cm,
-                       a.base_pos + lane_pos0 + (u64)j, is_rc ? 1u : 0u);
+            // windows that carry no k-mer hash garbage; they are rejected on the (rare) admit path only
+            if (__builtin_expect(h <= tau, 0)) {
+                if ((W >> j) & 1u)
+                    upsert(a.table, a.live, a.ctl, a.clog, a.cap, a.live_cap, a.clog_cap, h, cm,
+                           a.base_pos + lane_pos0 + (u64)j, is_rc ? 1u : 0u);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
+    // total_kmers (mash.rs:35): one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_xor(nvalid, off);
     if (lane == 0 && nvalid) atomicAdd((unsigned long long *)&a.ctl->total_kmers, (unsigned long long)nvalid);
 }
 
 template <int K>
 static hipError_t launch_k2_t(const SketchArgs &a, int blocks, hipStream_t st) {
-    if (a.hash_mask == ~0ull) hipLaunchKernelGGL((k2_sketch<K, false>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k2_sketch<K, true>), dim3(blocks), dim3(256), 0, st, a);
+    if (a.hash_mask != ~0ull) hipLaunchKernelGGL((k2_sketch<K, true, false>), dim3(blocks), dim3(256), 0, st, a);
+    else if (a.seed == 0) hipLaunchKernelGGL((k2_sketch<K, false, true>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k2_sketch<K, false, false>), dim3(blocks), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -17,13 +17,19 @@ static int run(const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hashes
     std::vector<uint8_t> buf(((len + 31) / 32) * 32 + 64, 0);
     memcpy(buf.data(), seq, len);
     std::vector<u64> T1(256), T2(256), TP(64, 0);
+    std::vector<u32> TQ(1024), TP32(128, 0);
     for (u32 q = 0; q < 256; ++q) {
         T1[q] = lut_entry(q, 4, MURMUR_C1);
         T2[q] = lut_entry(q, 4, MURMUR_C2);
+        TQ[q] = (u32)T1[q]; TQ[256 + q] = (u32)(T1[q] >> 32);
+        TQ[512 + q] = (u32)T2[q]; TQ[768 + q] = (u32)(T2[q] >> 32);
     }
     const int pnb = partial_nb(K);
     for (u32 q = 0; q < (1u << (2 * pnb)); ++q)
-        if (pnb) TP[q] = lut_entry(q, pnb, partial_const(K));
+        if (pnb) {
+            TP[q] = lut_entry(q, pnb, partial_const(K));
+            TP32[q] = (u32)TP[q]; TP32[64 + q] = (u32)(TP[q] >> 32);
+        }
     for (uint64_t s = 0; s < len; s += 32) {
         u32 cw[4], gw[4];
         for (int c = 0; c < 4; ++c) {
@@ -34,20 +40,24 @@ static int run(const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hashes
         const u64 clo = (u64)cw[0] | ((u64)cw[1] << 32), chi = (u64)cw[2] | ((u64)cw[3] << 32);
         const u64 g64 = (u64)gw[0] | ((u64)gw[1] << 16) | ((u64)gw[2] << 32) | ((u64)gw[3] << 48);
         Roll<K> roll;
-        roll.init(clo, (u32)g64);
+        roll.init(clo);
+        const u32 W = window_valid_mask<K>(g64 & 0x7FFFFFFFFFFFFFFFull);
         for (int j = 0; j < 32; ++j) {
             const int bi = j + K - 1;
             const u32 c = (u32)(((bi < 32) ? (clo >> (2 * bi)) : (chi >> (2 * (bi - 32)))) & 3u);
-            const u32 g = (u32)((g64 >> bi) & 1u);
-            roll.push(c, g);
+            roll.push(c);
             const uint64_t p = s + j;
             if (p >= len) break;
             bool rc;
             const u64 cm = roll.canonical(rc);
-            valid[p] = roll.valid() ? 1 : 0;
+            valid[p] = (W >> j) & 1u;
             isrc[p] = rc ? 1 : 0;
             canon[p] = cm;
-            hashes[p] = murmur_h1_lut<K>(cm, seed, T1.data(), T2.data(), TP.data());
+            const u64 h_ref = murmur_h1_lut<K>(cm, seed, T1.data(), T2.data(), TP.data());
+            const u64 h_fast = murmur_h1_fast<K, false>(cm, seed, TQ.data(), TP32.data());
+            if (h_fast != h_ref) return -2;
+            if (seed == 0 && murmur_h1_fast<K, true>(cm, 0, TQ.data(), TP32.data()) != h_ref) return -3;
+            hashes[p] = h_fast;
         }
     }
     return 0;
