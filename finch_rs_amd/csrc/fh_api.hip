@@ -42,7 +42,7 @@ int fail(int code, const char *fmt, ...) {
         if (_e != hipSuccess) return fail(FH_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
-constexpr uint64_t DEFAULT_MAX_LAUNCH = 64ull << 20; // k-mer start positions per launch
+constexpr uint64_t DEFAULT_MAX_LAUNCH = 256ull * 32 * TILE_POS; // k-mer start positions in flight (8192 waves)
 constexpr uint64_t FIRST_LAUNCH = 4096;
 constexpr uint64_t SMALL_N_MAX = 3000; // largest kmers_to_sketch served by the in-LDS selection alone
 constexpr uint32_t CLOG_CAP = 65536;
@@ -91,11 +91,19 @@ struct fh_sketcher {
     size_t sort_tmp_bytes = 0;
     uint32_t big_cap = 0;
     uint64_t n_big_prunes = 0;
-    // lagged status ring for open-loop launches
-    Ctl *h_ring[2] = {nullptr, nullptr};
-    hipEvent_t ring_ev[2] = {nullptr, nullptr};
-    bool ring_used[2] = {false, false};
-    uint64_t launch_idx = 0;
+    // the range of k-mer start positions currently on the device (one at a time); completion is checked
+    // lazily (drain) so that pushes stay asynchronous
+    struct Pending {
+        bool active = false;
+        const uint8_t *seq = nullptr;
+        uint64_t len = 0, base_pos = 0, p_begin = 0, p_end = 0;
+        uint32_t tiles_total = 0, n_chunks = 0, n_left_in = 0;
+        int left_cur = 0;
+    } pend;
+    uint32_t *left_buf[2] = {nullptr, nullptr}; // leftover tile ranges of a stopped launch (pairs)
+    uint64_t max_waves = 0;
+    uint64_t max_range = 0; // test knob: cap on positions per range
+    uint64_t n_launches = 0, n_relaunches = 0;
     // staging
     uint8_t *h_stage[N_STAGE] = {nullptr, nullptr};
     uint8_t *d_stage[N_STAGE] = {nullptr, nullptr};
@@ -157,8 +165,7 @@ int init_state(fh_sketcher *s) {
     s->open_loop = false;
     s->last_tau = initial_tau(s);
     s->last_live = 0;
-    s->ring_used[0] = s->ring_used[1] = false;
-    s->launch_idx = 0;
+    s->pend.active = false;
     s->carry_len = 0;
     s->live_target = s->big_mode ? std::max<uint64_t>(4 * s->p.size, 1ull << 16) : (uint64_t)SMALL_MAX;
     s->finished = false;
@@ -178,13 +185,28 @@ double admit_rate(uint64_t tau) { return tau == EMPTY64 ? 1.0 : ((double)tau + 1
 // per position, so its size is chosen from the threshold read back after the previous launch such that
 // the live set stays inside what the in-LDS prune can sort.  tau only ever decreases, so once a
 // maximum-size launch is safe it stays safe and launches go open-loop (no host feedback).
-uint64_t next_launch_size(const fh_sketcher *s) {
-    if (s->open_loop) return s->max_launch;
-    const double room = (double)s->live_target - (double)std::min<uint64_t>(s->last_live, s->live_target);
-    double P = 0.5 * room / admit_rate(s->last_tau);
-    if (P > (double)s->max_launch) P = (double)s->max_launch;
-    uint64_t Pi = ((uint64_t)P / TILE_POS) * TILE_POS;
-    return std::max<uint64_t>(Pi, TILE_POS);
+uint32_t soft_limit_of(const fh_sketcher *s) {
+    // stop pulling work when the live set reaches this; the table holds this + everything in flight
+    if (s->big_mode) return (uint32_t)std::min<uint64_t>(s->live_target, 0xFFFFFFF0ull);
+    return (uint32_t)(SMALL_MAX - 1024);
+}
+
+// Warm-up is closed-loop: while the admit threshold is loose, a range may insert up to one new hash
+// per position, so its size is chosen from the threshold read back after the previous range such that
+// the live set stays small.  Once (positions in flight x admit rate) is small, one launch takes the
+// whole remaining input: waves stop by themselves if the table ever nears its guarded size.
+uint64_t next_range_size(const fh_sketcher *s, uint64_t remaining) {
+    uint64_t P;
+    if (s->open_loop) {
+        P = remaining;
+    } else {
+        const double room = (double)s->live_target - (double)std::min<uint64_t>(s->last_live, s->live_target);
+        double p = 0.5 * room / admit_rate(s->last_tau);
+        P = p >= 1e18 ? remaining : (uint64_t)p;
+    }
+    if (s->max_range) P = std::min<uint64_t>(P, s->max_range);
+    P = std::max<uint64_t>((P / TILE_POS) * TILE_POS, TILE_POS);
+    return std::min<uint64_t>(P, ((remaining + TILE_POS - 1) / TILE_POS) * TILE_POS);
 }
 
 int check_ctl(fh_sketcher *s);
@@ -201,93 +223,127 @@ int collect_profile(fh_sketcher *s) {
     return FH_OK;
 }
 
+// one launch of the persistent sketch kernel over the pending range's queue (+ the in-stream prune)
+int launch_pending(fh_sketcher *s) {
+    fh_sketcher::Pending &r = s->pend;
+    SketchArgs a{};
+    a.seq = r.seq;
+    a.len_total = r.len;
+    a.p_begin = r.p_begin;
+    a.p_end = r.p_end;
+    a.base_pos = r.base_pos;
+    a.seed = s->p.seed;
+    a.hash_mask = s->p.hash_mask ? s->p.hash_mask : ~0ull;
+    a.ctl = s->ctl;
+    a.tiles_total = r.tiles_total;
+    a.n_chunks = r.n_chunks;
+    a.soft_limit = soft_limit_of(s);
+    // a range no longer than the table's slack cannot overflow it anyway: no per-wave budget (warm-up ranges)
+    a.wave_budget = (r.p_end - r.p_begin <= (uint64_t)s->live_cap - std::min<uint64_t>(s->live_cap, s->live_target))
+                        ? 0xFFFFFFFFu
+                        : (uint32_t)WAVE_BUDGET;
+    a.n_left_in = r.n_left_in;
+    a.left_in = s->left_buf[r.left_cur];
+    a.left_out = s->left_buf[r.left_cur ^ 1];
+    const uint64_t work_units = (uint64_t)r.n_chunks + r.n_left_in;
+    const uint64_t waves = std::max<uint64_t>(1, std::min<uint64_t>(work_units, s->max_waves));
+    const int blocks = (int)((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (s->profiling) {
+        if (s->prof_used == s->prof_events.size()) {
+            hipEvent_t a0, a1;
+            HIP_TRY(hipEventCreate(&a0));
+            HIP_TRY(hipEventCreate(&a1));
+            s->prof_events.emplace_back(a0, a1);
+        }
+        e0 = s->prof_events[s->prof_used].first;
+        e1 = s->prof_events[s->prof_used].second;
+        s->prof_used++;
+        HIP_TRY(hipEventRecord(e0, s->stream));
+    }
+    HIP_TRY(launch_k2((int)s->p.k, a, blocks, s->stream));
+    if (s->profiling) {
+        HIP_TRY(hipEventRecord(e1, s->stream));
+        s->prof_launches++;
+    }
+    if (!s->big_mode)
+        HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size, s->max_hash,
+                                   s->trigger, s->open_loop ? 0u : 1u, s->stream));
+    s->n_launches++;
+    return FH_OK;
+}
+
+// wait for the pending range; if its launch stopped early (table near its guarded size), prune and
+// relaunch until the queue is dry
+int drain(fh_sketcher *s) {
+    while (s->pend.active) {
+        if (int rc = check_ctl(s)) return rc;
+        const Ctl c = *s->h_ctl;
+        s->last_tau = c.tau;
+        s->last_live = c.n_live;
+        const bool remaining = c.next_chunk < s->pend.n_chunks || c.n_left_out > 0;
+        if (c.need_big || (s->big_mode && 4 * (uint64_t)c.n_live >= 3 * s->live_target) ||
+            (remaining && c.n_live >= soft_limit_of(s) / 2)) {
+            if (s->big_mode || c.need_big || c.n_live > (uint32_t)SMALL_MAX) {
+                if (int rc = big_prune(s)) return rc;
+            } else {
+                HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size,
+                                           s->max_hash, 0u, 1u, s->stream));
+            }
+        }
+        if (!remaining) {
+            s->pend.active = false;
+            break;
+        }
+        s->pend.n_left_in = c.n_left_out;
+        s->pend.left_cur ^= 1;
+        HIP_TRY(launch_queue_reset(s->ctl, 0u, s->stream));
+        s->n_relaunches++;
+        if (int rc = launch_pending(s)) return rc;
+    }
+    return FH_OK;
+}
+
 // sketch [0,len) of a device-resident packed stream whose first byte has stream coordinate base_pos
 int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos) {
+    if (int rc = drain(s)) return rc;
     if (len < s->p.k) return FH_OK;
     const uint64_t n_pos = len - s->p.k + 1; // windows that fit
     uint64_t pos = 0;
     while (pos < n_pos) {
-        const uint64_t P = next_launch_size(s);
+        if (int rc = drain(s)) return rc;
+        if (!s->open_loop) {
+            // status of everything before this range is known (drained): decide whether the threshold is
+            // tight enough to let launches run to completion on their own
+            const double inflight = (double)(s->max_waves * TILE_POS);
+            const double room = (double)s->live_target -
+                                (double)std::min<uint64_t>(std::max<uint64_t>(s->p.size, s->last_live), s->live_target);
+            if (s->positions_done > 0 && inflight * admit_rate(s->last_tau) <= 0.25 * room) s->open_loop = true;
+        }
+        const uint64_t P = next_range_size(s, n_pos - pos);
         const uint64_t end = std::min<uint64_t>(n_pos, pos + P);
-        SketchArgs a{};
-        a.seq = d_seq;
-        a.len_total = len;
-        a.p_begin = pos;
-        a.p_end = end;
-        a.base_pos = base_pos;
-        a.seed = s->p.seed;
-        a.hash_mask = s->p.hash_mask ? s->p.hash_mask : ~0ull;
-        a.table = s->table;
-        a.cap = s->cap;
-        a.live = s->live;
-        a.live_cap = s->live_cap;
-        a.ctl = s->ctl;
-        a.clog = s->clog;
-        a.clog_cap = CLOG_CAP;
+        fh_sketcher::Pending &r = s->pend;
+        r.seq = d_seq;
+        r.len = len;
+        r.base_pos = base_pos;
+        r.p_begin = pos;
+        r.p_end = end;
         const uint64_t tiles = (end - pos + TILE_POS - 1) / TILE_POS;
-        a.tiles_total = (uint32_t)tiles;
-        static const uint64_t waves_per_cu = [] {
-            const char *e = getenv("FH_WAVES_PER_CU"); // tuning knob
-            return e ? (uint64_t)atoi(e) : 16ull;
-        }();
-        const uint64_t max_waves = 256ull * waves_per_cu;
-        uint64_t waves = std::min<uint64_t>(tiles, max_waves);
-        a.tiles_per_wave = (uint32_t)((tiles + waves - 1) / waves);
-        waves = (tiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
-        const int blocks = (int)((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (s->profiling) {
-            if (s->prof_used == s->prof_events.size()) {
-                hipEvent_t a0, a1;
-                HIP_TRY(hipEventCreate(&a0));
-                HIP_TRY(hipEventCreate(&a1));
-                s->prof_events.emplace_back(a0, a1);
-            }
-            e0 = s->prof_events[s->prof_used].first;
-            e1 = s->prof_events[s->prof_used].second;
-            s->prof_used++;
-            HIP_TRY(hipEventRecord(e0, s->stream));
-        }
-        HIP_TRY(launch_k2((int)s->p.k, a, blocks, s->stream));
-        if (s->profiling) {
-            HIP_TRY(hipEventRecord(e1, s->stream));
-            s->prof_launches++;
-            s->prof_positions += end - pos;
-        }
-        if (!s->big_mode)
-            HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size,
-                                       s->max_hash, s->trigger, s->open_loop ? 0u : 1u, s->stream));
+        if (tiles >= (1ull << 31)) return fail(FH_ERR_INVALID, "block too large for one range");
+        r.tiles_total = (uint32_t)tiles;
+        r.n_chunks = (uint32_t)((tiles + CHUNK_TILES - 1) / CHUNK_TILES);
+        r.n_left_in = 0;
+        r.left_cur = 0;
+        HIP_TRY(launch_queue_reset(s->ctl, 1u, s->stream));
+        if (int rc = launch_pending(s)) return rc;
+        r.active = true;
+        if (s->profiling) s->prof_positions += end - pos;
         s->positions_done += end - pos;
         s->dirty = true;
         pos = end;
-        if (!s->open_loop) {
-            // closed loop: read the status back before sizing the next launch
-            if (int rc = check_ctl(s)) return rc;
-            s->last_tau = s->h_ctl->tau;
-            s->last_live = s->h_ctl->n_live;
-            if (s->h_ctl->need_big || (s->big_mode && 4 * (uint64_t)s->last_live >= 3 * s->live_target))
-                if (int rc = big_prune(s)) return rc;
-            const double room = (double)s->live_target - (double)std::min<uint64_t>(std::max<uint64_t>(s->p.size, s->last_live), s->live_target);
-            if ((double)s->max_launch * admit_rate(s->last_tau) <= 0.25 * room) s->open_loop = true;
-        } else {
-            // open loop: inspect the status of the launch before the previous one (long finished), so the
-            // GPU never idles; capacity covers two maximum launches beyond live_target
-            const int slot = (int)(s->launch_idx & 1);
-            if (s->ring_used[slot]) {
-                HIP_TRY(hipEventSynchronize(s->ring_ev[slot]));
-                const Ctl &c = *s->h_ring[slot];
-                if (c.overflow) return fail(FH_ERR_CAPACITY, "device hash table capacity exceeded");
-                s->last_tau = c.tau;
-                s->last_live = c.n_live;
-                if (c.need_big || (s->big_mode && c.n_live >= s->live_target))
-                    if (int rc = big_prune(s)) return rc;
-            }
-            HIP_TRY(hipMemcpyAsync(s->h_ring[slot], s->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s->stream));
-            HIP_TRY(hipEventRecord(s->ring_ev[slot], s->stream));
-            s->ring_used[slot] = true;
-        }
-        s->launch_idx++;
+        if (!s->open_loop)
+            if (int rc = drain(s)) return rc; // closed loop: the next range is sized from this one's outcome
     }
     return FH_OK;
 }
@@ -337,7 +393,7 @@ int big_prune(fh_sketcher *s) {
     // scaled sketches keep everything <= max_hash: the live set itself grows with the input
     if (2 * (uint64_t)s->last_live > s->live_target) {
         s->live_target = 2 * (uint64_t)s->last_live;
-        const uint64_t need = s->live_target + 2 * s->max_launch + 64;
+        const uint64_t need = s->live_target + s->max_waves * (uint64_t)(WAVE_BUDGET + TILE_POS) + 4096;
         if (need > s->live_cap)
             if (int rc = grow_table(s, need + need / 2)) return rc;
     }
@@ -366,6 +422,7 @@ int grow_table(fh_sketcher *s, uint64_t new_live_cap) {
     s->cap = (uint32_t)new_cap;
     s->live_cap = (uint32_t)new_live_cap;
     s->dead_cap = (uint32_t)new_live_cap;
+    HIP_TRY(launch_set_table(s->ctl, s->table, s->live, s->clog, s->cap, s->live_cap, CLOG_CAP, s->stream));
     return check_ctl(s);
 }
 
@@ -507,9 +564,18 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
     if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     s->big_mode = params->kind == FH_KIND_SCALED || params->size > SMALL_N_MAX;
     s->live_target = s->big_mode ? std::max<uint64_t>(4 * params->size, 1ull << 16) : (uint64_t)SMALL_MAX;
-    // worst case a launch inserts one new hash per position, and open-loop status lags by one launch:
-    // size the table so that it can never fill
-    const uint64_t live_cap = s->live_target + 2 * s->max_launch + 64;
+    // the table can never fill: waves stop pulling work at soft_limit (<= live_target) and each of the
+    // max_waves resident waves can insert at most one tile's worth (2048) after that
+    {
+        static const uint64_t waves_per_cu = [] {
+            const char *e = getenv("FH_WAVES_PER_CU"); // tuning knob
+            return e ? (uint64_t)atoi(e) : 32ull;
+        }();
+        s->max_waves = std::max<uint64_t>(1, std::min<uint64_t>(256ull * waves_per_cu, s->max_launch / TILE_POS));
+        const char *mr = getenv("FH_MAX_RANGE"); // test knob: force many ranges per push
+        s->max_range = mr ? strtoull(mr, nullptr, 10) : 0;
+    }
+    const uint64_t live_cap = s->live_target + s->max_waves * (uint64_t)(WAVE_BUDGET + TILE_POS) + 4096;
     const uint64_t cap = 2 * live_cap;
     if (cap >= (1ull << 32)) {
         fail(FH_ERR_INVALID, "max_launch too large");
@@ -523,13 +589,15 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
     s->dead_cap = (uint32_t)live_cap;
     if ((e = hipMalloc(&s->dead, (size_t)s->dead_cap * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(dead)", e);
     if ((e = hipMalloc(&s->ctl, sizeof(Ctl))) != hipSuccess) return bail("hipMalloc(ctl)", e);
+    for (int i = 0; i < 2; ++i)
+        if ((e = hipMalloc(&s->left_buf[i], (size_t)s->max_waves * 2 * sizeof(uint32_t) + 64)) != hipSuccess)
+            return bail("hipMalloc(left)", e);
     if ((e = hipMalloc(&s->clog, CLOG_CAP * sizeof(CollRec))) != hipSuccess) return bail("hipMalloc(clog)", e);
     if ((e = hipHostMalloc(&s->h_ctl, sizeof(Ctl), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
-    for (int i = 0; i < 2; ++i) {
-        if ((e = hipHostMalloc(&s->h_ring[i], sizeof(Ctl), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
-        if ((e = hipEventCreateWithFlags(&s->ring_ev[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    }
+
     if ((e = launch_fill_table(s->table, cap, s->stream)) != hipSuccess) return bail("fill_table", e);
+    if ((e = launch_set_table(s->ctl, s->table, s->live, s->clog, s->cap, s->live_cap, CLOG_CAP, s->stream)) != hipSuccess)
+        return bail("set_table", e);
     if (init_state(s) != FH_OK) {
         fh_free(s);
         return nullptr;
@@ -552,10 +620,8 @@ void fh_free(fh_sketcher *s) {
         if (s->stage_done[i]) (void)hipEventDestroy(s->stage_done[i]);
     }
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
-    for (int i = 0; i < 2; ++i) {
-        if (s->h_ring[i]) (void)hipHostFree(s->h_ring[i]);
-        if (s->ring_ev[i]) (void)hipEventDestroy(s->ring_ev[i]);
-    }
+    (void)hipFree(s->left_buf[0]);
+    (void)hipFree(s->left_buf[1]);
     (void)hipFree(s->keys_a);
     (void)hipFree(s->keys_b);
     (void)hipFree(s->slots_a);
@@ -579,6 +645,7 @@ void fh_free(fh_sketcher *s) {
 int fh_reset(fh_sketcher *s) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (int rc = set_device(s)) return rc;
+    if (int rc = drain(s)) return rc;
     if (s->dirty) {
         // clear only the slots this run touched (live + dropped); fall back to a full refill if the
         // dropped-slot list overflowed
@@ -682,6 +749,7 @@ int fh_push_block(fh_sketcher *s, const uint8_t *bytes, uint64_t len) { return f
 int fh_sync(fh_sketcher *s) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (int rc = set_device(s)) return rc;
+    if (int rc = drain(s)) return rc;
     if (int rc = check_ctl(s)) return rc;
     return collect_profile(s);
 }
@@ -690,6 +758,7 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (int rc = set_device(s)) return rc;
     if (!s->finished) {
+        if (int rc = drain(s)) return rc;
         if (int rc = check_ctl(s)) return rc;
         if (!s->big_mode && s->h_ctl->n_live <= (uint32_t)SMALL_MAX && !s->h_ctl->need_big) {
             HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size,
@@ -734,7 +803,8 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
                                        [](const ResultRec &r, uint64_t h) { return r.hash < h; });
             if (it != s->res.end() && it->hash == cr.hash && it->pos == cr.pos) it->kmer = cr.kmer;
         }
-        s->total_kmers = c.total_kmers;
+        s->total_kmers = 0;
+        for (int i = 0; i < 256; ++i) s->total_kmers += c.kmer_counts[i];
         s->finished = true;
     }
     if (n_out) *n_out = s->res.size();
@@ -831,11 +901,20 @@ int fh_set_profiling(fh_sketcher *s, int enable) {
 int fh_kernel_time(fh_sketcher *s, double *total_ms, uint64_t *launches, uint64_t *positions) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (int rc = set_device(s)) return rc;
+    if (int rc = drain(s)) return rc;
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (int rc = collect_profile(s)) return rc;
     if (total_ms) *total_ms = s->prof_ms;
     if (launches) *launches = s->prof_launches;
     if (positions) *positions = s->prof_positions;
+    return FH_OK;
+}
+
+int fh_debug_counters(fh_sketcher *s, uint64_t *launches, uint64_t *relaunches, uint64_t *big_prunes) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (launches) *launches = s->n_launches;
+    if (relaunches) *relaunches = s->n_relaunches;
+    if (big_prunes) *big_prunes = s->n_big_prunes;
     return FH_OK;
 }
 

@@ -107,7 +107,7 @@ __global__ void k_rehash(const Entry *src, const u32 *src_live, u32 M, Entry *ds
     const u32 stride = gridDim.x * blockDim.x;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) {
         const Entry e = src[src_live[i]];
-        const u32 key32 = (u32)e.hash ^ (u32)(e.hash >> 32) * 0x9E3779B1u;
+        const u32 key32 = slot_key(e.hash);
         u32 slot = (u32)(((u64)key32 * (u64)dst_cap) >> 32);
         bool placed = false;
         for (int probe = 0; probe < MAX_PROBE; ++probe) {

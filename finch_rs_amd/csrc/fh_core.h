@@ -400,6 +400,9 @@ FH_HD u64 murmur_h1_fast(u64 cm, u64 seed, const u32 *TQ, const u32 *TP) {
     return add64(h1, h2);
 }
 
+// table slot key: admitted hashes are small numbers, so mix before scaling to the table size
+FH_HD u32 slot_key(u64 h) { return (u32)((h * 0x9E3779B97F4A7C15ULL) >> 32); }
+
 // ---- synthetic data generator : splitmix64 counter RNG ----
 FH_HD u64 splitmix64(u64 x) {
     x += 0x9E3779B97F4A7C15ULL;

@@ -29,7 +29,7 @@ struct CollRec {        // an occurrence whose k-mer differs from the slot's k-m
 
 struct Ctl {
     uint64_t tau;           // admit iff hash <= tau
-    uint64_t total_kmers;   // number of valid k-mer windows seen (mash.rs:35)
+    uint64_t total_kmers;   // (unused by the kernels; kept for layout) see kmer_counts
     uint32_t n_live;        // entries in the live list
     uint32_t overflow;      // table probe limit hit / live list full (capacity error)
     uint32_t n_coll;        // collision log entries
@@ -38,8 +38,22 @@ struct Ctl {
     uint32_t launches_skipped;
     uint32_t n_dead;        // entries in the dropped-slot list (0xFFFFFFFF = list overflowed)
     uint32_t pad0;
+    // tile queue of the current range (dynamic scheduling; survives a stopped launch)
+    uint32_t next_chunk;    // next chunk of CHUNK_TILES tiles nobody has pulled yet
+    uint32_t left_in_pos;   // next unread entry of the leftover list handed to this launch
+    uint32_t n_left_out;    // leftover tile ranges recorded by waves that stopped mid-chunk
+    uint32_t stopped;       // some wave saw n_live >= soft_limit and stopped pulling work
     // the one hash value that cannot be a table key (== EMPTY64)
     uint64_t sp_count, sp_extra, sp_pos, sp_kmer;
+    // number of valid k-mer windows seen (mash.rs:35), spread over many words so that the one atomic each
+    // wave issues at its end does not serialise on a single L2 address (~12 ns per same-address atomic)
+    uint64_t kmer_counts[256];
+    // where the table lives (read on the rare admit path only, so that the hot loop does not have to keep
+    // these in scalar registers); written by the host whenever the table is (re)allocated
+    Entry *table;
+    uint32_t *live;
+    CollRec *clog;
+    uint32_t cap, live_cap, clog_cap, pad1;
 };
 
 constexpr int TILE_POS = 2048;   // k-mer start positions per wavefront tile (64 lanes x 32)
@@ -47,6 +61,11 @@ constexpr int LANE_POS = 32;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int SMALL_MAX = 8192;  // live entries the single-workgroup prune can sort in LDS
 constexpr int MAX_PROBE = 4096;
+#ifndef FH_CHUNK_TILES
+#define FH_CHUNK_TILES 8
+#endif
+constexpr int CHUNK_TILES = FH_CHUNK_TILES;
+constexpr int WAVE_BUDGET = 2048; // + at most TILE_POS-1 overshoot inside the tile that crosses it   // tiles a wave pulls from the queue at a time (contiguous: halo reuse)
 
 struct SketchArgs {
     const uint8_t *seq;   // packed stream (device), 16-byte aligned
@@ -56,15 +75,14 @@ struct SketchArgs {
     uint64_t base_pos;    // stream coordinate of seq[0]
     uint64_t seed;
     uint64_t hash_mask;   // ~0 unless the test hook is on
-    Entry *table;
-    uint32_t cap;
-    uint32_t *live;
-    uint32_t live_cap;
     Ctl *ctl;
-    CollRec *clog;
-    uint32_t clog_cap;
     uint32_t tiles_total;
-    uint32_t tiles_per_wave;
+    uint32_t n_chunks;       // ceil(tiles_total / CHUNK_TILES)
+    uint32_t soft_limit;     // stop pulling chunks once n_live reaches this (keeps the live set sortable / small)
+    uint32_t wave_budget;    // new hashes one wave may insert per launch before it stops (hard capacity guard)
+    uint32_t n_left_in;      // leftover tile ranges from the previous (stopped) launch of this range
+    const uint32_t *left_in; // pairs (t0, t1)
+    uint32_t *left_out;      // pairs (t0, t1), capacity >= number of waves
 };
 
 } // namespace fh

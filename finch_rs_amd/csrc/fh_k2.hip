@@ -59,28 +59,29 @@ __device__ __forceinline__ void log_collision(const TableRef a, u64 h, u64 kmer,
     }
 }
 
-__device__ __noinline__ void upsert(Entry *table, u32 *live, Ctl *ctl, CollRec *clog, u32 cap, u32 live_cap,
-                                    u32 clog_cap, u64 h, u64 kmer, u64 pos, u32 strand) {
+__device__ __noinline__ u32 upsert(Ctl *ctl, u64 h, u64 kmer, u64 pos, u32 strand) {
     typedef unsigned long long ull;
-    const TableRef a{table, live, ctl, clog, cap, live_cap, clog_cap};
+    const TableRef a{ctl->table, ctl->live, ctl, ctl->clog, ctl->cap, ctl->live_cap, ctl->clog_cap};
     if (h == EMPTY64) { // the one value that cannot be a table key
         atomicAdd((ull *)&a.ctl->sp_count, 1ull);
         if (strand) atomicAdd((ull *)&a.ctl->sp_extra, 1ull);
         atomicMin((ull *)&a.ctl->sp_pos, (ull)pos);
         ull oldk = atomicCAS((ull *)&a.ctl->sp_kmer, (ull)EMPTY64, (ull)kmer);
         if (oldk != EMPTY64 && oldk != kmer) log_collision(a, h, kmer, pos);
-        return;
+        return 0u;
     }
-    // admitted hashes are tiny numbers (<= tau) but their low bits are still uniform
-    u32 key32 = (u32)h ^ (u32)(h >> 32) * 0x9E3779B1u;
+    // admitted hashes are tiny numbers (<= tau): spread them with a multiplicative mix before mapping to a slot
+    u32 key32 = slot_key(h);
     u32 slot = (u32)(((u64)key32 * (u64)a.cap) >> 32);
     int probe = 0;
+    u32 inserted = 0u;
     for (; probe < MAX_PROBE; ++probe) {
         ull old = atomicCAS((ull *)&a.table[slot].hash, (ull)EMPTY64, (ull)h);
         if (old == EMPTY64) {
             u32 idx = atomicAdd(&a.ctl->n_live, 1u);
             if (idx < a.live_cap) a.live[idx] = slot;
             else atomicExch(&a.ctl->overflow, 1u);
+            inserted = 1u;
             break;
         }
         if (old == h) break;
@@ -88,7 +89,7 @@ __device__ __noinline__ void upsert(Entry *table, u32 *live, Ctl *ctl, CollRec *
     }
     if (probe == MAX_PROBE) {
         atomicExch(&a.ctl->overflow, 1u);
-        return;
+        return 0u;
     }
     Entry *e = &a.table[slot];
     atomicAdd((ull *)&e->count, 1ull);
@@ -96,6 +97,7 @@ __device__ __noinline__ void upsert(Entry *table, u32 *live, Ctl *ctl, CollRec *
     atomicMin((ull *)&e->pos, (ull)pos);
     ull oldk = atomicCAS((ull *)&e->kmer, (ull)EMPTY64, (ull)kmer);
     if (oldk != EMPTY64 && oldk != kmer) log_collision(a, h, kmer, pos);
+    return inserted;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -129,8 +131,11 @@ __device__ __forceinline__ void classify_tile(const SketchArgs &a, u64 tile, int
 // ------------------------------------------------------------------------------------------------
 // K2
 // ------------------------------------------------------------------------------------------------
+#ifndef FH_MIN_WAVES
+#define FH_MIN_WAVES 1
+#endif
 template <int K, bool MASKED, bool SEED0>
-__global__ __launch_bounds__(256) void k2_sketch(const SketchArgs a) {
+__global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs a) {
     __shared__ __attribute__((aligned(16))) u32 sTQ[1024];  // lo/hi(ascii4*c1), lo/hi(ascii4*c2)
     __shared__ __attribute__((aligned(16))) u32 sTP[128];   // lo/hi(partial group * its constant)
     __shared__ __attribute__((aligned(16))) u32 sCodes[WAVES_PER_BLOCK][256];
@@ -155,17 +160,43 @@ __global__ __launch_bounds__(256) void k2_sketch(const SketchArgs a) {
     const u64 tau = __hip_atomic_load(&a.ctl->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     const u32 gw = blockIdx.x * WAVES_PER_BLOCK + (u32)wave;
-    const u64 t0 = (u64)gw * a.tiles_per_wave;
-    u64 t1 = t0 + a.tiles_per_wave;
-    if (t1 > a.tiles_total) t1 = a.tiles_total;
-    if (t0 >= t1) return;
-
     u32 *codes_ring = sCodes[wave];
     u32 *good_ring = sGood[wave];
     u32 nvalid = 0; // per lane
 
-    classify_tile(a, t0, lane, codes_ring, good_ring);
-    for (u64 t = t0; t < t1; ++t) {
+    // Persistent wave: pull ranges of tiles until the queue is dry, the live set reaches its soft limit
+    // (checked once per pulled chunk -- polling one word per tile from 8192 waves serialises in L2), or the
+    // wave has used up its own insert budget.  The budget is what makes overflow impossible whatever the
+    // input: a wave inserts at most budget + 2047 new hashes per launch and the host sized the table for
+    // (#waves x that) beyond the soft limit.  A stopped launch leaves its unprocessed work in the queue
+    // (next_chunk + the leftover list); the host prunes and relaunches.
+    u32 wave_inserts = 0; // wave-uniform (reduced at tile ends)
+    u32 lane_inserts = 0; // new hashes this lane inserted in the current tile
+    for (;;) {
+        u32 rt0 = 0xFFFFFFFFu, rt1 = 0u;
+        if (lane == 0) {
+            u32 li = 0xFFFFFFFFu;
+            if (a.n_left_in) li = atomicAdd(&a.ctl->left_in_pos, 1u);
+            if (li < a.n_left_in) {
+                rt0 = a.left_in[2u * li];
+                rt1 = a.left_in[2u * li + 1u];
+            } else if (__hip_atomic_load(&a.ctl->n_live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.soft_limit) {
+                const u32 c = atomicAdd(&a.ctl->next_chunk, 1u);
+                if (c < a.n_chunks) {
+                    rt0 = c * (u32)CHUNK_TILES;
+                    rt1 = rt0 + (u32)CHUNK_TILES < a.tiles_total ? rt0 + (u32)CHUNK_TILES : a.tiles_total;
+                }
+            } else {
+                atomicExch(&a.ctl->stopped, 1u);
+            }
+        }
+        rt0 = (u32)__builtin_amdgcn_readfirstlane((int)rt0);
+        rt1 = (u32)__builtin_amdgcn_readfirstlane((int)rt1);
+        if (rt0 == 0xFFFFFFFFu) break;
+
+    bool stop = false;
+    classify_tile(a, rt0, lane, codes_ring, good_ring);
+    for (u64 t = rt0; t < rt1; ++t) {
         classify_tile(a, t + 1, lane, codes_ring, good_ring); // also provides the halo of lane 63
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -200,16 +231,39 @@ __global__ __launch_bounds__(256) void k2_sketch(const SketchArgs a) {
             if (MASKED) h &= a.hash_mask; // test hook only
             // windows that carry no k-mer hash garbage; they are rejected on the (rare) admit path only
             if (__builtin_expect(h <= tau, 0)) {
+                u32 ins = 0u;
                 if ((W >> j) & 1u)
-                    upsert(a.table, a.live, a.ctl, a.clog, a.cap, a.live_cap, a.clog_cap, h, cm,
-                           a.base_pos + lane_pos0 + (u64)j, is_rc ? 1u : 0u);
+                    ins = upsert(a.ctl, h, cm, a.base_pos + lane_pos0 + (u64)j, is_rc ? 1u : 0u);
+                lane_inserts += ins;
             }
         }
         __builtin_amdgcn_wave_barrier();
+        if (__any(lane_inserts != 0u)) { // rare once the threshold is tight
+            u32 v = lane_inserts;
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            wave_inserts += (u32)__builtin_amdgcn_readfirstlane((int)v);
+            lane_inserts = 0;
+        }
+        if (t + 1 < rt1 && wave_inserts >= a.wave_budget) {
+            if (lane == 0) {
+                const u32 idx = atomicAdd(&a.ctl->n_left_out, 1u);
+                a.left_out[2u * idx] = (u32)(t + 1);
+                a.left_out[2u * idx + 1u] = rt1;
+                atomicExch(&a.ctl->stopped, 1u);
+            }
+            stop = true;
+            break;
+        }
+    }
+        if (stop || wave_inserts >= a.wave_budget) {
+            if (!stop && lane == 0) atomicExch(&a.ctl->stopped, 1u);
+            break;
+        }
     }
     // total_kmers (mash.rs:35): one atomic per wave
     for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_xor(nvalid, off);
-    if (lane == 0 && nvalid) atomicAdd((unsigned long long *)&a.ctl->total_kmers, (unsigned long long)nvalid);
+    if (lane == 0 && nvalid)
+        atomicAdd((unsigned long long *)&a.ctl->kmer_counts[gw & 255u], (unsigned long long)nvalid);
 }
 
 template <int K>

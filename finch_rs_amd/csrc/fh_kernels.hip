@@ -207,6 +207,24 @@ hipError_t launch_clear_slots(Entry *table, u64 cap, const u32 *live, const u32 
     return hipGetLastError();
 }
 
+__global__ void k_set_table(Ctl *ctl, Entry *table, u32 *live, CollRec *clog, u32 cap, u32 live_cap, u32 clog_cap) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ctl->table = table;
+        ctl->live = live;
+        ctl->clog = clog;
+        ctl->cap = cap;
+        ctl->live_cap = live_cap;
+        ctl->clog_cap = clog_cap;
+        ctl->pad1 = 0;
+    }
+}
+
+hipError_t launch_set_table(Ctl *ctl, Entry *table, u32 *live, CollRec *clog, u32 cap, u32 live_cap, u32 clog_cap,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(k_set_table, dim3(1), dim3(64), 0, st, ctl, table, live, clog, cap, live_cap, clog_cap);
+    return hipGetLastError();
+}
+
 __global__ void k_init_ctl(Ctl *ctl, u64 tau0) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         Ctl c;
@@ -224,8 +242,41 @@ __global__ void k_init_ctl(Ctl *ctl, u64 tau0) {
         c.sp_extra = 0;
         c.sp_pos = EMPTY64;
         c.sp_kmer = EMPTY64;
-        *ctl = c;
+        ctl->tau = c.tau;
+        ctl->total_kmers = 0;
+        ctl->n_live = 0;
+        ctl->overflow = 0;
+        ctl->n_coll = 0;
+        ctl->need_big = 0;
+        ctl->sorted = 1;
+        ctl->launches_skipped = 0;
+        ctl->n_dead = 0;
+        ctl->pad0 = 0;
+        ctl->next_chunk = 0;
+        ctl->left_in_pos = 0;
+        ctl->n_left_out = 0;
+        ctl->stopped = 0;
+        ctl->sp_count = 0;
+        ctl->sp_extra = 0;
+        ctl->sp_pos = EMPTY64;
+        ctl->sp_kmer = EMPTY64;
     }
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) ctl->kmer_counts[i] = 0;
+}
+
+// new range: empty queue; relaunch of a stopped range: keep next_chunk, swap leftover lists
+__global__ void k_queue_reset(Ctl *ctl, u32 new_range) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (new_range) ctl->next_chunk = 0;
+        ctl->left_in_pos = 0;
+        ctl->n_left_out = 0;
+        ctl->stopped = 0;
+    }
+}
+
+hipError_t launch_queue_reset(Ctl *ctl, u32 new_range, hipStream_t st) {
+    hipLaunchKernelGGL(k_queue_reset, dim3(1), dim3(64), 0, st, ctl, new_range);
+    return hipGetLastError();
 }
 
 hipError_t launch_init_ctl(Ctl *ctl, u64 tau0, hipStream_t st) {

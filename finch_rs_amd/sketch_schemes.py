@@ -177,6 +177,11 @@ class HipSketcher:
                                       es.ctypes.data_as(C.c_void_p), km.ctypes.data_as(C.c_void_p),
                                       ps.ctypes.data_as(C.c_void_p), total_kmers))
 
+    def debug_counters(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(self._L.fh_debug_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"launches": a.value, "relaunches": b.value, "big_prunes": c.value}
+
     # --- measurement ---
     def set_profiling(self, on: bool) -> None:
         check(self._L.fh_set_profiling(self._h, 1 if on else 0))

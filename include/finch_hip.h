@@ -52,7 +52,8 @@ typedef struct fh_params {
     uint64_t size;        /* kmers_to_sketch */
     uint64_t seed;        /* hash_seed */
     double scale;         /* scaled only; max_hash = u64::MAX / ((1/scale) as u64) */
-    uint64_t max_launch;  /* 0 = default; max k-mer start positions per kernel launch (sizes the device table) */
+    uint64_t max_launch;  /* 0 = default (8192 waves x 2048); max k-mer start positions in flight at once:
+                             bounds the grid and sizes the device table (table slots ~ 2 x (this + 4 x size)) */
     uint64_t hash_mask;   /* 0 = none (all bits); test hook: AND every hash with this mask (forces collisions) */
 } fh_params;
 
@@ -128,6 +129,9 @@ int fh_set_profiling(fh_sketcher *s, int enable);
 /* sum of event-measured durations (ms) and number of sketch-kernel launches since the last reset,
  * and the k-mer start positions those launches covered */
 int fh_kernel_time(fh_sketcher *s, double *total_ms, uint64_t *launches, uint64_t *positions);
+
+/* diagnostics: sketch-kernel launches, relaunches after a capacity stop, device-wide selections */
+int fh_debug_counters(fh_sketcher *s, uint64_t *launches, uint64_t *relaunches, uint64_t *big_prunes);
 
 /* --- device memory helpers so callers need no HIP/torch binding (tests, bench) --- */
 int fh_device_alloc(int device, uint64_t bytes, void **out);

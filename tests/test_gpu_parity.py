@@ -216,6 +216,25 @@ def test_resident_stream_vs_oracle(k, n):
     assert all(np.array_equal(a, b) for a, b in zip(kc1, kc2))
 
 
+@pytest.mark.parametrize("n,inflight", [(3000, 65536), (1000, 16384), (20000, 262144)])
+def test_capacity_stop_and_relaunch(n, inflight):
+    """a launch whose waves stop because the table nears its guarded size is pruned and relaunched from the
+    tile queue: nothing lost, nothing counted twice"""
+    gl, nr, rl, seed = 500000, 200000, 150, 21
+    dg = F.DeviceBuffer(gl)
+    nbytes = nr * (rl + 1)
+    dr = F.DeviceBuffer(nbytes + 64)
+    S.synth_genome_device(dg, gl, seed)
+    S.synth_reads_device(dr, dg, gl, 0, nr, rl, seed, 10000, 500)
+    sk = F.SketchParams.mash(n, n, True, 21, 0).create_sketcher(max_launch=inflight)
+    sk.push_device(dr.ptr, nbytes)
+    ora = O.OracleSketcher(O.MASH, n, 21, 0)
+    ora.process_packed(dr.download(nbytes), 0)
+    assert_same(sk, ora, "stop/relaunch n=%d" % n)
+    c = sk.debug_counters()
+    assert c["relaunches"] >= 1, c
+
+
 def test_sharded_merge_equals_whole():
     """global sketch == merge of read-block shard sketches"""
     gl, nr, rl, seed = 300000, 120000, 150, 7
