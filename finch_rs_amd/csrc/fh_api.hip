@@ -97,7 +97,7 @@ struct fh_sketcher {
         bool active = false;
         const uint8_t *seq = nullptr;
         uint64_t len = 0, base_pos = 0, p_begin = 0, p_end = 0;
-        uint32_t tiles_total = 0, n_chunks = 0, n_left_in = 0;
+        uint32_t tiles_total = 0, n_units = 0, n_left_in = 0;
         int left_cur = 0;
     } pend;
     uint32_t *left_buf[2] = {nullptr, nullptr}; // leftover tile ranges of a stopped launch (pairs)
@@ -236,8 +236,7 @@ int launch_pending(fh_sketcher *s) {
     a.hash_mask = s->p.hash_mask ? s->p.hash_mask : ~0ull;
     a.ctl = s->ctl;
     a.tiles_total = r.tiles_total;
-    a.n_chunks = r.n_chunks;
-    a.soft_limit = soft_limit_of(s);
+    a.n_units = r.n_units;
     // a range no longer than the table's slack cannot overflow it anyway: no per-wave budget (warm-up ranges)
     a.wave_budget = (r.p_end - r.p_begin <= (uint64_t)s->live_cap - std::min<uint64_t>(s->live_cap, s->live_target))
                         ? 0xFFFFFFFFu
@@ -245,8 +244,9 @@ int launch_pending(fh_sketcher *s) {
     a.n_left_in = r.n_left_in;
     a.left_in = s->left_buf[r.left_cur];
     a.left_out = s->left_buf[r.left_cur ^ 1];
-    const uint64_t work_units = (uint64_t)r.n_chunks + r.n_left_in;
+    const uint64_t work_units = (uint64_t)r.n_units + r.n_left_in;
     const uint64_t waves = std::max<uint64_t>(1, std::min<uint64_t>(work_units, s->max_waves));
+    a.n_waves = (uint32_t)waves;
     const int blocks = (int)((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -282,7 +282,7 @@ int drain(fh_sketcher *s) {
         const Ctl c = *s->h_ctl;
         s->last_tau = c.tau;
         s->last_live = c.n_live;
-        const bool remaining = c.next_chunk < s->pend.n_chunks || c.n_left_out > 0;
+        const bool remaining = c.next_unit < s->pend.n_units || c.n_left_out > 0;
         if (c.need_big || (s->big_mode && 4 * (uint64_t)c.n_live >= 3 * s->live_target) ||
             (remaining && c.n_live >= soft_limit_of(s) / 2)) {
             if (s->big_mode || c.need_big || c.n_live > (uint32_t)SMALL_MAX) {
@@ -298,7 +298,7 @@ int drain(fh_sketcher *s) {
         }
         s->pend.n_left_in = c.n_left_out;
         s->pend.left_cur ^= 1;
-        HIP_TRY(launch_queue_reset(s->ctl, 0u, s->stream));
+        HIP_TRY(launch_queue_reset(s->ctl, 0u, soft_limit_of(s), s->stream));
         s->n_relaunches++;
         if (int rc = launch_pending(s)) return rc;
     }
@@ -332,10 +332,10 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
         const uint64_t tiles = (end - pos + TILE_POS - 1) / TILE_POS;
         if (tiles >= (1ull << 31)) return fail(FH_ERR_INVALID, "block too large for one range");
         r.tiles_total = (uint32_t)tiles;
-        r.n_chunks = (uint32_t)((tiles + CHUNK_TILES - 1) / CHUNK_TILES);
+        r.n_units = (uint32_t)((tiles + UNIT_TILES - 1) / UNIT_TILES);
         r.n_left_in = 0;
         r.left_cur = 0;
-        HIP_TRY(launch_queue_reset(s->ctl, 1u, s->stream));
+        HIP_TRY(launch_queue_reset(s->ctl, 1u, soft_limit_of(s), s->stream));
         if (int rc = launch_pending(s)) return rc;
         r.active = true;
         if (s->profiling) s->prof_positions += end - pos;

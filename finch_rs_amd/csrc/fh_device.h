@@ -38,11 +38,10 @@ struct Ctl {
     uint32_t launches_skipped;
     uint32_t n_dead;        // entries in the dropped-slot list (0xFFFFFFFF = list overflowed)
     uint32_t pad0;
-    // tile queue of the current range (dynamic scheduling; survives a stopped launch)
-    uint32_t next_chunk;    // next chunk of CHUNK_TILES tiles nobody has pulled yet
     uint32_t left_in_pos;   // next unread entry of the leftover list handed to this launch
     uint32_t n_left_out;    // leftover tile ranges recorded by waves that stopped mid-chunk
-    uint32_t stopped;       // some wave saw n_live >= soft_limit and stopped pulling work
+    uint32_t soft_limit;    // the inserter that takes n_live to this value raises `stopped`
+    uint32_t pad2;
     // the one hash value that cannot be a table key (== EMPTY64)
     uint64_t sp_count, sp_extra, sp_pos, sp_kmer;
     // number of valid k-mer windows seen (mash.rs:35), spread over many words so that the one atomic each
@@ -54,6 +53,14 @@ struct Ctl {
     uint32_t *live;
     CollRec *clog;
     uint32_t cap, live_cap, clog_cap, pad1;
+    // Tile queue of the current range (dynamic scheduling; survives a stopped launch).  Every wave hits
+    // these two words once per pull, and same-line atomics serialise in L2 (~12-16 ns each), so each gets a
+    // 128-byte line of its own, away from n_live / tau that the admit path updates.
+    uint32_t pad3[32];
+    uint32_t next_unit;     // next unit of UNIT_TILES tiles nobody has pulled yet
+    uint32_t pad4[31];
+    uint32_t stopped;       // raised when the live set reaches soft_limit (or a wave exhausts its budget)
+    uint32_t pad5[31];
 };
 
 constexpr int TILE_POS = 2048;   // k-mer start positions per wavefront tile (64 lanes x 32)
@@ -61,10 +68,14 @@ constexpr int LANE_POS = 32;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int SMALL_MAX = 8192;  // live entries the single-workgroup prune can sort in LDS
 constexpr int MAX_PROBE = 4096;
-#ifndef FH_CHUNK_TILES
-#define FH_CHUNK_TILES 8
+#ifndef FH_UNIT_TILES
+#define FH_UNIT_TILES 2
 #endif
-constexpr int CHUNK_TILES = FH_CHUNK_TILES;
+#ifndef FH_MAX_UNITS
+#define FH_MAX_UNITS 8
+#endif
+constexpr int UNIT_TILES = FH_UNIT_TILES; // queue granularity; a pull takes 1..MAX_UNITS consecutive units
+constexpr int MAX_UNITS = FH_MAX_UNITS;   // (guided self-scheduling: big pulls first, single units at the end)
 constexpr int WAVE_BUDGET = 2048; // + at most TILE_POS-1 overshoot inside the tile that crosses it   // tiles a wave pulls from the queue at a time (contiguous: halo reuse)
 
 struct SketchArgs {
@@ -77,8 +88,8 @@ struct SketchArgs {
     uint64_t hash_mask;   // ~0 unless the test hook is on
     Ctl *ctl;
     uint32_t tiles_total;
-    uint32_t n_chunks;       // ceil(tiles_total / CHUNK_TILES)
-    uint32_t soft_limit;     // stop pulling chunks once n_live reaches this (keeps the live set sortable / small)
+    uint32_t n_units;        // ceil(tiles_total / UNIT_TILES)
+    uint32_t n_waves;        // waves of this launch (guides the pull size)
     uint32_t wave_budget;    // new hashes one wave may insert per launch before it stops (hard capacity guard)
     uint32_t n_left_in;      // leftover tile ranges from the previous (stopped) launch of this range
     const uint32_t *left_in; // pairs (t0, t1)

@@ -81,6 +81,7 @@ __device__ __noinline__ u32 upsert(Ctl *ctl, u64 h, u64 kmer, u64 pos, u32 stran
             u32 idx = atomicAdd(&a.ctl->n_live, 1u);
             if (idx < a.live_cap) a.live[idx] = slot;
             else atomicExch(&a.ctl->overflow, 1u);
+            if (idx + 1u == a.ctl->soft_limit) atomicExch(&a.ctl->stopped, 1u); // live set full enough: drain & prune
             inserted = 1u;
             break;
         }
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
     // (next_chunk + the leftover list); the host prunes and relaunches.
     u32 wave_inserts = 0; // wave-uniform (reduced at tile ends)
     u32 lane_inserts = 0; // new hashes this lane inserted in the current tile
+    u32 last_unit = 0; // guides the pull size
     for (;;) {
         u32 rt0 = 0xFFFFFFFFu, rt1 = 0u;
         if (lane == 0) {
@@ -180,14 +182,18 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
             if (li < a.n_left_in) {
                 rt0 = a.left_in[2u * li];
                 rt1 = a.left_in[2u * li + 1u];
-            } else if (__hip_atomic_load(&a.ctl->n_live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.soft_limit) {
-                const u32 c = atomicAdd(&a.ctl->next_chunk, 1u);
-                if (c < a.n_chunks) {
-                    rt0 = c * (u32)CHUNK_TILES;
-                    rt1 = rt0 + (u32)CHUNK_TILES < a.tiles_total ? rt0 + (u32)CHUNK_TILES : a.tiles_total;
+            } else if (__hip_atomic_load(&a.ctl->stopped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                // guided self-scheduling: take 1/(4 x waves) of what seems to be left, 1..MAX_UNITS units
+                const u32 left = a.n_units > last_unit ? a.n_units - last_unit : 0u;
+                u32 k = left / (4u * a.n_waves);
+                k = k < 1u ? 1u : (k > (u32)MAX_UNITS ? (u32)MAX_UNITS : k);
+                const u32 c = atomicAdd(&a.ctl->next_unit, k);
+                last_unit = c + k;
+                if (c < a.n_units) {
+                    rt0 = c * (u32)UNIT_TILES;
+                    const u32 e = (c + k) * (u32)UNIT_TILES;
+                    rt1 = e < a.tiles_total ? e : a.tiles_total;
                 }
-            } else {
-                atomicExch(&a.ctl->stopped, 1u);
             }
         }
         rt0 = (u32)__builtin_amdgcn_readfirstlane((int)rt0);

@@ -252,10 +252,12 @@ __global__ void k_init_ctl(Ctl *ctl, u64 tau0) {
         ctl->launches_skipped = 0;
         ctl->n_dead = 0;
         ctl->pad0 = 0;
-        ctl->next_chunk = 0;
+        ctl->next_unit = 0;
         ctl->left_in_pos = 0;
         ctl->n_left_out = 0;
         ctl->stopped = 0;
+        ctl->soft_limit = 0xFFFFFFFFu;
+        ctl->pad2 = 0;
         ctl->sp_count = 0;
         ctl->sp_extra = 0;
         ctl->sp_pos = EMPTY64;
@@ -265,17 +267,19 @@ __global__ void k_init_ctl(Ctl *ctl, u64 tau0) {
 }
 
 // new range: empty queue; relaunch of a stopped range: keep next_chunk, swap leftover lists
-__global__ void k_queue_reset(Ctl *ctl, u32 new_range) {
+__global__ void k_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (new_range) ctl->next_chunk = 0;
+        if (new_range) ctl->next_unit = 0;
         ctl->left_in_pos = 0;
         ctl->n_left_out = 0;
-        ctl->stopped = 0;
+        ctl->soft_limit = soft_limit;
+        // the live set may already sit at/above the limit (nothing pruned since): stop at once
+        ctl->stopped = ctl->n_live >= soft_limit ? 1u : 0u;
     }
 }
 
-hipError_t launch_queue_reset(Ctl *ctl, u32 new_range, hipStream_t st) {
-    hipLaunchKernelGGL(k_queue_reset, dim3(1), dim3(64), 0, st, ctl, new_range);
+hipError_t launch_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, hipStream_t st) {
+    hipLaunchKernelGGL(k_queue_reset, dim3(1), dim3(64), 0, st, ctl, new_range, soft_limit);
     return hipGetLastError();
 }
 
