@@ -74,6 +74,8 @@ struct fh_sketcher {
     uint32_t cap = 0;
     uint32_t *live = nullptr;
     uint32_t live_cap = 0;
+    uint32_t *shard_cnt = nullptr, *shard_buf = nullptr; // per-shard append lists of new inserts
+    uint32_t shard_cap = 0;
     uint32_t *dead = nullptr; // slots dropped from the live list (garbage to clear on reset)
     uint32_t dead_cap = 0;
     Ctl *ctl = nullptr;
@@ -185,6 +187,24 @@ double admit_rate(uint64_t tau) { return tau == EMPTY64 ? 1.0 : ((double)tau + 1
 // per position, so its size is chosen from the threshold read back after the previous launch such that
 // the live set stays inside what the in-LDS prune can sort.  tau only ever decreases, so once a
 // maximum-size launch is safe it stays safe and launches go open-loop (no host feedback).
+// each shard serves ceil(waves / N_SHARDS) waves, each of which inserts at most WAVE_BUDGET + TILE_POS new
+// hashes per launch, plus its share of the room below the soft limit
+uint32_t shard_cap_for(const fh_sketcher *s, uint64_t live_target) {
+    const uint64_t waves_per_shard = (s->max_waves + N_SHARDS - 1) / N_SHARDS;
+    return (uint32_t)(waves_per_shard * (WAVE_BUDGET + TILE_POS) + live_target / N_SHARDS + 1024);
+}
+
+int alloc_shards(fh_sketcher *s, uint64_t live_target) {
+    const uint32_t cap = shard_cap_for(s, live_target);
+    if (s->shard_buf && cap <= s->shard_cap) return FH_OK;
+    if (s->shard_buf) (void)hipFree(s->shard_buf);
+    s->shard_buf = nullptr;
+    if (!s->shard_cnt) HIP_TRY(hipMalloc(&s->shard_cnt, (size_t)N_SHARDS * SHARD_STRIDE * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&s->shard_buf, (size_t)N_SHARDS * cap * sizeof(uint32_t)));
+    s->shard_cap = cap;
+    return FH_OK;
+}
+
 uint32_t soft_limit_of(const fh_sketcher *s) {
     // stop pulling work when the live set reaches this; the table holds this + everything in flight
     if (s->big_mode) return (uint32_t)std::min<uint64_t>(s->live_target, 0xFFFFFFF0ull);
@@ -237,10 +257,7 @@ int launch_pending(fh_sketcher *s) {
     a.ctl = s->ctl;
     a.tiles_total = r.tiles_total;
     a.n_units = r.n_units;
-    // a range no longer than the table's slack cannot overflow it anyway: no per-wave budget (warm-up ranges)
-    a.wave_budget = (r.p_end - r.p_begin <= (uint64_t)s->live_cap - std::min<uint64_t>(s->live_cap, s->live_target))
-                        ? 0xFFFFFFFFu
-                        : (uint32_t)WAVE_BUDGET;
+    a.wave_budget = (uint32_t)WAVE_BUDGET;
     a.n_left_in = r.n_left_in;
     a.left_in = s->left_buf[r.left_cur];
     a.left_out = s->left_buf[r.left_cur ^ 1];
@@ -267,6 +284,7 @@ int launch_pending(fh_sketcher *s) {
         HIP_TRY(hipEventRecord(e1, s->stream));
         s->prof_launches++;
     }
+    HIP_TRY(launch_live_flatten(s->ctl, s->stream)); // shard lists -> flat live list, n_live
     if (!s->big_mode)
         HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size, s->max_hash,
                                    s->trigger, s->open_loop ? 0u : 1u, s->stream));
@@ -394,8 +412,13 @@ int big_prune(fh_sketcher *s) {
     if (2 * (uint64_t)s->last_live > s->live_target) {
         s->live_target = 2 * (uint64_t)s->last_live;
         const uint64_t need = s->live_target + s->max_waves * (uint64_t)(WAVE_BUDGET + TILE_POS) + 4096;
-        if (need > s->live_cap)
+        if (need > s->live_cap) {
             if (int rc = grow_table(s, need + need / 2)) return rc;
+        } else if (shard_cap_for(s, s->live_target) > s->shard_cap) {
+            if (int rc = alloc_shards(s, s->live_target + s->live_target / 2)) return rc;
+            HIP_TRY(launch_set_table(s->ctl, s->table, s->live, s->clog, s->cap, s->live_cap, CLOG_CAP, s->shard_cnt,
+                                     s->shard_buf, s->shard_cap, s->stream));
+        }
     }
     return FH_OK;
 }
@@ -422,7 +445,9 @@ int grow_table(fh_sketcher *s, uint64_t new_live_cap) {
     s->cap = (uint32_t)new_cap;
     s->live_cap = (uint32_t)new_live_cap;
     s->dead_cap = (uint32_t)new_live_cap;
-    HIP_TRY(launch_set_table(s->ctl, s->table, s->live, s->clog, s->cap, s->live_cap, CLOG_CAP, s->stream));
+    if (int rc = alloc_shards(s, s->live_target)) return rc;
+    HIP_TRY(launch_set_table(s->ctl, s->table, s->live, s->clog, s->cap, s->live_cap, CLOG_CAP, s->shard_cnt, s->shard_buf,
+                             s->shard_cap, s->stream));
     return check_ctl(s);
 }
 
@@ -596,7 +621,12 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
     if ((e = hipHostMalloc(&s->h_ctl, sizeof(Ctl), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
 
     if ((e = launch_fill_table(s->table, cap, s->stream)) != hipSuccess) return bail("fill_table", e);
-    if ((e = launch_set_table(s->ctl, s->table, s->live, s->clog, s->cap, s->live_cap, CLOG_CAP, s->stream)) != hipSuccess)
+    if (alloc_shards(s, s->live_target) != FH_OK) {
+        fh_free(s);
+        return nullptr;
+    }
+    if ((e = launch_set_table(s->ctl, s->table, s->live, s->clog, s->cap, s->live_cap, CLOG_CAP, s->shard_cnt, s->shard_buf,
+                              s->shard_cap, s->stream)) != hipSuccess)
         return bail("set_table", e);
     if (init_state(s) != FH_OK) {
         fh_free(s);
@@ -630,6 +660,8 @@ void fh_free(fh_sketcher *s) {
     (void)hipFree(s->keep_dev);
     (void)hipFree(s->table);
     (void)hipFree(s->live);
+    (void)hipFree(s->shard_cnt);
+    (void)hipFree(s->shard_buf);
     (void)hipFree(s->dead);
     (void)hipFree(s->ctl);
     (void)hipFree(s->clog);

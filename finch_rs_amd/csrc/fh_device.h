@@ -52,7 +52,15 @@ struct Ctl {
     Entry *table;
     uint32_t *live;
     CollRec *clog;
-    uint32_t cap, live_cap, clog_cap, pad1;
+    uint32_t cap, live_cap, clog_cap, shard_cap;
+    // New inserts are appended to N_SHARDS per-shard lists (shard = wave id mod N_SHARDS) whose cursors sit
+    // on separate 128-byte lines: a single cursor would serialise every insert in L2 (~14 ns each, i.e. 0.1 s
+    // per 8 M inserts during the warm-up of a 2 M-hash sketch).  k_live_flatten appends the shard lists to
+    // `live` after every sketch launch, so the selection kernels only ever see one flat list.
+    uint32_t *shard_cnt;    // N_SHARDS cursors, stride SHARD_STRIDE dwords
+    uint32_t *shard_buf;    // N_SHARDS x shard_cap slot indices
+    uint32_t shard_soft;    // a shard reaching this many appends raises `stopped`
+    uint32_t pad1;
     // Tile queue of the current range (dynamic scheduling; survives a stopped launch).  Every wave hits
     // these two words once per pull, and same-line atomics serialise in L2 (~12-16 ns each), so each gets a
     // 128-byte line of its own, away from n_live / tau that the admit path updates.
@@ -68,6 +76,8 @@ constexpr int LANE_POS = 32;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int SMALL_MAX = 8192;  // live entries the single-workgroup prune can sort in LDS
 constexpr int MAX_PROBE = 4096;
+constexpr int N_SHARDS = 256;
+constexpr int SHARD_STRIDE = 32; // dwords between shard cursors (one 128-byte line each)
 #ifndef FH_UNIT_TILES
 #define FH_UNIT_TILES 2
 #endif

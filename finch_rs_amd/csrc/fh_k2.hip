@@ -59,7 +59,7 @@ __device__ __forceinline__ void log_collision(const TableRef a, u64 h, u64 kmer,
     }
 }
 
-__device__ __noinline__ u32 upsert(Ctl *ctl, u64 h, u64 kmer, u64 pos, u32 strand) {
+__device__ __noinline__ u32 upsert(Ctl *ctl, u64 h, u64 kmer, u64 pos, u32 strand, u32 shard) {
     typedef unsigned long long ull;
     const TableRef a{ctl->table, ctl->live, ctl, ctl->clog, ctl->cap, ctl->live_cap, ctl->clog_cap};
     if (h == EMPTY64) { // the one value that cannot be a table key
@@ -78,10 +78,11 @@ __device__ __noinline__ u32 upsert(Ctl *ctl, u64 h, u64 kmer, u64 pos, u32 stran
     for (; probe < MAX_PROBE; ++probe) {
         ull old = atomicCAS((ull *)&a.table[slot].hash, (ull)EMPTY64, (ull)h);
         if (old == EMPTY64) {
-            u32 idx = atomicAdd(&a.ctl->n_live, 1u);
-            if (idx < a.live_cap) a.live[idx] = slot;
+            // remember the slot: append to this wave's shard list (flattened into `live` after the launch)
+            const u32 idx = atomicAdd(&ctl->shard_cnt[shard * (u32)SHARD_STRIDE], 1u);
+            if (idx < ctl->shard_cap) ctl->shard_buf[(size_t)shard * ctl->shard_cap + idx] = slot;
             else atomicExch(&a.ctl->overflow, 1u);
-            if (idx + 1u == a.ctl->soft_limit) atomicExch(&a.ctl->stopped, 1u); // live set full enough: drain & prune
+            if (idx + 1u == ctl->shard_soft) atomicExch(&a.ctl->stopped, 1u); // live set full enough: drain & prune
             inserted = 1u;
             break;
         }
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
             if (__builtin_expect(h <= tau, 0)) {
                 u32 ins = 0u;
                 if ((W >> j) & 1u)
-                    ins = upsert(a.ctl, h, cm, a.base_pos + lane_pos0 + (u64)j, is_rc ? 1u : 0u);
+                    ins = upsert(a.ctl, h, cm, a.base_pos + lane_pos0 + (u64)j, is_rc ? 1u : 0u, gw & (u32)(N_SHARDS - 1));
                 lane_inserts += ins;
             }
         }

@@ -31,7 +31,8 @@ hipError_t launch_rehash(const Entry *src, const uint32_t *src_live, uint32_t M,
 hipError_t launch_fill_table(Entry *table, uint64_t cap, hipStream_t st);
 hipError_t launch_init_ctl(Ctl *ctl, uint64_t tau0, hipStream_t st);
 hipError_t launch_set_table(Ctl *ctl, Entry *table, uint32_t *live, CollRec *clog, uint32_t cap, uint32_t live_cap,
-                            uint32_t clog_cap, hipStream_t st);
+                            uint32_t clog_cap, uint32_t *shard_cnt, uint32_t *shard_buf, uint32_t shard_cap, hipStream_t st);
+hipError_t launch_live_flatten(Ctl *ctl, hipStream_t st);
 hipError_t launch_queue_reset(Ctl *ctl, uint32_t new_range, uint32_t soft_limit, hipStream_t st);
 hipError_t launch_synth_genome(uint8_t *out, uint64_t len, uint64_t seed, hipStream_t st);
 hipError_t launch_synth_reads(uint8_t *out, const uint8_t *genome, uint64_t genome_len, uint64_t first_read,

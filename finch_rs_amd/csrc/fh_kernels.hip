@@ -207,7 +207,8 @@ hipError_t launch_clear_slots(Entry *table, u64 cap, const u32 *live, const u32 
     return hipGetLastError();
 }
 
-__global__ void k_set_table(Ctl *ctl, Entry *table, u32 *live, CollRec *clog, u32 cap, u32 live_cap, u32 clog_cap) {
+__global__ void k_set_table(Ctl *ctl, Entry *table, u32 *live, CollRec *clog, u32 cap, u32 live_cap, u32 clog_cap,
+                            u32 *shard_cnt, u32 *shard_buf, u32 shard_cap) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         ctl->table = table;
         ctl->live = live;
@@ -215,13 +216,67 @@ __global__ void k_set_table(Ctl *ctl, Entry *table, u32 *live, CollRec *clog, u3
         ctl->cap = cap;
         ctl->live_cap = live_cap;
         ctl->clog_cap = clog_cap;
+        ctl->shard_cnt = shard_cnt;
+        ctl->shard_buf = shard_buf;
+        ctl->shard_cap = shard_cap;
         ctl->pad1 = 0;
     }
+    for (int i = threadIdx.x; i < N_SHARDS; i += blockDim.x) shard_cnt[i * SHARD_STRIDE] = 0;
 }
 
 hipError_t launch_set_table(Ctl *ctl, Entry *table, u32 *live, CollRec *clog, u32 cap, u32 live_cap, u32 clog_cap,
-                            hipStream_t st) {
-    hipLaunchKernelGGL(k_set_table, dim3(1), dim3(64), 0, st, ctl, table, live, clog, cap, live_cap, clog_cap);
+                            u32 *shard_cnt, u32 *shard_buf, u32 shard_cap, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_table, dim3(1), dim3(256), 0, st, ctl, table, live, clog, cap, live_cap, clog_cap, shard_cnt,
+                       shard_buf, shard_cap);
+    return hipGetLastError();
+}
+
+// Append the per-shard lists of newly inserted slots to the flat live list (block s copies shard s), then
+// k_live_commit publishes the new length and rewinds the shard cursors.
+__global__ __launch_bounds__(256) void k_live_flatten(Ctl *ctl) {
+    __shared__ u32 s_pre, s_cnt;
+    const u32 s = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        s_pre = 0;
+        s_cnt = 0;
+    }
+    __syncthreads();
+    u32 c = tid < (u32)N_SHARDS ? ctl->shard_cnt[tid * SHARD_STRIDE] : 0u;
+    if (c > ctl->shard_cap) c = ctl->shard_cap; // overflow already flagged by the inserter
+    if (tid < s) atomicAdd(&s_pre, c);
+    if (tid == s) s_cnt = c;
+    __syncthreads();
+    const u32 base = ctl->n_live + s_pre, n = s_cnt;
+    u32 *live = ctl->live;
+    const u32 *src = ctl->shard_buf + (size_t)s * ctl->shard_cap;
+    const u32 live_cap = ctl->live_cap;
+    for (u32 i = tid; i < n; i += blockDim.x) {
+        if (base + i < live_cap) live[base + i] = src[i];
+        else atomicExch(&ctl->overflow, 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_live_commit(Ctl *ctl) {
+    __shared__ u32 s_tot;
+    const u32 tid = threadIdx.x;
+    if (tid == 0) s_tot = 0;
+    __syncthreads();
+    u32 c = tid < (u32)N_SHARDS ? ctl->shard_cnt[tid * SHARD_STRIDE] : 0u;
+    if (c > ctl->shard_cap) c = ctl->shard_cap;
+    if (c) atomicAdd(&s_tot, c);
+    __syncthreads();
+    if (tid < (u32)N_SHARDS) ctl->shard_cnt[tid * SHARD_STRIDE] = 0;
+    if (tid == 0 && s_tot) {
+        u32 n = ctl->n_live + s_tot;
+        if (n > ctl->live_cap) n = ctl->live_cap;
+        ctl->n_live = n;
+        ctl->sorted = 0;
+    }
+}
+
+hipError_t launch_live_flatten(Ctl *ctl, hipStream_t st) {
+    hipLaunchKernelGGL(k_live_flatten, dim3(N_SHARDS), dim3(256), 0, st, ctl);
+    hipLaunchKernelGGL(k_live_commit, dim3(1), dim3(256), 0, st, ctl);
     return hipGetLastError();
 }
 
@@ -257,6 +312,7 @@ __global__ void k_init_ctl(Ctl *ctl, u64 tau0) {
         ctl->n_left_out = 0;
         ctl->stopped = 0;
         ctl->soft_limit = 0xFFFFFFFFu;
+        ctl->shard_soft = 0xFFFFFFFFu;
         ctl->pad2 = 0;
         ctl->sp_count = 0;
         ctl->sp_extra = 0;
@@ -273,8 +329,13 @@ __global__ void k_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit) {
         ctl->left_in_pos = 0;
         ctl->n_left_out = 0;
         ctl->soft_limit = soft_limit;
+        // inserts are spread over N_SHARDS lists: stop when one of them has taken its share of the room
+        const u32 nl = ctl->n_live;
+        const u32 room = soft_limit > nl ? soft_limit - nl : 0u;
+        u32 share = room / (u32)N_SHARDS;
+        ctl->shard_soft = share ? share : 1u;
         // the live set may already sit at/above the limit (nothing pruned since): stop at once
-        ctl->stopped = ctl->n_live >= soft_limit ? 1u : 0u;
+        ctl->stopped = nl >= soft_limit ? 1u : 0u;
     }
 }
 
