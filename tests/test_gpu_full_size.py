@@ -22,9 +22,10 @@ K, N = 21, 1000
 
 
 def _oracle_shard(args):
-    genome, first, count = args
+    genome, first, count = args[:3]
+    k, n = (args[3], args[4]) if len(args) > 3 else (K, N)
     reads = S.synth_reads_host(genome, first, count, RL, SEED, 10000, 500)  # same generator as the device (tested equal)
-    o = O.OracleSketcher(O.MASH, N, K, 0)
+    o = O.OracleSketcher(O.MASH, n, k, 0)
     o.process_packed(reads, 0)
     kc, km = o.to_vec()
     return kc, km, o.total_bases_and_kmers()[1]
@@ -90,3 +91,46 @@ def test_full_size_stream_bit_exact_vs_sharded_oracle():
     a.merge(b)
     m = a.to_arrays()
     assert np.array_equal(m[0], kc) and np.array_equal(m[1], km) and a.finish()[1] == tk
+
+
+def test_config3_oversketch_and_filtering_vs_sharded_oracle():
+    """BASELINE.json configs[2] shape: k=31, final 10 000 hashes, kmers_to_sketch = 2 000 000 (CLI oversketch x200,
+    cli.rs:187-192), strand filter 0.1, err filter 1% -> 0.31 (cli.rs:264-265), filtering on the host.
+    Default 2 Gbase (FH_FULL_GBASES_C3 to change): device sketch of 2 M hashes bit-exact vs the sharded oracle,
+    then filter_counts + process_post_filter through the C++ host layer vs the oracle's filters."""
+    from finch_rs_amd import host as H
+    gbases = float(os.environ.get("FH_FULL_GBASES_C3", "2"))
+    ncpu = max(1, min(len(os.sched_getaffinity(0)), 64))
+    if ncpu < 16 and "FH_FULL_GBASES_C3" not in os.environ:
+        gbases = 0.2
+    k, n_eff, final = 31, 2_000_000, 10_000
+    n_reads = int(np.ceil(gbases * 1e9 / RL))
+    rec = RL + 1
+    dg = F.DeviceBuffer(GL)
+    dr = F.DeviceBuffer(n_reads * rec + 64)
+    S.synth_genome_device(dg, GL, SEED)
+    S.synth_reads_device(dr, dg, GL, 0, n_reads, RL, SEED, 10000, 500)
+    params = F.SketchParams.mash(n_eff, final, False, k, 0)
+    sk = params.create_sketcher()
+    sk.push_device(dr.ptr, n_reads * rec)
+    kc, km, _ = sk.to_arrays()
+    tk = sk.finish()[1]
+    genome = S.synth_genome_host(GL, SEED)
+    shards = min(ncpu, 32)
+    bounds = np.linspace(0, n_reads, shards + 1).astype(np.int64)
+    jobs = [(genome, int(bounds[i]), int(bounds[i + 1] - bounds[i]), k, n_eff) for i in range(shards)]
+    with mp.get_context("fork").Pool(shards) as pool:
+        parts = pool.map(_oracle_shard, jobs, chunksize=1)
+    okc, okm, otk = merge_numpy(parts, n_eff)
+    assert np.array_equal(kc, okc) and np.array_equal(km, okm) and tk == otk
+    # host filtering (N1) on the device output
+    filt = H.FilterParams(True, (None, None), 0.31, 0.1)
+    res = H.sketches_from_arrays("c3", n_reads * RL, tk, kc, km, params, H.FilterParams(False))
+    fp = res.apply_filters(0, filt)
+    got = res.sketch(0)
+    a, ak = O.filter_strands(okc, okm, 0.1)
+    cutoff = O.guess_filter_threshold(a, 0.31)
+    b, bk = O.filter_abundance(a, ak, cutoff, None)
+    assert fp.abun_filter == (cutoff, None)
+    assert len(got.hashes) == final
+    assert np.array_equal(got.arrays[0], b[:final]) and np.array_equal(got.arrays[1], bk[:final])
