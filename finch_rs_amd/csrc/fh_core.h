@@ -79,13 +79,10 @@ FH_HD void classify4(u32 d, u32 &q8, u32 &good4) {
     // per byte: bit 7 set iff diff byte != 0
     u32 nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;
     u32 ok = nz ^ 0x80808080u; // bit 7 of byte i set iff good
-    u32 t = code | (code >> 6);
-    t = t | (t >> 12);
-    q8 = t & 0xFFu;
-    u32 g = ok >> 7; // bits 0,8,16,24
-    g = g | (g >> 7);
-    g = g | (g >> 14);
-    good4 = g & 0xFu;
+    // gather the four 2-bit codes / four flag bits with one multiply each: the partial products land on
+    // disjoint bits, the wanted ones adjacent at the top of the word
+    q8 = (code * 0x01041040u) >> 24;    // c0@24 c1@26 c2@28 c3@30
+    good4 = (ok * 0x00204081u) >> 28;   // b0@28 b1@29 b2@30 b3@31
 }
 
 // 16 bytes (4 dwords, little endian) -> 16 codes (32 bits, l-form) + 16 good bits
@@ -150,6 +147,22 @@ constexpr GroupGeom group_geom(int K, int g) {
 // the constant the partial (last, nb<4) group is multiplied by
 constexpr u64 partial_const(int K) { return group_geom(K, (K + 3) / 4 - 1).is_k2 ? MURMUR_C2 : MURMUR_C1; }
 constexpr int partial_nb(int K) { return K & 3; }
+
+// K = 4m+1 with the last full 4-base group in the low half of its 64-bit key word: that group and the single
+// trailing base are five consecutive key bytes of ONE word, so one 1024-entry table replaces two lookups.
+constexpr bool tail_merge5(int K) { return (K & 3) == 1 && K >= 5 && group_geom(K, (K + 3) / 4 - 1).hi; }
+
+// ASCII bytes of a 5-base group (m-form, first base in byte 0) as a 40-bit value
+FH_HD u64 ascii_group5(u32 q) {
+    u64 w = 0;
+    for (int i = 0; i < 5; ++i) {
+        u32 code = (q >> (2 * (4 - i))) & 3u;
+        u64 ch = code == 0 ? 0x41u : code == 1 ? 0x43u : code == 2 ? 0x47u : 0x54u;
+        w |= ch << (8 * i);
+    }
+    return w;
+}
+FH_HD u64 lut_entry5(u32 q, u64 c) { return ascii_group5(q) * c; }
 
 // Table entry builders (run once per workgroup into LDS / once on the host for tests)
 FH_HD u64 lut_entry(u32 q, int nb, u64 c) { return (u64)ascii_group(q, nb) * c; }
@@ -330,9 +343,12 @@ FH_HD u64 mul64c(U64H a, u64 C) {
 
 // murmurhash3_x64_128(ascii(canonical k-mer), seed).0 from the m-form canonical word, 32-bit split tables.
 // SEED0: compile-time knowledge that seed == 0 (the default; drops three 64-bit ops).
+// T5 (only if tail_merge5(K)): [0..1023] = lo, [1024..2047] = hi of ascii_group5 * partial_const(K)
 template <int K, bool SEED0>
-FH_HD u64 murmur_h1_fast(u64 cm, u64 seed, const u32 *TQ, const u32 *TP) {
-    constexpr int NB = K / 16, TAIL = K & 15, NG = (K + 3) / 4;
+FH_HD u64 murmur_h1_fast(u64 cm, u64 seed, const u32 *TQ, const u32 *TP, const u32 *T5) {
+    constexpr int NB = K / 16, TAIL = K & 15, NG_ALL = (K + 3) / 4;
+    constexpr bool M5 = tail_merge5(K);
+    constexpr int NG = M5 ? NG_ALL - 2 : NG_ALL; // groups looked up one by one
     const u32 cml = (u32)cm, cmh = (u32)(cm >> 32);
     u32 wl[2 * NB + 2], wh[2 * NB + 2];
 #if defined(__HIPCC__)
@@ -362,6 +378,12 @@ FH_HD u64 murmur_h1_fast(u64 cm, u64 seed, const u32 *TQ, const u32 *TP) {
             wl[gg.word] += plo; // at most one lo-half group per word: no carry
             wh[gg.word] += phi;
         }
+    }
+    if (M5) {
+        const GroupGeom gq = group_geom(K, NG_ALL - 2); // the lo-half quad; the merged group ends at bit 0
+        const u32 idx4 = (cml & 0x3FFu) << 2;
+        wl[gq.word] += *(const u32 *)((const char *)T5 + idx4);
+        wh[gq.word] += *(const u32 *)((const char *)(T5 + 1024) + idx4);
     }
     u64 h1 = seed, h2 = seed;
 #if defined(__HIPCC__)

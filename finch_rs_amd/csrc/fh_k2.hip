@@ -140,6 +140,7 @@ template <int K, bool MASKED, bool SEED0>
 __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs a) {
     __shared__ __attribute__((aligned(16))) u32 sTQ[1024];  // lo/hi(ascii4*c1), lo/hi(ascii4*c2)
     __shared__ __attribute__((aligned(16))) u32 sTP[128];   // lo/hi(partial group * its constant)
+    __shared__ __attribute__((aligned(16))) u32 sT5[tail_merge5(K) ? 2048 : 4]; // lo/hi(5-base tail group * its constant)
     __shared__ __attribute__((aligned(16))) u32 sCodes[WAVES_PER_BLOCK][256];
     __shared__ __attribute__((aligned(16))) u32 sGood[WAVES_PER_BLOCK][128];
 
@@ -155,6 +156,13 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
             const u64 ep = (PNB != 0 && tid < (1 << (2 * PNB))) ? lut_entry((u32)tid, PNB, partial_const(K)) : 0ull;
             sTP[tid] = (u32)ep;
             sTP[64 + tid] = (u32)(ep >> 32);
+        }
+        if (tail_merge5(K)) {
+            for (int q = tid; q < 1024; q += 256) {
+                const u64 e5 = lut_entry5((u32)q, partial_const(K));
+                sT5[q] = (u32)e5;
+                sT5[1024 + q] = (u32)(e5 >> 32);
+            }
         }
     }
     __syncthreads();
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
             roll.push(c);
             bool is_rc;
             const u64 cm = roll.canonical(is_rc);
-            u64 h = murmur_h1_fast<K, SEED0>(cm, a.seed, sTQ, sTP);
+            u64 h = murmur_h1_fast<K, SEED0>(cm, a.seed, sTQ, sTP, sT5);
             if (MASKED) h &= a.hash_mask; // test hook only
             // windows that carry no k-mer hash garbage; they are rejected on the (rare) admit path only
             if (__builtin_expect(h <= tau, 0)) {

@@ -30,6 +30,13 @@ static int run(const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hashes
             TP[q] = lut_entry(q, pnb, partial_const(K));
             TP32[q] = (u32)TP[q]; TP32[64 + q] = (u32)(TP[q] >> 32);
         }
+    std::vector<u32> T5(2048, 0);
+    if (tail_merge5(K))
+        for (u32 q = 0; q < 1024; ++q) {
+            const u64 e = lut_entry5(q, partial_const(K));
+            T5[q] = (u32)e;
+            T5[1024 + q] = (u32)(e >> 32);
+        }
     for (uint64_t s = 0; s < len; s += 32) {
         u32 cw[4], gw[4];
         for (int c = 0; c < 4; ++c) {
@@ -54,9 +61,9 @@ static int run(const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hashes
             isrc[p] = rc ? 1 : 0;
             canon[p] = cm;
             const u64 h_ref = murmur_h1_lut<K>(cm, seed, T1.data(), T2.data(), TP.data());
-            const u64 h_fast = murmur_h1_fast<K, false>(cm, seed, TQ.data(), TP32.data());
+            const u64 h_fast = murmur_h1_fast<K, false>(cm, seed, TQ.data(), TP32.data(), T5.data());
             if (h_fast != h_ref) return -2;
-            if (seed == 0 && murmur_h1_fast<K, true>(cm, 0, TQ.data(), TP32.data()) != h_ref) return -3;
+            if (seed == 0 && murmur_h1_fast<K, true>(cm, 0, TQ.data(), TP32.data(), T5.data()) != h_ref) return -3;
             hashes[p] = h_fast;
         }
     }
