@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--cpu-sample-mbases", type=float, default=450.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-launch", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="debug: map every rank to cuda:0 (with --backend gloo) to exercise the N>1 flow on a 1-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -61,12 +64,18 @@ def main():
 
     if not torch.cuda.is_available() or F.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libfinch_hip has no CPU path")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    gather_device = "cuda" if args.backend == "nccl" else None
 
     def barrier():
         if dist is not None:
@@ -100,7 +109,7 @@ def main():
         if dist is not None:
             # partial sketches are <= n records: ship them to rank 0 (one small fixed-size tensor per rank)
             # and merge on the host, O(N*n) -- finch_rs_amd/sharding.py
-            merged = SH.gather_and_merge(dist, params, (kc, km, pos, tk), args.n, device="cuda")
+            merged = SH.gather_and_merge(dist, params, (kc, km, pos, tk), args.n, device=gather_device)
             if rank == 0:
                 gathered = merged[:3]
         else:
@@ -119,7 +128,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -140,7 +149,8 @@ def main():
                 "alg_bytes_per_launch": int(kernel_pos / max(kernel_launches, 1)),
                 "note": "integer-ALU bound by construction (7 64-bit multiplies per k-mer); see DESIGN.md"}
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(prof):
+    # the committed PMC figure was collected on exactly the default workload; do not attach it to another one
+    if os.path.exists(prof) and (args.gbases, args.k, args.n, world) == (10.0, 21, 1000, 1):
         try:
             roofline["traffic"] = json.load(open(prof)).get("k2_hbm_bytes_per_launch")
         except Exception:

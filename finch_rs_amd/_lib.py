@@ -15,7 +15,7 @@ KIND_MASH, KIND_SCALED = 0, 1
 
 class FhParams(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("k", C.c_uint32), ("size", C.c_uint64), ("seed", C.c_uint64),
-                ("scale", C.c_double), ("max_launch", C.c_uint64), ("hash_mask", C.c_uint64)]
+                ("scale", C.c_double), ("max_launch", C.c_uint64), ("hash_mask", C.c_uint64), ("stage_bytes", C.c_uint64)]
 
 
 class FinchHipError(RuntimeError):

@@ -46,11 +46,12 @@ constexpr uint64_t DEFAULT_MAX_LAUNCH = 256ull * 32 * TILE_POS; // k-mer start p
 constexpr uint64_t FIRST_LAUNCH = 4096;
 constexpr uint64_t SMALL_N_MAX = 3000; // largest kmers_to_sketch served by the in-LDS selection alone
 constexpr uint32_t CLOG_CAP = 65536;
-const uint64_t STAGE_BYTES = [] {
+const uint64_t STAGE_BYTES_ENV = [] {
     const char *e = getenv("FH_STAGE_BYTES"); // test knob: force blocks to span staging slices
     const uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
-    return v >= 4096 ? v : (64ull << 20);
+    return v >= 4096 ? v : 0ull;
 }();
+constexpr uint64_t STAGE_BYTES_DEFAULT = 64ull << 20;
 constexpr int N_STAGE = 2;
 
 struct ResultRec {
@@ -112,6 +113,7 @@ struct fh_sketcher {
     hipEvent_t stage_done[N_STAGE] = {nullptr, nullptr};
     bool stage_busy[N_STAGE] = {false, false};
     int stage_next = 0;
+    uint64_t stage_bytes = 0;
     uint8_t carry[32] = {0}; // last K-1 staged bytes: k-mers span staging slices (and FH_PUSH_CONTINUE pushes)
     uint32_t carry_len = 0;
     Ctl *h_ctl = nullptr; // pinned
@@ -569,6 +571,7 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
     s->p = *params;
     s->device = device;
     s->max_hash = params->kind == FH_KIND_SCALED ? scaled_max_hash(params->scale) : 0;
+    s->stage_bytes = STAGE_BYTES_ENV ? STAGE_BYTES_ENV : (params->stage_bytes >= 4096 ? params->stage_bytes : STAGE_BYTES_DEFAULT);
     s->max_launch = params->max_launch ? params->max_launch : DEFAULT_MAX_LAUNCH;
     s->max_launch = std::max<uint64_t>((s->max_launch / TILE_POS) * TILE_POS, FIRST_LAUNCH);
     if (s->max_launch > (1ull << 30)) s->max_launch = 1ull << 30;
@@ -737,8 +740,8 @@ int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_
     if (int rc = set_device(s)) return rc;
     for (int i = 0; i < N_STAGE; ++i) {
         if (!s->h_stage[i]) {
-            HIP_TRY(hipHostMalloc((void **)&s->h_stage[i], STAGE_BYTES + 64, hipHostMallocDefault));
-            HIP_TRY(hipMalloc((void **)&s->d_stage[i], STAGE_BYTES + 64));
+            HIP_TRY(hipHostMalloc((void **)&s->h_stage[i], s->stage_bytes + 64, hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void **)&s->d_stage[i], s->stage_bytes + 64));
             HIP_TRY(hipEventCreateWithFlags(&s->stage_done[i], hipEventDisableTiming));
         }
     }
@@ -757,7 +760,7 @@ int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_
         const uint32_t carry_len = s->carry_len;
         memcpy(dst, s->carry, carry_len);
         uint64_t consumed = 0;
-        const uint64_t fresh = strip_copy(dst + carry_len, bytes + in, len - in, STAGE_BYTES - carry_len, &consumed);
+        const uint64_t fresh = strip_copy(dst + carry_len, bytes + in, len - in, s->stage_bytes - carry_len, &consumed);
         in += consumed;
         const uint64_t m = carry_len + fresh;
         const uint64_t base = s->stream_off - carry_len;

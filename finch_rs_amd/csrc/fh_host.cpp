@@ -478,7 +478,7 @@ static int parse_fastx(ByteSource &src, RecordSink &sink, FastxStats &st) {
 // ---------------------------------------------------------------------------------------------
 // sketch_stream (lib.rs:51-94)
 // ---------------------------------------------------------------------------------------------
-static fh_params to_fh(const finch_sketch_params &sp, uint64_t max_launch) {
+static fh_params to_fh(const finch_sketch_params &sp, uint64_t max_launch, uint64_t stage_bytes = 0) {
     fh_params p{};
     p.kind = sp.kind;
     p.k = sp.kmer_length;
@@ -487,6 +487,7 @@ static fh_params to_fh(const finch_sketch_params &sp, uint64_t max_launch) {
     p.scale = sp.scale;
     p.max_launch = max_launch;
     p.hash_mask = 0;
+    p.stage_bytes = stage_bytes;
     return p;
 }
 
@@ -754,9 +755,12 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
     uint32_t first_err_idx = UINT32_MAX;
     std::string first_err_msg;
     // lib.rs:34-36: par_iter over the files; here one worker = one device sketcher reused across its files
-    const uint64_t ml = env_max_launch() ? env_max_launch() : (n_files > 1 ? (16ull << 20) : 0ull);
+    // many files: one modest sketcher per worker (2 M positions in flight, 16 MiB staging) instead of one
+    // sized for a 10 Gbase stream
+    const bool batch = n_files > 1;
+    const uint64_t ml = env_max_launch() ? env_max_launch() : (batch ? (2ull << 20) : 0ull);
     auto worker = [&](uint32_t w) {
-        fh_params p = to_fh(*sp, ml);
+        fh_params p = to_fh(*sp, ml, batch ? (16ull << 20) : 0ull);
         fh_sketcher *h = nullptr;
         for (;;) {
             const uint32_t i = next.fetch_add(1);

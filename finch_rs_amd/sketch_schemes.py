@@ -85,11 +85,11 @@ class HipSketcher:
     """`impl SketchScheme` over the C ABI: MashSketcher (mash.rs) / ScaledSketcher (scaled.rs) on the GPU."""
 
     def __init__(self, kind: int, size: int, kmer_length: int, seed: int, scale: float = 0.001, device: int = 0,
-                 max_launch: int = 0, hash_mask: int = 0):
+                 max_launch: int = 0, hash_mask: int = 0, stage_bytes: int = 0):
         self._L = _lib.load()
         self.kind, self.size, self.kmer_length, self.seed, self.scale = kind, size, kmer_length, seed, scale
         self.device = device
-        p = FhParams(kind, kmer_length, size, seed, scale, max_launch, hash_mask)
+        p = FhParams(kind, kmer_length, size, seed, scale, max_launch, hash_mask, stage_bytes)
         self._h = self._L.fh_new(C.byref(p), device)
         if not self._h:
             raise FinchHipError(-1, (self._L.fh_last_error() or b"").decode(errors="replace"))
