@@ -37,6 +37,9 @@ SYMBOLS = {
     "fh_set_stream_offset": (C.c_int, [_P, C.c_uint64]),
     "fh_push_block": (C.c_int, [_P, _P, C.c_uint64]),
     "fh_push_block_ex": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32]),
+    "fh_text_buffer": (C.c_int, [_P, C.POINTER(_P), _U64P]),
+    "fh_push_fastq_text": (C.c_int, [_P, C.c_uint64]),
+    "fh_text_bases": (C.c_int, [_P, _U64P]),
     "fh_push_device": (C.c_int, [_P, _P, C.c_uint64]),
     "fh_sync": (C.c_int, [_P]),
     "fh_finish": (C.c_int, [_P, _U64P, _U64P]),

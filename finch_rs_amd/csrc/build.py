@@ -21,7 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 FLAGS += os.environ.get("FH_EXTRA_FLAGS", "").split()
 OUT = os.environ.get("FH_OUT", OUT)
 
-SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2.hip", "fh_kernels.hip", "fh_big.hip", "fh_api.hip", "fh_host.cpp", os.path.join("..", "..", "include", "finch_host.h"),
+SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2.hip", "fh_kernels.hip", "fh_big.hip", "fh_text.hip", "fh_api.hip", "fh_host.cpp", os.path.join("..", "..", "include", "finch_host.h"),
            os.path.join("..", "..", "include", "finch_hip.h")]
 
 
@@ -45,6 +45,7 @@ def build(force=False, verbose=False):
         jobs.append([HIPCC] + FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2.hip", "-o", os.path.join(OBJ, "fh_k2_%d.o" % part)])
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_kernels.hip", "-o", os.path.join(OBJ, "fh_kernels.o")])
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_big.hip", "-o", os.path.join(OBJ, "fh_big.o")])
+    jobs.append([HIPCC] + FLAGS + ["-c", "fh_text.hip", "-o", os.path.join(OBJ, "fh_text.o")])
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_api.hip", "-o", os.path.join(OBJ, "fh_api.o")])
     jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-c", "fh_host.cpp", "-o", os.path.join(OBJ, "fh_host.o")])
     with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:

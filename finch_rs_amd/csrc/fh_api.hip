@@ -114,6 +114,12 @@ struct fh_sketcher {
     bool stage_busy[N_STAGE] = {false, false};
     int stage_next = 0;
     uint64_t stage_bytes = 0;
+    // device-side FASTQ packing (fh_text.hip): packed output + block scan scratch per staging slot
+    uint8_t *d_packed[N_STAGE] = {nullptr, nullptr};
+    uint32_t *d_blk_a[N_STAGE] = {nullptr, nullptr}, *d_blk_b[N_STAGE] = {nullptr, nullptr};
+    uint32_t *d_text_tot = nullptr; // [0] newlines, [1] packed bytes, [2] error flag
+    uint32_t *h_text_tot = nullptr; // pinned
+    uint64_t text_bases = 0;
     uint8_t carry[32] = {0}; // last K-1 staged bytes: k-mers span staging slices (and FH_PUSH_CONTINUE pushes)
     uint32_t carry_len = 0;
     Ctl *h_ctl = nullptr; // pinned
@@ -651,7 +657,12 @@ void fh_free(fh_sketcher *s) {
         if (s->h_stage[i]) (void)hipHostFree(s->h_stage[i]);
         if (s->d_stage[i]) (void)hipFree(s->d_stage[i]);
         if (s->stage_done[i]) (void)hipEventDestroy(s->stage_done[i]);
+        (void)hipFree(s->d_packed[i]);
+        (void)hipFree(s->d_blk_a[i]);
+        (void)hipFree(s->d_blk_b[i]);
     }
+    (void)hipFree(s->d_text_tot);
+    if (s->h_text_tot) (void)hipHostFree(s->h_text_tot);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     (void)hipFree(s->left_buf[0]);
     (void)hipFree(s->left_buf[1]);
@@ -734,17 +745,13 @@ static inline uint64_t strip_copy(uint8_t *dst, const uint8_t *src, uint64_t n, 
     return m;
 }
 
+static int ensure_stage(fh_sketcher *s);
+
 int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_t flags) {
     if (!s || (!bytes && len)) return fail(FH_ERR_INVALID, "null argument");
     if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
     if (int rc = set_device(s)) return rc;
-    for (int i = 0; i < N_STAGE; ++i) {
-        if (!s->h_stage[i]) {
-            HIP_TRY(hipHostMalloc((void **)&s->h_stage[i], s->stage_bytes + 64, hipHostMallocDefault));
-            HIP_TRY(hipMalloc((void **)&s->d_stage[i], s->stage_bytes + 64));
-            HIP_TRY(hipEventCreateWithFlags(&s->stage_done[i], hipEventDisableTiming));
-        }
-    }
+    if (int rc = ensure_stage(s)) return rc;
     // normalize(false) drops whitespace (needletail; mash.rs:73): strip it while staging so that device
     // positions are contiguous.  k-mers may span staging slices of one block: carry K-1 bytes over.
     const uint32_t K = s->p.k;
@@ -776,6 +783,77 @@ int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_
             s->stage_next = (b + 1) % N_STAGE;
         }
     }
+    return FH_OK;
+}
+
+static int ensure_stage(fh_sketcher *s) {
+    for (int i = 0; i < N_STAGE; ++i) {
+        if (!s->h_stage[i]) {
+            HIP_TRY(hipHostMalloc((void **)&s->h_stage[i], s->stage_bytes + 64, hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void **)&s->d_stage[i], s->stage_bytes + 64));
+            HIP_TRY(hipEventCreateWithFlags(&s->stage_done[i], hipEventDisableTiming));
+        }
+    }
+    return FH_OK;
+}
+
+int fh_text_buffer(fh_sketcher *s, uint8_t **buf, uint64_t *cap) {
+    if (!s || !buf || !cap) return fail(FH_ERR_INVALID, "null argument");
+    if (int rc = set_device(s)) return rc;
+    if (int rc = ensure_stage(s)) return rc;
+    const int b = s->stage_next;
+    if (s->stage_busy[b]) {
+        HIP_TRY(hipEventSynchronize(s->stage_done[b]));
+        s->stage_busy[b] = false;
+    }
+    *buf = s->h_stage[b];
+    *cap = s->stage_bytes;
+    return FH_OK;
+}
+
+int fh_push_fastq_text(fh_sketcher *s, uint64_t len) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    if (len > s->stage_bytes) return fail(FH_ERR_INVALID, "text longer than the staging buffer");
+    if (int rc = set_device(s)) return rc;
+    if (int rc = ensure_stage(s)) return rc;
+    if (len == 0) return FH_OK;
+    const int b = s->stage_next;
+    const uint64_t nblk = (s->stage_bytes + 4095) / 4096 + 1;
+    if (!s->d_packed[b]) {
+        HIP_TRY(hipMalloc((void **)&s->d_packed[b], s->stage_bytes + 64));
+        HIP_TRY(hipMalloc((void **)&s->d_blk_a[b], nblk * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&s->d_blk_b[b], nblk * sizeof(uint32_t)));
+    }
+    if (!s->d_text_tot) {
+        HIP_TRY(hipMalloc((void **)&s->d_text_tot, 4 * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc((void **)&s->h_text_tot, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    // the packed buffer of this slot may still feed a pending range
+    if (int rc = drain(s)) return rc;
+    HIP_TRY(hipMemsetAsync(s->d_text_tot, 0, 4 * sizeof(uint32_t), s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_stage[b], s->h_stage[b], len, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+    s->stage_busy[b] = true;
+    HIP_TRY(launch_fastq_pack(s->d_stage[b], len, s->d_packed[b], s->d_blk_a[b], s->d_blk_b[b], s->d_text_tot, s->ctl,
+                              s->d_text_tot + 2, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_text_tot, s->d_text_tot, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->h_text_tot[2]) return fail(FH_ERR_INVALID, "not plain 4-line FASTQ text (header without '@' or separator without '+')");
+    const uint64_t n_packed = s->h_text_tot[1];
+    s->stage_next = (b + 1) % N_STAGE;
+    s->carry_len = 0; // every sequence line ends with its breaker: nothing spans chunks
+    const int rc = sketch_device_range(s, s->d_packed[b], n_packed, s->stream_off);
+    s->stream_off += n_packed;
+    return rc;
+}
+
+int fh_text_bases(fh_sketcher *s, uint64_t *total_bases) {
+    if (!s || !total_bases) return fail(FH_ERR_INVALID, "null argument");
+    if (int rc = set_device(s)) return rc;
+    if (int rc = drain(s)) return rc;
+    if (int rc = check_ctl(s)) return rc;
+    *total_bases = s->h_ctl->text_bases;
     return FH_OK;
 }
 

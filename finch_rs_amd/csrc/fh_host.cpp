@@ -248,7 +248,8 @@ struct GzSource : ByteSource {
 };
 
 // needletail parse_fastx_reader: sniff two magic bytes (lib.rs:60)
-static int open_source(std::unique_ptr<ByteSource> raw, std::unique_ptr<ByteSource> &out) {
+static int open_source(std::unique_ptr<ByteSource> raw, std::unique_ptr<ByteSource> &out, bool *is_gz = nullptr,
+                       int *first_byte = nullptr) {
     auto pre = std::make_unique<PrefixedSource>();
     pre->prefix.resize(2);
     size_t got = 0;
@@ -262,6 +263,8 @@ static int open_source(std::unique_ptr<ByteSource> raw, std::unique_ptr<ByteSour
     const bool bz = got == 2 && pre->prefix[0] == 0x42 && pre->prefix[1] == 0x5A;
     const bool xz = got == 2 && pre->prefix[0] == 0xFD && pre->prefix[1] == 0x37;
     pre->inner = std::move(raw);
+    if (is_gz) *is_gz = gz;
+    if (first_byte) *first_byte = got ? pre->prefix[0] : -1;
     if (bz || xz)
         return hfail(FH_ERR_UNSUPPORTED, "%s-compressed input: no %s development files in this build", bz ? "bzip2" : "xz",
                      bz ? "libbz2" : "liblzma");
@@ -491,20 +494,84 @@ static fh_params to_fh(const finch_sketch_params &sp, uint64_t max_launch, uint6
     return p;
 }
 
+// Device-side record splitting for plain 4-line FASTQ (fh_push_fastq_text): the host reads raw file bytes straight
+// into the sketcher's pinned staging buffer and only looks for a record boundary near the end of each chunk.
+// A line is a header iff it starts with '@' and the line two below starts with '+' (a quality line may start
+// with '@', but then the line two below is a sequence line).
+static int fastq_text_to_device(ByteSource &src, fh_sketcher *h) {
+    std::vector<uint8_t> left; // tail of the previous chunk after its last complete record
+    bool eof = false;
+    while (!eof || !left.empty()) {
+        uint8_t *buf = nullptr;
+        uint64_t cap = 0;
+        if (int rc = fh_text_buffer(h, &buf, &cap)) return hfail(rc, "%s", fh_last_error());
+        if (left.size() >= cap) return hfail(FH_ERR_INVALID, "FASTQ record longer than the staging buffer");
+        memcpy(buf, left.data(), left.size());
+        size_t fill = left.size();
+        left.clear();
+        while (!eof && fill < cap) {
+            const size_t got = src.read(buf + fill, cap - fill);
+            if (got == 0) eof = true;
+            fill += got;
+        }
+        if (fill == 0) break;
+        size_t cut = fill;
+        if (!eof) {
+            // starts of the last few lines, newest first (a line starts at 0 or right after a '\n')
+            size_t ls[16];
+            int n = 0;
+            size_t pos = fill; // look for newlines in [0, pos)
+            while (n < 16) {
+                const uint8_t *nl = pos > 0 ? (const uint8_t *)memrchr(buf, '\n', pos) : nullptr;
+                const size_t start = nl ? (size_t)(nl - buf) + 1 : 0;
+                if (start < fill) ls[n++] = start; // skip the empty "line" after a trailing newline
+                if (!nl) break;
+                pos = (size_t)(nl - buf);
+            }
+            cut = 0;
+            bool found = false;
+            for (int i = 2; i < n && !found; ++i) { // ls[i] is two lines above ls[i-2]
+                if (buf[ls[i]] == '@' && buf[ls[i - 2]] == '+') {
+                    cut = ls[i];
+                    found = true;
+                }
+            }
+            if (!found) return hfail(FH_ERR_INVALID, "no FASTQ record boundary found in a %zu byte chunk", fill);
+            left.assign(buf + cut, buf + fill);
+        }
+        if (cut)
+            if (int rc = fh_push_fastq_text(h, cut)) return hfail(rc, "%s", fh_last_error());
+        if (eof && left.empty()) break;
+    }
+    if (src.failed()) return hfail(FH_ERR_INVALID, "read error");
+    return FH_OK;
+}
+
 static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &name, const finch_sketch_params &sp,
                          const finch_filter_params &filters, fh_sketcher *h, Sketch &out) {
     std::unique_ptr<ByteSource> src;
-    if (int rc = open_source(std::move(raw), src)) return rc;
+    bool is_gz = false;
+    int first = -1;
+    if (int rc = open_source(std::move(raw), src, &is_gz, &first)) return rc;
     if (int rc = fh_reset(h)) return hfail(rc, "%s", fh_last_error());
-    DeviceSink sink(h);
     FastxStats st;
-    if (int rc = parse_fastx(*src, sink, st)) return rc;
-    if (int rc = sink.flush()) return rc;
+    const char *dp = getenv("FINCH_DEVICE_PARSE");
+    const bool device_parse = dp && dp[0] == '1' && !is_gz && first == '@';
+    if (device_parse) {
+        st.format = 2;
+        if (int rc = fastq_text_to_device(*src, h)) return rc;
+    } else {
+        DeviceSink sink(h);
+        if (int rc = parse_fastx(*src, sink, st)) return rc;
+        if (int rc = sink.flush()) return rc;
+    }
     finch_filter_params fp = filters;
     // lib.rs:70-76: filtering defaults to off for FASTA, on for FASTQ
     if (fp.filter_on < 0) fp.filter_on = st.format == 2 ? 1 : 0;
     uint64_t n = 0, total_kmers = 0;
     if (int rc = fh_finish(h, &n, &total_kmers)) return hfail(rc, "%s", fh_last_error());
+    if (device_parse)
+        if (int rc = fh_text_bases(h, &st.total_bases)) return hfail(rc, "%s", fh_last_error());
     const uint32_t k = sp.kmer_length;
     std::vector<uint64_t> hs(n);
     std::vector<uint32_t> cs(n), es(n);

@@ -320,6 +320,7 @@ __global__ void k_init_ctl(Ctl *ctl, u64 tau0) {
         ctl->sp_kmer = EMPTY64;
     }
     for (int i = threadIdx.x; i < 256; i += blockDim.x) ctl->kmer_counts[i] = 0;
+    if (threadIdx.x == 0) ctl->text_bases = 0;
 }
 
 // new range: empty queue; relaunch of a stopped range: keep next_chunk, swap leftover lists

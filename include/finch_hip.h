@@ -89,6 +89,18 @@ int fh_push_block(fh_sketcher *s, const uint8_t *bytes, uint64_t len);
 #define FH_PUSH_CONTINUE 1u
 int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_t flags);
 
+/* Device-side FASTQ parsing: the caller fills the handle's pinned staging buffer with RAW
+ * plain 4-line FASTQ text cut at a record boundary (it starts with a '@' header line and ends after a quality
+ * line) and the library finds the sequence lines on the device (line index mod 4), drops CR, turns each
+ * sequence line's newline into the record breaker and sketches the result.  Replaces needletail's record
+ * splitting for that format (lib.rs:60-68); anything else (FASTA, gz, blank lines between records) goes through
+ * fh_push_block.  fh_text_buffer hands out the buffer to fill next (capacity = stage_bytes); fh_push_fastq_text
+ * consumes its first `len` bytes.  FH_ERR_INVALID if the text is not 4-line FASTQ. */
+int fh_text_buffer(fh_sketcher *s, uint8_t **buf, uint64_t *cap);
+int fh_push_fastq_text(fh_sketcher *s, uint64_t len);
+/* sequence bytes seen by fh_push_fastq_text so far (what total_bases counts, mash.rs:72); valid after fh_finish */
+int fh_text_bases(fh_sketcher *s, uint64_t *total_bases);
+
 /* Same for a block that is already resident in this device's HBM (16-byte aligned, no whitespace
  * bytes: the packed stream produced by fh_push_block's staging or by fh_synth_reads_device).
  * The memory must stay valid until fh_finish/fh_sync returns. */

@@ -134,3 +134,52 @@ print("child ok")
 '''
     for env in [{"FINCH_BLOCK_BYTES": "1000"}, {"FH_STAGE_BYTES": "4096"}, {"FINCH_BLOCK_BYTES": "7777", "FH_STAGE_BYTES": "5000"}]:
         assert "child ok" in _run_child(code, env)
+
+
+def test_device_side_fastq_parsing_matches_host_parser(tmp_path):
+    """with FINCH_DEVICE_PARSE=1 the sequence lines of plain FASTQ are found on the device
+    (fh_text.hip); same sketch, seq_length and numValidKmers as the host parser, incl. CRLF, a last line
+    without newline, quality lines starting with '@', and chunks much smaller than the file."""
+    code = r'''
+import os, sys, numpy as np
+from finch_rs_amd import host as H, sketch_schemes as S
+rng = np.random.default_rng(5)
+g = S.synth_genome_host(200000, 3)
+nr, rl = 30000, 150
+reads = S.synth_reads_host(g, 0, nr, rl, 3, 10000, 500).reshape(nr, rl + 1)[:, :rl]
+def fq(eol, last_newline=True, varlen=False):
+    out = []
+    for i in range(nr):
+        L = int(rng.integers(1, rl + 1)) if varlen else rl
+        q = bytes(rng.choice(np.frombuffer(b"@+IJ#5", np.uint8), size=L))
+        out.append(b"@r%d some text" % i + eol + bytes(reads[i][:L]) + eol + b"+" + (b"r%d" % i if i % 3 == 0 else b"") + eol + q + eol)
+    data = b"".join(out)
+    return data if last_newline else data[:-len(eol)]
+p = S.SketchParams.mash(500, 500, False, 21, 0)
+f = H.FilterParams(False)
+for name, data in [("lf", fq(b"\n")), ("crlf", fq(b"\r\n")), ("nolast", fq(b"\n", False)), ("varlen", fq(b"\n", True, True))]:
+    path = os.path.join(sys.argv[1], name + ".fastq")
+    open(path, "wb").write(data)
+    os.environ.pop("FINCH_DEVICE_PARSE", None)
+    a = H.sketch_files([path], p, f).sketch(0)
+    os.environ["FINCH_DEVICE_PARSE"] = "1"
+    b = H.sketch_files([path], p, f).sketch(0)
+    assert np.array_equal(a.arrays[0], b.arrays[0]) and np.array_equal(a.arrays[1], b.arrays[1]), name
+    assert (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers), (name, a.seq_length, b.seq_length)
+# not 4-line FASTQ -> loud error
+bad = os.path.join(sys.argv[1], "bad.fastq")
+open(bad, "wb").write(b"@r1\nACGT\n+\nIIII\n\n@r2\nACGT\n+\nIIII\n" * 1000)
+try:
+    H.sketch_files([bad], p, f)
+    raise SystemExit("expected an error")
+except S.FinchError as e:
+    assert "FASTQ" in str(e)
+print("child ok")
+'''
+    for env in [{}, {"FH_STAGE_BYTES": "65536"}]:
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=e,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0 and "child ok" in r.stdout, r.stdout
