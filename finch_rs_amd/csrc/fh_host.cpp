@@ -149,6 +149,53 @@ static int process_post_filter(const finch_sketch_params &sp, std::vector<KmerCo
     return FH_OK;
 }
 
+// distance.rs:66-126 (raw_distance)
+static void raw_distance(const uint64_t *q, size_t nq, const uint64_t *r, size_t nr, double scale, double &containment,
+                         double &jaccard, uint64_t &common_out, uint64_t &total_out) {
+    size_t i = 0, j = 0;
+    uint64_t common = 0;
+    while (i < nq && j < nr) {
+        if (q[i] < r[j]) i++;
+        else if (q[i] > r[j]) j++;
+        else {
+            common++;
+            i++;
+            j++;
+        }
+    }
+    if (scale > 0.) {
+        // u64::MAX / scale.recip() as u64   (saturating float->int cast)
+        const double rec = 1.0 / scale;
+        uint64_t irec = rec >= 18446744073709551616.0 ? UINT64_MAX : (rec <= 0.0 || rec != rec ? 0 : (uint64_t)rec);
+        const uint64_t max_hash = irec ? UINT64_MAX / irec : UINT64_MAX;
+        while (i < nq && q[i] < max_hash) i++;
+        while (j < nr && r[j] < max_hash) j++;
+    }
+    containment = j == 0 ? 0. : (double)common / (double)j;
+    const uint64_t total = (uint64_t)i - common + (uint64_t)j;
+    jaccard = total == 0 ? 1. : (double)common / (double)total;
+    common_out = common;
+    total_out = total;
+}
+
+// distance.rs:136-157 (old_distance); the reference indexes query_sketch[0] unconditionally
+static int old_distance(const uint64_t *q, size_t nq, const uint64_t *r, size_t nr, double &containment, double &jaccard,
+                        uint64_t &common_out, uint64_t &total_out) {
+    if (nq == 0 && nr > 0) return hfail(FH_ERR_INVALID, "old_distance: empty query sketch");
+    size_t i = 0;
+    uint64_t common = 0, total = 0;
+    for (size_t t = 0; t < nr; ++t) {
+        while (q[i] < r[t] && i < nq - 1) i++;
+        if (q[i] == r[t]) common++;
+        total++;
+    }
+    containment = (double)common / (double)total;
+    jaccard = (double)common / (double)(common + 2 * (total - common));
+    common_out = common;
+    total_out = total;
+    return FH_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // byte sources: plain memory / FILE*, optionally through zlib (needletail sniffs 1F 8B)
 // ---------------------------------------------------------------------------------------------
@@ -944,6 +991,38 @@ int finch_apply_filters(finch_sketches *s, uint32_t i, finch_filter_params *filt
     if (int rc = process_post_filter(sk.sketch_params, f, sk.name)) return rc;
     sk.hashes.swap(f);
     sk.filter_params = *filters;
+    return FH_OK;
+}
+
+int finch_raw_distance(const uint64_t *query, uint64_t nq, const uint64_t *ref, uint64_t nr, double scale,
+                       finch_distance_out *out) {
+    if (!out || (nq && !query) || (nr && !ref)) return hfail(FH_ERR_INVALID, "null argument");
+    raw_distance(query, nq, ref, nr, scale, out->containment, out->jaccard, out->common_hashes, out->total_hashes);
+    out->mash_distance = 0.;
+    return FH_OK;
+}
+
+int finch_distance(const finch_sketches *a, uint32_t ia, const finch_sketches *b, uint32_t ib, int old_mode,
+                   finch_distance_out *out) {
+    if (!a || !b || !out || ia >= a->v.size() || ib >= b->v.size()) return hfail(FH_ERR_INVALID, "bad argument");
+    const Sketch &qs = a->v[ia], &rs = b->v[ib];
+    std::vector<uint64_t> q(qs.hashes.size()), r(rs.hashes.size());
+    for (size_t i = 0; i < q.size(); ++i) q[i] = qs.hashes[i].hash;
+    for (size_t i = 0; i < r.size(); ++i) r[i] = rs.hashes[i].hash;
+    if (old_mode) {
+        if (int rc = old_distance(q.data(), q.size(), r.data(), r.size(), out->containment, out->jaccard, out->common_hashes,
+                                  out->total_hashes))
+            return rc;
+    } else {
+        // distance.rs:16-29: a scale only if both sketches are scaled
+        double min_scale = 0.;
+        if (qs.sketch_params.kind == 1 && rs.sketch_params.kind == 1) min_scale = std::min(qs.sketch_params.scale, rs.sketch_params.scale);
+        raw_distance(q.data(), q.size(), r.data(), r.size(), min_scale, out->containment, out->jaccard, out->common_hashes,
+                     out->total_hashes);
+    }
+    const double k = (double)qs.sketch_params.kmer_length;
+    const double md = -1.0 * std::log((2.0 * out->jaccard) / (1.0 + out->jaccard)) / k; // distance.rs:37
+    out->mash_distance = std::min(1.0, std::max(0.0, md));
     return FH_OK;
 }
 

@@ -81,6 +81,13 @@ _SYMS = {
     "finch_guess_filter_threshold": (C.c_uint32, [_P, C.c_uint64, C.c_double]),
     "finch_fastx_scan": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
 }
+class CDistance(C.Structure):
+    _fields_ = [("containment", C.c_double), ("jaccard", C.c_double), ("mash_distance", C.c_double),
+                ("common_hashes", C.c_uint64), ("total_hashes", C.c_uint64)]
+
+
+_SYMS["finch_distance"] = (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, C.c_int, C.POINTER(CDistance)])
+_SYMS["finch_raw_distance"] = (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, C.c_double, C.POINTER(CDistance)])
 _bound = None
 
 
@@ -199,3 +206,20 @@ def fastx_scan(data: bytes):
     buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
     _check(lib().finch_fastx_scan(buf.ctypes.data, len(data), C.byref(n), C.byref(tb), C.byref(fmt)))
     return n.value, tb.value, fmt.value
+
+
+def raw_distance(query_hashes, ref_hashes, scale: float = 0.0):
+    """distance.rs:66-126 -> (containment, jaccard, common, total)"""
+    q = np.ascontiguousarray(query_hashes, np.uint64)
+    r = np.ascontiguousarray(ref_hashes, np.uint64)
+    d = CDistance()
+    _check(lib().finch_raw_distance(q.ctypes.data if len(q) else None, len(q), r.ctypes.data if len(r) else None, len(r), scale, C.byref(d)))
+    return d.containment, d.jaccard, d.common_hashes, d.total_hashes
+
+
+def distance(a: Sketches, ia: int, b: Sketches, ib: int, old_mode: bool = False):
+    """distance.rs:9-47 -> dict(containment, jaccard, mash_distance, common_hashes, total_hashes)"""
+    d = CDistance()
+    _check(lib().finch_distance(a._p, ia, b._p, ib, int(old_mode), C.byref(d)))
+    return {"containment": d.containment, "jaccard": d.jaccard, "mash_distance": d.mash_distance,
+            "common_hashes": d.common_hashes, "total_hashes": d.total_hashes}

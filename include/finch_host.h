@@ -85,6 +85,18 @@ int finch_sketch_copy(const finch_sketches *s, uint32_t i, uint64_t *hashes, uin
 int finch_sketches_to_json(const finch_sketches *s, char **out, uint64_t *len);
 void finch_free_string(char *p);
 
+/* distance (lib/src/distance.rs:9-47): compares sketch ia of `a` (query) with sketch ib of `b` (reference).
+ * raw_distance (distance.rs:66-126) unless old_mode (old_distance, distance.rs:136-157). */
+typedef struct finch_distance_out {
+    double containment, jaccard, mash_distance;
+    uint64_t common_hashes, total_hashes;
+} finch_distance_out;
+int finch_distance(const finch_sketches *a, uint32_t ia, const finch_sketches *b, uint32_t ib, int old_mode,
+                   finch_distance_out *out);
+/* raw_distance on bare ascending hash arrays */
+int finch_raw_distance(const uint64_t *query, uint64_t nq, const uint64_t *ref, uint64_t nr, double scale,
+                       finch_distance_out *out);
+
 /* ---- pieces that need no GPU (unit-testable on the host) ---- */
 /* Build a one-sketch result from arrays (to exercise filtering / serialisation without a device). */
 int finch_sketches_from_arrays(const char *name, uint64_t seq_length, uint64_t num_valid_kmers, uint64_t n,

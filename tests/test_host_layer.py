@@ -136,3 +136,39 @@ def test_sk_json_writer_format():
     for scale, txt in [(1.0, "1.0"), (0.5, "0.5"), (1e-7, "1e-7"), (0.00123, "0.00123")]:
         assert ('"scale":%s,' % txt) in H.sketches_from_arrays("s", 1, 1, kc, km, SketchParams.scaled(7, 5, scale, 0),
                                                               H.FilterParams(False)).to_json()
+
+
+def test_raw_distance_reference_known_answers():
+    # lib/src/distance.rs:176-240
+    assert H.raw_distance([0, 1, 2], [1, 2]) == (2. / 2., 2. / 3., 2, 3)
+    assert H.raw_distance([0, 2], [1, 2]) == (1. / 2., 1. / 3., 1, 3)
+    assert H.raw_distance([0, 1], [2, 3]) == (0., 0., 0, 2)
+    assert H.raw_distance([], []) == (0., 1., 0, 0)
+    assert H.raw_distance([], [5]) == (0., 1., 0, 0)
+    # scaled: 1e-18 -> max_hash 18
+    assert H.raw_distance([10, 15, 20], [15, 20], 1e-18) == (1., 2. / 3., 2, 3)
+    assert H.raw_distance([5, 10, 15], [5, 10], 1e-18) == (1., 2. / 3., 2, 3)
+    assert H.raw_distance([5, 10, 15, 20], [5, 10], 1e-18) == (1., 2. / 3., 2, 3)
+    assert H.raw_distance([5, 10], [5, 10, 15, 20], 1e-18) == (2. / 3., 2. / 3., 2, 3)
+
+
+def test_distance_between_sketches():
+    # distance.rs:314-337 shape: identical sketches -> jaccard 1, containment 1, mash distance 0
+    kc = kc_of([1, 1, 2], [1, 0, 1])
+    kc["hash"] = [11, 22, 33]
+    km = np.frombuffer(b"ccacaa", np.uint8).reshape(3, 2)
+    p = SketchParams.scaled(3, 2, 0.001, 42)
+    a = H.sketches_from_arrays("a", 1, 1, kc, km, p, H.FilterParams(False))
+    b = H.sketches_from_arrays("b", 1, 1, kc, km, p, H.FilterParams(False))
+    d = H.distance(a, 0, b, 0)
+    assert (d["jaccard"], d["containment"], d["common_hashes"], d["mash_distance"]) == (1.0, 1.0, 3, 0.0)
+    kc2 = kc.copy()
+    kc2["hash"] = [11, 22, 44]
+    c = H.sketches_from_arrays("c", 1, 1, kc2, km, SketchParams.mash(3, 3, True, 2, 42), H.FilterParams(False))
+    d = H.distance(a, 0, c, 0)
+    # the walk stops when one sketch is exhausted: 33 < 44 ends the query, the reference's 44 is never counted
+    assert d["common_hashes"] == 2 and d["total_hashes"] == 3 and d["jaccard"] == 2. / 3.
+    import math
+    j = 2. / 3.
+    assert abs(d["mash_distance"] - (-math.log(2 * j / (1 + j)) / 2)) < 1e-15
+    assert H.distance(a, 0, c, 0, old_mode=True)["common_hashes"] == 2
