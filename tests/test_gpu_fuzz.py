@@ -1,0 +1,93 @@
+"""Randomised differential test of the device engine against the oracle: random k / size / kind / seed,
+inputs with arbitrary bytes and whitespace, records cut into several pushes (FH_PUSH_CONTINUE), resident
+and staged blocks, tiny in-flight limits (forces stop/relaunch), handle reuse via reset."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import finch_rs_amd as F
+from finch_rs_amd import _lib
+from finch_rs_amd import sketch_schemes as S
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ALPHA = np.frombuffer(b"ACGTACGTACGTACGTNnacgtuURY-.*\n\r \t\x00\xff", dtype=np.uint8)
+
+
+def rand_record(rng, genome, maxlen):
+    L = int(rng.integers(0, maxlen + 1))
+    if L == 0:
+        return b""
+    if rng.random() < 0.8 and L < len(genome):
+        st = int(rng.integers(0, len(genome) - L))
+        r = genome[st:st + L].copy()
+        m = rng.random(L) < rng.choice([0.0, 0.002, 0.05])
+        r[m] = rng.choice(ALPHA, size=int(m.sum()))
+    else:
+        r = rng.choice(ALPHA, size=L)
+    r = r[r != 0]  # 0 is the record breaker of the packed format
+    return bytes(r)
+
+
+@pytest.mark.parametrize("case", range(120))
+def test_random_configuration(case):
+    rng = np.random.default_rng(9000 + case)
+    k = int(rng.choice([1, 2, 3, 5, 8, 11, 15, 16, 17, 21, 21, 21, 24, 27, 31, 31, 32]))
+    kind = "mash" if rng.random() < 0.6 else "scaled"
+    size = int(rng.choice([0, 1, 7, 100, 1000, 1000, 2999, 3001, 12000]))
+    scale = float(rng.choice([1.0, 0.5, 0.01, 0.001]))
+    seed = int(rng.choice([0, 0, 42, 2**63 + 12345]))
+    inflight = int(rng.choice([0, 0, 4096, 16384, 1 << 20]))
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(rng.choice([3000, 60000, 400000])))
+    n_rec = int(rng.choice([0, 1, 30, 400, 3000]))
+    maxlen = int(rng.choice([40, 200, 5000]))
+    if n_rec * maxlen > 3_000_000:
+        n_rec = 3_000_000 // maxlen
+    if kind == "scaled" and scale >= 0.5 and n_rec * maxlen > 600_000:
+        n_rec = 600_000 // maxlen
+    recs = [rand_record(rng, genome, maxlen) for _ in range(n_rec)]
+    params = (F.SketchParams.mash(size, size, True, k, seed) if kind == "mash"
+              else F.SketchParams.scaled(size, k, scale, seed))
+    sk = params.create_sketcher(max_launch=inflight, stage_bytes=int(rng.choice([0, 8192, 70000])))
+    L = _lib.load()
+    for rep in range(2):  # second round re-uses the handle after reset
+        ora = O.OracleSketcher(O.MASH if kind == "mash" else O.SCALED, size, k, seed, scale)
+        for r in recs:
+            ora.process(r)
+        mode = rng.choice(["one_block", "per_record", "cut_records", "resident"])
+        if mode == "one_block":
+            sk.push_block(b"".join(r + b"\x00" for r in recs))
+        elif mode == "per_record":
+            for r in recs:
+                sk.process(r)
+        elif mode == "cut_records":
+            # every record is pushed in 1..3 pieces; pieces after the first continue the record
+            for r in recs:
+                cuts = sorted(set(int(x) for x in rng.integers(0, len(r) + 1, size=int(rng.integers(0, 3)))))
+                pieces = [r[a:b] for a, b in zip([0] + cuts, cuts + [len(r)])]
+                for i, p in enumerate(pieces):
+                    last = i == len(pieces) - 1
+                    blk = np.frombuffer(p + (b"\x00" if last else b""), dtype=np.uint8)
+                    if len(blk) == 0:
+                        continue
+                    _lib.check(L.fh_push_block_ex(sk._h, blk.ctypes.data_as(C.c_void_p), len(blk), 1 if i > 0 else 0))
+                sk.total_bases = 0
+        else:
+            # resident block: the packed stream must be free of whitespace (normalize drops it)
+            ws = bytes.maketrans(b"", b"")
+            packed = b"".join(r.translate(ws, b" \t\r\n") + b"\x00" for r in recs)
+            buf = F.DeviceBuffer(len(packed) + 64)
+            if packed:
+                buf.upload(np.frombuffer(packed, dtype=np.uint8))
+            sk.push_device(buf.ptr, len(packed))
+            sk.sync()
+        kc, km, _ = sk.to_arrays()
+        okc, okm = ora.to_vec()
+        ctx = dict(case=case, k=k, kind=kind, size=size, scale=scale, seed=seed, inflight=inflight, n_rec=n_rec, mode=str(mode), rep=rep)
+        assert len(kc) == len(okc), ctx
+        assert np.array_equal(kc, okc), ctx
+        assert np.array_equal(km, okm), ctx
+        assert sk.finish()[1] == ora.total_bases_and_kmers()[1], ctx
+        sk.reset()
