@@ -295,7 +295,7 @@ int launch_pending(fh_sketcher *s) {
     HIP_TRY(launch_live_flatten(s->ctl, s->stream)); // shard lists -> flat live list, n_live
     if (!s->big_mode)
         HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size, s->max_hash,
-                                   s->trigger, s->open_loop ? 0u : 1u, s->stream));
+                                   s->trigger, s->open_loop ? 0u : 1u, 0u, s->stream));
     s->n_launches++;
     return FH_OK;
 }
@@ -315,7 +315,7 @@ int drain(fh_sketcher *s) {
                 if (int rc = big_prune(s)) return rc;
             } else {
                 HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size,
-                                           s->max_hash, 0u, 1u, s->stream));
+                                           s->max_hash, 0u, 1u, 0u, s->stream));
             }
         }
         if (!remaining) {
@@ -875,7 +875,7 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         if (int rc = check_ctl(s)) return rc;
         if (!s->big_mode && s->h_ctl->n_live <= (uint32_t)SMALL_MAX && !s->h_ctl->need_big) {
             HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size,
-                                       s->max_hash, 0u, 1u, s->stream));
+                                       s->max_hash, 0u, 1u, 1u, s->stream));
             if (int rc = check_ctl(s)) return rc;
         } else {
             if (int rc = big_prune(s)) return rc;

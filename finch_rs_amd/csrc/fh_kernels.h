@@ -14,7 +14,8 @@ hipError_t launch_k2_part1(int k, const SketchArgs &a, int blocks, hipStream_t s
 hipError_t launch_k2_part2(int k, const SketchArgs &a, int blocks, hipStream_t st);
 hipError_t launch_k2_part3(int k, const SketchArgs &a, int blocks, hipStream_t st);
 hipError_t launch_prune_small(Entry *table, uint32_t *live, uint32_t *dead, uint32_t dead_cap, Ctl *ctl, uint32_t kind,
-                              uint64_t size, uint64_t max_hash, uint32_t trigger, uint32_t force, hipStream_t st);
+                              uint64_t size, uint64_t max_hash, uint32_t trigger, uint32_t force, uint32_t sort_out,
+                              hipStream_t st);
 hipError_t launch_clear_slots(Entry *table, uint64_t cap, const uint32_t *live, const uint32_t *dead, const Ctl *ctl,
                               hipStream_t st);
 hipError_t launch_gather(const Entry *table, const uint32_t *live, const Ctl *ctl, int k, uint64_t *o_hash,

@@ -29,17 +29,147 @@ hipError_t launch_k2(int k, const SketchArgs &a, int blocks, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // K3 (small): single workgroup, bitonic sort of the live hashes in LDS
 // ------------------------------------------------------------------------------------------------
+// rank-th smallest (1-based) of the M distinct keys in LDS: MSB-first radix select, 8 bits per pass,
+// starting at the highest byte any key uses.  Every thread returns the same value.
+__device__ u64 lds_select_kth(const u64 *keys, u32 M, u32 rank, u32 *hist /* 256 */, u32 *wsum /* 16 */,
+                              u64 *bcast /* 2 */) {
+    const u32 tid = threadIdx.x, nthr = blockDim.x;
+    // OR of all keys -> first pass
+    u64 kor = 0;
+    for (u32 i = tid; i < M; i += nthr) kor |= keys[i];
+    for (int off = 32; off > 0; off >>= 1) kor |= __shfl_xor(kor, off);
+    if (tid == 0) bcast[0] = 0;
+    __syncthreads();
+    if ((tid & 63u) == 0 && kor) atomicOr((unsigned long long *)&bcast[0], (unsigned long long)kor);
+    __syncthreads();
+    kor = bcast[0];
+    int shift = kor ? (int)((63 - __builtin_clzll(kor)) & ~7) : 0;
+    u64 prefix = 0, pmask = 0;
+    for (;; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (u32 i = tid; i < M; i += nthr) {
+            const u64 key = keys[i];
+            if ((key & pmask) == prefix) atomicAdd(&hist[(u32)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        // inclusive scan of the 256 bins by the first 256 threads (4 waves)
+        u32 c = tid < 256 ? hist[tid] : 0u, inc = c;
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (tid < 256 && lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        if (tid < 256) {
+            u32 base = 0;
+            for (int w = 0; w < wave; ++w) base += wsum[w];
+            inc += base;
+            const u32 exc = inc - c;
+            if (exc < rank && rank <= inc) { // the bucket holding the rank-th key
+                bcast[0] = (u64)tid;
+                bcast[1] = (u64)exc;
+            }
+        }
+        __syncthreads();
+        const u32 b = (u32)bcast[0];
+        rank -= (u32)bcast[1];
+        prefix |= (u64)b << shift;
+        pmask |= 0xFFull << shift;
+        __syncthreads();
+        if (shift == 0) break;
+    }
+    return prefix;
+}
+
+// sort_out = 1: full sort (live list left ascending = to_vec order; used by fh_finish)
+// sort_out = 0: selection only (radix select of the new threshold + partition), ~5x cheaper
 __global__ __launch_bounds__(1024) void k3_prune_small(Entry *table, u32 *live, u32 *dead, u32 dead_cap, Ctl *ctl,
-                                                       u32 kind, u64 size, u64 max_hash, u32 trigger, u32 force) {
+                                                       u32 kind, u64 size, u64 max_hash, u32 trigger, u32 force,
+                                                       u32 sort_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u64 *keys = reinterpret_cast<u64 *>(smem);
     u32 *slots = reinterpret_cast<u32 *>(smem + (size_t)SMALL_MAX * 8);
+    __shared__ u32 s_hist[256];
+    __shared__ u32 s_wsum[16];
+    __shared__ u64 s_bcast[2];
+    __shared__ u32 s_cnt[2];
     const u32 tid = threadIdx.x, nthr = blockDim.x;
     const u32 M = ctl->n_live;
     if (ctl->need_big) return;
     if (!force && M <= trigger) return;
     if (M > (u32)SMALL_MAX) {
         if (tid == 0) ctl->need_big = 1u;
+        return;
+    }
+    if (!sort_out) {
+        for (u32 i = tid; i < M; i += nthr) {
+            const u32 sl = live[i];
+            keys[i] = table[sl].hash;
+            slots[i] = sl;
+        }
+        if (tid < 2) s_cnt[tid] = 0;
+        __syncthreads();
+        // decide the new threshold (same rule as the sorted path below)
+        u64 tau;
+        u32 keep;
+        if (kind == 0u) {
+            if ((u64)M >= size && size > 0) {
+                tau = lds_select_kth(keys, M, (u32)size, s_hist, s_wsum, s_bcast);
+                keep = (u32)size;
+            } else if (size == 0) {
+                tau = 0ull;
+                keep = 0;
+            } else {
+                tau = EMPTY64;
+                keep = M;
+            }
+        } else {
+            u32 c = 0;
+            for (u32 i = tid; i < M; i += nthr) c += keys[i] <= max_hash ? 1u : 0u;
+            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+            if ((tid & 63u) == 0 && c) atomicAdd(&s_cnt[1], c);
+            __syncthreads();
+            const u32 n_le = s_cnt[1];
+            __syncthreads();
+            if ((u64)n_le >= size) {
+                tau = max_hash;
+                keep = n_le;
+            } else if ((u64)M >= size) {
+                tau = lds_select_kth(keys, M, (u32)size, s_hist, s_wsum, s_bcast);
+                keep = (u32)size;
+            } else {
+                tau = (size != 0) ? EMPTY64 : max_hash;
+                keep = M;
+            }
+        }
+        // partition: keys are distinct, so exactly `keep` of them are <= tau (or keep == M)
+        const u32 nd0 = ctl->n_dead;
+        const u32 ndrop = M - keep;
+        const bool dead_fits = nd0 != 0xFFFFFFFFu && nd0 <= dead_cap && ndrop <= dead_cap - nd0;
+        if (keep < M) {
+            for (u32 i = tid; i < M; i += nthr) {
+                const bool k = (size == 0 && kind == 0u) ? false : keys[i] <= tau;
+                if (k) live[atomicAdd(&s_cnt[0], 1u)] = slots[i];
+            }
+            __syncthreads();
+            if (dead_fits) { // dropped slots, compacted
+                if (tid == 0) s_cnt[1] = 0;
+                __syncthreads();
+                for (u32 i = tid; i < M; i += nthr) {
+                    const bool k = (size == 0 && kind == 0u) ? false : keys[i] <= tau;
+                    if (!k) dead[nd0 + atomicAdd(&s_cnt[1], 1u)] = slots[i];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            ctl->n_live = keep;
+            ctl->tau = tau;
+            ctl->sorted = 0u;
+            ctl->n_dead = dead_fits ? nd0 + ndrop : 0xFFFFFFFFu;
+        }
         return;
     }
     u32 N = 1;
@@ -122,7 +252,7 @@ __global__ __launch_bounds__(1024) void k3_prune_small(Entry *table, u32 *live, 
 }
 
 hipError_t launch_prune_small(Entry *table, u32 *live, u32 *dead, u32 dead_cap, Ctl *ctl, u32 kind, u64 size,
-                              u64 max_hash, u32 trigger, u32 force, hipStream_t st) {
+                              u64 max_hash, u32 trigger, u32 force, u32 sort_out, hipStream_t st) {
     static bool attr_set = false;
     const size_t lds = (size_t)SMALL_MAX * 12;
     if (!attr_set) {
@@ -132,7 +262,7 @@ hipError_t launch_prune_small(Entry *table, u32 *live, u32 *dead, u32 dead_cap, 
         attr_set = true;
     }
     hipLaunchKernelGGL(k3_prune_small, dim3(1), dim3(1024), lds, st, table, live, dead, dead_cap, ctl, kind, size,
-                       max_hash, trigger, force);
+                       max_hash, trigger, force, sort_out);
     return hipGetLastError();
 }
 
