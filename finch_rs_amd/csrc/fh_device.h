@@ -29,13 +29,12 @@ struct CollRec {        // an occurrence whose k-mer differs from the slot's k-m
 
 struct Ctl {
     uint64_t tau;           // admit iff hash <= tau
-    uint64_t total_kmers;   // (unused by the kernels; kept for layout) see kmer_counts
     uint32_t n_live;        // entries in the live list
     uint32_t overflow;      // table probe limit hit / live list full (capacity error)
     uint32_t n_coll;        // collision log entries
     uint32_t need_big;      // the single-workgroup prune met more live entries than it can sort
     uint32_t sorted;        // live list currently sorted ascending by hash
-    uint32_t launches_skipped;
+    uint32_t pad_a;
     uint32_t n_dead;        // entries in the dropped-slot list (0xFFFFFFFF = list overflowed)
     uint32_t pad0;
     uint32_t left_in_pos;   // next unread entry of the leftover list handed to this launch

@@ -102,6 +102,24 @@ __device__ __noinline__ u32 upsert(Ctl *ctl, u64 h, u64 kmer, u64 pos, u32 stran
     return inserted;
 }
 
+// The admit path is batched: a lane whose hash passed the threshold parks (hash, k-mer, position|strand) in a
+// wave-private LDS queue; the queue is drained with all 64 lanes active, so the round trips of the atomics
+// overlap instead of stalling the wave once per event.  Returns the number of NEW hashes inserted.
+constexpr int QCAP = 64;
+struct AdmitQueue {
+    u64 h[QCAP], k[QCAP], p[QCAP];
+};
+
+__device__ __noinline__ u32 flush_queue(Ctl *ctl, const AdmitQueue *q, u32 qn, u32 shard) {
+    const u32 lane = threadIdx.x & 63u;
+    u32 ins = 0u;
+    if (lane < qn) {
+        const u64 pp = q->p[lane];
+        ins = upsert(ctl, q->h[lane], q->k[lane], pp & 0x7FFFFFFFFFFFFFFFull, (u32)(pp >> 63), shard);
+    }
+    return (u32)__popcll(__ballot(ins != 0u));
+}
+
 // ------------------------------------------------------------------------------------------------
 // phase A: classify the lane's own 32 bytes of tile `t` into the wave's LDS ring
 // ------------------------------------------------------------------------------------------------
@@ -143,6 +161,7 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
     __shared__ __attribute__((aligned(16))) u32 sT5[tail_merge5(K) ? 2048 : 4]; // lo/hi(5-base tail group * its constant)
     __shared__ __attribute__((aligned(16))) u32 sCodes[WAVES_PER_BLOCK][256];
     __shared__ __attribute__((aligned(16))) u32 sGood[WAVES_PER_BLOCK][128];
+    __shared__ __attribute__((aligned(16))) AdmitQueue sQueue[WAVES_PER_BLOCK];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     {
@@ -180,8 +199,10 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
     // input: a wave inserts at most budget + 2047 new hashes per launch and the host sized the table for
     // (#waves x that) beyond the soft limit.  A stopped launch leaves its unprocessed work in the queue
     // (next_chunk + the leftover list); the host prunes and relaunches.
-    u32 wave_inserts = 0; // wave-uniform (reduced at tile ends)
-    u32 lane_inserts = 0; // new hashes this lane inserted in the current tile
+    u32 wave_inserts = 0; // new hashes this wave inserted in this launch (wave-uniform)
+    u32 qn = 0;           // occupancy of the admit queue (wave-uniform)
+    AdmitQueue *queue = &sQueue[wave];
+    const u32 shard = gw & (u32)(N_SHARDS - 1);
     u32 last_unit = 0; // guides the pull size
     for (;;) {
         u32 rt0 = 0xFFFFFFFFu, rt1 = 0u;
@@ -245,21 +266,35 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
             u64 h = murmur_h1_fast<K, SEED0>(cm, a.seed, sTQ, sTP, sT5);
             if (MASKED) h &= a.hash_mask; // test hook only
             // windows that carry no k-mer hash garbage; they are rejected on the (rare) admit path only
-            if (__builtin_expect(h <= tau, 0)) {
-                u32 ins = 0u;
-                if ((W >> j) & 1u)
-                    ins = upsert(a.ctl, h, cm, a.base_pos + lane_pos0 + (u64)j, is_rc ? 1u : 0u, gw & (u32)(N_SHARDS - 1));
-                lane_inserts += ins;
+            if (__builtin_expect(__any(h <= tau), 0)) { // wave-uniform branch
+                const bool take = (h <= tau) && ((W >> j) & 1u);
+                const u64 mask = __ballot(take);
+                const u32 cnt = (u32)__popcll(mask);
+                if (cnt) {
+                    if (qn + cnt > (u32)QCAP) {
+                        wave_inserts += flush_queue(a.ctl, queue, qn, shard);
+                        qn = 0;
+                    }
+                    const u32 my = qn + __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+                    if (take) {
+                        queue->h[my] = h;
+                        queue->k[my] = cm;
+                        queue->p[my] = (a.base_pos + lane_pos0 + (u64)j) | ((u64)(is_rc ? 1u : 0u) << 63);
+                    }
+                    qn += cnt;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (__any(lane_inserts != 0u)) { // rare once the threshold is tight
-            u32 v = lane_inserts;
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            wave_inserts += (u32)__builtin_amdgcn_readfirstlane((int)v);
-            lane_inserts = 0;
+        if (qn >= (u32)(QCAP / 2) || (qn && t + 1 == rt1)) { // drain when half full or at the end of the pulled range
+            wave_inserts += flush_queue(a.ctl, queue, qn, shard);
+            qn = 0;
         }
         if (t + 1 < rt1 && wave_inserts >= a.wave_budget) {
+            if (qn) { // nothing may stay parked when the wave gives the rest of its range back
+                wave_inserts += flush_queue(a.ctl, queue, qn, shard);
+                qn = 0;
+            }
             if (lane == 0) {
                 const u32 idx = atomicAdd(&a.ctl->n_left_out, 1u);
                 a.left_out[2u * idx] = (u32)(t + 1);

@@ -412,29 +412,13 @@ hipError_t launch_live_flatten(Ctl *ctl, hipStream_t st) {
 
 __global__ void k_init_ctl(Ctl *ctl, u64 tau0) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        Ctl c;
-        c.tau = tau0;
-        c.total_kmers = 0;
-        c.n_live = 0;
-        c.overflow = 0;
-        c.n_coll = 0;
-        c.need_big = 0;
-        c.sorted = 1;
-        c.launches_skipped = 0;
-        c.n_dead = 0;
-        c.pad0 = 0;
-        c.sp_count = 0;
-        c.sp_extra = 0;
-        c.sp_pos = EMPTY64;
-        c.sp_kmer = EMPTY64;
-        ctl->tau = c.tau;
-        ctl->total_kmers = 0;
+        ctl->tau = tau0;
         ctl->n_live = 0;
         ctl->overflow = 0;
         ctl->n_coll = 0;
         ctl->need_big = 0;
         ctl->sorted = 1;
-        ctl->launches_skipped = 0;
+        ctl->pad_a = 0;
         ctl->n_dead = 0;
         ctl->pad0 = 0;
         ctl->next_unit = 0;

@@ -28,6 +28,16 @@ def test_header_symbols_all_exported(built):
         assert hasattr(built, name), name
 
 
+def test_host_header_symbols_all_exported(built):
+    from finch_rs_amd import host as H
+    hdr = open(os.path.join(ROOT, "include", "finch_host.h")).read()
+    declared = set(re.findall(r"\b(finch_[a-z0-9_]+)\s*\(", hdr))
+    assert declared and declared == set(H._SYMS), (declared ^ set(H._SYMS))
+    L = H.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+
+
 def test_abi_version(built):
     assert built.fh_abi_version() == 1
 
