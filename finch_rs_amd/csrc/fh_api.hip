@@ -123,6 +123,8 @@ struct fh_sketcher {
     uint8_t carry[32] = {0}; // last K-1 staged bytes: k-mers span staging slices (and FH_PUSH_CONTINUE pushes)
     uint32_t carry_len = 0;
     Ctl *h_ctl = nullptr; // pinned
+    void *h_out = nullptr; // pinned staging of the finished sketch (fh_finish)
+    size_t h_out_bytes = 0;
 
     // host bookkeeping
     uint64_t stream_off = 0;     // stream coordinate of the next byte
@@ -518,8 +520,22 @@ int merge_sorted(const std::vector<ResultRec> &a, const std::vector<ResultRec> &
     return FH_OK;
 }
 
+// m-form 2-bit k-mer -> ASCII, four bases per table lookup
+struct Ascii4Lut {
+    uint32_t v[256];
+    Ascii4Lut() {
+        for (uint32_t q = 0; q < 256; ++q) v[q] = ascii_group(q, 4);
+    }
+};
+const Ascii4Lut g_ascii4;
+
 void kmer_ascii(uint64_t m, int k, uint8_t *out) {
-    for (int b = 0; b < k; ++b) out[b] = (uint8_t) "ACGT"[(m >> (2 * (k - 1 - b))) & 3u];
+    int b = 0;
+    for (; b + 4 <= k; b += 4) {
+        const uint32_t w = g_ascii4.v[(m >> (2 * (k - b - 4))) & 0xFFu];
+        memcpy(out + b, &w, 4);
+    }
+    for (; b < k; ++b) out[b] = (uint8_t) "ACGT"[(m >> (2 * (k - 1 - b))) & 3u];
 }
 
 uint64_t ascii_kmer(const uint8_t *in, int k) {
@@ -664,6 +680,7 @@ void fh_free(fh_sketcher *s) {
     (void)hipFree(s->d_text_tot);
     if (s->h_text_tot) (void)hipHostFree(s->h_text_tot);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
+    if (s->h_out) (void)hipHostFree(s->h_out);
     (void)hipFree(s->left_buf[0]);
     (void)hipFree(s->left_buf[1]);
     (void)hipFree(s->keys_a);
@@ -887,14 +904,23 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         if (int rc = collect_profile(s)) return rc;
         const Ctl c = *s->h_ctl;
         const uint32_t n = c.n_live;
-        std::vector<uint64_t> hh(n), kk(n), pp(n);
-        std::vector<uint32_t> cc(n), ee(n);
+        // D2H through one pinned staging area (pageable destinations crawl at a few GB/s)
+        const size_t need = (size_t)n * 32 + 64;
+        if (need > s->h_out_bytes) {
+            if (s->h_out) (void)hipHostFree(s->h_out);
+            s->h_out = nullptr;
+            s->h_out_bytes = 0;
+            HIP_TRY(hipHostMalloc(&s->h_out, need + need / 4, hipHostMallocDefault));
+            s->h_out_bytes = need + need / 4;
+        }
+        uint64_t *hh = (uint64_t *)s->h_out, *kk = hh + n, *pp = kk + n;
+        uint32_t *cc = (uint32_t *)(pp + n), *ee = cc + n;
         if (n) {
-            HIP_TRY(hipMemcpyAsync(hh.data(), s->o_hash, n * 8ull, hipMemcpyDeviceToHost, s->stream));
-            HIP_TRY(hipMemcpyAsync(kk.data(), s->o_kmer, n * 8ull, hipMemcpyDeviceToHost, s->stream));
-            HIP_TRY(hipMemcpyAsync(pp.data(), s->o_pos, n * 8ull, hipMemcpyDeviceToHost, s->stream));
-            HIP_TRY(hipMemcpyAsync(cc.data(), s->o_count, n * 4ull, hipMemcpyDeviceToHost, s->stream));
-            HIP_TRY(hipMemcpyAsync(ee.data(), s->o_extra, n * 4ull, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(hh, s->o_hash, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(kk, s->o_kmer, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(pp, s->o_pos, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(cc, s->o_count, n * 4ull, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipMemcpyAsync(ee, s->o_extra, n * 4ull, hipMemcpyDeviceToHost, s->stream));
         }
         std::vector<CollRec> coll(std::min<uint32_t>(c.n_coll, CLOG_CAP));
         if (!coll.empty())
