@@ -52,6 +52,7 @@ const uint64_t STAGE_BYTES_ENV = [] {
     return v >= 4096 ? v : 0ull;
 }();
 constexpr uint64_t STAGE_BYTES_DEFAULT = 64ull << 20;
+constexpr uint64_t STAGE_HEADROOM = 32;
 constexpr int N_STAGE = 2;
 
 struct ResultRec {
@@ -806,8 +807,8 @@ int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_
 static int ensure_stage(fh_sketcher *s) {
     for (int i = 0; i < N_STAGE; ++i) {
         if (!s->h_stage[i]) {
-            HIP_TRY(hipHostMalloc((void **)&s->h_stage[i], s->stage_bytes + 64, hipHostMallocDefault));
-            HIP_TRY(hipMalloc((void **)&s->d_stage[i], s->stage_bytes + 64));
+            HIP_TRY(hipHostMalloc((void **)&s->h_stage[i], s->stage_bytes + 128, hipHostMallocDefault));
+            HIP_TRY(hipMalloc((void **)&s->d_stage[i], s->stage_bytes + 128));
             HIP_TRY(hipEventCreateWithFlags(&s->stage_done[i], hipEventDisableTiming));
         }
     }
@@ -823,8 +824,36 @@ int fh_text_buffer(fh_sketcher *s, uint8_t **buf, uint64_t *cap) {
         HIP_TRY(hipEventSynchronize(s->stage_done[b]));
         s->stage_busy[b] = false;
     }
-    *buf = s->h_stage[b];
+    *buf = s->h_stage[b] + STAGE_HEADROOM; // room in front for the K-1 carry bytes of fh_push_staged
     *cap = s->stage_bytes;
+    return FH_OK;
+}
+
+int fh_push_staged(fh_sketcher *s, uint64_t len, uint32_t flags) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    if (len > s->stage_bytes) return fail(FH_ERR_INVALID, "block longer than the staging buffer");
+    if (int rc = set_device(s)) return rc;
+    if (int rc = ensure_stage(s)) return rc;
+    if (!(flags & FH_PUSH_CONTINUE)) s->carry_len = 0;
+    if (len == 0) return FH_OK;
+    const int b = s->stage_next;
+    const uint32_t K = s->p.k;
+    const uint32_t carry_len = s->carry_len;
+    uint8_t *src = s->h_stage[b] + STAGE_HEADROOM - carry_len;
+    memcpy(src, s->carry, carry_len);
+    const uint64_t m = carry_len + len;
+    const uint64_t base = s->stream_off - carry_len;
+    // the device buffer of this slot may still feed a pending range
+    if (int rc = drain(s)) return rc;
+    HIP_TRY(hipMemcpyAsync(s->d_stage[b], src, m, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+    s->stage_busy[b] = true;
+    if (int rc = sketch_device_range(s, s->d_stage[b], m, base)) return rc;
+    s->stream_off += len;
+    s->carry_len = (uint32_t)std::min<uint64_t>(K - 1, m);
+    memcpy(s->carry, src + m - s->carry_len, s->carry_len);
+    s->stage_next = (b + 1) % N_STAGE;
     return FH_OK;
 }
 
@@ -849,7 +878,7 @@ int fh_push_fastq_text(fh_sketcher *s, uint64_t len) {
     // the packed buffer of this slot may still feed a pending range
     if (int rc = drain(s)) return rc;
     HIP_TRY(hipMemsetAsync(s->d_text_tot, 0, 4 * sizeof(uint32_t), s->stream));
-    HIP_TRY(hipMemcpyAsync(s->d_stage[b], s->h_stage[b], len, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_stage[b], s->h_stage[b] + STAGE_HEADROOM, len, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
     s->stage_busy[b] = true;
     HIP_TRY(launch_fastq_pack(s->d_stage[b], len, s->d_packed[b], s->d_blk_a[b], s->d_blk_b[b], s->d_text_tot, s->ctl,

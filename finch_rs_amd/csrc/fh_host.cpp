@@ -339,45 +339,82 @@ struct CountSink : RecordSink {
     }
 };
 
-// SketchScheme::process (mash.rs:67-80) over the C ABI: record bytes + one breaker byte, batched into
-// blocks; records longer than a block continue with FH_PUSH_CONTINUE
+// copy n bytes dropping ' ', '\t', '\r', '\n' (what normalize(false) removes, mash.rs:73); 8 bytes at a time when clean
+static inline size_t strip_copy(uint8_t *dst, const uint8_t *src, size_t n) {
+    size_t i = 0, m = 0;
+    while (i + 8 <= n) {
+        uint64_t x;
+        memcpy(&x, src + i, 8);
+        if (((x - 0x2121212121212121ull) & ~x & 0x8080808080808080ull) == 0) { // no byte < 0x21
+            memcpy(dst + m, &x, 8);
+            m += 8;
+        } else {
+            for (int j = 0; j < 8; ++j) {
+                const uint8_t c = src[i + j];
+                if (c == ' ' || c == '\t' || c == '\r' || c == '\n') continue;
+                dst[m++] = c;
+            }
+        }
+        i += 8;
+    }
+    for (; i < n; ++i) {
+        const uint8_t c = src[i];
+        if (c == ' ' || c == '\t' || c == '\r' || c == '\n') continue;
+        dst[m++] = c;
+    }
+    return m;
+}
+
+// SketchScheme::process (mash.rs:67-80) over the C ABI: record bytes + one breaker byte, written (whitespace
+// already dropped) straight into the sketcher's pinned staging buffer and committed in large blocks; a record
+// that does not fit continues in the next block with FH_PUSH_CONTINUE.
 struct DeviceSink : RecordSink {
     fh_sketcher *h;
-    std::vector<uint8_t> block;
-    size_t cap;
-    bool continuing = false; // the block starts inside a record that an earlier flush cut
+    uint8_t *buf = nullptr;
+    uint64_t cap = 0, fill = 0;
+    uint64_t limit = 0;      // test knob: commit after this many bytes
+    bool continuing = false; // the block starts inside a record that an earlier commit cut
     bool in_record = false;
-    static size_t default_cap() {
+    explicit DeviceSink(fh_sketcher *h_) : h(h_) {
         const char *e = getenv("FINCH_BLOCK_BYTES"); // test knob: force records to span blocks
-        const size_t v = e ? (size_t)strtoull(e, nullptr, 10) : 0;
-        return v ? v : (32u << 20);
+        limit = e ? strtoull(e, nullptr, 10) : 0;
     }
-    explicit DeviceSink(fh_sketcher *h_) : h(h_), cap(default_cap()) { block.reserve(cap + 4096); }
+    int acquire() {
+        if (buf) return FH_OK;
+        if (int rc = fh_text_buffer(h, &buf, &cap)) return hfail(rc, "%s", fh_last_error());
+        if (limit && limit < cap) cap = limit;
+        if (cap < 64) return hfail(FH_ERR_INVALID, "staging buffer too small");
+        fill = 0;
+        return FH_OK;
+    }
     int flush() {
-        if (block.empty()) return FH_OK;
-        const int rc = fh_push_block_ex(h, block.data(), block.size(), continuing ? FH_PUSH_CONTINUE : 0u);
+        if (!buf || fill == 0) return FH_OK;
+        const int rc = fh_push_staged(h, fill, continuing ? FH_PUSH_CONTINUE : 0u);
         if (rc != FH_OK) return hfail(rc, "%s", fh_last_error());
-        block.clear();
+        buf = nullptr;
+        fill = 0;
         continuing = in_record;
         return FH_OK;
     }
     int piece(const uint8_t *p, size_t n) override {
         in_record = true;
         while (n) {
-            const size_t room = cap - block.size();
+            if (int rc = acquire()) return rc;
+            const size_t room = (size_t)(cap - fill);
             const size_t m = std::min(room, n);
-            block.insert(block.end(), p, p + m);
+            fill += strip_copy(buf + fill, p, m);
             p += m;
             n -= m;
-            if (block.size() >= cap)
+            if (fill >= cap)
                 if (int rc = flush()) return rc;
         }
         return FH_OK;
     }
     int end_record() override {
-        block.push_back(0);
+        if (int rc = acquire()) return rc;
+        buf[fill++] = 0;
         in_record = false;
-        if (block.size() >= cap) return flush();
+        if (fill >= cap) return flush();
         return FH_OK;
     }
 };

@@ -98,6 +98,10 @@ int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_
  * consumes its first `len` bytes.  FH_ERR_INVALID if the text is not 4-line FASTQ. */
 int fh_text_buffer(fh_sketcher *s, uint8_t **buf, uint64_t *cap);
 int fh_push_fastq_text(fh_sketcher *s, uint64_t len);
+/* Zero-copy form of fh_push_block_ex: the caller writes packed-stream bytes (sequence bytes + one breaker byte per
+ * record, whitespace already removed) straight into the buffer handed out by fh_text_buffer and commits the first
+ * `len` of them.  Same flags as fh_push_block_ex. */
+int fh_push_staged(fh_sketcher *s, uint64_t len, uint32_t flags);
 /* sequence bytes seen by fh_push_fastq_text so far (what total_bases counts, mash.rs:72); valid after fh_finish */
 int fh_text_bases(fh_sketcher *s, uint64_t *total_bases);
 
