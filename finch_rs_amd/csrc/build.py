@@ -17,7 +17,7 @@ OUT = os.path.join(PKG, "libfinch_hip.so")
 OBJ = os.path.join(HERE, "obj")
 NPARTS = 4
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-cuda-compat"]
 FLAGS += os.environ.get("FH_EXTRA_FLAGS", "").split()
 OUT = os.environ.get("FH_OUT", OUT)
 
