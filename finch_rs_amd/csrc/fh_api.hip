@@ -107,6 +107,9 @@ struct fh_sketcher {
     uint32_t *left_buf[2] = {nullptr, nullptr}; // leftover tile ranges of a stopped launch (pairs)
     uint64_t max_waves = 0;
     uint64_t max_range = 0; // test knob: cap on positions per range
+    uint64_t tau_lo = 0;    // != 0 while a block is re-read for the hashes above a speculative threshold
+    bool no_spec = false;   // test knob: disable the speculative first pass
+    uint64_t n_spec = 0, n_spec_fallback = 0;
     uint64_t n_launches = 0, n_relaunches = 0;
     // staging
     uint8_t *h_stage[N_STAGE] = {nullptr, nullptr};
@@ -124,6 +127,7 @@ struct fh_sketcher {
     uint8_t carry[32] = {0}; // last K-1 staged bytes: k-mers span staging slices (and FH_PUSH_CONTINUE pushes)
     uint32_t carry_len = 0;
     Ctl *h_ctl = nullptr; // pinned
+    void *h_tau = nullptr; // pinned, 8 bytes
     void *h_out = nullptr; // pinned staging of the finished sketch (fh_finish)
     size_t h_out_bytes = 0;
 
@@ -179,6 +183,7 @@ int init_state(fh_sketcher *s) {
     s->last_tau = initial_tau(s);
     s->last_live = 0;
     s->pend.active = false;
+    s->tau_lo = 0;
     s->carry_len = 0;
     s->live_target = s->big_mode ? std::max<uint64_t>(4 * s->p.size, 1ull << 16) : (uint64_t)SMALL_MAX;
     s->finished = false;
@@ -265,6 +270,7 @@ int launch_pending(fh_sketcher *s) {
     a.base_pos = r.base_pos;
     a.seed = s->p.seed;
     a.hash_mask = s->p.hash_mask ? s->p.hash_mask : ~0ull;
+    a.tau_lo = s->tau_lo;
     a.ctl = s->ctl;
     a.tiles_total = r.tiles_total;
     a.n_units = r.n_units;
@@ -335,10 +341,95 @@ int drain(fh_sketcher *s) {
 }
 
 // sketch [0,len) of a device-resident packed stream whose first byte has stream coordinate base_pos
+int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos, uint64_t pos, uint64_t end) {
+    fh_sketcher::Pending &r = s->pend;
+    r.seq = d_seq;
+    r.len = len;
+    r.base_pos = base_pos;
+    r.p_begin = pos;
+    r.p_end = end;
+    const uint64_t tiles = (end - pos + TILE_POS - 1) / TILE_POS;
+    if (tiles >= (1ull << 31)) return fail(FH_ERR_INVALID, "block too large for one range");
+    r.tiles_total = (uint32_t)tiles;
+    r.n_units = (uint32_t)((tiles + UNIT_TILES - 1) / UNIT_TILES);
+    r.n_left_in = 0;
+    r.left_cur = 0;
+    HIP_TRY(launch_queue_reset(s->ctl, 1u, soft_limit_of(s), s->stream));
+    if (int rc = launch_pending(s)) return rc;
+    r.active = true;
+    if (s->profiling) s->prof_positions += end - pos;
+    s->dirty = true;
+    return FH_OK;
+}
+
+int set_tau(fh_sketcher *s, uint64_t tau) {
+    *(uint64_t *)s->h_tau = tau;
+    HIP_TRY(hipMemcpyAsync(&s->ctl->tau, s->h_tau, 8, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream)); // h_tau is reused
+    s->last_tau = tau;
+    return FH_OK;
+}
+
+// First block of a fresh sketcher, if it is small (a file of a few Mb..tens of Mb -- the batch-of-files case, where
+// the half dozen host round trips of the closed-loop warm-up dominate): instead of warming the threshold up
+// through a series of small ranges, guess it from the block length (about 4 x size hashes expected below it if
+// every k-mer were distinct) and sketch the block in one go.  Large blocks keep the closed-loop warm-up: its
+// cost is amortised there, while a wrong guess would cost a whole second pass.  As soon as `size` distinct hashes <= the guess have been seen the usual argument holds (everything not
+// recorded is larger than the size-th smallest so far).  If the block ends with fewer -- low-complexity input --
+// it is read a second time for the hashes above the guess only (HASLO launches), through the normal loop.
+int speculative_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos, uint64_t n_pos,
+                            bool *done) {
+    *done = false;
+    const double want = 4.0 * (double)std::max<uint64_t>(s->p.size, 1);
+    if (s->no_spec || s->max_range || s->p.hash_mask || n_pos < 32768 || n_pos > (64ull << 20) ||
+        want * 2.0 >= (double)n_pos)
+        return FH_OK;
+    if (s->p.kind == FH_KIND_SCALED && s->p.size == 0) return FH_OK; // threshold is max_hash from the start
+    uint64_t tau_spec = (uint64_t)(want / (double)n_pos * 18446744073709551616.0);
+    if (s->p.kind == FH_KIND_SCALED) tau_spec = std::max(tau_spec, s->max_hash);
+    if (tau_spec == 0 || tau_spec >= EMPTY64 - 1) return FH_OK;
+    if (int rc = set_tau(s, tau_spec)) return rc;
+    s->n_spec++;
+    const bool was_open = s->open_loop;
+    s->open_loop = true; // one range for the whole block; waves stop by themselves if the live set fills up
+    if (int rc = start_range(s, d_seq, len, base_pos, 0, n_pos)) return rc;
+    if (int rc = drain(s)) return rc;
+    s->open_loop = was_open;
+    // settle the live set and see whether the guess captured `size` distinct hashes
+    if (s->big_mode || s->last_live > (uint32_t)SMALL_MAX) {
+        if (int rc = big_prune(s)) return rc;
+    } else {
+        HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size, s->max_hash, 0u,
+                                   1u, 0u, s->stream));
+        if (int rc = check_ctl(s)) return rc;
+        s->last_tau = s->h_ctl->tau;
+        s->last_live = s->h_ctl->n_live;
+    }
+    if ((uint64_t)s->last_live >= s->p.size) {
+        s->positions_done += n_pos;
+        *done = true;
+        return FH_OK;
+    }
+    // too few: everything <= tau_spec is in the table with exact counts; re-read the block for the rest
+    s->n_spec_fallback++;
+    s->tau_lo = tau_spec;
+    if (int rc = set_tau(s, EMPTY64)) return rc;
+    return FH_OK;
+}
+
 int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos) {
     if (int rc = drain(s)) return rc;
     if (len < s->p.k) return FH_OK;
     const uint64_t n_pos = len - s->p.k + 1; // windows that fit
+    if (s->positions_done == 0 && s->tau_lo == 0) {
+        bool done = false;
+        if (int rc = speculative_first_block(s, d_seq, len, base_pos, n_pos, &done)) return rc;
+        if (done) return FH_OK;
+    }
+    struct LoGuard { // the lower bound only applies to this block
+        fh_sketcher *s;
+        ~LoGuard() { s->tau_lo = 0; }
+    } lo_guard{s};
     uint64_t pos = 0;
     while (pos < n_pos) {
         if (int rc = drain(s)) return rc;
@@ -352,26 +443,10 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
         }
         const uint64_t P = next_range_size(s, n_pos - pos);
         const uint64_t end = std::min<uint64_t>(n_pos, pos + P);
-        fh_sketcher::Pending &r = s->pend;
-        r.seq = d_seq;
-        r.len = len;
-        r.base_pos = base_pos;
-        r.p_begin = pos;
-        r.p_end = end;
-        const uint64_t tiles = (end - pos + TILE_POS - 1) / TILE_POS;
-        if (tiles >= (1ull << 31)) return fail(FH_ERR_INVALID, "block too large for one range");
-        r.tiles_total = (uint32_t)tiles;
-        r.n_units = (uint32_t)((tiles + UNIT_TILES - 1) / UNIT_TILES);
-        r.n_left_in = 0;
-        r.left_cur = 0;
-        HIP_TRY(launch_queue_reset(s->ctl, 1u, soft_limit_of(s), s->stream));
-        if (int rc = launch_pending(s)) return rc;
-        r.active = true;
-        if (s->profiling) s->prof_positions += end - pos;
+        if (int rc = start_range(s, d_seq, len, base_pos, pos, end)) return rc;
         s->positions_done += end - pos;
-        s->dirty = true;
         pos = end;
-        if (!s->open_loop)
+        if (!s->open_loop || s->tau_lo)
             if (int rc = drain(s)) return rc; // closed loop: the next range is sized from this one's outcome
     }
     return FH_OK;
@@ -645,6 +720,8 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
             return bail("hipMalloc(left)", e);
     if ((e = hipMalloc(&s->clog, CLOG_CAP * sizeof(CollRec))) != hipSuccess) return bail("hipMalloc(clog)", e);
     if ((e = hipHostMalloc(&s->h_ctl, sizeof(Ctl), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    if ((e = hipHostMalloc(&s->h_tau, 64, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    s->no_spec = getenv("FH_NO_SPEC") != nullptr;
 
     if ((e = launch_fill_table(s->table, cap, s->stream)) != hipSuccess) return bail("fill_table", e);
     if (alloc_shards(s, s->live_target) != FH_OK) {
@@ -682,6 +759,7 @@ void fh_free(fh_sketcher *s) {
     if (s->h_text_tot) (void)hipHostFree(s->h_text_tot);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     if (s->h_out) (void)hipHostFree(s->h_out);
+    if (s->h_tau) (void)hipHostFree(s->h_tau);
     (void)hipFree(s->left_buf[0]);
     (void)hipFree(s->left_buf[1]);
     (void)hipFree(s->keys_a);
@@ -1083,6 +1161,13 @@ int fh_debug_counters(fh_sketcher *s, uint64_t *launches, uint64_t *relaunches, 
     if (launches) *launches = s->n_launches;
     if (relaunches) *relaunches = s->n_relaunches;
     if (big_prunes) *big_prunes = s->n_big_prunes;
+    return FH_OK;
+}
+
+int fh_debug_speculation(fh_sketcher *s, uint64_t *first_pass, uint64_t *second_pass) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (first_pass) *first_pass = s->n_spec;
+    if (second_pass) *second_pass = s->n_spec_fallback;
     return FH_OK;
 }
 

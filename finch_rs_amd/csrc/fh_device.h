@@ -96,6 +96,7 @@ struct SketchArgs {
     uint64_t base_pos;    // stream coordinate of seq[0]
     uint64_t seed;
     uint64_t hash_mask;   // ~0 unless the test hook is on
+    uint64_t tau_lo;      // HASLO launches admit only hashes > tau_lo (second pass after a speculative threshold)
     Ctl *ctl;
     uint32_t tiles_total;
     uint32_t n_units;        // ceil(tiles_total / UNIT_TILES)

@@ -154,7 +154,7 @@ __device__ __forceinline__ void classify_tile(const SketchArgs &a, u64 tile, int
 #ifndef FH_MIN_WAVES
 #define FH_MIN_WAVES 1
 #endif
-template <int K, bool MASKED, bool SEED0>
+template <int K, bool MASKED, bool SEED0, bool HASLO>
 __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs a) {
     __shared__ __attribute__((aligned(16))) u32 sTQ[1024];  // lo/hi(ascii4*c1), lo/hi(ascii4*c2)
     __shared__ __attribute__((aligned(16))) u32 sTP[128];   // lo/hi(partial group * its constant)
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
             if (MASKED) h &= a.hash_mask; // test hook only
             // windows that carry no k-mer hash garbage; they are rejected on the (rare) admit path only
             if (__builtin_expect(__any(h <= tau), 0)) { // wave-uniform branch
-                const bool take = (h <= tau) && ((W >> j) & 1u);
+                const bool take = (h <= tau) && ((W >> j) & 1u) && (!HASLO || h > a.tau_lo);
                 const u64 mask = __ballot(take);
                 const u32 cnt = (u32)__popcll(mask);
                 if (cnt) {
@@ -310,17 +310,25 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
             break;
         }
     }
-    // total_kmers (mash.rs:35): one atomic per wave
+    // total_kmers (mash.rs:35): one atomic per wave (a HASLO launch re-reads positions already counted)
     for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_xor(nvalid, off);
-    if (lane == 0 && nvalid)
+    if (!HASLO && lane == 0 && nvalid)
         atomicAdd((unsigned long long *)&a.ctl->kmer_counts[gw & 255u], (unsigned long long)nvalid);
 }
 
 template <int K>
 static hipError_t launch_k2_t(const SketchArgs &a, int blocks, hipStream_t st) {
-    if (a.hash_mask != ~0ull) hipLaunchKernelGGL((k2_sketch<K, true, false>), dim3(blocks), dim3(256), 0, st, a);
-    else if (a.seed == 0) hipLaunchKernelGGL((k2_sketch<K, false, true>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k2_sketch<K, false, false>), dim3(blocks), dim3(256), 0, st, a);
+    const bool lo = a.tau_lo != 0ull;
+    if (a.hash_mask != ~0ull) {
+        if (lo) hipLaunchKernelGGL((k2_sketch<K, true, false, true>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k2_sketch<K, true, false, false>), dim3(blocks), dim3(256), 0, st, a);
+    } else if (a.seed == 0) {
+        if (lo) hipLaunchKernelGGL((k2_sketch<K, false, true, true>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k2_sketch<K, false, true, false>), dim3(blocks), dim3(256), 0, st, a);
+    } else {
+        if (lo) hipLaunchKernelGGL((k2_sketch<K, false, false, true>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k2_sketch<K, false, false, false>), dim3(blocks), dim3(256), 0, st, a);
+    }
     return hipGetLastError();
 }
 

@@ -180,7 +180,10 @@ class HipSketcher:
     def debug_counters(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(self._L.fh_debug_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return {"launches": a.value, "relaunches": b.value, "big_prunes": c.value}
+        d, e = C.c_uint64(), C.c_uint64()
+        check(self._L.fh_debug_speculation(self._h, C.byref(d), C.byref(e)))
+        return {"launches": a.value, "relaunches": b.value, "big_prunes": c.value, "spec": d.value,
+                "spec_second_pass": e.value}
 
     # --- measurement ---
     def set_profiling(self, on: bool) -> None:

@@ -150,6 +150,9 @@ int fh_kernel_time(fh_sketcher *s, double *total_ms, uint64_t *launches, uint64_
 /* diagnostics: sketch-kernel launches, relaunches after a capacity stop, device-wide selections */
 int fh_debug_counters(fh_sketcher *s, uint64_t *launches, uint64_t *relaunches, uint64_t *big_prunes);
 
+/* diagnostics: blocks sketched with a speculative threshold, and how many of them needed the second pass */
+int fh_debug_speculation(fh_sketcher *s, uint64_t *first_pass, uint64_t *second_pass);
+
 /* --- device memory helpers so callers need no HIP/torch binding (tests, bench) --- */
 int fh_device_alloc(int device, uint64_t bytes, void **out);
 int fh_device_free(int device, void *p);

@@ -235,6 +235,40 @@ def test_capacity_stop_and_relaunch(n, inflight):
     assert c["relaunches"] >= 1, c
 
 
+def test_speculative_threshold_and_its_second_pass():
+    """first block of a fresh sketcher: threshold guessed from the block length; low-complexity input (fewer than
+    `size` distinct k-mers below the guess) must trigger the second pass and still be bit-exact"""
+    rng = np.random.default_rng(17)
+    # (a) diverse input: the guess holds
+    g = S.synth_genome_host(400000, 4)
+    reads = S.synth_reads_host(g, 0, 20000, 150, 4, 10000, 500)
+    sk = F.SketchParams.mash(1000, 1000, True, 21, 0).create_sketcher()
+    sk.push_block(reads)
+    ora = O.OracleSketcher(O.MASH, 1000, 21, 0)
+    ora.process_packed(reads, 0)
+    assert_same(sk, ora, "spec ok")
+    c = sk.debug_counters()
+    assert c["spec"] == 1 and c["spec_second_pass"] == 0, c
+    # (b) 700 distinct k-mers repeated many times: the guess captures far fewer than 1000
+    unit = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=720))
+    block = (unit + b"\x00") * 400
+    for kind, size in [("mash", 1000), ("scaled", 1000), ("mash", 20000)]:
+        params = (F.SketchParams.mash(size, size, True, 21, 0) if kind == "mash" else F.SketchParams.scaled(size, 21, 1e-6, 0))
+        sk = params.create_sketcher()
+        sk.push_block(block)
+        ora = O.OracleSketcher(O.MASH if kind == "mash" else O.SCALED, size, 21, 0, 1e-6)
+        ora.process_packed(block, 0)
+        assert_same(sk, ora, "spec second pass %s %d" % (kind, size))
+        c = sk.debug_counters()
+        assert c["spec"] == 1 and c["spec_second_pass"] == 1, c
+        # a second block after that goes through the ordinary path
+        sk2 = params.create_sketcher()
+        sk2.push_block(block)
+        sk2.push_block(reads)
+        ora.process_packed(reads, 0)
+        assert_same(sk2, ora, "spec second pass then more data")
+
+
 def test_sharded_merge_equals_whole():
     """global sketch == merge of read-block shard sketches"""
     gl, nr, rl, seed = 300000, 120000, 150, 7
