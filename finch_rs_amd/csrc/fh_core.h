@@ -343,18 +343,26 @@ FH_HD u64 mul64c(U64H a, u64 C) {
 
 // murmurhash3_x64_128(ascii(canonical k-mer), seed).0 from the m-form canonical word, 32-bit split tables.
 // SEED0: compile-time knowledge that seed == 0 (the default; drops three 64-bit ops).
+// The first-stage products of the key words, as gathered from the tables: words [2b], [2b+1] = k1*c1, k2*c2 of
+// block b; [2NB], [2NB+1] = the tail's.  Split from the rest of the hash so that the kernel can issue the
+// lookups of the next position before it runs the dependent multiply chain of the current one.
+template <int K>
+struct KeyWords {
+    static constexpr int N = 2 * (K / 16) + 2;
+    u32 lo[N], hi[N];
+};
+
 // T5 (only if tail_merge5(K)): [0..1023] = lo, [1024..2047] = hi of ascii_group5 * partial_const(K)
-template <int K, bool SEED0>
-FH_HD u64 murmur_h1_fast(u64 cm, u64 seed, const u32 *TQ, const u32 *TP, const u32 *T5) {
-    constexpr int NB = K / 16, TAIL = K & 15, NG_ALL = (K + 3) / 4;
+template <int K>
+FH_HD void murmur_lookup(u64 cm, const u32 *TQ, const u32 *TP, const u32 *T5, KeyWords<K> &w) {
+    constexpr int NG_ALL = (K + 3) / 4;
     constexpr bool M5 = tail_merge5(K);
     constexpr int NG = M5 ? NG_ALL - 2 : NG_ALL; // groups looked up one by one
     const u32 cml = (u32)cm, cmh = (u32)(cm >> 32);
-    u32 wl[2 * NB + 2], wh[2 * NB + 2];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int i = 0; i < 2 * NB + 2; ++i) wl[i] = wh[i] = 0;
+    for (int i = 0; i < KeyWords<K>::N; ++i) w.lo[i] = w.hi[i] = 0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -372,31 +380,37 @@ FH_HD u64 murmur_h1_fast(u64 cm, u64 seed, const u32 *TQ, const u32 *TP, const u
         const u32 hi_off = (gg.nb == 4) ? 256u : 64u;
         const u32 plo = *(const u32 *)((const char *)T + idx4);
         if (gg.hi) {
-            wh[gg.word] += plo;
+            w.hi[gg.word] += plo;
         } else {
             const u32 phi = *(const u32 *)((const char *)(T + hi_off) + idx4);
-            wl[gg.word] += plo; // at most one lo-half group per word: no carry
-            wh[gg.word] += phi;
+            w.lo[gg.word] += plo; // at most one lo-half group per word: no carry
+            w.hi[gg.word] += phi;
         }
     }
     if (M5) {
         const GroupGeom gq = group_geom(K, NG_ALL - 2); // the lo-half quad; the merged group ends at bit 0
         const u32 idx4 = (cml & 0x3FFu) << 2;
-        wl[gq.word] += *(const u32 *)((const char *)T5 + idx4);
-        wh[gq.word] += *(const u32 *)((const char *)(T5 + 1024) + idx4);
+        w.lo[gq.word] += *(const u32 *)((const char *)T5 + idx4);
+        w.hi[gq.word] += *(const u32 *)((const char *)(T5 + 1024) + idx4);
     }
+}
+
+// SEED0: compile-time knowledge that seed == 0 (the default; drops three 64-bit ops).
+template <int K, bool SEED0>
+FH_HD u64 murmur_finish(const KeyWords<K> &w, u64 seed) {
+    constexpr int NB = K / 16, TAIL = K & 15;
     u64 h1 = seed, h2 = seed;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int b = 0; b < NB; ++b) {
-        u64 k1 = mul64c(rotl64h<31>(U64H{wl[2 * b], wh[2 * b]}), MURMUR_C2);
+        u64 k1 = mul64c(rotl64h<31>(U64H{w.lo[2 * b], w.hi[2 * b]}), MURMUR_C2);
         if (SEED0 && b == 0) h1 = k1;
         else h1 ^= k1;
         h1 = join64(rotl64h<27>(make64(h1)));
         if (!(SEED0 && b == 0)) h1 = add64(h1, h2);
         h1 = mul5_add(h1, 0x52dce729ULL);
-        u64 k2 = mul64c(rotl64h<33>(U64H{wl[2 * b + 1], wh[2 * b + 1]}), MURMUR_C1);
+        u64 k2 = mul64c(rotl64h<33>(U64H{w.lo[2 * b + 1], w.hi[2 * b + 1]}), MURMUR_C1);
         if (SEED0 && b == 0) h2 = k2;
         else h2 ^= k2;
         h2 = join64(rotl64h<31>(make64(h2)));
@@ -404,12 +418,12 @@ FH_HD u64 murmur_h1_fast(u64 cm, u64 seed, const u32 *TQ, const u32 *TP, const u
         h2 = mul5_add(h2, 0x38495ab5ULL);
     }
     if (TAIL > 8) {
-        u64 k2 = mul64c(rotl64h<33>(U64H{wl[2 * NB + 1], wh[2 * NB + 1]}), MURMUR_C1);
+        u64 k2 = mul64c(rotl64h<33>(U64H{w.lo[2 * NB + 1], w.hi[2 * NB + 1]}), MURMUR_C1);
         if (SEED0 && NB == 0) h2 = k2;
         else h2 ^= k2;
     }
     if (TAIL > 0) {
-        u64 k1 = mul64c(rotl64h<31>(U64H{wl[2 * NB], wh[2 * NB]}), MURMUR_C2);
+        u64 k1 = mul64c(rotl64h<31>(U64H{w.lo[2 * NB], w.hi[2 * NB]}), MURMUR_C2);
         if (SEED0 && NB == 0) h1 = k1;
         else h1 ^= k1;
     }
@@ -420,6 +434,14 @@ FH_HD u64 murmur_h1_fast(u64 cm, u64 seed, const u32 *TQ, const u32 *TP, const u
     h1 = fmix64(h1);
     h2 = fmix64(h2);
     return add64(h1, h2);
+}
+
+// murmurhash3_x64_128(ascii(canonical k-mer), seed).0 from the m-form canonical word, 32-bit split tables.
+template <int K, bool SEED0>
+FH_HD u64 murmur_h1_fast(u64 cm, u64 seed, const u32 *TQ, const u32 *TP, const u32 *T5) {
+    KeyWords<K> w;
+    murmur_lookup<K>(cm, TQ, TP, T5, w);
+    return murmur_finish<K, SEED0>(w, seed);
 }
 
 // table slot key: admitted hashes are small numbers, so mix before scaling to the table size

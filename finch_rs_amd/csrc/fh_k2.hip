@@ -256,14 +256,31 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
         Roll<K> roll;
         roll.init(clo);
 
-#pragma unroll(UNROLL_J)
-        for (int j = 0; j < LANE_POS; ++j) {
+        // software pipeline: the table lookups of position j+1 are issued before the dependent multiply chain of
+        // position j runs, so their LDS latency is hidden inside the wave
+        auto window = [&](int j, u64 &cm, bool &is_rc) {
             const int bi = j + K - 1;
             const u32 c = (bi < 32) ? ((u32)(clo >> (2 * bi)) & 3u) : ((u32)(chi >> (2 * (bi - 32))) & 3u);
             roll.push(c);
-            bool is_rc;
-            const u64 cm = roll.canonical(is_rc);
-            u64 h = murmur_h1_fast<K, SEED0>(cm, a.seed, sTQ, sTP, sT5);
+            cm = roll.canonical(is_rc);
+        };
+        u64 cm_cur;
+        bool rc_cur;
+        KeyWords<K> kw_cur;
+        window(0, cm_cur, rc_cur);
+        murmur_lookup<K>(cm_cur, sTQ, sTP, sT5, kw_cur);
+#pragma unroll(UNROLL_J)
+        for (int j = 0; j < LANE_POS; ++j) {
+            u64 cm_nxt = 0;
+            bool rc_nxt = false;
+            KeyWords<K> kw_nxt;
+            if (j + 1 < LANE_POS) {
+                window(j + 1, cm_nxt, rc_nxt);
+                murmur_lookup<K>(cm_nxt, sTQ, sTP, sT5, kw_nxt);
+            }
+            const u64 cm = cm_cur;
+            const bool is_rc = rc_cur;
+            u64 h = murmur_finish<K, SEED0>(kw_cur, a.seed);
             if (MASKED) h &= a.hash_mask; // test hook only
             // windows that carry no k-mer hash garbage; they are rejected on the (rare) admit path only
             if (__builtin_expect(__any(h <= tau), 0)) { // wave-uniform branch
@@ -283,6 +300,11 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
                     }
                     qn += cnt;
                 }
+            }
+            if (j + 1 < LANE_POS) {
+                cm_cur = cm_nxt;
+                rc_cur = rc_nxt;
+                kw_cur = kw_nxt;
             }
         }
         __builtin_amdgcn_wave_barrier();
