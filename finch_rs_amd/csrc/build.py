@@ -55,7 +55,7 @@ def build(force=False, verbose=False):
             if o.strip():
                 print(o)
     objs = [j[-1] for j in jobs]
-    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lz", "-lpthread"])
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lz", "-lpthread", "-ldl"])
     return OUT
 
 

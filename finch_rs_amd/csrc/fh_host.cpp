@@ -3,6 +3,7 @@
 // this file parses FASTA/FASTQ, stages record bytes, applies the O(n) filters and serialises.
 //
 // Reference items mirrored (relative to the finch-rs tree) are cited at each function.
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -294,6 +295,161 @@ struct GzSource : ByteSource {
     }
 };
 
+// bzip2 / xz: the image ships the runtime libraries (libbz2.so.1, liblzma.so.5) but not their headers, so the few
+// entry points needed are declared here and bound with dlopen.  Layouts follow the public bzlib.h / lzma.h ABIs.
+struct BzStream {
+    char *next_in;
+    unsigned int avail_in, total_in_lo32, total_in_hi32;
+    char *next_out;
+    unsigned int avail_out, total_out_lo32, total_out_hi32;
+    void *state;
+    void *(*bzalloc)(void *, int, int);
+    void (*bzfree)(void *, void *);
+    void *opaque;
+};
+
+struct Bz2Api {
+    int (*init)(BzStream *, int, int) = nullptr;
+    int (*decompress)(BzStream *) = nullptr;
+    int (*end)(BzStream *) = nullptr;
+    bool ok = false;
+    Bz2Api() {
+        void *h = dlopen("libbz2.so.1", RTLD_NOW);
+        if (!h) h = dlopen("libbz2.so.1.0", RTLD_NOW);
+        if (!h) return;
+        init = (int (*)(BzStream *, int, int))dlsym(h, "BZ2_bzDecompressInit");
+        decompress = (int (*)(BzStream *))dlsym(h, "BZ2_bzDecompress");
+        end = (int (*)(BzStream *))dlsym(h, "BZ2_bzDecompressEnd");
+        ok = init && decompress && end;
+    }
+};
+
+struct Bz2Source : ByteSource {
+    static const Bz2Api &api() {
+        static Bz2Api a;
+        return a;
+    }
+    std::unique_ptr<ByteSource> inner;
+    BzStream bs{};
+    std::vector<uint8_t> inbuf;
+    bool eof = false, bad = false, init = false;
+    explicit Bz2Source(std::unique_ptr<ByteSource> in) : inner(std::move(in)), inbuf(1 << 20) {
+        init = api().ok && api().init(&bs, 0, 0) == 0;
+        bad = !init;
+    }
+    ~Bz2Source() override {
+        if (init) api().end(&bs);
+    }
+    bool failed() const override { return bad; }
+    size_t read(uint8_t *dst, size_t cap) override {
+        if (eof || bad) return 0;
+        bs.next_out = (char *)dst;
+        bs.avail_out = (unsigned int)std::min<size_t>(cap, 1u << 30);
+        while (bs.avail_out > 0) {
+            if (bs.avail_in == 0) {
+                const size_t got = inner->read(inbuf.data(), inbuf.size());
+                if (got == 0) {
+                    eof = true;
+                    break;
+                }
+                bs.next_in = (char *)inbuf.data();
+                bs.avail_in = (unsigned int)got;
+            }
+            const int rc = api().decompress(&bs);
+            if (rc == 4 /* BZ_STREAM_END */) {
+                // concatenated streams: start over if more input follows
+                api().end(&bs);
+                init = api().init(&bs, 0, 0) == 0;
+                if (!init) {
+                    bad = true;
+                    break;
+                }
+                char *no = bs.next_out;
+                (void)no;
+                continue;
+            }
+            if (rc != 0 /* BZ_OK */) {
+                bad = true;
+                break;
+            }
+        }
+        return (size_t)((uint8_t *)bs.next_out - dst);
+    }
+};
+
+// lzma_stream of liblzma 5.x (public ABI: see lzma/base.h)
+struct LzmaStream {
+    const uint8_t *next_in;
+    size_t avail_in;
+    uint64_t total_in;
+    uint8_t *next_out;
+    size_t avail_out;
+    uint64_t total_out;
+    const void *allocator;
+    void *internal;
+    void *reserved_ptr1, *reserved_ptr2, *reserved_ptr3, *reserved_ptr4;
+    uint64_t reserved_int1, reserved_int2;
+    size_t reserved_int3, reserved_int4;
+    int reserved_enum1, reserved_enum2;
+};
+
+struct LzmaApi {
+    int (*decoder)(LzmaStream *, uint64_t, uint32_t) = nullptr;
+    int (*code)(LzmaStream *, int) = nullptr;
+    void (*end)(LzmaStream *) = nullptr;
+    bool ok = false;
+    LzmaApi() {
+        void *h = dlopen("liblzma.so.5", RTLD_NOW);
+        if (!h) return;
+        decoder = (int (*)(LzmaStream *, uint64_t, uint32_t))dlsym(h, "lzma_stream_decoder");
+        code = (int (*)(LzmaStream *, int))dlsym(h, "lzma_code");
+        end = (void (*)(LzmaStream *))dlsym(h, "lzma_end");
+        ok = decoder && code && end;
+    }
+};
+
+struct XzSource : ByteSource {
+    static const LzmaApi &api() {
+        static LzmaApi a;
+        return a;
+    }
+    std::unique_ptr<ByteSource> inner;
+    LzmaStream ls{};
+    std::vector<uint8_t> inbuf;
+    bool eof = false, bad = false, init = false, in_eof = false;
+    explicit XzSource(std::unique_ptr<ByteSource> in) : inner(std::move(in)), inbuf(1 << 20) {
+        init = api().ok && api().decoder(&ls, UINT64_MAX, 0x08 /* LZMA_CONCATENATED */) == 0;
+        bad = !init;
+    }
+    ~XzSource() override {
+        if (init) api().end(&ls);
+    }
+    bool failed() const override { return bad; }
+    size_t read(uint8_t *dst, size_t cap) override {
+        if (eof || bad) return 0;
+        ls.next_out = dst;
+        ls.avail_out = cap;
+        while (ls.avail_out > 0) {
+            if (ls.avail_in == 0 && !in_eof) {
+                const size_t got = inner->read(inbuf.data(), inbuf.size());
+                if (got == 0) in_eof = true;
+                ls.next_in = inbuf.data();
+                ls.avail_in = got;
+            }
+            const int rc = api().code(&ls, in_eof ? 3 /* LZMA_FINISH */ : 0 /* LZMA_RUN */);
+            if (rc == 1 /* LZMA_STREAM_END */) {
+                eof = true;
+                break;
+            }
+            if (rc != 0 /* LZMA_OK */) {
+                bad = true;
+                break;
+            }
+        }
+        return (size_t)(ls.next_out - dst);
+    }
+};
+
 // needletail parse_fastx_reader: sniff two magic bytes (lib.rs:60)
 static int open_source(std::unique_ptr<ByteSource> raw, std::unique_ptr<ByteSource> &out, bool *is_gz = nullptr,
                        int *first_byte = nullptr) {
@@ -312,10 +468,12 @@ static int open_source(std::unique_ptr<ByteSource> raw, std::unique_ptr<ByteSour
     pre->inner = std::move(raw);
     if (is_gz) *is_gz = gz;
     if (first_byte) *first_byte = got ? pre->prefix[0] : -1;
-    if (bz || xz)
-        return hfail(FH_ERR_UNSUPPORTED, "%s-compressed input: no %s development files in this build", bz ? "bzip2" : "xz",
-                     bz ? "libbz2" : "liblzma");
+    if (bz && !Bz2Source::api().ok) return hfail(FH_ERR_UNSUPPORTED, "bzip2-compressed input: libbz2.so.1 not found");
+    if (xz && !XzSource::api().ok) return hfail(FH_ERR_UNSUPPORTED, "xz-compressed input: liblzma.so.5 not found");
+    if (is_gz) *is_gz = gz || bz || xz; // "compressed": not eligible for device-side text parsing
     if (gz) out = std::make_unique<GzSource>(std::move(pre));
+    else if (bz) out = std::make_unique<Bz2Source>(std::move(pre));
+    else if (xz) out = std::make_unique<XzSource>(std::move(pre));
     else out = std::move(pre);
     return FH_OK;
 }

@@ -8,7 +8,7 @@
  *                                                       rayon par_iter over files -> worker threads, each with its
  *                                                       own device sketcher; files are mapped round-robin to GPUs)
  *   finch_sketch_buffer     finch::sketch_stream       lib/src/lib.rs:51-94   (in-memory FASTA/FASTQ[.gz] image)
- *   FASTX reading           needletail 0.5.0 parse_fastx_reader (lib.rs:60-68): gz sniffed by magic bytes,
+ *   FASTX reading           needletail 0.5.0 parse_fastx_reader (lib.rs:60-68): gz / bz2 / xz sniffed by magic bytes,
  *                           '>' FASTA (multi-line), '@' FASTQ (4-line records)
  *   filtering               FilterParams::filter_counts lib/src/filtering.rs:60-87 (strand -> err -> abundance)
  *   post filter             SketchParams::process_post_filter lib/src/sketch_schemes/mod.rs:115-128

@@ -50,6 +50,13 @@ def test_fastq_scan_and_errors(golden_dir):
     n, tb, fmt = H.fastx_scan(b"@r1\r\nACGT\r\n+\r\nIIII\r\n@r2\nAC\n+\nII")  # CRLF and no final newline
     assert (n, tb) == (2, 6)
     assert H.fastx_scan(gzip.compress(fq)) == (3, 6, 2)
+    import bz2, lzma
+    assert H.fastx_scan(bz2.compress(fq)) == (3, 6, 2)     # needletail sniffs 'BZ' ...
+    assert H.fastx_scan(lzma.compress(fq)) == (3, 6, 2)    # ... and FD 37 (xz)
+    big = fq * 200000
+    assert H.fastx_scan(bz2.compress(big)) == (600000, 1200000, 2)
+    assert H.fastx_scan(lzma.compress(big, preset=1)) == (600000, 1200000, 2)
+    assert H.fastx_scan(gzip.compress(big, 1) + gzip.compress(fq)) == (600003, 1200006, 2)  # concatenated members
     for bad in [b"@r1\nACGT\n+\nIII\n", b"@r1\nACGT\nIIII\n+\n", b"@r1\nACGT\n", b"xyz", b""]:
         with pytest.raises(FinchError):
             H.fastx_scan(bad)
