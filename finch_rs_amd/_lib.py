@@ -73,6 +73,14 @@ def load():
     """dlopen libfinch_hip.so and bind every declared symbol.  Raises if the library is missing."""
     global _lib
     if _lib is None:
+        if not os.path.exists(SO_PATH) and "FH_LIB" not in os.environ and not os.environ.get("FH_NO_AUTOBUILD"):
+            # source checkout without the built artefact: compile it (hipcc, ~20 s).  This builds the HIP library
+            # itself -- there is no alternative implementation to fall back to.
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("fh_build", os.path.join(_HERE, "csrc", "build.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            mod.build()
         if not os.path.exists(SO_PATH):
             raise FinchHipError(FH_ERR_NO_DEVICE, "%s not built -- run `python finch_rs_amd/csrc/build.py` "
                                 "(or __graft_entry__.build())" % SO_PATH)
