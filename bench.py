@@ -33,6 +33,37 @@ SUB_PPM, N_PPM = 10_000, 500
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+_SHARED = {}  # inherited by fork()ed workers: no pickling of the sample
+
+
+def _usable_cpus() -> int:
+    """hardware threads this process may actually use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
+def _oracle_shard_job(job):
+    from oracle import oracle as O
+    i, per_bytes, n, k = job
+    data = _SHARED["big"][i * per_bytes:(i + 1) * per_bytes]
+    o = O.OracleSketcher(O.MASH, n, k, 0)
+    o.process_packed(data, 0)
+    return len(o.to_vec()[0])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,6 +74,8 @@ def main():
     ap.add_argument("--n", type=int, default=1000)
     ap.add_argument("--cpu-sample-mbases", type=float, default=450.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-allcores-mbases", type=float, default=100.0,
+                    help="Mbases per process for the extra all-cores CPU figure (0 = skip)")
     ap.add_argument("--max-launch", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -156,7 +189,14 @@ def main():
         except Exception:
             pass
 
+    # measured streaming-read peak of this box next to the spec peak; not in the timed region
+    try:
+        roofline["measured_stream_read_GBps"] = round(S.measure_read_bandwidth(dr, min(nbytes, 4 << 30) // 16 * 16), 1)
+    except Exception:
+        roofline["measured_stream_read_GBps"] = None
+
     cpu = None
+    cpu_all = None
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O  # the checker, timed as the reported CPU baseline ("port")
         ns = min(n_reads, int(args.cpu_sample_mbases * 1e6 / READ_LEN))
@@ -168,8 +208,24 @@ def main():
         cpu = {"value": round(ns * READ_LEN / ct, 1), "unit": "bases/s", "cores": 1, "kind": "port",
                "sample": "first %d reads (%.0f Mbases) of the same stream; single thread = the reference's "
                          "behaviour for a single input file (rayon parallelises over files only)" % (ns, ns * READ_LEN / 1e6)}
-        # cheap end-to-end sanity: the GPU sketch of the full stream must contain only hashes <= the
-        # sample's n-th hash or be consistent where they overlap (full parity is in tests/)
+        # extra, NOT the reference's behaviour (it runs one input file on one core): the same oracle on read-block
+        # shards of the stream, one process per host core, partial sketches merged afterwards
+        if args.cpu_allcores_mbases > 0:
+            import multiprocessing as mp
+            ncpu = max(1, min(_usable_cpus(), 256))
+            per = min(n_reads // ncpu, int(args.cpu_allcores_mbases * 1e6 / READ_LEN), int(3e9 / READ_LEN) // ncpu)
+            if per > 0:
+                _SHARED["big"] = dr.download(ncpu * per * rec)
+                jobs = [(i, per * rec, args.n, args.k) for i in range(ncpu)]
+                with mp.get_context("fork").Pool(ncpu) as pool:
+                    pool.map(_oracle_shard_job, [(0, 151 * 64, args.n, args.k)] * ncpu, chunksize=1)  # start the workers
+                    c0 = time.perf_counter()
+                    pool.map(_oracle_shard_job, jobs, chunksize=1)
+                    ct = time.perf_counter() - c0
+                _SHARED.clear()
+                cpu_all = {"value": round(ncpu * per * READ_LEN / ct, 1), "unit": "bases/s", "cores": ncpu, "kind": "port",
+                           "sample": "%d read-block shards of %d reads, one oracle process per hardware thread (not what the "
+                                     "reference does for a single file)" % (ncpu, per)}
     out = {
         "metric": "bases/sec sketched (k=%d, n=%d)" % (args.k, args.n),
         "value": round(value, 1), "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -178,7 +234,7 @@ def main():
         "config": {"workload": "%.1f Gbase synthetic 150 bp reads per GPU (configs[1]), mash k=%d n=%d seed 0, "
                                "input resident in HBM as packed stream" % (args.gbases, args.k, args.n),
                    "reads_per_gpu": n_reads, "parallelism": "read-block sharding x%d, host merge" % world},
-        "roofline": roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all,
         "sketch_check": {"n_hashes": int(len(gathered[0])), "min_hash": int(gathered[0]["hash"][0]) if len(gathered[0]) else None,
                          "max_hash": int(gathered[0]["hash"][-1]) if len(gathered[0]) else None},
     }

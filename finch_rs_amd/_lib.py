@@ -54,6 +54,7 @@ SYMBOLS = {
     "fh_kernel_time": (C.c_int, [_P, C.POINTER(C.c_double), _U64P, _U64P]),
     "fh_debug_counters": (C.c_int, [_P, _U64P, _U64P, _U64P]),
     "fh_debug_speculation": (C.c_int, [_P, _U64P, _U64P]),
+    "fh_measure_read_bandwidth": (C.c_int, [C.c_int, _P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     "fh_device_alloc": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(_P)]),
     "fh_device_free": (C.c_int, [C.c_int, _P]),
     "fh_copy_to_device": (C.c_int, [C.c_int, _P, _P, C.c_uint64]),

@@ -1171,6 +1171,31 @@ int fh_debug_speculation(fh_sketcher *s, uint64_t *first_pass, uint64_t *second_
     return FH_OK;
 }
 
+int fh_measure_read_bandwidth(int device, const void *dev_bytes, uint64_t bytes, int reps, double *gb_per_s) {
+    if (!dev_bytes || !gb_per_s || bytes < 16) return fail(FH_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    uint32_t *sink = nullptr;
+    HIP_TRY(hipMalloc(&sink, 16));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    double best = 0.0;
+    for (int r = 0; r < std::max(reps, 1) + 1; ++r) { // first pass warms up
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        HIP_TRY(launch_read_probe(dev_bytes, bytes, sink, nullptr));
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0 && ms > 0.f) best = std::max(best, (double)(bytes / 16 * 16) / (ms * 1e-3) / 1e9);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    *gb_per_s = best;
+    return FH_OK;
+}
+
 int fh_device_alloc(int device, uint64_t bytes, void **out) {
     if (!out) return fail(FH_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(device));

@@ -465,6 +465,29 @@ hipError_t launch_init_ctl(Ctl *ctl, u64 tau0, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// streaming-read probe (measured HBM read peak of the box; reporting only)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_read_probe(const uint4 *p, u64 n16, u32 *sink) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 acc = 0;
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) { // four loads in flight per lane
+        const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+    }
+    for (; i < n16; i += stride) {
+        const uint4 a = p[i];
+        acc ^= a.x ^ a.y ^ a.z ^ a.w;
+    }
+    if (acc == 0x9E3779B9u) *sink = acc; // practically never: keeps the loads alive
+}
+
+hipError_t launch_read_probe(const void *p, u64 bytes, u32 *sink, hipStream_t st) {
+    hipLaunchKernelGGL(k_read_probe, dim3(256 * 8), dim3(256), 0, st, (const uint4 *)p, bytes / 16, sink);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // synthetic inputs (not part of the timed path)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_synth_genome(uint8_t *out, u64 len, u64 seed) {

@@ -247,5 +247,12 @@ def synth_reads_device(out: DeviceBuffer, genome: DeviceBuffer, genome_len: int,
                                             genome_len, first_read, n_reads, read_len, seed, sub_ppm, n_ppm))
 
 
+def measure_read_bandwidth(buf: "DeviceBuffer", nbytes: int, reps: int = 3) -> float:
+    """streaming-read GB/s of this box's HBM over a resident buffer (reporting only)"""
+    out = C.c_double()
+    check(_lib.load().fh_measure_read_bandwidth(buf.device, C.c_void_p(buf.ptr), nbytes, reps, C.byref(out)))
+    return out.value
+
+
 def device_count() -> int:
     return _lib.load().fh_device_count()

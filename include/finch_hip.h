@@ -153,6 +153,10 @@ int fh_debug_counters(fh_sketcher *s, uint64_t *launches, uint64_t *relaunches, 
 /* diagnostics: blocks sketched with a speculative threshold, and how many of them needed the second pass */
 int fh_debug_speculation(fh_sketcher *s, uint64_t *first_pass, uint64_t *second_pass);
 
+/* streaming-read bandwidth of this box's HBM over [dev_bytes, dev_bytes+bytes) (16 B/lane loads, best of `reps`):
+ * the measured counterpart of the 8 TB/s spec peak that bench.py prints next to the roofline */
+int fh_measure_read_bandwidth(int device, const void *dev_bytes, uint64_t bytes, int reps, double *gb_per_s);
+
 /* --- device memory helpers so callers need no HIP/torch binding (tests, bench) --- */
 int fh_device_alloc(int device, uint64_t bytes, void **out);
 int fh_device_free(int device, void *p);

@@ -50,7 +50,7 @@ def test_full_size_stream_bit_exact_vs_sharded_oracle():
     gbases = float(os.environ.get("FH_FULL_GBASES", "10"))
     n_reads = int(np.ceil(gbases * 1e9 / RL))
     rec = RL + 1
-    ncpu = max(1, min(len(os.sched_getaffinity(0)), 96))
+    ncpu = max(1, min(len(os.sched_getaffinity(0)), 96))  # more processes than granted cores only cost a little
     if ncpu < 16 and "FH_FULL_GBASES" not in os.environ:
         gbases = 1.0  # keep the CPU side of the check within a minute on small hosts
         n_reads = int(np.ceil(gbases * 1e9 / RL))
