@@ -396,8 +396,27 @@ FH_HD void murmur_lookup(u64 cm, const u32 *TQ, const u32 *TP, const u32 *T5, Ke
 }
 
 // SEED0: compile-time knowledge that seed == 0 (the default; drops three 64-bit ops).
+// The hash is produced in two steps so that the hot loop can reject on high words alone: `parts` are the two
+// fmix64 results short of their last `k ^= k >> 33` (which only touches the low word), the hash is
+// (a ^ a>>33) + (b ^ b>>33).  hi(hash) is hi(a) + hi(b) or that plus one, so
+//     hash <= tau  =>  hi(a) + hi(b) + 1  (mod 2^32)  <=  hi(tau) + 1
+// (for hi(tau) != 2^32-1; the wrap of the left side to 0 covers hi(a)+hi(b) = 2^32-1 with a carry).
+struct HashParts {
+    u64 a, b;
+};
+FH_HD u64 fmix64_head(u64 k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    return k;
+}
+FH_HD u64 parts_hash(HashParts p) { return add64(p.a ^ (p.a >> 33), p.b ^ (p.b >> 33)); }
+FH_HD u32 parts_hi_plus1(HashParts p) { return (u32)(p.a >> 32) + (u32)(p.b >> 32) + 1u; }
+FH_HD u32 tau_hi_bound(u64 tau) { return (u32)(tau >> 32) == 0xFFFFFFFFu ? 0xFFFFFFFFu : (u32)(tau >> 32) + 1u; }
+
 template <int K, bool SEED0>
-FH_HD u64 murmur_finish(const KeyWords<K> &w, u64 seed) {
+FH_HD HashParts murmur_finish_parts(const KeyWords<K> &w, u64 seed) {
     constexpr int NB = K / 16, TAIL = K & 15;
     u64 h1 = seed, h2 = seed;
 #if defined(__HIPCC__)
@@ -431,9 +450,12 @@ FH_HD u64 murmur_finish(const KeyWords<K> &w, u64 seed) {
     h2 ^= (u64)K;
     h1 = add64(h1, h2);
     h2 = add64(h2, h1);
-    h1 = fmix64(h1);
-    h2 = fmix64(h2);
-    return add64(h1, h2);
+    return HashParts{fmix64_head(h1), fmix64_head(h2)};
+}
+
+template <int K, bool SEED0>
+FH_HD u64 murmur_finish(const KeyWords<K> &w, u64 seed) {
+    return parts_hash(murmur_finish_parts<K, SEED0>(w, seed));
 }
 
 // murmurhash3_x64_128(ascii(canonical k-mer), seed).0 from the m-form canonical word, 32-bit split tables.

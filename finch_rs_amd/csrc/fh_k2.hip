@@ -187,6 +187,8 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
     __syncthreads();
 
     const u64 tau = __hip_atomic_load(&a.ctl->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // readfirstlane keeps the bound an opaque scalar (otherwise the select inside is re-expanded per position)
+    const u32 tau_hi1 = (u32)__builtin_amdgcn_readfirstlane((int)tau_hi_bound(tau));
 
     const u32 gw = blockIdx.x * WAVES_PER_BLOCK + (u32)wave;
     u32 *codes_ring = sCodes[wave];
@@ -280,10 +282,13 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
             }
             const u64 cm = cm_cur;
             const bool is_rc = rc_cur;
-            u64 h = murmur_finish<K, SEED0>(kw_cur, a.seed);
-            if (MASKED) h &= a.hash_mask; // test hook only
+            const HashParts hp = murmur_finish_parts<K, SEED0>(kw_cur, a.seed);
+            // reject on the high words alone (fh_core.h, HashParts); the hash_mask test hook needs the full hash.
             // windows that carry no k-mer hash garbage; they are rejected on the (rare) admit path only
-            if (__builtin_expect(__any(h <= tau), 0)) { // wave-uniform branch
+            const bool cand = MASKED ? ((parts_hash(hp) & a.hash_mask) <= tau) : (parts_hi_plus1(hp) <= tau_hi1);
+            if (__builtin_expect(__any(cand), 0)) { // wave-uniform branch
+                u64 h = parts_hash(hp);
+                if (MASKED) h &= a.hash_mask; // test hook only
                 const bool take = (h <= tau) && ((W >> j) & 1u) && (!HASLO || h > a.tau_lo);
                 const u64 mask = __ballot(take);
                 const u32 cnt = (u32)__popcll(mask);

@@ -91,3 +91,22 @@ extern "C" void fhcore_synth(uint8_t *genome, uint64_t glen, uint8_t *reads, uin
         for (uint32_t j = 0; j <= rl; ++j)
             reads[r * (rl + 1) + j] = synth_read_byte(genome, glen, first + r, j, rl, seed, sub_ppm, n_ppm);
 }
+
+// high-word prefilter (fh_core.h HashParts): returns the number of violations of
+//   parts_hash(p) <= tau  =>  parts_hi_plus1(p) <= tau_hi_bound(tau)
+// over the given (a, b, tau) triples, and writes the prefilter's pass count (selectivity check)
+extern "C" uint64_t fhcore_prefilter_check(const uint64_t *a, const uint64_t *b, const uint64_t *tau, uint64_t n,
+                                           uint64_t *n_pass, uint64_t *n_true) {
+    uint64_t bad = 0, pass = 0, tr = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const HashParts p{a[i], b[i]};
+        const bool truth = parts_hash(p) <= tau[i];
+        const bool cand = parts_hi_plus1(p) <= tau_hi_bound(tau[i]);
+        if (truth && !cand) ++bad;
+        pass += cand;
+        tr += truth;
+    }
+    *n_pass = pass;
+    *n_true = tr;
+    return bad;
+}

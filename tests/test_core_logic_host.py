@@ -81,3 +81,37 @@ def test_palindrome_reports_rc(core):
     # ACGT and AATT are their own reverse complement: tie -> is_rc = true (canonical_kmers: `if fwd < rc`)
     assert out[1][0] == 1 and out[2][0] == 1
     assert out[1][8] == 1 and out[2][8] == 1
+
+
+def test_high_word_prefilter_never_drops_a_candidate(core):
+    """the hot loop rejects on hi(a)+hi(b)+1 <= hi(tau)+1 before it forms the 64-bit hash: that test must
+    pass every position whose real hash is <= tau (carry out of the low words, wrap at 2^32-1, tau = max)"""
+    core.fhcore_prefilter_check.restype = C.c_uint64
+    core.fhcore_prefilter_check.argtypes = [C.c_void_p] * 3 + [C.c_uint64, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(7)
+    n = 400000
+    a = rng.integers(0, 2**64, n, dtype=np.uint64)
+    b = rng.integers(0, 2**64, n, dtype=np.uint64)
+    tau = rng.integers(0, 2**64, n, dtype=np.uint64)
+    # adversarial quarter: sums that land just below / above tau, with and without a low-word carry
+    q = n // 4
+    tau[:q] = rng.integers(0, 2**40, q, dtype=np.uint64)  # small thresholds like a converged sketch
+    fin = lambda x: x ^ (x >> np.uint64(33))
+    target = rng.integers(0, 2**41, q, dtype=np.uint64)
+    # choose b so that fin(a) + fin(b) == target: fin is an involution on the low 31 bits given the high word
+    want = (target - fin(a[:q])).astype(np.uint64)
+    b[:q] = want ^ (want >> np.uint64(33))
+    assert np.array_equal((fin(a[:q]) + fin(b[:q])).astype(np.uint64), target)
+    tau[q:q + 1000] = np.uint64(2**64 - 1)
+    tau[q + 1000:q + 2000] = np.uint64(0xFFFFFFFF00000000)
+    tau[q + 2000:q + 3000] = np.uint64(0xFFFFFFFEFFFFFFFF)
+    n_pass = C.c_uint64(0)
+    n_true = C.c_uint64(0)
+    bad = core.fhcore_prefilter_check(a.ctypes.data, b.ctypes.data, tau.ctypes.data, n, C.byref(n_pass), C.byref(n_true))
+    assert bad == 0
+    assert n_true.value > q // 4  # the adversarial part really produced hits
+    # selectivity: the prefilter passes at most the true hits plus a sliver (two extra high-word values)
+    small = tau < np.uint64(2**40)
+    h = (fin(a) + fin(b)).astype(np.uint64)
+    extra = np.count_nonzero(small & (h > tau) & ((h >> np.uint64(32)) <= (tau >> np.uint64(32)) + np.uint64(1)))
+    assert extra < q
