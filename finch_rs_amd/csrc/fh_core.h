@@ -396,23 +396,41 @@ FH_HD void murmur_lookup(u64 cm, const u32 *TQ, const u32 *TP, const u32 *T5, Ke
 }
 
 // SEED0: compile-time knowledge that seed == 0 (the default; drops three 64-bit ops).
-// The hash is produced in two steps so that the hot loop can reject on high words alone: `parts` are the two
-// fmix64 results short of their last `k ^= k >> 33` (which only touches the low word), the hash is
-// (a ^ a>>33) + (b ^ b>>33).  hi(hash) is hi(a) + hi(b) or that plus one, so
+// The hash is produced in two steps so that the hot loop can reject on high words alone.  `HashParts` are the two
+// fmix64 states short of their last multiply and xor-shift:  a = ka * M2, b = kb * M2,
+// hash = (a ^ a>>33) + (b ^ b>>33).  The final xor-shifts only touch the low words, so hi(hash) is hi(a) + hi(b)
+// or that plus one, and
 //     hash <= tau  =>  hi(a) + hi(b) + 1  (mod 2^32)  <=  hi(tau) + 1
-// (for hi(tau) != 2^32-1; the wrap of the left side to 0 covers hi(a)+hi(b) = 2^32-1 with a carry).
+// (for hi(tau) != 2^32-1; the wrap of the left side to 0 covers hi(a)+hi(b) = 2^32-1 with a carry).  Multiplication
+// by M2 is linear mod 2^32 in the cross terms, so the sum of the two high words needs two mul_hi and two mul_lo
+// instead of two full 64-bit products:
+//     hi(a) + hi(b) = mulhi(ka.lo, M2.lo) + mulhi(kb.lo, M2.lo) + (ka.lo + kb.lo) * M2.hi + (ka.hi + kb.hi) * M2.lo
 struct HashParts {
-    u64 a, b;
+    u64 ka, kb;
 };
+constexpr u64 FMIX_M1 = 0xff51afd7ed558ccdULL, FMIX_M2 = 0xc4ceb9fe1a85ec53ULL;
 FH_HD u64 fmix64_head(u64 k) {
     k ^= k >> 33;
-    k *= 0xff51afd7ed558ccdULL;
+    k *= FMIX_M1;
     k ^= k >> 33;
-    k *= 0xc4ceb9fe1a85ec53ULL;
     return k;
 }
-FH_HD u64 parts_hash(HashParts p) { return add64(p.a ^ (p.a >> 33), p.b ^ (p.b >> 33)); }
-FH_HD u32 parts_hi_plus1(HashParts p) { return (u32)(p.a >> 32) + (u32)(p.b >> 32) + 1u; }
+FH_HD u32 mulhi32(u32 x, u32 y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(x, y);
+#else
+    return (u32)(((u64)x * y) >> 32);
+#endif
+}
+FH_HD u64 parts_hash(HashParts p) {
+    const u64 a = p.ka * FMIX_M2, b = p.kb * FMIX_M2;
+    return add64(a ^ (a >> 33), b ^ (b >> 33));
+}
+FH_HD u32 parts_hi_plus1(HashParts p) {
+    constexpr u32 M2L = (u32)FMIX_M2, M2H = (u32)(FMIX_M2 >> 32);
+    const u32 al = (u32)p.ka, ah = (u32)(p.ka >> 32), bl = (u32)p.kb, bh = (u32)(p.kb >> 32);
+    return mulhi32(al, M2L) + mulhi32(bl, M2L) + (al + bl) * M2H + (ah + bh) * M2L + 1u;
+}
 FH_HD u32 tau_hi_bound(u64 tau) { return (u32)(tau >> 32) == 0xFFFFFFFFu ? 0xFFFFFFFFu : (u32)(tau >> 32) + 1u; }
 
 template <int K, bool SEED0>

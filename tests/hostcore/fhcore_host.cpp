@@ -99,7 +99,7 @@ extern "C" uint64_t fhcore_prefilter_check(const uint64_t *a, const uint64_t *b,
                                            uint64_t *n_pass, uint64_t *n_true) {
     uint64_t bad = 0, pass = 0, tr = 0;
     for (uint64_t i = 0; i < n; ++i) {
-        const HashParts p{a[i], b[i]};
+        const HashParts p{a[i], b[i]}; // (ka, kb)
         const bool truth = parts_hash(p) <= tau[i];
         const bool cand = parts_hi_plus1(p) <= tau_hi_bound(tau[i]);
         if (truth && !cand) ++bad;
