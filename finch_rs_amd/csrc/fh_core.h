@@ -148,23 +148,7 @@ constexpr GroupGeom group_geom(int K, int g) {
 constexpr u64 partial_const(int K) { return group_geom(K, (K + 3) / 4 - 1).is_k2 ? MURMUR_C2 : MURMUR_C1; }
 constexpr int partial_nb(int K) { return K & 3; }
 
-// K = 4m+1 with the last full 4-base group in the low half of its 64-bit key word: that group and the single
-// trailing base are five consecutive key bytes of ONE word, so one 1024-entry table replaces two lookups.
-constexpr bool tail_merge5(int K) { return (K & 3) == 1 && K >= 5 && group_geom(K, (K + 3) / 4 - 1).hi; }
-
-// ASCII bytes of a 5-base group (m-form, first base in byte 0) as a 40-bit value
-FH_HD u64 ascii_group5(u32 q) {
-    u64 w = 0;
-    for (int i = 0; i < 5; ++i) {
-        u32 code = (q >> (2 * (4 - i))) & 3u;
-        u64 ch = code == 0 ? 0x41u : code == 1 ? 0x43u : code == 2 ? 0x47u : 0x54u;
-        w |= ch << (8 * i);
-    }
-    return w;
-}
-FH_HD u64 lut_entry5(u32 q, u64 c) { return ascii_group5(q) * c; }
-
-// Table entry builders (run once per workgroup into LDS / once on the host for tests)
+// Entry of the plain first-stage tables (64-bit; used by murmur_h1_lut, the host-side cross-check form)
 FH_HD u64 lut_entry(u32 q, int nb, u64 c) { return (u64)ascii_group(q, nb) * c; }
 
 // murmurhash3_x64_128(ascii(canonical k-mer), seed).0 given the m-form canonical word.
@@ -287,9 +271,28 @@ FH_HD u32 window_valid_mask(u64 g64) {
     return (u32)W;
 }
 
-// ---- 32-bit split lookup tables for the LUT murmur (device layout: u32 T[4][256] + partial tables) ----
-// TQ[0] = lo(ascii4*c1), TQ[1] = hi(ascii4*c1), TQ[2] = lo(ascii4*c2), TQ[3] = hi(ascii4*c2)
-// TP[0] = lo(ascii_nb*cp), TP[1] = hi(ascii_nb*cp)  (64 entries each, nb = K & 3)
+// ---- lookup tables with murmur3's second stage folded in ----
+// A key word x (8 key bytes: group A = low 4 bytes, group B = high 4 bytes, either possibly short) enters the
+// hash as  kx = rotl(x * c, R) * C  with (c, R, C) = (c1, 31, c2) for k1 words and (c2, 33, c1) for k2 words.
+// x * c = u + (v << 32) with u = ascii(A) * c (64 bit) and v = lo32(ascii(B) * c): the first multiply is linear in
+// the groups, so u and v come from tables indexed by the 2-bit codes of A and B.  The rotate and second multiply
+// are folded into the tables as far as linearity reaches; w = hi(u) + v (mod 2^32) is the only non-linear coupling:
+//   R = 33:  rotl(x,33) = (u << 33) + 2w + (lo(u) >> 31)            =>  kx = U2[A] + w * (2C)
+//            U2[A] = ((u << 33) + (lo(u) >> 31)) * C
+//   R = 31:  rotl(x,31) = (u << 31) + (v << 63) + (w >> 1)          =>  kx = U1[A] + ((v << 31) << 32) + (w >> 1) * C
+//            U1[A] = (u << 31) * C          (C odd: (v << 63) * C = v << 63)
+//   no B  :  kx = F[A] straight from the table (A up to five bases: a lone trailing base is merged into A).
+// That is one 32x32->64 multiply-add, one mul_lo and a few adds per two-group word instead of a rotate (2 alignbit)
+// and a full 64-bit multiply (4 multiplier ops), and nothing at all for the single-group tail word.
+// Records are laid out for one LDS access per group: A records 16 B {lo(U), hi(U), hi(u), -}, B records 8 B
+// {v, v << 31}, single-group records 8 B {lo(kx), hi(kx)} (an 8-byte LDS read costs what a 4-byte one does).
+struct alignas(16) Rec4 {
+    u32 x, y, z, w;
+};
+struct alignas(8) Rec2 {
+    u32 x, y;
+};
+
 struct U64H {
     u32 lo, hi;
 };
@@ -341,58 +344,162 @@ FH_HD u64 mul64c(U64H a, u64 C) {
     return p + ((u64)cross << 32);
 }
 
-// murmurhash3_x64_128(ascii(canonical k-mer), seed).0 from the m-form canonical word, 32-bit split tables.
-// SEED0: compile-time knowledge that seed == 0 (the default; drops three 64-bit ops).
-// The first-stage products of the key words, as gathered from the tables: words [2b], [2b+1] = k1*c1, k2*c2 of
-// block b; [2NB], [2NB+1] = the tail's.  Split from the rest of the hash so that the kernel can issue the
-// lookups of the next position before it runs the dependent multiply chain of the current one.
+// geometry of key word i of a K-byte key (words 2b, 2b+1 = k1, k2 of block b; 2NB, 2NB+1 = the tail's)
+struct WordGeom {
+    int kind;   // 0 = absent, 1 = single group (table holds the finished word), 2 = two groups
+    int nbA, nbB; // bases in the low / high group (nbA = 5: trailing base merged into the low group)
+    int shiftA, shiftB; // right shift of the m-form canonical word that brings the group to bit 0
+    bool is_k2;
+    bool partial; // the word's last group is looked up in the per-K table P
+};
+constexpr WordGeom word_geom(int K, int i) {
+    WordGeom r{};
+    const int NB = K / 16;
+    const int off = (i < 2 * NB) ? 8 * i : 16 * NB + 8 * (i - 2 * NB);
+    const int rem = K - off;
+    r.is_k2 = (i & 1) != 0;
+    r.nbA = rem <= 0 ? 0 : (rem < 4 ? rem : 4);
+    r.nbB = rem <= 4 ? 0 : (rem - 4 < 4 ? rem - 4 : 4);
+    if (r.nbB == 1) {
+        r.nbA = 5;
+        r.nbB = 0;
+    }
+    r.shiftA = 2 * (K - off - r.nbA);
+    r.shiftB = r.nbB ? 2 * (K - off - 4 - r.nbB) : 0;
+    r.kind = r.nbA == 0 ? 0 : (r.nbB == 0 ? 1 : 2);
+    r.partial = r.kind == 1 || (r.kind == 2 && r.nbB < 4);
+    return r;
+}
+constexpr int n_key_words(int K) { return 2 * (K / 16) + 2; }
+// the one word of a key that uses the per-K table P (always the last one present), -1 if none (K % 8 == 0)
+constexpr int partial_word(int K) {
+    for (int i = 0; i < n_key_words(K); ++i)
+        if (word_geom(K, i).kind != 0 && word_geom(K, i).partial) return i;
+    return -1;
+}
+// entries of P: finished words of a single group (4^nbA) or B records of a short high group (4^nbB)
+constexpr int partial_entries(int K) {
+    const int i = partial_word(K);
+    if (i < 0) return 1;
+    const WordGeom g = word_geom(K, i);
+    return g.kind == 1 ? (1 << (2 * g.nbA)) : (1 << (2 * g.nbB));
+}
+constexpr bool has_pair_word(int K, bool k2) {
+    for (int i = 0; i < n_key_words(K); ++i)
+        if (word_geom(K, i).kind == 2 && word_geom(K, i).is_k2 == k2) return true;
+    return false;
+}
+
+// ASCII bytes of an nb-base group (nb <= 5), first base in byte 0, from its m-form digits
+FH_HD u64 ascii_group_n(u32 q, int nb) {
+    u64 w = 0;
+    for (int i = 0; i < nb; ++i) {
+        const u32 code = (q >> (2 * (nb - 1 - i))) & 3u;
+        const u64 ch = code == 0 ? 0x41u : code == 1 ? 0x43u : code == 2 ? 0x47u : 0x54u;
+        w |= ch << (8 * i);
+    }
+    return w;
+}
+FH_HD u64 rotl64c(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+
+// table builders (once per workgroup into LDS; on the host for the logic tests)
+FH_HD Rec4 lut_rec_A(u32 q, bool k2) {
+    const u64 u = ascii_group_n(q, 4) * (k2 ? MURMUR_C2 : MURMUR_C1);
+    const u64 U = k2 ? ((u << 33) + (u64)((u32)u >> 31)) * MURMUR_C1 : (u << 31) * MURMUR_C2;
+    return Rec4{(u32)U, (u32)(U >> 32), (u32)(u >> 32), 0u};
+}
+FH_HD Rec2 lut_rec_B(u32 q, int nb, bool k2) {
+    const u32 v = (u32)(ascii_group_n(q, nb) * (k2 ? MURMUR_C2 : MURMUR_C1));
+    return Rec2{v, v << 31};
+}
+FH_HD Rec2 lut_rec_S(u32 q, int nb, bool k2) {
+    const u64 x = ascii_group_n(q, nb) * (k2 ? MURMUR_C2 : MURMUR_C1);
+    const u64 kx = k2 ? rotl64c(x, 33) * MURMUR_C1 : rotl64c(x, 31) * MURMUR_C2;
+    return Rec2{(u32)kx, (u32)(kx >> 32)};
+}
 template <int K>
-struct KeyWords {
-    static constexpr int N = 2 * (K / 16) + 2;
-    u32 lo[N], hi[N];
+FH_HD Rec2 lut_rec_P(u32 q) {
+    constexpr int i = partial_word(K);
+    if (i < 0) return Rec2{0u, 0u};
+    constexpr WordGeom g = word_geom(K, i < 0 ? 0 : i);
+    return g.kind == 1 ? lut_rec_S(q, g.nbA, g.is_k2) : lut_rec_B(q, g.nbB, g.is_k2);
+}
+
+struct LutTables {
+    const Rec4 *A1, *A2; // 256 A records for k1 / k2 words
+    const Rec2 *B1, *B2; // 256 B records for k1 / k2 words (full 4-base high group)
+    const Rec2 *P;       // partial_entries(K) records for the key's last word
 };
 
-// T5 (only if tail_merge5(K)): [0..1023] = lo, [1024..2047] = hi of ascii_group5 * partial_const(K)
+// What the lookups of one position return, kept raw so that the kernel can issue the loads of the next position
+// before it runs the dependent arithmetic of the current one.
 template <int K>
-FH_HD void murmur_lookup(u64 cm, const u32 *TQ, const u32 *TP, const u32 *T5, KeyWords<K> &w) {
-    constexpr int NG_ALL = (K + 3) / 4;
-    constexpr bool M5 = tail_merge5(K);
-    constexpr int NG = M5 ? NG_ALL - 2 : NG_ALL; // groups looked up one by one
+struct KeyWords {
+    static constexpr int N = n_key_words(K);
+    u32 a0[N], a1[N], a2[N], b0[N], b1[N];
+};
+
+// byte offset ((cm >> shift) & (4^nb - 1)) << lg of a record
+FH_HD u32 field_off(u32 cml, u32 cmh, int shift, int nb, int lg) {
+    const int sh = shift - lg;
+    const u32 fm = ((1u << (2 * nb)) - 1u) << lg;
+    if (sh >= 32) return (cmh >> (sh - 32)) & fm;
+    if (sh >= 0 && shift + 2 * nb <= 32) return (cml >> sh) & fm;
+    if (sh >= 0) return alignbit_b32(cmh, cml, (u32)sh) & fm;
+    return (cml << (-sh)) & fm;
+}
+
+template <int K>
+FH_HD void murmur_lookup(u64 cm, const LutTables &T, KeyWords<K> &w) {
     const u32 cml = (u32)cm, cmh = (u32)(cm >> 32);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int i = 0; i < KeyWords<K>::N; ++i) w.lo[i] = w.hi[i] = 0;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (int g = 0; g < NG; ++g) {
-        const GroupGeom gg = group_geom(K, g);
-        // byte offset (index * 4) of the group in a 32-bit table
-        const int sh = gg.shift - 2; // want ((cm >> shift) & m) << 2
-        const u32 fm = ((1u << (2 * gg.nb)) - 1u) << 2;
-        u32 idx4;
-        if (sh >= 32) idx4 = (cmh >> (sh - 32)) & fm;
-        else if (sh >= 0 && sh + 2 * gg.nb + 2 <= 32) idx4 = (cml >> sh) & fm;
-        else if (sh >= 0) idx4 = alignbit_b32(cmh, cml, (u32)sh) & fm;
-        else idx4 = (cml << (-sh)) & fm;
-        const u32 *T = (gg.nb == 4) ? (TQ + (gg.is_k2 ? 512 : 0)) : TP;
-        const u32 hi_off = (gg.nb == 4) ? 256u : 64u;
-        const u32 plo = *(const u32 *)((const char *)T + idx4);
-        if (gg.hi) {
-            w.hi[gg.word] += plo;
-        } else {
-            const u32 phi = *(const u32 *)((const char *)(T + hi_off) + idx4);
-            w.lo[gg.word] += plo; // at most one lo-half group per word: no carry
-            w.hi[gg.word] += phi;
+    for (int i = 0; i < KeyWords<K>::N; ++i) {
+        const WordGeom g = word_geom(K, i);
+        w.a0[i] = w.a1[i] = w.a2[i] = w.b0[i] = w.b1[i] = 0;
+        if (g.kind == 1) {
+            const Rec2 r = *(const Rec2 *)((const char *)T.P + field_off(cml, cmh, g.shiftA, g.nbA, 3));
+            w.a0[i] = r.x;
+            w.a1[i] = r.y;
+        } else if (g.kind == 2) {
+            const Rec4 ra = *(const Rec4 *)((const char *)(g.is_k2 ? T.A2 : T.A1) + field_off(cml, cmh, g.shiftA, 4, 4));
+            const Rec2 *TB = g.partial ? T.P : (g.is_k2 ? T.B2 : T.B1);
+            const Rec2 rb = *(const Rec2 *)((const char *)TB + field_off(cml, cmh, g.shiftB, g.nbB, 3));
+            w.a0[i] = ra.x;
+            w.a1[i] = ra.y;
+            w.a2[i] = ra.z;
+            w.b0[i] = rb.x;
+            w.b1[i] = rb.y;
         }
     }
-    if (M5) {
-        const GroupGeom gq = group_geom(K, NG_ALL - 2); // the lo-half quad; the merged group ends at bit 0
-        const u32 idx4 = (cml & 0x3FFu) << 2;
-        w.lo[gq.word] += *(const u32 *)((const char *)T5 + idx4);
-        w.hi[gq.word] += *(const u32 *)((const char *)(T5 + 1024) + idx4);
+}
+
+// a * b + c (32 x 32 + 64 -> 64): one v_mad_u64_u32, pinned so that the addend stays the register pair the table
+// record was loaded into
+FH_HD u64 mad64(u32 a, u32 b, u64 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 r, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "s"(b), "v"(c));
+    return r;
+#else
+    return (u64)a * b + c;
+#endif
+}
+
+// kx = rotl(x * c, R) * C of key word i from its records (see the derivation above)
+template <int K>
+FH_HD u64 key_word_mix(const KeyWords<K> &w, int i) {
+    const WordGeom g = word_geom(K, i);
+    const u64 acc = ((u64)w.a1[i] << 32) | w.a0[i];
+    if (g.kind == 1) return acc;
+    const u32 ww = w.a2[i] + w.b0[i];
+    if (g.is_k2) {
+        constexpr u64 M = MURMUR_C1 << 1;
+        return mad64(ww, (u32)M, acc) + ((u64)(ww * (u32)(M >> 32)) << 32);
     }
+    const u32 y = ww >> 1;
+    return mad64(y, (u32)MURMUR_C2, acc) + ((u64)(y * (u32)(MURMUR_C2 >> 32) + w.b1[i]) << 32);
 }
 
 // SEED0: compile-time knowledge that seed == 0 (the default; drops three 64-bit ops).
@@ -441,13 +548,13 @@ FH_HD HashParts murmur_finish_parts(const KeyWords<K> &w, u64 seed) {
 #pragma unroll
 #endif
     for (int b = 0; b < NB; ++b) {
-        u64 k1 = mul64c(rotl64h<31>(U64H{w.lo[2 * b], w.hi[2 * b]}), MURMUR_C2);
+        u64 k1 = key_word_mix<K>(w, 2 * b);
         if (SEED0 && b == 0) h1 = k1;
         else h1 ^= k1;
         h1 = join64(rotl64h<27>(make64(h1)));
         if (!(SEED0 && b == 0)) h1 = add64(h1, h2);
         h1 = mul5_add(h1, 0x52dce729ULL);
-        u64 k2 = mul64c(rotl64h<33>(U64H{w.lo[2 * b + 1], w.hi[2 * b + 1]}), MURMUR_C1);
+        u64 k2 = key_word_mix<K>(w, 2 * b + 1);
         if (SEED0 && b == 0) h2 = k2;
         else h2 ^= k2;
         h2 = join64(rotl64h<31>(make64(h2)));
@@ -455,12 +562,12 @@ FH_HD HashParts murmur_finish_parts(const KeyWords<K> &w, u64 seed) {
         h2 = mul5_add(h2, 0x38495ab5ULL);
     }
     if (TAIL > 8) {
-        u64 k2 = mul64c(rotl64h<33>(U64H{w.lo[2 * NB + 1], w.hi[2 * NB + 1]}), MURMUR_C1);
+        u64 k2 = key_word_mix<K>(w, 2 * NB + 1);
         if (SEED0 && NB == 0) h2 = k2;
         else h2 ^= k2;
     }
     if (TAIL > 0) {
-        u64 k1 = mul64c(rotl64h<31>(U64H{w.lo[2 * NB], w.hi[2 * NB]}), MURMUR_C2);
+        u64 k1 = key_word_mix<K>(w, 2 * NB);
         if (SEED0 && NB == 0) h1 = k1;
         else h1 ^= k1;
     }
@@ -476,11 +583,11 @@ FH_HD u64 murmur_finish(const KeyWords<K> &w, u64 seed) {
     return parts_hash(murmur_finish_parts<K, SEED0>(w, seed));
 }
 
-// murmurhash3_x64_128(ascii(canonical k-mer), seed).0 from the m-form canonical word, 32-bit split tables.
+// murmurhash3_x64_128(ascii(canonical k-mer), seed).0 from the m-form canonical word
 template <int K, bool SEED0>
-FH_HD u64 murmur_h1_fast(u64 cm, u64 seed, const u32 *TQ, const u32 *TP, const u32 *T5) {
+FH_HD u64 murmur_h1_fast(u64 cm, u64 seed, const LutTables &T) {
     KeyWords<K> w;
-    murmur_lookup<K>(cm, TQ, TP, T5, w);
+    murmur_lookup<K>(cm, T, w);
     return murmur_finish<K, SEED0>(w, seed);
 }
 

@@ -156,34 +156,30 @@ __device__ __forceinline__ void classify_tile(const SketchArgs &a, u64 tile, int
 #endif
 template <int K, bool MASKED, bool SEED0, bool HASLO>
 __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs a) {
-    __shared__ __attribute__((aligned(16))) u32 sTQ[1024];  // lo/hi(ascii4*c1), lo/hi(ascii4*c2)
-    __shared__ __attribute__((aligned(16))) u32 sTP[128];   // lo/hi(partial group * its constant)
-    __shared__ __attribute__((aligned(16))) u32 sT5[tail_merge5(K) ? 2048 : 4]; // lo/hi(5-base tail group * its constant)
+    // murmur3 lookup tables with the second stage folded in (fh_core.h): A / B records of two-group key words,
+    // P = the key's last (short) word; sized by what this K uses
+    __shared__ Rec4 sA1[has_pair_word(K, false) ? 256 : 1];
+    __shared__ Rec4 sA2[has_pair_word(K, true) ? 256 : 1];
+    __shared__ Rec2 sB1[has_pair_word(K, false) ? 256 : 1];
+    __shared__ Rec2 sB2[has_pair_word(K, true) ? 256 : 1];
+    __shared__ Rec2 sP[partial_entries(K)];
     __shared__ __attribute__((aligned(16))) u32 sCodes[WAVES_PER_BLOCK][256];
     __shared__ __attribute__((aligned(16))) u32 sGood[WAVES_PER_BLOCK][128];
     __shared__ __attribute__((aligned(16))) AdmitQueue sQueue[WAVES_PER_BLOCK];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     {
-        const u64 e1 = lut_entry((u32)tid, 4, MURMUR_C1), e2 = lut_entry((u32)tid, 4, MURMUR_C2);
-        sTQ[tid] = (u32)e1;
-        sTQ[256 + tid] = (u32)(e1 >> 32);
-        sTQ[512 + tid] = (u32)e2;
-        sTQ[768 + tid] = (u32)(e2 >> 32);
-        constexpr int PNB = partial_nb(K);
-        if (tid < 64) {
-            const u64 ep = (PNB != 0 && tid < (1 << (2 * PNB))) ? lut_entry((u32)tid, PNB, partial_const(K)) : 0ull;
-            sTP[tid] = (u32)ep;
-            sTP[64 + tid] = (u32)(ep >> 32);
+        if (has_pair_word(K, false)) {
+            sA1[tid] = lut_rec_A((u32)tid, false);
+            sB1[tid] = lut_rec_B((u32)tid, 4, false);
         }
-        if (tail_merge5(K)) {
-            for (int q = tid; q < 1024; q += 256) {
-                const u64 e5 = lut_entry5((u32)q, partial_const(K));
-                sT5[q] = (u32)e5;
-                sT5[1024 + q] = (u32)(e5 >> 32);
-            }
+        if (has_pair_word(K, true)) {
+            sA2[tid] = lut_rec_A((u32)tid, true);
+            sB2[tid] = lut_rec_B((u32)tid, 4, true);
         }
+        for (int q = tid; q < partial_entries(K); q += 256) sP[q] = lut_rec_P<K>((u32)q);
     }
+    const LutTables LT{sA1, sA2, sB1, sB2, sP};
     __syncthreads();
 
     const u64 tau = __hip_atomic_load(&a.ctl->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -270,7 +266,7 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
         bool rc_cur;
         KeyWords<K> kw_cur;
         window(0, cm_cur, rc_cur);
-        murmur_lookup<K>(cm_cur, sTQ, sTP, sT5, kw_cur);
+        murmur_lookup<K>(cm_cur, LT, kw_cur);
 #pragma unroll(UNROLL_J)
         for (int j = 0; j < LANE_POS; ++j) {
             u64 cm_nxt = 0;
@@ -278,7 +274,7 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
             KeyWords<K> kw_nxt;
             if (j + 1 < LANE_POS) {
                 window(j + 1, cm_nxt, rc_nxt);
-                murmur_lookup<K>(cm_nxt, sTQ, sTP, sT5, kw_nxt);
+                murmur_lookup<K>(cm_nxt, LT, kw_nxt);
             }
             const u64 cm = cm_cur;
             const bool is_rc = rc_cur;

@@ -17,26 +17,24 @@ static int run(const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hashes
     std::vector<uint8_t> buf(((len + 31) / 32) * 32 + 64, 0);
     memcpy(buf.data(), seq, len);
     std::vector<u64> T1(256), T2(256), TP(64, 0);
-    std::vector<u32> TQ(1024), TP32(128, 0);
     for (u32 q = 0; q < 256; ++q) {
         T1[q] = lut_entry(q, 4, MURMUR_C1);
         T2[q] = lut_entry(q, 4, MURMUR_C2);
-        TQ[q] = (u32)T1[q]; TQ[256 + q] = (u32)(T1[q] >> 32);
-        TQ[512 + q] = (u32)T2[q]; TQ[768 + q] = (u32)(T2[q] >> 32);
     }
     const int pnb = partial_nb(K);
     for (u32 q = 0; q < (1u << (2 * pnb)); ++q)
-        if (pnb) {
-            TP[q] = lut_entry(q, pnb, partial_const(K));
-            TP32[q] = (u32)TP[q]; TP32[64 + q] = (u32)(TP[q] >> 32);
-        }
-    std::vector<u32> T5(2048, 0);
-    if (tail_merge5(K))
-        for (u32 q = 0; q < 1024; ++q) {
-            const u64 e = lut_entry5(q, partial_const(K));
-            T5[q] = (u32)e;
-            T5[1024 + q] = (u32)(e >> 32);
-        }
+        if (pnb) TP[q] = lut_entry(q, pnb, partial_const(K));
+    // the kernel's tables (second stage folded in), built exactly as the workgroup prologue builds them
+    std::vector<Rec4> A1(256), A2(256);
+    std::vector<Rec2> B1(256), B2(256), P(partial_entries(K));
+    for (u32 q = 0; q < 256; ++q) {
+        A1[q] = lut_rec_A(q, false);
+        A2[q] = lut_rec_A(q, true);
+        B1[q] = lut_rec_B(q, 4, false);
+        B2[q] = lut_rec_B(q, 4, true);
+    }
+    for (u32 q = 0; q < (u32)partial_entries(K); ++q) P[q] = lut_rec_P<K>(q);
+    const LutTables LT{A1.data(), A2.data(), B1.data(), B2.data(), P.data()};
     for (uint64_t s = 0; s < len; s += 32) {
         u32 cw[4], gw[4];
         for (int c = 0; c < 4; ++c) {
@@ -61,9 +59,9 @@ static int run(const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hashes
             isrc[p] = rc ? 1 : 0;
             canon[p] = cm;
             const u64 h_ref = murmur_h1_lut<K>(cm, seed, T1.data(), T2.data(), TP.data());
-            const u64 h_fast = murmur_h1_fast<K, false>(cm, seed, TQ.data(), TP32.data(), T5.data());
+            const u64 h_fast = murmur_h1_fast<K, false>(cm, seed, LT);
             if (h_fast != h_ref) return -2;
-            if (seed == 0 && murmur_h1_fast<K, true>(cm, 0, TQ.data(), TP32.data(), T5.data()) != h_ref) return -3;
+            if (seed == 0 && murmur_h1_fast<K, true>(cm, 0, LT) != h_ref) return -3;
             hashes[p] = h_fast;
         }
     }
