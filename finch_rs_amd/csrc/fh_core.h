@@ -212,38 +212,71 @@ FH_HD u64 murmur_h1_lut(u64 cm, u64 seed, const u64 *T1, const u64 *T2, const u6
     return h1 + h2;
 }
 
-// ---- rolling window state of one lane ----
-// Fm  : m-form of the forward window (bottom aligned, masked)
-// Rcm : m-form of the reverse complement of the window == l-form of the complemented codes, which rolls
-//       by (x >> 2) | (cbar << 2(K-1)) with no mask (the oldest digit falls off the bottom)
-template <int K>
-struct Roll {
-    u64 Fm;
-    u64 Rcm;
+// funnel shift right: low 32 bits of {hi:lo} >> sh
+FH_HD u32 alignbit_b32(u32 hi, u32 lo, u32 sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (u32)(((((u64)hi) << 32) | lo) >> (sh & 31));
+#endif
+}
 
-    // state after the first K-1 bases of the lane segment; s64 = l-form code stream of bases 0..31
-    FH_HDM void init(u64 s64) {
-        if (K == 1) {
-            Fm = 0;
-            Rcm = 0;
-            return;
+// bit field extract (x >> off) & (2^width - 1), width < 32: one v_bfe_u32 (left to itself the compiler widens the
+// shift to 64 bits)
+FH_HD u32 bfe_u32(u32 x, u32 off, u32 width) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(x, off, width);
+#else
+    return (x >> off) & ((1u << width) - 1u);
+#endif
+}
+
+// ---- the K-base windows of one lane ----
+// A lane owns 32 start positions and sees 64 bases (its own 32 + the neighbour's) as 2-bit codes in l-form
+// (base b at bits [2b, 2b+2) of clo | chi << 64).  Both strands' m-form words of every window are bit fields of
+// two 128-bit strings built once per tile, so a window costs two funnel shifts per strand and no window depends
+// on the previous one:
+//   nC = ~codes            : window j's reverse complement in m-form is bits [2j, 2j + 2K) of nC
+//                            (complement = 3 - c; reversing the order turns l-form into m-form)
+//   D  = digit-reversed    : base b at digit 63 - b; window j's forward m-form is bits [2(64-K-j), +2K) of D
+// canonical(): (fwd < rc) ? fwd : rc -- ties (even-k palindromes) report rc, as needletail's canonical_kmers.
+template <int K>
+struct Windows {
+    u32 nC[5], D[5];
+
+    FH_HDM void init(u64 clo, u64 chi) {
+        nC[0] = ~(u32)clo;
+        nC[1] = ~(u32)(clo >> 32);
+        nC[2] = ~(u32)chi;
+        nC[3] = ~(u32)(chi >> 32);
+        nC[4] = 0;
+        const u64 rl = pairrev64(chi), rh = pairrev64(clo);
+        D[0] = (u32)rl;
+        D[1] = (u32)(rl >> 32);
+        D[2] = (u32)rh;
+        D[3] = (u32)(rh >> 32);
+        D[4] = 0;
+    }
+    // bits [off, off + 2K) of the 128-bit string W (off, K compile-time after unrolling)
+    static FH_HDM u64 field(const u32 *W, int off) {
+        const int w = off >> 5, s = off & 31, nbits = 2 * K;
+        u32 lo = s ? alignbit_b32(W[w + 1], W[w], (u32)s) : W[w];
+        u32 hi = 0;
+        if (nbits < 32) lo &= (1u << nbits) - 1u;
+        if (nbits > 32) {
+            const int hb = nbits - 32; // 2..32
+            const u32 hm = hb >= 32 ? 0xFFFFFFFFu : ((1u << hb) - 1u);
+            if (s + hb <= 32) hi = (hb >= 32) ? W[w + 1] : bfe_u32(W[w + 1], (u32)s, (u32)hb);
+            else hi = alignbit_b32(W[w + 2], W[w + 1], (u32)s) & hm;
         }
-        const u64 mask = kmask(K);
-        Rcm = ((~s64) << 2) & mask;
-        const u64 low = s64 & ((1ULL << (2 * (K - 1))) - 1ULL); // K-1 <= 31
-        Fm = pairrev64(low) >> (64 - 2 * (K - 1));
+        return ((u64)hi << 32) | lo;
     }
-    // roll in one base (code c)
-    FH_HDM void push(u32 c) {
-        const u64 mask = kmask(K);
-        Fm = ((Fm << 2) | c) & mask;
-        Rcm = (Rcm >> 2) | ((u64)(c ^ 3u) << (2 * (K - 1)));
-    }
-    // canonical m-form and strand (true = reverse complement retained), canonical_kmers semantics:
-    // (fwd < rc) ? fwd : rc   -- ties (even-k palindromes) report rc
-    FH_HDM u64 canonical(bool &is_rc) const {
-        is_rc = !(Fm < Rcm);
-        return is_rc ? Rcm : Fm;
+    FH_HDM u64 fwd(int j) const { return field(D, 2 * (64 - K - j)); }
+    FH_HDM u64 rc(int j) const { return field(nC, 2 * j); }
+    FH_HDM u64 canonical(int j, bool &is_rc) const {
+        const u64 f = fwd(j), r = rc(j);
+        is_rc = !(f < r);
+        return is_rc ? r : f;
     }
 };
 
@@ -299,14 +332,6 @@ struct U64H {
 
 FH_HD U64H make64(u64 x) { return U64H{(u32)x, (u32)(x >> 32)}; }
 FH_HD u64 join64(U64H x) { return ((u64)x.hi << 32) | x.lo; }
-
-FH_HD u32 alignbit_b32(u32 hi, u32 lo, u32 sh) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_alignbit(hi, lo, sh);
-#else
-    return (u32)(((((u64)hi) << 32) | lo) >> (sh & 31));
-#endif
-}
 
 template <int R>
 FH_HD U64H rotl64h(U64H x) {

@@ -151,11 +151,12 @@ __device__ __forceinline__ void classify_tile(const SketchArgs &a, u64 tile, int
 // ------------------------------------------------------------------------------------------------
 // K2
 // ------------------------------------------------------------------------------------------------
-#ifndef FH_MIN_WAVES
-#define FH_MIN_WAVES 1
-#endif
+// Register budget: the unrolled position loop of K <= 21 needs just under 128 VGPRs; telling the compiler to aim for
+// four waves per SIMD keeps it there (left alone it lands on 129-130 and loses a wave).  Larger K need 136-170
+// (three waves) and would spill under the same bound.
+constexpr int k2_min_waves(int K) { return K <= 21 ? 4 : 1; }
 template <int K, bool MASKED, bool SEED0, bool HASLO>
-__global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs a) {
+__global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchArgs a) {
     // murmur3 lookup tables with the second stage folded in (fh_core.h): A / B records of two-group key words,
     // P = the key's last (short) word; sized by what this K uses
     __shared__ Rec4 sA1[has_pair_word(K, false) ? 256 : 1];
@@ -251,17 +252,12 @@ __global__ __launch_bounds__(256, FH_MIN_WAVES) void k2_sketch(const SketchArgs 
         const u32 W = window_valid_mask<K>(g64) & (limit >= 32u ? 0xFFFFFFFFu : ((1u << limit) - 1u));
         nvalid += (u32)__popc(W);
 
-        Roll<K> roll;
-        roll.init(clo);
+        Windows<K> win;
+        win.init(clo, chi);
 
         // software pipeline: the table lookups of position j+1 are issued before the dependent multiply chain of
         // position j runs, so their LDS latency is hidden inside the wave
-        auto window = [&](int j, u64 &cm, bool &is_rc) {
-            const int bi = j + K - 1;
-            const u32 c = (bi < 32) ? ((u32)(clo >> (2 * bi)) & 3u) : ((u32)(chi >> (2 * (bi - 32))) & 3u);
-            roll.push(c);
-            cm = roll.canonical(is_rc);
-        };
+        auto window = [&](int j, u64 &cm, bool &is_rc) { cm = win.canonical(j, is_rc); };
         u64 cm_cur;
         bool rc_cur;
         KeyWords<K> kw_cur;

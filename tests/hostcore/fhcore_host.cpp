@@ -44,17 +44,14 @@ static int run(const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hashes
         }
         const u64 clo = (u64)cw[0] | ((u64)cw[1] << 32), chi = (u64)cw[2] | ((u64)cw[3] << 32);
         const u64 g64 = (u64)gw[0] | ((u64)gw[1] << 16) | ((u64)gw[2] << 32) | ((u64)gw[3] << 48);
-        Roll<K> roll;
-        roll.init(clo);
+        Windows<K> win;
+        win.init(clo, chi);
         const u32 W = window_valid_mask<K>(g64 & 0x7FFFFFFFFFFFFFFFull);
         for (int j = 0; j < 32; ++j) {
-            const int bi = j + K - 1;
-            const u32 c = (u32)(((bi < 32) ? (clo >> (2 * bi)) : (chi >> (2 * (bi - 32)))) & 3u);
-            roll.push(c);
             const uint64_t p = s + j;
             if (p >= len) break;
             bool rc;
-            const u64 cm = roll.canonical(rc);
+            const u64 cm = win.canonical(j, rc);
             valid[p] = (W >> j) & 1u;
             isrc[p] = rc ? 1 : 0;
             canon[p] = cm;
