@@ -340,7 +340,9 @@ FH_HD U64H rotl64h(U64H x) {
     return U64H{alignbit_b32(x.hi, x.lo, 64 - R), alignbit_b32(x.lo, x.hi, 64 - R)};
 }
 
-// 64-bit add / (x*5 + c) on the device as single v_lshl_add_u64 instructions
+// 64-bit add and h * 5 + c as v_lshl_add_u64.  The compiler selects the instruction for plain adds by itself, but the
+// pinned form schedules measurably better in the unrolled position loop (A/B on MI355X: +1.4 %); h * 5 + c would be
+// turned into two v_mad_u64_u32 and a move.
 FH_HD u64 add64(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     u64 r;
@@ -353,10 +355,9 @@ FH_HD u64 add64(u64 a, u64 b) {
 
 FH_HD u64 mul5_add(u64 h, u64 c) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    u64 t, r;
+    u64 t;
     asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(t) : "v"(h));
-    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(t), "s"(c));
-    return r;
+    return t + c;
 #else
     return h * 5 + c;
 #endif
