@@ -66,34 +66,34 @@ FH_HD u32 perm_b32(u32 s0, u32 s1, u32 sel) {
 #endif
 }
 
-// 4 ASCII bytes -> q8: 2-bit codes, base i at bits [2i+1:2i];  good4: bit i set iff byte i is in ACGTUacgtu
-FH_HD void classify4(u32 d, u32 &q8, u32 &good4) {
-    // (c >> 1) & 3 : A->0 C->1 G->3 T/U->2 ; x ^ (x >> 1) : 0 1 2 3
-    u32 x = (d >> 1) & 0x03030303u;
-    u32 code = x ^ ((x >> 1) & 0x01010101u);
-    // the letter this code stands for, as an 8-entry byte LUT in a register
-    u32 expect = perm_b32(0u, 0x54474341u /* 'T','G','C','A' */, code);
-    u32 upper = d & 0xDFDFDFDFu; // fold case
-    u32 tmask = (code & (code >> 1)) & 0x01010101u; // 1 where code == 3: accept U (0x55) for T (0x54)
-    u32 diff = (upper ^ expect) & ~tmask;
-    // per byte: bit 7 set iff diff byte != 0
-    u32 nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u;
-    u32 ok = nz ^ 0x80808080u; // bit 7 of byte i set iff good
-    // gather the four 2-bit codes / four flag bits with one multiply each: the partial products land on
-    // disjoint bits, the wanted ones adjacent at the top of the word
-    q8 = (code * 0x01041040u) >> 24;    // c0@24 c1@26 c2@28 c3@30
-    good4 = (ok * 0x00204081u) >> 28;   // b0@28 b1@29 b2@30 b3@31
+// Classification of 4 ASCII bytes (needletail normalize(false) + canonical_kmers: ACGT, acgt and U/u are bases,
+// every other byte breaks k-mers).  The low three bits of the five accepted upper-case letters are distinct
+// (A 001, C 011, T 100, U 101, G 111), so they index two 8-entry byte tables held in registers (v_perm_b32): the
+// letter the byte has to be, and its 2-bit code (A 0, C 1, G 2, T/U 3).
+//   qtop : the four codes gathered into the TOP byte (base i at bits [24+2i, 26+2i)); lower bytes are scrap
+//   btop : bit 28+i set iff byte i is NOT a base; lower bits are scrap
+FH_HD void classify4(u32 d, u32 &qtop, u32 &btop) {
+    const u32 sel = d & 0x07070707u;
+    const u32 expect = perm_b32(0x47FF5554u, 0x43FF41FFu, sel); // idx 0..7: -, A, -, C, T, U, -, G  (0xFF = none)
+    const u32 code = perm_b32(0x02000303u, 0x01000000u, sel);   // idx 0..7: 0, 0, 0, 1, 3, 3, 0, 2
+    const u32 diff = (d & 0xDFDFDFDFu) ^ expect;                // case folded; a byte is 0 iff it is a base
+    const u32 nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u; // bit 7 of byte i: byte != 0
+    // gather with one multiply each: the partial products land on disjoint bits, the wanted ones adjacent on top
+    qtop = code * 0x01041040u; // c0@24 c1@26 c2@28 c3@30
+    btop = nz * 0x00204081u;   // b0@28 b1@29 b2@30 b3@31
 }
 
 // 16 bytes (4 dwords, little endian) -> 16 codes (32 bits, l-form) + 16 good bits
 FH_HD void classify_chunk(u32 d0, u32 d1, u32 d2, u32 d3, u32 &codes, u32 &good) {
-    u32 q0, q1, q2, q3, g0, g1, g2, g3;
-    classify4(d0, q0, g0);
-    classify4(d1, q1, g1);
-    classify4(d2, q2, g2);
-    classify4(d3, q3, g3);
-    codes = q0 | (q1 << 8) | (q2 << 16) | (q3 << 24);
-    good = g0 | (g1 << 4) | (g2 << 8) | (g3 << 12);
+    u32 q0, q1, q2, q3, b0, b1, b2, b3;
+    classify4(d0, q0, b0);
+    classify4(d1, q1, b1);
+    classify4(d2, q2, b2);
+    classify4(d3, q3, b3);
+    // pack the four top bytes: selector 3 / 7 = top byte of the second / first operand, 0x0c = zero
+    codes = perm_b32(q1, q0, 0x0c0c0703u) | perm_b32(q3, q2, 0x07030c0cu);
+    const u32 bad = (b0 >> 28) | ((b1 >> 28) << 4) | ((b2 >> 28) << 8) | ((b3 >> 28) << 12);
+    good = bad ^ 0xFFFFu;
 }
 
 FH_HD u64 kmask(int K) { return K >= 32 ? ~0ULL : ((1ULL << (2 * K)) - 1ULL); }
@@ -438,17 +438,23 @@ FH_HD Rec2 lut_rec_B(u32 q, int nb, bool k2) {
     const u32 v = (u32)(ascii_group_n(q, nb) * (k2 ? MURMUR_C2 : MURMUR_C1));
     return Rec2{v, v << 31};
 }
-FH_HD Rec2 lut_rec_S(u32 q, int nb, bool k2) {
+// xr: a constant folded in by xor (the key length, which murmur3 xors into h1 / h2 right after the tail words)
+FH_HD Rec2 lut_rec_S(u32 q, int nb, bool k2, u64 xr) {
     const u64 x = ascii_group_n(q, nb) * (k2 ? MURMUR_C2 : MURMUR_C1);
-    const u64 kx = k2 ? rotl64c(x, 33) * MURMUR_C1 : rotl64c(x, 31) * MURMUR_C2;
+    const u64 kx = (k2 ? rotl64c(x, 33) * MURMUR_C1 : rotl64c(x, 31) * MURMUR_C2) ^ xr;
     return Rec2{(u32)kx, (u32)(kx >> 32)};
+}
+// the single-group word of a key is a tail word (K % 16 != 0 there), so `h ^= K` can ride in its table
+constexpr bool len_folded(int K, bool k2) {
+    const int i = 2 * (K / 16) + (k2 ? 1 : 0);
+    return word_geom(K, i).kind == 1;
 }
 template <int K>
 FH_HD Rec2 lut_rec_P(u32 q) {
     constexpr int i = partial_word(K);
     if (i < 0) return Rec2{0u, 0u};
     constexpr WordGeom g = word_geom(K, i < 0 ? 0 : i);
-    return g.kind == 1 ? lut_rec_S(q, g.nbA, g.is_k2) : lut_rec_B(q, g.nbB, g.is_k2);
+    return g.kind == 1 ? lut_rec_S(q, g.nbA, g.is_k2, (u64)K) : lut_rec_B(q, g.nbB, g.is_k2);
 }
 
 struct LutTables {
@@ -597,8 +603,8 @@ FH_HD HashParts murmur_finish_parts(const KeyWords<K> &w, u64 seed) {
         if (SEED0 && NB == 0) h1 = k1;
         else h1 ^= k1;
     }
-    h1 ^= (u64)K;
-    h2 ^= (u64)K;
+    if (!len_folded(K, false)) h1 ^= (u64)K;
+    if (!len_folded(K, true)) h2 ^= (u64)K;
     h1 = add64(h1, h2);
     h2 = add64(h2, h1);
     return HashParts{fmix64_head(h1), fmix64_head(h2)};

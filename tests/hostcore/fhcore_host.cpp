@@ -105,3 +105,12 @@ extern "C" uint64_t fhcore_prefilter_check(const uint64_t *a, const uint64_t *b,
     *n_true = tr;
     return bad;
 }
+
+// classification of n 16-byte chunks: codes (32 bits, base i at bits [2i, 2i+2)) and good bits per chunk
+extern "C" void fhcore_classify(const uint8_t *bytes, uint64_t n_chunks, uint32_t *codes, uint32_t *good) {
+    for (uint64_t c = 0; c < n_chunks; ++c) {
+        u32 d[4];
+        memcpy(d, bytes + 16 * c, 16);
+        classify_chunk(d[0], d[1], d[2], d[3], codes[c], good[c]);
+    }
+}

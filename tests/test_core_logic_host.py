@@ -118,3 +118,32 @@ def test_high_word_prefilter_never_drops_a_candidate(core):
     lim = (tau >> np.uint64(32)) + np.uint64(1)
     loose = np.count_nonzero(((h >> np.uint64(32)) <= lim) | ((h >> np.uint64(32)) == np.uint64(0xFFFFFFFF)))
     assert n_true.value <= n_pass.value <= loose
+
+
+def test_classification_every_byte_value_every_slot(core):
+    """all 256 byte values in each of the 16 slots of a chunk, neighbours random: good bit iff the byte is one of
+    ACGTacgtUu (needletail normalize + canonical_kmers: everything else breaks k-mers), code A0 C1 G2 T/U3"""
+    core.fhcore_classify.restype = None
+    core.fhcore_classify.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(3)
+    chunks = rng.integers(0, 256, (256 * 16, 16), dtype=np.uint8)
+    for v in range(256):
+        for slot in range(16):
+            chunks[v * 16 + slot, slot] = v
+    flat = np.ascontiguousarray(chunks)
+    codes = np.zeros(len(flat), dtype=np.uint32)
+    good = np.zeros(len(flat), dtype=np.uint32)
+    core.fhcore_classify(flat.ctypes.data, len(flat), codes.ctypes.data, good.ctypes.data)
+    code_of = {ord(c): i for c, i in zip("ACGT", range(4))}
+    code_of.update({ord(c): i for c, i in zip("acgt", range(4))})
+    code_of[ord("U")] = code_of[ord("u")] = 3
+    exp_good = np.zeros(len(flat), dtype=np.uint32)
+    for s in range(16):
+        col = flat[:, s]
+        is_base = np.isin(col, list(code_of))
+        exp_good |= is_base.astype(np.uint32) << np.uint32(s)
+        want = np.array([code_of.get(int(b), 0) for b in col], dtype=np.uint32)
+        got = (codes >> np.uint32(2 * s)) & np.uint32(3)
+        assert np.array_equal(got[is_base], want[is_base]), s
+    assert np.array_equal(good, exp_good)
+    assert not np.any(good >> np.uint32(16))
