@@ -180,7 +180,7 @@ def main():
                 "kernel": "k2_sketch<%d>" % args.k, "launches": kernel_launches,
                 "avg_launch_ms": round(kernel_ms / max(kernel_launches, 1), 4),
                 "alg_bytes_per_launch": int(kernel_pos / max(kernel_launches, 1)),
-                "note": "integer-ALU bound by construction (7 64-bit multiplies per k-mer); see DESIGN.md"}
+                "note": "integer-ALU bound by construction (murmur3: four 64-bit multiplies + three mad-based key-word mixes per k-mer, VALU ~92% busy); see DESIGN.md 3.1"}
     prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     # the committed PMC figure was collected on exactly the default workload; do not attach it to another one
     if os.path.exists(prof) and (args.gbases, args.k, args.n, world) == (10.0, 21, 1000, 1):

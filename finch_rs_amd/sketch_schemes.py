@@ -140,15 +140,15 @@ class HipSketcher:
     def to_arrays(self):
         """-> (structured [hash,count,extra_count], kmers uint8 [n,k], first_pos uint64 [n]) ascending by hash"""
         n, _ = self.finish()
-        hs = np.zeros(n, dtype=np.uint64)
-        cs = np.zeros(n, dtype=np.uint32)
-        es = np.zeros(n, dtype=np.uint32)
-        km = np.zeros((n, self.kmer_length), dtype=np.uint8)
-        ps = np.zeros(n, dtype=np.uint64)
+        hs = np.empty(n, dtype=np.uint64)
+        cs = np.empty(n, dtype=np.uint32)
+        es = np.empty(n, dtype=np.uint32)
+        km = np.empty((n, self.kmer_length), dtype=np.uint8)
+        ps = np.empty(n, dtype=np.uint64)
         check(self._L.fh_copy_out(self._h, hs.ctypes.data_as(C.c_void_p), cs.ctypes.data_as(C.c_void_p),
                                   es.ctypes.data_as(C.c_void_p), km.ctypes.data_as(C.c_void_p),
                                   ps.ctypes.data_as(C.c_void_p)))
-        kc = np.zeros(n, dtype=KC_DTYPE)
+        kc = np.empty(n, dtype=KC_DTYPE)
         kc["hash"], kc["count"], kc["extra_count"] = hs, cs, es
         return kc, km, ps
 

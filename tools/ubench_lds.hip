@@ -10,12 +10,13 @@ constexpr int ITER = 1000, REP = 8;
 // MODE 0: b32, 256-entry dword table      1: two b32 reads, split lo/hi tables (read2st64 form)
 //      2: b64, 256 x 8 B                  4: b128 of 256 x 16 B records
 //      5: b64, 1024 x 8 B                 6: b32, 1024-entry dword table      7: b128 of 1024 x 16 B
+//      8: b96 of 256 x 16 B records (three of the four dwords used)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_lut(unsigned *out, unsigned seed) {
     __shared__ __attribute__((aligned(16))) unsigned T[4096];
     for (int i = threadIdx.x; i < 4096; i += 256) T[i] = i * 2654435761u + seed;
     __syncthreads();
-    constexpr unsigned ENT = (MODE >= 5) ? 1024u : 256u;
+    constexpr unsigned ENT = (MODE >= 5 && MODE != 8) ? 1024u : 256u;
     constexpr unsigned RB = (MODE == 0 || MODE == 1 || MODE == 6) ? 4u : (MODE == 2 || MODE == 5) ? 8u : 16u; // record bytes
     unsigned lane_h = (threadIdx.x + blockIdx.x * 256u) * 2654435761u + seed;
     unsigned idx[4], inc[4];
@@ -39,6 +40,9 @@ __global__ __launch_bounds__(256) void k_lut(unsigned *out, unsigned seed) {
                 } else if (MODE == 2 || MODE == 5) {
                     const uint2 v = *(const uint2 *)(base + off);
                     acc ^= v.x ^ v.y;
+                } else if (MODE == 8) {
+                    const uint4 v = *(const uint4 *)(base + off);
+                    acc ^= v.x ^ v.y ^ v.z;
                 } else {
                     const uint4 v = *(const uint4 *)(base + off);
                     acc ^= v.x ^ v.y ^ v.z ^ v.w;
@@ -85,6 +89,7 @@ int main(int argc, char **argv) {
         run("2xb32 256-entry split lo/hi", k_lut<1>, d_out, blocks, cus, clk);
         run("b64   256 x 8 B", k_lut<2>, d_out, blocks, cus, clk);
         run("b128  256 x 16 B", k_lut<4>, d_out, blocks, cus, clk);
+        run("b96   256 x 16 B", k_lut<8>, d_out, blocks, cus, clk);
         run("b32   1024-entry", k_lut<6>, d_out, blocks, cus, clk);
         run("b64   1024 x 8 B", k_lut<5>, d_out, blocks, cus, clk);
         run("b128  1024 x 16 B", k_lut<7>, d_out, blocks, cus, clk);
