@@ -238,7 +238,9 @@ uint64_t next_range_size(const fh_sketcher *s, uint64_t remaining) {
         P = remaining;
     } else {
         const double room = (double)s->live_target - (double)std::min<uint64_t>(s->last_live, s->live_target);
-        double p = 0.5 * room / admit_rate(s->last_tau);
+        // small mode keeps half the room in reserve (the live set has to fit the in-LDS prune); in big mode the
+        // soft-limit stop makes overshoot harmless, and halving the room every range cost 5-11 launches per prune
+        double p = (s->big_mode ? 1.0 : 0.5) * room / admit_rate(s->last_tau);
         P = p >= 1e18 ? remaining : (uint64_t)p;
     }
     if (s->max_range) P = std::min<uint64_t>(P, s->max_range);
@@ -247,7 +249,7 @@ uint64_t next_range_size(const fh_sketcher *s, uint64_t remaining) {
 }
 
 int check_ctl(fh_sketcher *s);
-int big_prune(fh_sketcher *s);
+int big_prune(fh_sketcher *s, bool sorted = true);
 int grow_table(fh_sketcher *s, uint64_t new_live_cap);
 
 int collect_profile(fh_sketcher *s) {
@@ -275,13 +277,22 @@ int launch_pending(fh_sketcher *s) {
     a.ctl = s->ctl;
     a.tiles_total = r.tiles_total;
     a.n_units = r.n_units;
-    a.wave_budget = (uint32_t)WAVE_BUDGET;
     a.n_left_in = r.n_left_in;
     a.left_in = s->left_buf[r.left_cur];
     a.left_out = s->left_buf[r.left_cur ^ 1];
     const uint64_t work_units = (uint64_t)r.n_units + r.n_left_in;
     const uint64_t waves = std::max<uint64_t>(1, std::min<uint64_t>(work_units, s->max_waves));
     a.n_waves = (uint32_t)waves;
+    // per-wave insert budget: the table and the shard lists are sized for max_waves waves inserting
+    // WAVE_BUDGET + TILE_POS new hashes each, so a launch with fewer waves may let each of them insert
+    // proportionally more (warm-up ranges at a loose threshold would otherwise stop after one tile per wave
+    // and be relaunched for the rest)
+    {
+        const uint64_t per_wave = (uint64_t)WAVE_BUDGET + TILE_POS;
+        const uint64_t wps_max = (s->max_waves + N_SHARDS - 1) / N_SHARDS, wps = (waves + N_SHARDS - 1) / N_SHARDS;
+        const uint64_t b_table = s->max_waves * per_wave / waves, b_shard = wps_max * per_wave / wps;
+        a.wave_budget = (uint32_t)std::min<uint64_t>(std::min(b_table, b_shard) - TILE_POS, 1u << 30);
+    }
     const int blocks = (int)((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -319,10 +330,15 @@ int drain(fh_sketcher *s) {
         s->last_tau = c.tau;
         s->last_live = c.n_live;
         const bool remaining = c.next_unit < s->pend.n_units || c.n_left_out > 0;
-        if (c.need_big || (s->big_mode && 4 * (uint64_t)c.n_live >= 3 * s->live_target) ||
+        static const bool trace = getenv("FH_TRACE") != nullptr; // per-launch outcome on stderr (debug aid)
+        if (trace)
+            fprintf(stderr, "[fh] launch %llu: units %u/%u left_in %u left_out %u n_live %u stopped %u tau %.3e soft %u\n",
+                    (unsigned long long)s->n_launches, c.next_unit, s->pend.n_units, s->pend.n_left_in, c.n_left_out,
+                    c.n_live, c.stopped, (double)c.tau, soft_limit_of(s));
+        if (c.need_big || (s->big_mode && 2 * (uint64_t)c.n_live >= s->live_target) ||
             (remaining && c.n_live >= soft_limit_of(s) / 2)) {
             if (s->big_mode || c.need_big || c.n_live > (uint32_t)SMALL_MAX) {
-                if (int rc = big_prune(s)) return rc;
+                if (int rc = big_prune(s, false)) return rc;
             } else {
                 HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size,
                                            s->max_hash, 0u, 1u, 0u, s->stream));
@@ -398,7 +414,7 @@ int speculative_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, 
     s->open_loop = was_open;
     // settle the live set and see whether the guess captured `size` distinct hashes
     if (s->big_mode || s->last_live > (uint32_t)SMALL_MAX) {
-        if (int rc = big_prune(s)) return rc;
+        if (int rc = big_prune(s, false)) return rc;
     } else {
         HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size, s->max_hash, 0u,
                                    1u, 0u, s->stream));
@@ -473,19 +489,27 @@ int ensure_big_buffers(fh_sketcher *s, uint32_t M) {
     HIP_TRY(hipMalloc(&s->slots_b, (size_t)cap * 4));
     HIP_TRY(big_sort_tmp_bytes(cap, &s->sort_tmp_bytes));
     HIP_TRY(hipMalloc(&s->sort_tmp, s->sort_tmp_bytes ? s->sort_tmp_bytes : 16));
-    if (!s->keep_dev) HIP_TRY(hipMalloc(&s->keep_dev, 16));
+    if (!s->keep_dev) HIP_TRY(hipMalloc(&s->keep_dev, 64 + SEL_SCRATCH_BYTES)); // [0,64) keep count, then select scratch
     s->big_cap = cap;
     return FH_OK;
 }
 
 // device-wide bottom-n selection (fh_big.hip); host-driven because it runs a handful of times per stream
-int big_prune(fh_sketcher *s) {
+// sorted = false (between launches): only the new threshold and the partition of the live list are needed, found by
+// a radix select; fh_finish asks for the sorted live list (to_vec order)
+int big_prune(fh_sketcher *s, bool sorted) {
     if (int rc = check_ctl(s)) return rc;
     const uint32_t M = s->h_ctl->n_live;
     if (int rc = ensure_big_buffers(s, M)) return rc;
-    HIP_TRY(launch_big_prune(s->table, s->live, s->dead, s->dead_cap, s->ctl, M, s->h_ctl->n_dead, s->p.kind, s->p.size,
-                             s->max_hash, s->keys_a, s->keys_b, s->slots_a, s->slots_b, s->sort_tmp, s->sort_tmp_bytes,
-                             s->keep_dev, s->stream));
+    static const bool no_select = getenv("FH_NO_SELECT") != nullptr; // A/B and debugging: always sort
+    if (!sorted && !no_select && s->p.size >= 1)
+        HIP_TRY(launch_big_prune_select(s->table, s->live, s->dead, s->dead_cap, s->ctl, M, s->h_ctl->n_dead, s->p.kind,
+                                        s->p.size, s->max_hash, s->keys_a, s->slots_a, (char *)s->keep_dev + 64,
+                                        s->keep_dev, s->stream));
+    else
+        HIP_TRY(launch_big_prune(s->table, s->live, s->dead, s->dead_cap, s->ctl, M, s->h_ctl->n_dead, s->p.kind,
+                                 s->p.size, s->max_hash, s->keys_a, s->keys_b, s->slots_a, s->slots_b, s->sort_tmp,
+                                 s->sort_tmp_bytes, s->keep_dev, s->stream));
     if (M == 0) {
         // nothing to sort; still clear the flag
         uint32_t zero = 0;

@@ -27,6 +27,11 @@ hipError_t launch_big_prune(Entry *table, uint32_t *live, uint32_t *dead, uint32
                             uint32_t n_dead_now, uint32_t kind, uint64_t size, uint64_t max_hash, uint64_t *keys_a,
                             uint64_t *keys_b, uint32_t *slots_a, uint32_t *slots_b, void *tmp, size_t tmp_bytes,
                             uint32_t *keep_dev, hipStream_t st);
+// in-stream prune without the sort (radix select + partition); scratch >= SEL_SCRATCH_BYTES
+constexpr size_t SEL_SCRATCH_BYTES = 16384;
+hipError_t launch_big_prune_select(Entry *table, uint32_t *live, uint32_t *dead, uint32_t dead_cap, Ctl *ctl, uint32_t M,
+                                   uint32_t n_dead_now, uint32_t kind, uint64_t size, uint64_t max_hash, uint64_t *keys,
+                                   uint32_t *slots, void *scratch, uint32_t *keep_dev, hipStream_t st);
 hipError_t launch_rehash(const Entry *src, const uint32_t *src_live, uint32_t M, Entry *dst, uint32_t dst_cap,
                          uint32_t *dst_live, Ctl *ctl, hipStream_t st);
 // fh_text.hip
