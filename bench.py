@@ -231,8 +231,10 @@ def main():
         "value": round(value, 1), "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "%.1f Gbase synthetic 150 bp reads per GPU (configs[1]), mash k=%d n=%d seed 0, "
-                               "input resident in HBM as packed stream" % (args.gbases, args.k, args.n),
+        "config": {"workload": "%.1f Gbase synthetic 150 bp reads per GPU (%s), mash k=%d n=%d seed 0, "
+                               "input resident in HBM as packed stream"
+                               % (args.gbases, "configs[1]" if (args.gbases, args.k, args.n) == (10.0, 21, 1000)
+                                  else "configs[1] generator, non-default size/sketch", args.k, args.n),
                    "reads_per_gpu": n_reads, "parallelism": "read-block sharding x%d, host merge" % world},
         "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all,
         "sketch_check": {"n_hashes": int(len(gathered[0])), "min_hash": int(gathered[0]["hash"][0]) if len(gathered[0]) else None,
