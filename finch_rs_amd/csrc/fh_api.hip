@@ -387,18 +387,20 @@ int set_tau(fh_sketcher *s, uint64_t tau) {
     return FH_OK;
 }
 
-// First block of a fresh sketcher, if it is small (a file of a few Mb..tens of Mb -- the batch-of-files case, where
-// the half dozen host round trips of the closed-loop warm-up dominate): instead of warming the threshold up
-// through a series of small ranges, guess it from the block length (about 4 x size hashes expected below it if
-// every k-mer were distinct) and sketch the block in one go.  Large blocks keep the closed-loop warm-up: its
-// cost is amortised there, while a wrong guess would cost a whole second pass.  As soon as `size` distinct hashes <= the guess have been seen the usual argument holds (everything not
-// recorded is larger than the size-th smallest so far).  If the block ends with fewer -- low-complexity input --
-// it is read a second time for the hashes above the guess only (HASLO launches), through the normal loop.
+// First block of a fresh sketcher: instead of warming the threshold up through a series of small closed-loop ranges
+// (half a dozen to a dozen host round trips, which dominate a file of a few Mb and still cost ~1 ms of a 10 Gbase
+// pass), guess it from the length (about 4 x size hashes expected below it if every k-mer were distinct) and sketch
+// the block -- or, for a block above 64 M positions, its first 32 M positions -- in one go.  As soon as `size` distinct
+// hashes <= the guess have been seen the usual argument holds (everything not recorded is larger than the size-th
+// smallest so far) and the rest of the input continues from a tight threshold.  If the speculated part ends with
+// fewer -- low-complexity input -- it is read a second time for the hashes above the guess only (HASLO launches),
+// through the normal loop; a wrong guess therefore costs at most one extra pass over 64 M positions.
+constexpr uint64_t SPEC_MAX_POS = 64ull << 20, SPEC_PREFIX_POS = 32ull << 20; // multiples of TILE_POS
 int speculative_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos, uint64_t n_pos,
                             bool *done) {
     *done = false;
     const double want = 4.0 * (double)std::max<uint64_t>(s->p.size, 1);
-    if (s->no_spec || s->max_range || s->p.hash_mask || n_pos < 32768 || n_pos > (64ull << 20) ||
+    if (s->no_spec || s->max_range || s->p.hash_mask || n_pos < 32768 || n_pos > SPEC_MAX_POS ||
         want * 2.0 >= (double)n_pos)
         return FH_OK;
     if (s->p.kind == FH_KIND_SCALED && s->p.size == 0) return FH_OK; // threshold is max_hash from the start
@@ -438,18 +440,28 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
     if (int rc = drain(s)) return rc;
     if (len < s->p.k) return FH_OK;
     const uint64_t n_pos = len - s->p.k + 1; // windows that fit
+    uint64_t pos = 0;
+    uint64_t lo_end = 0; // a failed speculation re-reads [0, lo_end) for the hashes above its guess only
     if (s->positions_done == 0 && s->tau_lo == 0) {
+        // a large first block speculates on its first 32 M positions only: a wrong guess then costs a second pass
+        // over that prefix (0.1 ms), a right one replaces the ten closed-loop warm-up ranges and their round trips
+        const uint64_t spec_pos = n_pos <= SPEC_MAX_POS ? n_pos : SPEC_PREFIX_POS;
         bool done = false;
-        if (int rc = speculative_first_block(s, d_seq, len, base_pos, n_pos, &done)) return rc;
-        if (done) return FH_OK;
+        if (int rc = speculative_first_block(s, d_seq, len, base_pos, spec_pos, &done)) return rc;
+        if (done) {
+            if (spec_pos == n_pos) return FH_OK;
+            pos = spec_pos;
+        } else if (s->tau_lo) {
+            lo_end = spec_pos;
+        }
     }
-    struct LoGuard { // the lower bound only applies to this block
+    struct LoGuard { // the lower bound only applies inside this call
         fh_sketcher *s;
         ~LoGuard() { s->tau_lo = 0; }
     } lo_guard{s};
-    uint64_t pos = 0;
     while (pos < n_pos) {
         if (int rc = drain(s)) return rc;
+        if (s->tau_lo && pos >= lo_end) s->tau_lo = 0; // the re-read of the speculated prefix is complete (drained)
         if (!s->open_loop) {
             // status of everything before this range is known (drained): decide whether the threshold is
             // tight enough to let launches run to completion on their own
@@ -458,8 +470,9 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
                                 (double)std::min<uint64_t>(std::max<uint64_t>(s->p.size, s->last_live), s->live_target);
             if (s->positions_done > 0 && inflight * admit_rate(s->last_tau) <= 0.25 * room) s->open_loop = true;
         }
-        const uint64_t P = next_range_size(s, n_pos - pos);
-        const uint64_t end = std::min<uint64_t>(n_pos, pos + P);
+        const uint64_t limit = s->tau_lo ? lo_end : n_pos;
+        const uint64_t P = next_range_size(s, limit - pos);
+        const uint64_t end = std::min<uint64_t>(limit, pos + P);
         if (int rc = start_range(s, d_seq, len, base_pos, pos, end)) return rc;
         s->positions_done += end - pos;
         pos = end;
