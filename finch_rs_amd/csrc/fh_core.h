@@ -6,19 +6,17 @@
 //                              k-mer-relevant alphabet (mash.rs:73): {A,C,G,T,a,c,g,t,u,U} -> 2-bit codes
 //                              (u/U -> T), every other byte breaks k-mers.  Whitespace never reaches the
 //                              device (stripped while staging, see fh_api).
-//   canonical selection      : needletail canonical_kmers (mash.rs:76): fwd < rc ? (fwd,false) : (rc,true)
-//   murmur_h1_lut<K>         : murmurhash3 0.0.5 murmurhash3_x64_128(kmer, seed).0 (hashing.rs:10-12) on the
-//                              ASCII bytes of the canonical k-mer.
+//   Windows<K>::canonical    : needletail canonical_kmers (mash.rs:76): fwd < rc ? (fwd,false) : (rc,true)
+//   murmur_h1_fast<K>        : murmurhash3 0.0.5 murmurhash3_x64_128(kmer, seed).0 (hashing.rs:10-12) on the
+//                              ASCII bytes of the canonical k-mer -- the kernel's form (lookup tables with both
+//                              key-word stages folded in, see "lookup tables" below)
+//   murmur_h1_lut<K>         : the same hash from plain first-stage tables; kept as an independent form that the
+//                              host logic test cross-checks the kernel's form against (not used on the device)
 //
 // Layouts.  A k-mer is held as a 2-bit word, A=0 C=1 G=2 T=3 (ASCII order == code order):
 //   "m-form" (MSB-first): first base in the most significant used digit -> numeric order == lexicographic
 //   "l-form" (LSB-first): base i at bits [2i+1:2i]
 // For a forward window with l-form F and m-form Fm:  m-form of its reverse complement == ~F & mask.
-//
-// murmur3 via lookup tables: the three "first stage" products k1*c1, k2*c2 (block) and the tail products
-// are linear in the key bytes, so  (ascii bytes of a 4-base group) * c  mod 2^64 is tabulated per group
-// value (256 entries x 8 B per constant) and summed; only the 7 (k=21) / 8 (k=31) data-dependent
-// 64-bit multiplies of the later stages remain.
 #pragma once
 #include <stdint.h>
 
@@ -95,8 +93,6 @@ FH_HD void classify_chunk(u32 d0, u32 d1, u32 d2, u32 d3, u32 &codes, u32 &good)
     const u32 bad = (b0 >> 28) | ((b1 >> 28) << 4) | ((b2 >> 28) << 8) | ((b3 >> 28) << 12);
     good = bad ^ 0xFFFFu;
 }
-
-FH_HD u64 kmask(int K) { return K >= 32 ? ~0ULL : ((1ULL << (2 * K)) - 1ULL); }
 
 // reverse the order of the 32 2-bit digits of a 64-bit word
 FH_HD u64 pairrev64(u64 x) {
@@ -361,13 +357,6 @@ FH_HD u64 mul5_add(u64 h, u64 c) {
 #else
     return h * 5 + c;
 #endif
-}
-
-FH_HD u64 mul64c(U64H a, u64 C) {
-    const u32 cl = (u32)C, ch = (u32)(C >> 32);
-    u64 p = (u64)a.lo * cl;
-    const u32 cross = a.lo * ch + a.hi * cl;
-    return p + ((u64)cross << 32);
 }
 
 // geometry of key word i of a K-byte key (words 2b, 2b+1 = k1, k2 of block b; 2NB, 2NB+1 = the tail's)
