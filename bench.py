@@ -77,7 +77,11 @@ def main():
     ap.add_argument("--cpu-allcores-mbases", type=float, default=100.0,
                     help="Mbases per process for the extra all-cores CPU figure (0 = skip)")
     ap.add_argument("--max-launch", type=int, default=0)
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
+    ap.add_argument("--backend", default="gloo",
+                    help="torch.distributed backend for N>1.  The data path has no collective (read blocks are "
+                         "independent; SURVEY 8e): the only traffic is the control-plane gather of one <= 40 KB partial "
+                         "sketch per rank plus the timing reduction, which gloo carries as CPU tensors.  'nccl' (= RCCL) "
+                         "moves the same gather onto the GPUs.")
     ap.add_argument("--share-gpu", action="store_true",
                     help="debug: map every rank to cuda:0 (with --backend gloo) to exercise the N>1 flow on a 1-GPU box")
     args = ap.parse_args()
