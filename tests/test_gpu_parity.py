@@ -269,6 +269,73 @@ def test_speculative_threshold_and_its_second_pass():
         assert_same(sk2, ora, "spec second pass then more data")
 
 
+def test_speculation_on_the_prefix_of_a_large_first_block():
+    """a first block above 64 M positions speculates on its first 32 M positions only; if that prefix is
+    low-complexity the second pass covers the prefix alone and the rest of the block continues normally"""
+    k, n = 21, 1000
+    rng = np.random.default_rng(23)
+    g = S.synth_genome_host(12_000_000, 9)  # low coverage: most k-mers of the prefix are distinct
+    reads = S.synth_reads_host(g, 0, 300000, 150, 9, 10000, 500)  # 45 MB of diverse reads
+    # (a) diverse from the start: the guess holds, no second pass
+    big = np.concatenate([reads, S.synth_reads_host(g, 300000, 250000, 150, 9, 10000, 500)])
+    assert len(big) > (64 << 20) + 1000
+    buf = F.DeviceBuffer(len(big) + 64)
+    buf.upload(big)
+    sk = F.SketchParams.mash(n, n, True, k, 0).create_sketcher()
+    sk.push_device(buf.ptr, len(big))
+    ora = O.OracleSketcher(O.MASH, n, k, 0)
+    ora.process_packed(big, 0)
+    assert_same(sk, ora, "prefix speculation ok")
+    c = sk.debug_counters()
+    assert c["spec"] == 1 and c["spec_second_pass"] == 0, c
+    buf.free()
+    # (b) 40 MB of a 720-base unit (700 distinct k-mers) in front of the diverse reads: the prefix holds fewer than
+    # n distinct hashes below the guess -> second pass over the prefix only, then the ordinary path for the rest
+    unit = np.frombuffer(bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=720)) + b"\x00", np.uint8)
+    low = np.tile(unit, (40 << 20) // len(unit))
+    mixed = np.concatenate([low, reads])
+    assert len(mixed) > (64 << 20) + 1000 and len(low) > (32 << 20)
+    for kind, size in [("mash", n), ("scaled", n)]:
+        params = F.SketchParams.mash(size, size, True, k, 0) if kind == "mash" else F.SketchParams.scaled(size, k, 1e-6, 0)
+        buf = F.DeviceBuffer(len(mixed) + 64)
+        buf.upload(mixed)
+        sk = params.create_sketcher()
+        sk.push_device(buf.ptr, len(mixed))
+        ora = O.OracleSketcher(O.MASH if kind == "mash" else O.SCALED, size, k, 0, 1e-6)
+        ora.process_packed(mixed, 0)
+        assert_same(sk, ora, "prefix speculation, second pass (%s)" % kind)
+        c = sk.debug_counters()
+        assert c["spec"] == 1 and c["spec_second_pass"] == 1, c
+        buf.free()
+
+
+def test_select_prune_equals_sort_prune():
+    """between launches large live sets are pruned by a radix select; FH_NO_SELECT=1 makes every prune the full
+    sort that fh_finish uses.  Both must give the same sketch (run in a subprocess: the switch is read once)."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, finch_rs_amd as F\n"
+        "from finch_rs_amd import sketch_schemes as S\n"
+        "g = S.synth_genome_host(1500000, 31)\n"
+        "r = S.synth_reads_host(g, 0, 150000, 150, 31, 10000, 500)\n"
+        "out = []\n"
+        "for p in (F.SketchParams.mash(60000, 60000, True, 25, 3), F.SketchParams.scaled(30000, 19, 0.002, 0)):\n"
+        "    sk = p.create_sketcher(); sk.push_block(r); kc, km, pos = sk.to_arrays()\n"
+        "    out.append((kc['hash'].sum(dtype=np.uint64), int(kc['count'].sum()), int(kc['extra_count'].sum()), len(kc),\n"
+        "                int(km.astype(np.uint64).sum()), sk.debug_counters()['big_prunes']))\n"
+        "print(repr(out))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for extra in ({}, {"FH_NO_SELECT": "1"}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(eval(r.stdout.strip().splitlines()[-1], {"np": np}))
+    assert res[0] == res[1], res
+    assert all(x[5] >= 2 for x in res[0]), res[0]  # the in-stream big prune really ran
+
+
 def test_sharded_merge_equals_whole():
     """global sketch == merge of read-block shard sketches"""
     gl, nr, rl, seed = 300000, 120000, 150, 7
