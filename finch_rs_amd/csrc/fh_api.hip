@@ -122,6 +122,8 @@ struct fh_sketcher {
     // device-side FASTQ packing (fh_text.hip): packed output + block scan scratch per staging slot
     uint8_t *d_packed[N_STAGE] = {nullptr, nullptr};
     uint32_t *d_blk_a[N_STAGE] = {nullptr, nullptr}, *d_blk_b[N_STAGE] = {nullptr, nullptr};
+    const uint8_t *dprev_ptr = nullptr; // fh_push_fasta_text: the previous chunk's packed range (device), for the
+    uint64_t dprev_len = 0;             // K-1 bytes a k-mer may span across chunks
     uint32_t *d_text_tot = nullptr; // [0] newlines, [1] packed bytes, [2] error flag
     uint32_t *h_text_tot = nullptr; // pinned
     uint64_t text_bases = 0;
@@ -186,6 +188,7 @@ int init_state(fh_sketcher *s) {
     s->pend.active = false;
     s->tau_lo = 0;
     s->carry_len = 0;
+    s->dprev_len = 0;
     s->live_target = s->big_mode ? std::max<uint64_t>(4 * s->p.size, 1ull << 16) : (uint64_t)SMALL_MAX;
     s->finished = false;
     s->dirty = false;
@@ -1031,6 +1034,55 @@ int fh_push_fastq_text(fh_sketcher *s, uint64_t len) {
     s->carry_len = 0; // every sequence line ends with its breaker: nothing spans chunks
     const int rc = sketch_device_range(s, s->d_packed[b], n_packed, s->stream_off);
     s->stream_off += n_packed;
+    return rc;
+}
+
+// Device-side FASTA: the staged chunk is raw file text (header lines, wrapped sequence lines); which bytes are
+// sequence is decided by launch_fasta_pack.  A record's sequence spans lines and chunks, so like FH_PUSH_CONTINUE
+// pushes the packed stream of this chunk is preceded by the last K-1 packed bytes of the previous one (copied
+// device to device).  start_state: what the chunk begins in the middle of (0 line start, 1 sequence line, 2 header).
+int fh_push_fasta_text(fh_sketcher *s, uint64_t len, uint32_t start_state, uint32_t flags) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    if (start_state > 2u) return fail(FH_ERR_INVALID, "bad start_state");
+    if (len > s->stage_bytes || len >= (1ull << 30)) return fail(FH_ERR_INVALID, "text longer than the staging buffer");
+    if (int rc = set_device(s)) return rc;
+    if (int rc = ensure_stage(s)) return rc;
+    if (!(flags & FH_PUSH_CONTINUE)) s->dprev_len = 0;
+    if (len == 0) return FH_OK;
+    const int b = s->stage_next;
+    const uint64_t nblk = (s->stage_bytes + 4095) / 4096 + 1;
+    if (!s->d_packed[b]) {
+        HIP_TRY(hipMalloc((void **)&s->d_packed[b], s->stage_bytes + 64));
+        HIP_TRY(hipMalloc((void **)&s->d_blk_a[b], nblk * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&s->d_blk_b[b], nblk * sizeof(uint32_t)));
+    }
+    if (!s->d_text_tot) {
+        HIP_TRY(hipMalloc((void **)&s->d_text_tot, 4 * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc((void **)&s->h_text_tot, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    // the packed buffer of this slot may still feed a pending range
+    if (int rc = drain(s)) return rc;
+    const uint64_t K = s->p.k;
+    const uint64_t carry_len = std::min<uint64_t>(K - 1, s->dprev_len);
+    uint8_t *dst = s->d_packed[b];
+    HIP_TRY(hipMemsetAsync(s->d_text_tot, 0, 4 * sizeof(uint32_t), s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_stage[b], s->h_stage[b] + STAGE_HEADROOM, len, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+    s->stage_busy[b] = true;
+    if (carry_len)
+        HIP_TRY(hipMemcpyAsync(dst, s->dprev_ptr + s->dprev_len - carry_len, carry_len, hipMemcpyDeviceToDevice, s->stream));
+    HIP_TRY(launch_fasta_pack(s->d_stage[b], len, start_state, dst + carry_len, s->d_blk_a[b], s->d_blk_b[b], s->d_text_tot,
+                              s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_text_tot, s->d_text_tot, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const uint64_t n_packed = s->h_text_tot[1];
+    s->stage_next = (b + 1) % N_STAGE;
+    s->carry_len = 0; // the host-side carry belongs to the fh_push_block / fh_push_staged paths
+    const int rc = sketch_device_range(s, dst, carry_len + n_packed, s->stream_off - carry_len);
+    s->stream_off += n_packed;
+    s->dprev_ptr = dst;
+    s->dprev_len = carry_len + n_packed;
     return rc;
 }
 

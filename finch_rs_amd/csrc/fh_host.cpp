@@ -789,6 +789,107 @@ static int fastq_text_to_device(ByteSource &src, fh_sketcher *h) {
     return FH_OK;
 }
 
+// Device-side FASTA (fh_push_fasta_text): the host reads raw file bytes into the pinned staging buffer, cuts chunks
+// after a newline and does the bookkeeping that needs no per-base work: the record count and total_bases =
+// sum of the raw lengths of the records' sequence regions (everything between a header line and the next
+// line-start '>', internal newlines included, one trailing line end trimmed -- what parse_fastx counts, mash.rs:72).
+// '>' is rare, so one memchr for it per chunk finds the header lines.
+struct FastaCounter {
+    bool at_line_start = true, in_header = false, have_record = false;
+    uint64_t raw_len = 0, total_bases = 0, n_records = 0;
+    uint8_t prev = 0, last = 0;
+    void close_record() {
+        uint64_t trim = 0;
+        if (raw_len >= 1 && last == '\n') {
+            trim = 1;
+            if (raw_len >= 2 && prev == '\r') trim = 2;
+        } else if (raw_len >= 1 && last == '\r') {
+            trim = 1;
+        }
+        total_bases += raw_len - trim;
+        n_records++;
+    }
+    void seq_bytes(const uint8_t *p, size_t n) { // n bytes of a sequence region
+        if (!n) return;
+        raw_len += n;
+        prev = n >= 2 ? p[n - 2] : last;
+        last = p[n - 1];
+        at_line_start = last == '\n';
+    }
+    // what fh_push_fasta_text has to be told about the point the next chunk starts at
+    uint32_t start_state() const { return in_header ? 2u : (at_line_start ? 0u : 1u); }
+    void feed(const uint8_t *p, size_t n) {
+        size_t i = 0;
+        while (i < n) {
+            if (in_header) {
+                const uint8_t *nl = (const uint8_t *)memchr(p + i, '\n', n - i);
+                if (!nl) return; // the header line continues in the next chunk
+                i = (size_t)(nl - p) + 1;
+                in_header = false;
+                at_line_start = true;
+                continue;
+            }
+            const uint8_t *g = (const uint8_t *)memchr(p + i, '>', n - i);
+            const size_t gi = g ? (size_t)(g - p) : n;
+            const bool line_start = g && (gi == i ? at_line_start : p[gi - 1] == '\n');
+            if (g && !line_start) { // a '>' inside a line is sequence text
+                seq_bytes(p + i, gi + 1 - i);
+                i = gi + 1;
+                continue;
+            }
+            seq_bytes(p + i, gi - i);
+            i = gi;
+            if (g) {
+                if (have_record) close_record();
+                have_record = true;
+                raw_len = 0;
+                prev = last = 0;
+                in_header = true;
+            }
+        }
+    }
+    void finish() {
+        if (have_record) close_record();
+        have_record = false;
+    }
+};
+
+static int fasta_text_to_device(ByteSource &src, fh_sketcher *h, FastxStats &st) {
+    FastaCounter fc;
+    std::vector<uint8_t> left; // tail of the previous chunk after its last newline
+    bool eof = false, first = true;
+    while (!eof || !left.empty()) {
+        uint8_t *buf = nullptr;
+        uint64_t cap = 0;
+        if (int rc = fh_text_buffer(h, &buf, &cap)) return hfail(rc, "%s", fh_last_error());
+        cap = std::min<uint64_t>(cap, (1ull << 30) - 1);
+        size_t fill = std::min<size_t>(left.size(), cap);
+        memcpy(buf, left.data(), fill);
+        left.erase(left.begin(), left.begin() + fill);
+        while (!eof && fill < cap) {
+            const size_t got = src.read(buf + fill, cap - fill);
+            if (got == 0) eof = true;
+            fill += got;
+        }
+        if (fill == 0) break;
+        size_t cut = fill;
+        if (!eof || !left.empty()) {
+            const uint8_t *nl = (const uint8_t *)memrchr(buf, '\n', fill);
+            if (nl) cut = (size_t)(nl - buf) + 1; // else: one line longer than the buffer, cut anywhere
+            left.insert(left.begin(), buf + cut, buf + fill);
+        }
+        const uint32_t state = fc.start_state();
+        fc.feed(buf, cut);
+        if (int rc = fh_push_fasta_text(h, cut, state, first ? 0u : FH_PUSH_CONTINUE)) return hfail(rc, "%s", fh_last_error());
+        first = false;
+    }
+    if (src.failed()) return hfail(FH_ERR_INVALID, "read error");
+    fc.finish();
+    st.total_bases = fc.total_bases;
+    st.n_records = fc.n_records;
+    return FH_OK;
+}
+
 static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &name, const finch_sketch_params &sp,
                          const finch_filter_params &filters, fh_sketcher *h, Sketch &out) {
     std::unique_ptr<ByteSource> src;
@@ -798,8 +899,15 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     if (int rc = fh_reset(h)) return hfail(rc, "%s", fh_last_error());
     FastxStats st;
     const char *dp = getenv("FINCH_DEVICE_PARSE");
-    const bool device_parse = dp && dp[0] == '1' && !is_gz && first == '@';
-    if (device_parse) {
+    // FINCH_DEVICE_PARSE: unset = FASTA text is split on the device (any text is valid FASTA, nothing can fail there),
+    // FASTQ on the host (blank lines between records and other 4-line violations are the host parser's to judge);
+    // 1 = both on the device; 0 = both on the host.  Compressed input is always parsed where it is inflated.
+    const bool dp_on = dp && dp[0] == '1', dp_off = dp && dp[0] == '0';
+    const bool device_parse = !is_gz && ((first == '>' && !dp_off) || (first == '@' && dp_on));
+    if (device_parse && first == '>') {
+        st.format = 1;
+        if (int rc = fasta_text_to_device(*src, h, st)) return rc;
+    } else if (device_parse) {
         st.format = 2;
         if (int rc = fastq_text_to_device(*src, h)) return rc;
     } else {
@@ -812,7 +920,7 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     if (fp.filter_on < 0) fp.filter_on = st.format == 2 ? 1 : 0;
     uint64_t n = 0, total_kmers = 0;
     if (int rc = fh_finish(h, &n, &total_kmers)) return hfail(rc, "%s", fh_last_error());
-    if (device_parse)
+    if (device_parse && st.format == 2)
         if (int rc = fh_text_bases(h, &st.total_bases)) return hfail(rc, "%s", fh_last_error());
     const uint32_t k = sp.kmer_length;
     std::vector<uint64_t> hs(n);

@@ -37,6 +37,8 @@ hipError_t launch_rehash(const Entry *src, const uint32_t *src_live, uint32_t M,
 // fh_text.hip
 hipError_t launch_fastq_pack(const uint8_t *text, uint64_t len, uint8_t *out, uint32_t *blk_a, uint32_t *blk_b,
                              uint32_t *totals, Ctl *ctl, uint32_t *err, hipStream_t st);
+hipError_t launch_fasta_pack(const uint8_t *text, uint64_t len, uint32_t start_state, uint8_t *out, uint32_t *blk_a,
+                             uint32_t *blk_b, uint32_t *totals, hipStream_t st);
 hipError_t launch_fill_table(Entry *table, uint64_t cap, hipStream_t st);
 hipError_t launch_init_ctl(Ctl *ctl, uint64_t tau0, hipStream_t st);
 hipError_t launch_set_table(Ctl *ctl, Entry *table, uint32_t *live, CollRec *clog, uint32_t cap, uint32_t live_cap,

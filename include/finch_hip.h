@@ -93,11 +93,19 @@ int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_
  * plain 4-line FASTQ text cut at a record boundary (it starts with a '@' header line and ends after a quality
  * line) and the library finds the sequence lines on the device (line index mod 4), drops CR, turns each
  * sequence line's newline into the record breaker and sketches the result.  Replaces needletail's record
- * splitting for that format (lib.rs:60-68); anything else (FASTA, gz, blank lines between records) goes through
- * fh_push_block.  fh_text_buffer hands out the buffer to fill next (capacity = stage_bytes); fh_push_fastq_text
+ * splitting for that format (lib.rs:60-68); FASTA has fh_push_fasta_text, anything else (blank lines between FASTQ
+ * records, multi-line FASTQ) goes through fh_push_block.  fh_text_buffer hands out the buffer to fill next (capacity = stage_bytes); fh_push_fastq_text
  * consumes its first `len` bytes.  FH_ERR_INVALID if the text is not 4-line FASTQ. */
 int fh_text_buffer(fh_sketcher *s, uint8_t **buf, uint64_t *cap);
 int fh_push_fastq_text(fh_sketcher *s, uint64_t len);
+/* Device-side FASTA parsing: the staged text is raw (multi-line) FASTA.  A line that begins with '>' is a header
+ * (dropped; it ends the previous record: one breaker byte is emitted), every other line is sequence: its bytes are
+ * kept except ' ', '\t', '\r' and the newline itself, so k-mers span line breaks exactly as they do after
+ * needletail's FASTA reader + normalize(false) (lib.rs:60-68, mash.rs:73).  `start_state` says what the chunk begins
+ * in the middle of: 0 = a line start (chunks are normally cut after a newline), 1 = a sequence line, 2 = a header
+ * line.  With FH_PUSH_CONTINUE the chunk continues the previous fh_push_fasta_text chunk (k-mers span the cut).
+ * total_bases (raw sequence-region lengths, mash.rs:72) is the caller's to count: it needs no per-base work. */
+int fh_push_fasta_text(fh_sketcher *s, uint64_t len, uint32_t start_state, uint32_t flags);
 /* Zero-copy form of fh_push_block_ex: the caller writes packed-stream bytes (sequence bytes + one breaker byte per
  * record, whitespace already removed) straight into the buffer handed out by fh_text_buffer and commits the first
  * `len` of them.  Same flags as fh_push_block_ex. */

@@ -183,3 +183,56 @@ print("child ok")
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode == 0 and "child ok" in r.stdout, r.stdout
+
+
+def test_device_side_fasta_parsing_matches_host_parser(tmp_path):
+    """with FINCH_DEVICE_PARSE=1 the sequence bytes of multi-line FASTA are found on the device
+    (fh_text.hip, latest-event max-scan); same sketch, seq_length and numValidKmers as the host parser: LF / CRLF,
+    ragged line lengths, '>' inside lines, blank lines, spaces and tabs, empty records, a last line without newline,
+    many short records, 0xFF bytes, header and sequence lines longer than the staging chunk, chunks of 4 KiB"""
+    code = r'''
+import os, sys, numpy as np
+from finch_rs_amd import host as H, sketch_schemes as S
+rng = np.random.default_rng(11)
+g = bytes(S.synth_genome_host(600000, 13))
+def wrap(seq, w, eol):
+    return eol.join(seq[i:i + w] for i in range(0, len(seq), w)) + eol
+def contigs(n, eol, w, last_newline=True):
+    cuts = sorted(rng.integers(0, len(g), n - 1).tolist())
+    parts = [g[a:b] for a, b in zip([0] + cuts, cuts + [len(g)])]
+    out = b"".join(b">contig%d len=%d" % (i, len(s)) + eol + (wrap(s, w, eol) if s else b"") for i, s in enumerate(parts))
+    return out if last_newline else out.rstrip(b"\r\n")
+cases = {
+    "lf70": contigs(7, b"\n", 70),
+    "crlf60": contigs(5, b"\r\n", 60),
+    "nolast": contigs(3, b"\n", 80, False),
+    "oneline": b">x\n" + g[:300000] + b"\n>y\n" + g[300000:] + b"\n",           # lines far longer than a chunk
+    "longheader": b">" + b"h" * 20000 + b"\n" + wrap(g[:50000], 61, b"\n"),
+    "many": b"".join(b">r%d\n" % i + g[i * 97:i * 97 + int(rng.integers(1, 200))] + b"\n" for i in range(4000)),
+    "odd": (b">a desc > with gt\nACGT>ACGTAC\n\n  ACG TAC\tGT \r\nNNNN\n>\n>empty\n>b\n" + wrap(g[1000:9000], 33, b"\n") +
+            b">c\n" + g[:500] + b"\xff" + g[500:1000] + b"\n>last\nACGTACGTACGTACGTACGTACGTACGT"),
+}
+p = S.SketchParams.mash(400, 400, True, 21, 0)
+f = H.FilterParams(False)
+for name, data in cases.items():
+    path = os.path.join(sys.argv[1], name + ".fa")
+    open(path, "wb").write(data)
+    os.environ["FINCH_DEVICE_PARSE"] = "0"
+    a = H.sketch_files([path], p, f).sketch(0)
+    for mode in ("1", None):  # explicit, and the default (FASTA is split on the device unless told otherwise)
+        if mode is None:
+            os.environ.pop("FINCH_DEVICE_PARSE", None)
+        else:
+            os.environ["FINCH_DEVICE_PARSE"] = mode
+        b = H.sketch_files([path], p, f).sketch(0)
+        assert np.array_equal(a.arrays[0], b.arrays[0]) and np.array_equal(a.arrays[1], b.arrays[1]), name
+        assert (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers), (name, a.seq_length, b.seq_length, a.num_valid_kmers, b.num_valid_kmers)
+print("child ok")
+'''
+    for env in [{}, {"FH_STAGE_BYTES": "65536"}, {"FH_STAGE_BYTES": "4096"}]:
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=e,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0 and "child ok" in r.stdout, r.stdout

@@ -25,7 +25,7 @@ for rep in range(2):
     t = time.time(); res2 = H.sketch_files([path], p, H.FilterParams(False)); dt = time.time() - t
     print("sketch_files fastq, device-side parsing: %.2f s  %.2f GB/s text  %.1f Mbases/s" % (dt, size / dt / 1e9, n_reads * rl / dt / 1e6))
 assert np.array_equal(res.sketch(0).arrays[0], res2.sketch(0).arrays[0])
-os.environ.pop("FINCH_DEVICE_PARSE")
+os.environ.pop("FINCH_DEVICE_PARSE")  # (FASTQ: the host parser is the default)
 # FASTA genome-like
 fa = "/tmp/e2e.fa"
 seq = S.synth_genome_host(200_000_000, 7).tobytes()
@@ -34,8 +34,14 @@ with open(fa, "wb") as f:
     for i in range(0, len(seq), 70 * 100000):
         blk = seq[i:i + 70 * 100000]
         f.write(b"\n".join(blk[j:j + 70] for j in range(0, len(blk), 70))); f.write(b"\n")
-t = time.time(); res = H.sketch_files([fa], p, H.FilterParams(False)); dt = time.time() - t
-print("sketch_files fasta 200 Mb: %.2f s  %.1f Mbases/s" % (dt, 200e6 / dt / 1e6))
+for dev in (0, 0, 1, 1):
+    os.environ["FINCH_DEVICE_PARSE"] = "1" if dev else "0"
+    t = time.time(); r = H.sketch_files([fa], p, H.FilterParams(False)); dt = time.time() - t
+    print("sketch_files fasta 200 Mb%s: %.2f s  %.1f Mbases/s" % (", device-side parsing" if dev else "", dt, 200e6 / dt / 1e6))
+    if not dev:
+        res = r
+assert np.array_equal(res.sketch(0).arrays[0], r.sketch(0).arrays[0]) and res.sketch(0).seq_length == r.sketch(0).seq_length
+os.environ.pop("FINCH_DEVICE_PARSE", None)
 # batch of small fastas across threads
 paths = []
 for i in range(256):
@@ -44,6 +50,9 @@ for i in range(256):
         f.write(b">g\n"); s5 = seq[(i % 60) * 3_000_000:(i % 60 + 1) * 3_000_000 + 2_000_000]
         f.write(b"\n".join(s5[j:j + 70] for j in range(0, len(s5), 70))); f.write(b"\n")
     paths.append(pth)
-for nt in (1, 4, 8, 16, 32):
-    t = time.time(); res = H.sketch_files(paths, p, H.FilterParams(False), n_threads=nt); dt = time.time() - t
-    print("batch 256 x 5 Mb fasta, %d threads: %.2f s  %.1f files/s  %.1f Mbases/s" % (nt, dt, 256 / dt, 256 * 5e6 / dt / 1e6))
+for dev in (0, 1):
+    os.environ["FINCH_DEVICE_PARSE"] = "1" if dev else "0"
+    for nt in (1, 4, 8, 16):
+        t = time.time(); res = H.sketch_files(paths, p, H.FilterParams(False), n_threads=nt); dt = time.time() - t
+        print("batch 256 x 5 Mb fasta%s, %d threads: %.2f s  %.1f files/s  %.1f Mbases/s"
+              % (", device-side parsing" if dev else "", nt, dt, 256 / dt, 256 * 5e6 / dt / 1e6))
