@@ -872,6 +872,8 @@ int fh_push_device(fh_sketcher *s, const void *dev_bytes, uint64_t len) {
     if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
     if (((uintptr_t)dev_bytes & 15u) != 0) return fail(FH_ERR_INVALID, "device block must be 16-byte aligned");
     if (int rc = set_device(s)) return rc;
+    s->carry_len = 0;
+    s->dprev_len = 0;
     int rc = sketch_device_range(s, (const uint8_t *)dev_bytes, len, s->stream_off);
     s->stream_off += len;
     return rc;
@@ -917,6 +919,7 @@ int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_
     // positions are contiguous.  k-mers may span staging slices of one block: carry K-1 bytes over.
     const uint32_t K = s->p.k;
     if (!(flags & FH_PUSH_CONTINUE)) s->carry_len = 0;
+    s->dprev_len = 0; // a device-side FASTA chunk chain ends here
     uint64_t in = 0;
     while (in < len) {
         const int b = s->stage_next;
@@ -979,6 +982,7 @@ int fh_push_staged(fh_sketcher *s, uint64_t len, uint32_t flags) {
     if (int rc = set_device(s)) return rc;
     if (int rc = ensure_stage(s)) return rc;
     if (!(flags & FH_PUSH_CONTINUE)) s->carry_len = 0;
+    s->dprev_len = 0; // a device-side FASTA chunk chain ends here
     if (len == 0) return FH_OK;
     const int b = s->stage_next;
     const uint32_t K = s->p.k;
@@ -1032,6 +1036,7 @@ int fh_push_fastq_text(fh_sketcher *s, uint64_t len) {
     const uint64_t n_packed = s->h_text_tot[1];
     s->stage_next = (b + 1) % N_STAGE;
     s->carry_len = 0; // every sequence line ends with its breaker: nothing spans chunks
+    s->dprev_len = 0;
     const int rc = sketch_device_range(s, s->d_packed[b], n_packed, s->stream_off);
     s->stream_off += n_packed;
     return rc;
