@@ -130,7 +130,6 @@ struct fh_sketcher {
     uint8_t carry[32] = {0}; // last K-1 staged bytes: k-mers span staging slices (and FH_PUSH_CONTINUE pushes)
     uint32_t carry_len = 0;
     Ctl *h_ctl = nullptr; // pinned
-    void *h_tau = nullptr; // pinned, 8 bytes
     void *h_out = nullptr; // pinned staging of the finished sketch (fh_finish)
     size_t h_out_bytes = 0;
 
@@ -383,9 +382,7 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
 }
 
 int set_tau(fh_sketcher *s, uint64_t tau) {
-    *(uint64_t *)s->h_tau = tau;
-    HIP_TRY(hipMemcpyAsync(&s->ctl->tau, s->h_tau, 8, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream)); // h_tau is reused
+    HIP_TRY(launch_set_tau(s->ctl, tau, s->stream));
     s->last_tau = tau;
     return FH_OK;
 }
@@ -785,7 +782,6 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
             return bail("hipMalloc(left)", e);
     if ((e = hipMalloc(&s->clog, CLOG_CAP * sizeof(CollRec))) != hipSuccess) return bail("hipMalloc(clog)", e);
     if ((e = hipHostMalloc(&s->h_ctl, sizeof(Ctl), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
-    if ((e = hipHostMalloc(&s->h_tau, 64, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
     s->no_spec = getenv("FH_NO_SPEC") != nullptr;
 
     if ((e = launch_fill_table(s->table, cap, s->stream)) != hipSuccess) return bail("fill_table", e);
@@ -824,7 +820,6 @@ void fh_free(fh_sketcher *s) {
     if (s->h_text_tot) (void)hipHostFree(s->h_text_tot);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     if (s->h_out) (void)hipHostFree(s->h_out);
-    if (s->h_tau) (void)hipHostFree(s->h_tau);
     (void)hipFree(s->left_buf[0]);
     (void)hipFree(s->left_buf[1]);
     (void)hipFree(s->keys_a);
@@ -1126,7 +1121,7 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         if (int rc = ensure_out(s, s->h_ctl->n_live)) return rc;
         HIP_TRY(launch_gather(s->table, s->live, s->ctl, (int)s->p.k, s->o_hash, s->o_count, s->o_extra, s->o_kmer,
                               s->o_pos, s->out_cap, s->stream));
-        if (int rc = check_ctl(s)) return rc;
+        // (the control block read back after the prune is final: the gather only reads it)
         if (int rc = collect_profile(s)) return rc;
         const Ctl c = *s->h_ctl;
         const uint32_t n = c.n_live;

@@ -154,7 +154,10 @@ __device__ __forceinline__ void classify_tile(const SketchArgs &a, u64 tile, int
 // Register budget: the unrolled position loop of K <= 21 needs just under 128 VGPRs; telling the compiler to aim for
 // four waves per SIMD keeps it there (left alone it lands on 129-130 and loses a wave).  Larger K need 136-170
 // (three waves) and would spill under the same bound.
-constexpr int k2_min_waves(int K) { return K <= 21 ? 4 : 1; }
+#ifndef FH_MINW_KMAX
+#define FH_MINW_KMAX 21
+#endif
+constexpr int k2_min_waves(int K) { return K <= FH_MINW_KMAX ? 4 : 1; }
 template <int K, bool MASKED, bool SEED0, bool HASLO>
 __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchArgs a) {
     // murmur3 lookup tables with the second stage folded in (fh_core.h): A / B records of two-group key words,

@@ -41,6 +41,7 @@ hipError_t launch_fasta_pack(const uint8_t *text, uint64_t len, uint32_t start_s
                              uint32_t *blk_b, uint32_t *totals, hipStream_t st);
 hipError_t launch_fill_table(Entry *table, uint64_t cap, hipStream_t st);
 hipError_t launch_init_ctl(Ctl *ctl, uint64_t tau0, hipStream_t st);
+hipError_t launch_set_tau(Ctl *ctl, uint64_t tau, hipStream_t st);
 hipError_t launch_set_table(Ctl *ctl, Entry *table, uint32_t *live, CollRec *clog, uint32_t cap, uint32_t live_cap,
                             uint32_t clog_cap, uint32_t *shard_cnt, uint32_t *shard_buf, uint32_t shard_cap, hipStream_t st);
 hipError_t launch_live_flatten(Ctl *ctl, hipStream_t st);

@@ -459,6 +459,16 @@ hipError_t launch_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, hipStream
     return hipGetLastError();
 }
 
+__global__ void k_set_tau(Ctl *ctl, u64 tau) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctl->tau = tau;
+}
+
+// the threshold as a kernel argument: no host buffer to keep alive, no synchronisation
+hipError_t launch_set_tau(Ctl *ctl, u64 tau, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_tau, dim3(1), dim3(64), 0, st, ctl, tau);
+    return hipGetLastError();
+}
+
 hipError_t launch_init_ctl(Ctl *ctl, u64 tau0, hipStream_t st) {
     hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, st, ctl, tau0);
     return hipGetLastError();
