@@ -2,6 +2,7 @@
 inputs with arbitrary bytes and whitespace, records cut into several pushes (FH_PUSH_CONTINUE), resident
 and staged blocks, tiny in-flight limits (forces stop/relaunch), handle reuse via reset."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -31,9 +32,14 @@ def rand_record(rng, genome, maxlen):
     return bytes(r)
 
 
-@pytest.mark.parametrize("case", range(120))
+# soak runs: FH_FUZZ_CASES=600 FH_FUZZ_SEED=123456 python -m pytest tests/test_gpu_fuzz.py -m gpu
+N_CASES = int(os.environ.get("FH_FUZZ_CASES", "120"))
+SEED0 = int(os.environ.get("FH_FUZZ_SEED", "9000"))
+
+
+@pytest.mark.parametrize("case", range(N_CASES))
 def test_random_configuration(case):
-    rng = np.random.default_rng(9000 + case)
+    rng = np.random.default_rng(SEED0 + case)
     k = int(rng.choice([1, 2, 3, 5, 8, 11, 15, 16, 17, 21, 21, 21, 24, 27, 31, 31, 32]))
     kind = "mash" if rng.random() < 0.6 else "scaled"
     size = int(rng.choice([0, 1, 7, 100, 1000, 1000, 2999, 3001, 12000]))

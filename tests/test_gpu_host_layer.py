@@ -236,3 +236,39 @@ print("child ok")
                            cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode == 0 and "child ok" in r.stdout, r.stdout
+
+
+def test_device_side_fasta_parsing_random_text():
+    """random FASTA-shaped text (arbitrary bytes, '>' anywhere, LF / CRLF, blank lines, ragged lines, empty records)
+    through sketch_stream: device-side splitting == host parser, sketch and seq_length, for several k; repeated with
+    4 KiB staging chunks so that the cuts land everywhere (the knob is read when the library loads: child process)"""
+    code = r'''
+import os, numpy as np
+from finch_rs_amd import host as H, sketch_schemes as S
+alpha = np.frombuffer(b"ACGTACGTACGTACGTacgtNnuU>>- \t\r\xff*", dtype=np.uint8)
+for case in range(30):
+    rng = np.random.default_rng(4200 + case)
+    lines = []
+    for i in range(int(rng.choice([1, 5, 60, 800, 4000]))):
+        r = rng.random()
+        if i == 0 or r < 0.08:
+            lines.append(b">" + bytes(rng.choice(alpha, size=int(rng.integers(0, 40)))))
+        elif r < 0.12:
+            lines.append(b"")
+        else:
+            lines.append(bytes(rng.choice(alpha, size=int(rng.choice([1, 7, 60, 70, 500, 6000])))))
+    eol = [b"\n", b"\r\n"][int(rng.integers(0, 2))]
+    data = eol.join(lines) + (eol if rng.random() < 0.7 else b"")
+    k = int(rng.choice([3, 16, 21, 31]))
+    p = S.SketchParams.mash(50, 50, True, k, 0)
+    f = H.FilterParams(False)
+    os.environ["FINCH_DEVICE_PARSE"] = "0"
+    a = H.sketch_stream(data, "x", p, f).sketch(0)
+    os.environ["FINCH_DEVICE_PARSE"] = "1"
+    b = H.sketch_stream(data, "x", p, f).sketch(0)
+    assert np.array_equal(a.arrays[0], b.arrays[0]) and np.array_equal(a.arrays[1], b.arrays[1]), case
+    assert (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers), (case, a.seq_length, b.seq_length)
+print("child ok")
+'''
+    for env in [{}, {"FH_STAGE_BYTES": "4096"}, {"FH_STAGE_BYTES": "5001"}]:
+        assert "child ok" in _run_child(code, env)
