@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -151,6 +152,12 @@ struct fh_sketcher {
     uint64_t prof_launches = 0, prof_positions = 0;
 
     // finished result (host), ascending by hash
+    // fh_finish leaves the result as arrays in the pinned D2H buffer (r_* point into h_out); the record vector is
+    // only built when a merge needs it (2 M records: 10 ms of host time that fh_copy_out does not need)
+    uint64_t *r_hash = nullptr, *r_kmer = nullptr, *r_pos = nullptr;
+    uint32_t *r_count = nullptr, *r_extra = nullptr;
+    size_t r_n = 0;
+    bool res_built = false;
     std::vector<ResultRec> res;
     uint64_t total_kmers = 0;
 };
@@ -192,6 +199,8 @@ int init_state(fh_sketcher *s) {
     s->finished = false;
     s->dirty = false;
     s->res.clear();
+    s->res_built = false;
+    s->r_n = 0;
     s->total_kmers = 0;
     s->prof_used = 0;
     s->prof_ms = 0.0;
@@ -1105,9 +1114,27 @@ int fh_sync(fh_sketcher *s) {
     return collect_profile(s);
 }
 
+static size_t result_count(const fh_sketcher *s) { return s->res_built ? s->res.size() : s->r_n; }
+
+// the record form of a finished sketch (merges work on it); built from the arrays fh_finish left behind
+static void ensure_records(fh_sketcher *s) {
+    if (s->res_built) return;
+    s->res.resize(s->r_n);
+    for (size_t i = 0; i < s->r_n; ++i)
+        s->res[i] = ResultRec{s->r_hash[i], s->r_count[i], s->r_extra[i], s->r_kmer[i], s->r_pos[i]};
+    s->res_built = true;
+}
+
 int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (int rc = set_device(s)) return rc;
+    static const bool trace = getenv("FH_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
+    auto t1 = t0, t2 = t0, t3 = t0;
     if (!s->finished) {
         if (int rc = drain(s)) return rc;
         if (int rc = check_ctl(s)) return rc;
@@ -1118,6 +1145,7 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         } else {
             if (int rc = big_prune(s)) return rc;
         }
+        t1 = now(); // drained + pruned
         if (int rc = ensure_out(s, s->h_ctl->n_live)) return rc;
         HIP_TRY(launch_gather(s->table, s->live, s->ctl, (int)s->p.k, s->o_hash, s->o_count, s->o_extra, s->o_kmer,
                               s->o_pos, s->out_cap, s->stream));
@@ -1125,8 +1153,10 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         if (int rc = collect_profile(s)) return rc;
         const Ctl c = *s->h_ctl;
         const uint32_t n = c.n_live;
-        // D2H through one pinned staging area (pageable destinations crawl at a few GB/s)
-        const size_t need = (size_t)n * 32 + 64;
+        // D2H through one pinned staging area (pageable destinations crawl at a few GB/s); one spare record for the
+        // special hash
+        const size_t cap = (size_t)n + 1;
+        const size_t need = cap * 32 + 64;
         if (need > s->h_out_bytes) {
             if (s->h_out) (void)hipHostFree(s->h_out);
             s->h_out = nullptr;
@@ -1134,8 +1164,8 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
             HIP_TRY(hipHostMalloc(&s->h_out, need + need / 4, hipHostMallocDefault));
             s->h_out_bytes = need + need / 4;
         }
-        uint64_t *hh = (uint64_t *)s->h_out, *kk = hh + n, *pp = kk + n;
-        uint32_t *cc = (uint32_t *)(pp + n), *ee = cc + n;
+        uint64_t *hh = (uint64_t *)s->h_out, *kk = hh + cap, *pp = kk + cap;
+        uint32_t *cc = (uint32_t *)(pp + cap), *ee = cc + cap;
         if (n) {
             HIP_TRY(hipMemcpyAsync(hh, s->o_hash, n * 8ull, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipMemcpyAsync(kk, s->o_kmer, n * 8ull, hipMemcpyDeviceToHost, s->stream));
@@ -1147,27 +1177,43 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         if (!coll.empty())
             HIP_TRY(hipMemcpyAsync(coll.data(), s->clog, coll.size() * sizeof(CollRec), hipMemcpyDeviceToHost, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
-        s->res.resize(n);
-        for (uint32_t i = 0; i < n; ++i) s->res[i] = ResultRec{hh[i], cc[i], ee[i], kk[i], pp[i]}; // threads do not help here (measured)
+        t2 = now(); // gathered + copied to the host
+        size_t m = n;
         // the hash value that cannot be a table key, if it occurred (it sorts last)
         if (c.sp_count) {
-            ResultRec r{EMPTY64, (uint32_t)std::min<uint64_t>(c.sp_count, UINT32_MAX),
-                        (uint32_t)std::min<uint64_t>(c.sp_extra, UINT32_MAX), c.sp_kmer, c.sp_pos};
-            s->res.push_back(r);
+            hh[m] = EMPTY64;
+            cc[m] = (uint32_t)std::min<uint64_t>(c.sp_count, UINT32_MAX);
+            ee[m] = (uint32_t)std::min<uint64_t>(c.sp_extra, UINT32_MAX);
+            kk[m] = c.sp_kmer;
+            pp[m] = c.sp_pos;
+            ++m;
         }
-        select_final(s, s->res);
+        // final selection (mash.rs:57-60 / scaled.rs:41-58 net effect) on the ascending hash array
+        if (s->p.kind == FH_KIND_MASH) {
+            m = std::min<size_t>(m, s->p.size);
+        } else {
+            const size_t n_le = (size_t)(std::upper_bound(hh, hh + m, s->max_hash) - hh);
+            m = std::max<size_t>(n_le, std::min<size_t>(m, s->p.size));
+        }
         // 64-bit hash collisions between distinct k-mers: the reference keeps the bytes of the first
         // occurrence (mash.rs:52-56).  Occurrences whose k-mer differed from the slot's were logged.
         for (const CollRec &cr : coll) {
-            auto it = std::lower_bound(s->res.begin(), s->res.end(), cr.hash,
-                                       [](const ResultRec &r, uint64_t h) { return r.hash < h; });
-            if (it != s->res.end() && it->hash == cr.hash && it->pos == cr.pos) it->kmer = cr.kmer;
+            const uint64_t *it = std::lower_bound(hh, hh + m, cr.hash);
+            if (it != hh + m && *it == cr.hash && pp[it - hh] == cr.pos) kk[it - hh] = cr.kmer;
         }
+        s->r_hash = hh; s->r_kmer = kk; s->r_pos = pp; s->r_count = cc; s->r_extra = ee;
+        s->r_n = m;
+        s->res.clear();
+        s->res_built = false;
         s->total_kmers = 0;
         for (int i = 0; i < 256; ++i) s->total_kmers += c.kmer_counts[i];
         s->finished = true;
+        t3 = now();
+        if (trace)
+            fprintf(stderr, "[fh] finish: drain+prune %.2f ms, gather+D2H %.2f ms, host records %.2f ms (n=%zu)\n", ms(t0, t1),
+                    ms(t1, t2), ms(t2, t3), s->r_n);
     }
-    if (n_out) *n_out = s->res.size();
+    if (n_out) *n_out = result_count(s);
     if (total_kmers) *total_kmers = s->total_kmers;
     return FH_OK;
 }
@@ -1177,16 +1223,30 @@ int fh_copy_out(fh_sketcher *s, uint64_t *hashes, uint32_t *counts, uint32_t *ex
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (!s->finished) return fail(FH_ERR_STATE, "fh_copy_out before fh_finish");
     const int k = (int)s->p.k;
-    const ResultRec *res = s->res.data();
-    parallel_for(s->res.size(), [=](size_t lo, size_t hi) {
-        for (size_t i = lo; i < hi; ++i) {
-            const ResultRec &r = res[i];
-            if (hashes) hashes[i] = r.hash;
-            if (counts) counts[i] = r.count;
-            if (extra_counts) extra_counts[i] = r.extra;
-            if (kmers) kmer_ascii(r.kmer, k, kmers + i * (size_t)k);
-            if (first_pos) first_pos[i] = r.pos;
-        }
+    if (s->res_built) { // after a merge the record vector is the result
+        const ResultRec *res = s->res.data();
+        parallel_for(s->res.size(), [=](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                const ResultRec &r = res[i];
+                if (hashes) hashes[i] = r.hash;
+                if (counts) counts[i] = r.count;
+                if (extra_counts) extra_counts[i] = r.extra;
+                if (kmers) kmer_ascii(r.kmer, k, kmers + i * (size_t)k);
+                if (first_pos) first_pos[i] = r.pos;
+            }
+        });
+        return FH_OK;
+    }
+    const uint64_t *hh = s->r_hash, *kk = s->r_kmer, *pp = s->r_pos;
+    const uint32_t *cc = s->r_count, *ee = s->r_extra;
+    parallel_for(s->r_n, [=](size_t lo, size_t hi) {
+        const size_t cnt = hi - lo;
+        if (hashes) memcpy(hashes + lo, hh + lo, cnt * 8);
+        if (counts) memcpy(counts + lo, cc + lo, cnt * 4);
+        if (extra_counts) memcpy(extra_counts + lo, ee + lo, cnt * 4);
+        if (first_pos) memcpy(first_pos + lo, pp + lo, cnt * 8);
+        if (kmers)
+            for (size_t i = lo; i < hi; ++i) kmer_ascii(kk[i], k, kmers + i * (size_t)k);
     });
     return FH_OK;
 }
@@ -1201,6 +1261,7 @@ int fh_merge_arrays(fh_sketcher *dst, uint64_t n, const uint64_t *hashes, const 
     std::vector<ResultRec> src(n), out;
     for (uint64_t j = 0; j < n; ++j)
         src[j] = ResultRec{hashes[j], counts[j], extra_counts[j], ascii_kmer(kmers + j * (size_t)k, k), first_pos[j]};
+    ensure_records(dst);
     if (int rc = merge_sorted(dst->res, src, out)) return rc;
     select_final(dst, out);
     dst->res.swap(out);
@@ -1240,6 +1301,7 @@ int fh_merge(fh_sketcher *dst, const fh_sketcher *src) {
     if (!src->finished) return fail(FH_ERR_STATE, "fh_merge: src not finished");
     if (dst->p.k != src->p.k || dst->p.kind != src->p.kind || dst->p.seed != src->p.seed || dst->p.size != src->p.size)
         return fail(FH_ERR_INVALID, "fh_merge: incompatible sketch parameters");
+    ensure_records(const_cast<fh_sketcher *>(src));
     const size_t n = src->res.size();
     const int k = (int)src->p.k;
     std::vector<uint64_t> hh(n), pp(n);
