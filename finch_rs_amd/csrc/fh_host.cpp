@@ -4,6 +4,7 @@
 //
 // Reference items mirrored (relative to the finch-rs tree) are cited at each function.
 #include <dlfcn.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -1176,8 +1177,18 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
     // sized for a 10 Gbase stream
     const bool batch = n_files > 1;
     const uint64_t ml = env_max_launch() ? env_max_launch() : (batch ? (2ull << 20) : 0ull);
+    // a single small file: size the one sketcher for it (pinning 2 x 64 MiB of staging memory alone takes ~40 ms, the
+    // whole sketch of a 5 Mb genome well under 10)
+    uint64_t single_stage = 0, single_ml = ml;
+    if (!batch && n_files == 1 && strcmp(filenames[0], "-") != 0) {
+        struct stat sb;
+        if (stat(filenames[0], &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size < (48ull << 20)) {
+            single_stage = std::max<uint64_t>(((uint64_t)sb.st_size + (1ull << 20)) & ~((1ull << 20) - 1), 1ull << 20);
+            if (!single_ml) single_ml = 2ull << 20;
+        }
+    }
     auto worker = [&](uint32_t w) {
-        fh_params p = to_fh(*sp, ml, batch ? (16ull << 20) : 0ull);
+        fh_params p = to_fh(*sp, batch ? ml : single_ml, batch ? (16ull << 20) : single_stage);
         fh_sketcher *h = nullptr;
         for (;;) {
             const uint32_t i = next.fetch_add(1);
