@@ -118,6 +118,7 @@ struct fh_sketcher {
     uint8_t *d_stage[N_STAGE] = {nullptr, nullptr};
     hipEvent_t stage_done[N_STAGE] = {nullptr, nullptr};
     bool stage_busy[N_STAGE] = {false, false};
+    uint64_t stage_cap[N_STAGE] = {0, 0}; // bytes a slot can hold (<= stage_bytes; slots grow with the pushes they serve)
     int stage_next = 0;
     uint64_t stage_bytes = 0;
     // device-side FASTQ packing (fh_text.hip): packed output + block scan scratch per staging slot
@@ -913,12 +914,12 @@ static inline uint64_t strip_copy(uint8_t *dst, const uint8_t *src, uint64_t n, 
 }
 
 static int ensure_stage(fh_sketcher *s);
+static int ensure_slot(fh_sketcher *s, int i, uint64_t want);
 
 int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_t flags) {
     if (!s || (!bytes && len)) return fail(FH_ERR_INVALID, "null argument");
     if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
     if (int rc = set_device(s)) return rc;
-    if (int rc = ensure_stage(s)) return rc;
     // normalize(false) drops whitespace (needletail; mash.rs:73): strip it while staging so that device
     // positions are contiguous.  k-mers may span staging slices of one block: carry K-1 bytes over.
     const uint32_t K = s->p.k;
@@ -927,15 +928,16 @@ int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_
     uint64_t in = 0;
     while (in < len) {
         const int b = s->stage_next;
+        const uint32_t carry_len = s->carry_len;
+        if (int rc = ensure_slot(s, b, len - in + carry_len + 64)) return rc;
         if (s->stage_busy[b]) {
             HIP_TRY(hipEventSynchronize(s->stage_done[b]));
             s->stage_busy[b] = false;
         }
         uint8_t *dst = s->h_stage[b];
-        const uint32_t carry_len = s->carry_len;
         memcpy(dst, s->carry, carry_len);
         uint64_t consumed = 0;
-        const uint64_t fresh = strip_copy(dst + carry_len, bytes + in, len - in, s->stage_bytes - carry_len, &consumed);
+        const uint64_t fresh = strip_copy(dst + carry_len, bytes + in, len - in, s->stage_cap[b] - carry_len, &consumed);
         in += consumed;
         const uint64_t m = carry_len + fresh;
         const uint64_t base = s->stream_off - carry_len;
@@ -954,14 +956,34 @@ int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_
     return FH_OK;
 }
 
-static int ensure_stage(fh_sketcher *s) {
-    for (int i = 0; i < N_STAGE; ++i) {
-        if (!s->h_stage[i]) {
-            HIP_TRY(hipHostMalloc((void **)&s->h_stage[i], s->stage_bytes + 128, hipHostMallocDefault));
-            HIP_TRY(hipMalloc((void **)&s->d_stage[i], s->stage_bytes + 128));
-            HIP_TRY(hipEventCreateWithFlags(&s->stage_done[i], hipEventDisableTiming));
-        }
+// Staging slot i able to hold `want` bytes.  Pinning memory is slow (2 x 64 MiB: ~40 ms), so a slot is only as large
+// as the pushes it has served: a sketcher that sees one 5 MB record block never pins more than that.
+static int ensure_slot(fh_sketcher *s, int i, uint64_t want) {
+    want = std::min<uint64_t>(std::max<uint64_t>(want, 1ull << 20), s->stage_bytes);
+    if (!s->stage_done[i]) HIP_TRY(hipEventCreateWithFlags(&s->stage_done[i], hipEventDisableTiming));
+    if (s->stage_cap[i] >= want) return FH_OK;
+    if (s->stage_cap[i]) {
+        const uint64_t old_cap = s->stage_cap[i];
+        // growing: whatever still reads the old buffers has to finish first
+        if (int rc = drain(s)) return rc;
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        s->stage_busy[i] = false;
+        (void)hipHostFree(s->h_stage[i]);
+        (void)hipFree(s->d_stage[i]);
+        s->h_stage[i] = s->d_stage[i] = nullptr;
+        s->stage_cap[i] = 0;
+        want = std::min<uint64_t>(std::max<uint64_t>(want, 2 * old_cap), s->stage_bytes); // grow geometrically
     }
+    HIP_TRY(hipHostMalloc((void **)&s->h_stage[i], want + 128, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&s->d_stage[i], want + 128));
+    s->stage_cap[i] = want;
+    return FH_OK;
+}
+
+// the zero-copy paths hand the caller a buffer of the full staging size
+static int ensure_stage(fh_sketcher *s) {
+    for (int i = 0; i < N_STAGE; ++i)
+        if (int rc = ensure_slot(s, i, s->stage_bytes)) return rc;
     return FH_OK;
 }
 

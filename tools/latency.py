@@ -18,3 +18,7 @@ for rep in range(3):
 for rep in range(3):
     t = time.perf_counter(); sk = p.create_sketcher(max_launch=2 << 20, stage_bytes=16 << 20); t1 = time.perf_counter(); sk.close(); t2 = time.perf_counter()
     print("fh_new (2 M positions in flight) %.2f ms, fh_free %.2f ms" % ((t1 - t) * 1e3, (t2 - t1) * 1e3))
+blk = np.frombuffer(seq + b"\x00", dtype=np.uint8)
+for rep in range(3):
+    t = time.perf_counter(); sk = p.create_sketcher(); sk.push_block(blk); n, tk = sk.finish(); t1 = time.perf_counter(); sk.close()
+    print("fh_new + fh_push_block(5 MB) + fh_finish (the Rust binding's sequence for one small file): %.2f ms" % ((t1 - t) * 1e3))
