@@ -33,6 +33,7 @@ SYMBOLS = {
     "fh_abi_version": (C.c_int, []),
     "fh_new": (_P, [C.POINTER(FhParams), C.c_int]),
     "fh_free": (None, [_P]),
+    "fh_release_cached": (None, []),
     "fh_reset": (C.c_int, [_P]),
     "fh_set_stream_offset": (C.c_int, [_P, C.c_uint64]),
     "fh_push_block": (C.c_int, [_P, _P, C.c_uint64]),

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -715,7 +716,70 @@ int fh_device_count(void) {
     return n;
 }
 
+// ---- handle cache ----
+// finch creates one sketcher per file and drops it after to_vec (lib.rs:58-79), and a sketcher here owns gigabytes of
+// table plus pinned staging memory: creating and freeing one costs ~5 ms, a 5 Mb genome ~1 ms to sketch.  fh_free
+// therefore resets the handle and parks it; the next fh_new with the same parameters on the same device takes it
+// over.  At most pool_max() handles stay parked (FH_POOL, default 8; 0 = off); fh_release_cached frees them.
+namespace {
+std::mutex g_pool_mu;
+std::vector<fh_sketcher *> g_pool;
+size_t pool_max() {
+    static const size_t v = [] {
+        const char *e = getenv("FH_POOL");
+        return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)8;
+    }();
+    return v;
+}
+bool same_params(const fh_params &a, const fh_params &b) {
+    return a.kind == b.kind && a.k == b.k && a.size == b.size && a.seed == b.seed && memcmp(&a.scale, &b.scale, sizeof(double)) == 0 &&
+           a.max_launch == b.max_launch && a.hash_mask == b.hash_mask && a.stage_bytes == b.stage_bytes;
+}
+void destroy_handle(fh_sketcher *s);
+} // namespace
+
+void fh_release_cached(void) {
+    std::vector<fh_sketcher *> victims;
+    {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        victims.swap(g_pool);
+    }
+    for (fh_sketcher *s : victims) destroy_handle(s);
+}
+
+static fh_sketcher *new_handle(const fh_params *params, int device);
+
 fh_sketcher *fh_new(const fh_params *params, int device) {
+    if (params && pool_max()) {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); ++i) {
+            fh_sketcher *s = g_pool[i];
+            if (s->device == device && same_params(s->p, *params)) {
+                g_pool.erase(g_pool.begin() + (long)i);
+                // fh_free left it reset; only the per-handle statistics are still the previous owner's
+                s->n_launches = s->n_relaunches = s->n_big_prunes = 0;
+                s->n_spec = s->n_spec_fallback = 0;
+                s->profiling = false;
+                return s;
+            }
+        }
+    }
+    fh_sketcher *s = new_handle(params, device);
+    if (!s && pool_max()) { // the parked handles may be what exhausted the device memory
+        bool any;
+        {
+            std::lock_guard<std::mutex> g(g_pool_mu);
+            any = !g_pool.empty();
+        }
+        if (any) {
+            fh_release_cached();
+            s = new_handle(params, device);
+        }
+    }
+    return s;
+}
+
+static fh_sketcher *new_handle(const fh_params *params, int device) {
     if (!params) {
         fail(FH_ERR_INVALID, "params is NULL");
         return nullptr;
@@ -754,7 +818,7 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
     }
     auto bail = [&](const char *what, hipError_t e) -> fh_sketcher * {
         fail(FH_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
-        fh_free(s);
+        destroy_handle(s);
         return nullptr;
     };
     hipError_t e;
@@ -777,7 +841,7 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
     const uint64_t cap = 2 * live_cap;
     if (cap >= (1ull << 32)) {
         fail(FH_ERR_INVALID, "max_launch too large");
-        fh_free(s);
+        destroy_handle(s);
         return nullptr;
     }
     s->cap = (uint32_t)cap;
@@ -796,14 +860,14 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
 
     if ((e = launch_fill_table(s->table, cap, s->stream)) != hipSuccess) return bail("fill_table", e);
     if (alloc_shards(s, s->live_target) != FH_OK) {
-        fh_free(s);
+        destroy_handle(s);
         return nullptr;
     }
     if ((e = launch_set_table(s->ctl, s->table, s->live, s->clog, s->cap, s->live_cap, CLOG_CAP, s->shard_cnt, s->shard_buf,
                               s->shard_cap, s->stream)) != hipSuccess)
         return bail("set_table", e);
     if (init_state(s) != FH_OK) {
-        fh_free(s);
+        destroy_handle(s);
         return nullptr;
     }
     if ((e = hipStreamSynchronize(s->stream)) != hipSuccess) return bail("hipStreamSynchronize", e);
@@ -811,6 +875,19 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
 }
 
 void fh_free(fh_sketcher *s) {
+    if (!s) return;
+    if (pool_max() && s->ctl && fh_reset(s) == FH_OK) {
+        std::lock_guard<std::mutex> g(g_pool_mu);
+        if (g_pool.size() < pool_max()) {
+            g_pool.push_back(s);
+            return;
+        }
+    }
+    destroy_handle(s);
+}
+
+namespace {
+void destroy_handle(fh_sketcher *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
@@ -853,6 +930,7 @@ void fh_free(fh_sketcher *s) {
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
+} // namespace
 
 int fh_reset(fh_sketcher *s) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
