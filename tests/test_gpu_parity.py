@@ -387,3 +387,40 @@ def test_hash_collisions_keep_first_kmer():
         dup = set(vals[cnt > 1].tolist())
         n_coll_members += sum(1 for h in ora.to_vec()[0]["hash"].tolist() if h in dup)
     assert n_coll_members > 0
+
+
+def test_handle_cache_returns_a_clean_sketcher():
+    """fh_free parks the reset handle, fh_new with the same parameters takes it over: the second owner must see a
+    fresh sketcher (empty, counters at zero, same results as a brand-new one); different parameters get their own
+    handle; fh_release_cached empties the cache"""
+    from finch_rs_amd import _lib
+    g = S.synth_genome_host(200000, 21)
+    reads = S.synth_reads_host(g, 0, 8000, 150, 21, 10000, 500)
+    other = S.synth_reads_host(g, 8000, 3000, 150, 21, 10000, 500)
+    p = F.SketchParams.mash(500, 500, True, 21, 0)
+    a = p.create_sketcher()
+    a.push_block(other)
+    a.finish()
+    assert a.debug_counters()["launches"] > 0
+    a.close()                      # parked
+    b = p.create_sketcher()        # the same handle again
+    c = b.debug_counters()
+    assert c["launches"] == 0 and c["spec"] == 0, c
+    assert b.finish() == (0, 0)    # empty sketch, state as after fh_new
+    b.reset()
+    b.push_block(reads)
+    ora = O.OracleSketcher(O.MASH, 500, 21, 0)
+    ora.process_packed(reads, 0)
+    assert_same(b, ora, "recycled handle")
+    q = F.SketchParams.mash(500, 500, True, 31, 7).create_sketcher()   # other parameters: not the parked one
+    q.push_block(reads)
+    ora2 = O.OracleSketcher(O.MASH, 500, 31, 7)
+    ora2.process_packed(reads, 0)
+    assert_same(q, ora2, "different parameters")
+    b.close()
+    q.close()
+    _lib.load().fh_release_cached()
+    d = p.create_sketcher()        # a new allocation after the cache was emptied
+    d.push_block(reads)
+    assert_same(d, ora, "after fh_release_cached")
+    d.close()
