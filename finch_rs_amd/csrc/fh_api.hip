@@ -720,16 +720,23 @@ int fh_device_count(void) {
 // finch creates one sketcher per file and drops it after to_vec (lib.rs:58-79), and a sketcher here owns gigabytes of
 // table plus pinned staging memory: creating and freeing one costs ~5 ms, a 5 Mb genome ~1 ms to sketch.  fh_free
 // therefore resets the handle and parks it; the next fh_new with the same parameters on the same device takes it
-// over.  At most pool_max() handles stay parked (FH_POOL, default 8; 0 = off); fh_release_cached frees them.
+// over.  At most pool_max() handles (FH_POOL, default 64; 0 = off) holding at most 48 GB together stay parked;
+// fh_release_cached frees them.
 namespace {
 std::mutex g_pool_mu;
 std::vector<fh_sketcher *> g_pool;
 size_t pool_max() {
     static const size_t v = [] {
         const char *e = getenv("FH_POOL");
-        return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)8;
+        return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)64;
     }();
     return v;
+}
+constexpr uint64_t POOL_MAX_BYTES = 48ull << 30; // device memory the parked handles may hold together
+uint64_t handle_bytes(const fh_sketcher *s) {
+    uint64_t b = (uint64_t)s->cap * sizeof(Entry) + (uint64_t)s->live_cap * 8 + (uint64_t)s->shard_cap * N_SHARDS * 4;
+    for (int i = 0; i < N_STAGE; ++i) b += 2 * s->stage_cap[i];
+    return b + (uint64_t)s->out_cap * 32 + (uint64_t)s->big_cap * 24;
 }
 bool same_params(const fh_params &a, const fh_params &b) {
     return a.kind == b.kind && a.k == b.k && a.size == b.size && a.seed == b.seed && memcmp(&a.scale, &b.scale, sizeof(double)) == 0 &&
@@ -878,7 +885,9 @@ void fh_free(fh_sketcher *s) {
     if (!s) return;
     if (pool_max() && s->ctl && fh_reset(s) == FH_OK) {
         std::lock_guard<std::mutex> g(g_pool_mu);
-        if (g_pool.size() < pool_max()) {
+        uint64_t held = handle_bytes(s);
+        for (const fh_sketcher *q : g_pool) held += handle_bytes(q);
+        if (g_pool.size() < pool_max() && held <= POOL_MAX_BYTES) {
             g_pool.push_back(s);
             return;
         }

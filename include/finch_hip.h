@@ -69,8 +69,8 @@ int fh_abi_version(void);
 /* create_sketcher: allocate the device-resident sketch state on `device`. NULL on error. */
 fh_sketcher *fh_new(const fh_params *params, int device);
 /* Drop a sketcher.  finch creates one per file and drops it after to_vec (lib.rs:58-79); since a sketcher owns
- * gigabytes of device memory, fh_free resets it and keeps up to FH_POOL (environment, default 8, 0 = never) of them
- * parked, and fh_new hands a parked one back when the parameters and the device match (~0.1 ms instead of ~5 ms).
+ * gigabytes of device memory, fh_free resets it and keeps up to FH_POOL (environment, default 64, 0 = never) of them
+ * parked (48 GB of device memory at most), and fh_new hands a parked one back when the parameters and the device match (~0.1 ms instead of ~5 ms).
  * fh_release_cached frees what is parked. */
 void fh_free(fh_sketcher *s);
 void fh_release_cached(void);
