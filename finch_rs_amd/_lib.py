@@ -52,6 +52,8 @@ SYMBOLS = {
     "fh_merge_partials": (C.c_int, [C.c_uint32, C.c_uint64, C.c_double, C.c_uint32,
                                     C.c_uint64, _P, _P, _P, _P, _P, C.c_uint64, _P, _P, _P, _P, _P,
                                     _U64P, _P, _P, _P, _P, _P]),
+    "fh_merge_wire": (C.c_int, [C.c_uint32, C.c_uint64, C.c_double, C.c_uint32, C.c_uint64, C.c_uint32, _P, _U64P, _P, _P, _P, _P, _P,
+                      _U64P]),
     "fh_set_profiling": (C.c_int, [_P, C.c_int]),
     "fh_kernel_time": (C.c_int, [_P, C.POINTER(C.c_double), _U64P, _U64P]),
     "fh_debug_counters": (C.c_int, [_P, _U64P, _U64P, _U64P]),

@@ -1405,6 +1405,78 @@ int fh_merge_partials(uint32_t kind, uint64_t size, double scale, uint32_t k, ui
     return FH_OK;
 }
 
+// N partial sketches in the sharding wire format (finch_hip.h) -> one: a k-way walk over the sorted hash lists.
+// The same rule as merge_sorted applied pairwise (sums are formed in 64 bits and clamped once, which equals a chain of
+// saturating adds; the k-mer of the smallest first position wins), without building records or decoding k-mers.
+int fh_merge_wire(uint32_t kind, uint64_t size, double scale, uint32_t k, uint64_t pad_n, uint32_t n_parts,
+                  const int64_t *const *bufs, uint64_t *n_out, uint64_t *out_hashes, uint32_t *out_counts,
+                  uint32_t *out_extra, uint8_t *out_kmers, uint64_t *out_pos, uint64_t *total_kmers) {
+    if (!bufs || !n_out || !out_hashes || !out_counts || !out_extra || !out_kmers || !out_pos || k < 1 || k > 32 ||
+        (kind != FH_KIND_MASH && kind != FH_KIND_SCALED))
+        return fail(FH_ERR_INVALID, "bad argument");
+    const uint64_t kmw = (k + 7) / 8;
+    struct Part {
+        const uint64_t *h, *pos;
+        const int64_t *cnt, *ext;
+        const uint8_t *km;
+        uint64_t n, i;
+    };
+    std::vector<Part> parts(n_parts);
+    uint64_t tk = 0;
+    for (uint32_t p = 0; p < n_parts; ++p) {
+        const int64_t *b = bufs[p];
+        if (!b) return fail(FH_ERR_INVALID, "null partial");
+        const uint64_t n = (uint64_t)b[0];
+        if (n > pad_n) return fail(FH_ERR_INVALID, "partial sketch larger than its padding");
+        tk += (uint64_t)b[1];
+        const int64_t *q = b + 2;
+        parts[p] = Part{(const uint64_t *)q, (const uint64_t *)(q + 3 * pad_n), q + pad_n, q + 2 * pad_n,
+                        (const uint8_t *)(q + 4 * pad_n), n, 0};
+        for (uint64_t j = 1; j < n; ++j)
+            if (parts[p].h[j] <= parts[p].h[j - 1]) return fail(FH_ERR_INVALID, "merge: input not ascending");
+    }
+    const uint64_t max_hash = kind == FH_KIND_SCALED ? scaled_max_hash(scale) : 0;
+    uint64_t m = 0;
+    for (;;) {
+        // smallest head
+        bool any = false;
+        uint64_t hmin = 0;
+        for (const Part &pt : parts)
+            if (pt.i < pt.n && (!any || pt.h[pt.i] < hmin)) {
+                hmin = pt.h[pt.i];
+                any = true;
+            }
+        if (!any) break;
+        // (mash: nothing beyond the size-th distinct hash can be kept; scaled needs the count <= max_hash first)
+        if (kind == FH_KIND_MASH && m >= size) break;
+        uint64_t c = 0, e = 0, best_pos = 0;
+        const uint8_t *best_km = nullptr;
+        for (Part &pt : parts)
+            if (pt.i < pt.n && pt.h[pt.i] == hmin) {
+                c += (uint64_t)pt.cnt[pt.i];
+                e += (uint64_t)pt.ext[pt.i];
+                if (!best_km || pt.pos[pt.i] < best_pos) {
+                    best_pos = pt.pos[pt.i];
+                    best_km = pt.km + pt.i * kmw * 8;
+                }
+                ++pt.i;
+            }
+        out_hashes[m] = hmin;
+        out_counts[m] = (uint32_t)std::min<uint64_t>(c, UINT32_MAX);
+        out_extra[m] = (uint32_t)std::min<uint64_t>(e, UINT32_MAX);
+        memcpy(out_kmers + m * (size_t)k, best_km, k);
+        out_pos[m] = best_pos;
+        ++m;
+    }
+    if (kind == FH_KIND_SCALED) {
+        const uint64_t n_le = (uint64_t)(std::upper_bound(out_hashes, out_hashes + m, max_hash) - out_hashes);
+        m = std::max<uint64_t>(n_le, std::min<uint64_t>(m, size));
+    }
+    *n_out = m;
+    if (total_kmers) *total_kmers = tk;
+    return FH_OK;
+}
+
 int fh_merge(fh_sketcher *dst, const fh_sketcher *src) {
     if (!dst || !src) return fail(FH_ERR_INVALID, "null handle");
     if (!src->finished) return fail(FH_ERR_STATE, "fh_merge: src not finished");

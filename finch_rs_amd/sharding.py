@@ -89,6 +89,28 @@ def merge_partials(params: SketchParams, partials: List[tuple]):
     return kc, km, pos, tk
 
 
+def merge_wire(params: SketchParams, bufs: List[np.ndarray], pad_n: int):
+    """N packed partial sketches (pack_partial layout) -> merged (kc, km, pos, total_kmers) in one C call"""
+    L = _lib.load()
+    k = params.kmer_length
+    kind = {"mash": 0, "scaled": 1}[params.kind]
+    bufs = [np.ascontiguousarray(b, dtype=np.int64) for b in bufs]
+    cap = int(sum(int(b[0]) for b in bufs))
+    if params.kind == "mash":
+        cap = min(cap, params.kmers_to_sketch)
+    cap = max(cap, 1)
+    oh, oc, oe = np.empty(cap, np.uint64), np.empty(cap, np.uint32), np.empty(cap, np.uint32)
+    ok, op = np.empty((cap, k), np.uint8), np.empty(cap, np.uint64)
+    ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+    n_out, tk = C.c_uint64(), C.c_uint64()
+    check(L.fh_merge_wire(kind, params.kmers_to_sketch, params.scale, k, pad_n, len(bufs), ptrs, C.byref(n_out),
+                          oh.ctypes.data, oc.ctypes.data, oe.ctypes.data, ok.ctypes.data, op.ctypes.data, C.byref(tk)))
+    n = n_out.value
+    kc = np.empty(n, dtype=KC_DTYPE)
+    kc["hash"], kc["count"], kc["extra_count"] = oh[:n], oc[:n], oe[:n]
+    return kc, ok[:n], op[:n], int(tk.value)
+
+
 def gather_and_merge(dist, params: SketchParams, partial: tuple, pad_n: int, device=None):
     """rank 0 returns the merged sketch, the other ranks None.  `dist` = torch.distributed (any backend)."""
     import torch
@@ -102,5 +124,4 @@ def gather_and_merge(dist, params: SketchParams, partial: tuple, pad_n: int, dev
     dist.gather(t, outs, dst=0)
     if rank != 0:
         return None
-    parts = [unpack_partial(o.cpu().numpy(), pad_n, k) for o in outs]
-    return merge_partials(params, parts)
+    return merge_wire(params, [o.cpu().numpy() for o in outs], pad_n)

@@ -153,6 +153,16 @@ int fh_merge_partials(uint32_t kind, uint64_t size, double scale, uint32_t k, ui
                       const uint8_t *kmersB, const uint64_t *posB, uint64_t *n_out, uint64_t *out_hashes,
                       uint32_t *out_counts, uint32_t *out_extra, uint8_t *out_kmers, uint64_t *out_pos);
 
+/* N-way form over the sharding wire format (finch_rs_amd/sharding.py pack_partial; what the ranks of a sharded job
+ * gather on rank 0): one buffer of int64 words per partial sketch,
+ *   [0] n   [1] total_kmers   then, each padded to pad_n entries: hashes (u64), counts, extra_counts (as i64),
+ *   first positions (u64), k-mers (ASCII, ceil(k/8)*8 bytes each).
+ * out_* must hold the sum of the partial sizes (mash: `size` records are enough).  Same result as chaining
+ * fh_merge_partials. */
+int fh_merge_wire(uint32_t kind, uint64_t size, double scale, uint32_t k, uint64_t pad_n, uint32_t n_parts,
+                  const int64_t *const *bufs, uint64_t *n_out, uint64_t *out_hashes, uint32_t *out_counts,
+                  uint32_t *out_extra, uint8_t *out_kmers, uint64_t *out_pos, uint64_t *total_kmers);
+
 /* --- measurement support (bench.py) --- */
 /* when enabled, every sketch-kernel launch is bracketed by HIP events on the handle's stream */
 int fh_set_profiling(fh_sketcher *s, int enable);

@@ -101,3 +101,39 @@ def test_pack_unpack_roundtrip():
         p = SH.pack_partial(kc, km, pos, 123456789012, 64, k)
         kc2, km2, pos2, tk = SH.unpack_partial(p, 64, k)
         assert np.array_equal(kc, kc2) and np.array_equal(km, km2) and np.array_equal(pos, pos2) and tk == 123456789012
+
+
+@pytest.mark.parametrize("kind", ["mash", "scaled"])
+def test_kway_merge_equals_the_chain_of_pairwise_merges(kind):
+    """merge_wire (fh_merge_wire: one k-way pass over the packed partial sketches, what gather_and_merge uses) ==
+    merge_partials (pairwise fh_merge_partials): shared hashes, counts that saturate, equal hashes with different
+    k-mers (the smaller first position wins), empty partials, fewer than n hashes in total"""
+    from finch_rs_amd import sharding as SH
+    from finch_rs_amd.sketch_schemes import KC_DTYPE, SketchParams
+    rng = np.random.default_rng(99)
+    k = 21
+    for trial in range(12):
+        world = int(rng.integers(3, 9))
+        n = int(rng.choice([5, 200, 1000]))
+        params = SketchParams.mash(n, n, True, k, 0) if kind == "mash" else SketchParams.scaled(n, k, float(rng.choice([0.5, 0.01])), 0)
+        pool_h = np.unique(rng.integers(0, 2**64 - 1, 3 * n + 7, dtype=np.uint64) >> np.uint64(int(rng.choice([0, 4, 40]))))
+        pool_km = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(len(pool_h), k))
+        parts = []
+        for r in range(world):
+            m = int(rng.integers(0, min(n, len(pool_h)) + 1)) if trial % 4 else 0 if r == 0 else min(n, len(pool_h))
+            idx = np.sort(rng.choice(len(pool_h), size=m, replace=False))
+            kc = np.zeros(m, dtype=KC_DTYPE)
+            kc["hash"] = pool_h[idx]
+            kc["count"] = rng.choice(np.array([1, 2, 7, 2**31, 2**32 - 1], dtype=np.uint64), size=m).astype(np.uint32)
+            kc["extra_count"] = (kc["count"] // rng.integers(1, 4, m)).astype(np.uint32)
+            km = pool_km[idx].copy()
+            flip = rng.random(m) < 0.1          # a different k-mer under the same hash (64-bit collision across shards)
+            km[flip] = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(int(flip.sum()), k))
+            pos = rng.permutation(10_000_000)[:m].astype(np.uint64) + np.uint64(r * 10_000_000)
+            parts.append((kc, km, pos, int(rng.integers(0, 2**40))))
+        a = SH.merge_partials(params, parts)
+        pad = max(len(p[0]) for p in parts) + int(rng.integers(0, 5))
+        b = SH.merge_wire(params, [SH.pack_partial(p[0], p[1], p[2], p[3], pad, k) for p in parts], pad)
+        assert a[3] == b[3]
+        assert np.array_equal(a[0], b[0]), (trial, kind)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (trial, kind)
