@@ -108,6 +108,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "gloo" and os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            # one node: keep gloo off hostname resolution (the container's hostname may not resolve)
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
