@@ -205,12 +205,19 @@ struct ByteSource {
     virtual ~ByteSource() {}
     virtual size_t read(uint8_t *dst, size_t cap) = 0; // 0 = EOF
     virtual bool failed() const { return false; }
+    virtual bool can_rewind() const { return false; } // regular files, memory
+    virtual bool rewind() { return false; }           // back to the first byte
 };
 
 struct MemSource : ByteSource {
     const uint8_t *p;
     size_t n, off = 0;
     MemSource(const uint8_t *p_, size_t n_) : p(p_), n(n_) {}
+    bool can_rewind() const override { return true; }
+    bool rewind() override {
+        off = 0;
+        return true;
+    }
     size_t read(uint8_t *dst, size_t cap) override {
         const size_t m = std::min(cap, n - off);
         memcpy(dst, p + off, m);
@@ -227,6 +234,11 @@ struct FileSource : ByteSource {
         if (own && f) fclose(f);
     }
     size_t read(uint8_t *dst, size_t cap) override { return fread(dst, 1, cap, f); }
+    bool can_rewind() const override {
+        struct stat sb;
+        return own && f && fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode);
+    }
+    bool rewind() override { return can_rewind() && fseek(f, 0, SEEK_SET) == 0; }
 };
 
 // prepends already-consumed sniff bytes
@@ -242,6 +254,12 @@ struct PrefixedSource : ByteSource {
             return m;
         }
         return inner->read(dst, cap);
+    }
+    bool can_rewind() const override { return inner->can_rewind(); }
+    bool rewind() override {
+        if (!inner->rewind()) return false;
+        off = prefix.size(); // the inner source delivers the sniffed bytes itself again
+        return true;
     }
 };
 
@@ -900,18 +918,28 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     if (int rc = fh_reset(h)) return hfail(rc, "%s", fh_last_error());
     FastxStats st;
     const char *dp = getenv("FINCH_DEVICE_PARSE");
-    // FINCH_DEVICE_PARSE: unset = FASTA text is split on the device (any text is valid FASTA, nothing can fail there),
-    // FASTQ on the host (blank lines between records and other 4-line violations are the host parser's to judge);
-    // 1 = both on the device; 0 = both on the host.  Compressed input is always parsed where it is inflated.
+    // FINCH_DEVICE_PARSE: unset = plain FASTA and FASTQ text is split on the device (FASTQ with the host parser as the
+    // fallback, see below); 1 = on the device, no fallback; 0 = on the host.  Compressed input is always parsed where
+    // it is inflated.
     const bool dp_on = dp && dp[0] == '1', dp_off = dp && dp[0] == '0';
-    const bool device_parse = !is_gz && ((first == '>' && !dp_off) || (first == '@' && dp_on));
+    bool device_parse = !is_gz && !dp_off && (first == '>' || first == '@');
+    if (device_parse && first == '@' && !dp_on && !src->can_rewind()) device_parse = false; // no second chance: host parser
+    if (device_parse && first == '@') {
+        // FASTQ on the device has to be strictly 4-line.  Unless the caller insists (FINCH_DEVICE_PARSE=1: errors stay
+        // loud), a file the device pass rejects is read again through the host parser, which is the judge of what
+        // needletail accepts (blank lines between records, ...); sources that cannot rewind start on the host.
+        st.format = 2;
+        const int rc = fastq_text_to_device(*src, h);
+        if (rc != FH_OK) {
+            if (dp_on || rc != FH_ERR_INVALID || !src->rewind()) return rc;
+            if (int r2 = fh_reset(h)) return hfail(r2, "%s", fh_last_error());
+            device_parse = false;
+        }
+    }
     if (device_parse && first == '>') {
         st.format = 1;
         if (int rc = fasta_text_to_device(*src, h, st)) return rc;
-    } else if (device_parse) {
-        st.format = 2;
-        if (int rc = fastq_text_to_device(*src, h)) return rc;
-    } else {
+    } else if (!device_parse) {
         DeviceSink sink(h);
         if (int rc = parse_fastx(*src, sink, st)) return rc;
         if (int rc = sink.flush()) return rc;

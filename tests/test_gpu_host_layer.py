@@ -160,7 +160,7 @@ f = H.FilterParams(False)
 for name, data in [("lf", fq(b"\n")), ("crlf", fq(b"\r\n")), ("nolast", fq(b"\n", False)), ("varlen", fq(b"\n", True, True))]:
     path = os.path.join(sys.argv[1], name + ".fastq")
     open(path, "wb").write(data)
-    os.environ.pop("FINCH_DEVICE_PARSE", None)
+    os.environ["FINCH_DEVICE_PARSE"] = "0"
     a = H.sketch_files([path], p, f).sketch(0)
     os.environ["FINCH_DEVICE_PARSE"] = "1"
     b = H.sketch_files([path], p, f).sketch(0)
@@ -174,6 +174,28 @@ try:
     raise SystemExit("expected an error")
 except S.FinchError as e:
     assert "FASTQ" in str(e)
+# default mode (no FINCH_DEVICE_PARSE): the device pass is tried first and the same file falls back to the host parser
+blank = os.path.join(sys.argv[1], "blank.fastq")   # real reads, a blank line after every 7th record
+recs = fq(b"\n").split(b"\n@r")
+open(blank, "wb").write(b"\n@r".join(r + (b"\n" if i % 7 == 3 else b"") for i, r in enumerate(recs)))
+os.environ["FINCH_DEVICE_PARSE"] = "0"
+a = H.sketch_files([blank], p, f).sketch(0)
+os.environ.pop("FINCH_DEVICE_PARSE")
+b = H.sketch_files([blank], p, f).sketch(0)
+assert np.array_equal(a.arrays[0], b.arrays[0]) and (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers)
+os.environ["FINCH_DEVICE_PARSE"] = "1"
+try:
+    H.sketch_files([blank], p, f)
+    raise SystemExit("expected an error")
+except S.FinchError as e:
+    assert "FASTQ" in str(e)
+os.environ.pop("FINCH_DEVICE_PARSE")
+# ... and a well-formed file takes the device path by default with the host parser's result
+good = os.path.join(sys.argv[1], "lf.fastq")
+b = H.sketch_files([good], p, f).sketch(0)
+os.environ["FINCH_DEVICE_PARSE"] = "0"
+a = H.sketch_files([good], p, f).sketch(0)
+assert np.array_equal(a.arrays[0], b.arrays[0]) and (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers)
 print("child ok")
 '''
     for env in [{}, {"FH_STAGE_BYTES": "65536"}]:

@@ -17,15 +17,16 @@ with open(path, "wb") as f:
 size = os.path.getsize(path)
 print("wrote %.2f GB fastq in %.1fs" % (size / 1e9, time.time() - t))
 p = SketchParams.mash(1000, 1000, True, 21, 0)
+os.environ["FINCH_DEVICE_PARSE"] = "0"
 for rep in range(2):
     t = time.time(); res = H.sketch_files([path], p, H.FilterParams(False)); dt = time.time() - t
-    print("sketch_files fastq: %.2f s  %.2f GB/s text  %.1f Mbases/s" % (dt, size / dt / 1e9, n_reads * rl / dt / 1e6))
+    print("sketch_files fastq, host parser: %.2f s  %.2f GB/s text  %.1f Mbases/s" % (dt, size / dt / 1e9, n_reads * rl / dt / 1e6))
 os.environ["FINCH_DEVICE_PARSE"] = "1"
 for rep in range(2):
     t = time.time(); res2 = H.sketch_files([path], p, H.FilterParams(False)); dt = time.time() - t
     print("sketch_files fastq, device-side parsing: %.2f s  %.2f GB/s text  %.1f Mbases/s" % (dt, size / dt / 1e9, n_reads * rl / dt / 1e6))
 assert np.array_equal(res.sketch(0).arrays[0], res2.sketch(0).arrays[0])
-os.environ.pop("FINCH_DEVICE_PARSE")  # (FASTQ: the host parser is the default)
+os.environ.pop("FINCH_DEVICE_PARSE")
 # FASTA genome-like
 fa = "/tmp/e2e.fa"
 seq = S.synth_genome_host(200_000_000, 7).tobytes()
