@@ -236,16 +236,31 @@ FH_HD u32 bfe_u32(u32 x, u32 off, u32 width) {
 //                            (complement = 3 - c; reversing the order turns l-form into m-form)
 //   D  = digit-reversed    : base b at digit 63 - b; window j's forward m-form is bits [2(64-K-j), +2K) of D
 // canonical(): (fwd < rc) ? fwd : rc -- ties (even-k palindromes) report rc, as needletail's canonical_kmers.
+// The canonical word leaves here shifted left by pre_shift(K) bits (its low pre_shift bits are scrap): that puts every
+// 4-base group of the murmur3 key on a byte boundary of the word, and a byte of a register times the record size is ONE
+// instruction (v_lshlrev_b32_sdwa) where a bit field is a shift and a mask or a funnel shift and a mask.
+constexpr int pre_shift(int K) { return (8 - (2 * K) % 8) % 8; } // 2K + pre_shift <= 64 for every K <= 32
+
 template <int K>
 struct Windows {
+    static constexpr int PRE = pre_shift(K), NB = 2 * K + PRE;
     u32 nC[5], D[5];
 
     FH_HDM void init(u64 clo, u64 chi) {
-        nC[0] = ~(u32)clo;
-        nC[1] = ~(u32)(clo >> 32);
-        nC[2] = ~(u32)chi;
-        nC[3] = ~(u32)(chi >> 32);
-        nC[4] = 0;
+        const u32 c0 = ~(u32)clo, c1 = ~(u32)(clo >> 32), c2 = ~(u32)chi, c3 = ~(u32)(chi >> 32);
+        if (PRE == 0) {
+            nC[0] = c0;
+            nC[1] = c1;
+            nC[2] = c2;
+            nC[3] = c3;
+            nC[4] = 0;
+        } else { // the reverse-complement string is kept shifted left by PRE bits, so its windows start at >= 0
+            nC[0] = c0 << PRE;
+            nC[1] = alignbit_b32(c1, c0, 32 - PRE);
+            nC[2] = alignbit_b32(c2, c1, 32 - PRE);
+            nC[3] = alignbit_b32(c3, c2, 32 - PRE);
+            nC[4] = c3 >> (32 - PRE);
+        }
         const u64 rl = pairrev64(chi), rh = pairrev64(clo);
         D[0] = (u32)rl;
         D[1] = (u32)(rl >> 32);
@@ -253,9 +268,9 @@ struct Windows {
         D[3] = (u32)(rh >> 32);
         D[4] = 0;
     }
-    // bits [off, off + 2K) of the 128-bit string W (off, K compile-time after unrolling)
+    // bits [off, off + NB) of the string W (off, K compile-time after unrolling)
     static FH_HDM u64 field(const u32 *W, int off) {
-        const int w = off >> 5, s = off & 31, nbits = 2 * K;
+        const int w = off >> 5, s = off & 31, nbits = NB;
         u32 lo = s ? alignbit_b32(W[w + 1], W[w], (u32)s) : W[w];
         u32 hi = 0;
         if (nbits < 32) lo &= (1u << nbits) - 1u;
@@ -267,8 +282,10 @@ struct Windows {
         }
         return ((u64)hi << 32) | lo;
     }
-    FH_HDM u64 fwd(int j) const { return field(D, 2 * (64 - K - j)); }
-    FH_HDM u64 rc(int j) const { return field(nC, 2 * j); }
+    FH_HDM u64 fwd(int j) const { return field(D, 2 * (64 - K - j) - PRE); } // low PRE bits: scrap (later bases)
+    FH_HDM u64 rc(int j) const { return field(nC, 2 * j) & ~((1ULL << PRE) - 1ULL); }
+    // the canonical m-form word << PRE.  The reverse complement's scrap bits are cleared, the forward word's are
+    // not, so fwd' < rc' exactly when fwd < rc (equal words compare as "not less": the tie goes to rc, as it must)
     FH_HDM u64 canonical(int j, bool &is_rc) const {
         const u64 f = fwd(j), r = rc(j);
         is_rc = !(f < r);
@@ -460,8 +477,24 @@ struct KeyWords {
     u32 a0[N], a1[N], a2[N], b0[N], b1[N];
 };
 
-// byte offset ((cm >> shift) & (4^nb - 1)) << lg of a record
+// (byte `b` of x) << lg in one instruction
+FH_HD u32 byte_shl(u32 x, int b, int lg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 r;
+    const u32 amount = (u32)lg;
+    if (b == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "s"(amount), "v"(x));
+    else if (b == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "s"(amount), "v"(x));
+    else if (b == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "s"(amount), "v"(x));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "s"(amount), "v"(x));
+    return r;
+#else
+    return ((x >> (8 * b)) & 0xFFu) << lg;
+#endif
+}
+
+// byte offset ((cm >> shift) & (4^nb - 1)) << lg of a record; cm = canonical word << pre_shift(K), shift includes it
 FH_HD u32 field_off(u32 cml, u32 cmh, int shift, int nb, int lg) {
+    if (nb == 4 && (shift & 7) == 0) return byte_shl(shift < 32 ? cml : cmh, (shift >> 3) & 3, lg);
     const int sh = shift - lg;
     const u32 fm = ((1u << (2 * nb)) - 1u) << lg;
     if (sh >= 32) return (cmh >> (sh - 32)) & fm;
@@ -471,7 +504,8 @@ FH_HD u32 field_off(u32 cml, u32 cmh, int shift, int nb, int lg) {
 }
 
 template <int K>
-FH_HD void murmur_lookup(u64 cm, const LutTables &T, KeyWords<K> &w) {
+FH_HD void murmur_lookup(u64 cm, const LutTables &T, KeyWords<K> &w) { // cm = canonical word << pre_shift(K)
+    constexpr int PRE = pre_shift(K);
     const u32 cml = (u32)cm, cmh = (u32)(cm >> 32);
 #if defined(__HIPCC__)
 #pragma unroll
@@ -480,13 +514,13 @@ FH_HD void murmur_lookup(u64 cm, const LutTables &T, KeyWords<K> &w) {
         const WordGeom g = word_geom(K, i);
         w.a0[i] = w.a1[i] = w.a2[i] = w.b0[i] = w.b1[i] = 0;
         if (g.kind == 1) {
-            const Rec2 r = *(const Rec2 *)((const char *)T.P + field_off(cml, cmh, g.shiftA, g.nbA, 3));
+            const Rec2 r = *(const Rec2 *)((const char *)T.P + field_off(cml, cmh, g.shiftA + PRE, g.nbA, 3));
             w.a0[i] = r.x;
             w.a1[i] = r.y;
         } else if (g.kind == 2) {
-            const Rec4 ra = *(const Rec4 *)((const char *)(g.is_k2 ? T.A2 : T.A1) + field_off(cml, cmh, g.shiftA, 4, 4));
+            const Rec4 ra = *(const Rec4 *)((const char *)(g.is_k2 ? T.A2 : T.A1) + field_off(cml, cmh, g.shiftA + PRE, 4, 4));
             const Rec2 *TB = g.partial ? T.P : (g.is_k2 ? T.B2 : T.B1);
-            const Rec2 rb = *(const Rec2 *)((const char *)TB + field_off(cml, cmh, g.shiftB, g.nbB, 3));
+            const Rec2 rb = *(const Rec2 *)((const char *)TB + field_off(cml, cmh, g.shiftB + PRE, g.nbB, 3));
             w.a0[i] = ra.x;
             w.a1[i] = ra.y;
             w.a2[i] = ra.z;

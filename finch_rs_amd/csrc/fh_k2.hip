@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
                     const u32 my = qn + __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
                     if (take) {
                         queue->h[my] = h;
-                        queue->k[my] = cm;
+                        queue->k[my] = cm >> pre_shift(K); // the loop carries the canonical word pre-shifted (fh_core.h)
                         queue->p[my] = (a.base_pos + lane_pos0 + (u64)j) | ((u64)(is_rc ? 1u : 0u) << 63);
                     }
                     qn += cnt;

@@ -54,8 +54,8 @@ static int run(const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hashes
             const u64 cm = win.canonical(j, rc);
             valid[p] = (W >> j) & 1u;
             isrc[p] = rc ? 1 : 0;
-            canon[p] = cm;
-            const u64 h_ref = murmur_h1_lut<K>(cm, seed, T1.data(), T2.data(), TP.data());
+            canon[p] = cm >> pre_shift(K);
+            const u64 h_ref = murmur_h1_lut<K>(cm >> pre_shift(K), seed, T1.data(), T2.data(), TP.data());
             const u64 h_fast = murmur_h1_fast<K, false>(cm, seed, LT);
             if (h_fast != h_ref) return -2;
             if (seed == 0 && murmur_h1_fast<K, true>(cm, 0, LT) != h_ref) return -3;
