@@ -283,9 +283,14 @@ struct Windows {
         return ((u64)hi << 32) | lo;
     }
     FH_HDM u64 fwd(int j) const { return field(D, 2 * (64 - K - j) - PRE); } // low PRE bits: scrap (later bases)
-    FH_HDM u64 rc(int j) const { return field(nC, 2 * j) & ~((1ULL << PRE) - 1ULL); }
-    // the canonical m-form word << PRE.  The reverse complement's scrap bits are cleared, the forward word's are
-    // not, so fwd' < rc' exactly when fwd < rc (equal words compare as "not less": the tie goes to rc, as it must)
+    // A k-mer can equal its reverse complement only for even K.  There the reverse complement's scrap bits are cleared
+    // (the forward word's are not), so fwd' < rc' exactly when fwd < rc and equal words compare as "not less": the tie
+    // goes to rc, as it must.  For odd K the words differ above the scrap bits and the scrap cannot matter.
+    FH_HDM u64 rc(int j) const {
+        const u64 r = field(nC, 2 * j);
+        return (K % 2 == 0) ? (r & ~((1ULL << PRE) - 1ULL)) : r;
+    }
+    // the canonical m-form word << PRE
     FH_HDM u64 canonical(int j, bool &is_rc) const {
         const u64 f = fwd(j), r = rc(j);
         is_rc = !(f < r);
