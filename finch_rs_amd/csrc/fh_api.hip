@@ -248,13 +248,13 @@ uint32_t soft_limit_of(const fh_sketcher *s) {
 uint64_t next_range_size(const fh_sketcher *s, uint64_t remaining) {
     uint64_t P;
     if (s->open_loop) {
-        P = remaining;
+        P = ((remaining + TILE_POS - 1) / TILE_POS) * TILE_POS; // everything, incl. the last partial tile
     } else {
         const double room = (double)s->live_target - (double)std::min<uint64_t>(s->last_live, s->live_target);
         // small mode keeps half the room in reserve (the live set has to fit the in-LDS prune); in big mode the
         // soft-limit stop makes overshoot harmless, and halving the room every range cost 5-11 launches per prune
         double p = (s->big_mode ? 1.0 : 0.5) * room / admit_rate(s->last_tau);
-        P = p >= 1e18 ? remaining : (uint64_t)p;
+        P = p >= 1e18 ? remaining + TILE_POS : (uint64_t)p; // (rounded down below; capped at the rounded-up remainder)
     }
     if (s->max_range) P = std::min<uint64_t>(P, s->max_range);
     P = std::max<uint64_t>((P / TILE_POS) * TILE_POS, TILE_POS);
