@@ -1387,4 +1387,25 @@ int finch_fastx_scan(const uint8_t *data, uint64_t len, uint64_t *n_records, uin
     return FH_OK;
 }
 
+// The record / total_bases bookkeeping of the device-side FASTA path (FastaCounter), fed in chunks of `chunk` bytes cut
+// the way fasta_text_to_device cuts them: lets the host-only tests check it against finch_fastx_scan without a GPU.
+int finch_fasta_count_chunked(const uint8_t *data, uint64_t len, uint64_t chunk, uint64_t *n_records, uint64_t *total_bases) {
+    if ((!data && len) || chunk == 0) return hfail(FH_ERR_INVALID, "bad argument");
+    FastaCounter fc;
+    uint64_t off = 0;
+    while (off < len) {
+        uint64_t n = std::min<uint64_t>(chunk, len - off);
+        if (off + n < len) { // not the last chunk: cut after the last newline, if there is one
+            const void *nl = memrchr(data + off, '\n', (size_t)n);
+            if (nl) n = (uint64_t)((const uint8_t *)nl - (data + off)) + 1;
+        }
+        fc.feed(data + off, (size_t)n);
+        off += n;
+    }
+    fc.finish();
+    if (n_records) *n_records = fc.n_records;
+    if (total_bases) *total_bases = fc.total_bases;
+    return FH_OK;
+}
+
 } // extern "C"

@@ -80,6 +80,7 @@ _SYMS = {
     "finch_apply_filters": (C.c_int, [_P, C.c_uint32, C.POINTER(CFilterParams)]),
     "finch_guess_filter_threshold": (C.c_uint32, [_P, C.c_uint64, C.c_double]),
     "finch_fastx_scan": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "finch_fasta_count_chunked": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }
 class CDistance(C.Structure):
     _fields_ = [("containment", C.c_double), ("jaccard", C.c_double), ("mash_distance", C.c_double),
@@ -206,6 +207,14 @@ def fastx_scan(data: bytes):
     buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
     _check(lib().finch_fastx_scan(buf.ctypes.data, len(data), C.byref(n), C.byref(tb), C.byref(fmt)))
     return n.value, tb.value, fmt.value
+
+
+def fasta_count_chunked(data: bytes, chunk: int):
+    """(records, total_bases) as the device-side FASTA path counts them, text fed in `chunk`-byte pieces"""
+    n, tb = C.c_uint64(), C.c_uint64()
+    buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+    _check(lib().finch_fasta_count_chunked(buf.ctypes.data, len(data), chunk, C.byref(n), C.byref(tb)))
+    return n.value, tb.value
 
 
 def raw_distance(query_hashes, ref_hashes, scale: float = 0.0):

@@ -112,6 +112,10 @@ uint32_t finch_guess_filter_threshold(const uint32_t *counts, uint64_t n, double
  * the format of the first record (1 FASTA, 2 FASTQ).  gz images are inflated first. */
 int finch_fastx_scan(const uint8_t *data, uint64_t len, uint64_t *n_records, uint64_t *total_bases, int *format);
 
+/* Record count / total_bases exactly as the device-side FASTA path keeps them (the host reads raw text into the staging
+ * buffer in chunks cut after a newline and only locates the header lines); test hook: must agree with finch_fastx_scan. */
+int finch_fasta_count_chunked(const uint8_t *data, uint64_t len, uint64_t chunk, uint64_t *n_records, uint64_t *total_bases);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,3 +179,26 @@ def test_distance_between_sketches():
     j = 2. / 3.
     assert abs(d["mash_distance"] - (-math.log(2 * j / (1 + j)) / 2)) < 1e-15
     assert H.distance(a, 0, c, 0, old_mode=True)["common_hashes"] == 2
+
+
+def test_fasta_counter_of_the_device_path_agrees_with_the_parser():
+    """the device-side FASTA path counts records and total_bases on the host from the positions of the '>' bytes
+    (FastaCounter); whatever the chunking, it must report what parse_fastx reports: random FASTA-shaped text with
+    '>' inside lines, blank lines, CRLF, missing final newline, empty records, lines longer than a chunk"""
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGTACGTNacgt> \t\r-", dtype=np.uint8)
+    for case in range(300):
+        lines = []
+        for i in range(int(rng.choice([1, 3, 20, 200]))):
+            r = rng.random()
+            if i == 0 or r < 0.15:
+                lines.append(b">" + bytes(rng.choice(alpha, size=int(rng.integers(0, 30)))))
+            elif r < 0.22:
+                lines.append(b"")
+            else:
+                lines.append(bytes(rng.choice(alpha, size=int(rng.choice([1, 5, 60, 300])))))
+        eol = [b"\n", b"\r\n"][int(rng.integers(0, 2))]
+        data = eol.join(lines) + (eol if rng.random() < 0.6 else b"")
+        want = H.fastx_scan(data)[:2]
+        for chunk in (1, 7, 64, 4096, 1 << 20):
+            assert H.fasta_count_chunked(data, chunk) == want, (case, chunk, data[:80])
