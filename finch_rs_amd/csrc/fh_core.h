@@ -524,6 +524,13 @@ FH_HD void murmur_lookup(u64 cm, const LutTables &T, KeyWords<K> &w) { // cm = c
             w.a1[i] = r.y;
         } else if (g.kind == 2) {
             const Rec4 ra = *(const Rec4 *)((const char *)(g.is_k2 ? T.A2 : T.A1) + field_off(cml, cmh, g.shiftA + PRE, 4, 4));
+#if defined(__HIP_DEVICE_COMPILE__)
+            // A 16-byte LDS read costs 9.5 cycles per wave, the 12-byte read the compiler narrows this to costs 16
+            // (tools/ubench_lds.hip).  Keys with three or four two-group words (K >= 22: 6-8 lookups per position)
+            // are LDS-bound with the narrow reads, so the unused fourth dword is kept "live" there; K <= 21 is
+            // VALU-bound and has no register to spare for it.
+            if (K >= 22) asm volatile("" ::"v"(ra.w));
+#endif
             const Rec2 *TB = g.partial ? T.P : (g.is_k2 ? T.B2 : T.B1);
             const Rec2 rb = *(const Rec2 *)((const char *)TB + field_off(cml, cmh, g.shiftB + PRE, g.nbB, 3));
             w.a0[i] = ra.x;

@@ -151,13 +151,14 @@ __device__ __forceinline__ void classify_tile(const SketchArgs &a, u64 tile, int
 // ------------------------------------------------------------------------------------------------
 // K2
 // ------------------------------------------------------------------------------------------------
-// Register budget: the unrolled position loop of K <= 21 needs just under 128 VGPRs; telling the compiler to aim for
-// four waves per SIMD keeps it there (left alone it lands on 129-130 and loses a wave).  Larger K need 136-170
-// (three waves) and would spill under the same bound.
-#ifndef FH_MINW_KMAX
-#define FH_MINW_KMAX 21
+// Register budget: four waves per SIMD (<= 128 VGPRs) for every K.  K <= 21 needs just under that by itself (left
+// alone it lands on 129-137 and loses a wave).  K >= 22 would take 150-190 registers, but those kernels do 6-8 table
+// lookups per position and live off the LDS pipe, where a fourth wave is worth more than the 5-20 registers it makes
+// the compiler spill (measured k = 31: 373 Gbases/s unbounded at 2 waves, 427 at 3, 443 at 4, 272 at 5).
+#ifndef FH_MINW_BIG
+#define FH_MINW_BIG 4
 #endif
-constexpr int k2_min_waves(int K) { return K <= FH_MINW_KMAX ? 4 : 1; }
+constexpr int k2_min_waves(int K) { return K <= 21 ? 4 : FH_MINW_BIG; }
 template <int K, bool MASKED, bool SEED0, bool HASLO>
 __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchArgs a) {
     // murmur3 lookup tables with the second stage folded in (fh_core.h): A / B records of two-group key words,
