@@ -52,7 +52,7 @@ typedef struct fh_params {
     uint64_t size;        /* kmers_to_sketch */
     uint64_t seed;        /* hash_seed */
     double scale;         /* scaled only; max_hash = u64::MAX / ((1/scale) as u64) */
-    uint64_t max_launch;  /* 0 = default (8192 waves x 2048); max k-mer start positions in flight at once:
+    uint64_t max_launch;  /* 0 = default (16 M); max k-mer start positions in flight at once (bounds the launched waves):
                              bounds the grid and sizes the device table (table slots ~ 2 x (this + 4 x size)) */
     uint64_t hash_mask;   /* 0 = none (all bits); test hook: AND every hash with this mask (forces collisions) */
     uint64_t stage_bytes; /* 0 = default (64 MiB); size of each of the two pinned/device staging buffers of fh_push_block */

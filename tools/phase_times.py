@@ -17,6 +17,7 @@ ap.add_argument("--k", type=int, default=31)
 ap.add_argument("--n", type=int, default=2000000)
 ap.add_argument("--gbases", type=float, default=10.0)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--scale", type=float, default=0.0, help="> 0: a Scaled sketch (kmers_to_sketch = --n, this scale)")
 a = ap.parse_args()
 READ_LEN, GENOME_LEN, SEED = 150, 5_000_000, 20250620
 n_reads = int(np.ceil(a.gbases * 1e9 / READ_LEN))
@@ -25,7 +26,7 @@ dg = F.DeviceBuffer(GENOME_LEN)
 dr = F.DeviceBuffer(nbytes + 64)
 S.synth_genome_device(dg, GENOME_LEN, SEED)
 S.synth_reads_device(dr, dg, GENOME_LEN, 0, n_reads, READ_LEN, SEED, 10000, 500)
-sk = F.SketchParams.mash(a.n, a.n, True, a.k, 0).create_sketcher()
+sk = (F.SketchParams.scaled(a.n, a.k, a.scale, 0) if a.scale > 0 else F.SketchParams.mash(a.n, a.n, True, a.k, 0)).create_sketcher()
 for rep in range(a.reps):
     t = [time.perf_counter()]
     sk.reset(); sk.sync(); t.append(time.perf_counter())
