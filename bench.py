@@ -244,8 +244,13 @@ def main():
                                   else "configs[1] generator, non-default size/sketch", args.k, args.n),
                    "reads_per_gpu": n_reads, "parallelism": "read-block sharding x%d, host merge" % world},
         "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all,
+        # fingerprint of the final (merged) sketch: N ranks x G Gbase must give what one rank gives on N*G Gbase
         "sketch_check": {"n_hashes": int(len(gathered[0])), "min_hash": int(gathered[0]["hash"][0]) if len(gathered[0]) else None,
-                         "max_hash": int(gathered[0]["hash"][-1]) if len(gathered[0]) else None},
+                         "max_hash": int(gathered[0]["hash"][-1]) if len(gathered[0]) else None,
+                         "hash_xor": int(np.bitwise_xor.reduce(gathered[0]["hash"])) if len(gathered[0]) else 0,
+                         "count_sum": int(gathered[0]["count"].astype(np.uint64).sum()),
+                         "extra_sum": int(gathered[0]["extra_count"].astype(np.uint64).sum()),
+                         "kmer_byte_sum": int(gathered[1].astype(np.uint64).sum())},
     }
     print(json.dumps(out))
     if dist is not None:
