@@ -158,7 +158,10 @@ __device__ __forceinline__ void classify_tile(const SketchArgs &a, u64 tile, int
 #ifndef FH_MINW_BIG
 #define FH_MINW_BIG 4
 #endif
-constexpr int k2_min_waves(int K) { return K <= 21 ? 4 : FH_MINW_BIG; }
+#ifndef FH_MINW_SMALL
+#define FH_MINW_SMALL 4
+#endif
+constexpr int k2_min_waves(int K) { return K <= 21 ? FH_MINW_SMALL : FH_MINW_BIG; }
 template <int K, bool MASKED, bool SEED0, bool HASLO>
 __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchArgs a) {
     // murmur3 lookup tables with the second stage folded in (fh_core.h): A / B records of two-group key words,
