@@ -106,6 +106,7 @@ struct fh_sketcher {
         uint64_t len = 0, base_pos = 0, p_begin = 0, p_end = 0;
         uint32_t tiles_total = 0, n_units = 0, n_left_in = 0;
         int left_cur = 0;
+        double admit_at_start = 1.0; // admit rate the range started with (for the novelty estimate)
     } pend;
     uint32_t *left_buf[2] = {nullptr, nullptr}; // leftover tile ranges of a stopped launch (pairs)
     uint64_t max_waves = 0;
@@ -113,6 +114,10 @@ struct fh_sketcher {
     uint64_t tau_lo = 0;    // != 0 while a block is re-read for the hashes above a speculative threshold
     bool no_spec = false;   // test knob: disable the speculative first pass
     uint64_t n_spec = 0, n_spec_fallback = 0;
+    // observed novelty: new hashes per position over the last completed range (admitted occurrences of hashes that are
+    // already in the table cost time, but they do not fill it)
+    uint64_t ins_seen = 0;
+    double novelty = 1.0; // new hashes per ADMITTED occurrence, over the last completed range (1 = assume the worst)
     uint64_t n_launches = 0, n_relaunches = 0;
     // staging
     uint8_t *h_stage[N_STAGE] = {nullptr, nullptr};
@@ -189,6 +194,8 @@ int set_device(const fh_sketcher *s) {
 int init_state(fh_sketcher *s) {
     HIP_TRY(launch_init_ctl(s->ctl, initial_tau(s), s->stream));
     s->stream_off = 0;
+    s->ins_seen = 0;
+    s->novelty = 1.0;
     s->positions_done = 0;
     s->open_loop = false;
     s->last_tau = initial_tau(s);
@@ -212,6 +219,10 @@ int init_state(fh_sketcher *s) {
 }
 
 double admit_rate(uint64_t tau) { return tau == EMPTY64 ? 1.0 : ((double)tau + 1.0) / 18446744073709551616.0; }
+// expected new hashes per position: what fills the live set.  Occurrences of hashes already in the table are admitted
+// too, but only cost time; on low-diversity input (small k, deep coverage) they are nearly all there is, and sizing
+// ranges by the admit rate alone kept such streams in closed-loop mode for good (k = 11, 10 Gbase: 1400 ranges per pass).
+double fill_rate(const fh_sketcher *s) { return admit_rate(s->last_tau) * std::min(1.0, 2.0 * s->novelty); }
 
 // Warm-up is closed-loop: while the admit threshold is loose, a launch may insert up to one new hash
 // per position, so its size is chosen from the threshold read back after the previous launch such that
@@ -253,7 +264,8 @@ uint64_t next_range_size(const fh_sketcher *s, uint64_t remaining) {
         const double room = (double)s->live_target - (double)std::min<uint64_t>(s->last_live, s->live_target);
         // small mode keeps half the room in reserve (the live set has to fit the in-LDS prune); in big mode the
         // soft-limit stop makes overshoot harmless, and halving the room every range cost 5-11 launches per prune
-        double p = (s->big_mode ? 1.0 : 0.5) * room / admit_rate(s->last_tau);
+        const double fr = fill_rate(s);
+        double p = fr > 0.0 ? (s->big_mode ? 1.0 : 0.5) * room / fr : 1e19;
         P = p >= 1e18 ? remaining + TILE_POS : (uint64_t)p; // (rounded down below; capped at the rounded-up remainder)
     }
     if (s->max_range) P = std::min<uint64_t>(P, s->max_range);
@@ -358,6 +370,15 @@ int drain(fh_sketcher *s) {
             }
         }
         if (!remaining) {
+            // novelty of this range: new hashes per admitted occurrence (the threshold only went down while it ran, so
+            // dividing by the admit rate it started with errs low by at most the stops it had; a short or stopped
+            // range is not trusted to say "nothing new")
+            const uint64_t dpos = s->pend.p_end - s->pend.p_begin;
+            const uint64_t dins = c.inserted_total - s->ins_seen;
+            s->ins_seen = c.inserted_total;
+            const double expected = (double)dpos * std::max(0.0, s->pend.admit_at_start - (s->tau_lo ? admit_rate(s->tau_lo) : 0.0));
+            if (expected >= 200.0) s->novelty = std::min(1.0, (double)(dins + 1) / expected);
+            else if (dins) s->novelty = 1.0;
             s->pend.active = false;
             break;
         }
@@ -384,6 +405,7 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
     r.n_units = (uint32_t)((tiles + UNIT_TILES - 1) / UNIT_TILES);
     r.n_left_in = 0;
     r.left_cur = 0;
+    r.admit_at_start = admit_rate(s->last_tau);
     HIP_TRY(launch_queue_reset(s->ctl, 1u, soft_limit_of(s), s->stream));
     if (int rc = launch_pending(s)) return rc;
     r.active = true;
@@ -479,7 +501,7 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
             const double inflight = (double)(s->max_waves * TILE_POS);
             const double room = (double)s->live_target -
                                 (double)std::min<uint64_t>(std::max<uint64_t>(s->p.size, s->last_live), s->live_target);
-            if (s->positions_done > 0 && inflight * admit_rate(s->last_tau) <= 0.25 * room) s->open_loop = true;
+            if (s->positions_done > 0 && inflight * fill_rate(s) <= 0.25 * room) s->open_loop = true;
         }
         const uint64_t limit = s->tau_lo ? lo_end : n_pos;
         const uint64_t P = next_range_size(s, limit - pos);

@@ -322,10 +322,6 @@ FH_HD u32 window_valid_mask(u64 g64) {
     return (u32)W;
 }
 
-#ifndef FH_B128_KMIN
-#define FH_B128_KMIN 20 // keys from this length on read their A records 16 bytes wide (see murmur_lookup)
-#endif
-
 // ---- lookup tables with murmur3's second stage folded in ----
 // A key word x (8 key bytes: group A = low 4 bytes, group B = high 4 bytes, either possibly short) enters the
 // hash as  kx = rotl(x * c, R) * C  with (c, R, C) = (c1, 31, c2) for k1 words and (c2, 33, c1) for k2 words.
@@ -530,10 +526,9 @@ FH_HD void murmur_lookup(u64 cm, const LutTables &T, KeyWords<K> &w) { // cm = c
             const Rec4 ra = *(const Rec4 *)((const char *)(g.is_k2 ? T.A2 : T.A1) + field_off(cml, cmh, g.shiftA + PRE, 4, 4));
 #if defined(__HIP_DEVICE_COMPILE__)
             // A 16-byte LDS read costs 9.5 cycles per wave, the 12-byte read the compiler narrows this to costs 16
-            // (tools/ubench_lds.hip), so the unused fourth dword is kept "live".  Measured: k = 21 +2.7 %, k = 24 +12 %,
-            // k = 31 +10 % (those kernels are close to or at the LDS pipe's limit); k <= 19 nothing, the extra register
-            // costs as much as the read saves.
-            if (K >= FH_B128_KMIN) asm volatile("" ::"v"(ra.w));
+            // (tools/ubench_lds.hip), so the unused fourth dword is kept "live".  Measured: k = 14-16 +3 %, k = 21 +2.7 %,
+            // k = 24 +12 %, k = 31 +10 % (all of these kernels are close to the LDS pipe's limit).
+            asm volatile("" ::"v"(ra.w));
 #endif
             const Rec2 *TB = g.partial ? T.P : (g.is_k2 ? T.B2 : T.B1);
             const Rec2 rb = *(const Rec2 *)((const char *)TB + field_off(cml, cmh, g.shiftB + PRE, g.nbB, 3));

@@ -47,6 +47,7 @@ struct Ctl {
     // wave issues at its end does not serialise on a single L2 address (~12 ns per same-address atomic)
     uint64_t kmer_counts[256];
     uint64_t text_bases;    // sequence bytes emitted by the device-side FASTQ packer (fh_text.hip)
+    uint64_t inserted_total; // new hashes inserted since the last reset (k_live_commit adds each launch's appends)
     // where the table lives (read on the rare admit path only, so that the hot loop does not have to keep
     // these in scalar registers); written by the host whenever the table is (re)allocated
     Entry *table;

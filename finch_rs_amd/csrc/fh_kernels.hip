@@ -397,6 +397,7 @@ __global__ __launch_bounds__(256) void k_live_commit(Ctl *ctl) {
     __syncthreads();
     if (tid < (u32)N_SHARDS) ctl->shard_cnt[tid * SHARD_STRIDE] = 0;
     if (tid == 0 && s_tot) {
+        ctl->inserted_total += s_tot;
         u32 n = ctl->n_live + s_tot;
         if (n > ctl->live_cap) n = ctl->live_cap;
         ctl->n_live = n;
@@ -413,6 +414,7 @@ hipError_t launch_live_flatten(Ctl *ctl, hipStream_t st) {
 __global__ void k_init_ctl(Ctl *ctl, u64 tau0) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         ctl->tau = tau0;
+        ctl->inserted_total = 0;
         ctl->n_live = 0;
         ctl->overflow = 0;
         ctl->n_coll = 0;
