@@ -309,6 +309,27 @@ def test_speculation_on_the_prefix_of_a_large_first_block():
         buf.free()
 
 
+def test_low_diversity_stream_does_not_crawl_through_tiny_ranges():
+    """small k on a long stream: once every distinct k-mer is in the table each admitted occurrence is a duplicate, so
+    the live set stops growing; ranges must be sized from the observed novelty, not from the admit rate alone
+    (k = 8 used to take ~280 closed-loop launches per 32 M positions)"""
+    n = 1000
+    g = S.synth_genome_host(12_000_000, 31)
+    reads = S.synth_reads_host(g, 0, 470000, 150, 31, 10000, 500)  # ~70 M positions
+    assert len(reads) > (64 << 20)
+    buf = F.DeviceBuffer(len(reads) + 64)
+    buf.upload(reads)
+    for k in (7, 8, 11):
+        sk = F.SketchParams.mash(n, n, True, k, 0).create_sketcher()
+        sk.push_device(buf.ptr, len(reads))
+        ora = O.OracleSketcher(O.MASH, n, k, 0)
+        ora.process_packed(reads, 0)
+        assert_same(sk, ora, "low diversity k=%d" % k)
+        c = sk.debug_counters()
+        assert c["launches"] <= 40, (k, c)
+    buf.free()
+
+
 def test_select_prune_equals_sort_prune():
     """between launches large live sets are pruned by a radix select; FH_NO_SELECT=1 makes every prune the full
     sort that fh_finish uses.  Both must give the same sketch (run in a subprocess: the switch is read once)."""
