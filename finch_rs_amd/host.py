@@ -123,7 +123,7 @@ class Sketches:
         self._p, self.params = ptr, params
 
     def __del__(self):
-        if getattr(self, "_p", None):
+        if getattr(self, "_p", None) and lib is not None:  # module globals are gone at interpreter shutdown
             lib().finch_sketches_free(self._p)
             self._p = None
 
