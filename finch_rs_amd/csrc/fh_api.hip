@@ -222,6 +222,18 @@ double admit_rate(uint64_t tau) { return tau == EMPTY64 ? 1.0 : ((double)tau + 1
 // expected new hashes per position: what fills the live set.  Occurrences of hashes already in the table are admitted
 // too, but only cost time; on low-diversity input (small k, deep coverage) they are nearly all there is, and sizing
 // ranges by the admit rate alone kept such streams in closed-loop mode for good (k = 11, 10 Gbase: 1400 ranges per pass).
+// How the admit path of the next launch touches an entry (fh_k2.hip, upsert).  Reading it first turns the five
+// atomics of an occurrence whose hash is already in the table into three loads and one or two adds; the device
+// sustains ~25 G atomics/s but twice that in loads (tools/ubench_atomics.hip).  Measured per 10 Gbase pass
+// (bench.py, 8 steps, three runs each): k = 31, n = 2 M 57.7 -> 54.3 ms; k = 21, n = 200 000 20.8 -> 20.2 ms; Scaled
+// 0.008 24.5 -> 24.2 ms; nothing to gain or lose at n = 1000.  The exception is a stream whose admitted occurrences
+// all land on a handful of hot entries (k = 8: 1000 entries take 3 % of all positions): there the loads queue behind
+// the atomics on the same lines (103 -> 112 ms) and the launch keeps the plain form; the observed novelty tells.
+uint32_t read_first_of(const fh_sketcher *s) {
+    if (const char *e = getenv("FH_READ_FIRST")) return atoi(e) ? 1u : 0u; // A/B and tests: 0 = never, 1 = always
+    return s->novelty >= 0.02 ? 1u : 0u;
+}
+
 double fill_rate(const fh_sketcher *s) { return admit_rate(s->last_tau) * std::min(1.0, 2.0 * s->novelty); }
 
 // Warm-up is closed-loop: while the admit threshold is loose, a launch may insert up to one new hash
@@ -384,7 +396,7 @@ int drain(fh_sketcher *s) {
         }
         s->pend.n_left_in = c.n_left_out;
         s->pend.left_cur ^= 1;
-        HIP_TRY(launch_queue_reset(s->ctl, 0u, soft_limit_of(s), s->stream));
+        HIP_TRY(launch_queue_reset(s->ctl, 0u, soft_limit_of(s), read_first_of(s), s->stream));
         s->n_relaunches++;
         if (int rc = launch_pending(s)) return rc;
     }
@@ -406,7 +418,7 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
     r.n_left_in = 0;
     r.left_cur = 0;
     r.admit_at_start = admit_rate(s->last_tau);
-    HIP_TRY(launch_queue_reset(s->ctl, 1u, soft_limit_of(s), s->stream));
+    HIP_TRY(launch_queue_reset(s->ctl, 1u, soft_limit_of(s), read_first_of(s), s->stream));
     if (int rc = launch_pending(s)) return rc;
     r.active = true;
     if (s->profiling) s->prof_positions += end - pos;
@@ -626,14 +638,15 @@ int ensure_out(fh_sketcher *s, uint32_t n) {
 uint32_t sat_add(uint32_t a, uint32_t b);
 
 // Large sketches (kmers_to_sketch in the millions: the CLI's oversketch x200) make the per-record host loops of
-// fh_copy_out tens of MB of decode work; split it over a few threads (2 M records, k = 31: 21 -> 11 ms with four;
-// the plain gather loop in fh_finish got slower with threads and stays inline).  Small sketches run inline.
+// fh_copy_out tens of MB of decode work; split it over a few threads (2 M records, k = 31: 7.7 ms with two, 3.9 with
+// four, 2.1 with eight, 1.3 with sixteen; the plain gather loop in fh_finish got slower with threads and stays
+// inline).  Sketches below 128 k records run inline.
 template <class F>
 void parallel_for(size_t n, F f) {
     const size_t MIN_PER_THREAD = 1u << 16;
     static const unsigned cap = [] {
         const char *e = getenv("FH_HOST_THREADS"); // 1 = always inline
-        const unsigned v = e ? (unsigned)atoi(e) : 4u;
+        const unsigned v = e ? (unsigned)atoi(e) : 8u;
         return v ? v : 1u;
     }();
     unsigned hw = std::thread::hardware_concurrency();
@@ -1380,6 +1393,27 @@ int fh_copy_out(fh_sketcher *s, uint64_t *hashes, uint32_t *counts, uint32_t *ex
             for (size_t i = lo; i < hi; ++i) kmer_ascii(kk[i], k, kmers + i * (size_t)k);
     });
     return FH_OK;
+}
+
+int fh_copy_out_records(fh_sketcher *s, fh_kmer_count *records, uint8_t *kmers, uint64_t *first_pos) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (!s->finished) return fail(FH_ERR_STATE, "fh_copy_out before fh_finish");
+    if (records) {
+        if (s->res_built) {
+            const ResultRec *res = s->res.data();
+            parallel_for(s->res.size(), [=](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) records[i] = fh_kmer_count{res[i].hash, res[i].count, res[i].extra};
+            });
+        } else {
+            const uint64_t *hh = s->r_hash;
+            const uint32_t *cc = s->r_count, *ee = s->r_extra;
+            parallel_for(s->r_n, [=](size_t lo, size_t hi) {
+                for (size_t i = lo; i < hi; ++i) records[i] = fh_kmer_count{hh[i], cc[i], ee[i]};
+            });
+        }
+    }
+    if (!kmers && !first_pos) return FH_OK;
+    return fh_copy_out(s, nullptr, nullptr, nullptr, kmers, first_pos);
 }
 
 int fh_merge_arrays(fh_sketcher *dst, uint64_t n, const uint64_t *hashes, const uint32_t *counts,

@@ -40,7 +40,7 @@ struct Ctl {
     uint32_t left_in_pos;   // next unread entry of the leftover list handed to this launch
     uint32_t n_left_out;    // leftover tile ranges recorded by waves that stopped mid-chunk
     uint32_t soft_limit;    // the inserter that takes n_live to this value raises `stopped`
-    uint32_t pad2;
+    uint32_t read_first;    // admit path of this launch reads an entry before it issues atomics on it (fh_k2.hip, upsert)
     // the one hash value that cannot be a table key (== EMPTY64)
     uint64_t sp_count, sp_extra, sp_pos, sp_kmer;
     // number of valid k-mer windows seen (mash.rs:35), spread over many words so that the one atomic each

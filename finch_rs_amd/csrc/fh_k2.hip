@@ -75,8 +75,27 @@ __device__ __noinline__ u32 upsert(Ctl *ctl, u64 h, u64 kmer, u64 pos, u32 stran
     u32 slot = (u32)(((u64)key32 * (u64)a.cap) >> 32);
     int probe = 0;
     u32 inserted = 0u;
+    // The device sustains ~25 G 64-bit atomics/s whatever the table size, but 50-100 G loads/s
+    // (tools/ubench_atomics.hip), and an admitted occurrence is nearly always one of a hash that is already in the
+    // table with its k-mer and an earlier first position.  Unless the stream keeps hitting a few hot entries
+    // (ctl->read_first, chosen by the host per launch: fh_api.hip, read_first_of) the entry is therefore *read*
+    // first (key, k-mer, position in one round trip; agent-scope loads, the atomics of other XCDs are visible to
+    // them) and an atomic is only issued where the value read says it could change something.  Stale reads are harmless: keys and k-mers go
+    // EMPTY -> value once per launch and positions only decrease, so "already there" / "already smaller" stay true.
+    const bool read_first = ctl->read_first != 0u; // wave-uniform
+    ull seen_kmer = EMPTY64, seen_pos = EMPTY64;
     for (; probe < MAX_PROBE; ++probe) {
-        ull old = atomicCAS((ull *)&a.table[slot].hash, (ull)EMPTY64, (ull)h);
+        Entry *e = &a.table[slot];
+        ull old = EMPTY64;
+        if (read_first) {
+            old = __hip_atomic_load((ull *)&e->hash, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen_kmer = __hip_atomic_load((ull *)&e->kmer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen_pos = __hip_atomic_load((ull *)&e->pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (old == EMPTY64) {
+            old = atomicCAS((ull *)&e->hash, (ull)EMPTY64, (ull)h);
+            seen_kmer = seen_pos = EMPTY64; // whoever owns the slot now: what was read belongs to nobody
+        }
         if (old == EMPTY64) {
             // remember the slot: append to this wave's shard list (flattened into `live` after the launch)
             const u32 idx = atomicAdd(&ctl->shard_cnt[shard * (u32)SHARD_STRIDE], 1u);
@@ -96,8 +115,9 @@ __device__ __noinline__ u32 upsert(Ctl *ctl, u64 h, u64 kmer, u64 pos, u32 stran
     Entry *e = &a.table[slot];
     atomicAdd((ull *)&e->count, 1ull);
     if (strand) atomicAdd((ull *)&e->extra, 1ull);
-    atomicMin((ull *)&e->pos, (ull)pos);
-    ull oldk = atomicCAS((ull *)&e->kmer, (ull)EMPTY64, (ull)kmer);
+    if (seen_pos > (ull)pos) atomicMin((ull *)&e->pos, (ull)pos);
+    ull oldk = seen_kmer;
+    if (oldk == EMPTY64) oldk = atomicCAS((ull *)&e->kmer, (ull)EMPTY64, (ull)kmer);
     if (oldk != EMPTY64 && oldk != kmer) log_collision(a, h, kmer, pos);
     return inserted;
 }

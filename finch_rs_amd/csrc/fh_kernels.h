@@ -45,7 +45,7 @@ hipError_t launch_set_tau(Ctl *ctl, uint64_t tau, hipStream_t st);
 hipError_t launch_set_table(Ctl *ctl, Entry *table, uint32_t *live, CollRec *clog, uint32_t cap, uint32_t live_cap,
                             uint32_t clog_cap, uint32_t *shard_cnt, uint32_t *shard_buf, uint32_t shard_cap, hipStream_t st);
 hipError_t launch_live_flatten(Ctl *ctl, hipStream_t st);
-hipError_t launch_queue_reset(Ctl *ctl, uint32_t new_range, uint32_t soft_limit, hipStream_t st);
+hipError_t launch_queue_reset(Ctl *ctl, uint32_t new_range, uint32_t soft_limit, uint32_t read_first, hipStream_t st);
 hipError_t launch_read_probe(const void *p, uint64_t bytes, uint32_t *sink, hipStream_t st);
 hipError_t launch_synth_genome(uint8_t *out, uint64_t len, uint64_t seed, hipStream_t st);
 hipError_t launch_synth_reads(uint8_t *out, const uint8_t *genome, uint64_t genome_len, uint64_t first_read,

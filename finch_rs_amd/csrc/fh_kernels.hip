@@ -429,7 +429,7 @@ __global__ void k_init_ctl(Ctl *ctl, u64 tau0) {
         ctl->stopped = 0;
         ctl->soft_limit = 0xFFFFFFFFu;
         ctl->shard_soft = 0xFFFFFFFFu;
-        ctl->pad2 = 0;
+        ctl->read_first = 0;
         ctl->sp_count = 0;
         ctl->sp_extra = 0;
         ctl->sp_pos = EMPTY64;
@@ -440,12 +440,13 @@ __global__ void k_init_ctl(Ctl *ctl, u64 tau0) {
 }
 
 // new range: empty queue; relaunch of a stopped range: keep next_chunk, swap leftover lists
-__global__ void k_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit) {
+__global__ void k_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, u32 read_first) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (new_range) ctl->next_unit = 0;
         ctl->left_in_pos = 0;
         ctl->n_left_out = 0;
         ctl->soft_limit = soft_limit;
+        ctl->read_first = read_first;
         // inserts are spread over N_SHARDS lists: stop when one of them has taken its share of the room
         const u32 nl = ctl->n_live;
         const u32 room = soft_limit > nl ? soft_limit - nl : 0u;
@@ -456,8 +457,8 @@ __global__ void k_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit) {
     }
 }
 
-hipError_t launch_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, hipStream_t st) {
-    hipLaunchKernelGGL(k_queue_reset, dim3(1), dim3(64), 0, st, ctl, new_range, soft_limit);
+hipError_t launch_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, u32 read_first, hipStream_t st) {
+    hipLaunchKernelGGL(k_queue_reset, dim3(1), dim3(64), 0, st, ctl, new_range, soft_limit, read_first);
     return hipGetLastError();
 }
 

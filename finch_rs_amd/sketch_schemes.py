@@ -140,16 +140,11 @@ class HipSketcher:
     def to_arrays(self):
         """-> (structured [hash,count,extra_count], kmers uint8 [n,k], first_pos uint64 [n]) ascending by hash"""
         n, _ = self.finish()
-        hs = np.empty(n, dtype=np.uint64)
-        cs = np.empty(n, dtype=np.uint32)
-        es = np.empty(n, dtype=np.uint32)
+        kc = np.empty(n, dtype=KC_DTYPE)  # = struct fh_kmer_count
         km = np.empty((n, self.kmer_length), dtype=np.uint8)
         ps = np.empty(n, dtype=np.uint64)
-        check(self._L.fh_copy_out(self._h, hs.ctypes.data_as(C.c_void_p), cs.ctypes.data_as(C.c_void_p),
-                                  es.ctypes.data_as(C.c_void_p), km.ctypes.data_as(C.c_void_p),
-                                  ps.ctypes.data_as(C.c_void_p)))
-        kc = np.empty(n, dtype=KC_DTYPE)
-        kc["hash"], kc["count"], kc["extra_count"] = hs, cs, es
+        check(self._L.fh_copy_out_records(self._h, kc.ctypes.data_as(C.c_void_p), km.ctypes.data_as(C.c_void_p),
+                                          ps.ctypes.data_as(C.c_void_p)))
         return kc, km, ps
 
     def to_vec(self) -> List[KmerCount]:

@@ -134,6 +134,15 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers);
  * (uppercase canonical k-mer of the first occurrence).  first_pos = stream coordinate of that occurrence. */
 int fh_copy_out(fh_sketcher *s, uint64_t *hashes, uint32_t *counts, uint32_t *extra_counts, uint8_t *kmers,
                 uint64_t *first_pos);
+/* The same with (hash, count, extra_count) interleaved as the reference's KmerCount holds them
+ * (sketch_schemes/mod.rs:16-22, minus the k-mer bytes, which go to `kmers` as above): to_vec() fills its
+ * Vec<KmerCount> from one array.  Any pointer may be NULL. */
+typedef struct fh_kmer_count {
+    uint64_t hash;
+    uint32_t count;
+    uint32_t extra_count;
+} fh_kmer_count;
+int fh_copy_out_records(fh_sketcher *s, fh_kmer_count *records, uint8_t *kmers, uint64_t *first_pos);
 
 /* Host-side merge of partial sketches (multi-GPU read-block sharding): union, counts
  * summed (saturating), k-mer of the smallest first_pos, re-select per kind.  Both must be finished.

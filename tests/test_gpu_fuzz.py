@@ -58,6 +58,18 @@ def test_random_configuration(case):
               else F.SketchParams.scaled(size, k, scale, seed))
     sk = params.create_sketcher(max_launch=inflight, stage_bytes=int(rng.choice([0, 8192, 70000])))
     L = _lib.load()
+    # admit path: chosen per launch by the library (None), or forced to read entries first / to plain atomics
+    form = [None, "1", "0"][case % 3]
+    os.environ.pop("FH_READ_FIRST", None)
+    if form is not None:
+        os.environ["FH_READ_FIRST"] = form
+    try:
+        _run_case(rng, sk, L, recs, kind, size, k, seed, scale, case, inflight, n_rec)
+    finally:
+        os.environ.pop("FH_READ_FIRST", None)
+
+
+def _run_case(rng, sk, L, recs, kind, size, k, seed, scale, case, inflight, n_rec):
     for rep in range(2):  # second round re-uses the handle after reset
         ora = O.OracleSketcher(O.MASH if kind == "mash" else O.SCALED, size, k, seed, scale)
         for r in recs:

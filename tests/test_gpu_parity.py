@@ -330,6 +330,32 @@ def test_low_diversity_stream_does_not_crawl_through_tiny_ranges():
     buf.free()
 
 
+def test_copy_out_forms_agree():
+    """fh_copy_out (separate arrays) and fh_copy_out_records (KmerCount-shaped records) return the same sketch,
+    inline (small) and threaded (>= 128 k records), before and after a merge"""
+    import ctypes as C
+    g = S.synth_genome_host(3_000_000, 77)
+    for n in (500, 300_000):
+        sk = F.SketchParams.mash(n, n, True, 21, 0).create_sketcher()
+        sk.push_block(g)
+        other = F.SketchParams.mash(n, n, True, 21, 0).create_sketcher()
+        other.push_block(S.synth_genome_host(1_000_000, 78))
+        other.finish()
+        for merged in (False, True):
+            if merged:
+                sk.merge(other)
+            kc, km, ps = sk.to_arrays()
+            m = len(kc)
+            assert m == n
+            hs, cs, es = np.zeros(m, np.uint64), np.zeros(m, np.uint32), np.zeros(m, np.uint32)
+            km2, ps2 = np.zeros((m, 21), np.uint8), np.zeros(m, np.uint64)
+            P = lambda a: a.ctypes.data_as(C.c_void_p)
+            S.check(sk._L.fh_copy_out(sk._h, P(hs), P(cs), P(es), P(km2), P(ps2)))
+            assert (kc["hash"] == hs).all() and (kc["count"] == cs).all() and (kc["extra_count"] == es).all()
+            assert (km == km2).all() and (ps == ps2).all()
+            assert (np.diff(hs.astype(np.float64)) > 0).all()
+
+
 def test_select_prune_equals_sort_prune():
     """between launches large live sets are pruned by a radix select; FH_NO_SELECT=1 makes every prune the full
     sort that fh_finish uses.  Both must give the same sketch (run in a subprocess: the switch is read once)."""
