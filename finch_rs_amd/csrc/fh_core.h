@@ -165,17 +165,12 @@ FH_HD u64 murmur_h1_lut(u64 cm, u64 seed, const u64 *T1, const u64 *T2, const u6
         const GroupGeom gg = group_geom(K, g);
         u32 q = (u32)(cm >> gg.shift) & ((1u << (2 * gg.nb)) - 1u);
         const u64 *T = (gg.nb == 4) ? (gg.is_k2 ? T2 : T1) : TP;
-#if defined(FH_ABL_NOLDS)
-        (void)T;
-        wc[gg.word] += gg.hi ? ((u64)q << 32) : (u64)q * 0x9E3779B1ull; // ablation: no table lookups
-#else
         if (gg.hi) {
             u32 plo = ((const u32 *)T)[2 * q]; // low dword of the 64-bit entry (little endian)
             wc[gg.word] += (u64)plo << 32;
         } else {
             wc[gg.word] += T[q];
         }
-#endif
     }
     u64 h1 = seed, h2 = seed;
 #if defined(__HIPCC__)

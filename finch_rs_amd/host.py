@@ -81,6 +81,7 @@ _SYMS = {
     "finch_guess_filter_threshold": (C.c_uint32, [_P, C.c_uint64, C.c_double]),
     "finch_fastx_scan": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "finch_fasta_count_chunked": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "finch_read_file_probe": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
 }
 class CDistance(C.Structure):
     _fields_ = [("containment", C.c_double), ("jaccard", C.c_double), ("mash_distance", C.c_double),
@@ -215,6 +216,14 @@ def fasta_count_chunked(data: bytes, chunk: int):
     buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
     _check(lib().finch_fasta_count_chunked(buf.ctypes.data, len(data), chunk, C.byref(n), C.byref(tb)))
     return n.value, tb.value
+
+
+def read_file_probe(path: str, chunk: int, read_threads: int, cap: int) -> bytes:
+    """the bytes the text paths get from a plain file read in `chunk`-byte requests (test hook)"""
+    buf = np.zeros(max(cap, 1), np.uint8)
+    got = C.c_uint64()
+    _check(lib().finch_read_file_probe(path.encode(), chunk, read_threads, buf.ctypes.data, cap, C.byref(got)))
+    return buf[:got.value].tobytes()
 
 
 def raw_distance(query_hashes, ref_hashes, scale: float = 0.0):

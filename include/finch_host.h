@@ -116,6 +116,10 @@ int finch_fastx_scan(const uint8_t *data, uint64_t len, uint64_t *n_records, uin
  * buffer in chunks cut after a newline and only locates the header lines); test hook: must agree with finch_fastx_scan. */
 int finch_fasta_count_chunked(const uint8_t *data, uint64_t len, uint64_t chunk, uint64_t *n_records, uint64_t *total_bases);
 
+/* Test hook: read `path` the way the text paths read plain files (requests of `chunk` bytes; requests of >= 16 MiB on
+ * a regular file are split over `read_threads` threads) into dst[0, cap); *got = bytes delivered. */
+int finch_read_file_probe(const char *path, uint64_t chunk, uint32_t read_threads, uint8_t *dst, uint64_t cap, uint64_t *got);
+
 #ifdef __cplusplus
 }
 #endif

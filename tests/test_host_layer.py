@@ -202,3 +202,17 @@ def test_fasta_counter_of_the_device_path_agrees_with_the_parser():
         want = H.fastx_scan(data)[:2]
         for chunk in (1, 7, 64, 4096, 1 << 20):
             assert H.fasta_count_chunked(data, chunk) == want, (case, chunk, data[:80])
+
+
+def test_large_reads_split_over_threads_deliver_the_file(tmp_path):
+    """FileSource::read splits requests of >= 16 MiB on a regular file over threads (pread); whatever the request
+    size, thread count or file length, the bytes and their order are the file's, short tails and a rewind included"""
+    rng = np.random.default_rng(5)
+    M = 1 << 20
+    for size in (0, 1, 2, 3 * M + 17, 16 * M, 16 * M + 2, 37 * M + 4099):
+        data = rng.integers(0, 256, size=size, dtype=np.uint8).tobytes()
+        p = tmp_path / ("f%d.bin" % size)
+        p.write_bytes(data)
+        for chunk, thr in ((64 * M, 4), (16 * M, 3), (17 * M + 5, 8), (1 * M, 4), (64 * M, 1)):
+            got = H.read_file_probe(str(p), chunk, thr, size + 4096)
+            assert got == data, (size, chunk, thr, len(got))
