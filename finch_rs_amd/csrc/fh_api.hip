@@ -372,6 +372,11 @@ int drain(fh_sketcher *s) {
             fprintf(stderr, "[fh] launch %llu: units %u/%u left_in %u left_out %u n_live %u stopped %u tau %.3e soft %u\n",
                     (unsigned long long)s->n_launches, c.next_unit, s->pend.n_units, s->pend.n_left_in, c.n_left_out,
                     c.n_live, c.stopped, (double)c.tau, soft_limit_of(s));
+        if (trace && c.dbg_wave_cycles)
+            fprintf(stderr, "[fh]   (cumulative) flush: %.3g wave-cycles in %llu calls, %llu entries; waves alive %.3g cycles => %.1f %% of wave time, %.0f cycles per call\n",
+                    (double)c.dbg_flush_cycles, (unsigned long long)c.dbg_flush_calls, (unsigned long long)c.dbg_flush_entries,
+                    (double)c.dbg_wave_cycles, 100.0 * (double)c.dbg_flush_cycles / (double)c.dbg_wave_cycles,
+                    (double)c.dbg_flush_cycles / (double)std::max<uint64_t>(c.dbg_flush_calls, 1));
         if (c.need_big || (s->big_mode && 2 * (uint64_t)c.n_live >= s->live_target) ||
             (remaining && c.n_live >= soft_limit_of(s) / 2)) {
             if (s->big_mode || c.need_big || c.n_live > (uint32_t)SMALL_MAX) {

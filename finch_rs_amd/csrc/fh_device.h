@@ -19,8 +19,9 @@ struct Entry {          // 40 B
     uint64_t hash;      // EMPTY64 = free slot
     uint64_t kmer;      // m-form canonical k-mer, EMPTY64 until claimed
     uint64_t pos;       // smallest stream position of an occurrence (atomicMin)
-    uint64_t count;     // occurrences            (clamped to u32::MAX on output, mash.rs:46-49)
-    uint64_t extra;     // occurrences on the rc strand
+    uint64_t count;     // occurrences whose canonical k-mer is the forward window   } one atomic add per occurrence;
+    uint64_t extra;     // occurrences whose canonical k-mer is the reverse complement } output: count = sum, extra_count
+                        // = extra, each clamped to u32::MAX (mash.rs:46-49)
 };
 
 struct CollRec {        // an occurrence whose k-mer differs from the slot's k-mer (64-bit hash collision)
@@ -70,6 +71,8 @@ struct Ctl {
     uint32_t pad4[31];
     uint32_t stopped;       // raised when the live set reaches soft_limit (or a wave exhausts its budget)
     uint32_t pad5[31];
+    // -DFH_PROFILE_FLUSH builds only: wave-cycles spent inside flush_queue, number of flushes, entries flushed
+    uint64_t dbg_flush_cycles, dbg_flush_calls, dbg_flush_entries, dbg_wave_cycles;
 };
 
 constexpr int TILE_POS = 2048;   // k-mer start positions per wavefront tile (64 lanes x 32)

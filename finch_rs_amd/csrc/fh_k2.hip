@@ -59,9 +59,41 @@ __device__ __forceinline__ void log_collision(const TableRef a, u64 h, u64 kmer,
     }
 }
 
-__device__ __noinline__ u32 upsert(Ctl *ctl, u64 h, u64 kmer, u64 pos, u32 strand, u32 shard) {
-    typedef unsigned long long ull;
-    const TableRef a{ctl->table, ctl->live, ctl, ctl->clog, ctl->cap, ctl->live_cap, ctl->clog_cap};
+// a wave-uniform pointer that arrives in vector registers (arguments of a noinline function do): telling the
+// compiler so turns the loads through it into scalar loads and the accesses behind it into global_* with a scalar
+// base instead of flat_* instructions
+template <class T>
+__device__ __forceinline__ T *uniform_ptr(T *p) {
+    const u64 v = (u64)p;
+    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)v), hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32));
+    return (T *)(((u64)hi << 32) | lo);
+}
+
+// The table and the control block are global memory, but the pointers to them come out of memory / vector registers
+// and would be treated as generic: spelled out, the entry accesses are global_* instead of flat_* instructions.
+#define FH_GLOBAL __attribute__((address_space(1)))
+typedef unsigned long long ull;
+typedef FH_GLOBAL ull gull;
+__device__ __forceinline__ ull g_load(const ull *p) {
+    return __hip_atomic_load((const gull *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ ull g_cas(ull *p, ull expected, ull desired) {
+    __hip_atomic_compare_exchange_strong((gull *)p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+    return expected;
+}
+__device__ __forceinline__ void g_add(ull *p, ull v) {
+    (void)__hip_atomic_fetch_add((gull *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void g_min(ull *p, ull v) {
+    (void)__hip_atomic_fetch_min((gull *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __noinline__ u32 upsert(Ctl *ctl_v, u64 h, u64 kmer, u64 pos, u32 strand, u32 shard_v) {
+    Ctl *ctl = uniform_ptr(ctl_v);
+    const FH_GLOBAL Ctl *gctl = (const FH_GLOBAL Ctl *)ctl;
+    const u32 shard = (u32)__builtin_amdgcn_readfirstlane((int)shard_v);
+    const TableRef a{gctl->table, gctl->live, ctl, gctl->clog, gctl->cap, gctl->live_cap, gctl->clog_cap};
     if (h == EMPTY64) { // the one value that cannot be a table key
         atomicAdd((ull *)&a.ctl->sp_count, 1ull);
         if (strand) atomicAdd((ull *)&a.ctl->sp_extra, 1ull);
@@ -82,18 +114,18 @@ __device__ __noinline__ u32 upsert(Ctl *ctl, u64 h, u64 kmer, u64 pos, u32 stran
     // first (key, k-mer, position in one round trip; agent-scope loads, the atomics of other XCDs are visible to
     // them) and an atomic is only issued where the value read says it could change something.  Stale reads are harmless: keys and k-mers go
     // EMPTY -> value once per launch and positions only decrease, so "already there" / "already smaller" stay true.
-    const bool read_first = ctl->read_first != 0u; // wave-uniform
+    const bool read_first = gctl->read_first != 0u; // wave-uniform
     ull seen_kmer = EMPTY64, seen_pos = EMPTY64;
     for (; probe < MAX_PROBE; ++probe) {
         Entry *e = &a.table[slot];
         ull old = EMPTY64;
         if (read_first) {
-            old = __hip_atomic_load((ull *)&e->hash, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            seen_kmer = __hip_atomic_load((ull *)&e->kmer, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            seen_pos = __hip_atomic_load((ull *)&e->pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = g_load((const ull *)&e->hash);
+            seen_kmer = g_load((const ull *)&e->kmer);
+            seen_pos = g_load((const ull *)&e->pos);
         }
         if (old == EMPTY64) {
-            old = atomicCAS((ull *)&e->hash, (ull)EMPTY64, (ull)h);
+            old = g_cas((ull *)&e->hash, (ull)EMPTY64, (ull)h);
             seen_kmer = seen_pos = EMPTY64; // whoever owns the slot now: what was read belongs to nobody
         }
         if (old == EMPTY64) {
@@ -113,11 +145,10 @@ __device__ __noinline__ u32 upsert(Ctl *ctl, u64 h, u64 kmer, u64 pos, u32 stran
         return 0u;
     }
     Entry *e = &a.table[slot];
-    atomicAdd((ull *)&e->count, 1ull);
-    if (strand) atomicAdd((ull *)&e->extra, 1ull);
-    if (seen_pos > (ull)pos) atomicMin((ull *)&e->pos, (ull)pos);
+    g_add((ull *)(strand ? &e->extra : &e->count), 1ull); // one counter per strand: one atomic per occurrence
+    if (seen_pos > (ull)pos) g_min((ull *)&e->pos, (ull)pos);
     ull oldk = seen_kmer;
-    if (oldk == EMPTY64) oldk = atomicCAS((ull *)&e->kmer, (ull)EMPTY64, (ull)kmer);
+    if (oldk == EMPTY64) oldk = g_cas((ull *)&e->kmer, (ull)EMPTY64, (ull)kmer);
     if (oldk != EMPTY64 && oldk != kmer) log_collision(a, h, kmer, pos);
     return inserted;
 }
@@ -130,9 +161,13 @@ struct AdmitQueue {
     u64 h[QCAP], k[QCAP], p[QCAP];
 };
 
-__device__ __noinline__ u32 flush_queue(Ctl *ctl, const AdmitQueue *q, u32 qn, u32 shard) {
+__device__ __noinline__ u32 flush_queue(Ctl *ctl, const AdmitQueue *q_generic, u32 qn_v, u32 shard) {
     const u32 lane = threadIdx.x & 63u;
     u32 ins = 0u;
+    // the queue lives in LDS: read it with ds_read, not through the generic (flat) pointer it arrives as
+    typedef __attribute__((address_space(3))) const AdmitQueue LdsQueue;
+    LdsQueue *q = (LdsQueue *)uniform_ptr(q_generic);
+    const u32 qn = (u32)__builtin_amdgcn_readfirstlane((int)qn_v);
     if (lane < qn) {
         const u64 pp = q->p[lane];
         ins = upsert(ctl, q->h[lane], q->k[lane], pp & 0x7FFFFFFFFFFFFFFFull, (u32)(pp >> 63), shard);
@@ -195,7 +230,10 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
     __shared__ __attribute__((aligned(16))) u32 sGood[WAVES_PER_BLOCK][128];
     __shared__ __attribute__((aligned(16))) AdmitQueue sQueue[WAVES_PER_BLOCK];
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // the wave index is uniform, and saying so keeps everything derived from it (ring and queue addresses, shard) in
+    // scalar registers instead of vector registers the hot loop would have to spill
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     {
         if (has_pair_word(K, false)) {
             sA1[tid] = lut_rec_A((u32)tid, false);
@@ -210,7 +248,11 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
     const LutTables LT{sA1, sA2, sB1, sB2, sP};
     __syncthreads();
 
-    const u64 tau = __hip_atomic_load(&a.ctl->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (a loaded value lands in vector registers; the threshold is needed on the admit path only, and a 64-bit vector
+    // value that lives across the whole unrolled loop gets spilled and reloaded from scratch there)
+    const u64 tau_v = __hip_atomic_load(&a.ctl->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u64 tau = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(tau_v >> 32)) << 32) |
+                    (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)tau_v);
     // readfirstlane keeps the bound an opaque scalar (otherwise the select inside is re-expanded per position)
     const u32 tau_hi1 = (u32)__builtin_amdgcn_readfirstlane((int)tau_hi_bound(tau));
 
@@ -225,6 +267,13 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
     // input: a wave inserts at most budget + 2047 new hashes per launch and the host sized the table for
     // (#waves x that) beyond the soft limit.  A stopped launch leaves its unprocessed work in the queue
     // (next_chunk + the leftover list); the host prunes and relaunches.
+#ifdef FH_PROFILE_FLUSH
+    u64 prof_cycles = 0, prof_calls = 0, prof_entries = 0;
+    const u64 prof_t0 = __builtin_readcyclecounter();
+#define FLUSH(ctl_, q_, qn_, shard_) ([&] { const u64 t0_ = __builtin_readcyclecounter(); const u32 r_ = flush_queue(ctl_, q_, qn_, shard_); prof_cycles += __builtin_readcyclecounter() - t0_; prof_calls++; prof_entries += qn_; return r_; }())
+#else
+#define FLUSH(ctl_, q_, qn_, shard_) flush_queue(ctl_, q_, qn_, shard_)
+#endif
     u32 wave_inserts = 0; // new hashes this wave inserted in this launch (wave-uniform)
     u32 qn = 0;           // occupancy of the admit queue (wave-uniform)
     AdmitQueue *queue = &sQueue[wave];
@@ -274,7 +323,9 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
         const u64 g64 = (u64)g_own | ((u64)g_nbr << 32);
 
         // which of the lane's 32 start positions carry a k-mer: all K bases good and inside [p_begin, p_end)
-        const u64 lane_pos0 = a.p_begin + t * (u64)TILE_POS + (u64)lane * LANE_POS;
+        const u64 tile_pos0 = a.p_begin + t * (u64)TILE_POS;     // wave-uniform
+        const u64 tile_stream_pos = a.base_pos + tile_pos0;      // stream coordinate of the tile's first position
+        const u64 lane_pos0 = tile_pos0 + (u64)lane * LANE_POS;
         const u32 limit = (a.p_end > lane_pos0) ? (u32)((a.p_end - lane_pos0) < 32 ? (a.p_end - lane_pos0) : 32) : 0u;
         const u32 W = window_valid_mask<K>(g64) & (limit >= 32u ? 0xFFFFFFFFu : ((1u << limit) - 1u));
         nvalid += (u32)__popc(W);
@@ -313,14 +364,19 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
                 const u32 cnt = (u32)__popcll(mask);
                 if (cnt) {
                     if (qn + cnt > (u32)QCAP) {
-                        wave_inserts += flush_queue(a.ctl, queue, qn, shard);
+                        wave_inserts += FLUSH(a.ctl, queue, qn, shard);
                         qn = 0;
                     }
                     const u32 my = qn + __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
                     if (take) {
                         queue->h[my] = h;
                         queue->k[my] = cm >> pre_shift(K); // the loop carries the canonical word pre-shifted (fh_core.h)
-                        queue->p[my] = (a.base_pos + lane_pos0 + (u64)j) | ((u64)(is_rc ? 1u : 0u) << 63);
+                        // position of this window, from scalars + the lane id recomputed here (two instructions)
+                        // rather than a 64-bit per-lane value kept alive -- i.e. spilled -- across the loop
+                        u32 lane_here; // (volatile: or the compiler hoists it out of the loop and spills it after all)
+                        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_here));
+                        const u64 pos = tile_stream_pos + (u64)(lane_here * (u32)LANE_POS + (u32)j);
+                        queue->p[my] = pos | ((u64)(is_rc ? 1u : 0u) << 63);
                     }
                     qn += cnt;
                 }
@@ -333,12 +389,12 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
         }
         __builtin_amdgcn_wave_barrier();
         if (qn >= (u32)(QCAP / 2) || (qn && t + 1 == rt1)) { // drain when half full or at the end of the pulled range
-            wave_inserts += flush_queue(a.ctl, queue, qn, shard);
+            wave_inserts += FLUSH(a.ctl, queue, qn, shard);
             qn = 0;
         }
         if (t + 1 < rt1 && wave_inserts >= a.wave_budget) {
             if (qn) { // nothing may stay parked when the wave gives the rest of its range back
-                wave_inserts += flush_queue(a.ctl, queue, qn, shard);
+                wave_inserts += FLUSH(a.ctl, queue, qn, shard);
                 qn = 0;
             }
             if (lane == 0) {
@@ -356,6 +412,14 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
             break;
         }
     }
+#ifdef FH_PROFILE_FLUSH
+    if (lane == 0) {
+        atomicAdd((unsigned long long *)&a.ctl->dbg_flush_cycles, (unsigned long long)prof_cycles);
+        atomicAdd((unsigned long long *)&a.ctl->dbg_flush_calls, (unsigned long long)prof_calls);
+        atomicAdd((unsigned long long *)&a.ctl->dbg_flush_entries, (unsigned long long)prof_entries);
+        atomicAdd((unsigned long long *)&a.ctl->dbg_wave_cycles, (unsigned long long)(__builtin_readcyclecounter() - prof_t0));
+    }
+#endif
     // total_kmers (mash.rs:35): one atomic per wave (a HASLO launch re-reads positions already counted)
     for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_xor(nvalid, off);
     if (!HASLO && lane == 0 && nvalid)

@@ -275,7 +275,8 @@ __global__ void k4_gather(const Entry *table, const u32 *live, const Ctl *ctl, i
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const Entry e = table[live[i]];
         o_hash[i] = e.hash;
-        o_count[i] = e.count > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)e.count;
+        const u64 occ = e.count + e.extra; // the table counts the two strands separately (fh_device.h)
+        o_count[i] = occ > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)occ;
         o_extra[i] = e.extra > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)e.extra;
         o_kmer[i] = e.kmer;
         o_pos[i] = e.pos;
@@ -430,6 +431,7 @@ __global__ void k_init_ctl(Ctl *ctl, u64 tau0) {
         ctl->soft_limit = 0xFFFFFFFFu;
         ctl->shard_soft = 0xFFFFFFFFu;
         ctl->read_first = 0;
+        ctl->dbg_flush_cycles = ctl->dbg_flush_calls = ctl->dbg_flush_entries = ctl->dbg_wave_cycles = 0;
         ctl->sp_count = 0;
         ctl->sp_extra = 0;
         ctl->sp_pos = EMPTY64;

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_upd(Entry *t, uint64_t n_entries, int p
 // of a hash that is already there then only needs its counter adds.  PACKED: both counters in one add.
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_upd_loads(Entry *t, uint64_t n_entries, int per_lane, uint64_t seed, ull *sink) {
-    const uint64_t gid = blockIdx.x * 256ull + threadIdx.x;
+    const uint64_t gid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     ull acc = 0;
     for (int i = 0; i < per_lane; ++i) {
         const uint64_t r = mix(seed + gid * 1315423911ull + (uint64_t)i * 0x9E3779B97F4A7C15ull);
@@ -118,6 +118,26 @@ static double run(Entry *t, uint64_t n_entries, ull *sink) {
     return 4.0 * blocks * 256.0 * per_lane / (ms * 1e-3) / 1e9;
 }
 
+// latency under light load: the read-first update with 1..16 waves per CU (the sketch kernel keeps only a few
+// percent of its waves in the admit path at any time)
+static void occupancy_sweep(Entry *t, uint64_t n_entries, ull *sink) {
+    printf("waves/CU   G updates/s   us per update per lane   (3 loads + adds, %llu MiB table)\n", (ull)(n_entries * sizeof(Entry) >> 20));
+    for (int wpc : {1, 2, 4, 8, 16}) {
+        const int blocks = 256 * wpc, per_lane = 64; // one wave per block
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_upd_loads<false>, dim3(blocks), dim3(64), 0, 0, t, n_entries, per_lane, 5ull, sink);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(k_upd_loads<false>, dim3(blocks), dim3(64), 0, 0, t, n_entries, per_lane, 5ull, sink);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double upd = 4.0 * blocks * 64.0 * per_lane;
+        printf("%5d      %8.2f      %8.2f\n", wpc, upd / (ms * 1e-3) / 1e9, (ms * 1e3 / 4.0) / per_lane);
+    }
+}
+
 int main() {
     ull *sink; CHECK(hipMalloc(&sink, 8));
     const uint64_t sizes_mb[] = {8, 64, 192, 512, 2048, 8192};
@@ -129,6 +149,7 @@ int main() {
         CHECK(hipDeviceSynchronize());
         double a = run<0>(t, n, sink), b = run<1>(t, n, sink), c = run<2>(t, n, sink), d = run<3>(t, n, sink), e = run<4>(t, n, sink), f = run<5>(t, n, sink), g = run_loads<false>(t, n, sink), h2 = run_loads<true>(t, n, sink);
         printf("%5llu MiB              %8.2f   %8.2f  %8.2f  %8.2f  %8.2f  %8.2f  %8.2f  %8.2f\n", (ull)mb, a, b, c, d, e, f, g, h2);
+        if (mb == 2048) occupancy_sweep(t, n, sink);
         CHECK(hipFree(t));
     }
     return 0;
