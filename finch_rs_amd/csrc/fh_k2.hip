@@ -272,7 +272,8 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
     const u64 prof_t0 = __builtin_readcyclecounter();
 #define FLUSH(ctl_, q_, qn_, shard_) ([&] { const u64 t0_ = __builtin_readcyclecounter(); const u32 r_ = flush_queue(ctl_, q_, qn_, shard_); prof_cycles += __builtin_readcyclecounter() - t0_; prof_calls++; prof_entries += qn_; return r_; }())
 #else
-#define FLUSH(ctl_, q_, qn_, shard_) flush_queue(ctl_, q_, qn_, shard_)
+// (the count returned is wave-uniform; saying so keeps wave_inserts, qn and the branches on them scalar)
+#define FLUSH(ctl_, q_, qn_, shard_) ((u32)__builtin_amdgcn_readfirstlane((int)flush_queue(ctl_, q_, qn_, shard_)))
 #endif
     u32 wave_inserts = 0; // new hashes this wave inserted in this launch (wave-uniform)
     u32 qn = 0;           // occupancy of the admit queue (wave-uniform)
