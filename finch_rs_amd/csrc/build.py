@@ -23,6 +23,8 @@ FLAGS += os.environ.get("FH_EXTRA_FLAGS", "").split()
 # scheduling strategy fits it without spills where the default one spills 11-21 registers (k = 21: +1 %, k = 24-31:
 # +2.5 %, A/B on MI355X).
 K2_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+if "FH_K2_FLAGS" in os.environ:  # A/B builds of the sketch kernel only
+    K2_FLAGS = os.environ["FH_K2_FLAGS"].split()
 OUT = os.environ.get("FH_OUT", OUT)
 
 SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2.hip", "fh_kernels.hip", "fh_big.hip", "fh_text.hip", "fh_api.hip", "fh_host.cpp", os.path.join("..", "..", "include", "finch_host.h"),
