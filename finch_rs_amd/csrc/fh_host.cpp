@@ -208,6 +208,7 @@ struct ByteSource {
     virtual bool failed() const { return false; }
     virtual bool can_rewind() const { return false; } // regular files, memory
     virtual bool rewind() { return false; }           // back to the first byte
+    virtual unsigned threads_hint() const { return 1; } // host threads the reader of this source may use
 };
 
 struct MemSource : ByteSource {
@@ -277,6 +278,7 @@ struct FileSource : ByteSource {
         return own && f && fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode);
     }
     bool rewind() override { return can_rewind() && fseek(f, 0, SEEK_SET) == 0; }
+    unsigned threads_hint() const override { return n_thr; }
 };
 
 // prepends already-consumed sniff bytes
@@ -299,6 +301,7 @@ struct PrefixedSource : ByteSource {
         off = prefix.size(); // the inner source delivers the sniffed bytes itself again
         return true;
     }
+    unsigned threads_hint() const override { return inner->threads_hint(); }
 };
 
 struct GzSource : ByteSource {
@@ -349,6 +352,144 @@ struct GzSource : ByteSource {
             }
         }
         return (size_t)(zs.next_out - dst);
+    }
+};
+
+// BGZF (bgzip / htslib): a series of gzip members of at most 64 KiB each whose header states the member's own size
+// (extra subfield 'B','C').  The members are independent deflate streams, so a batch of them is inflated by several
+// threads at once -- what a single zlib stream cannot offer (plain gzip stays at inflate speed, ~0.3 Gbases/s).
+// Every member's CRC-32 and length are checked as zlib's gzip wrapper would; a member without the subfield hands the
+// rest of the input to the sequential GzSource.
+struct BgzfSource : ByteSource {
+    std::unique_ptr<ByteSource> inner;
+    unsigned n_thr;
+    std::vector<uint8_t> cbuf; // compressed bytes [c_lo, c_hi) not yet consumed
+    size_t c_lo = 0, c_hi = 0;
+    std::vector<uint8_t> obuf; // inflated bytes [o_lo, o_hi) not yet delivered
+    size_t o_lo = 0, o_hi = 0;
+    bool in_eof = false, bad = false;
+    std::unique_ptr<GzSource> tail;
+    static constexpr size_t BATCH = 512; // members per round (<= 32 MiB inflated)
+
+    BgzfSource(std::unique_ptr<ByteSource> in, unsigned threads) : inner(std::move(in)), n_thr(std::max(1u, threads)), cbuf(BATCH * 65536 + 65536) {}
+    bool failed() const override { return bad || (tail && tail->failed()); }
+
+    // total size of the BGZF member starting at p (0 = not a BGZF member); needs 18 readable bytes
+    static uint32_t member_size(const uint8_t *p, uint32_t *hdr_len) {
+        if (p[0] != 0x1F || p[1] != 0x8B || p[2] != 8 || p[3] != 4) return 0; // FLG must be exactly FEXTRA
+        const uint32_t xlen = p[10] | ((uint32_t)p[11] << 8);
+        if (xlen != 6 || p[12] != 'B' || p[13] != 'C' || p[14] != 2 || p[15] != 0) return 0; // what bgzip writes
+        *hdr_len = 12 + xlen;
+        return (p[16] | ((uint32_t)p[17] << 8)) + 1u;
+    }
+    bool fill_compressed(size_t need) { // make [c_lo, c_hi) hold at least `need` bytes if the input has them
+        if (c_hi - c_lo >= need) return true;
+        if (c_lo && (cbuf.size() - c_lo < need || c_hi == c_lo)) {
+            memmove(cbuf.data(), cbuf.data() + c_lo, c_hi - c_lo);
+            c_hi -= c_lo;
+            c_lo = 0;
+        }
+        while (!in_eof && c_hi - c_lo < need) {
+            const size_t got = inner->read(cbuf.data() + c_hi, cbuf.size() - c_hi);
+            if (got == 0) in_eof = true;
+            c_hi += got;
+        }
+        return c_hi - c_lo >= need;
+    }
+    struct Member { size_t in_off, in_len, out_off; uint32_t isize, crc; };
+    bool refill() { // inflate the next batch of members into obuf
+        o_lo = o_hi = 0;
+        std::vector<Member> ms;
+        size_t out_total = 0, scan = 0; // scan: offset from c_lo of the next member header
+        // top the buffer up once, then take the members that are completely in it
+        fill_compressed(cbuf.size() - (cbuf.size() >> 3));
+        while (ms.size() < BATCH) {
+            if (c_hi - c_lo - scan < 18) {
+                if (scan == 0 && c_hi - c_lo > 0 && in_eof) bad = true; // trailing garbage / truncated header
+                break;
+            }
+            const uint8_t *p = cbuf.data() + c_lo + scan;
+            uint32_t hdr = 0;
+            const uint32_t tot = member_size(p, &hdr);
+            if (tot == 0) {
+                if (scan) break; // deliver what precedes it first
+                // not BGZF from here on: the sequential reader takes over (it sees the buffered bytes first)
+                auto pre = std::make_unique<PrefixedSource>();
+                pre->prefix.assign(cbuf.data() + c_lo, cbuf.data() + c_hi);
+                pre->inner = std::move(inner);
+                c_lo = c_hi = 0;
+                tail = std::make_unique<GzSource>(std::move(pre));
+                return true;
+            }
+            if (tot < hdr + 8u + 2u) { bad = true; return false; }
+            if (c_hi - c_lo - scan < tot) {
+                if (in_eof) { bad = true; return false; } // truncated member
+                if (scan == 0) { // a single member must fit after a refill
+                    if (!fill_compressed(tot)) { bad = true; return false; }
+                    continue;
+                }
+                break;
+            }
+            Member m;
+            m.in_off = c_lo + scan + hdr;
+            m.in_len = tot - hdr - 8;
+            m.crc = p[tot - 8] | ((uint32_t)p[tot - 7] << 8) | ((uint32_t)p[tot - 6] << 16) | ((uint32_t)p[tot - 5] << 24);
+            m.isize = p[tot - 4] | ((uint32_t)p[tot - 3] << 8) | ((uint32_t)p[tot - 2] << 16) | ((uint32_t)p[tot - 1] << 24);
+            if (m.isize > 65536u) { bad = true; return false; }
+            m.out_off = out_total;
+            out_total += m.isize;
+            ms.push_back(m);
+            scan += tot;
+        }
+        if (ms.empty()) return !bad && false;
+        if (obuf.size() < out_total + 1) obuf.resize(out_total + 1); // (+1: zlib refuses a null next_out even for an empty member)
+        std::atomic<bool> ok{true};
+        const unsigned nt = (unsigned)std::min<size_t>(n_thr, ms.size());
+        auto job = [&](unsigned t) {
+            z_stream zs{};
+            if (inflateInit2(&zs, -15) != Z_OK) { ok = false; return; }
+            for (size_t i = t; i < ms.size() && ok; i += nt) {
+                const Member &m = ms[i];
+                inflateReset(&zs);
+                zs.next_in = cbuf.data() + m.in_off;
+                zs.avail_in = (uInt)m.in_len;
+                zs.next_out = obuf.data() + m.out_off;
+                zs.avail_out = m.isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                const bool done = (rc == Z_STREAM_END) && zs.avail_out == 0 && zs.avail_in == 0;
+                if (!done || (uint32_t)crc32(crc32(0L, Z_NULL, 0), obuf.data() + m.out_off, m.isize) != m.crc) ok = false;
+            }
+            inflateEnd(&zs);
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(job, t);
+        job(0);
+        for (auto &x : th) x.join();
+        if (!ok) { bad = true; return false; }
+        c_lo += scan;
+        o_hi = out_total;
+        return true;
+    }
+    size_t read(uint8_t *dst, size_t cap) override {
+        size_t n = 0;
+        while (n < cap && !bad) {
+            if (tail) {
+                const size_t g = tail->read(dst + n, cap - n);
+                n += g;
+                if (g == 0) break;
+                continue;
+            }
+            if (o_lo == o_hi) {
+                if (!refill()) break; // end of input or error
+                if (tail) continue;
+                if (o_lo == o_hi) continue; // a batch of empty members (the EOF marker): look further
+            }
+            const size_t m = std::min(cap - n, o_hi - o_lo);
+            memcpy(dst + n, obuf.data() + o_lo, m);
+            o_lo += m;
+            n += m;
+        }
+        return n;
     }
 };
 
@@ -522,13 +663,18 @@ static int open_source(std::unique_ptr<ByteSource> raw, std::unique_ptr<ByteSour
     const bool gz = got == 2 && pre->prefix[0] == 0x1F && pre->prefix[1] == 0x8B;
     const bool bz = got == 2 && pre->prefix[0] == 0x42 && pre->prefix[1] == 0x5A;
     const bool xz = got == 2 && pre->prefix[0] == 0xFD && pre->prefix[1] == 0x37;
+    // threads the decompressor may use: what the source was given (finch_sketch_files shares FINCH_READ_THREADS
+    // among its workers); FINCH_BGZF_THREADS overrides it (tests, in-memory inputs)
+    unsigned dec_threads = raw->threads_hint();
+    if (const char *e = getenv("FINCH_BGZF_THREADS")) dec_threads = (unsigned)std::max(1, atoi(e));
     pre->inner = std::move(raw);
     if (is_gz) *is_gz = gz;
     if (first_byte) *first_byte = got ? pre->prefix[0] : -1;
     if (bz && !Bz2Source::api().ok) return hfail(FH_ERR_UNSUPPORTED, "bzip2-compressed input: libbz2.so.1 not found");
     if (xz && !XzSource::api().ok) return hfail(FH_ERR_UNSUPPORTED, "xz-compressed input: liblzma.so.5 not found");
     if (is_gz) *is_gz = gz || bz || xz; // "compressed": not eligible for device-side text parsing
-    if (gz) out = std::make_unique<GzSource>(std::move(pre));
+    if (gz && dec_threads > 1) out = std::make_unique<BgzfSource>(std::move(pre), dec_threads); // falls back member by member
+    else if (gz) out = std::make_unique<GzSource>(std::move(pre));
     else if (bz) out = std::make_unique<Bz2Source>(std::move(pre));
     else if (xz) out = std::make_unique<XzSource>(std::move(pre));
     else out = std::move(pre);

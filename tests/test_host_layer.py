@@ -216,3 +216,46 @@ def test_large_reads_split_over_threads_deliver_the_file(tmp_path):
         for chunk, thr in ((64 * M, 4), (16 * M, 3), (17 * M + 5, 8), (1 * M, 4), (64 * M, 1)):
             got = H.read_file_probe(str(p), chunk, thr, size + 4096)
             assert got == data, (size, chunk, thr, len(got))
+
+
+def _bgzf(data: bytes, block: int = 60000, eof_marker: bool = True) -> bytes:
+    """what bgzip writes: gzip members of <= 64 KiB with their own size in the 'BC' extra subfield"""
+    import struct
+    import zlib
+    out = []
+    chunks = [data[i:i + block] for i in range(0, len(data), block)] + ([b""] if eof_marker else [])
+    for ch in chunks:
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        c = co.compress(ch) + co.flush()
+        hdr = b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(c) + 25)
+        out.append(hdr + c + struct.pack("<II", zlib.crc32(ch), len(ch)))
+    return b"".join(out)
+
+
+def test_bgzf_members_are_inflated_in_parallel_and_checked(monkeypatch):
+    """BGZF input (bgzip): with more than one decompression thread the members are inflated concurrently; the records
+    must be those of the plain text, a non-BGZF member hands over to the sequential reader, damage stays loud"""
+    rng = np.random.default_rng(11)
+    reads = [bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=int(rng.integers(1, 400)))) for _ in range(30000)]
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads))
+    want = H.fastx_scan(fq)
+    assert want[0] == len(reads) and want[2] == 2
+    z = _bgzf(fq)
+    for thr in ("1", "2", "5"):
+        monkeypatch.setenv("FINCH_BGZF_THREADS", thr)
+        assert H.fastx_scan(z) == want, thr
+        assert H.fastx_scan(_bgzf(fq, 65536)) == want                      # full-size members
+        assert H.fastx_scan(_bgzf(fq, 777, eof_marker=False)) == want      # thousands of tiny members, no EOF marker
+        # a plain gzip member in the middle / at the start: the sequential reader takes over from there
+        half = fq.index(b"@r15000\n")
+        assert H.fastx_scan(_bgzf(fq[:half], eof_marker=False) + gzip.compress(fq[half:], 1)) == want
+        assert H.fastx_scan(gzip.compress(fq[:half], 1) + _bgzf(fq[half:])) == want
+        with pytest.raises(FinchError, match="empty input"):                 # only the EOF marker: empty, as for plain text
+            H.fastx_scan(_bgzf(b""))
+    monkeypatch.setenv("FINCH_BGZF_THREADS", "4")
+    bad = bytearray(z)
+    bad[len(z) // 2] ^= 0x55  # flips a bit inside some member's deflate data or trailer
+    with pytest.raises(Exception):
+        H.fastx_scan(bytes(bad))
+    with pytest.raises(Exception):
+        H.fastx_scan(z[:len(z) // 2])  # truncated inside a member

@@ -26,3 +26,24 @@ with open(path, "rb") as f:
         if not b: break
         n += len(d.decompress(b))
 print("zlib inflate alone (python): %.2f s  %.2f GB/s" % (time.time() - t, n / (time.time() - t) / 1e9))
+# the same text as BGZF (bgzip): independent 64 KiB members, inflated by FINCH_READ_THREADS threads
+import struct
+def bgzf(data, block=65280):
+    out = []
+    for i in list(range(0, len(data), block)) + [None]:
+        ch = b"" if i is None else data[i:i + block]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15); c = co.compress(ch) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(c) + 25) + c + struct.pack("<II", zlib.crc32(ch), len(ch)))
+    return b"".join(out)
+bpath = "/tmp/e2e.fastq.bgz"
+t = time.time()
+with open(bpath, "wb") as f: f.write(bgzf(raw))
+print("wrote the same text as %.0f MB BGZF in %.1f s" % (os.path.getsize(bpath) / 1e6, time.time() - t))
+ref = res.sketch(0).arrays[0]
+for thr in ("1", "2", "4", "8", "16"):
+    os.environ["FINCH_READ_THREADS"] = thr
+    best = 1e9
+    for rep in range(2):
+        t = time.time(); rb = H.sketch_files([bpath], p, H.FilterParams(False)); best = min(best, time.time() - t)
+    assert np.array_equal(rb.sketch(0).arrays[0], ref)
+    print("sketch_files fastq BGZF, %2s threads: %.2f s  %.2f GB/s of inflated text  %.1f Mbases/s" % (thr, best, len(raw) / best / 1e9, n_reads * rl / best / 1e6))
