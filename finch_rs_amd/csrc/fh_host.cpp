@@ -371,7 +371,8 @@ struct BgzfSource : ByteSource {
     std::unique_ptr<GzSource> tail;
     static constexpr size_t BATCH = 512; // members per round (<= 32 MiB inflated)
 
-    BgzfSource(std::unique_ptr<ByteSource> in, unsigned threads) : inner(std::move(in)), n_thr(std::max(1u, threads)), cbuf(BATCH * 65536 + 65536) {}
+    bool confirmed = false;              // the first member was BGZF: the batch buffer is worth allocating
+    BgzfSource(std::unique_ptr<ByteSource> in, unsigned threads) : inner(std::move(in)), n_thr(std::max(1u, threads)), cbuf(1 << 16) {}
     bool failed() const override { return bad || (tail && tail->failed()); }
 
     // total size of the BGZF member starting at p (0 = not a BGZF member); needs 18 readable bytes
@@ -401,8 +402,21 @@ struct BgzfSource : ByteSource {
         o_lo = o_hi = 0;
         std::vector<Member> ms;
         size_t out_total = 0, scan = 0; // scan: offset from c_lo of the next member header
+        // (a plain gzip file also lands here when several threads are available: look at its first header before
+        // buffering 32 MiB of it)
+        if (!confirmed && fill_compressed(18)) {
+            uint32_t hdr = 0;
+            if (member_size(cbuf.data() + c_lo, &hdr)) {
+                confirmed = true;
+                std::vector<uint8_t> big(BATCH * 65536 + 65536);
+                memcpy(big.data(), cbuf.data() + c_lo, c_hi - c_lo);
+                c_hi -= c_lo;
+                c_lo = 0;
+                cbuf.swap(big);
+            }
+        }
         // top the buffer up once, then take the members that are completely in it
-        fill_compressed(cbuf.size() - (cbuf.size() >> 3));
+        if (confirmed) fill_compressed(cbuf.size() - (cbuf.size() >> 3));
         while (ms.size() < BATCH) {
             if (c_hi - c_lo - scan < 18) {
                 if (scan == 0 && c_hi - c_lo > 0 && in_eof) bad = true; // trailing garbage / truncated header
