@@ -294,3 +294,40 @@ print("child ok")
 '''
     for env in [{}, {"FH_STAGE_BYTES": "4096"}, {"FH_STAGE_BYTES": "5001"}]:
         assert "child ok" in _run_child(code, env)
+
+
+def test_bgzf_and_gzip_files_give_the_sketch_of_the_plain_file(tmp_path):
+    """sketch_files on the same FASTQ as plain text, gzip and BGZF (members inflated by the call's read threads)"""
+    import struct
+    import zlib
+    g = S.synth_genome_host(400_000, 5)
+    reads = S.synth_reads_host(g, 0, 40000, 150, 5, 10000, 500).reshape(40000, 151)[:, :150]
+    fq = b"".join(b"@r%d\n" % i + reads[i].tobytes() + b"\n+\n" + b"I" * 150 + b"\n" for i in range(len(reads)))
+
+    def bgzf(data, block=65280):
+        out = []
+        for i in list(range(0, len(data), block)) + [None]:
+            ch = b"" if i is None else data[i:i + block]
+            co = zlib.compressobj(1, zlib.DEFLATED, -15)
+            c = co.compress(ch) + co.flush()
+            out.append(b"\x1f\x8b\x08\x04\0\0\0\0\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(c) + 25) + c
+                       + struct.pack("<II", zlib.crc32(ch), len(ch)))
+        return b"".join(out)
+
+    files = {"a.fastq": fq, "a.fastq.gz": gzip.compress(fq, 1), "a.fastq.bgz": bgzf(fq)}
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+    p = SketchParams.mash(1000, 1000, False, 21, 0)
+    res = H.sketch_files([str(tmp_path / n) for n in files], p, H.FilterParams(None))
+    a = [res.sketch(i) for i in range(3)]
+    for s in a[1:]:
+        assert np.array_equal(s.arrays[0], a[0].arrays[0]) and np.array_equal(s.arrays[1], a[0].arrays[1])
+        assert s.seq_length == a[0].seq_length and s.num_valid_kmers == a[0].num_valid_kmers
+    # a single BGZF file: the call's read threads all go to its members
+    one = H.sketch_files([str(tmp_path / "a.fastq.bgz")], p, H.FilterParams(None)).sketch(0)
+    assert np.array_equal(one.arrays[0], a[0].arrays[0])
+    bad = bytearray(files["a.fastq.bgz"])
+    bad[len(bad) // 3] ^= 0x10
+    (tmp_path / "bad.bgz").write_bytes(bytes(bad))
+    with pytest.raises(FinchError):
+        H.sketch_files([str(tmp_path / "bad.bgz")], p, H.FilterParams(None))
