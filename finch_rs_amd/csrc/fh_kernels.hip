@@ -9,6 +9,8 @@
 // (the hot kernel k2_sketch<K> lives in fh_k2.hip)
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "fh_core.h"
 #include "fh_device.h"
 #include "fh_kernels.h"
@@ -253,13 +255,17 @@ __global__ __launch_bounds__(1024) void k3_prune_small(Entry *table, u32 *live, 
 
 hipError_t launch_prune_small(Entry *table, u32 *live, u32 *dead, u32 dead_cap, Ctl *ctl, u32 kind, u64 size,
                               u64 max_hash, u32 trigger, u32 force, u32 sort_out, hipStream_t st) {
-    static bool attr_set = false;
     const size_t lds = (size_t)SMALL_MAX * 12;
-    if (!attr_set) {
+    // function attributes belong to the current device: once per device, and harmless if two worker threads of the
+    // same device both get here first
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k3_prune_small),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(k3_prune_small, dim3(1), dim3(1024), lds, st, table, live, dead, dead_cap, ctl, kind, size,
                        max_hash, trigger, force, sort_out);
