@@ -206,10 +206,12 @@ __device__ __forceinline__ void classify_tile(const SketchArgs &a, u64 tile, int
 // ------------------------------------------------------------------------------------------------
 // K2
 // ------------------------------------------------------------------------------------------------
-// Register budget: four waves per SIMD (<= 128 VGPRs) for every K.  K <= 21 needs just under that by itself (left
-// alone it lands on 129-137 and loses a wave).  K >= 22 would take 150-190 registers, but those kernels do 6-8 table
-// lookups per position and live off the LDS pipe, where a fourth wave is worth more than the 5-20 registers it makes
-// the compiler spill (measured k = 31: 373 Gbases/s unbounded at 2 waves, 427 at 3, 443 at 4, 272 at 5).
+// Register budget: four waves per SIMD (<= 128 VGPRs) for every K.  With everything wave-uniform kept scalar
+// (threshold, wave index, queue bookkeeping) K <= 24 fits with room to spare (k = 21: 120 VGPRs, no scratch); K >= 25
+// would take 150-190 registers, but those kernels do 6-8 table lookups per position and live off the LDS pipe, where a
+// fourth wave is worth more than the handful of registers it makes the compiler spill (measured k = 31: 373 Gbases/s
+// unbounded at 2 waves, 427 at 3, 443 at 4, 272 at 5).  What must never be spilled is anything the admit path reads:
+// a reload there stalls ~40 % of the wave-iterations of a launch that admits 1 %.
 #ifndef FH_MINW_BIG
 #define FH_MINW_BIG 4
 #endif
