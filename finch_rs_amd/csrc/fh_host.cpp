@@ -302,13 +302,14 @@ struct PrefixedSource : ByteSource {
         return true;
     }
     unsigned threads_hint() const override { return inner->threads_hint(); }
+    bool failed() const override { return inner->failed(); }
 };
 
 struct GzSource : ByteSource {
     std::unique_ptr<ByteSource> inner;
     z_stream zs{};
     std::vector<uint8_t> inbuf;
-    bool eof = false, bad = false, init = false;
+    bool eof = false, bad = false, init = false, mid_member = false;
     explicit GzSource(std::unique_ptr<ByteSource> in) : inner(std::move(in)), inbuf(1 << 20) {
         init = inflateInit2(&zs, 15 + 32) == Z_OK; // gzip/zlib auto-detect
         bad = !init;
@@ -317,6 +318,13 @@ struct GzSource : ByteSource {
         if (init) inflateEnd(&zs);
     }
     bool failed() const override { return bad; }
+    bool can_rewind() const override { return init && inner->can_rewind(); }
+    bool rewind() override { // inflate again from the first byte
+        if (!can_rewind() || !inner->rewind() || inflateReset(&zs) != Z_OK) return false;
+        zs.avail_in = 0;
+        eof = bad = mid_member = false;
+        return true;
+    }
     size_t read(uint8_t *dst, size_t cap) override {
         if (eof || bad) return 0;
         zs.next_out = dst;
@@ -326,13 +334,16 @@ struct GzSource : ByteSource {
                 const size_t got = inner->read(inbuf.data(), inbuf.size());
                 if (got == 0) {
                     eof = true;
+                    if (mid_member) bad = true; // the input ends inside a member: truncated (flate2: UnexpectedEof)
                     break;
                 }
                 zs.next_in = inbuf.data();
                 zs.avail_in = (uInt)got;
             }
+            mid_member = true;
             const int rc = inflate(&zs, Z_NO_FLUSH);
             if (rc == Z_STREAM_END) {
+                mid_member = false;
                 // concatenated gzip members (bgzip) continue with a fresh header
                 if (zs.avail_in == 0) {
                     const size_t got = inner->read(inbuf.data(), inbuf.size());
@@ -374,6 +385,14 @@ struct BgzfSource : ByteSource {
     bool confirmed = false;              // the first member was BGZF: the batch buffer is worth allocating
     BgzfSource(std::unique_ptr<ByteSource> in, unsigned threads) : inner(std::move(in)), n_thr(std::max(1u, threads)), cbuf(1 << 16) {}
     bool failed() const override { return bad || (tail && tail->failed()); }
+    // (once the sequential reader has taken over it owns the input: no way back from there)
+    bool can_rewind() const override { return !tail && inner && inner->can_rewind(); }
+    bool rewind() override {
+        if (!can_rewind() || !inner->rewind()) return false;
+        c_lo = c_hi = o_lo = o_hi = 0;
+        in_eof = bad = false;
+        return true;
+    }
 
     // total size of the BGZF member starting at p (0 = not a BGZF member); needs 18 readable bytes
     static uint32_t member_size(const uint8_t *p, uint32_t *hdr_len) {
@@ -1002,7 +1021,7 @@ static int fastq_text_to_device(ByteSource &src, fh_sketcher *h) {
             if (int rc = fh_push_fastq_text(h, cut)) return hfail(rc, "%s", fh_last_error());
         if (eof && left.empty()) break;
     }
-    if (src.failed()) return hfail(FH_ERR_INVALID, "read error");
+    if (src.failed()) return hfail(FH_ERR_INVALID, "read error or corrupt compressed stream");
     return FH_OK;
 }
 
@@ -1100,7 +1119,7 @@ static int fasta_text_to_device(ByteSource &src, fh_sketcher *h, FastxStats &st)
         if (int rc = fh_push_fasta_text(h, cut, state, first ? 0u : FH_PUSH_CONTINUE)) return hfail(rc, "%s", fh_last_error());
         first = false;
     }
-    if (src.failed()) return hfail(FH_ERR_INVALID, "read error");
+    if (src.failed()) return hfail(FH_ERR_INVALID, "read error or corrupt compressed stream");
     fc.finish();
     st.total_bases = fc.total_bases;
     st.n_records = fc.n_records;
@@ -1117,10 +1136,21 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     FastxStats st;
     const char *dp = getenv("FINCH_DEVICE_PARSE");
     // FINCH_DEVICE_PARSE: unset = plain FASTA and FASTQ text is split on the device (FASTQ with the host parser as the
-    // fallback, see below); 1 = on the device, no fallback; 0 = on the host.  Compressed input is always parsed where
-    // it is inflated.
+    // fallback, see below); 1 = on the device, no fallback; 0 = on the host.  Compressed input is inflated on the host
+    // and its text treated the same way.
     const bool dp_on = dp && dp[0] == '1', dp_off = dp && dp[0] == '0';
-    bool device_parse = !is_gz && !dp_off && (first == '>' || first == '@');
+    if (is_gz && !dp_off) {
+        // compressed: the format shows in the first inflated byte; what follows it reaches the staging buffer straight
+        // from the decompressor, so the host only inflates (gzip: one thread, BGZF: the call's read threads)
+        uint8_t b = 0;
+        const size_t g = src->read(&b, 1);
+        auto pre = std::make_unique<PrefixedSource>();
+        pre->prefix.assign(&b, &b + g);
+        pre->inner = std::move(src);
+        src = std::move(pre);
+        first = g ? (int)b : -1;
+    }
+    bool device_parse = !dp_off && (first == '>' || first == '@');
     if (device_parse && first == '@' && !dp_on && !src->can_rewind()) device_parse = false; // no second chance: host parser
     if (device_parse && first == '@') {
         // FASTQ on the device has to be strictly 4-line.  Unless the caller insists (FINCH_DEVICE_PARSE=1: errors stay

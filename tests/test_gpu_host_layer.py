@@ -331,3 +331,43 @@ def test_bgzf_and_gzip_files_give_the_sketch_of_the_plain_file(tmp_path):
     (tmp_path / "bad.bgz").write_bytes(bytes(bad))
     with pytest.raises(FinchError):
         H.sketch_files([str(tmp_path / "bad.bgz")], p, H.FilterParams(None))
+
+
+def test_compressed_text_goes_through_the_device_side_splitters(tmp_path, monkeypatch):
+    """gz input is inflated on the host and its text split on the device like plain text: same sketches as the host
+    parser for FASTA.gz, strict FASTQ.gz, and a FASTQ.gz with blank lines (device pass rejects it -> the gzip stream is
+    rewound and read by the host parser)"""
+    g = S.synth_genome_host(300_000, 8)
+    fa = b">a desc\n" + b"\n".join(g.tobytes()[i:i + 61] for i in range(0, 200_000, 61)) + b"\n>b\n" + g.tobytes()[200_000:] + b"\n"
+    reads = S.synth_reads_host(g, 0, 20000, 150, 8, 10000, 500).reshape(20000, 151)[:, :150]
+    fq = b"".join(b"@r%d\n" % i + reads[i].tobytes() + b"\n+\n" + b"I" * 150 + b"\n" for i in range(len(reads)))
+    loose = fq.replace(b"\n@r777\n", b"\n\n@r777\n", 1)  # a blank line between two records: needletail accepts it
+    assert loose != fq
+    files = {"a.fa.gz": gzip.compress(fa, 1), "s.fq.gz": gzip.compress(fq, 1), "l.fq.gz": gzip.compress(loose, 1)}
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+    paths = [str(tmp_path / n) for n in files]
+    p = SketchParams.mash(500, 500, False, 21, 0)
+    monkeypatch.setenv("FINCH_DEVICE_PARSE", "0")
+    want = H.sketch_files(paths, p, H.FilterParams(None))
+    monkeypatch.delenv("FINCH_DEVICE_PARSE")
+    got = H.sketch_files(paths, p, H.FilterParams(None))
+    for i in range(len(paths)):
+        a, b = want.sketch(i), got.sketch(i)
+        assert np.array_equal(a.arrays[0], b.arrays[0]) and np.array_equal(a.arrays[1], b.arrays[1]), paths[i]
+        assert (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers), paths[i]
+    assert np.array_equal(got.sketch(1).arrays[0], got.sketch(2).arrays[0])  # the blank line changes nothing
+    # device only: the loose file is an error, the strict ones are not
+    monkeypatch.setenv("FINCH_DEVICE_PARSE", "1")
+    H.sketch_files(paths[:2], p, H.FilterParams(None))
+    with pytest.raises(FinchError):
+        H.sketch_files(paths[2:], p, H.FilterParams(None))
+    # a truncated gzip stream fails loudly on either route
+    (tmp_path / "t.fq.gz").write_bytes(files["s.fq.gz"][:len(files["s.fq.gz"]) // 2])
+    for mode in ("0", "1", None):
+        if mode is None:
+            monkeypatch.delenv("FINCH_DEVICE_PARSE")
+        else:
+            monkeypatch.setenv("FINCH_DEVICE_PARSE", mode)
+        with pytest.raises(FinchError):
+            H.sketch_files([str(tmp_path / "t.fq.gz")], p, H.FilterParams(None))

@@ -259,3 +259,19 @@ def test_bgzf_members_are_inflated_in_parallel_and_checked(monkeypatch):
         H.fastx_scan(bytes(bad))
     with pytest.raises(Exception):
         H.fastx_scan(z[:len(z) // 2])  # truncated inside a member
+
+
+def test_truncated_gzip_is_an_error():
+    """flate2 (needletail's decoder) reports UnexpectedEof for a gzip stream that ends inside a member; so must we --
+    cut inside the deflate data, inside the trailer, and between two members (the only clean place)"""
+    fq = b"".join(b"@r%d\nACGTACGTACGTTTGACCA\n+\nIIIIIIIIIIIIIIIIIII\n" % i for i in range(5000))
+    z = gzip.compress(fq, 6)
+    assert H.fastx_scan(z)[0] == 5000
+    for cut in (len(z) // 2, len(z) - 1, len(z) - 5, len(z) - 9):
+        with pytest.raises(FinchError):
+            H.fastx_scan(z[:cut])
+    two = z + gzip.compress(fq, 1)
+    assert H.fastx_scan(two)[0] == 10000
+    assert H.fastx_scan(two[:len(z)])[0] == 5000
+    with pytest.raises(FinchError):
+        H.fastx_scan(two[:len(z) + 40])
