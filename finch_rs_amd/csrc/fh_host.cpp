@@ -563,7 +563,7 @@ struct Bz2Source : ByteSource {
     std::unique_ptr<ByteSource> inner;
     BzStream bs{};
     std::vector<uint8_t> inbuf;
-    bool eof = false, bad = false, init = false;
+    bool eof = false, bad = false, init = false, mid_stream = false;
     explicit Bz2Source(std::unique_ptr<ByteSource> in) : inner(std::move(in)), inbuf(1 << 20) {
         init = api().ok && api().init(&bs, 0, 0) == 0;
         bad = !init;
@@ -581,13 +581,16 @@ struct Bz2Source : ByteSource {
                 const size_t got = inner->read(inbuf.data(), inbuf.size());
                 if (got == 0) {
                     eof = true;
+                    if (mid_stream) bad = true; // the input ends inside a stream: truncated
                     break;
                 }
                 bs.next_in = (char *)inbuf.data();
                 bs.avail_in = (unsigned int)got;
             }
+            mid_stream = true;
             const int rc = api().decompress(&bs);
             if (rc == 4 /* BZ_STREAM_END */) {
+                mid_stream = false;
                 // concatenated streams: start over if more input follows
                 api().end(&bs);
                 init = api().init(&bs, 0, 0) == 0;

@@ -275,3 +275,15 @@ def test_truncated_gzip_is_an_error():
     assert H.fastx_scan(two[:len(z)])[0] == 5000
     with pytest.raises(FinchError):
         H.fastx_scan(two[:len(z) + 40])
+
+
+def test_truncated_bz2_and_xz_are_errors():
+    import bz2
+    import lzma
+    fq = b"".join(b"@r%d\nACGTACGTACGTTTGACCA\n+\nIIIIIIIIIIIIIIIIIII\n" % i for i in range(20000))
+    for comp in (bz2.compress(fq), lzma.compress(fq, preset=1)):
+        assert H.fastx_scan(comp)[0] == 20000
+        for cut in (len(comp) // 2, len(comp) - 3):
+            with pytest.raises(FinchError):
+                H.fastx_scan(comp[:cut])
+    assert H.fastx_scan(bz2.compress(fq) + bz2.compress(fq))[0] == 40000  # concatenated streams, as needletail reads them
