@@ -417,8 +417,10 @@ struct BgzfSource : ByteSource {
         return c_hi - c_lo >= need;
     }
     struct Member { size_t in_off, in_len, out_off; uint32_t isize, crc; };
-    bool refill() { // inflate the next batch of members into obuf
-        o_lo = o_hi = 0;
+    // inflate the next batch of members into out[0, out_cap) (>= 64 KiB: room for any one member); false = end of
+    // input or error; *produced may be 0 for a batch of empty members
+    bool refill(uint8_t *out, size_t out_cap, size_t *produced) {
+        *produced = 0;
         std::vector<Member> ms;
         size_t out_total = 0, scan = 0; // scan: offset from c_lo of the next member header
         // (a plain gzip file also lands here when several threads are available: look at its first header before
@@ -469,13 +471,13 @@ struct BgzfSource : ByteSource {
             m.crc = p[tot - 8] | ((uint32_t)p[tot - 7] << 8) | ((uint32_t)p[tot - 6] << 16) | ((uint32_t)p[tot - 5] << 24);
             m.isize = p[tot - 4] | ((uint32_t)p[tot - 3] << 8) | ((uint32_t)p[tot - 2] << 16) | ((uint32_t)p[tot - 1] << 24);
             if (m.isize > 65536u) { bad = true; return false; }
+            if (out_total + m.isize > out_cap) break; // the destination is full
             m.out_off = out_total;
             out_total += m.isize;
             ms.push_back(m);
             scan += tot;
         }
-        if (ms.empty()) return !bad && false;
-        if (obuf.size() < out_total + 1) obuf.resize(out_total + 1); // (+1: zlib refuses a null next_out even for an empty member)
+        if (ms.empty()) return false;
         std::atomic<bool> ok{true};
         const unsigned nt = (unsigned)std::min<size_t>(n_thr, ms.size());
         auto job = [&](unsigned t) {
@@ -486,11 +488,11 @@ struct BgzfSource : ByteSource {
                 inflateReset(&zs);
                 zs.next_in = cbuf.data() + m.in_off;
                 zs.avail_in = (uInt)m.in_len;
-                zs.next_out = obuf.data() + m.out_off;
+                zs.next_out = out + m.out_off;
                 zs.avail_out = m.isize;
                 const int rc = inflate(&zs, Z_FINISH);
                 const bool done = (rc == Z_STREAM_END) && zs.avail_out == 0 && zs.avail_in == 0;
-                if (!done || (uint32_t)crc32(crc32(0L, Z_NULL, 0), obuf.data() + m.out_off, m.isize) != m.crc) ok = false;
+                if (!done || (uint32_t)crc32(crc32(0L, Z_NULL, 0), out + m.out_off, m.isize) != m.crc) ok = false;
             }
             inflateEnd(&zs);
         };
@@ -500,7 +502,7 @@ struct BgzfSource : ByteSource {
         for (auto &x : th) x.join();
         if (!ok) { bad = true; return false; }
         c_lo += scan;
-        o_hi = out_total;
+        *produced = out_total;
         return true;
     }
     size_t read(uint8_t *dst, size_t cap) override {
@@ -513,9 +515,18 @@ struct BgzfSource : ByteSource {
                 continue;
             }
             if (o_lo == o_hi) {
-                if (!refill()) break; // end of input or error
-                if (tail) continue;
-                if (o_lo == o_hi) continue; // a batch of empty members (the EOF marker): look further
+                size_t got = 0;
+                if (cap - n >= ((size_t)1 << 20)) { // room for a batch: inflate straight into the caller's buffer
+                    if (!refill(dst + n, cap - n, &got)) break; // end of input or error
+                    n += got;
+                    continue;
+                }
+                const size_t own = BATCH * 65536;
+                if (obuf.size() < own) obuf.resize(own);
+                o_lo = o_hi = 0;
+                if (!refill(obuf.data(), own, &got)) break;
+                o_hi = got;
+                continue; // (tail set, an empty batch, or data to hand out: the loop sorts it out)
             }
             const size_t m = std::min(cap - n, o_hi - o_lo);
             memcpy(dst + n, obuf.data() + o_lo, m);
