@@ -50,6 +50,14 @@ struct KmerCount {
     uint32_t count, extra_count;
 };
 
+// the same without the k-mer bytes (they stay in the copy-out array, `row` says where): what the filters work on when a
+// 2 M-hash oversketch is about to be cut down to its final 10 000 -- no point in building 2 M strings first
+struct KmerRef {
+    uint64_t hash;
+    uint32_t count, extra_count;
+    uint32_t row;
+};
+
 struct Sketch {
     std::string name;
     uint64_t seq_length = 0, num_valid_kmers = 0;
@@ -60,7 +68,8 @@ struct Sketch {
 };
 
 // statistics.rs:30-47
-static std::vector<uint64_t> hist(const std::vector<KmerCount> &sketch) {
+template <class KC>
+static std::vector<uint64_t> hist(const std::vector<KC> &sketch) {
     uint64_t max_count = 0;
     for (const auto &k : sketch) max_count = std::max<uint64_t>(max_count, k.count);
     std::vector<uint64_t> counts(max_count, 0);
@@ -69,7 +78,8 @@ static std::vector<uint64_t> hist(const std::vector<KmerCount> &sketch) {
 }
 
 // filtering.rs:154-195
-static uint32_t guess_filter_threshold(const std::vector<KmerCount> &sketch, double filter_level) {
+template <class KC>
+static uint32_t guess_filter_threshold(const std::vector<KC> &sketch, double filter_level) {
     const std::vector<uint64_t> hist_data = hist(sketch);
     uint64_t total = 0;
     for (size_t i = 0; i < hist_data.size(); ++i) total += (uint64_t)(i + 1) * hist_data[i];
@@ -100,8 +110,9 @@ static uint32_t guess_filter_threshold(const std::vector<KmerCount> &sketch, dou
 }
 
 // filtering.rs:413-432
-static std::vector<KmerCount> filter_strands(const std::vector<KmerCount> &sketch, double ratio_cutoff) {
-    std::vector<KmerCount> filtered;
+template <class KC>
+static std::vector<KC> filter_strands(const std::vector<KC> &sketch, double ratio_cutoff) {
+    std::vector<KC> filtered;
     for (const auto &kmer : sketch) {
         if (kmer.count < 16) {
             filtered.push_back(kmer);
@@ -114,19 +125,20 @@ static std::vector<KmerCount> filter_strands(const std::vector<KmerCount> &sketc
 }
 
 // filtering.rs:329-343
-static std::vector<KmerCount> filter_abundance(const std::vector<KmerCount> &sketch, bool has_lo, uint32_t lo, bool has_hi,
-                                               uint32_t hi) {
+template <class KC>
+static std::vector<KC> filter_abundance(const std::vector<KC> &sketch, bool has_lo, uint32_t lo, bool has_hi, uint32_t hi) {
     const uint32_t lo_t = has_lo ? lo : 0u, hi_t = has_hi ? hi : UINT32_MAX;
-    std::vector<KmerCount> filtered;
+    std::vector<KC> filtered;
     for (const auto &kmer : sketch)
         if (lo_t <= kmer.count && kmer.count <= hi_t) filtered.push_back(kmer);
     return filtered;
 }
 
 // FilterParams::filter_counts (filtering.rs:60-87); updates `fp` like the reference updates self
-static std::vector<KmerCount> filter_counts(finch_filter_params &fp, const std::vector<KmerCount> &hashes) {
+template <class KC>
+static std::vector<KC> filter_counts(finch_filter_params &fp, const std::vector<KC> &hashes) {
     const bool filter_on = fp.filter_on == 1;
-    std::vector<KmerCount> filtered = hashes;
+    std::vector<KC> filtered = hashes;
     if (filter_on && fp.strand_filter > 0.0) filtered = filter_strands(filtered, fp.strand_filter);
     if (filter_on && fp.err_filter > 0.0) {
         const uint32_t cutoff = guess_filter_threshold(filtered, fp.err_filter);
@@ -143,7 +155,8 @@ static std::vector<KmerCount> filter_counts(finch_filter_params &fp, const std::
 }
 
 // SketchParams::process_post_filter (mod.rs:115-128)
-static int process_post_filter(const finch_sketch_params &sp, std::vector<KmerCount> &kmers, const std::string &name) {
+template <class KC>
+static int process_post_filter(const finch_sketch_params &sp, std::vector<KC> &kmers, const std::string &name) {
     if (sp.kind == 0) {
         if (kmers.size() > sp.final_size) kmers.resize(sp.final_size);
         if (!sp.no_strict && kmers.size() < sp.final_size)
@@ -1198,16 +1211,20 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     std::vector<uint32_t> cs(n), es(n);
     std::vector<uint8_t> km(n * (size_t)k + 1);
     if (int rc = fh_copy_out(h, hs.data(), cs.data(), es.data(), km.data(), nullptr)) return hfail(rc, "%s", fh_last_error());
-    std::vector<KmerCount> hashes(n);
-    for (uint64_t i = 0; i < n; ++i)
-        hashes[i] = KmerCount{hs[i], std::string((const char *)km.data() + i * k, k), cs[i], es[i]};
-    std::vector<KmerCount> filtered = filter_counts(fp, hashes);          // lib.rs:82
+    if (n > UINT32_MAX) return hfail(FH_ERR_UNSUPPORTED, "sketch of %llu hashes", (unsigned long long)n);
+    std::vector<KmerRef> hashes(n);
+    for (uint64_t i = 0; i < n; ++i) hashes[i] = KmerRef{hs[i], cs[i], es[i], (uint32_t)i};
+    std::vector<KmerRef> filtered = filter_counts(fp, hashes);            // lib.rs:82
     if (int rc = process_post_filter(sp, filtered, name)) return rc;      // lib.rs:83
     out.name = name;
     out.seq_length = st.total_bases;
     out.num_valid_kmers = total_kmers;
     out.comment = "";
-    out.hashes.swap(filtered);
+    out.hashes.resize(filtered.size());
+    for (size_t i = 0; i < filtered.size(); ++i) {
+        const KmerRef &r = filtered[i];
+        out.hashes[i] = KmerCount{r.hash, std::string((const char *)km.data() + (size_t)r.row * k, k), r.count, r.extra_count};
+    }
     out.filter_params = fp;
     out.sketch_params = sp;
     return FH_OK;
