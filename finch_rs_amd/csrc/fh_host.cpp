@@ -113,6 +113,7 @@ static uint32_t guess_filter_threshold(const std::vector<KC> &sketch, double fil
 template <class KC>
 static std::vector<KC> filter_strands(const std::vector<KC> &sketch, double ratio_cutoff) {
     std::vector<KC> filtered;
+    filtered.reserve(sketch.size());
     for (const auto &kmer : sketch) {
         if (kmer.count < 16) {
             filtered.push_back(kmer);
@@ -129,6 +130,7 @@ template <class KC>
 static std::vector<KC> filter_abundance(const std::vector<KC> &sketch, bool has_lo, uint32_t lo, bool has_hi, uint32_t hi) {
     const uint32_t lo_t = has_lo ? lo : 0u, hi_t = has_hi ? hi : UINT32_MAX;
     std::vector<KC> filtered;
+    filtered.reserve(sketch.size());
     for (const auto &kmer : sketch)
         if (lo_t <= kmer.count && kmer.count <= hi_t) filtered.push_back(kmer);
     return filtered;
@@ -136,9 +138,9 @@ static std::vector<KC> filter_abundance(const std::vector<KC> &sketch, bool has_
 
 // FilterParams::filter_counts (filtering.rs:60-87); updates `fp` like the reference updates self
 template <class KC>
-static std::vector<KC> filter_counts(finch_filter_params &fp, const std::vector<KC> &hashes) {
+static std::vector<KC> filter_counts(finch_filter_params &fp, std::vector<KC> hashes) { // (by value: callers that are done with it move it in)
     const bool filter_on = fp.filter_on == 1;
-    std::vector<KC> filtered = hashes;
+    std::vector<KC> filtered = std::move(hashes);
     if (filter_on && fp.strand_filter > 0.0) filtered = filter_strands(filtered, fp.strand_filter);
     if (filter_on && fp.err_filter > 0.0) {
         const uint32_t cutoff = guess_filter_threshold(filtered, fp.err_filter);
@@ -1207,14 +1209,16 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     if (device_parse && st.format == 2)
         if (int rc = fh_text_bases(h, &st.total_bases)) return hfail(rc, "%s", fh_last_error());
     const uint32_t k = sp.kmer_length;
-    std::vector<uint64_t> hs(n);
-    std::vector<uint32_t> cs(n), es(n);
-    std::vector<uint8_t> km(n * (size_t)k + 1);
-    if (int rc = fh_copy_out(h, hs.data(), cs.data(), es.data(), km.data(), nullptr)) return hfail(rc, "%s", fh_last_error());
     if (n > UINT32_MAX) return hfail(FH_ERR_UNSUPPORTED, "sketch of %llu hashes", (unsigned long long)n);
-    std::vector<KmerRef> hashes(n);
-    for (uint64_t i = 0; i < n; ++i) hashes[i] = KmerRef{hs[i], cs[i], es[i], (uint32_t)i};
-    std::vector<KmerRef> filtered = filter_counts(fp, hashes);            // lib.rs:82
+    // (arrays the library fills completely: allocated without zeroing -- 2 M hashes are 100 MB here)
+    std::unique_ptr<fh_kmer_count[]> recs(new fh_kmer_count[n ? n : 1]);
+    std::unique_ptr<uint8_t[]> km(new uint8_t[n * (size_t)k + 1]);
+    if (int rc = fh_copy_out_records(h, recs.get(), km.get(), nullptr)) return hfail(rc, "%s", fh_last_error());
+    std::vector<KmerRef> hashes;
+    hashes.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) hashes.push_back(KmerRef{recs[i].hash, recs[i].count, recs[i].extra_count, (uint32_t)i});
+    recs.reset();
+    std::vector<KmerRef> filtered = filter_counts(fp, std::move(hashes)); // lib.rs:82
     if (int rc = process_post_filter(sp, filtered, name)) return rc;      // lib.rs:83
     out.name = name;
     out.seq_length = st.total_bases;
@@ -1223,7 +1227,7 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     out.hashes.resize(filtered.size());
     for (size_t i = 0; i < filtered.size(); ++i) {
         const KmerRef &r = filtered[i];
-        out.hashes[i] = KmerCount{r.hash, std::string((const char *)km.data() + (size_t)r.row * k, k), r.count, r.extra_count};
+        out.hashes[i] = KmerCount{r.hash, std::string((const char *)km.get() + (size_t)r.row * k, k), r.count, r.extra_count};
     }
     out.filter_params = fp;
     out.sketch_params = sp;
