@@ -1155,20 +1155,45 @@ static int fasta_text_to_device(ByteSource &src, fh_sketcher *h, FastxStats &st)
     return FH_OK;
 }
 
+// The sketchers of one worker.  With filtering off, a Mash sketch of `kmers_to_sketch` hashes that is then truncated to
+// `final_size` (mod.rs:115-128) is hash for hash, count for count the sketch of `final_size` hashes: the bottom
+// final_size of the bottom kmers_to_sketch are the bottom final_size, and the counts are exact occurrence counts either
+// way.  The CLI's defaults oversketch 200-fold, and FASTA input defaults to filtering off (lib.rs:70-76), so
+// `finch sketch *.fa` only ever needs the small sketcher (a batch of 5 Mb genomes: 1160 -> 4900 files/s); FASTQ input
+// (filtering on by default) and explicit filters get the full one.  Both are created on first use.
+struct HandleSet {
+    fh_params full{};
+    uint64_t final_size = 0;
+    int device = 0;
+    fh_sketcher *h_full = nullptr, *h_small = nullptr;
+    fh_sketcher *get(bool small) {
+        fh_sketcher *&h = small ? h_small : h_full;
+        if (!h) {
+            fh_params p = full;
+            if (small) p.size = final_size;
+            h = fh_new(&p, device);
+        }
+        return h;
+    }
+    ~HandleSet() {
+        if (h_full) fh_free(h_full);
+        if (h_small) fh_free(h_small);
+    }
+};
+
 static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &name, const finch_sketch_params &sp,
-                         const finch_filter_params &filters, fh_sketcher *h, Sketch &out) {
+                         const finch_filter_params &filters, HandleSet &handles, Sketch &out) {
     std::unique_ptr<ByteSource> src;
     bool is_gz = false;
     int first = -1;
     if (int rc = open_source(std::move(raw), src, &is_gz, &first)) return rc;
-    if (int rc = fh_reset(h)) return hfail(rc, "%s", fh_last_error());
     FastxStats st;
     const char *dp = getenv("FINCH_DEVICE_PARSE");
     // FINCH_DEVICE_PARSE: unset = plain FASTA and FASTQ text is split on the device (FASTQ with the host parser as the
     // fallback, see below); 1 = on the device, no fallback; 0 = on the host.  Compressed input is inflated on the host
     // and its text treated the same way.
     const bool dp_on = dp && dp[0] == '1', dp_off = dp && dp[0] == '0';
-    if (is_gz && !dp_off) {
+    if (is_gz) {
         // compressed: the format shows in the first inflated byte; what follows it reaches the staging buffer straight
         // from the decompressor, so the host only inflates (gzip: one thread, BGZF: the call's read threads)
         uint8_t b = 0;
@@ -1179,6 +1204,13 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
         src = std::move(pre);
         first = g ? (int)b : -1;
     }
+    // which sketcher: needletail takes the format from the first byte, and the format decides the filtering default
+    const int filter_on_eff = filters.filter_on < 0 ? (first == '@' ? 1 : 0) : filters.filter_on;
+    const bool small = (first == '>' || first == '@') && sp.kind == 0 && filter_on_eff == 0 && sp.final_size >= 1 &&
+                       sp.final_size < sp.kmers_to_sketch && getenv("FINCH_NO_SMALL_SKETCHER") == nullptr;
+    fh_sketcher *h = handles.get(small);
+    if (!h) return hfail(FH_ERR_NO_DEVICE, "%s", fh_last_error());
+    if (int rc = fh_reset(h)) return hfail(rc, "%s", fh_last_error());
     bool device_parse = !dp_off && (first == '>' || first == '@');
     if (device_parse && first == '@' && !dp_on && !src->can_rewind()) device_parse = false; // no second chance: host parser
     if (device_parse && first == '@') {
@@ -1435,13 +1467,13 @@ static uint64_t env_max_launch() {
 int finch_sketch_buffer(const uint8_t *data, uint64_t len, const char *name, const finch_sketch_params *sp,
                         const finch_filter_params *filters, int device, finch_sketches **out) {
     if ((!data && len) || !sp || !filters || !out) return hfail(FH_ERR_INVALID, "null argument");
-    fh_params p = to_fh(*sp, env_max_launch());
-    fh_sketcher *h = fh_new(&p, device);
-    if (!h) return hfail(FH_ERR_NO_DEVICE, "%s", fh_last_error());
+    HandleSet handles;
+    handles.full = to_fh(*sp, env_max_launch());
+    handles.final_size = sp->final_size;
+    handles.device = device;
     auto res = std::make_unique<finch_sketches>();
     res->v.resize(1);
-    const int rc = sketch_stream(std::make_unique<MemSource>(data, (size_t)len), name ? name : "", *sp, *filters, h, res->v[0]);
-    fh_free(h);
+    const int rc = sketch_stream(std::make_unique<MemSource>(data, (size_t)len), name ? name : "", *sp, *filters, handles, res->v[0]);
     if (rc != FH_OK) return rc;
     *out = res.release();
     return FH_OK;
@@ -1483,28 +1515,23 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
     const unsigned read_total = std::min(rt_env ? (unsigned)std::max(1, atoi(rt_env)) : 8u, 16u);
     const unsigned read_threads = std::max(1u, read_total / n_threads);
     auto worker = [&](uint32_t w) {
-        fh_params p = to_fh(*sp, batch ? ml : single_ml, batch ? (16ull << 20) : single_stage);
-        fh_sketcher *h = nullptr;
+        HandleSet handles;
+        handles.full = to_fh(*sp, batch ? ml : single_ml, batch ? (16ull << 20) : single_stage);
+        handles.final_size = sp->final_size;
+        handles.device = devs[w % devs.size()];
         for (;;) {
             const uint32_t i = next.fetch_add(1);
             if (i >= n_files) break;
             int rc = FH_OK;
             std::string msg;
-            if (!h) {
-                h = fh_new(&p, devs[w % devs.size()]);
-                if (!h) {
-                    rc = FH_ERR_NO_DEVICE;
-                    msg = fh_last_error();
-                }
-            }
-            if (rc == FH_OK) {
+            {
                 const std::string fn = filenames[i];
                 FILE *f = fn == "-" ? stdin : fopen(fn.c_str(), "rb");
                 if (!f) {
                     rc = FH_ERR_INVALID;
                     msg = fn + ": " + strerror(errno) + " (os error " + std::to_string(errno) + ")";
                 } else {
-                    rc = sketch_stream(std::make_unique<FileSource>(f, f != stdin, read_threads), fn, *sp, *filters, h, res->v[i]);
+                    rc = sketch_stream(std::make_unique<FileSource>(f, f != stdin, read_threads), fn, *sp, *filters, handles, res->v[i]);
                     if (rc != FH_OK) msg = g_host_err;
                 }
             }
@@ -1517,7 +1544,6 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
                 }
             }
         }
-        if (h) fh_free(h);
     };
     std::vector<std::thread> th;
     for (uint32_t w = 0; w < n_threads; ++w) th.emplace_back(worker, w);

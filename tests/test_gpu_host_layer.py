@@ -371,3 +371,26 @@ def test_compressed_text_goes_through_the_device_side_splitters(tmp_path, monkey
             monkeypatch.setenv("FINCH_DEVICE_PARSE", mode)
         with pytest.raises(FinchError):
             H.sketch_files([str(tmp_path / "t.fq.gz")], p, H.FilterParams(None))
+
+
+def test_oversketch_without_filtering_uses_the_small_sketcher_and_changes_nothing(tmp_path, monkeypatch):
+    """Mash, filtering off: bottom final_size of bottom kmers_to_sketch == bottom final_size, counts included, so the
+    host layer sketches final_size hashes directly -- the result (JSON too) must equal the oversketched one"""
+    g = S.synth_genome_host(2_000_000, 21)
+    fa = tmp_path / "g.fa"
+    fa.write_bytes(b">g\n" + b"\n".join(g.tobytes()[i:i + 80] for i in range(0, len(g), 80)) + b"\n")
+    reads = S.synth_reads_host(g, 0, 30000, 150, 21, 10000, 500).reshape(30000, 151)[:, :150]
+    fq = tmp_path / "r.fq"
+    fq.write_bytes(b"".join(b"@r%d\n" % i + reads[i].tobytes() + b"\n+\n" + b"I" * 150 + b"\n" for i in range(len(reads))))
+    p = SketchParams.mash(50_000, 700, True, 21, 0)  # no_strict: the abundance filter empties the genome's sketch
+    for filt in (H.FilterParams(None), H.FilterParams(False), H.FilterParams(True, (2, None), 0.0, 0.0)):
+        monkeypatch.setenv("FINCH_NO_SMALL_SKETCHER", "1")
+        want = H.sketch_files([str(fa), str(fq)], p, filt)
+        monkeypatch.delenv("FINCH_NO_SMALL_SKETCHER")
+        got = H.sketch_files([str(fa), str(fq)], p, filt)
+        assert got.to_json() == want.to_json()
+        for i in range(2):
+            a, b = want.sketch(i), got.sketch(i)
+            assert len(b.arrays[0]) <= 700
+            assert np.array_equal(a.arrays[0], b.arrays[0]) and np.array_equal(a.arrays[1], b.arrays[1])
+            assert (a.seq_length, a.num_valid_kmers, a.filter_params) == (b.seq_length, b.num_valid_kmers, b.filter_params)
