@@ -1705,6 +1705,23 @@ int finch_read_file_probe(const char *path, uint64_t chunk, uint32_t read_thread
     return FH_OK;
 }
 
+// What the parsers and the device-side text paths read from an input image after magic-byte sniffing and decompression,
+// requested `chunk` bytes at a time (large requests take BgzfSource's inflate-into-the-caller's-buffer route).
+int finch_source_probe(const uint8_t *data, uint64_t len, uint64_t chunk, uint8_t *dst, uint64_t cap, uint64_t *got) {
+    if ((!data && len) || !dst || !got || chunk == 0) return hfail(FH_ERR_INVALID, "bad argument");
+    std::unique_ptr<ByteSource> src;
+    if (int rc = open_source(std::make_unique<MemSource>(data, (size_t)len), src)) return rc;
+    uint64_t n = 0;
+    while (n < cap) {
+        const size_t g = src->read(dst + n, (size_t)std::min<uint64_t>(chunk, cap - n));
+        if (g == 0) break;
+        n += g;
+    }
+    if (src->failed()) return hfail(FH_ERR_INVALID, "corrupt compressed stream");
+    *got = n;
+    return FH_OK;
+}
+
 // The record / total_bases bookkeeping of the device-side FASTA path (FastaCounter), fed in chunks of `chunk` bytes cut
 // the way fasta_text_to_device cuts them: lets the host-only tests check it against finch_fastx_scan without a GPU.
 int finch_fasta_count_chunked(const uint8_t *data, uint64_t len, uint64_t chunk, uint64_t *n_records, uint64_t *total_bases) {

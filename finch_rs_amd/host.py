@@ -82,6 +82,7 @@ _SYMS = {
     "finch_fastx_scan": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "finch_fasta_count_chunked": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "finch_read_file_probe": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "finch_source_probe": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
 }
 class CDistance(C.Structure):
     _fields_ = [("containment", C.c_double), ("jaccard", C.c_double), ("mash_distance", C.c_double),
@@ -216,6 +217,15 @@ def fasta_count_chunked(data: bytes, chunk: int):
     buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
     _check(lib().finch_fasta_count_chunked(buf.ctypes.data, len(data), chunk, C.byref(n), C.byref(tb)))
     return n.value, tb.value
+
+
+def source_probe(data: bytes, chunk: int, cap: int) -> bytes:
+    """the (decompressed) byte stream the parsers see for an input image, read `chunk` bytes at a time (test hook)"""
+    src = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+    buf = np.zeros(max(cap, 1), np.uint8)
+    got = C.c_uint64()
+    _check(lib().finch_source_probe(src.ctypes.data, len(data), chunk, buf.ctypes.data, cap, C.byref(got)))
+    return buf[:got.value].tobytes()
 
 
 def read_file_probe(path: str, chunk: int, read_threads: int, cap: int) -> bytes:

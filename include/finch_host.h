@@ -120,6 +120,10 @@ int finch_fasta_count_chunked(const uint8_t *data, uint64_t len, uint64_t chunk,
  * a regular file are split over `read_threads` threads) into dst[0, cap); *got = bytes delivered. */
 int finch_read_file_probe(const char *path, uint64_t chunk, uint32_t read_threads, uint8_t *dst, uint64_t cap, uint64_t *got);
 
+/* Test hook: the byte stream the parsers see for an input image (magic-byte sniffing, gzip / BGZF / bzip2 / xz
+ * decompression), read in requests of `chunk` bytes into dst[0, cap); *got = bytes delivered. */
+int finch_source_probe(const uint8_t *data, uint64_t len, uint64_t chunk, uint8_t *dst, uint64_t cap, uint64_t *got);
+
 #ifdef __cplusplus
 }
 #endif
