@@ -45,7 +45,18 @@ def _run(cmd):
 def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= _newest_src():
         return OUT
+    # several processes may get here at once (the ranks of a torch.distributed.run launch on a fresh checkout): one
+    # builds, the others wait for the lock and find the library there
+    import fcntl
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= _newest_src():
+            return OUT
+        return _build_locked(verbose)
+
+
+def _build_locked(verbose):
     jobs = []
     for part in range(NPARTS):
         jobs.append([HIPCC] + FLAGS + K2_FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2.hip", "-o", os.path.join(OBJ, "fh_k2_%d.o" % part)])
@@ -61,7 +72,9 @@ def build(force=False, verbose=False):
             if o.strip():
                 print(o)
     objs = [j[-1] for j in jobs]
-    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lz", "-lpthread", "-ldl"])
+    tmp = OUT + ".tmp.%d" % os.getpid()  # never let a reader dlopen a half-written library
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + ["-lz", "-lpthread", "-ldl"])
+    os.replace(tmp, OUT)
     return OUT
 
 

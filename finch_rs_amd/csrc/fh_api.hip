@@ -45,6 +45,36 @@ int fail(int code, const char *fmt, ...) {
         if (_e != hipSuccess) return fail(FH_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
+// Device / pinned allocations made while a handle is in use.  fh_free parks reset handles (see "handle cache" below) and
+// those keep their device memory; before an allocation is allowed to fail for lack of memory the parked handles are
+// given back and it is tried once more.
+template <class T>
+hipError_t dev_malloc(T **p, size_t bytes) {
+    hipError_t e = hipMalloc((void **)p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        fh_release_cached();
+        (void)hipSetDevice(dev);
+        e = hipMalloc((void **)p, bytes);
+    }
+    return e;
+}
+template <class T>
+hipError_t host_malloc(T **p, size_t bytes) {
+    hipError_t e = hipHostMalloc((void **)p, bytes, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        fh_release_cached();
+        (void)hipSetDevice(dev);
+        e = hipHostMalloc((void **)p, bytes, hipHostMallocDefault);
+    }
+    return e;
+}
+
 constexpr uint64_t DEFAULT_MAX_LAUNCH = 256ull * 32 * TILE_POS; // k-mer start positions in flight (upper bound on the waves)
 constexpr uint64_t FIRST_LAUNCH = 4096;
 constexpr uint64_t SMALL_N_MAX = 3000; // largest kmers_to_sketch served by the in-LDS selection alone
@@ -252,8 +282,8 @@ int alloc_shards(fh_sketcher *s, uint64_t live_target) {
     if (s->shard_buf && cap <= s->shard_cap) return FH_OK;
     if (s->shard_buf) (void)hipFree(s->shard_buf);
     s->shard_buf = nullptr;
-    if (!s->shard_cnt) HIP_TRY(hipMalloc(&s->shard_cnt, (size_t)N_SHARDS * SHARD_STRIDE * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&s->shard_buf, (size_t)N_SHARDS * cap * sizeof(uint32_t)));
+    if (!s->shard_cnt) HIP_TRY(dev_malloc(&s->shard_cnt, (size_t)N_SHARDS * SHARD_STRIDE * sizeof(uint32_t)));
+    HIP_TRY(dev_malloc(&s->shard_buf, (size_t)N_SHARDS * cap * sizeof(uint32_t)));
     s->shard_cap = cap;
     return FH_OK;
 }
@@ -546,13 +576,13 @@ int ensure_big_buffers(fh_sketcher *s, uint32_t M) {
     if (s->keys_a) { (void)hipFree(s->keys_a); (void)hipFree(s->keys_b); (void)hipFree(s->slots_a); (void)hipFree(s->slots_b); (void)hipFree(s->sort_tmp); }
     s->keys_a = s->keys_b = nullptr; s->slots_a = s->slots_b = nullptr; s->sort_tmp = nullptr;
     const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)M + M / 2 + 1024, s->live_cap);
-    HIP_TRY(hipMalloc(&s->keys_a, (size_t)cap * 8));
-    HIP_TRY(hipMalloc(&s->keys_b, (size_t)cap * 8));
-    HIP_TRY(hipMalloc(&s->slots_a, (size_t)cap * 4));
-    HIP_TRY(hipMalloc(&s->slots_b, (size_t)cap * 4));
+    HIP_TRY(dev_malloc(&s->keys_a, (size_t)cap * 8));
+    HIP_TRY(dev_malloc(&s->keys_b, (size_t)cap * 8));
+    HIP_TRY(dev_malloc(&s->slots_a, (size_t)cap * 4));
+    HIP_TRY(dev_malloc(&s->slots_b, (size_t)cap * 4));
     HIP_TRY(big_sort_tmp_bytes(cap, &s->sort_tmp_bytes));
-    HIP_TRY(hipMalloc(&s->sort_tmp, s->sort_tmp_bytes ? s->sort_tmp_bytes : 16));
-    if (!s->keep_dev) HIP_TRY(hipMalloc(&s->keep_dev, 64 + SEL_SCRATCH_BYTES)); // [0,64) keep count, then select scratch
+    HIP_TRY(dev_malloc(&s->sort_tmp, s->sort_tmp_bytes ? s->sort_tmp_bytes : 16));
+    if (!s->keep_dev) HIP_TRY(dev_malloc(&s->keep_dev, 64 + SEL_SCRATCH_BYTES)); // [0,64) keep count, then select scratch
     s->big_cap = cap;
     return FH_OK;
 }
@@ -602,9 +632,9 @@ int grow_table(fh_sketcher *s, uint64_t new_live_cap) {
     if (new_cap >= (1ull << 32)) return fail(FH_ERR_CAPACITY, "sketch state would exceed 2^32 table slots");
     Entry *nt = nullptr;
     uint32_t *nl = nullptr, *nd = nullptr;
-    HIP_TRY(hipMalloc(&nt, new_cap * sizeof(Entry)));
-    HIP_TRY(hipMalloc(&nl, new_live_cap * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(&nd, new_live_cap * sizeof(uint32_t)));
+    HIP_TRY(dev_malloc(&nt, new_cap * sizeof(Entry)));
+    HIP_TRY(dev_malloc(&nl, new_live_cap * sizeof(uint32_t)));
+    HIP_TRY(dev_malloc(&nd, new_live_cap * sizeof(uint32_t)));
     HIP_TRY(launch_fill_table(nt, new_cap, s->stream));
     HIP_TRY(launch_rehash(s->table, s->live, s->last_live, nt, (uint32_t)new_cap, nl, s->ctl, s->stream));
     uint32_t zero = 0;
@@ -631,11 +661,11 @@ int ensure_out(fh_sketcher *s, uint32_t n) {
     (void)hipFree(s->o_hash); (void)hipFree(s->o_kmer); (void)hipFree(s->o_pos); (void)hipFree(s->o_count); (void)hipFree(s->o_extra);
     s->o_hash = s->o_kmer = s->o_pos = nullptr; s->o_count = s->o_extra = nullptr;
     const uint32_t cap = std::max<uint32_t>(n, (uint32_t)SMALL_MAX);
-    HIP_TRY(hipMalloc(&s->o_hash, (size_t)cap * 8));
-    HIP_TRY(hipMalloc(&s->o_kmer, (size_t)cap * 8));
-    HIP_TRY(hipMalloc(&s->o_pos, (size_t)cap * 8));
-    HIP_TRY(hipMalloc(&s->o_count, (size_t)cap * 4));
-    HIP_TRY(hipMalloc(&s->o_extra, (size_t)cap * 4));
+    HIP_TRY(dev_malloc(&s->o_hash, (size_t)cap * 8));
+    HIP_TRY(dev_malloc(&s->o_kmer, (size_t)cap * 8));
+    HIP_TRY(dev_malloc(&s->o_pos, (size_t)cap * 8));
+    HIP_TRY(dev_malloc(&s->o_count, (size_t)cap * 4));
+    HIP_TRY(dev_malloc(&s->o_extra, (size_t)cap * 4));
     s->out_cap = cap;
     return FH_OK;
 }
@@ -760,8 +790,9 @@ int fh_device_count(void) {
 // finch creates one sketcher per file and drops it after to_vec (lib.rs:58-79), and a sketcher here owns gigabytes of
 // table plus pinned staging memory: creating and freeing one costs ~5 ms, a 5 Mb genome ~1 ms to sketch.  fh_free
 // therefore resets the handle and parks it; the next fh_new with the same parameters on the same device takes it
-// over.  At most pool_max() handles (FH_POOL, default 64; 0 = off) holding at most 48 GB together stay parked;
-// fh_release_cached frees them.
+// over.  At most pool_max() handles (FH_POOL, default 64; 0 = off) holding at most pool_max_bytes() (FH_POOL_BYTES,
+// default 8 GiB) together stay parked; fh_release_cached frees them, and so does any allocation of the library that
+// would otherwise run out of memory.
 namespace {
 std::mutex g_pool_mu;
 std::vector<fh_sketcher *> g_pool;
@@ -772,7 +803,16 @@ size_t pool_max() {
     }();
     return v;
 }
-constexpr uint64_t POOL_MAX_BYTES = 48ull << 30; // device memory the parked handles may hold together
+// device memory the parked handles may hold together (FH_POOL_BYTES, default 8 GiB: room for the eight worker sketchers
+// per GPU of a finch_sketch_files batch, small next to 288 GB, and given back the moment any allocation of the library
+// would otherwise fail -- dev_malloc above; an embedding process that wants it all back calls fh_release_cached)
+uint64_t pool_max_bytes() {
+    static const uint64_t v = [] {
+        const char *e = getenv("FH_POOL_BYTES");
+        return e ? (uint64_t)strtoull(e, nullptr, 10) : (8ull << 30);
+    }();
+    return v;
+}
 uint64_t handle_bytes(const fh_sketcher *s) {
     uint64_t b = (uint64_t)s->cap * sizeof(Entry) + (uint64_t)s->live_cap * 8 + (uint64_t)s->shard_cap * N_SHARDS * 4;
     for (int i = 0; i < N_STAGE; ++i) b += 2 * s->stage_cap[i];
@@ -807,6 +847,12 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
                 s->n_launches = s->n_relaunches = s->n_big_prunes = 0;
                 s->n_spec = s->n_spec_fallback = 0;
                 s->profiling = false;
+                // the environment knobs a handle reads at creation are the new owner's to set
+                s->no_spec = getenv("FH_NO_SPEC") != nullptr;
+                {
+                    const char *mr = getenv("FH_MAX_RANGE");
+                    s->max_range = mr ? strtoull(mr, nullptr, 10) : 0;
+                }
                 return s;
             }
         }
@@ -927,7 +973,7 @@ void fh_free(fh_sketcher *s) {
         std::lock_guard<std::mutex> g(g_pool_mu);
         uint64_t held = handle_bytes(s);
         for (const fh_sketcher *q : g_pool) held += handle_bytes(q);
-        if (g_pool.size() < pool_max() && held <= POOL_MAX_BYTES) {
+        if (g_pool.size() < pool_max() && held <= pool_max_bytes()) {
             g_pool.push_back(s);
             return;
         }
@@ -1101,8 +1147,8 @@ static int ensure_slot(fh_sketcher *s, int i, uint64_t want) {
         s->stage_cap[i] = 0;
         want = std::min<uint64_t>(std::max<uint64_t>(want, 2 * old_cap), s->stage_bytes); // grow geometrically
     }
-    HIP_TRY(hipHostMalloc((void **)&s->h_stage[i], want + 128, hipHostMallocDefault));
-    HIP_TRY(hipMalloc((void **)&s->d_stage[i], want + 128));
+    HIP_TRY(host_malloc((void **)&s->h_stage[i], want + 128));
+    HIP_TRY(dev_malloc((void **)&s->d_stage[i], want + 128));
     s->stage_cap[i] = want;
     return FH_OK;
 }
@@ -1167,13 +1213,13 @@ int fh_push_fastq_text(fh_sketcher *s, uint64_t len) {
     const int b = s->stage_next;
     const uint64_t nblk = (s->stage_bytes + 4095) / 4096 + 1;
     if (!s->d_packed[b]) {
-        HIP_TRY(hipMalloc((void **)&s->d_packed[b], s->stage_bytes + 64));
-        HIP_TRY(hipMalloc((void **)&s->d_blk_a[b], nblk * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **)&s->d_blk_b[b], nblk * sizeof(uint32_t)));
+        HIP_TRY(dev_malloc((void **)&s->d_packed[b], s->stage_bytes + 64));
+        HIP_TRY(dev_malloc((void **)&s->d_blk_a[b], nblk * sizeof(uint32_t)));
+        HIP_TRY(dev_malloc((void **)&s->d_blk_b[b], nblk * sizeof(uint32_t)));
     }
     if (!s->d_text_tot) {
-        HIP_TRY(hipMalloc((void **)&s->d_text_tot, 4 * sizeof(uint32_t)));
-        HIP_TRY(hipHostMalloc((void **)&s->h_text_tot, 4 * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(dev_malloc((void **)&s->d_text_tot, 4 * sizeof(uint32_t)));
+        HIP_TRY(host_malloc((void **)&s->h_text_tot, 4 * sizeof(uint32_t)));
     }
     // the packed buffer of this slot may still feed a pending range
     if (int rc = drain(s)) return rc;
@@ -1211,13 +1257,13 @@ int fh_push_fasta_text(fh_sketcher *s, uint64_t len, uint32_t start_state, uint3
     const int b = s->stage_next;
     const uint64_t nblk = (s->stage_bytes + 4095) / 4096 + 1;
     if (!s->d_packed[b]) {
-        HIP_TRY(hipMalloc((void **)&s->d_packed[b], s->stage_bytes + 64));
-        HIP_TRY(hipMalloc((void **)&s->d_blk_a[b], nblk * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **)&s->d_blk_b[b], nblk * sizeof(uint32_t)));
+        HIP_TRY(dev_malloc((void **)&s->d_packed[b], s->stage_bytes + 64));
+        HIP_TRY(dev_malloc((void **)&s->d_blk_a[b], nblk * sizeof(uint32_t)));
+        HIP_TRY(dev_malloc((void **)&s->d_blk_b[b], nblk * sizeof(uint32_t)));
     }
     if (!s->d_text_tot) {
-        HIP_TRY(hipMalloc((void **)&s->d_text_tot, 4 * sizeof(uint32_t)));
-        HIP_TRY(hipHostMalloc((void **)&s->h_text_tot, 4 * sizeof(uint32_t), hipHostMallocDefault));
+        HIP_TRY(dev_malloc((void **)&s->d_text_tot, 4 * sizeof(uint32_t)));
+        HIP_TRY(host_malloc((void **)&s->h_text_tot, 4 * sizeof(uint32_t)));
     }
     // the packed buffer of this slot may still feed a pending range
     if (int rc = drain(s)) return rc;
@@ -1310,7 +1356,7 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
             if (s->h_out) (void)hipHostFree(s->h_out);
             s->h_out = nullptr;
             s->h_out_bytes = 0;
-            HIP_TRY(hipHostMalloc(&s->h_out, need + need / 4, hipHostMallocDefault));
+            HIP_TRY(host_malloc(&s->h_out, need + need / 4));
             s->h_out_bytes = need + need / 4;
         }
         uint64_t *hh = (uint64_t *)s->h_out, *kk = hh + cap, *pp = kk + cap;
@@ -1596,7 +1642,7 @@ int fh_measure_read_bandwidth(int device, const void *dev_bytes, uint64_t bytes,
     if (!dev_bytes || !gb_per_s || bytes < 16) return fail(FH_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(device));
     uint32_t *sink = nullptr;
-    HIP_TRY(hipMalloc(&sink, 16));
+    HIP_TRY(dev_malloc(&sink, 16));
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -1620,7 +1666,7 @@ int fh_measure_read_bandwidth(int device, const void *dev_bytes, uint64_t bytes,
 int fh_device_alloc(int device, uint64_t bytes, void **out) {
     if (!out) return fail(FH_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(device));
-    HIP_TRY(hipMalloc(out, bytes ? bytes : 16));
+    HIP_TRY(dev_malloc(out, bytes ? bytes : 16));
     return FH_OK;
 }
 

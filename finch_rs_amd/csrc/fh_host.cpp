@@ -73,7 +73,10 @@ static std::vector<uint64_t> hist(const std::vector<KC> &sketch) {
     uint64_t max_count = 0;
     for (const auto &k : sketch) max_count = std::max<uint64_t>(max_count, k.count);
     std::vector<uint64_t> counts(max_count, 0);
-    for (const auto &k : sketch) counts[k.count - 1] += 1;
+    // (a count of 0 cannot come out of a sketcher -- push() starts every entry at 1, mash.rs:53 -- and the C ABI
+    // rejects caller-supplied arrays that hold one; skipped here as well so that no input can index below the array)
+    for (const auto &k : sketch)
+        if (k.count) counts[k.count - 1] += 1;
     return counts;
 }
 
@@ -119,7 +122,8 @@ static std::vector<KC> filter_strands(const std::vector<KC> &sketch, double rati
             filtered.push_back(kmer);
             continue;
         }
-        const uint32_t lowest = std::min(kmer.extra_count, kmer.count - kmer.extra_count);
+        // (extra_count <= count for everything a sketcher emits and everything the C ABI lets in)
+        const uint32_t lowest = std::min(kmer.extra_count, kmer.count - std::min(kmer.extra_count, kmer.count));
         if (((double)lowest / (double)kmer.count) >= ratio_cutoff) filtered.push_back(kmer);
     }
     return filtered;
@@ -1602,6 +1606,13 @@ int finch_sketches_from_arrays(const char *name, uint64_t seq_length, uint64_t n
                                const uint8_t *kmers, const finch_sketch_params *sp, const finch_filter_params *filters,
                                finch_sketches **out) {
     if (!sp || !filters || !out || (n && (!hashes || !counts || !extra_counts))) return hfail(FH_ERR_INVALID, "null argument");
+    // KmerCount invariants of the reference's sketchers (mash.rs:45-56: count starts at 1, extra_count is bumped with it):
+    // the filters index a histogram by count - 1 and subtract extra_count from count
+    for (uint64_t i = 0; i < n; ++i) {
+        if (counts[i] == 0) return hfail(FH_ERR_INVALID, "record %llu has count 0", (unsigned long long)i);
+        if (extra_counts[i] > counts[i])
+            return hfail(FH_ERR_INVALID, "record %llu has extra_count %u > count %u", (unsigned long long)i, extra_counts[i], counts[i]);
+    }
     auto res = std::make_unique<finch_sketches>();
     res->v.resize(1);
     Sketch &s = res->v[0];
@@ -1662,6 +1673,15 @@ int finch_distance(const finch_sketches *a, uint32_t ia, const finch_sketches *b
 }
 
 uint32_t finch_guess_filter_threshold(const uint32_t *counts, uint64_t n, double filter_level) {
+    if (n && !counts) {
+        hfail(FH_ERR_INVALID, "null argument");
+        return 0; // (a threshold is always >= 1)
+    }
+    for (uint64_t i = 0; i < n; ++i)
+        if (counts[i] == 0) {
+            hfail(FH_ERR_INVALID, "count %llu is 0", (unsigned long long)i);
+            return 0;
+        }
     std::vector<KmerCount> v(n);
     for (uint64_t i = 0; i < n; ++i) v[i] = KmerCount{i, std::string(), counts[i], 0};
     return guess_filter_threshold(v, filter_level);

@@ -70,8 +70,9 @@ int fh_abi_version(void);
 fh_sketcher *fh_new(const fh_params *params, int device);
 /* Drop a sketcher.  finch creates one per file and drops it after to_vec (lib.rs:58-79); since a sketcher owns
  * gigabytes of device memory, fh_free resets it and keeps up to FH_POOL (environment, default 64, 0 = never) of them
- * parked (48 GB of device memory at most), and fh_new hands a parked one back when the parameters and the device match (~0.1 ms instead of ~5 ms).
- * fh_release_cached frees what is parked. */
+ * parked -- FH_POOL_BYTES of device memory at most (environment, default 8 GiB) -- and fh_new hands a parked one back
+ * when the parameters and the device match (~0.1 ms instead of ~5 ms).  fh_release_cached frees what is parked; the
+ * library does so itself before any of its own allocations fails for lack of memory. */
 void fh_free(fh_sketcher *s);
 void fh_release_cached(void);
 /* forget everything pushed so far (state as after fh_new); keeps device memory */

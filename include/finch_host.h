@@ -98,7 +98,8 @@ int finch_raw_distance(const uint64_t *query, uint64_t nq, const uint64_t *ref, 
                        finch_distance_out *out);
 
 /* ---- pieces that need no GPU (unit-testable on the host) ---- */
-/* Build a one-sketch result from arrays (to exercise filtering / serialisation without a device). */
+/* Build a one-sketch result from arrays (to exercise filtering / serialisation without a device).  FH_ERR_INVALID for
+ * records no sketcher can emit: count == 0 or extra_count > count (mash.rs:45-56). */
 int finch_sketches_from_arrays(const char *name, uint64_t seq_length, uint64_t num_valid_kmers, uint64_t n,
                                const uint64_t *hashes, const uint32_t *counts, const uint32_t *extra_counts,
                                const uint8_t *kmers, const finch_sketch_params *sketch_params,
@@ -106,7 +107,8 @@ int finch_sketches_from_arrays(const char *name, uint64_t seq_length, uint64_t n
 /* filter_counts (filtering.rs:60-87) + process_post_filter (mod.rs:115-128) applied in place to sketch i;
  * `filters` is updated exactly as the reference updates its FilterParams. */
 int finch_apply_filters(finch_sketches *s, uint32_t i, finch_filter_params *filters);
-/* guess_filter_threshold (filtering.rs:154-195) */
+/* guess_filter_threshold (filtering.rs:154-195); counts must be >= 1.  Returns 0 (never a valid threshold) and sets
+ * finch_last_error for a null array or a zero count. */
 uint32_t finch_guess_filter_threshold(const uint32_t *counts, uint64_t n, double filter_level);
 /* FASTX scan only: number of records, sum of sequence() lengths (what total_bases counts, mash.rs:72) and
  * the format of the first record (1 FASTA, 2 FASTQ).  gz images are inflated first. */

@@ -25,6 +25,22 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+def use_native() -> str:
+    """Compile the oracle on THIS host with -march=native and bind that build (bench.py's cpu_baseline leg: the CPU
+    baseline is timed with the flags BASELINE.md names).  Falls back to the portable build if the compiler is missing.
+    Returns the flags in use."""
+    global _lib, _SO
+    native = os.path.join(_HERE, "libfinch_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"])
+    except Exception:
+        lib()
+        return "-O3 -march=x86-64-v2"
+    _SO, _lib = native, None
+    lib()
+    return "-O3 -march=native"
+
+
 class KmerCountC(C.Structure):
     _fields_ = [("hash", C.c_uint64), ("count", C.c_uint32), ("extra_count", C.c_uint32)]
 
@@ -35,7 +51,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if not _SO.endswith("_native.so"):
+            build()
         L = C.CDLL(_SO)
         L.fo_hash_f.restype = C.c_uint64
         L.fo_hash_f.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]

@@ -121,6 +121,28 @@ def test_filter_counts_matches_oracle_and_updates_params():
         sk3.apply_filters(0, H.FilterParams(False))
 
 
+def test_records_no_sketcher_can_emit_are_rejected_at_the_abi():
+    """count == 0 would index the count histogram at -1 (statistics.rs:30-47 panics there), extra_count > count would
+    underflow the strand filter (filtering.rs:424): caller-supplied arrays are checked at the boundary."""
+    params = SketchParams.mash(10, 10, True, 21, 0)
+    km = np.full((3, 21), ord("A"), np.uint8)
+    bad0 = kc_of([3, 0, 2])
+    bad0["hash"] = [1, 2, 3]
+    with pytest.raises(FinchError, match="count 0"):
+        H.sketches_from_arrays("x", 1, 2, bad0, km, params, H.FilterParams(False))
+    bad1 = kc_of([3, 1, 2], [0, 2, 0])
+    bad1["hash"] = [1, 2, 3]
+    with pytest.raises(FinchError, match="extra_count 2 > count 1"):
+        H.sketches_from_arrays("x", 1, 2, bad1, km, params, H.FilterParams(False))
+    assert H.guess_filter_threshold([4, 0, 1], 0.2) == 0  # 0 is never a threshold: error return
+    assert b"is 0" in H.lib().finch_last_error()
+    assert H.lib().finch_guess_filter_threshold(None, 5, 0.2) == 0
+    ok = kc_of([3, 1, 2], [0, 1, 2])
+    ok["hash"] = [1, 2, 3]
+    sk = H.sketches_from_arrays("x", 1, 2, ok, km, params, H.FilterParams(False))
+    sk.apply_filters(0, H.FilterParams(True, (None, None), 0.5, 0.1))
+
+
 def test_sk_json_writer_format():
     kc = kc_of([3, 1], [1, 0])
     kc["hash"] = [12345678901234567890, 18446744073709551615]
