@@ -42,6 +42,7 @@ SYMBOLS = {
     "fh_push_fastq_text": (C.c_int, [_P, C.c_uint64]),
     "fh_push_fasta_text": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32]),
     "fh_push_staged": (C.c_int, [_P, C.c_uint64, C.c_uint32]),
+    "fh_set_text_halo": (C.c_int, [_P, _P, C.c_uint32]),
     "fh_text_bases": (C.c_int, [_P, _U64P]),
     "fh_push_device": (C.c_int, [_P, _P, C.c_uint64]),
     "fh_sync": (C.c_int, [_P]),

@@ -165,8 +165,10 @@ struct fh_sketcher {
     uint32_t *d_text_tot = nullptr; // [0] newlines, [1] packed bytes, [2] error flag
     uint32_t *h_text_tot = nullptr; // pinned
     uint64_t text_bases = 0;
-    uint8_t carry[32] = {0}; // last K-1 staged bytes: k-mers span staging slices (and FH_PUSH_CONTINUE pushes)
+    uint8_t carry[64] = {0}; // last K-1 staged bytes: k-mers span staging slices (and FH_PUSH_CONTINUE pushes)
     uint32_t carry_len = 0;
+    uint8_t halo[64] = {0};  // fh_set_text_halo: packed bytes that precede the next fh_push_fasta_text chunk
+    uint32_t halo_len = 0;
     Ctl *h_ctl = nullptr; // pinned
     void *h_out = nullptr; // pinned staging of the finished sketch (fh_finish)
     size_t h_out_bytes = 0;
@@ -234,6 +236,7 @@ int init_state(fh_sketcher *s) {
     s->tau_lo = 0;
     s->carry_len = 0;
     s->dprev_len = 0;
+    s->halo_len = 0;
     s->live_target = s->big_mode ? std::max<uint64_t>(4 * s->p.size, 1ull << 16) : (uint64_t)SMALL_MAX;
     s->finished = false;
     s->dirty = false;
@@ -776,7 +779,7 @@ uint32_t sat_add(uint32_t a, uint32_t b) {
 
 extern "C" {
 
-int fh_abi_version(void) { return 1; }
+int fh_abi_version(void) { return 2; }
 
 const char *fh_last_error(void) { return g_err.c_str(); }
 
@@ -1253,6 +1256,9 @@ int fh_push_fasta_text(fh_sketcher *s, uint64_t len, uint32_t start_state, uint3
     if (int rc = set_device(s)) return rc;
     if (int rc = ensure_stage(s)) return rc;
     if (!(flags & FH_PUSH_CONTINUE)) s->dprev_len = 0;
+    const uint32_t halo_len = s->halo_len; // applies to this chunk only
+    s->halo_len = 0;
+    if (halo_len && (flags & FH_PUSH_CONTINUE)) return fail(FH_ERR_STATE, "fh_set_text_halo and FH_PUSH_CONTINUE exclude each other");
     if (len == 0) return FH_OK;
     const int b = s->stage_next;
     const uint64_t nblk = (s->stage_bytes + 4095) / 4096 + 1;
@@ -1268,13 +1274,15 @@ int fh_push_fasta_text(fh_sketcher *s, uint64_t len, uint32_t start_state, uint3
     // the packed buffer of this slot may still feed a pending range
     if (int rc = drain(s)) return rc;
     const uint64_t K = s->p.k;
-    const uint64_t carry_len = std::min<uint64_t>(K - 1, s->dprev_len);
+    const uint64_t carry_len = halo_len ? halo_len : std::min<uint64_t>(K - 1, s->dprev_len);
     uint8_t *dst = s->d_packed[b];
     HIP_TRY(hipMemsetAsync(s->d_text_tot, 0, 4 * sizeof(uint32_t), s->stream));
     HIP_TRY(hipMemcpyAsync(s->d_stage[b], s->h_stage[b] + STAGE_HEADROOM, len, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
     s->stage_busy[b] = true;
-    if (carry_len)
+    if (halo_len) // (the call synchronises the stream below, before s->halo can change)
+        HIP_TRY(hipMemcpyAsync(dst, s->halo, halo_len, hipMemcpyHostToDevice, s->stream));
+    else if (carry_len)
         HIP_TRY(hipMemcpyAsync(dst, s->dprev_ptr + s->dprev_len - carry_len, carry_len, hipMemcpyDeviceToDevice, s->stream));
     HIP_TRY(launch_fasta_pack(s->d_stage[b], len, start_state, dst + carry_len, s->d_blk_a[b], s->d_blk_b[b], s->d_text_tot,
                               s->stream));
@@ -1288,6 +1296,14 @@ int fh_push_fasta_text(fh_sketcher *s, uint64_t len, uint32_t start_state, uint3
     s->dprev_ptr = dst;
     s->dprev_len = carry_len + n_packed;
     return rc;
+}
+
+int fh_set_text_halo(fh_sketcher *s, const uint8_t *halo, uint32_t n) {
+    if (!s || (n && !halo)) return fail(FH_ERR_INVALID, "null argument");
+    if (n >= s->p.k || n > sizeof s->halo) return fail(FH_ERR_INVALID, "halo of %u bytes (at most k-1 = %u)", n, s->p.k - 1);
+    memcpy(s->halo, halo, n);
+    s->halo_len = n;
+    return FH_OK;
 }
 
 int fh_text_bases(fh_sketcher *s, uint64_t *total_bases) {

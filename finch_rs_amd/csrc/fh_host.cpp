@@ -12,6 +12,7 @@
 #include <atomic>
 #include <cerrno>
 #include <charconv>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -992,6 +993,11 @@ static int parse_fastx(ByteSource &src, RecordSink &sink, FastxStats &st) {
 // ---------------------------------------------------------------------------------------------
 // sketch_stream (lib.rs:51-94)
 // ---------------------------------------------------------------------------------------------
+static uint64_t env_max_launch_value() {
+    const char *e = getenv("FINCH_MAX_LAUNCH");
+    return e ? strtoull(e, nullptr, 10) : 0;
+}
+
 static fh_params to_fh(const finch_sketch_params &sp, uint64_t max_launch, uint64_t stage_bytes = 0) {
     fh_params p{};
     p.kind = sp.kind;
@@ -1185,6 +1191,41 @@ struct HandleSet {
     }
 };
 
+// to_vec -> filter_counts -> process_post_filter -> Sketch (lib.rs:70-93) from a sketcher that holds the whole input
+// (one handle, or the merge of the partial sketches of a sharded input)
+static int finish_sketch(fh_sketcher *h, const std::string &name, const finch_sketch_params &sp, const finch_filter_params &filters,
+                         const FastxStats &st, Sketch &out) {
+    finch_filter_params fp = filters;
+    // lib.rs:70-76: filtering defaults to off for FASTA, on for FASTQ
+    if (fp.filter_on < 0) fp.filter_on = st.format == 2 ? 1 : 0;
+    uint64_t n = 0, total_kmers = 0;
+    if (int rc = fh_finish(h, &n, &total_kmers)) return hfail(rc, "%s", fh_last_error());
+    const uint32_t k = sp.kmer_length;
+    if (n > UINT32_MAX) return hfail(FH_ERR_UNSUPPORTED, "sketch of %llu hashes", (unsigned long long)n);
+    // (arrays the library fills completely: allocated without zeroing -- 2 M hashes are 100 MB here)
+    std::unique_ptr<fh_kmer_count[]> recs(new fh_kmer_count[n ? n : 1]);
+    std::unique_ptr<uint8_t[]> km(new uint8_t[n * (size_t)k + 1]);
+    if (int rc = fh_copy_out_records(h, recs.get(), km.get(), nullptr)) return hfail(rc, "%s", fh_last_error());
+    std::vector<KmerRef> hashes;
+    hashes.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) hashes.push_back(KmerRef{recs[i].hash, recs[i].count, recs[i].extra_count, (uint32_t)i});
+    recs.reset();
+    std::vector<KmerRef> filtered = filter_counts(fp, std::move(hashes)); // lib.rs:82
+    if (int rc = process_post_filter(sp, filtered, name)) return rc;      // lib.rs:83
+    out.name = name;
+    out.seq_length = st.total_bases;
+    out.num_valid_kmers = total_kmers;
+    out.comment = "";
+    out.hashes.resize(filtered.size());
+    for (size_t i = 0; i < filtered.size(); ++i) {
+        const KmerRef &r = filtered[i];
+        out.hashes[i] = KmerCount{r.hash, std::string((const char *)km.get() + (size_t)r.row * k, k), r.count, r.extra_count};
+    }
+    out.filter_params = fp;
+    out.sketch_params = sp;
+    return FH_OK;
+}
+
 static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &name, const finch_sketch_params &sp,
                          const finch_filter_params &filters, HandleSet &handles, Sketch &out) {
     std::unique_ptr<ByteSource> src;
@@ -1237,37 +1278,330 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
         if (int rc = parse_fastx(*src, sink, st)) return rc;
         if (int rc = sink.flush()) return rc;
     }
-    finch_filter_params fp = filters;
-    // lib.rs:70-76: filtering defaults to off for FASTA, on for FASTQ
-    if (fp.filter_on < 0) fp.filter_on = st.format == 2 ? 1 : 0;
-    uint64_t n = 0, total_kmers = 0;
-    if (int rc = fh_finish(h, &n, &total_kmers)) return hfail(rc, "%s", fh_last_error());
-    if (device_parse && st.format == 2)
+    if (device_parse && st.format == 2) {
         if (int rc = fh_text_bases(h, &st.total_bases)) return hfail(rc, "%s", fh_last_error());
-    const uint32_t k = sp.kmer_length;
-    if (n > UINT32_MAX) return hfail(FH_ERR_UNSUPPORTED, "sketch of %llu hashes", (unsigned long long)n);
-    // (arrays the library fills completely: allocated without zeroing -- 2 M hashes are 100 MB here)
-    std::unique_ptr<fh_kmer_count[]> recs(new fh_kmer_count[n ? n : 1]);
-    std::unique_ptr<uint8_t[]> km(new uint8_t[n * (size_t)k + 1]);
-    if (int rc = fh_copy_out_records(h, recs.get(), km.get(), nullptr)) return hfail(rc, "%s", fh_last_error());
-    std::vector<KmerRef> hashes;
-    hashes.reserve(n);
-    for (uint64_t i = 0; i < n; ++i) hashes.push_back(KmerRef{recs[i].hash, recs[i].count, recs[i].extra_count, (uint32_t)i});
-    recs.reset();
-    std::vector<KmerRef> filtered = filter_counts(fp, std::move(hashes)); // lib.rs:82
-    if (int rc = process_post_filter(sp, filtered, name)) return rc;      // lib.rs:83
-    out.name = name;
-    out.seq_length = st.total_bases;
-    out.num_valid_kmers = total_kmers;
-    out.comment = "";
-    out.hashes.resize(filtered.size());
-    for (size_t i = 0; i < filtered.size(); ++i) {
-        const KmerRef &r = filtered[i];
-        out.hashes[i] = KmerCount{r.hash, std::string((const char *)km.get() + (size_t)r.row * k, k), r.count, r.extra_count};
     }
-    out.filter_params = fp;
-    out.sketch_params = sp;
-    return FH_OK;
+    return finish_sketch(h, name, sp, filters, st, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One input across several devices (north_star: "a single large input is partitioned by read blocks across the
+// GPUs of one node with a final host-side merge of the tiny partial sketches").  The reference parallelises over
+// files only (lib.rs:34-36); this goes beyond it on the strength of SURVEY 8e: a sketch is a function of the multiset
+// of k-mers, so the partial sketches of any partition of the input merge exactly.
+//
+// One reader (the calling thread) cuts the decompressed text into chunks -- FASTQ: after a whole record; FASTA: after
+// a newline -- and deals them round-robin to one worker per device handle.  A worker copies its chunk into its
+// handle's pinned staging buffer, tells the handle where the chunk sits in the input (fh_set_stream_offset: text
+// offsets order the chunks of all handles, which is all "first occurrence" needs) and has the device split and sketch it
+// (fh_push_fastq_text / fh_push_fasta_text).  A FASTA record may span chunks: the reader keeps the last k-1 sequence
+// bytes before each cut and the worker passes them along as the chunk's halo (fh_set_text_halo), so that the k-mers
+// across a cut are formed exactly once, on the device that takes the later chunk.  Then: fh_finish per handle,
+// fh_merge into the first, filters, Sketch.
+// ---------------------------------------------------------------------------------------------
+struct ShardWork {
+    std::vector<uint8_t> *buf = nullptr;
+    size_t len = 0;
+    uint64_t text_off = 0;
+    uint32_t start_state = 0;
+    uint8_t halo[64];
+    uint32_t halo_len = 0;
+    bool stop = false;
+};
+
+struct ShardQueue { // one per worker, depth <= 2
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<ShardWork> q;
+};
+
+// Last `want` kept (non-whitespace) sequence bytes of the record that text[0, cut) ends in the middle of; none if
+// the text ends in a header line.  `state0` = what the text starts in the middle of (0 line start, 1 sequence line,
+// 2 header line); `prev` = the same answer for the text before it (used when the walk reaches the start of this text).
+static void fasta_tail(const uint8_t *text, size_t cut, uint32_t state0, uint32_t want, const uint8_t *prev, uint32_t prev_len,
+                       uint8_t *out, uint32_t *out_len) {
+    uint8_t rev[64];
+    uint32_t n = 0;
+    size_t pos = cut;
+    bool boundary = false;
+    while (pos > 0 && n < want) {
+        const size_t scan_end = text[pos - 1] == '\n' ? pos - 1 : pos; // the line ending at pos (its newline included)
+        const void *nl = scan_end ? memrchr(text, '\n', scan_end) : nullptr;
+        const size_t ls = nl ? (size_t)((const uint8_t *)nl - text) + 1 : 0;
+        const bool header = ls > 0 ? text[ls] == '>' : (state0 == 2 || (state0 == 0 && text[0] == '>'));
+        if (header) {
+            boundary = true;
+            break;
+        }
+        for (size_t i = pos; i > ls && n < want; --i) {
+            const uint8_t c = text[i - 1];
+            if (c == ' ' || c == '\t' || c == '\r' || c == '\n') continue;
+            rev[n++] = c;
+        }
+        pos = ls;
+    }
+    if (!boundary && n < want && pos == 0) // the record began before this text
+        for (uint32_t i = prev_len; i > 0 && n < want; --i) rev[n++] = prev[i - 1];
+    for (uint32_t i = 0; i < n; ++i) out[i] = rev[n - 1 - i];
+    *out_len = n;
+}
+
+// The reader of a sharded input: cuts the text into chunks and hands them to `emit` with everything a sketcher needs to
+// take the chunk on its own (offset in the text, FASTA start state and halo).  Also counts what needs no per-base work
+// (FASTA: records, total_bases).
+template <class Take, class Give, class Emit>
+static int shard_reader(ByteSource &src_ref, bool fastq, uint32_t K, Take take_buf, Give give_back, Emit emit,
+                        const std::atomic<bool> &abort, FastxStats &st) {
+    ByteSource *src = &src_ref;
+    int rrc = FH_OK;
+    {
+        std::vector<uint8_t> left;
+        bool eof = false;
+        uint64_t text_off = 0; // offset of the next chunk's first byte in the decompressed text
+        FastaCounter fc;
+        uint8_t halo[64];
+        uint32_t halo_len = 0;
+        while ((!eof || !left.empty()) && !abort) {
+            std::vector<uint8_t> *b = take_buf();
+            uint8_t *buf = b->data();
+            const size_t cap = b->size();
+            if (left.size() >= cap && fastq) {
+                give_back(b);
+                rrc = hfail(FH_ERR_INVALID, "FASTQ record longer than the staging buffer");
+                break;
+            }
+            size_t fill = std::min(left.size(), cap);
+            memcpy(buf, left.data(), fill);
+            left.erase(left.begin(), left.begin() + (long)fill);
+            while (!eof && fill < cap) {
+                const size_t got = src->read(buf + fill, cap - fill);
+                if (got == 0) eof = true;
+                fill += got;
+            }
+            if (fill == 0) {
+                give_back(b);
+                break;
+            }
+            size_t cut = fill;
+            if (fastq) {
+                if (!eof) { // the last header line whose line two below is a '+' line (see fastq_text_to_device)
+                    size_t ls[16];
+                    int n = 0;
+                    size_t pos = fill;
+                    while (n < 16) {
+                        const uint8_t *nl = pos > 0 ? (const uint8_t *)memrchr(buf, '\n', pos) : nullptr;
+                        const size_t start = nl ? (size_t)(nl - buf) + 1 : 0;
+                        if (start < fill) ls[n++] = start;
+                        if (!nl) break;
+                        pos = (size_t)(nl - buf);
+                    }
+                    cut = 0;
+                    bool found = false;
+                    for (int i = 2; i < n && !found; ++i)
+                        if (buf[ls[i]] == '@' && buf[ls[i - 2]] == '+') {
+                            cut = ls[i];
+                            found = true;
+                        }
+                    if (!found) {
+                        give_back(b);
+                        rrc = hfail(FH_ERR_INVALID, "no FASTQ record boundary found in a %zu byte chunk", fill);
+                        break;
+                    }
+                    left.assign(buf + cut, buf + fill);
+                }
+            } else if (!eof || !left.empty()) {
+                const uint8_t *nl = (const uint8_t *)memrchr(buf, '\n', fill);
+                if (nl) cut = (size_t)(nl - buf) + 1; // else: one line longer than the buffer, cut anywhere
+                left.insert(left.begin(), buf + cut, buf + fill);
+            }
+            if (cut == 0) {
+                give_back(b);
+                continue;
+            }
+            ShardWork job;
+            job.buf = b;
+            job.len = cut;
+            job.text_off = text_off;
+            if (!fastq) {
+                job.start_state = fc.start_state();
+                // a chunk that begins inside a record (not in or at a header line) carries the k-1 bases before it
+                job.halo_len = 0;
+                if (job.start_state != 2 && fc.have_record && halo_len) {
+                    memcpy(job.halo, halo, halo_len);
+                    job.halo_len = halo_len;
+                }
+                uint8_t nh[64];
+                uint32_t nh_len = 0;
+                fasta_tail(buf, cut, job.start_state, K - 1, halo, (job.start_state != 2 && fc.have_record) ? halo_len : 0u, nh, &nh_len);
+                fc.feed(buf, cut);
+                memcpy(halo, nh, nh_len);
+                halo_len = nh_len;
+            }
+            text_off += cut;
+            emit(job);
+        }
+        if (rrc == FH_OK && src->failed()) rrc = hfail(FH_ERR_INVALID, "read error or corrupt compressed stream");
+        if (!fastq) {
+            fc.finish();
+            st.total_bases = fc.total_bases;
+            st.n_records = fc.n_records;
+        }
+    }
+    return rrc;
+}
+
+static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::string &name, const finch_sketch_params &sp,
+                                 const finch_filter_params &filters, const std::vector<int> &devs, uint64_t chunk_bytes,
+                                 Sketch &out) {
+    std::unique_ptr<ByteSource> src;
+    bool compressed = false;
+    int first = -1;
+    if (int rc = open_source(std::move(raw), src, &compressed, &first)) return rc;
+    { // the format shows in the first (decompressed) byte
+        uint8_t b = 0;
+        size_t g = 0;
+        if (compressed || first < 0) g = src->read(&b, 1);
+        if (compressed) {
+            auto pre = std::make_unique<PrefixedSource>();
+            pre->prefix.assign(&b, &b + g);
+            pre->inner = std::move(src);
+            src = std::move(pre);
+            first = g ? (int)b : -1;
+        }
+    }
+    if (src->failed()) return hfail(FH_ERR_INVALID, "corrupt compressed stream");
+    if (first < 0) return hfail(FH_ERR_INVALID, "empty input: not a FASTA/FASTQ file");
+    if (first != '>' && first != '@') return hfail(FH_ERR_INVALID, "not a FASTA/FASTQ file (first byte 0x%02x)", first);
+    const bool fastq = first == '@';
+    FastxStats st;
+    st.format = fastq ? 2 : 1;
+    const int filter_on_eff = filters.filter_on < 0 ? (fastq ? 1 : 0) : filters.filter_on;
+    const bool small = sp.kind == 0 && filter_on_eff == 0 && sp.final_size >= 1 && sp.final_size < sp.kmers_to_sketch &&
+                       getenv("FINCH_NO_SMALL_SKETCHER") == nullptr;
+    finch_sketch_params sp_dev = sp;
+    if (small) sp_dev.kmers_to_sketch = sp.final_size; // (see HandleSet)
+    const uint64_t stage = chunk_bytes ? std::max<uint64_t>(chunk_bytes, 4096) : (32ull << 20);
+    const fh_params fp = to_fh(sp_dev, env_max_launch_value(), stage);
+    const uint32_t K = sp.kmer_length;
+    if (K < 1 || K > 64) return hfail(FH_ERR_UNSUPPORTED, "kmer_length %u", K);
+
+    const size_t n_w = devs.size();
+    struct Worker {
+        fh_sketcher *h = nullptr;
+        ShardQueue q;
+        std::thread th;
+        int rc = FH_OK;
+        std::string msg;
+    };
+    std::vector<std::unique_ptr<Worker>> W;
+    struct Cleanup {
+        std::vector<std::unique_ptr<Worker>> &W;
+        ~Cleanup() {
+            for (auto &w : W)
+                if (w->h) fh_free(w->h);
+        }
+    } cleanup{W};
+    for (size_t d = 0; d < n_w; ++d) {
+        W.push_back(std::make_unique<Worker>());
+        W[d]->h = fh_new(&fp, devs[d]);
+        if (!W[d]->h) return hfail(FH_ERR_NO_DEVICE, "%s", fh_last_error());
+        if (int rc = fh_reset(W[d]->h)) return hfail(rc, "%s", fh_last_error());
+    }
+    // chunk buffers circulate between the reader and the workers
+    std::mutex free_mu;
+    std::condition_variable free_cv;
+    std::vector<std::unique_ptr<std::vector<uint8_t>>> bufs;
+    std::vector<std::vector<uint8_t> *> free_list;
+    for (size_t i = 0; i < 2 * n_w + 1; ++i) {
+        bufs.push_back(std::make_unique<std::vector<uint8_t>>(stage));
+        free_list.push_back(bufs.back().get());
+    }
+    std::atomic<bool> abort{false};
+    auto give_back = [&](std::vector<uint8_t> *b) {
+        std::lock_guard<std::mutex> g(free_mu);
+        free_list.push_back(b);
+        free_cv.notify_one();
+    };
+    auto worker_main = [&](Worker *w) {
+        for (;;) {
+            ShardWork job;
+            {
+                std::unique_lock<std::mutex> lk(w->q.mu);
+                w->q.cv.wait(lk, [&] { return !w->q.q.empty(); });
+                job = w->q.q.front();
+                w->q.q.erase(w->q.q.begin());
+                w->q.cv.notify_all();
+            }
+            if (job.stop) return;
+            if (w->rc == FH_OK && !abort) {
+                uint8_t *dst = nullptr;
+                uint64_t cap = 0;
+                int rc = fh_text_buffer(w->h, &dst, &cap);
+                if (rc == FH_OK && job.len > cap) rc = FH_ERR_INVALID;
+                if (rc == FH_OK) {
+                    memcpy(dst, job.buf->data(), job.len);
+                    rc = fh_set_stream_offset(w->h, job.text_off);
+                }
+                if (rc == FH_OK && fastq) rc = fh_push_fastq_text(w->h, job.len);
+                if (rc == FH_OK && !fastq) {
+                    if (job.halo_len) rc = fh_set_text_halo(w->h, job.halo, job.halo_len);
+                    if (rc == FH_OK) rc = fh_push_fasta_text(w->h, job.len, job.start_state, 0u);
+                }
+                if (rc != FH_OK) {
+                    w->rc = rc;
+                    w->msg = fh_last_error();
+                    abort = true;
+                }
+            }
+            give_back(job.buf);
+        }
+    };
+    for (auto &w : W) w->th = std::thread(worker_main, w.get());
+    auto send = [&](size_t d, const ShardWork &job) {
+        Worker *w = W[d].get();
+        std::unique_lock<std::mutex> lk(w->q.mu);
+        w->q.cv.wait(lk, [&] { return w->q.q.size() < 2; });
+        w->q.q.push_back(job);
+        w->q.cv.notify_all();
+    };
+    auto take_buf = [&]() {
+        std::unique_lock<std::mutex> lk(free_mu);
+        free_cv.wait(lk, [&] { return !free_list.empty(); });
+        std::vector<uint8_t> *b = free_list.back();
+        free_list.pop_back();
+        return b;
+    };
+
+    // ---- the reader ----
+    size_t next_w = 0;
+    const int rrc = shard_reader(*src, fastq, K, take_buf, give_back, [&](const ShardWork &job) {
+        send(next_w, job);
+        next_w = (next_w + 1) % n_w;
+    }, abort, st);
+    for (size_t d = 0; d < n_w; ++d) {
+        ShardWork stop;
+        stop.stop = true;
+        send(d, stop);
+    }
+    for (auto &w : W) w->th.join();
+    if (rrc != FH_OK) return rrc;
+    for (auto &w : W)
+        if (w->rc != FH_OK) return hfail(w->rc, "%s", w->msg.c_str());
+    // ---- partial sketches -> one ----
+    uint64_t text_bases = 0;
+    for (size_t d = 0; d < n_w; ++d) {
+        uint64_t n = 0, tk = 0;
+        if (int rc = fh_finish(W[d]->h, &n, &tk)) return hfail(rc, "%s", fh_last_error());
+        if (fastq) {
+            uint64_t tb = 0;
+            if (int rc = fh_text_bases(W[d]->h, &tb)) return hfail(rc, "%s", fh_last_error());
+            text_bases += tb;
+        }
+        if (d > 0)
+            if (int rc = fh_merge(W[0]->h, W[d]->h)) return hfail(rc, "%s", fh_last_error());
+    }
+    if (fastq) st.total_bases = text_bases;
+    return finish_sketch(W[0]->h, name, sp, filters, st, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1554,6 +1888,80 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
     for (auto &t : th) t.join();
     if (first_err_code != FH_OK) return hfail(first_err_code, "%s", first_err_msg.c_str());
     *out = res.release();
+    return FH_OK;
+}
+
+static int sharded_devices(const int *devices, uint32_t n_devices, std::vector<int> &devs) {
+    if (devices && n_devices) devs.assign(devices, devices + n_devices);
+    else devs.push_back(0);
+    if (devs.size() > 64) return hfail(FH_ERR_INVALID, "more than 64 device handles");
+    return FH_OK;
+}
+
+int finch_sketch_file_sharded(const char *filename, const finch_sketch_params *sp, const finch_filter_params *filters,
+                              const int *devices, uint32_t n_devices, uint64_t chunk_bytes, finch_sketches **out) {
+    if (!filename || !sp || !filters || !out) return hfail(FH_ERR_INVALID, "null argument");
+    std::vector<int> devs;
+    if (int rc = sharded_devices(devices, n_devices, devs)) return rc;
+    const std::string fn = filename;
+    FILE *f = fn == "-" ? stdin : fopen(fn.c_str(), "rb");
+    if (!f) return hfail(FH_ERR_INVALID, "%s: %s (os error %d)", fn.c_str(), strerror(errno), errno);
+    const char *rt_env = getenv("FINCH_READ_THREADS");
+    const unsigned read_threads = std::min(rt_env ? (unsigned)std::max(1, atoi(rt_env)) : 8u, 16u);
+    auto res = std::make_unique<finch_sketches>();
+    res->v.resize(1);
+    const int rc = sketch_stream_sharded(std::make_unique<FileSource>(f, f != stdin, read_threads), fn, *sp, *filters, devs, chunk_bytes,
+                                         res->v[0]);
+    if (rc != FH_OK) return rc;
+    *out = res.release();
+    return FH_OK;
+}
+
+int finch_sketch_buffer_sharded(const uint8_t *data, uint64_t len, const char *name, const finch_sketch_params *sp,
+                                const finch_filter_params *filters, const int *devices, uint32_t n_devices, uint64_t chunk_bytes,
+                                finch_sketches **out) {
+    if ((!data && len) || !sp || !filters || !out) return hfail(FH_ERR_INVALID, "null argument");
+    std::vector<int> devs;
+    if (int rc = sharded_devices(devices, n_devices, devs)) return rc;
+    auto res = std::make_unique<finch_sketches>();
+    res->v.resize(1);
+    const int rc = sketch_stream_sharded(std::make_unique<MemSource>(data, (size_t)len), name ? name : "", *sp, *filters, devs,
+                                         chunk_bytes, res->v[0]);
+    if (rc != FH_OK) return rc;
+    *out = res.release();
+    return FH_OK;
+}
+
+// Test hook (no device): the chunks the sharded reader would deal out for an input image -- per chunk 4 words
+// (text offset, length, FASTA start state, halo length) in `meta` and 64 halo bytes in `halos`.
+int finch_shard_probe(const uint8_t *data, uint64_t len, uint32_t k, uint64_t chunk_bytes, uint64_t max_chunks, uint64_t *meta,
+                      uint8_t *halos, uint64_t *n_chunks, uint64_t *n_records, uint64_t *total_bases) {
+    if ((!data && len) || !n_chunks || k < 1 || k > 64 || chunk_bytes < 16) return hfail(FH_ERR_INVALID, "bad argument");
+    std::unique_ptr<ByteSource> src;
+    int first = -1;
+    if (int rc = open_source(std::make_unique<MemSource>(data, (size_t)len), src, nullptr, &first)) return rc;
+    if (first != '>' && first != '@') return hfail(FH_ERR_INVALID, "not a FASTA/FASTQ file");
+    std::vector<uint8_t> buf((size_t)chunk_bytes);
+    std::atomic<bool> abort{false};
+    FastxStats st;
+    uint64_t n = 0;
+    const int rc = shard_reader(*src, first == '@', k, [&] { return &buf; }, [](std::vector<uint8_t> *) {},
+                                [&](const ShardWork &job) {
+                                    if (n < max_chunks) {
+                                        if (meta) {
+                                            meta[4 * n] = job.text_off;
+                                            meta[4 * n + 1] = job.len;
+                                            meta[4 * n + 2] = job.start_state;
+                                            meta[4 * n + 3] = job.halo_len;
+                                        }
+                                        if (halos) memcpy(halos + 64 * n, job.halo, job.halo_len);
+                                    }
+                                    ++n;
+                                }, abort, st);
+    if (rc != FH_OK) return rc;
+    *n_chunks = n;
+    if (n_records) *n_records = st.n_records;
+    if (total_bases) *total_bases = st.total_bases;
     return FH_OK;
 }
 

@@ -65,6 +65,12 @@ _SYMS = {
                                      C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.POINTER(_P)]),
     "finch_sketch_buffer": (C.c_int, [_P, C.c_uint64, C.c_char_p, C.POINTER(CSketchParams), C.POINTER(CFilterParams),
                                       C.c_int, C.POINTER(_P)]),
+    "finch_sketch_file_sharded": (C.c_int, [C.c_char_p, C.POINTER(CSketchParams), C.POINTER(CFilterParams), C.POINTER(C.c_int),
+                                            C.c_uint32, C.c_uint64, C.POINTER(_P)]),
+    "finch_sketch_buffer_sharded": (C.c_int, [_P, C.c_uint64, C.c_char_p, C.POINTER(CSketchParams), C.POINTER(CFilterParams),
+                                              C.POINTER(C.c_int), C.c_uint32, C.c_uint64, C.POINTER(_P)]),
+    "finch_shard_probe": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, _P, _P, C.POINTER(C.c_uint64),
+                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "finch_sketches_free": (None, [_P]),
     "finch_sketches_len": (C.c_uint32, [_P]),
     "finch_sketch_name": (C.c_char_p, [_P, C.c_uint32]),
@@ -184,6 +190,46 @@ def sketch_stream(data: bytes, name: str, sketch_params: SketchParams, filters: 
     buf = np.frombuffer(data, dtype=np.uint8)
     _check(lib().finch_sketch_buffer(buf.ctypes.data, len(data), name.encode(), C.byref(sp), C.byref(fp), device, C.byref(out)))
     return Sketches(out, sketch_params)
+
+
+def sketch_file_sharded(filename: str, sketch_params: SketchParams, filters: FilterParams, devices: Sequence[int],
+                        chunk_bytes: int = 0) -> Sketches:
+    """ONE input partitioned over the handles in `devices` (an entry per handle; entries may repeat), partial sketches
+    merged on the host: the north_star's single-large-input path (include/finch_host.h)"""
+    devs = list(devices)
+    darr = (C.c_int * len(devs))(*devs)
+    sp, fp = _params_c(sketch_params), filters.to_c()
+    out = _P()
+    _check(lib().finch_sketch_file_sharded(filename.encode(), C.byref(sp), C.byref(fp), darr, len(devs), chunk_bytes, C.byref(out)))
+    return Sketches(out, sketch_params)
+
+
+def sketch_stream_sharded(data: bytes, name: str, sketch_params: SketchParams, filters: FilterParams, devices: Sequence[int],
+                          chunk_bytes: int = 0) -> Sketches:
+    devs = list(devices)
+    darr = (C.c_int * len(devs))(*devs)
+    sp, fp = _params_c(sketch_params), filters.to_c()
+    out = _P()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    _check(lib().finch_sketch_buffer_sharded(buf.ctypes.data, len(data), name.encode(), C.byref(sp), C.byref(fp), darr, len(devs),
+                                             chunk_bytes, C.byref(out)))
+    return Sketches(out, sketch_params)
+
+
+def shard_probe(data: bytes, k: int, chunk_bytes: int):
+    """chunks the sharded reader deals out (test hook, no device): [(text_off, length, start_state, halo bytes)], records, total_bases"""
+    src = np.frombuffer(data, dtype=np.uint8)
+    cap = len(data) // max(1, chunk_bytes // 4) + 64
+    meta, halos = np.zeros(4 * cap, np.uint64), np.zeros(64 * cap, np.uint8)
+    n, nr, tb = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    _check(lib().finch_shard_probe(src.ctypes.data, len(data), k, chunk_bytes, cap, meta.ctypes.data, halos.ctypes.data,
+                                   C.byref(n), C.byref(nr), C.byref(tb)))
+    assert n.value <= cap
+    out = []
+    for i in range(n.value):
+        off, ln, st, hl = (int(x) for x in meta[4 * i:4 * i + 4])
+        out.append((off, ln, st, halos[64 * i:64 * i + hl].tobytes()))
+    return out, nr.value, tb.value
 
 
 def sketches_from_arrays(name, seq_length, num_valid_kmers, kc, km, sketch_params: SketchParams, filters: FilterParams) -> Sketches:

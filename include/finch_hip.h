@@ -112,6 +112,12 @@ int fh_push_fastq_text(fh_sketcher *s, uint64_t len);
  * line.  With FH_PUSH_CONTINUE the chunk continues the previous fh_push_fasta_text chunk (k-mers span the cut).
  * total_bases (raw sequence-region lengths, mash.rs:72) is the caller's to count: it needs no per-base work. */
 int fh_push_fasta_text(fh_sketcher *s, uint64_t len, uint32_t start_state, uint32_t flags);
+/* One FASTA input split over several sketchers (finch_sketch_file_sharded): the chunk the NEXT fh_push_fasta_text
+ * pushes continues a record whose preceding text went to another sketcher.  `halo` holds the last n (<= k-1) packed
+ * sequence bytes before the cut (whitespace already dropped): k-mers that span the cut are formed here, k-mers inside
+ * the halo are the other sketcher's.  Their stream coordinates are the n coordinates below the chunk's
+ * (fh_set_stream_offset).  Applies to one push; excludes FH_PUSH_CONTINUE. */
+int fh_set_text_halo(fh_sketcher *s, const uint8_t *halo, uint32_t n);
 /* Zero-copy form of fh_push_block_ex: the caller writes packed-stream bytes (sequence bytes + one breaker byte per
  * record, whitespace already removed) straight into the buffer handed out by fh_text_buffer and commits the first
  * `len` of them.  Same flags as fh_push_block_ex. */

@@ -67,6 +67,19 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
 /* sketch_stream over an in-memory file image */
 int finch_sketch_buffer(const uint8_t *data, uint64_t len, const char *name, const finch_sketch_params *sketch_params,
                         const finch_filter_params *filters, int device, finch_sketches **out);
+/* ONE input across several devices (north_star; beyond the reference, which parallelises over files only,
+ * lib.rs:34-36): a reader cuts the decompressed FASTQ / FASTA text into record- (FASTQ) or line-aligned (FASTA) chunks of
+ * about `chunk_bytes` (0 = 32 MiB) and deals them round-robin to one sketcher per entry of `devices` (an entry may
+ * repeat: several handles on one GPU); every handle splits and sketches its chunks on its device at the chunks' own
+ * stream offsets, FASTA records that span a cut hand their last k-1 bases over as a halo; the partial sketches are
+ * merged on the host (fh_merge), then filters / post filter as in sketch_stream.  The result is the Sketch
+ * finch_sketch_files returns for the same file.  FASTQ must be plain 4-line FASTQ (anything else: FH_ERR_INVALID;
+ * use finch_sketch_files, whose host parser is the judge of what needletail accepts). */
+int finch_sketch_file_sharded(const char *filename, const finch_sketch_params *sketch_params, const finch_filter_params *filters,
+                              const int *devices, uint32_t n_devices, uint64_t chunk_bytes, finch_sketches **out);
+int finch_sketch_buffer_sharded(const uint8_t *data, uint64_t len, const char *name, const finch_sketch_params *sketch_params,
+                                const finch_filter_params *filters, const int *devices, uint32_t n_devices, uint64_t chunk_bytes,
+                                finch_sketches **out);
 void finch_sketches_free(finch_sketches *s);
 
 uint32_t finch_sketches_len(const finch_sketches *s);
@@ -125,6 +138,12 @@ int finch_read_file_probe(const char *path, uint64_t chunk, uint32_t read_thread
 /* Test hook: the byte stream the parsers see for an input image (magic-byte sniffing, gzip / BGZF / bzip2 / xz
  * decompression), read in requests of `chunk` bytes into dst[0, cap); *got = bytes delivered. */
 int finch_source_probe(const uint8_t *data, uint64_t len, uint64_t chunk, uint8_t *dst, uint64_t cap, uint64_t *got);
+
+/* Test hook (no device): the chunks finch_sketch_*_sharded's reader deals out for an input image.  Per chunk: meta[4i..] =
+ * (offset in the decompressed text, length, FASTA start state, halo length), halos[64i..] = the halo bytes.  FASTA only:
+ * n_records / total_bases as the reader counts them. */
+int finch_shard_probe(const uint8_t *data, uint64_t len, uint32_t k, uint64_t chunk_bytes, uint64_t max_chunks, uint64_t *meta,
+                      uint8_t *halos, uint64_t *n_chunks, uint64_t *n_records, uint64_t *total_bases);
 
 #ifdef __cplusplus
 }

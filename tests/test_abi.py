@@ -39,7 +39,7 @@ def test_host_header_symbols_all_exported(built):
 
 
 def test_abi_version(built):
-    assert built.fh_abi_version() == 1
+    assert built.fh_abi_version() == 2
 
 
 def test_no_silent_cpu_fallback(built):

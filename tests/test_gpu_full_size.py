@@ -96,10 +96,10 @@ def test_full_size_stream_bit_exact_vs_sharded_oracle():
 def test_config3_oversketch_and_filtering_vs_sharded_oracle():
     """BASELINE.json configs[2] shape: k=31, final 10 000 hashes, kmers_to_sketch = 2 000 000 (CLI oversketch x200,
     cli.rs:187-192), strand filter 0.1, err filter 1% -> 0.31 (cli.rs:264-265), filtering on the host.
-    Default 2 Gbase (FH_FULL_GBASES_C3 to change): device sketch of 2 M hashes bit-exact vs the sharded oracle,
+    Full size, 10 Gbase (FH_FULL_GBASES_C3 to change): device sketch of 2 M hashes bit-exact vs the sharded oracle,
     then filter_counts + process_post_filter through the C++ host layer vs the oracle's filters."""
     from finch_rs_amd import host as H
-    gbases = float(os.environ.get("FH_FULL_GBASES_C3", "2"))
+    gbases = float(os.environ.get("FH_FULL_GBASES_C3", "10"))
     ncpu = max(1, min(len(os.sched_getaffinity(0)), 64))
     if ncpu < 16 and "FH_FULL_GBASES_C3" not in os.environ:
         gbases = 0.2
@@ -134,3 +134,140 @@ def test_config3_oversketch_and_filtering_vs_sharded_oracle():
     assert fp.abun_filter == (cutoff, None)
     assert len(got.hashes) == final
     assert np.array_equal(got.arrays[0], b[:final]) and np.array_equal(got.arrays[1], bk[:final])
+
+
+def test_c4_50gbase_sharded_read_blocks_and_host_merge():
+    """BASELINE.json configs[3] at its full size on ONE MI355X: the 50 Gbase stream (50.3 GB) is resident, sketched
+    (a) as one stream and (b) as the 8 read blocks the 8 ranks of a node would take (shard_bounds, one handle per block,
+    fh_set_stream_offset, then the host merge of the 8 partial sketches in their wire format, fh_merge_wire -- the
+    bench.py --gpus 8 path minus the transport).  Both must equal the oracle run on 256 read-block shards and merged
+    with the independent numpy merge above (the size-independent property of SURVEY 8e).  FH_FULL_GBASES_C4 to change."""
+    from finch_rs_amd import sharding as SH
+    gbases = float(os.environ.get("FH_FULL_GBASES_C4", "50"))
+    ncpu = max(1, min(len(os.sched_getaffinity(0)), 96))
+    if ncpu < 16 and "FH_FULL_GBASES_C4" not in os.environ:
+        gbases = 1.0
+    n_reads = int(np.ceil(gbases * 1e9 / RL))
+    rec = RL + 1
+    dg = F.DeviceBuffer(GL)
+    dr = F.DeviceBuffer(n_reads * rec + 64)
+    S.synth_genome_device(dg, GL, SEED)
+    S.synth_reads_device(dr, dg, GL, 0, n_reads, RL, SEED, 10000, 500)
+    params = F.SketchParams.mash(N, N, True, K, 0)
+    # (a) one stream
+    sk = params.create_sketcher()
+    sk.push_device(dr.ptr, n_reads * rec)
+    kc, km, pos = sk.to_arrays()
+    tk = sk.finish()[1]
+    assert len(kc) == N
+    # (b) 8 read blocks, each on its own handle at its own stream offset; partial sketches through the wire format
+    world = 8
+    bufs = []
+    for r in range(world):
+        lo, hi = SH.shard_bounds(n_reads, r, world)
+        lo, hi = (lo // 16) * 16, (hi // 16) * 16 if r + 1 < world else hi  # device blocks start 16-byte aligned
+        h = params.create_sketcher()
+        h.set_stream_offset(lo * rec)
+        h.push_device(dr.ptr + lo * rec, (hi - lo) * rec)
+        pkc, pkm, ppos = h.to_arrays()
+        bufs.append(SH.pack_partial(pkc, pkm, ppos, h.finish()[1], N, K))
+        h.close()
+    mkc, mkm, mpos, mtk = SH.merge_wire(params, bufs, N)
+    assert np.array_equal(mkc, kc) and np.array_equal(mkm, km) and np.array_equal(mpos, pos) and mtk == tk
+    # oracle on 256 shards (a shard's reads are generated inside its worker: ~200 MB each)
+    genome = S.synth_genome_host(GL, SEED)
+    for first in (0, n_reads // 3, n_reads - 1000):
+        assert np.array_equal(dr.download(1000 * rec, first * rec), S.synth_reads_host(genome, first, 1000, RL, SEED, 10000, 500))
+    shards = 256
+    bounds = np.linspace(0, n_reads, shards + 1).astype(np.int64)
+    jobs = [(genome, int(bounds[i]), int(bounds[i + 1] - bounds[i])) for i in range(shards) if bounds[i + 1] > bounds[i]]
+    with mp.get_context("fork").Pool(ncpu) as pool:
+        parts = pool.map(_oracle_shard, jobs, chunksize=1)
+    okc, okm, otk = merge_numpy(parts, N)
+    assert np.array_equal(kc, okc) and np.array_equal(km, okm) and tk == otk
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & (2**64 - 1)
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+    return x ^ (x >> 31)
+
+
+def _c5_length(i):
+    """log-uniform 1..10 Mb from the per-file seed, scaled by FH_C5_SCALE"""
+    u = (_splitmix64(SEED + 7919 * i) >> 11) / float(1 << 53)
+    return max(1000, int(1e6 * 10.0 ** u * float(os.environ.get("FH_C5_SCALE_EFFECTIVE", "1"))))
+
+
+def _c5_fasta(i):
+    L = _c5_length(i)
+    g = S.synth_genome_host(L, SEED + 1000003 * (i + 1))
+    rows = (L + 69) // 70
+    a = np.full((rows, 71), ord("\n"), np.uint8)  # 70-column lines
+    gp = np.zeros(rows * 70, np.uint8)
+    gp[:L] = g
+    a[:, :70] = gp.reshape(rows, 70)
+    last = L - (rows - 1) * 70
+    return b">genome_%05d len=%d\n" % (i, L) + a.reshape(-1)[:(rows - 1) * 71 + last].tobytes() + b"\n"
+
+
+def _c5_write(args):
+    d, i = args
+    with open(os.path.join(d, "g%05d.fa" % i), "wb") as f:
+        f.write(_c5_fasta(i))
+
+
+def _c5_oracle(i):
+    o = O.OracleSketcher(O.MASH, N, K, 0)
+    assert o.sketch_stream(_c5_fasta(i)) == 1
+    return o.to_vec() + (o.total_bases_and_kmers(),)
+
+
+def test_c5_batch_of_10k_fastas_through_sketch_files():
+    """BASELINE.json configs[4] on one GPU: 10 000 synthetic RefSeq-sized FASTAs (log-uniform 1-10 Mb, 70-column lines,
+    ~39 GB of text) through ONE finch_sketch_files call (lib.rs:29-49): one sketch per file in input order with the
+    file's name, seq_length and n = 1000 hashes; a seeded sample of 256 files is compared bit-exact (hashes, counts,
+    k-mers, seq_length, numValidKmers) with the oracle's own sketch_stream on the same bytes.  The files go to the
+    roomiest of /dev/shm and the temp directory; if neither holds the full set the lengths are scaled down and the
+    scale is printed (FH_C5_FILES / FH_C5_SCALE to force)."""
+    import shutil
+    import tempfile
+    from finch_rs_amd import host as H
+    n_files = int(os.environ.get("FH_C5_FILES", "10000"))
+    ncpu = max(1, min(len(os.sched_getaffinity(0)), 64))
+    cands = [d for d in ("/dev/shm", tempfile.gettempdir()) if os.path.isdir(d)]
+    base = max(cands, key=lambda d: shutil.disk_usage(d).free)
+    free = shutil.disk_usage(base).free
+    if base == "/dev/shm":  # tmpfs pages are RAM: leave room for the processes
+        import psutil
+        free = min(free, psutil.virtual_memory().available - (24 << 30))
+    need = 3.95e6 * 1.015 * n_files  # mean of the log-uniform lengths + newlines
+    scale = float(os.environ.get("FH_C5_SCALE", "0")) or min(1.0, 0.8 * free / need)
+    if ncpu < 16 and "FH_C5_SCALE" not in os.environ:
+        scale = min(scale, 0.02)  # small hosts: keep generation + oracle within a minute
+    os.environ["FH_C5_SCALE_EFFECTIVE"] = repr(scale)
+    print("C5: %d files under %s, length scale %.3f" % (n_files, base, scale))
+    d = tempfile.mkdtemp(prefix="finch_c5_", dir=base)
+    try:
+        with mp.get_context("fork").Pool(ncpu) as pool:
+            pool.map(_c5_write, [(d, i) for i in range(n_files)], chunksize=16)
+            paths = [os.path.join(d, "g%05d.fa" % i) for i in range(n_files)]
+            res = H.sketch_files(paths, F.SketchParams.default(), H.FilterParams(None))
+            assert len(res) == n_files
+            L = H.lib()
+            for i in range(n_files):
+                ln = _c5_length(i)
+                assert L.finch_sketch_name(res._p, i).decode() == paths[i]
+                assert L.finch_sketch_seq_length(res._p, i) == ln + (ln - 1) // 70  # raw region: bases + inner newlines
+                assert L.finch_sketch_n_hashes(res._p, i) == N
+            rng = np.random.default_rng(SEED)
+            sample = sorted(rng.choice(n_files, size=min(256, n_files), replace=False).tolist())
+            oracles = pool.map(_c5_oracle, sample, chunksize=4)
+        for i, (okc, okm, totals) in zip(sample, oracles):
+            sk = res.sketch(i)
+            assert np.array_equal(sk.arrays[0], okc) and np.array_equal(sk.arrays[1], okm), i
+            assert (sk.seq_length, sk.num_valid_kmers) == totals, i
+            assert sk.filter_params.filter_on is False  # lib.rs:70-76: FASTA defaults to no filtering
+    finally:
+        shutil.rmtree(d, ignore_errors=True)

@@ -143,6 +143,16 @@ def test_device_side_fastq_parsing_matches_host_parser(tmp_path):
     code = r'''
 import os, sys, numpy as np
 from finch_rs_amd import host as H, sketch_schemes as S
+from oracle import oracle as O
+def vs_oracle(b, data, p, tag):
+    """the device-split sketch against the oracle's own parser + sketcher (returns False if the oracle's parser rejects the text)"""
+    o = O.OracleSketcher(O.MASH, p.kmers_to_sketch, p.kmer_length, 0)
+    if o.sketch_stream(data) <= 0:
+        return False
+    okc, okm = o.to_vec()
+    assert np.array_equal(b.arrays[0], okc) and np.array_equal(b.arrays[1], okm), tag
+    assert (b.seq_length, b.num_valid_kmers) == o.total_bases_and_kmers(), (tag, b.seq_length, b.num_valid_kmers, o.total_bases_and_kmers())
+    return True
 rng = np.random.default_rng(5)
 g = S.synth_genome_host(200000, 3)
 nr, rl = 30000, 150
@@ -166,6 +176,7 @@ for name, data in [("lf", fq(b"\n")), ("crlf", fq(b"\r\n")), ("nolast", fq(b"\n"
     b = H.sketch_files([path], p, f).sketch(0)
     assert np.array_equal(a.arrays[0], b.arrays[0]) and np.array_equal(a.arrays[1], b.arrays[1]), name
     assert (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers), (name, a.seq_length, b.seq_length)
+    assert vs_oracle(b, data, p, name), name  # LF, CRLF, no final newline, ragged reads + '@'/'+' quality lines: all oracle-checked
 # not 4-line FASTQ -> loud error
 bad = os.path.join(sys.argv[1], "bad.fastq")
 open(bad, "wb").write(b"@r1\nACGT\n+\nIIII\n\n@r2\nACGT\n+\nIIII\n" * 1000)
@@ -183,6 +194,7 @@ a = H.sketch_files([blank], p, f).sketch(0)
 os.environ.pop("FINCH_DEVICE_PARSE")
 b = H.sketch_files([blank], p, f).sketch(0)
 assert np.array_equal(a.arrays[0], b.arrays[0]) and (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers)
+assert vs_oracle(b, open(blank, "rb").read(), p, "blank lines between records")
 os.environ["FINCH_DEVICE_PARSE"] = "1"
 try:
     H.sketch_files([blank], p, f)
@@ -215,6 +227,16 @@ def test_device_side_fasta_parsing_matches_host_parser(tmp_path):
     code = r'''
 import os, sys, numpy as np
 from finch_rs_amd import host as H, sketch_schemes as S
+from oracle import oracle as O
+def vs_oracle(b, data, p, tag):
+    """the device-split sketch against the oracle's own parser + sketcher (returns False if the oracle's parser rejects the text)"""
+    o = O.OracleSketcher(O.MASH, p.kmers_to_sketch, p.kmer_length, 0)
+    if o.sketch_stream(data) <= 0:
+        return False
+    okc, okm = o.to_vec()
+    assert np.array_equal(b.arrays[0], okc) and np.array_equal(b.arrays[1], okm), tag
+    assert (b.seq_length, b.num_valid_kmers) == o.total_bases_and_kmers(), (tag, b.seq_length, b.num_valid_kmers, o.total_bases_and_kmers())
+    return True
 rng = np.random.default_rng(11)
 g = bytes(S.synth_genome_host(600000, 13))
 def wrap(seq, w, eol):
@@ -249,6 +271,9 @@ for name, data in cases.items():
         b = H.sketch_files([path], p, f).sketch(0)
         assert np.array_equal(a.arrays[0], b.arrays[0]) and np.array_equal(a.arrays[1], b.arrays[1]), name
         assert (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers), (name, a.seq_length, b.seq_length, a.num_valid_kmers, b.num_valid_kmers)
+        # every one of these texts is FASTA to the oracle's parser: CRLF, '>' inside lines, blank lines, spaces and tabs,
+        # empty records, no final newline, 0xFF bytes, lines longer than a chunk -- device splitter vs the oracle directly
+        assert vs_oracle(b, data, p, name), name
 print("child ok")
 '''
     for env in [{}, {"FH_STAGE_BYTES": "65536"}, {"FH_STAGE_BYTES": "4096"}]:
@@ -267,6 +292,17 @@ def test_device_side_fasta_parsing_random_text():
     code = r'''
 import os, numpy as np
 from finch_rs_amd import host as H, sketch_schemes as S
+from oracle import oracle as O
+def vs_oracle(b, data, p, tag):
+    """the device-split sketch against the oracle's own parser + sketcher (returns False if the oracle's parser rejects the text)"""
+    o = O.OracleSketcher(O.MASH, p.kmers_to_sketch, p.kmer_length, 0)
+    if o.sketch_stream(data) <= 0:
+        return False
+    okc, okm = o.to_vec()
+    assert np.array_equal(b.arrays[0], okc) and np.array_equal(b.arrays[1], okm), tag
+    assert (b.seq_length, b.num_valid_kmers) == o.total_bases_and_kmers(), (tag, b.seq_length, b.num_valid_kmers, o.total_bases_and_kmers())
+    return True
+n_oracle = 0
 alpha = np.frombuffer(b"ACGTACGTACGTACGTacgtNnuU>>- \t\r\xff*", dtype=np.uint8)
 for case in range(30):
     rng = np.random.default_rng(4200 + case)
@@ -290,6 +326,8 @@ for case in range(30):
     b = H.sketch_stream(data, "x", p, f).sketch(0)
     assert np.array_equal(a.arrays[0], b.arrays[0]) and np.array_equal(a.arrays[1], b.arrays[1]), case
     assert (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers), (case, a.seq_length, b.seq_length)
+    n_oracle += vs_oracle(b, data, p, case)
+assert n_oracle == 30, n_oracle  # the text always begins with '>': the oracle's parser takes every case
 print("child ok")
 '''
     for env in [{}, {"FH_STAGE_BYTES": "4096"}, {"FH_STAGE_BYTES": "5001"}]:
@@ -394,3 +432,58 @@ def test_oversketch_without_filtering_uses_the_small_sketcher_and_changes_nothin
             assert len(b.arrays[0]) <= 700
             assert np.array_equal(a.arrays[0], b.arrays[0]) and np.array_equal(a.arrays[1], b.arrays[1])
             assert (a.seq_length, a.num_valid_kmers, a.filter_params) == (b.seq_length, b.num_valid_kmers, b.filter_params)
+
+
+def test_one_input_across_several_device_handles(tmp_path):
+    """finch_sketch_file_sharded (north_star: one large input partitioned across the GPUs of a node, host merge): on the
+    1-GPU box the handles all sit on device 0.  FASTQ (record-aligned chunks) and FASTA with records far longer than a
+    chunk (line-aligned chunks + the k-1 base halo across every cut) must give the Sketch of the single-handle path
+    and of the oracle: hashes, counts, extra_counts, k-mers, seq_length, numValidKmers, filters."""
+    fq, g = make_fastq(40000, seed=8, gl=300000)
+    pq = tmp_path / "reads.fastq"
+    pq.write_bytes(fq)
+    pz = tmp_path / "reads.fastq.gz"
+    pz.write_bytes(gzip.compress(fq, 1))
+    filt = H.FilterParams(None, (None, None), 0.21, 0.1)
+    for k, n_eff, final in ((21, 3000, 200), (31, 500, 500)):
+        params = SketchParams.mash(n_eff, final, False, k, 0)
+        one = H.sketch_files([str(pq)], params, filt).sketch(0)
+        o, fmt = oracle_sketch(fq, O.MASH, n_eff, k)
+        okc, okm = o.to_vec()
+        a, ak = O.filter_strands(okc, okm, 0.1)
+        cutoff = O.guess_filter_threshold(a, 0.21)
+        b, bk = O.filter_abundance(a, ak, cutoff, None)
+        for path, devs, chunk in ((pq, [0, 0, 0], 1 << 20), (pq, [0, 0], 70000), (pz, [0, 0, 0, 0, 0], 300000), (pq, [0], 0)):
+            sk = H.sketch_file_sharded(str(path), params, filt, devs, chunk).sketch(0)
+            assert np.array_equal(sk.arrays[0], one.arrays[0]) and np.array_equal(sk.arrays[1], one.arrays[1]), (k, devs, chunk)
+            assert (sk.seq_length, sk.num_valid_kmers) == (one.seq_length, one.num_valid_kmers) == o.total_bases_and_kmers()
+            assert sk.filter_params.abun_filter == (cutoff, None) and sk.filter_params.filter_on is True
+            assert np.array_equal(sk.arrays[0], b[:final]) and np.array_equal(sk.arrays[1], bk[:final])
+    # FASTA: two chromosomes of 0.9 and 0.3 Mb (70-column lines, CRLF in the second) + short contigs, an N run, blank lines
+    g = bytes(S.synth_genome_host(1_200_000, 21))
+    fa = (b">chr1 long\n" + b"\n".join(g[j:j + 70] for j in range(0, 900000, 70)) + b"\n>chr2\r\n" +
+          b"\r\n".join(g[j:j + 61] for j in range(900000, 1200000, 61)) + b"\r\n>c3\nACGTNNNNNNN" + g[5000:5100] + b"\n\n" +
+          g[100:180] + b"\n>c4\n" + g[777:800] + b"\n>empty\n>c5\n" + g[:60])
+    pa = tmp_path / "genome.fa"
+    pa.write_bytes(fa)
+    for k in (21, 32, 11):
+        params = SketchParams.mash(1000, 1000, False, k, 0)
+        o, fmt = oracle_sketch(fa, O.MASH, 1000, k)
+        assert fmt == 1
+        one = H.sketch_files([str(pa)], params, H.FilterParams(None)).sketch(0)
+        same(one, o)
+        for devs, chunk in (([0, 0, 0], 4096), ([0, 0], 5001), ([0, 0, 0, 0], 1 << 16), ([0, 0, 0], 0)):
+            sk = H.sketch_file_sharded(str(pa), params, H.FilterParams(None), devs, chunk).sketch(0)
+            same(sk, o)
+            assert sk.filter_params.filter_on is False and sk.name == str(pa)
+    # in-memory image, scaled sketch
+    res = H.sketch_stream_sharded(fa, "mem", SketchParams.scaled(100, 21, 0.01, 0), H.FilterParams(None), [0, 0, 0], 8192)
+    o, _ = oracle_sketch(fa, O.SCALED, 100, 21, 0, 0.01)
+    same(res.sketch(0), o)
+    # not 4-line FASTQ: loud error (finch_sketch_files is the path with the host parser behind it)
+    bad = tmp_path / "bad.fastq"
+    bad.write_bytes(b"@r1\nACGT\n+\nIIII\n\n@r2\nACGT\n+\nIIII\n" * 100)
+    with pytest.raises(FinchError, match="FASTQ"):
+        H.sketch_file_sharded(str(bad), SketchParams.mash(10, 10, True, 21, 0), H.FilterParams(False), [0, 0], 4096)
+    with pytest.raises(FinchError, match="No such file"):
+        H.sketch_file_sharded(str(tmp_path / "nope.fq"), SketchParams.default(), H.FilterParams(False), [0, 0], 0)

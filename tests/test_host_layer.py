@@ -327,3 +327,72 @@ def test_decompressed_stream_is_the_text_whatever_the_request_size(monkeypatch):
             want = text if name in ("plain", "gzip", "bgzf", "bgzf+gzip") else text[:3_000_000]
             for chunk in (4096, 1 << 20, (5 << 20) + 13, 64 << 20):
                 assert H.source_probe(img, chunk, len(text) + 4096) == want, (name, thr, chunk)
+
+
+def _naive_state_and_halo(text: bytes, off: int, k: int):
+    """what a sketcher that starts at text[off] has to be told: (start_state, last k-1 kept bytes of the record so far)"""
+    in_header, have, kept = False, False, bytearray()
+    i = 0
+    line_start = True
+    while i < off:
+        c = text[i]
+        if line_start and c == 0x3E:
+            in_header, have, kept = True, True, bytearray()
+        if c == 0x0A:
+            in_header = False
+            line_start = True
+        else:
+            if not in_header and c not in b" \t\r":
+                kept.append(c)
+            line_start = False
+        i += 1
+    state = 2 if in_header else (0 if line_start else 1)
+    return state, (bytes(kept[-(k - 1):]) if (k > 1 and have and not in_header) else b"")
+
+
+def test_sharded_reader_chunks_tile_the_text_and_carry_the_right_halo():
+    """finch_sketch_file_sharded's reader (host only): FASTA chunks are cut after newlines, tile the text, and each one
+    carries the start state and the k-1 sequence bytes a sketcher needs to form the k-mers across the cut -- checked
+    against a byte-by-byte walk of the text, with chunks small enough that a halo has to be chained through several of
+    them; FASTQ chunks hold whole records.  Record count / total_bases agree with the parser's."""
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACGTACGTACGTNacgt> \t\r", np.uint8)
+    for case in range(40):
+        lines = []
+        for i in range(int(rng.choice([3, 40, 400]))):
+            r = rng.random()
+            if i == 0 or r < 0.1:
+                lines.append(b">" + bytes(rng.choice(alpha, size=int(rng.integers(0, 30)))).replace(b"\r", b""))
+            elif r < 0.2:
+                lines.append(bytes(rng.choice(np.frombuffer(b" \t", np.uint8), size=int(rng.integers(0, 4)))))
+            else:
+                lines.append(bytes(rng.choice(alpha, size=int(rng.choice([1, 5, 30, 70, 200])))).replace(b"\r", b""))
+        eol = [b"\n", b"\r\n"][case % 2]
+        text = eol.join(lines) + (eol if case % 3 else b"")
+        for k, chunk in ((21, 16), (31, 64), (5, 17), (32, 257), (21, 4096), (64, 100)):
+            chunks, nrec, tb = H.shard_probe(text, k, chunk)
+            pos = 0
+            for off, ln, st, halo in chunks:
+                assert off == pos and 0 < ln <= chunk
+                pos += ln
+                want_st, want_halo = _naive_state_and_halo(text, off, k)
+                assert st == want_st, (case, k, chunk, off)
+                if st == 0 and text[off:off + 1] == b">":
+                    pass  # a header follows at once: whatever halo is passed is cut off by the record breaker
+                else:
+                    assert halo == want_halo, (case, k, chunk, off, halo, want_halo)
+                if pos < len(text) and b"\n" in text[off:pos]:
+                    assert text[pos - 1:pos] == b"\n"  # cut after a newline whenever the chunk holds one
+            assert pos == len(text)
+            n2, tb2, fmt = H.fastx_scan(text)
+            assert (nrec, tb) == (n2, tb2) and fmt == 1
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, b"ACGT" * (1 + i % 9), b"@I+#" * (1 + i % 9)) for i in range(300))
+    for chunk in (200, 1000, 1 << 20):
+        chunks, _, _ = H.shard_probe(fq, 21, chunk)
+        pos = 0
+        for off, ln, st, halo in chunks:
+            assert off == pos and halo == b""
+            piece = fq[off:off + ln]
+            assert piece.startswith(b"@r") and piece.endswith(b"\n") and piece.count(b"\n") % 4 == 0
+            pos += ln
+        assert pos == len(fq)

@@ -1,15 +1,20 @@
 #!/bin/bash
-# full-size bench (configs[1]: 10 Gbase) + rocprofv3 kernel stats + PMC passes for the roofline block
-# usage: bash tools/gpu_bench_full.sh <tag>   -> gpurun_out/<tag>_*
-TAG=${1:-r01}
+# full-size bench + rocprofv3 kernel stats + PMC passes for the roofline block
+# usage: bash tools/gpu_bench_full.sh <tag> [<pmc key> [bench args...]]   -> gpurun_out/<tag>_*
+#   default: configs[1] (10 Gbase, k=21, n=1000), key c2_k21_n1000
+#   e.g.     bash tools/gpu_bench_full.sh r02a_k31 c2_k31_n1000 --k 31
+TAG=${1:-r02}; KEY=${2:-c2_k21_n1000}; shift; shift
+ARGS="$@"
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-python bench.py --steps 5 --warmup 1 2>&1 | tail -1 | tee gpurun_out/${TAG}_bench_10G.json
+if [ -z "$ARGS" ]; then python bench.py --steps 5 --warmup 1 2>&1 | tail -1 | tee gpurun_out/${TAG}_bench_10G.json
+else python bench.py --steps 5 --warmup 1 --no-extras $ARGS 2>&1 | tail -1 | tee gpurun_out/${TAG}_bench_10G.json; fi
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o stats --output-format csv -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_stats.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --kernel-trace -d $R/gpurun_out/${TAG}_pmc_fetch -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/${TAG}_pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --kernel-trace -d $R/gpurun_out/${TAG}_pmc_write -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/${TAG}_pmc_write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $R/gpurun_out/${TAG}_pmc_sq -o p --output-format csv -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/${TAG}_pmc_sq.log 2>&1
+B="python $R/bench.py --no-cpu-baseline --no-extras $ARGS"
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o stats --output-format csv -- $B --steps 5 --warmup 1 > $R/gpurun_out/${TAG}_stats.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --kernel-trace -d $R/gpurun_out/${TAG}_pmc_fetch -o p --output-format csv -- $B --steps 1 --warmup 0 > $R/gpurun_out/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --kernel-trace -d $R/gpurun_out/${TAG}_pmc_write -o p --output-format csv -- $B --steps 1 --warmup 0 > $R/gpurun_out/${TAG}_pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d $R/gpurun_out/${TAG}_pmc_sq -o p --output-format csv -- $B --steps 1 --warmup 0 > $R/gpurun_out/${TAG}_pmc_sq.log 2>&1
 cd $R
 python - <<PY
 import csv,glob,collections,json
@@ -28,7 +33,13 @@ for d in ["gpurun_out/%s_pmc_fetch"%tag,"gpurun_out/%s_pmc_write"%tag,"gpurun_ou
             if "k2_sketch" in r["Kernel_Name"]:
                 tot+=int(r["End_Timestamp"])-int(r["Start_Timestamp"]); cnt+=1
         out.setdefault("k2_duration_ns",{})[d.split("_pmc_")[-1]]={"sum":tot,"dispatches":cnt}
+# positions the profiled launches covered: from the bench line of the same run
+for line in open("gpurun_out/%s_pmc_sq.log"%tag):
+    if line.startswith("{"):
+        r=json.loads(line)["roofline"]; out["positions"]=r["alg_bytes_per_launch"]*r["launches"]; out["launches"]=r["launches"]
 json.dump(out,open("gpurun_out/%s_pmc_k2.json"%tag,"w"),indent=1)
 print(json.dumps(out,indent=1))
 PY
 head -6 gpurun_out/${TAG}_stats/stats_kernel_stats.csv
+cp gpurun_out/${TAG}_stats/stats_kernel_stats.csv gpurun_out/${TAG}_kernel_stats_bench10G.csv
+echo "KEY=$KEY positions=$(python -c "import json;print(json.load(open('gpurun_out/${TAG}_pmc_k2.json')).get('positions'))")"
