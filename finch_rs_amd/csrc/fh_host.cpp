@@ -24,14 +24,13 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/finch_hip.h"
-#include "../../include/finch_host.h"
+#include "fh_host_model.h"
 
 namespace finch {
 
 thread_local std::string g_host_err;
 
-static int hfail(int code, const char *fmt, ...) {
+int hfail(int code, const char *fmt, ...) {
     char buf[768];
     va_list ap;
     va_start(ap, fmt);
@@ -40,33 +39,6 @@ static int hfail(int code, const char *fmt, ...) {
     g_host_err = buf;
     return code;
 }
-
-// ---------------------------------------------------------------------------------------------
-// data model: KmerCount (sketch_schemes/mod.rs:16-22), FilterParams (filtering.rs:11-16),
-// SketchParams (mod.rs:54-71), Sketch (serialization/mod.rs:46-55)
-// ---------------------------------------------------------------------------------------------
-struct KmerCount {
-    uint64_t hash;
-    std::string kmer;
-    uint32_t count, extra_count;
-};
-
-// the same without the k-mer bytes (they stay in the copy-out array, `row` says where): what the filters work on when a
-// 2 M-hash oversketch is about to be cut down to its final 10 000 -- no point in building 2 M strings first
-struct KmerRef {
-    uint64_t hash;
-    uint32_t count, extra_count;
-    uint32_t row;
-};
-
-struct Sketch {
-    std::string name;
-    uint64_t seq_length = 0, num_valid_kmers = 0;
-    std::string comment;
-    std::vector<KmerCount> hashes;
-    finch_filter_params filter_params{};
-    finch_sketch_params sketch_params{};
-};
 
 // statistics.rs:30-47
 template <class KC>
@@ -1711,25 +1683,40 @@ static void json_filters(std::string &o, const finch_filter_params &fp) {
     o.push_back('}');
 }
 
-static int to_json(const std::vector<Sketch> &sketches, std::string &o) {
-    if (sketches.empty()) return hfail(FH_ERR_INVALID, "no sketches to serialise");
-    // SketchParams::from_sketches (mod.rs:158-180): all sketches must be compatible with the first
+// SketchParams::check_compatibility (mod.rs:182-212) of every sketch with the first (from_sketches, mod.rs:158-180)
+int check_compatible(const std::vector<Sketch> &sketches) {
+    if (sketches.empty()) return hfail(FH_ERR_INVALID, "no sketches");
+    auto hash_type = [](const finch_sketch_params &p) { return p.kind == 2 ? "None" : "MurmurHash3_x64_128"; };
+    auto hash_bits = [](const finch_sketch_params &p) { return p.kind == 2 ? 0u : 64u; };
+    auto hash_seed = [](const finch_sketch_params &p) { return p.kind == 2 ? 0ull : (unsigned long long)p.hash_seed; };
     const finch_sketch_params &sp = sketches[0].sketch_params;
     for (size_t i = 1; i < sketches.size(); ++i) {
         const finch_sketch_params &q = sketches[i].sketch_params;
         if (q.kmer_length != sp.kmer_length)
             return hfail(FH_ERR_INVALID, "First sketch has k %u, but sketch %zu has k %u", sp.kmer_length, i + 1, q.kmer_length);
-        if (q.hash_seed != sp.hash_seed)
-            return hfail(FH_ERR_INVALID, "First sketch has hash seed %llu, but sketch %zu has hash seed %llu",
-                         (unsigned long long)sp.hash_seed, i + 1, (unsigned long long)q.hash_seed);
+        if (strcmp(hash_type(q), hash_type(sp)) != 0)
+            return hfail(FH_ERR_INVALID, "First sketch has hash type %s, but sketch %zu has hash type %s", hash_type(sp), i + 1, hash_type(q));
+        if (hash_bits(q) != hash_bits(sp))
+            return hfail(FH_ERR_INVALID, "First sketch has hash bits %u, but sketch %zu has hash bits %u", hash_bits(sp), i + 1, hash_bits(q));
+        if (hash_seed(q) != hash_seed(sp))
+            return hfail(FH_ERR_INVALID, "First sketch has hash seed %llu, but sketch %zu has hash seed %llu", hash_seed(sp), i + 1, hash_seed(q));
     }
-    const uint64_t expected = sp.kind == 0 ? sp.final_size : sp.kmers_to_sketch; // mod.rs:148-156
+    return FH_OK;
+}
+
+static int to_json(const std::vector<Sketch> &sketches, std::string &o) {
+    if (sketches.empty()) return hfail(FH_ERR_INVALID, "no sketches to serialise");
+    if (int rc = check_compatible(sketches)) return rc; // SketchParams::from_sketches (mod.rs:158-180)
+    const finch_sketch_params &sp = sketches[0].sketch_params;
+    // expected_size (mod.rs:148-156); AllCounts: 4^k as the reference's `as u32` leaves it
+    const uint64_t expected = sp.kind == 0 ? sp.final_size : sp.kind == 1 ? sp.kmers_to_sketch
+                              : (sp.kmer_length < 32 ? (1ull << (2 * sp.kmer_length)) : 0ull);
     o.clear();
     o += "{\"kmer\":" + std::to_string(sp.kmer_length);
     o += ",\"alphabet\":\"ACGT\",\"preserveCase\":false,\"canonical\":true";
     o += ",\"sketchSize\":" + std::to_string((uint32_t)expected);
-    o += ",\"hashType\":\"MurmurHash3_x64_128\",\"hashBits\":64";
-    o += ",\"hashSeed\":" + std::to_string(sp.hash_seed);
+    if (sp.kind == 2) o += ",\"hashType\":\"None\",\"hashBits\":0,\"hashSeed\":0"; // hash_info of AllCounts (mod.rs:138-146)
+    else o += ",\"hashType\":\"MurmurHash3_x64_128\",\"hashBits\":64,\"hashSeed\":" + std::to_string(sp.hash_seed);
     o += ",\"scale\":" + (sp.kind == 1 ? json_f64(sp.scale) : std::string("null"));
     o += ",\"sketches\":[";
     for (size_t i = 0; i < sketches.size(); ++i) {
@@ -1770,10 +1757,6 @@ static int to_json(const std::vector<Sketch> &sketches, std::string &o) {
 // C ABI
 // =============================================================================================
 using namespace finch;
-
-struct finch_sketches {
-    std::vector<Sketch> v;
-};
 
 extern "C" {
 

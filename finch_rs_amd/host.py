@@ -71,6 +71,19 @@ _SYMS = {
                                               C.POINTER(C.c_int), C.c_uint32, C.c_uint64, C.POINTER(_P)]),
     "finch_shard_probe": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, _P, _P, C.POINTER(C.c_uint64),
                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "finch_sketches_to_bsk": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "finch_sketches_to_msh": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "finch_free_bytes": (None, [_P]),
+    "finch_sketches_from_bsk": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    "finch_sketches_from_msh": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    "finch_sketches_from_json": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    "finch_open_sketch_file": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "finch_write_sketch_file": (C.c_int, [_P, C.c_char_p]),
+    "finch_sketch_params_of": (C.c_int, [_P, C.c_uint32, C.POINTER(CSketchParams)]),
+    "finch_sketch_comment": (C.c_char_p, [_P, C.c_uint32]),
+    "finch_sketch_set_comment": (C.c_int, [_P, C.c_uint32, C.c_char_p]),
+    "finch_sketches_append": (C.c_int, [_P, _P]),
+    "finch_filter_sketch": (C.c_int, [_P, C.c_uint32, C.POINTER(CFilterParams)]),
     "finch_sketches_free": (None, [_P]),
     "finch_sketches_len": (C.c_uint32, [_P]),
     "finch_sketch_name": (C.c_char_p, [_P, C.c_uint32]),
@@ -138,9 +151,19 @@ class Sketches:
     def __len__(self):
         return lib().finch_sketches_len(self._p)
 
+    def params_of(self, i: int) -> SketchParams:
+        c = CSketchParams()
+        _check(lib().finch_sketch_params_of(self._p, i, C.byref(c)))
+        kind = {0: "mash", 1: "scaled", 2: "allcounts"}[c.kind]
+        # (only the Scaled variant has a scale; the dataclass default stands in elsewhere so that equal variants compare equal)
+        return SketchParams(kind, c.kmers_to_sketch, c.final_size, bool(c.no_strict), c.kmer_length, c.hash_seed,
+                            c.scale if kind == "scaled" else SketchParams().scale)
+
     def sketch(self, i: int) -> Sketch:
         L = lib()
         n = L.finch_sketch_n_hashes(self._p, i)
+        if self.params is None:
+            return self._sketch_loaded(i)
         k = self.params.kmer_length
         hs, cs, es = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
         km = np.zeros((n, k), np.uint8)
@@ -153,6 +176,55 @@ class Sketches:
         return Sketch(L.finch_sketch_name(self._p, i).decode(), L.finch_sketch_seq_length(self._p, i),
                       L.finch_sketch_num_valid_kmers(self._p, i), "", hashes, FilterParams.from_c(fp), self.params,
                       (kc, km))
+
+    def _sketch_loaded(self, i: int) -> Sketch:
+        """a sketch that came out of a file: k-mers may be absent (.msh) or of any length"""
+        L = lib()
+        n = L.finch_sketch_n_hashes(self._p, i)
+        p = self.params_of(i)
+        hs, cs, es = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        km = np.zeros((n, p.kmer_length), np.uint8)
+        _check(L.finch_sketch_copy(self._p, i, hs.ctypes.data, cs.ctypes.data, es.ctypes.data, km.ctypes.data))
+        fp = CFilterParams()
+        _check(L.finch_sketch_filter_params(self._p, i, C.byref(fp)))
+        kc = np.zeros(n, dtype=KC_DTYPE)
+        kc["hash"], kc["count"], kc["extra_count"] = hs, cs, es
+        has_kmers = bool(km.any())
+        hashes = [KmerCount(int(hs[j]), bytes(km[j]) if has_kmers else b"", int(cs[j]), int(es[j])) for j in range(n)]
+        return Sketch(L.finch_sketch_name(self._p, i).decode(), L.finch_sketch_seq_length(self._p, i),
+                      L.finch_sketch_num_valid_kmers(self._p, i), L.finch_sketch_comment(self._p, i).decode(), hashes,
+                      FilterParams.from_c(fp), p, (kc, km))
+
+    def _bytes(self, fn) -> bytes:
+        out, n = _P(), C.c_uint64()
+        _check(fn(self._p, C.byref(out), C.byref(n)))
+        try:
+            return C.string_at(out.value, n.value)
+        finally:
+            lib().finch_free_bytes(out)
+
+    def to_bsk(self) -> bytes:
+        """write_finch_file (serialization/mod.rs:123-166)"""
+        return self._bytes(lib().finch_sketches_to_bsk)
+
+    def to_msh(self) -> bytes:
+        """write_mash_file (serialization/mash.rs:12-58)"""
+        return self._bytes(lib().finch_sketches_to_msh)
+
+    def write(self, path: str) -> None:
+        """.sk / .json, .bsk or .msh by file name (cli/src/main.rs:53-70)"""
+        _check(lib().finch_write_sketch_file(self._p, path.encode()))
+
+    def append(self, other: "Sketches") -> None:
+        _check(lib().finch_sketches_append(self._p, other._p))
+
+    def set_comment(self, i: int, comment: str) -> None:
+        _check(lib().finch_sketch_set_comment(self._p, i, comment.encode()))
+
+    def filter_sketch(self, i: int, filters: FilterParams) -> None:
+        """FilterParams::filter_sketch (filtering.rs:20-54)"""
+        c = filters.to_c()
+        _check(lib().finch_filter_sketch(self._p, i, C.byref(c)))
 
     def to_list(self) -> List[Sketch]:
         return [self.sketch(i) for i in range(len(self))]
@@ -230,6 +302,36 @@ def shard_probe(data: bytes, k: int, chunk_bytes: int):
         off, ln, st, hl = (int(x) for x in meta[4 * i:4 * i + 4])
         out.append((off, ln, st, halos[64 * i:64 * i + hl].tobytes()))
     return out, nr.value, tb.value
+
+
+def _loaded(fn, *args) -> Sketches:
+    out = _P()
+    _check(fn(*args, C.byref(out)))
+    return Sketches(out, None)  # parameters live per sketch (Sketches.params_of)
+
+
+def sketches_from_bsk(data: bytes) -> Sketches:
+    """read_finch_file (serialization/mod.rs:168-222)"""
+    buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+    return _loaded(lib().finch_sketches_from_bsk, buf.ctypes.data, len(data))
+
+
+def sketches_from_msh(data: bytes) -> Sketches:
+    """read_mash_file (serialization/mash.rs:60-135)"""
+    buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+    return _loaded(lib().finch_sketches_from_msh, buf.ctypes.data, len(data))
+
+
+def sketches_from_json(text) -> Sketches:
+    """MultiSketch::to_sketches (serialization/json.rs:244-262)"""
+    data = text.encode() if isinstance(text, str) else bytes(text)
+    buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+    return _loaded(lib().finch_sketches_from_json, buf.ctypes.data, len(data))
+
+
+def open_sketch_file(path: str) -> Sketches:
+    """finch::open_sketch_file (lib.rs:96-118)"""
+    return _loaded(lib().finch_open_sketch_file, path.encode())
 
 
 def sketches_from_arrays(name, seq_length, num_valid_kmers, kc, km, sketch_params: SketchParams, filters: FilterParams) -> Sketches:

@@ -29,7 +29,7 @@ extern "C" {
 
 /* SketchParams (mod.rs:54-71); AllCounts is not on the accelerated path */
 typedef struct finch_sketch_params {
-    uint32_t kind;            /* 0 = Mash, 1 = Scaled */
+    uint32_t kind;            /* 0 = Mash, 1 = Scaled (2 = AllCounts: serialisation only) */
     uint32_t kmer_length;
     uint64_t kmers_to_sketch;
     uint64_t final_size;      /* Mash only */
@@ -97,6 +97,33 @@ int finch_sketch_copy(const finch_sketches *s, uint32_t i, uint64_t *hashes, uin
  * finch_free_string. */
 int finch_sketches_to_json(const finch_sketches *s, char **out, uint64_t *len);
 void finch_free_string(char *p);
+
+/* ---- the other sketch file formats (lib/src/serialization/) ----
+ * .bsk = write_finch_file / read_finch_file (mod.rs:123-222, schema finch.capnp), .msh = write_mash_file / read_mash_file
+ * (mash.rs:12-135, schema mash.capnp): Cap'n Proto messages in the standard unpacked stream framing, as the reference's
+ * capnp::serialize::write_message emits them.  The writers produce single-segment messages (at most 4 GiB; beyond that
+ * FH_ERR_UNSUPPORTED); the readers take any valid message, the reference's multi-segment files included.  *out is
+ * malloc'ed: finch_free_bytes. */
+int finch_sketches_to_bsk(const finch_sketches *s, uint8_t **out, uint64_t *len);
+int finch_sketches_to_msh(const finch_sketches *s, uint8_t **out, uint64_t *len);
+void finch_free_bytes(uint8_t *p);
+int finch_sketches_from_bsk(const uint8_t *data, uint64_t len, finch_sketches **out);
+int finch_sketches_from_msh(const uint8_t *data, uint64_t len, finch_sketches **out);
+/* MultiSketch::to_sketches over serde_json::from_slice (json.rs:92-139, 160-262; filtering.rs:110-134): the `.sk` reader */
+int finch_sketches_from_json(const uint8_t *data, uint64_t len, finch_sketches **out);
+/* open_sketch_file (lib.rs:96-118): *.msh / *.bsk / *.sk, *.json by file name */
+int finch_open_sketch_file(const char *path, finch_sketches **out);
+/* the `sketch` subcommand's output step (cli/src/main.rs:53-70): format by file name */
+int finch_write_sketch_file(const finch_sketches *s, const char *path);
+/* SketchParams of sketch i; kind 2 = AllCounts (only ever seen in files that were read: it is not on the accelerated path) */
+int finch_sketch_params_of(const finch_sketches *s, uint32_t i, finch_sketch_params *out);
+const char *finch_sketch_comment(const finch_sketches *s, uint32_t i);
+int finch_sketch_set_comment(finch_sketches *s, uint32_t i, const char *comment);
+/* dst.extend(src): the CLI collects the sketches of all its inputs before it writes one file (main.rs:60-70) */
+int finch_sketches_append(finch_sketches *dst, const finch_sketches *src);
+/* FilterParams::filter_sketch (filtering.rs:20-54) exactly as the reference has it: sketch i's filter parameters take
+ * the stricter of their own and `filters`' values; its hashes are left alone (the reference drops the filtered list). */
+int finch_filter_sketch(finch_sketches *s, uint32_t i, const finch_filter_params *filters);
 
 /* distance (lib/src/distance.rs:9-47): compares sketch ia of `a` (query) with sketch ib of `b` (reference).
  * raw_distance (distance.rs:66-126) unless old_mode (old_distance, distance.rs:136-157). */

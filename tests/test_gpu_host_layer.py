@@ -445,8 +445,8 @@ def test_one_input_across_several_device_handles(tmp_path):
     pz = tmp_path / "reads.fastq.gz"
     pz.write_bytes(gzip.compress(fq, 1))
     filt = H.FilterParams(None, (None, None), 0.21, 0.1)
-    for k, n_eff, final in ((21, 3000, 200), (31, 500, 500)):
-        params = SketchParams.mash(n_eff, final, False, k, 0)
+    for k, n_eff, final in ((21, 20000, 200), (31, 500, 500)):
+        params = SketchParams.mash(n_eff, final, True, k, 0)
         one = H.sketch_files([str(pq)], params, filt).sketch(0)
         o, fmt = oracle_sketch(fq, O.MASH, n_eff, k)
         okc, okm = o.to_vec()
