@@ -652,6 +652,168 @@ FH_HD u64 murmur_h1_fast(u64 cm, u64 seed, const LutTables &T) {
     return murmur_finish<K, SEED0>(w, seed);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// K = 33..64: k-mers of two 64-bit words.  finch's kmer_length is a u8 (sketch_schemes/mod.rs:54-71) and the reference
+// hashes whatever length it is given; beyond 32 bases the canonical word no longer fits a register pair, so these K use
+// their own window type.  Everything else -- classification, the lookup tables (a K-byte murmur3 key is K/16 blocks of
+// two 8-byte words + a tail, each word two 4-base groups: word_geom, key_word_mix, murmur_finish_parts are written for any
+// K) -- is shared with the narrow path.
+//   * a lane still owns 32 start positions, but a window now reaches up to 63 bases beyond its start: the lane sees 96
+//     bases (its own 32 and the two following lanes' 32 each) as three l-form code words;
+//   * the reverse-complement string nC (~codes << PRE) and the digit-reversed string D (base b at digit 95 - b) are 192 bits
+//     long; window j is bits [2j, +NB) of nC and bits [2(96 - K - j) - PRE, +NB) of D, NB = 2K + PRE <= 128;
+//   * the canonical word (<< PRE) is four dwords; every 4-base group of the murmur3 key is a byte of one of them.
+// ------------------------------------------------------------------------------------------------------------------
+struct U128 {
+    u64 lo, hi;
+};
+FH_HD bool less128(U128 a, U128 b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+
+template <int K>
+struct WindowsW {
+    static_assert(K > 32 && K <= 64, "WindowsW serves K = 33..64");
+    static constexpr int PRE = pre_shift(K), NB = 2 * K + PRE; // 72..128
+    u32 nC[8], D[8];
+
+    FH_HDM void init(u64 c0, u64 c1, u64 c2) {
+        const u32 w[6] = {~(u32)c0, ~(u32)(c0 >> 32), ~(u32)c1, ~(u32)(c1 >> 32), ~(u32)c2, ~(u32)(c2 >> 32)};
+        if (PRE == 0) {
+            for (int i = 0; i < 6; ++i) nC[i] = w[i];
+            nC[6] = 0;
+        } else {
+            nC[0] = w[0] << PRE;
+            for (int i = 1; i < 6; ++i) nC[i] = alignbit_b32(w[i], w[i - 1], 32 - PRE);
+            nC[6] = w[5] >> (32 - PRE);
+        }
+        nC[7] = 0;
+        const u64 r0 = pairrev64(c2), r1 = pairrev64(c1), r2 = pairrev64(c0);
+        D[0] = (u32)r0;
+        D[1] = (u32)(r0 >> 32);
+        D[2] = (u32)r1;
+        D[3] = (u32)(r1 >> 32);
+        D[4] = (u32)r2;
+        D[5] = (u32)(r2 >> 32);
+        D[6] = D[7] = 0;
+    }
+    // bits [off, off + NB) of the string W, as four dwords d[0..3]
+    static FH_HDM void field(const u32 *W, int off, u32 *d) {
+        const int w = off >> 5, s = off & 31;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 4; ++i) {
+            if (32 * i >= NB) d[i] = 0;
+            else {
+                u32 x = s ? alignbit_b32(W[w + i + 1], W[w + i], (u32)s) : W[w + i];
+                if (NB - 32 * i < 32) x &= (1u << (NB - 32 * i)) - 1u;
+                d[i] = x;
+            }
+        }
+    }
+    FH_HDM void fwd(int j, u32 *d) const { field(D, 2 * (96 - K - j) - PRE, d); }
+    // (even K: a k-mer may equal its reverse complement; the scrap bits are cleared on this side so that the tie goes to
+    //  rc, exactly as in Windows<K>::rc)
+    FH_HDM void rc(int j, u32 *d) const {
+        field(nC, 2 * j, d);
+        if (K % 2 == 0 && PRE) d[0] &= ~((1u << PRE) - 1u);
+    }
+    // the canonical m-form word << PRE as four dwords; tie -> rc (needletail canonical_kmers)
+    FH_HDM void canonical(int j, u32 *cm, bool &is_rc) const {
+        u32 f[4], r[4];
+        fwd(j, f);
+        rc(j, r);
+        const U128 F{((u64)f[1] << 32) | f[0], ((u64)f[3] << 32) | f[2]}, R{((u64)r[1] << 32) | r[0], ((u64)r[3] << 32) | r[2]};
+        is_rc = !less128(F, R);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 4; ++i) cm[i] = is_rc ? r[i] : f[i];
+    }
+};
+
+// the canonical k-mer itself (m-form, 2K bits) from the pre-shifted dwords
+template <int K>
+FH_HD U128 kmer_words_w(const u32 *cm) {
+    constexpr int PRE = pre_shift(K);
+    const u64 lo = ((u64)cm[1] << 32) | cm[0], hi = ((u64)cm[3] << 32) | cm[2];
+    if (PRE == 0) return U128{lo, hi};
+    return U128{(lo >> PRE) | (hi << (64 - PRE)), hi >> PRE};
+}
+
+// bit j: the K-base window starting at base j (0..31) lies entirely in good bases; g0 / g1 / g2 = good bits of the lane's
+// own 32 bases and of the next two lanes'
+template <int K>
+FH_HD u32 window_valid_mask_w(u32 g0, u32 g1, u32 g2) {
+    typedef unsigned __int128 u128;
+    u128 A[7];
+    A[0] = (u128)g0 | ((u128)g1 << 32) | ((u128)g2 << 64);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int p = 1; p < 7; ++p) A[p] = A[p - 1] & (A[p - 1] >> (1 << (p - 1)));
+    u128 W = ~(u128)0;
+    int off = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int p = 6; p >= 0; --p) {
+        if (K & (1 << p)) {
+            W &= (A[p] >> off);
+            off += (1 << p);
+        }
+    }
+    return (u32)W;
+}
+
+// byte offset of a group's record: full groups are bytes of one of the four dwords (shift is a multiple of 8, see
+// pre_shift); the key's last, short group sits in the low bits of dword 0
+FH_HD u32 field_off_w(const u32 *cm, int shift, int nb, int lg) {
+    if (nb == 4 && (shift & 7) == 0) return byte_shl(cm[shift >> 5], (shift >> 3) & 3, lg);
+    const u32 fm = ((1u << (2 * nb)) - 1u) << lg;
+    const int sh = shift - lg;
+    return sh >= 0 ? (cm[0] >> sh) & fm : (cm[0] << (-sh)) & fm;
+}
+
+template <int K>
+FH_HD void murmur_lookup_w(const u32 *cm, const LutTables &T, KeyWords<K> &w) { // cm = canonical word << pre_shift(K), 4 dwords
+    constexpr int PRE = pre_shift(K);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < KeyWords<K>::N; ++i) {
+        const WordGeom g = word_geom(K, i);
+        w.a0[i] = w.a1[i] = w.a2[i] = w.b0[i] = w.b1[i] = 0;
+        if (g.kind == 1) {
+            const Rec2 r = *(const Rec2 *)((const char *)T.P + field_off_w(cm, g.shiftA + PRE, g.nbA, 3));
+            w.a0[i] = r.x;
+            w.a1[i] = r.y;
+        } else if (g.kind == 2) {
+            const Rec4 ra = *(const Rec4 *)((const char *)(g.is_k2 ? T.A2 : T.A1) + field_off_w(cm, g.shiftA + PRE, 4, 4));
+            const Rec2 *TB = g.partial ? T.P : (g.is_k2 ? T.B2 : T.B1);
+            const Rec2 rb = *(const Rec2 *)((const char *)TB + field_off_w(cm, g.shiftB + PRE, g.nbB, 3));
+            w.a0[i] = ra.x;
+            w.a1[i] = ra.y;
+            w.a2[i] = ra.z;
+            w.b0[i] = rb.x;
+            w.b1[i] = rb.y;
+        }
+    }
+}
+
+template <int K>
+FH_HD u64 murmur_h1_fast_w(const u32 *cm, u64 seed, const LutTables &T) {
+    KeyWords<K> w;
+    murmur_lookup_w<K>(cm, T, w);
+    return murmur_finish<K, false>(w, seed);
+}
+
+// ASCII of a k-mer held as two m-form words (hi: the first K - 32 bases when K > 32)
+FH_HD uint8_t kmer_base(u64 lo, u64 hi, int k, int b) {
+    const int d = k - 1 - b; // digit, counted from the last base
+    const u32 code = (u32)(((d >= 32) ? (hi >> (2 * (d - 32))) : (lo >> (2 * d))) & 3u);
+    return (uint8_t) "ACGT"[code];
+}
+
 // table slot key: admitted hashes are small numbers, so mix before scaling to the table size
 FH_HD u32 slot_key(u64 h) { return (u32)((h * 0x9E3779B97F4A7C15ULL) >> 32); }
 

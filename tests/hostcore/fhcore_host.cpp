@@ -79,6 +79,65 @@ extern "C" int fhcore_positions(const uint8_t *seq, uint64_t len, int k, uint64_
     return dispatch<32>(k, seq, len, seed, hashes, valid, isrc, canon);
 }
 
+// K = 33..64 (WindowsW): the same walk with three code words per lane segment; canon receives two words per position
+// (low, high) of the canonical k-mer in m-form
+template <int K>
+static int run_w(const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hashes, uint8_t *valid, uint8_t *isrc,
+                 uint64_t *canon) {
+    std::vector<uint8_t> buf(((len + 31) / 32) * 32 + 128, 0);
+    memcpy(buf.data(), seq, len);
+    std::vector<Rec4> A1(256), A2(256);
+    std::vector<Rec2> B1(256), B2(256), P(partial_entries(K));
+    for (u32 q = 0; q < 256; ++q) {
+        A1[q] = lut_rec_A(q, false);
+        A2[q] = lut_rec_A(q, true);
+        B1[q] = lut_rec_B(q, 4, false);
+        B2[q] = lut_rec_B(q, 4, true);
+    }
+    for (u32 q = 0; q < (u32)partial_entries(K); ++q) P[q] = lut_rec_P<K>(q);
+    const LutTables LT{A1.data(), A2.data(), B1.data(), B2.data(), P.data()};
+    for (uint64_t s = 0; s < len; s += 32) {
+        u32 cw[6], gw[6];
+        for (int c = 0; c < 6; ++c) {
+            u32 d[4];
+            memcpy(d, buf.data() + s + 16 * c, 16);
+            classify_chunk(d[0], d[1], d[2], d[3], cw[c], gw[c]);
+        }
+        const u64 c0 = (u64)cw[0] | ((u64)cw[1] << 32), c1 = (u64)cw[2] | ((u64)cw[3] << 32), c2 = (u64)cw[4] | ((u64)cw[5] << 32);
+        WindowsW<K> win;
+        win.init(c0, c1, c2);
+        const u32 W = window_valid_mask_w<K>(gw[0] | (gw[1] << 16), gw[2] | (gw[3] << 16), gw[4] | (gw[5] << 16));
+        for (int j = 0; j < 32; ++j) {
+            const uint64_t p = s + j;
+            if (p >= len) break;
+            bool rc;
+            u32 cm[4];
+            win.canonical(j, cm, rc);
+            valid[p] = (W >> j) & 1u;
+            isrc[p] = rc ? 1 : 0;
+            const U128 km = kmer_words_w<K>(cm);
+            canon[2 * p] = km.lo;
+            canon[2 * p + 1] = km.hi;
+            hashes[p] = murmur_h1_fast_w<K>(cm, seed, LT);
+        }
+    }
+    return 0;
+}
+
+template <int K>
+static int dispatch_w(int k, const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hashes, uint8_t *valid,
+                      uint8_t *isrc, uint64_t *canon) {
+    if (k == K) return run_w<K>(seq, len, seed, hashes, valid, isrc, canon);
+    if constexpr (K > 33) return dispatch_w<K - 1>(k, seq, len, seed, hashes, valid, isrc, canon);
+    return -1;
+}
+
+extern "C" int fhcore_positions_w(const uint8_t *seq, uint64_t len, int k, uint64_t seed, uint64_t *hashes,
+                                  uint8_t *valid, uint8_t *isrc, uint64_t *canon) {
+    if (k < 33 || k > 64) return -1;
+    return dispatch_w<64>(k, seq, len, seed, hashes, valid, isrc, canon);
+}
+
 extern "C" void fhcore_synth(uint8_t *genome, uint64_t glen, uint8_t *reads, uint64_t first, uint64_t n, uint32_t rl,
                              uint64_t seed, uint32_t sub_ppm, uint32_t n_ppm) {
     for (uint64_t i = 0; i < glen; ++i) genome[i] = synth_genome_base(seed, i);

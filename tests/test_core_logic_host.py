@@ -24,6 +24,8 @@ def core():
     L = C.CDLL(SO)
     L.fhcore_positions.restype = C.c_int
     L.fhcore_positions.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64] + [C.c_void_p] * 4
+    L.fhcore_positions_w.restype = C.c_int
+    L.fhcore_positions_w.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64] + [C.c_void_p] * 4
     return L
 
 
@@ -70,6 +72,45 @@ def test_positions_match_oracle(core, k):
         if v:
             assert isrc[p] == r, (k, p)
             assert int(hashes[p]) == h, (k, p)
+
+
+@pytest.mark.parametrize("k", list(range(33, 65)))
+def test_wide_positions_match_oracle(core, k):
+    """K = 33..64 (two-word k-mers, WindowsW): valid / strand / hash per position and the canonical k-mer's 2K bits"""
+    rng = np.random.default_rng(500 + k)
+    alphabet = np.frombuffer(b"ACGTNacgtuU-.x\x00\xff", dtype=np.uint8)
+    probs = np.array([30, 30, 30, 30, .4, 2, 2, 2, 2, 1, 1, .1, .1, .1, .1, .1])
+    probs = probs / probs.sum()
+    seq = rng.choice(alphabet, size=int(rng.integers(300, 700)), p=probs)
+    if k % 2 == 0:  # plant a reverse-palindromic k-mer: the tie must report rc
+        half = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=k // 2)
+        comp = {65: 84, 67: 71, 71: 67, 84: 65}
+        seq[100:100 + k] = np.concatenate([half, np.array([comp[int(b)] for b in half[::-1]], np.uint8)])
+    seed = int(rng.integers(0, 2**63)) if k % 2 else 0
+    n = len(seq)
+    hashes, valid, isrc = np.zeros(n, np.uint64), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    canon = np.zeros(2 * n, np.uint64)
+    assert core.fhcore_positions_w(seq.ctypes.data, n, k, seed, hashes.ctypes.data, valid.ctypes.data, isrc.ctypes.data,
+                                   canon.ctypes.data) == 0
+    norm = O.normalize(bytes(seq))
+    assert len(norm) == n
+    ref = naive(norm, k, seed)
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    n_valid = 0
+    for p, (v, r, h) in enumerate(ref):
+        assert valid[p] == v, (k, p)
+        if v:
+            n_valid += 1
+            assert isrc[p] == r and int(hashes[p]) == h, (k, p)
+            w = norm[p:p + k]
+            km = bytes(comp[b] for b in reversed(w)) if r else w
+            val = 0
+            for b in km:
+                val = (val << 2) | b"ACGT".index(b)
+            assert (int(canon[2 * p + 1]) << 64) | int(canon[2 * p]) == val, (k, p)
+    assert n_valid > 20
+    if k % 2 == 0:
+        assert valid[100] == 1 and isrc[100] == 1
 
 
 def test_palindrome_reports_rc(core):
