@@ -91,8 +91,9 @@ constexpr int N_STAGE = 2;
 struct ResultRec {
     uint64_t hash;
     uint32_t count, extra;
-    uint64_t kmer; // m-form
+    uint64_t kmer; // m-form (K > 32: the last 32 bases)
     uint64_t pos;
+    uint64_t kmer_hi = 0; // K > 32: the first K - 32 bases
 };
 
 } // namespace
@@ -117,6 +118,8 @@ struct fh_sketcher {
     CollRec *clog = nullptr;
     // gather outputs (device), capacity out_cap (grown on demand)
     uint64_t *o_hash = nullptr, *o_kmer = nullptr, *o_pos = nullptr;
+    uint64_t *o_kmer_hi = nullptr; // K > 32 only
+    uint64_t *kmer_hi = nullptr;   // K > 32 only: high words of the table's k-mers, one per slot (fh_device.h)
     uint32_t *o_count = nullptr, *o_extra = nullptr;
     uint32_t out_cap = 0;
     // device-wide selection (fh_big.hip), allocated on first use
@@ -193,7 +196,7 @@ struct fh_sketcher {
     // finished result (host), ascending by hash
     // fh_finish leaves the result as arrays in the pinned D2H buffer (r_* point into h_out); the record vector is
     // only built when a merge needs it (2 M records: 10 ms of host time that fh_copy_out does not need)
-    uint64_t *r_hash = nullptr, *r_kmer = nullptr, *r_pos = nullptr;
+    uint64_t *r_hash = nullptr, *r_kmer = nullptr, *r_pos = nullptr, *r_kmer_hi = nullptr;
     uint32_t *r_count = nullptr, *r_extra = nullptr;
     size_t r_n = 0;
     bool res_built = false;
@@ -624,7 +627,7 @@ int big_prune(fh_sketcher *s, bool sorted) {
         } else if (shard_cap_for(s, s->live_target) > s->shard_cap) {
             if (int rc = alloc_shards(s, s->live_target + s->live_target / 2)) return rc;
             HIP_TRY(launch_set_table(s->ctl, s->table, s->live, s->clog, s->cap, s->live_cap, CLOG_CAP, s->shard_cnt,
-                                     s->shard_buf, s->shard_cap, s->stream));
+                                     s->shard_buf, s->shard_cap, s->kmer_hi, s->stream));
         }
     }
     return FH_OK;
@@ -638,14 +641,21 @@ int grow_table(fh_sketcher *s, uint64_t new_live_cap) {
     HIP_TRY(dev_malloc(&nt, new_cap * sizeof(Entry)));
     HIP_TRY(dev_malloc(&nl, new_live_cap * sizeof(uint32_t)));
     HIP_TRY(dev_malloc(&nd, new_live_cap * sizeof(uint32_t)));
+    uint64_t *nh = nullptr;
+    if (s->p.k > 32) {
+        HIP_TRY(dev_malloc(&nh, new_cap * sizeof(uint64_t)));
+        HIP_TRY(hipMemsetAsync(nh, 0xFF, new_cap * sizeof(uint64_t), s->stream)); // EMPTY64 = not written
+    }
     HIP_TRY(launch_fill_table(nt, new_cap, s->stream));
-    HIP_TRY(launch_rehash(s->table, s->live, s->last_live, nt, (uint32_t)new_cap, nl, s->ctl, s->stream));
+    HIP_TRY(launch_rehash(s->table, s->live, s->last_live, nt, (uint32_t)new_cap, nl, s->ctl, s->kmer_hi, nh, s->stream));
     uint32_t zero = 0;
     HIP_TRY(hipMemcpyAsync(&s->ctl->n_dead, &zero, 4, hipMemcpyHostToDevice, s->stream)); // garbage stayed behind
     HIP_TRY(hipStreamSynchronize(s->stream));
     (void)hipFree(s->table);
     (void)hipFree(s->live);
     (void)hipFree(s->dead);
+    (void)hipFree(s->kmer_hi);
+    s->kmer_hi = nh;
     s->table = nt;
     s->live = nl;
     s->dead = nd;
@@ -654,7 +664,7 @@ int grow_table(fh_sketcher *s, uint64_t new_live_cap) {
     s->dead_cap = (uint32_t)new_live_cap;
     if (int rc = alloc_shards(s, s->live_target)) return rc;
     HIP_TRY(launch_set_table(s->ctl, s->table, s->live, s->clog, s->cap, s->live_cap, CLOG_CAP, s->shard_cnt, s->shard_buf,
-                             s->shard_cap, s->stream));
+                             s->shard_cap, s->kmer_hi, s->stream));
     return check_ctl(s);
 }
 
@@ -662,10 +672,12 @@ int ensure_out(fh_sketcher *s, uint32_t n) {
     if (n <= s->out_cap) return FH_OK;
     HIP_TRY(hipStreamSynchronize(s->stream));
     (void)hipFree(s->o_hash); (void)hipFree(s->o_kmer); (void)hipFree(s->o_pos); (void)hipFree(s->o_count); (void)hipFree(s->o_extra);
-    s->o_hash = s->o_kmer = s->o_pos = nullptr; s->o_count = s->o_extra = nullptr;
+    (void)hipFree(s->o_kmer_hi);
+    s->o_hash = s->o_kmer = s->o_pos = s->o_kmer_hi = nullptr; s->o_count = s->o_extra = nullptr;
     const uint32_t cap = std::max<uint32_t>(n, (uint32_t)SMALL_MAX);
     HIP_TRY(dev_malloc(&s->o_hash, (size_t)cap * 8));
     HIP_TRY(dev_malloc(&s->o_kmer, (size_t)cap * 8));
+    if (s->p.k > 32) HIP_TRY(dev_malloc(&s->o_kmer_hi, (size_t)cap * 8));
     HIP_TRY(dev_malloc(&s->o_pos, (size_t)cap * 8));
     HIP_TRY(dev_malloc(&s->o_count, (size_t)cap * 4));
     HIP_TRY(dev_malloc(&s->o_extra, (size_t)cap * 4));
@@ -733,6 +745,7 @@ int merge_sorted(const std::vector<ResultRec> &a, const std::vector<ResultRec> &
             if (d.pos < r.pos) {
                 r.pos = d.pos;
                 r.kmer = d.kmer;
+                r.kmer_hi = d.kmer_hi;
             }
             out.push_back(r);
             ++i;
@@ -751,7 +764,14 @@ struct Ascii4Lut {
 };
 const Ascii4Lut g_ascii4;
 
-void kmer_ascii(uint64_t m, int k, uint8_t *out) {
+// (mhi: the first k - 32 bases of a k-mer longer than 32)
+void kmer_ascii(uint64_t m, uint64_t mhi, int k, uint8_t *out) {
+    if (k > 32) {
+        const int nh = k - 32;
+        for (int b = 0; b < nh; ++b) out[b] = (uint8_t) "ACGT"[(mhi >> (2 * (nh - 1 - b))) & 3u];
+        out += nh;
+        k = 32;
+    }
     int b = 0;
     for (; b + 4 <= k; b += 4) {
         const uint32_t w = g_ascii4.v[(m >> (2 * (k - b - 4))) & 0xFFu];
@@ -760,14 +780,22 @@ void kmer_ascii(uint64_t m, int k, uint8_t *out) {
     for (; b < k; ++b) out[b] = (uint8_t) "ACGT"[(m >> (2 * (k - 1 - b))) & 3u];
 }
 
-uint64_t ascii_kmer(const uint8_t *in, int k) {
-    uint64_t m = 0;
+uint64_t ascii_kmer(const uint8_t *in, int k, uint64_t *mhi) {
+    uint64_t m = 0, h = 0;
     for (int b = 0; b < k; ++b) {
         const uint8_t c = in[b];
         const uint64_t code = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3;
+        h = (h << 2) | (m >> 62);
         m = (m << 2) | code;
     }
+    *mhi = h;
     return m;
+}
+
+ResultRec make_rec(uint64_t hash, uint32_t count, uint32_t extra, const uint8_t *kmer_ascii_bytes, int k, uint64_t pos) {
+    ResultRec r{hash, count, extra, 0, pos};
+    r.kmer = ascii_kmer(kmer_ascii_bytes, k, &r.kmer_hi);
+    return r;
 }
 
 uint32_t sat_add(uint32_t a, uint32_t b) {
@@ -817,7 +845,7 @@ uint64_t pool_max_bytes() {
     return v;
 }
 uint64_t handle_bytes(const fh_sketcher *s) {
-    uint64_t b = (uint64_t)s->cap * sizeof(Entry) + (uint64_t)s->live_cap * 8 + (uint64_t)s->shard_cap * N_SHARDS * 4;
+    uint64_t b = (uint64_t)s->cap * (sizeof(Entry) + (s->kmer_hi ? 8 : 0)) + (uint64_t)s->live_cap * 8 + (uint64_t)s->shard_cap * N_SHARDS * 4;
     for (int i = 0; i < N_STAGE; ++i) b += 2 * s->stage_cap[i];
     return b + (uint64_t)s->out_cap * 32 + (uint64_t)s->big_cap * 24;
 }
@@ -880,8 +908,8 @@ static fh_sketcher *new_handle(const fh_params *params, int device) {
         fail(FH_ERR_INVALID, "params is NULL");
         return nullptr;
     }
-    if (params->k < 1 || params->k > 32) {
-        fail(FH_ERR_UNSUPPORTED, "kmer_length %u outside the device range 1..32", params->k);
+    if (params->k < 1 || params->k > (uint32_t)FH_MAX_K) {
+        fail(FH_ERR_UNSUPPORTED, "kmer_length %u outside the device range 1..%d", params->k, FH_MAX_K);
         return nullptr;
     }
     if (params->kind != FH_KIND_MASH && params->kind != FH_KIND_SCALED) {
@@ -943,6 +971,10 @@ static fh_sketcher *new_handle(const fh_params *params, int device) {
     s->cap = (uint32_t)cap;
     s->live_cap = (uint32_t)live_cap;
     if ((e = hipMalloc(&s->table, cap * sizeof(Entry))) != hipSuccess) return bail("hipMalloc(table)", e);
+    if (params->k > 32) { // two-word k-mers: the high words live beside the table (fh_device.h, Ctl::kmer_hi)
+        if ((e = hipMalloc(&s->kmer_hi, cap * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc(kmer_hi)", e);
+        if ((e = hipMemsetAsync(s->kmer_hi, 0xFF, cap * sizeof(uint64_t), s->stream)) != hipSuccess) return bail("hipMemset(kmer_hi)", e);
+    }
     if ((e = hipMalloc(&s->live, live_cap * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(live)", e);
     s->dead_cap = (uint32_t)live_cap;
     if ((e = hipMalloc(&s->dead, (size_t)s->dead_cap * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(dead)", e);
@@ -960,7 +992,7 @@ static fh_sketcher *new_handle(const fh_params *params, int device) {
         return nullptr;
     }
     if ((e = launch_set_table(s->ctl, s->table, s->live, s->clog, s->cap, s->live_cap, CLOG_CAP, s->shard_cnt, s->shard_buf,
-                              s->shard_cap, s->stream)) != hipSuccess)
+                              s->shard_cap, s->kmer_hi, s->stream)) != hipSuccess)
         return bail("set_table", e);
     if (init_state(s) != FH_OK) {
         destroy_handle(s);
@@ -1022,6 +1054,8 @@ void destroy_handle(fh_sketcher *s) {
     (void)hipFree(s->clog);
     (void)hipFree(s->o_hash);
     (void)hipFree(s->o_kmer);
+    (void)hipFree(s->o_kmer_hi);
+    (void)hipFree(s->kmer_hi);
     (void)hipFree(s->o_pos);
     (void)hipFree(s->o_count);
     (void)hipFree(s->o_extra);
@@ -1332,7 +1366,7 @@ static void ensure_records(fh_sketcher *s) {
     if (s->res_built) return;
     s->res.resize(s->r_n);
     for (size_t i = 0; i < s->r_n; ++i)
-        s->res[i] = ResultRec{s->r_hash[i], s->r_count[i], s->r_extra[i], s->r_kmer[i], s->r_pos[i]};
+        s->res[i] = ResultRec{s->r_hash[i], s->r_count[i], s->r_extra[i], s->r_kmer[i], s->r_pos[i], s->r_kmer_hi ? s->r_kmer_hi[i] : 0ull};
     s->res_built = true;
 }
 
@@ -1359,7 +1393,7 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         t1 = now(); // drained + pruned
         if (int rc = ensure_out(s, s->h_ctl->n_live)) return rc;
         HIP_TRY(launch_gather(s->table, s->live, s->ctl, (int)s->p.k, s->o_hash, s->o_count, s->o_extra, s->o_kmer,
-                              s->o_pos, s->out_cap, s->stream));
+                              s->o_kmer_hi, s->o_pos, s->out_cap, s->stream));
         // (the control block read back after the prune is final: the gather only reads it)
         if (int rc = collect_profile(s)) return rc;
         const Ctl c = *s->h_ctl;
@@ -1367,7 +1401,8 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         // D2H through one pinned staging area (pageable destinations crawl at a few GB/s); one spare record for the
         // special hash
         const size_t cap = (size_t)n + 1;
-        const size_t need = cap * 32 + 64;
+        const bool wide = s->p.k > 32;
+        const size_t need = cap * (wide ? 40 : 32) + 64;
         if (need > s->h_out_bytes) {
             if (s->h_out) (void)hipHostFree(s->h_out);
             s->h_out = nullptr;
@@ -1376,10 +1411,12 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
             s->h_out_bytes = need + need / 4;
         }
         uint64_t *hh = (uint64_t *)s->h_out, *kk = hh + cap, *pp = kk + cap;
-        uint32_t *cc = (uint32_t *)(pp + cap), *ee = cc + cap;
+        uint64_t *kh = wide ? pp + cap : nullptr;
+        uint32_t *cc = (uint32_t *)(pp + cap + (wide ? cap : 0)), *ee = cc + cap;
         if (n) {
             HIP_TRY(hipMemcpyAsync(hh, s->o_hash, n * 8ull, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipMemcpyAsync(kk, s->o_kmer, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+            if (wide) HIP_TRY(hipMemcpyAsync(kh, s->o_kmer_hi, n * 8ull, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipMemcpyAsync(pp, s->o_pos, n * 8ull, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipMemcpyAsync(cc, s->o_count, n * 4ull, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipMemcpyAsync(ee, s->o_extra, n * 4ull, hipMemcpyDeviceToHost, s->stream));
@@ -1396,6 +1433,7 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
             cc[m] = (uint32_t)std::min<uint64_t>(c.sp_count, UINT32_MAX);
             ee[m] = (uint32_t)std::min<uint64_t>(c.sp_extra, UINT32_MAX);
             kk[m] = c.sp_kmer;
+            if (wide) kh[m] = 0; // (two-word k-mers of this hash are all in the collision log, see upsert)
             pp[m] = c.sp_pos;
             ++m;
         }
@@ -1410,9 +1448,13 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         // occurrence (mash.rs:52-56).  Occurrences whose k-mer differed from the slot's were logged.
         for (const CollRec &cr : coll) {
             const uint64_t *it = std::lower_bound(hh, hh + m, cr.hash);
-            if (it != hh + m && *it == cr.hash && pp[it - hh] == cr.pos) kk[it - hh] = cr.kmer;
+            if (it != hh + m && *it == cr.hash && pp[it - hh] == cr.pos) {
+                kk[it - hh] = cr.kmer;
+                if (wide) kh[it - hh] = cr.kmer_hi;
+            }
         }
         s->r_hash = hh; s->r_kmer = kk; s->r_pos = pp; s->r_count = cc; s->r_extra = ee;
+        s->r_kmer_hi = kh;
         s->r_n = m;
         s->res.clear();
         s->res_built = false;
@@ -1442,13 +1484,13 @@ int fh_copy_out(fh_sketcher *s, uint64_t *hashes, uint32_t *counts, uint32_t *ex
                 if (hashes) hashes[i] = r.hash;
                 if (counts) counts[i] = r.count;
                 if (extra_counts) extra_counts[i] = r.extra;
-                if (kmers) kmer_ascii(r.kmer, k, kmers + i * (size_t)k);
+                if (kmers) kmer_ascii(r.kmer, r.kmer_hi, k, kmers + i * (size_t)k);
                 if (first_pos) first_pos[i] = r.pos;
             }
         });
         return FH_OK;
     }
-    const uint64_t *hh = s->r_hash, *kk = s->r_kmer, *pp = s->r_pos;
+    const uint64_t *hh = s->r_hash, *kk = s->r_kmer, *pp = s->r_pos, *kh = s->r_kmer_hi;
     const uint32_t *cc = s->r_count, *ee = s->r_extra;
     parallel_for(s->r_n, [=](size_t lo, size_t hi) {
         const size_t cnt = hi - lo;
@@ -1457,7 +1499,7 @@ int fh_copy_out(fh_sketcher *s, uint64_t *hashes, uint32_t *counts, uint32_t *ex
         if (extra_counts) memcpy(extra_counts + lo, ee + lo, cnt * 4);
         if (first_pos) memcpy(first_pos + lo, pp + lo, cnt * 8);
         if (kmers)
-            for (size_t i = lo; i < hi; ++i) kmer_ascii(kk[i], k, kmers + i * (size_t)k);
+            for (size_t i = lo; i < hi; ++i) kmer_ascii(kk[i], kh ? kh[i] : 0ull, k, kmers + i * (size_t)k);
     });
     return FH_OK;
 }
@@ -1492,7 +1534,7 @@ int fh_merge_arrays(fh_sketcher *dst, uint64_t n, const uint64_t *hashes, const 
     const int k = (int)dst->p.k;
     std::vector<ResultRec> src(n), out;
     for (uint64_t j = 0; j < n; ++j)
-        src[j] = ResultRec{hashes[j], counts[j], extra_counts[j], ascii_kmer(kmers + j * (size_t)k, k), first_pos[j]};
+        src[j] = make_rec(hashes[j], counts[j], extra_counts[j], kmers + j * (size_t)k, k, first_pos[j]);
     ensure_records(dst);
     if (int rc = merge_sorted(dst->res, src, out)) return rc;
     select_final(dst, out);
@@ -1506,15 +1548,15 @@ int fh_merge_partials(uint32_t kind, uint64_t size, double scale, uint32_t k, ui
                       uint64_t nB, const uint64_t *hashesB, const uint32_t *countsB, const uint32_t *extraB,
                       const uint8_t *kmersB, const uint64_t *posB, uint64_t *n_out, uint64_t *out_hashes,
                       uint32_t *out_counts, uint32_t *out_extra, uint8_t *out_kmers, uint64_t *out_pos) {
-    if (!n_out || k < 1 || k > 32 || (kind != FH_KIND_MASH && kind != FH_KIND_SCALED))
+    if (!n_out || k < 1 || k > (uint32_t)FH_MAX_K || (kind != FH_KIND_MASH && kind != FH_KIND_SCALED))
         return fail(FH_ERR_INVALID, "bad argument");
     if ((nA && (!hashesA || !countsA || !extraA || !kmersA || !posA)) || (nB && (!hashesB || !countsB || !extraB || !kmersB || !posB)))
         return fail(FH_ERR_INVALID, "null argument");
     std::vector<ResultRec> a(nA), b(nB), out;
     for (uint64_t j = 0; j < nA; ++j)
-        a[j] = ResultRec{hashesA[j], countsA[j], extraA[j], ascii_kmer(kmersA + j * (size_t)k, (int)k), posA[j]};
+        a[j] = make_rec(hashesA[j], countsA[j], extraA[j], kmersA + j * (size_t)k, (int)k, posA[j]);
     for (uint64_t j = 0; j < nB; ++j)
-        b[j] = ResultRec{hashesB[j], countsB[j], extraB[j], ascii_kmer(kmersB + j * (size_t)k, (int)k), posB[j]};
+        b[j] = make_rec(hashesB[j], countsB[j], extraB[j], kmersB + j * (size_t)k, (int)k, posB[j]);
     if (int rc = merge_sorted(a, b, out)) return rc;
     select_final_p(kind, size, kind == FH_KIND_SCALED ? scaled_max_hash(scale) : 0, out);
     *n_out = out.size();
@@ -1522,7 +1564,7 @@ int fh_merge_partials(uint32_t kind, uint64_t size, double scale, uint32_t k, ui
         if (out_hashes) out_hashes[j] = out[j].hash;
         if (out_counts) out_counts[j] = out[j].count;
         if (out_extra) out_extra[j] = out[j].extra;
-        if (out_kmers) kmer_ascii(out[j].kmer, (int)k, out_kmers + j * (size_t)k);
+        if (out_kmers) kmer_ascii(out[j].kmer, out[j].kmer_hi, (int)k, out_kmers + j * (size_t)k);
         if (out_pos) out_pos[j] = out[j].pos;
     }
     return FH_OK;
@@ -1534,7 +1576,7 @@ int fh_merge_partials(uint32_t kind, uint64_t size, double scale, uint32_t k, ui
 int fh_merge_wire(uint32_t kind, uint64_t size, double scale, uint32_t k, uint64_t pad_n, uint32_t n_parts,
                   const int64_t *const *bufs, uint64_t *n_out, uint64_t *out_hashes, uint32_t *out_counts,
                   uint32_t *out_extra, uint8_t *out_kmers, uint64_t *out_pos, uint64_t *total_kmers) {
-    if (!bufs || !n_out || !out_hashes || !out_counts || !out_extra || !out_kmers || !out_pos || k < 1 || k > 32 ||
+    if (!bufs || !n_out || !out_hashes || !out_counts || !out_extra || !out_kmers || !out_pos || k < 1 || k > (uint32_t)FH_MAX_K ||
         (kind != FH_KIND_MASH && kind != FH_KIND_SCALED))
         return fail(FH_ERR_INVALID, "bad argument");
     const uint64_t kmw = (k + 7) / 8;
@@ -1616,7 +1658,7 @@ int fh_merge(fh_sketcher *dst, const fh_sketcher *src) {
         cc[i] = src->res[i].count;
         ee[i] = src->res[i].extra;
         pp[i] = src->res[i].pos;
-        kmer_ascii(src->res[i].kmer, k, km.data() + i * (size_t)k);
+        kmer_ascii(src->res[i].kmer, src->res[i].kmer_hi, k, km.data() + i * (size_t)k);
     }
     return fh_merge_arrays(dst, n, hh.data(), cc.data(), ee.data(), km.data(), pp.data(), src->total_kmers);
 }

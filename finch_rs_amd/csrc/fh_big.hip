@@ -348,7 +348,8 @@ hipError_t launch_big_prune_select(Entry *table, u32 *live, u32 *dead, u32 dead_
 }
 
 // ---- table growth / garbage compaction: move the live entries into a fresh table ----
-__global__ void k_rehash(const Entry *src, const u32 *src_live, u32 M, Entry *dst, u32 dst_cap, u32 *dst_live, Ctl *ctl) {
+__global__ void k_rehash(const Entry *src, const u32 *src_live, u32 M, Entry *dst, u32 dst_cap, u32 *dst_live, Ctl *ctl,
+                         const u64 *src_hi, u64 *dst_hi) {
     typedef unsigned long long ull;
     const u32 stride = gridDim.x * blockDim.x;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) {
@@ -369,6 +370,7 @@ __global__ void k_rehash(const Entry *src, const u32 *src_live, u32 M, Entry *ds
             continue;
         }
         dst[slot].kmer = e.kmer;
+        if (dst_hi) dst_hi[slot] = src_hi[src_live[i]]; // K > 32: the k-mer's high word moves along
         dst[slot].pos = e.pos;
         dst[slot].count = e.count;
         dst[slot].extra = e.extra;
@@ -377,10 +379,10 @@ __global__ void k_rehash(const Entry *src, const u32 *src_live, u32 M, Entry *ds
 }
 
 hipError_t launch_rehash(const Entry *src, const u32 *src_live, u32 M, Entry *dst, u32 dst_cap, u32 *dst_live, Ctl *ctl,
-                         hipStream_t st) {
+                         const u64 *src_hi, u64 *dst_hi, hipStream_t st) {
     if (M == 0) return hipSuccess;
     const int blocks = (int)((M + 255u) / 256u < 4096u ? (M + 255u) / 256u : 4096u);
-    hipLaunchKernelGGL(k_rehash, dim3(blocks), dim3(256), 0, st, src, src_live, M, dst, dst_cap, dst_live, ctl);
+    hipLaunchKernelGGL(k_rehash, dim3(blocks), dim3(256), 0, st, src, src_live, M, dst, dst_cap, dst_live, ctl, src_hi, dst_hi);
     return hipGetLastError();
 }
 

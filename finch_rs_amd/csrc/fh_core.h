@@ -717,6 +717,22 @@ struct WindowsW {
         field(nC, 2 * j, d);
         if (K % 2 == 0 && PRE) d[0] &= ~((1u << PRE) - 1u);
     }
+    // Move the lane's view eight positions on: afterwards window j of this object is what window j + 8 was.  (The kernel
+    // runs 4 rounds of 8 fully unrolled positions: bit-field offsets stay compile-time constants while the code is a
+    // quarter of the 32-position unroll, which needed all 256 VGPRs.)  nC moves down 16 bits, D up 16 bits: D's 192 bits
+    // sit in 256, so three moves lose nothing a later window reads.
+    FH_HDM void advance8() {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = 0; i < 7; ++i) nC[i] = alignbit_b32(nC[i + 1], nC[i], 16);
+        nC[7] >>= 16;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int i = 7; i > 0; --i) D[i] = alignbit_b32(D[i], D[i - 1], 16);
+        D[0] <<= 16;
+    }
     // the canonical m-form word << PRE as four dwords; tie -> rc (needletail canonical_kmers)
     FH_HDM void canonical(int j, u32 *cm, bool &is_rc) const {
         u32 f[4], r[4];

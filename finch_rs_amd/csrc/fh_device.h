@@ -26,6 +26,7 @@ struct Entry {          // 40 B
 
 struct CollRec {        // an occurrence whose k-mer differs from the slot's k-mer (64-bit hash collision)
     uint64_t hash, kmer, pos;
+    uint64_t kmer_hi;   // K > 32: the first K - 32 bases (0 otherwise)
 };
 
 struct Ctl {
@@ -44,6 +45,9 @@ struct Ctl {
     uint32_t read_first;    // admit path of this launch reads an entry before it issues atomics on it (fh_k2.hip, upsert)
     // the one hash value that cannot be a table key (== EMPTY64)
     uint64_t sp_count, sp_extra, sp_pos, sp_kmer;
+    // K > 32: a k-mer is two words.  The table entry keeps the low one (the last 32 bases); the first K - 32 bases of slot i
+    // sit in kmer_hi[i], an array of its own so that the entry layout and the K <= 32 kernels do not change.  null otherwise.
+    uint64_t *kmer_hi;
     // number of valid k-mer windows seen (mash.rs:35), spread over many words so that the one atomic each
     // wave issues at its end does not serialise on a single L2 address (~12 ns per same-address atomic)
     uint64_t kmer_counts[256];

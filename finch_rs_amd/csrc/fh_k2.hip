@@ -22,6 +22,7 @@
 #include "fh_core.h"
 #include "fh_device.h"
 #include "fh_kernels.h"
+#include "fh_k2_common.h"
 
 #ifndef FH_PART
 #error "compile with -DFH_PART=<0..FH_NPARTS-1>"
@@ -34,174 +35,6 @@
 namespace fh {
 
 constexpr int UNROLL_J = FH_UNROLL;
-
-// ------------------------------------------------------------------------------------------------
-// rare path: one k-mer occurrence with hash <= tau
-// ------------------------------------------------------------------------------------------------
-// (all arguments by value: a by-reference SketchArgs would force every wave to spill the 128-byte
-//  argument block to scratch at kernel entry)
-struct TableRef {
-    Entry *table;
-    u32 *live;
-    Ctl *ctl;
-    CollRec *clog;
-    u32 cap, live_cap, clog_cap;
-};
-
-__device__ __forceinline__ void log_collision(const TableRef a, u64 h, u64 kmer, u64 pos) {
-    u32 i = atomicAdd(&a.ctl->n_coll, 1u);
-    if (i < a.clog_cap) {
-        a.clog[i].hash = h;
-        a.clog[i].kmer = kmer;
-        a.clog[i].pos = pos;
-    } else {
-        atomicExch(&a.ctl->overflow, 2u);
-    }
-}
-
-// a wave-uniform pointer that arrives in vector registers (arguments of a noinline function do): telling the
-// compiler so turns the loads through it into scalar loads and the accesses behind it into global_* with a scalar
-// base instead of flat_* instructions
-template <class T>
-__device__ __forceinline__ T *uniform_ptr(T *p) {
-    const u64 v = (u64)p;
-    const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)v), hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32));
-    return (T *)(((u64)hi << 32) | lo);
-}
-
-// The table and the control block are global memory, but the pointers to them come out of memory / vector registers
-// and would be treated as generic: spelled out, the entry accesses are global_* instead of flat_* instructions.
-#define FH_GLOBAL __attribute__((address_space(1)))
-typedef unsigned long long ull;
-typedef FH_GLOBAL ull gull;
-__device__ __forceinline__ ull g_load(const ull *p) {
-    return __hip_atomic_load((const gull *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ ull g_cas(ull *p, ull expected, ull desired) {
-    __hip_atomic_compare_exchange_strong((gull *)p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT);
-    return expected;
-}
-__device__ __forceinline__ void g_add(ull *p, ull v) {
-    (void)__hip_atomic_fetch_add((gull *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void g_min(ull *p, ull v) {
-    (void)__hip_atomic_fetch_min((gull *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __noinline__ u32 upsert(Ctl *ctl_v, u64 h, u64 kmer, u64 pos, u32 strand, u32 shard_v) {
-    Ctl *ctl = uniform_ptr(ctl_v);
-    const FH_GLOBAL Ctl *gctl = (const FH_GLOBAL Ctl *)ctl;
-    const u32 shard = (u32)__builtin_amdgcn_readfirstlane((int)shard_v);
-    const TableRef a{gctl->table, gctl->live, ctl, gctl->clog, gctl->cap, gctl->live_cap, gctl->clog_cap};
-    if (h == EMPTY64) { // the one value that cannot be a table key
-        atomicAdd((ull *)&a.ctl->sp_count, 1ull);
-        if (strand) atomicAdd((ull *)&a.ctl->sp_extra, 1ull);
-        atomicMin((ull *)&a.ctl->sp_pos, (ull)pos);
-        ull oldk = atomicCAS((ull *)&a.ctl->sp_kmer, (ull)EMPTY64, (ull)kmer);
-        if (oldk != EMPTY64 && oldk != kmer) log_collision(a, h, kmer, pos);
-        return 0u;
-    }
-    // admitted hashes are tiny numbers (<= tau): spread them with a multiplicative mix before mapping to a slot
-    u32 key32 = slot_key(h);
-    u32 slot = (u32)(((u64)key32 * (u64)a.cap) >> 32);
-    int probe = 0;
-    u32 inserted = 0u;
-    // The device sustains ~25 G 64-bit atomics/s whatever the table size, but 50-100 G loads/s
-    // (tools/ubench_atomics.hip), and an admitted occurrence is nearly always one of a hash that is already in the
-    // table with its k-mer and an earlier first position.  Unless the stream keeps hitting a few hot entries
-    // (ctl->read_first, chosen by the host per launch: fh_api.hip, read_first_of) the entry is therefore *read*
-    // first (key, k-mer, position in one round trip; agent-scope loads, the atomics of other XCDs are visible to
-    // them) and an atomic is only issued where the value read says it could change something.  Stale reads are harmless: keys and k-mers go
-    // EMPTY -> value once per launch and positions only decrease, so "already there" / "already smaller" stay true.
-    const bool read_first = gctl->read_first != 0u; // wave-uniform
-    ull seen_kmer = EMPTY64, seen_pos = EMPTY64;
-    for (; probe < MAX_PROBE; ++probe) {
-        Entry *e = &a.table[slot];
-        ull old = EMPTY64;
-        if (read_first) {
-            old = g_load((const ull *)&e->hash);
-            seen_kmer = g_load((const ull *)&e->kmer);
-            seen_pos = g_load((const ull *)&e->pos);
-        }
-        if (old == EMPTY64) {
-            old = g_cas((ull *)&e->hash, (ull)EMPTY64, (ull)h);
-            seen_kmer = seen_pos = EMPTY64; // whoever owns the slot now: what was read belongs to nobody
-        }
-        if (old == EMPTY64) {
-            // remember the slot: append to this wave's shard list (flattened into `live` after the launch)
-            const u32 idx = atomicAdd(&ctl->shard_cnt[shard * (u32)SHARD_STRIDE], 1u);
-            if (idx < ctl->shard_cap) ctl->shard_buf[(size_t)shard * ctl->shard_cap + idx] = slot;
-            else atomicExch(&a.ctl->overflow, 1u);
-            if (idx + 1u == ctl->shard_soft) atomicExch(&a.ctl->stopped, 1u); // live set full enough: drain & prune
-            inserted = 1u;
-            break;
-        }
-        if (old == h) break;
-        slot = (slot + 1u == a.cap) ? 0u : slot + 1u;
-    }
-    if (probe == MAX_PROBE) {
-        atomicExch(&a.ctl->overflow, 1u);
-        return 0u;
-    }
-    Entry *e = &a.table[slot];
-    g_add((ull *)(strand ? &e->extra : &e->count), 1ull); // one counter per strand: one atomic per occurrence
-    if (seen_pos > (ull)pos) g_min((ull *)&e->pos, (ull)pos);
-    ull oldk = seen_kmer;
-    if (oldk == EMPTY64) oldk = g_cas((ull *)&e->kmer, (ull)EMPTY64, (ull)kmer);
-    if (oldk != EMPTY64 && oldk != kmer) log_collision(a, h, kmer, pos);
-    return inserted;
-}
-
-// The admit path is batched: a lane whose hash passed the threshold parks (hash, k-mer, position|strand) in a
-// wave-private LDS queue; the queue is drained with all 64 lanes active, so the round trips of the atomics
-// overlap instead of stalling the wave once per event.  Returns the number of NEW hashes inserted.
-constexpr int QCAP = 64;
-struct AdmitQueue {
-    u64 h[QCAP], k[QCAP], p[QCAP];
-};
-
-__device__ __noinline__ u32 flush_queue(Ctl *ctl, const AdmitQueue *q_generic, u32 qn_v, u32 shard) {
-    const u32 lane = threadIdx.x & 63u;
-    u32 ins = 0u;
-    // the queue lives in LDS: read it with ds_read, not through the generic (flat) pointer it arrives as
-    typedef __attribute__((address_space(3))) const AdmitQueue LdsQueue;
-    LdsQueue *q = (LdsQueue *)uniform_ptr(q_generic);
-    const u32 qn = (u32)__builtin_amdgcn_readfirstlane((int)qn_v);
-    if (lane < qn) {
-        const u64 pp = q->p[lane];
-        ins = upsert(ctl, q->h[lane], q->k[lane], pp & 0x7FFFFFFFFFFFFFFFull, (u32)(pp >> 63), shard);
-    }
-    return (u32)__popcll(__ballot(ins != 0u));
-}
-
-// ------------------------------------------------------------------------------------------------
-// phase A: classify the lane's own 32 bytes of tile `t` into the wave's LDS ring
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint4 load_chunk_guarded(const uint8_t *seq, u64 off, u64 len) {
-    if (off + 16 <= len) return *reinterpret_cast<const uint4 *>(seq + off);
-    uint4 r = make_uint4(0u, 0u, 0u, 0u); // bytes past the end read as 0 => k-mer breakers
-    if (off < len) {
-        u32 w[4] = {0u, 0u, 0u, 0u};
-        const u32 n = (u32)(len - off);
-        for (u32 i = 0; i < n; ++i) w[i >> 2] |= (u32)seq[off + i] << (8 * (i & 3));
-        r = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    return r;
-}
-
-__device__ __forceinline__ void classify_tile(const SketchArgs &a, u64 tile, int lane, u32 *codes_ring,
-                                              u32 *good_ring) {
-    const u64 off = a.p_begin + tile * (u64)TILE_POS + (u64)lane * LANE_POS;
-    const uint4 c0 = load_chunk_guarded(a.seq, off, a.len_total);
-    const uint4 c1 = load_chunk_guarded(a.seq, off + 16, a.len_total);
-    u32 q0, g0, q1, g1;
-    classify_chunk(c0.x, c0.y, c0.z, c0.w, q0, g0);
-    classify_chunk(c1.x, c1.y, c1.z, c1.w, q1, g1);
-    const u32 par = (u32)(tile & 1u);
-    *reinterpret_cast<uint2 *>(&codes_ring[par * 128u + 2u * (u32)lane]) = make_uint2(q0, q1);
-    good_ring[par * 64u + (u32)lane] = g0 | (g1 << 16);
-}
 
 // ------------------------------------------------------------------------------------------------
 // K2

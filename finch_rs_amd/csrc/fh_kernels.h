@@ -13,14 +13,21 @@ hipError_t launch_k2_part0(int k, const SketchArgs &a, int blocks, hipStream_t s
 hipError_t launch_k2_part1(int k, const SketchArgs &a, int blocks, hipStream_t st);
 hipError_t launch_k2_part2(int k, const SketchArgs &a, int blocks, hipStream_t st);
 hipError_t launch_k2_part3(int k, const SketchArgs &a, int blocks, hipStream_t st);
+// fh_k2w.hip: K = 33..64, again in FH_NPARTS translation units
+hipError_t launch_k2w_part0(int k, const SketchArgs &a, int blocks, hipStream_t st);
+hipError_t launch_k2w_part1(int k, const SketchArgs &a, int blocks, hipStream_t st);
+hipError_t launch_k2w_part2(int k, const SketchArgs &a, int blocks, hipStream_t st);
+hipError_t launch_k2w_part3(int k, const SketchArgs &a, int blocks, hipStream_t st);
+constexpr int FH_MAX_K = 64;
 hipError_t launch_prune_small(Entry *table, uint32_t *live, uint32_t *dead, uint32_t dead_cap, Ctl *ctl, uint32_t kind,
                               uint64_t size, uint64_t max_hash, uint32_t trigger, uint32_t force, uint32_t sort_out,
                               hipStream_t st);
 hipError_t launch_clear_slots(Entry *table, uint64_t cap, const uint32_t *live, const uint32_t *dead, const Ctl *ctl,
                               hipStream_t st);
+// (o_kmer_hi: K > 32 only, else null)
 hipError_t launch_gather(const Entry *table, const uint32_t *live, const Ctl *ctl, int k, uint64_t *o_hash,
-                         uint32_t *o_count, uint32_t *o_extra, uint64_t *o_kmer, uint64_t *o_pos, uint32_t cap_out,
-                         hipStream_t st);
+                         uint32_t *o_count, uint32_t *o_extra, uint64_t *o_kmer, uint64_t *o_kmer_hi, uint64_t *o_pos,
+                         uint32_t cap_out, hipStream_t st);
 // fh_big.hip
 hipError_t big_sort_tmp_bytes(uint32_t M, size_t *bytes);
 hipError_t launch_big_prune(Entry *table, uint32_t *live, uint32_t *dead, uint32_t dead_cap, Ctl *ctl, uint32_t M,
@@ -33,7 +40,7 @@ hipError_t launch_big_prune_select(Entry *table, uint32_t *live, uint32_t *dead,
                                    uint32_t n_dead_now, uint32_t kind, uint64_t size, uint64_t max_hash, uint64_t *keys,
                                    uint32_t *slots, void *scratch, uint32_t *keep_dev, hipStream_t st);
 hipError_t launch_rehash(const Entry *src, const uint32_t *src_live, uint32_t M, Entry *dst, uint32_t dst_cap,
-                         uint32_t *dst_live, Ctl *ctl, hipStream_t st);
+                         uint32_t *dst_live, Ctl *ctl, const uint64_t *src_hi, uint64_t *dst_hi, hipStream_t st);
 // fh_text.hip
 hipError_t launch_fastq_pack(const uint8_t *text, uint64_t len, uint8_t *out, uint32_t *blk_a, uint32_t *blk_b,
                              uint32_t *totals, Ctl *ctl, uint32_t *err, hipStream_t st);
@@ -43,7 +50,8 @@ hipError_t launch_fill_table(Entry *table, uint64_t cap, hipStream_t st);
 hipError_t launch_init_ctl(Ctl *ctl, uint64_t tau0, hipStream_t st);
 hipError_t launch_set_tau(Ctl *ctl, uint64_t tau, hipStream_t st);
 hipError_t launch_set_table(Ctl *ctl, Entry *table, uint32_t *live, CollRec *clog, uint32_t cap, uint32_t live_cap,
-                            uint32_t clog_cap, uint32_t *shard_cnt, uint32_t *shard_buf, uint32_t shard_cap, hipStream_t st);
+                            uint32_t clog_cap, uint32_t *shard_cnt, uint32_t *shard_buf, uint32_t shard_cap, uint64_t *kmer_hi,
+                            hipStream_t st);
 hipError_t launch_live_flatten(Ctl *ctl, hipStream_t st);
 hipError_t launch_queue_reset(Ctl *ctl, uint32_t new_range, uint32_t soft_limit, uint32_t read_first, hipStream_t st);
 hipError_t launch_read_probe(const void *p, uint64_t bytes, uint32_t *sink, hipStream_t st);

@@ -19,7 +19,15 @@ namespace fh {
 
 hipError_t launch_k2(int k, const SketchArgs &a, int blocks, hipStream_t st) {
     static_assert(FH_NPARTS == 4, "dispatcher below is written for 4 parts");
-    if (k < 1 || k > 32) return hipErrorInvalidValue;
+    if (k < 1 || k > FH_MAX_K) return hipErrorInvalidValue;
+    if (k > 32) { // two-word k-mers (fh_k2w.hip)
+        switch ((k - 33) / (32 / FH_NPARTS)) {
+        case 0: return launch_k2w_part0(k, a, blocks, st);
+        case 1: return launch_k2w_part1(k, a, blocks, st);
+        case 2: return launch_k2w_part2(k, a, blocks, st);
+        default: return launch_k2w_part3(k, a, blocks, st);
+        }
+    }
     switch ((k - 1) / (32 / FH_NPARTS)) {
     case 0: return launch_k2_part0(k, a, blocks, st);
     case 1: return launch_k2_part1(k, a, blocks, st);
@@ -276,7 +284,7 @@ hipError_t launch_prune_small(Entry *table, u32 *live, u32 *dead, u32 dead_cap, 
 // K4: to_vec
 // ------------------------------------------------------------------------------------------------
 __global__ void k4_gather(const Entry *table, const u32 *live, const Ctl *ctl, int k, u64 *o_hash, u32 *o_count,
-                          u32 *o_extra, u64 *o_kmer, u64 *o_pos, u32 cap_out) {
+                          u32 *o_extra, u64 *o_kmer, u64 *o_kmer_hi, u64 *o_pos, u32 cap_out) {
     const u32 n = ctl->n_live < cap_out ? ctl->n_live : cap_out;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const Entry e = table[live[i]];
@@ -285,15 +293,16 @@ __global__ void k4_gather(const Entry *table, const u32 *live, const Ctl *ctl, i
         o_count[i] = occ > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)occ;
         o_extra[i] = e.extra > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)e.extra;
         o_kmer[i] = e.kmer;
+        if (o_kmer_hi) o_kmer_hi[i] = ctl->kmer_hi[live[i]];
         o_pos[i] = e.pos;
     }
     (void)k;
 }
 
 hipError_t launch_gather(const Entry *table, const u32 *live, const Ctl *ctl, int k, u64 *o_hash, u32 *o_count,
-                         u32 *o_extra, u64 *o_kmer, u64 *o_pos, u32 cap_out, hipStream_t st) {
+                         u32 *o_extra, u64 *o_kmer, u64 *o_kmer_hi, u64 *o_pos, u32 cap_out, hipStream_t st) {
     hipLaunchKernelGGL(k4_gather, dim3(64), dim3(256), 0, st, table, live, ctl, k, o_hash, o_count, o_extra, o_kmer,
-                       o_pos, cap_out);
+                       o_kmer_hi, o_pos, cap_out);
     return hipGetLastError();
 }
 
@@ -331,12 +340,22 @@ __global__ void k_clear_slots(Entry *table, u64 cap, const u32 *live, const u32 
     const u64 stride = (u64)gridDim.x * blockDim.x;
     const u64 t0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 nl = ctl->n_live, nd = ctl->n_dead;
+    u64 *khi = ctl->kmer_hi; // K > 32: the k-mers' high words, "not written" = EMPTY64
     if (nd == 0xFFFFFFFFu) {
-        for (u64 i = t0; i < cap; i += stride) clear_entry(&table[i]);
+        for (u64 i = t0; i < cap; i += stride) {
+            clear_entry(&table[i]);
+            if (khi) khi[i] = EMPTY64;
+        }
         return;
     }
-    for (u64 i = t0; i < nl; i += stride) clear_entry(&table[live[i]]);
-    for (u64 i = t0; i < nd; i += stride) clear_entry(&table[dead[i]]);
+    for (u64 i = t0; i < nl; i += stride) {
+        clear_entry(&table[live[i]]);
+        if (khi) khi[live[i]] = EMPTY64;
+    }
+    for (u64 i = t0; i < nd; i += stride) {
+        clear_entry(&table[dead[i]]);
+        if (khi) khi[dead[i]] = EMPTY64;
+    }
 }
 
 hipError_t launch_clear_slots(Entry *table, u64 cap, const u32 *live, const u32 *dead, const Ctl *ctl, hipStream_t st) {
@@ -345,8 +364,9 @@ hipError_t launch_clear_slots(Entry *table, u64 cap, const u32 *live, const u32 
 }
 
 __global__ void k_set_table(Ctl *ctl, Entry *table, u32 *live, CollRec *clog, u32 cap, u32 live_cap, u32 clog_cap,
-                            u32 *shard_cnt, u32 *shard_buf, u32 shard_cap) {
+                            u32 *shard_cnt, u32 *shard_buf, u32 shard_cap, u64 *kmer_hi) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ctl->kmer_hi = kmer_hi;
         ctl->table = table;
         ctl->live = live;
         ctl->clog = clog;
@@ -362,9 +382,9 @@ __global__ void k_set_table(Ctl *ctl, Entry *table, u32 *live, CollRec *clog, u3
 }
 
 hipError_t launch_set_table(Ctl *ctl, Entry *table, u32 *live, CollRec *clog, u32 cap, u32 live_cap, u32 clog_cap,
-                            u32 *shard_cnt, u32 *shard_buf, u32 shard_cap, hipStream_t st) {
+                            u32 *shard_cnt, u32 *shard_buf, u32 shard_cap, u64 *kmer_hi, hipStream_t st) {
     hipLaunchKernelGGL(k_set_table, dim3(1), dim3(256), 0, st, ctl, table, live, clog, cap, live_cap, clog_cap, shard_cnt,
-                       shard_buf, shard_cap);
+                       shard_buf, shard_cap, kmer_hi);
     return hipGetLastError();
 }
 

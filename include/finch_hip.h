@@ -35,12 +35,14 @@ extern "C" {
 #endif
 
 #define FH_OK 0
-#define FH_ERR_INVALID (-1)     /* bad argument (k outside 1..32, null pointer, ...) */
+#define FH_ERR_INVALID (-1)     /* bad argument (null pointer, unknown kind, ...) */
 #define FH_ERR_NO_DEVICE (-2)   /* no usable HIP device / device index out of range */
 #define FH_ERR_HIP (-3)         /* a HIP runtime call failed (message has the HIP error string) */
 #define FH_ERR_STATE (-4)       /* call not valid in the handle's current state */
 #define FH_ERR_CAPACITY (-5)    /* device table / collision log capacity exceeded */
 #define FH_ERR_UNSUPPORTED (-6) /* valid request this build cannot serve on the device */
+
+#define FH_MAX_KMER_LENGTH 64
 
 #define FH_KIND_MASH 0   /* SketchParams::Mash   (mod.rs:55-61)  -> MashSketcher::new(size, k, seed)          */
 #define FH_KIND_SCALED 1 /* SketchParams::Scaled (mod.rs:62-67)  -> ScaledSketcher::new(size, scale, k, seed) */
@@ -48,7 +50,8 @@ extern "C" {
 /* POD mirror of the sketcher constructor arguments (mash.rs:21, scaled.rs:22). */
 typedef struct fh_params {
     uint32_t kind;        /* FH_KIND_MASH | FH_KIND_SCALED */
-    uint32_t k;           /* kmer_length, 1..32 on the device */
+    uint32_t k;           /* kmer_length, 1..64 on the device (FH_MAX_KMER_LENGTH; beyond: FH_ERR_UNSUPPORTED).  k <= 32 runs the
+                             single-word kernels the roofline is quoted on, 33..64 the two-word ones (fh_k2w.hip) */
     uint64_t size;        /* kmers_to_sketch */
     uint64_t seed;        /* hash_seed */
     double scale;         /* scaled only; max_hash = u64::MAX / ((1/scale) as u64) */

@@ -120,6 +120,19 @@ static int run_w(const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hash
             canon[2 * p + 1] = km.hi;
             hashes[p] = murmur_h1_fast_w<K>(cm, seed, LT);
         }
+        // the kernel's form: four rounds of eight positions, the strings moved on between rounds
+        WindowsW<K> adv;
+        adv.init(c0, c1, c2);
+        for (int c = 0; c < 4; ++c) {
+            for (int u = 0; u < 8; ++u) {
+                bool rc0, rc1;
+                u32 a[4], b[4];
+                adv.canonical(u, a, rc0);
+                win.canonical(8 * c + u, b, rc1);
+                if (rc0 != rc1 || memcmp(a, b, 16) != 0) return -4;
+            }
+            adv.advance8();
+        }
     }
     return 0;
 }

@@ -40,7 +40,7 @@ SEED0 = int(os.environ.get("FH_FUZZ_SEED", "9000"))
 @pytest.mark.parametrize("case", range(N_CASES))
 def test_random_configuration(case):
     rng = np.random.default_rng(SEED0 + case)
-    k = int(rng.choice([1, 2, 3, 5, 8, 11, 15, 16, 17, 21, 21, 21, 24, 27, 31, 31, 32]))
+    k = int(rng.choice([1, 2, 3, 5, 8, 11, 15, 16, 17, 21, 21, 21, 24, 27, 31, 31, 32, 33, 40, 48, 55, 63, 64]))
     kind = "mash" if rng.random() < 0.6 else "scaled"
     size = int(rng.choice([0, 1, 7, 100, 1000, 1000, 2999, 3001, 12000]))
     scale = float(rng.choice([1.0, 0.5, 0.01, 0.001]))

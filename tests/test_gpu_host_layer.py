@@ -466,7 +466,7 @@ def test_one_input_across_several_device_handles(tmp_path):
           g[100:180] + b"\n>c4\n" + g[777:800] + b"\n>empty\n>c5\n" + g[:60])
     pa = tmp_path / "genome.fa"
     pa.write_bytes(fa)
-    for k in (21, 32, 11):
+    for k in (21, 32, 11, 64, 45):  # (the halo a cut hands over is k-1 bases: up to 63)
         params = SketchParams.mash(1000, 1000, False, k, 0)
         o, fmt = oracle_sketch(fa, O.MASH, 1000, k)
         assert fmt == 1

@@ -89,7 +89,8 @@ def test_longer_sequence_hashes(vec):
     assert [str(int(h)) for h in kc["hash"]] == v["hashes"]
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 8, 11, 15, 16, 17, 20, 21, 24, 27, 31, 32])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 8, 11, 15, 16, 17, 20, 21, 24, 27, 31, 32,
+                               33, 34, 40, 47, 48, 49, 56, 57, 62, 63, 64])  # > 32: two-word k-mers (fh_k2w.hip)
 def test_random_reads_all_k(k):
     rng = np.random.default_rng(1000 + k)
     genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=20000)
@@ -434,6 +435,77 @@ def test_hash_collisions_keep_first_kmer():
         dup = set(vals[cnt > 1].tolist())
         n_coll_members += sum(1 for h in ora.to_vec()[0]["hash"].tolist() if h in dup)
     assert n_coll_members > 0
+
+
+@pytest.mark.parametrize("k", [33, 48, 63, 64])
+def test_two_word_kmers_full_feature_parity(k):
+    """k = 33..64 (finch's kmer_length is a u8; mod.rs:54-71): the two-word kernel through everything the one-word path
+    is tested with -- resident streams with a capacity-limited table, large sketches (device-wide selection), scaled
+    sketches incl. table growth, sharded merge, forced 64-bit hash collisions (k-mer bytes of the first occurrence)."""
+    g = S.synth_genome_host(400000, 50 + k)
+    reads = S.synth_reads_host(g, 0, 20000, 150, 50 + k, 10000, 500)
+    for n, inflight in ((1000, 0), (500, 8192), (20000, 0)):
+        sk = F.SketchParams.mash(n, n, True, k, 0).create_sketcher(max_launch=inflight)
+        sk.push_block(reads)
+        ora = O.OracleSketcher(O.MASH, n, k, 0)
+        ora.process_packed(reads, 0)
+        assert_same(sk, ora, "k=%d n=%d inflight=%d" % (k, n, inflight))
+    # resident block, seed != 0
+    db = F.DeviceBuffer(len(reads) + 64)
+    db.upload(reads)
+    sk = F.SketchParams.mash(300, 300, True, k, 42).create_sketcher()
+    sk.push_device(db.ptr, len(reads))
+    ora = O.OracleSketcher(O.MASH, 300, k, 42)
+    ora.process_packed(reads, 0)
+    assert_same(sk, ora, "resident k=%d" % k)
+    # scaled, incl. an unbounded one that outgrows its table
+    for size, scale in ((100, 0.001), (0, 0.2)):
+        sk = F.SketchParams.scaled(size, k, scale, 0).create_sketcher()
+        sk.push_block(reads)
+        ora = O.OracleSketcher(O.SCALED, size, k, 0, scale)
+        ora.process_packed(reads, 0)
+        assert_same(sk, ora, "scaled k=%d %r" % (k, scale))
+    # two read blocks on two handles, merged on the host
+    half = 10000 * 151
+    a = F.SketchParams.mash(700, 700, True, k, 0).create_sketcher()
+    b = F.SketchParams.mash(700, 700, True, k, 0).create_sketcher()
+    a.push_block(reads[:half])
+    b.set_stream_offset(half)
+    b.push_block(reads[half:])
+    a.finish(); b.finish()
+    a.merge(b)
+    ora = O.OracleSketcher(O.MASH, 700, k, 0)
+    ora.process_packed(reads, 0)
+    assert_same(a, ora, "merged k=%d" % k)
+    # forced collisions: distinct k-mers sharing a (masked) hash -- and, for good measure, k-mers that share their last
+    # 32 bases (a repeat planted in the reads), which is what the two-word compare has to tell apart
+    rep = bytes(S.synth_genome_host(100, 7))
+    block = reads[:3000 * 151].tobytes() + b"".join(bytes(g[i * 100:i * 100 + 40]) + rep[:70] + b"\x00" for i in range(400))
+    for mask in (0xFFFFF, 0x3FFF):
+        sk = F.SketchParams.mash(300, 300, True, k, 0).create_sketcher(hash_mask=mask)
+        sk.push_block(block)
+        ora = O.OracleSketcher(O.MASH, 300, k, 0)
+        ora.set_hash_mask(mask)
+        ora.process_packed(block, 0)
+        assert_same(sk, ora, "masked %x k=%d" % (mask, k))
+
+
+def test_the_one_64mer_whose_low_word_looks_unclaimed():
+    """k = 64: the table marks an unclaimed k-mer word with all ones, which is also the low word of a 64-mer that ends in 32 T
+    (only A^32 T^32 is canonical with it).  Its occurrences, and a second k-mer forced onto the same hash, must come out
+    with the bytes of the first occurrence (mash.rs:52-56), whichever order they arrive in."""
+    special = b"A" * 32 + b"T" * 32
+    other = bytes(S.synth_genome_host(64, 99))
+    for recs in ([special] * 5 + [other] * 3, [other] * 2 + [special] * 4, [special, other, special]):
+        block = b"".join(r + b"\x00" for r in recs)
+        for mask in (0, 0x1):  # mask 1: nearly everything collides
+            sk = F.SketchParams.mash(10, 10, True, 64, 0).create_sketcher(hash_mask=mask)
+            sk.push_block(block)
+            ora = O.OracleSketcher(O.MASH, 10, 64, 0)
+            if mask:
+                ora.set_hash_mask(mask)
+            ora.process_packed(block, 0)
+            assert_same(sk, ora, "special 64-mer, mask %x" % mask)
 
 
 def test_handle_cache_returns_a_clean_sketcher():
