@@ -458,6 +458,59 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
                 "text_GBps": round(data.size / best / 1e9, 2)}
     guarded("end_to_end_fastq_text", e2e)
 
+    # -- compressed input: the host inflates (fh_inflate.h), the device splits records and sketches --
+    def gz():
+        import shutil
+        import struct
+        import tempfile
+        import zlib
+        ns = min(n_reads, 1_000_000)
+        reads = dr.download(ns * rec).reshape(ns, rec)[:, :READ_LEN]
+        w = 11 + READ_LEN + 3 + READ_LEN + 1
+        txt = np.empty((ns, w), np.uint8)
+        txt[:, 0], txt[:, 1] = ord("@"), ord("r")
+        idx = np.arange(ns, dtype=np.int64)
+        for d in range(9):
+            txt[:, 10 - d] = 48 + (idx // 10 ** d) % 10
+        txt[:, 11] = 10
+        txt[:, 12:12 + READ_LEN] = reads
+        txt[:, 12 + READ_LEN:15 + READ_LEN] = np.frombuffer(b"\n+\n", np.uint8)
+        txt[:, 15 + READ_LEN:15 + 2 * READ_LEN] = ord("I")
+        txt[:, w - 1] = 10
+        raw = txt.tobytes()
+        del txt
+        d = tempfile.mkdtemp(prefix="finch_bench_gz_")
+        try:
+            co = zlib.compressobj(1, zlib.DEFLATED, 31)
+            gzp = os.path.join(d, "reads.fastq.gz")
+            with open(gzp, "wb") as f:
+                f.write(co.compress(raw) + co.flush())
+            bgp = os.path.join(d, "reads.fastq.bgz")
+            with open(bgp, "wb") as f:  # BGZF as bgzip writes it: independent members of <= 64 KiB with their size in the header
+                for i in list(range(0, len(raw), 65280)) + [None]:
+                    ch = b"" if i is None else raw[i:i + 65280]
+                    c = zlib.compressobj(1, zlib.DEFLATED, -15)
+                    body = c.compress(ch) + c.flush()
+                    f.write(b"\x1f\x8b\x08\x04\0\0\0\0\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(body) + 25) +
+                            body + struct.pack("<II", zlib.crc32(ch), len(ch)))
+            p = F.SketchParams.mash(1000, 1000, True, 21, 0)
+            out = {"what": "finch_sketch_files on one %.0f MB FASTQ (%d reads) compressed with zlib level 1: as a single gzip stream "
+                           "(one host thread inflates) and as BGZF (members inflated by the call's read threads); k=21 n=1000"
+                           % (len(raw) / 1e6, ns)}
+            for key, path in (("gzip", gzp), ("bgzf", bgp)):
+                best = 1e30
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    res = H.sketch_files([path], p, H.FilterParams(False), devices=[dev])
+                    best = min(best, time.perf_counter() - t0)
+                    assert H.lib().finch_sketch_seq_length(res._p, 0) == ns * READ_LEN
+                out[key + "_gbases_per_s"] = round(ns * READ_LEN / best / 1e9, 3)
+                out[key + "_text_GBps"] = round(len(raw) / best / 1e9, 3)
+            return out
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    guarded("compressed_fastq", gz)
+
     # -- configs[4]'s shape on one GPU: a batch of FASTA files through ONE finch_sketch_files call --
     def c5():
         import multiprocessing as mp

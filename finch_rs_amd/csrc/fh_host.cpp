@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "fh_host_model.h"
+#include "fh_inflate.h"
 
 namespace finch {
 
@@ -358,6 +359,189 @@ struct GzSource : ByteSource {
     }
 };
 
+// gzip through fh_inflate.h's decoder (the default; FINCH_ZLIB_INFLATE=1 selects the zlib-based GzSource above for A/B runs).
+// Same contract: concatenated members, every member's CRC-32 and ISIZE checked, input that ends inside a member or
+// garbage after a member is an error (flate2 / zlib behaviour), never short output.
+struct FastGzSource : ByteSource {
+    std::unique_ptr<ByteSource> inner;
+    std::unique_ptr<inf::Decoder> dec;
+    std::vector<uint8_t> inbuf; // compressed bytes [in_lo, in_hi), 16 bytes of zero padding behind in_hi
+    size_t in_lo = 0, in_hi = 0;
+    bool in_eof = false;
+    // inflated bytes pass through a window: [0, w_have) valid, [w_out, w_have) not yet delivered, the last 32 KiB stay
+    // as match history when the window is recycled
+    static constexpr size_t HIST = 32768, WIN = (size_t)1 << 20;
+    std::vector<uint8_t> win;
+    size_t w_have = 0, w_out = 0, w_member = 0; // w_member: where the current member's output starts (a match may not reach before it)
+    enum { GZ_HEADER, BODY, TRAILER, END } st = GZ_HEADER;
+    uint32_t crc = 0;
+    uint64_t isize = 0;
+    bool bad = false, any_member = false;
+
+    explicit FastGzSource(std::unique_ptr<ByteSource> in)
+        : inner(std::move(in)), dec(new inf::Decoder()), inbuf(((size_t)1 << 20) + 16), win(HIST + WIN + (size_t)inf::OUT_MARGIN) {}
+    bool failed() const override { return bad; }
+    bool can_rewind() const override { return inner->can_rewind(); }
+    bool rewind() override {
+        if (!inner->rewind()) return false;
+        in_lo = in_hi = 0;
+        in_eof = bad = any_member = false;
+        w_have = w_out = w_member = 0;
+        st = GZ_HEADER;
+        return true;
+    }
+    unsigned threads_hint() const override { return inner->threads_hint(); }
+
+    // more compressed bytes behind [in_lo, in_hi); false at the end of the input
+    bool refill() {
+        if (in_eof) return false;
+        if (in_lo) {
+            memmove(inbuf.data(), inbuf.data() + in_lo, in_hi - in_lo);
+            in_hi -= in_lo;
+            in_lo = 0;
+        }
+        const size_t cap = inbuf.size() - 16;
+        if (in_hi == cap) return false; // (cannot happen: no single item is that long)
+        const size_t got = inner->read(inbuf.data() + in_hi, cap - in_hi);
+        if (got == 0) {
+            in_eof = true;
+            return false;
+        }
+        in_hi += got;
+        memset(inbuf.data() + in_hi, 0, 16);
+        return true;
+    }
+    // RFC 1952 member header at in_lo: 1 = parsed, 0 = need more input, -1 = not a gzip header
+    int parse_header() {
+        const uint8_t *p = inbuf.data() + in_lo;
+        const size_t n = in_hi - in_lo;
+        if (n < 10) return 0;
+        if (p[0] != 0x1F || p[1] != 0x8B || p[2] != 8 || (p[3] & 0xE0)) return -1;
+        const uint8_t flg = p[3];
+        size_t off = 10;
+        if (flg & 4) { // FEXTRA
+            if (n < off + 2) return 0;
+            const size_t xlen = p[off] | ((size_t)p[off + 1] << 8);
+            off += 2;
+            if (n < off + xlen) return 0;
+            off += xlen;
+        }
+        for (int bit : {8, 16}) // FNAME, FCOMMENT: zero-terminated
+            if (flg & bit) {
+                const void *z = memchr(p + off, 0, n - off);
+                if (!z) return (n > inbuf.size() - 64) ? -1 : 0;
+                off = (size_t)((const uint8_t *)z - p) + 1;
+            }
+        if (flg & 2) { // FHCRC
+            if (n < off + 2) return 0;
+            off += 2;
+        }
+        in_lo += off;
+        return 1;
+    }
+    // produce more inflated bytes into the window; false = end of stream or error
+    bool produce() {
+        for (;;) {
+            if (st == END || bad) return false;
+            if (st == GZ_HEADER) {
+                if (in_hi == in_lo && !refill()) { // clean end of input between members
+                    if (!any_member) bad = true;  // (an empty file is not gzip)
+                    st = END;
+                    return false;
+                }
+                const int r = parse_header();
+                if (r < 0) {
+                    bad = true;
+                    return false;
+                }
+                if (r == 0) {
+                    if (!refill()) { // the input ends inside a header
+                        bad = true;
+                        return false;
+                    }
+                    continue;
+                }
+                dec->reset();
+                crc = 0;
+                isize = 0;
+                w_member = w_have;
+                any_member = true;
+                st = BODY;
+            }
+            if (st == BODY) {
+                if (w_out == w_have && w_have > HIST) { // everything delivered: recycle the window, keeping the history
+                    const size_t shift = w_have - HIST;
+                    memmove(win.data(), win.data() + shift, HIST);
+                    w_have = w_out = HIST;
+                    w_member = w_member > shift ? w_member - shift : 0;
+                }
+                const uint8_t *ip = inbuf.data() + in_lo;
+                uint8_t *op = win.data() + w_have;
+                const inf::Status s = dec->run(ip, inbuf.data() + in_hi, op, win.data() + win.size(), win.data() + w_member);
+                in_lo = (size_t)(ip - inbuf.data());
+                const size_t fresh = (size_t)(op - (win.data() + w_have));
+                if (fresh) {
+                    crc = inf::crc32_fast(crc, win.data() + w_have, fresh);
+                    isize += fresh;
+                    w_have += fresh;
+                }
+                if (s == inf::BAD) {
+                    bad = true;
+                    return false;
+                }
+                if (s == inf::STREAM_END) {
+                    in_lo -= (size_t)(dec->bitcnt >> 3); // whole bytes still in the bit buffer belong to the trailer
+                    st = TRAILER;
+                } else if (s == inf::NEED_INPUT) {
+                    if (!refill()) { // the input ends inside a member: truncated
+                        bad = true;
+                        return false;
+                    }
+                }
+                if (fresh) return true; // (NEED_OUTPUT: the caller drains the window and comes back)
+                continue;
+            }
+            if (st == TRAILER) {
+                if (in_hi - in_lo < 8) {
+                    if (!refill()) {
+                        bad = true;
+                        return false;
+                    }
+                    continue;
+                }
+                const uint8_t *p = inbuf.data() + in_lo;
+                const uint32_t want_crc = p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+                const uint32_t want_len = p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
+                in_lo += 8;
+                if (want_crc != crc || want_len != (uint32_t)isize) {
+                    bad = true;
+                    return false;
+                }
+                st = GZ_HEADER;
+            }
+        }
+    }
+    size_t read(uint8_t *dst, size_t cap) override {
+        size_t n = 0;
+        while (n < cap) {
+            if (w_out == w_have && !produce()) break;
+            const size_t m = std::min(cap - n, w_have - w_out);
+            memcpy(dst + n, win.data() + w_out, m);
+            w_out += m;
+            n += m;
+        }
+        return n;
+    }
+};
+
+static bool use_zlib_inflate() {
+    static const bool v = [] {
+        const char *e = getenv("FINCH_ZLIB_INFLATE");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
+
 // BGZF (bgzip / htslib): a series of gzip members of at most 64 KiB each whose header states the member's own size
 // (extra subfield 'B','C').  The members are independent deflate streams, so a batch of them is inflated by several
 // threads at once -- what a single zlib stream cannot offer (plain gzip stays at inflate speed, ~0.3 Gbases/s).
@@ -371,7 +555,7 @@ struct BgzfSource : ByteSource {
     std::vector<uint8_t> obuf; // inflated bytes [o_lo, o_hi) not yet delivered
     size_t o_lo = 0, o_hi = 0;
     bool in_eof = false, bad = false;
-    std::unique_ptr<GzSource> tail;
+    std::unique_ptr<ByteSource> tail; // the sequential gzip reader, once a member that is not BGZF turns up
     static constexpr size_t BATCH = 512; // members per round (<= 32 MiB inflated)
 
     bool confirmed = false;              // the first member was BGZF: the batch buffer is worth allocating
@@ -445,7 +629,8 @@ struct BgzfSource : ByteSource {
                 pre->prefix.assign(cbuf.data() + c_lo, cbuf.data() + c_hi);
                 pre->inner = std::move(inner);
                 c_lo = c_hi = 0;
-                tail = std::make_unique<GzSource>(std::move(pre));
+                if (use_zlib_inflate()) tail = std::make_unique<GzSource>(std::move(pre));
+                else tail = std::make_unique<FastGzSource>(std::move(pre));
                 return true;
             }
             if (tot < hdr + 8u + 2u) { bad = true; return false; }
@@ -472,7 +657,19 @@ struct BgzfSource : ByteSource {
         if (ms.empty()) return false;
         std::atomic<bool> ok{true};
         const unsigned nt = (unsigned)std::min<size_t>(n_thr, ms.size());
+        static const bool zl = use_zlib_inflate();
         auto job = [&](unsigned t) {
+            if (!zl) { // fh_inflate.h: one decoder per thread, members are whole DEFLATE streams of known size
+                std::unique_ptr<inf::Decoder> dec(new inf::Decoder());
+                for (size_t i = t; i < ms.size() && ok; i += nt) {
+                    const Member &m = ms[i];
+                    // (8 readable bytes behind the compressed data: the member's own CRC-32 / ISIZE trailer)
+                    if (!inf::inflate_exact(*dec, cbuf.data() + m.in_off, m.in_len, out + m.out_off, m.isize) ||
+                        inf::crc32_fast(0, out + m.out_off, m.isize) != m.crc)
+                        ok = false;
+                }
+                return;
+            }
             z_stream zs{};
             if (inflateInit2(&zs, -15) != Z_OK) { ok = false; return; }
             for (size_t i = t; i < ms.size() && ok; i += nt) {
@@ -713,7 +910,8 @@ static int open_source(std::unique_ptr<ByteSource> raw, std::unique_ptr<ByteSour
     if (xz && !XzSource::api().ok) return hfail(FH_ERR_UNSUPPORTED, "xz-compressed input: liblzma.so.5 not found");
     if (is_gz) *is_gz = gz || bz || xz; // "compressed": not eligible for device-side text parsing
     if (gz && dec_threads > 1) out = std::make_unique<BgzfSource>(std::move(pre), dec_threads); // falls back member by member
-    else if (gz) out = std::make_unique<GzSource>(std::move(pre));
+    else if (gz && use_zlib_inflate()) out = std::make_unique<GzSource>(std::move(pre));
+    else if (gz) out = std::make_unique<FastGzSource>(std::move(pre));
     else if (bz) out = std::make_unique<Bz2Source>(std::move(pre));
     else if (xz) out = std::make_unique<XzSource>(std::move(pre));
     else out = std::move(pre);

@@ -24,8 +24,15 @@
 #include <immintrin.h>
 #endif
 
+// the hot loop is compiled twice (BMI2 gives three-operand variable shifts and bit-field extracts); the dynamic linker picks
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define FH_INFLATE_CLONES __attribute__((target_clones("bmi2", "default"), noinline))
+#else
+#define FH_INFLATE_CLONES
+#endif
+
 namespace finch {
-namespace inflate {
+namespace inf {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // CRC-32 (IEEE 802.3, reflected): folding with PCLMULQDQ ("Fast CRC Computation for Generic Polynomials Using PCLMULQDQ
@@ -155,6 +162,9 @@ static inline uint32_t crc32_fast(uint32_t crc, const uint8_t *buf, size_t len) 
 // Entry (32 bits):  [31:16] value (literal byte / length or distance base / subtable start)   [15:12] kind
 //                   [11:8] number of extra bits (lengths, distances) or subtable index bits   [7:0] bits the entry consumes
 // For lengths and distances the consumed bits INCLUDE the extra bits, which sit right above the code in the bit buffer.
+// Two literals whose codes fit the first-level index together share an entry: [23:16] the first, [31:24] the second,
+// [11:8] the first one's code length (0 = the entry holds a single literal), [7:0] both lengths -- nucleotide text is
+// 2-3 bits per symbol under a Huffman code, so most lookups of a FASTQ stream return two bytes.
 constexpr uint32_t K_LITERAL = 1u << 12, K_EOB = 2u << 12, K_SUB = 4u << 12, K_LEN = 8u << 12; // kind 0 = invalid code
 constexpr int LIT_BITS = 11, DIST_BITS = 8;
 constexpr int LIT_TABLE_MAX = (1 << LIT_BITS) + 1024, DIST_TABLE_MAX = (1 << DIST_BITS) + 512; // with every possible subtable
@@ -242,10 +252,29 @@ static inline bool build_table(const uint8_t *lengths, int n, int primary_bits, 
     return true;
 }
 
+// second pass over the first level of a literal/length table: pair up literals (see the entry format)
+static inline void pair_literals(uint32_t *table) {
+    const int P = 1 << LIT_BITS;
+    static thread_local uint32_t single[1 << LIT_BITS];
+    memcpy(single, table, sizeof single);
+    for (int i = 0; i < P; ++i) {
+        const uint32_t e = single[i];
+        if ((e & (K_LITERAL | K_SUB)) != K_LITERAL) continue;
+        const uint32_t l1 = e & 0xFFu;
+        if (l1 >= (uint32_t)LIT_BITS) continue;
+        const uint32_t f = single[(uint32_t)i >> l1]; // what the bits after the first code select, zero-extended ...
+        if ((f & (K_LITERAL | K_SUB)) != K_LITERAL) continue;
+        const uint32_t l2 = f & 0xFFu;
+        if (l1 + l2 > (uint32_t)LIT_BITS) continue;   // ... which is only meaningful if the second code lies inside the index
+        table[i] = (f & 0x00FF0000u) << 8 | (e & 0x00FF0000u) | K_LITERAL | (l1 << 8) | (l1 + l2);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // the decoder
 // ---------------------------------------------------------------------------------------------------------------------
 enum Status { OK = 0, NEED_INPUT, NEED_OUTPUT, STREAM_END, BAD };
+constexpr ptrdiff_t OUT_MARGIN = 258 + 16 + 80; // longest match + copy overshoot + the literals of one refill (<= 2 per 2 bits)
 
 struct Decoder {
     // bit reader
@@ -415,50 +444,45 @@ struct Decoder {
             memset(lens + hlit, 0, (size_t)(288 - hlit));
         }
         if (!build_table(lens, hlit, LIT_BITS, lit, LIT_TABLE_MAX, litlen_entry)) return BAD;
+        pair_literals(lit);
         if (!build_table(lens + 288, hdist, DIST_BITS, dist, DIST_TABLE_MAX, dist_entry)) return BAD;
         state = CODES;
         return OK;
     }
 
-    Status codes(const uint8_t *&in_ref, const uint8_t *in_end, uint8_t *&out_ref, uint8_t *out_end, const uint8_t *win_start) {
+    FH_INFLATE_CLONES Status codes(const uint8_t *&in_ref, const uint8_t *in_end, uint8_t *&out_ref, uint8_t *out_end, const uint8_t *win_start) {
         const uint8_t *in = in_ref;
         uint8_t *out = out_ref;
         uint64_t bb = bitbuf;
         int bc = bitcnt;
         Status result = OK;
         const uint32_t *const LT = lit, *const DT = dist;
-        // ---- fast loop: >= 8 input bytes for every refill, room for the longest match plus the copy overshoot ----
-        while (in_end - in >= 16 && out_end - out >= 258 + 32) {
+        // ---- fast loop: >= 8 input bytes for every refill; room for the literals one refill can hold (<= 36), the longest
+        //      match and the copy overshoot ----
+        while (in_end - in >= 16 && out_end - out >= OUT_MARGIN) {
             // top up to >= 56 bits: one unaligned load; the bytes already in the buffer are re-read, not skipped
             bb |= load64(in) << bc;
             in += (63 - bc) >> 3;
             bc |= 56;
             uint32_t e = LT[bb & ((1u << LIT_BITS) - 1u)];
-            if (e & K_SUB) {
-                bb >>= LIT_BITS;
-                bc -= LIT_BITS;
-                e = LT[(e >> 16) + (uint32_t)(bb & ((1u << ((e >> 8) & 15u)) - 1u))];
-            }
-            if (e & K_LITERAL) {
-                *out++ = (uint8_t)(e >> 16);
+            // literals: as many as the buffered bits allow (nucleotide text under a Huffman code is 2-3 bits per symbol);
+            // the loop is left with >= 20 bits, enough for any length code and its extra bits
+            for (;;) {
+                if (__builtin_expect((e & K_SUB) != 0, 0)) {
+                    bb >>= LIT_BITS;
+                    bc -= LIT_BITS;
+                    e = LT[(e >> 16) + (uint32_t)(bb & ((1u << ((e >> 8) & 15u)) - 1u))];
+                }
+                if (!(e & K_LITERAL)) break;
+                out[0] = (uint8_t)(e >> 16);
+                out[1] = (uint8_t)(e >> 24); // (the second literal of a paired entry; otherwise overwritten by what follows)
+                out += 1 + (((e >> 8) & 15u) != 0u);
                 bb >>= (e & 0xFFu);
                 bc -= (int)(e & 0xFFu);
-                // two more literals off the same refill (<= 15 bits each, >= 41 - 11 left after the first)
+                if (bc < 20) goto next_symbol; // any length code with its extra bits still fits? else top up first
                 e = LT[bb & ((1u << LIT_BITS) - 1u)];
-                if ((e & (K_LITERAL | K_SUB)) == K_LITERAL) {
-                    *out++ = (uint8_t)(e >> 16);
-                    bb >>= (e & 0xFFu);
-                    bc -= (int)(e & 0xFFu);
-                    e = LT[bb & ((1u << LIT_BITS) - 1u)];
-                    if ((e & (K_LITERAL | K_SUB)) == K_LITERAL) {
-                        *out++ = (uint8_t)(e >> 16);
-                        bb >>= (e & 0xFFu);
-                        bc -= (int)(e & 0xFFu);
-                    }
-                }
-                continue;
             }
-            if (!(e & K_LEN)) {
+            if (__builtin_expect(!(e & K_LEN), 0)) {
                 if (e & K_EOB) {
                     bb >>= (e & 0xFFu);
                     bc -= (int)(e & 0xFFu);
@@ -473,20 +497,18 @@ struct Decoder {
                 const uint32_t length = (e >> 16) + (uint32_t)((bb >> (total - nx)) & ((1u << nx) - 1u));
                 bb >>= total;
                 bc -= (int)total;
-                // (<= 15 + 5 + 15 bits gone since the refill in the worst case: a distance needs <= 15 + 13 more; top up
-                //  only when the buffer has dropped below that)
-                if (bc < 28) {
+                if (bc < 28) { // a distance is <= 15 + 13 bits
                     bb |= load64(in) << bc;
                     in += (63 - bc) >> 3;
                     bc |= 56;
                 }
                 uint32_t d = DT[bb & ((1u << DIST_BITS) - 1u)];
-                if (d & K_SUB) {
+                if (__builtin_expect((d & K_SUB) != 0, 0)) {
                     bb >>= DIST_BITS;
                     bc -= DIST_BITS;
                     d = DT[(d >> 16) + (uint32_t)(bb & ((1u << ((d >> 8) & 15u)) - 1u))];
                 }
-                if (!(d & K_LEN)) {
+                if (__builtin_expect(!(d & K_LEN), 0)) {
                     result = BAD;
                     goto done;
                 }
@@ -494,7 +516,7 @@ struct Decoder {
                 const uint32_t distance = (d >> 16) + (uint32_t)((bb >> (dtotal - dnx)) & ((1u << dnx) - 1u));
                 bb >>= dtotal;
                 bc -= (int)dtotal;
-                if ((size_t)(out - win_start) < distance) {
+                if (__builtin_expect((size_t)(out - win_start) < distance, 0)) {
                     result = BAD; // reaches before the start of the stream
                     goto done;
                 }
@@ -524,7 +546,10 @@ struct Decoder {
                 }
                 out = end;
             }
+        next_symbol:;
         }
+        // (the word loads leave true-but-uncounted stream bits above `bc`; everything below works on a clean buffer)
+        bb &= bc >= 64 ? ~0ull : ((1ull << bc) - 1ull);
         // ---- careful loop: the same decoding with every bound checked; a symbol is consumed only when all of it (its
         //      extra bits and its distance included) is in the input and fits the output ----
         for (;;) {
@@ -546,7 +571,7 @@ struct Decoder {
                 result = s;
             };
             // the fast loop takes over again as soon as its margins are there
-            if (in_end - in >= 16 && out_end - out >= 258 + 32) {
+            if (in_end - in >= 16 && out_end - out >= OUT_MARGIN) {
                 bitbuf = bb;
                 bitcnt = bc;
                 in_ref = in;
@@ -569,6 +594,12 @@ struct Decoder {
                 break;
             }
             used += (int)(e & 0xFFu);
+            // a paired entry: the second literal only if its bits are all there and there is room for it
+            int l1 = (e & K_LITERAL) ? (int)((e >> 8) & 15u) : 0;
+            if (l1 && (used > bc || out_end - out < 2)) {
+                used = l1;
+                l1 = 0;
+            }
             if (used > bc) {
                 give_up(NEED_INPUT);
                 break;
@@ -579,6 +610,7 @@ struct Decoder {
                     break;
                 }
                 *out++ = (uint8_t)(e >> 16);
+                if (l1) *out++ = (uint8_t)(e >> 24);
                 bb >>= used;
                 bc -= used;
                 continue;
@@ -630,6 +662,7 @@ struct Decoder {
             out += length;
         }
     done:
+        bb &= bc >= 64 ? ~0ull : ((1ull << bc) - 1ull);
         bitbuf = bb;
         bitcnt = bc;
         in_ref = in;
@@ -650,5 +683,5 @@ static inline bool inflate_exact(Decoder &dec, const uint8_t *in, size_t in_len,
     return (size_t)(ip - in) - (size_t)(dec.bitcnt >> 3) == in_len;
 }
 
-} // namespace inflate
+} // namespace inf
 } // namespace finch

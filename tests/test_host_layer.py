@@ -396,3 +396,93 @@ def test_sharded_reader_chunks_tile_the_text_and_carry_the_right_halo():
             assert piece.startswith(b"@r") and piece.endswith(b"\n") and piece.count(b"\n") % 4 == 0
             pos += ln
         assert pos == len(fq)
+
+
+def _gzip_member(data: bytes, level=6, strategy=0, name=None, comment=None, extra=None, hcrc=False) -> bytes:
+    """a gzip member with any of the optional header fields of RFC 1952"""
+    import struct
+    import zlib
+    co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    body = co.compress(data) + co.flush()
+    flg = (4 if extra is not None else 0) | (8 if name is not None else 0) | (16 if comment is not None else 0) | (2 if hcrc else 0)
+    hdr = b"\x1f\x8b\x08" + bytes([flg]) + b"\0\0\0\0\x00\xff"
+    if extra is not None:
+        hdr += struct.pack("<H", len(extra)) + extra
+    if name is not None:
+        hdr += name + b"\0"
+    if comment is not None:
+        hdr += comment + b"\0"
+    if hcrc:
+        hdr += struct.pack("<H", zlib.crc32(hdr) & 0xFFFF)
+    return hdr + body + struct.pack("<II", zlib.crc32(data), len(data) & 0xFFFFFFFF)
+
+
+def test_the_library_s_own_inflate_decodes_what_zlib_writes(monkeypatch):
+    """fh_inflate.h (the gzip path of the byte sources): stored / fixed / dynamic blocks, every compression level and
+    strategy zlib has, data from incompressible to one long run, optional header fields, concatenated members, requests of
+    1 byte to 16 MiB -- the delivered stream is the text.  Damaged input is an error: truncation at any point, flipped
+    bits (caught by the decoder or by the member's CRC-32 / ISIZE), garbage after a member."""
+    import zlib
+    monkeypatch.setenv("FINCH_BGZF_THREADS", "1")  # the sequential reader (the parallel BGZF reader has its own test above)
+    rng = np.random.default_rng(31)
+    kinds = {
+        "random": lambda n: rng.integers(0, 256, n, dtype=np.uint8).tobytes(),
+        "dna": lambda n: rng.choice(np.frombuffer(b"ACGT", np.uint8), size=n).tobytes(),
+        "fastq": lambda n: (b"".join(b"@r%d\n%s\n+\n%s\n" % (i, rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=100).tobytes(),
+                                                                 rng.choice(np.frombuffer(b"FF:,#", np.uint8), size=100).tobytes())
+                                     for i in range(n // 210 + 1)))[:n],
+        "runs": lambda n: (b"I" * 997 + b"\n" + b"AC" * 333) * (n // 1664 + 1),
+        "zeros": lambda n: bytes(n),
+    }
+    n_checked = 0
+    for kind, gen in kinds.items():
+        for n in (0, 1, 5, 300, 70000, 700000):
+            data = gen(n)[:n]
+            for level, strategy in ((0, 0), (1, 0), (6, 0), (9, 0), (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE), (6, zlib.Z_FILTERED)):
+                if n > 70000 and (level, strategy) not in ((1, 0), (6, 0), (6, zlib.Z_FIXED)):
+                    continue
+                gz = _gzip_member(data, level, strategy)
+                for chunk in (1 << 24, 4096, 1) if n <= 300 else (1 << 24, 65536 + 1):
+                    assert H.source_probe(gz, chunk, n + 64) == data, (kind, n, level, strategy, chunk)
+                    n_checked += 1
+    assert n_checked > 300
+    text = kinds["fastq"](200000)
+    text = text[:text.rindex(b"\n@r") + 1]  # whole records
+    # optional header fields, several members (bgzip-style and plain), an empty member in between
+    multi = (_gzip_member(text[:50000], 6, 0, name=b"reads.fq", comment=b"made by a test", extra=b"XY\x03\x00abc", hcrc=True) +
+             _gzip_member(b"") + _gzip_member(text[50000:120000], 1) + _gzip_member(text[120000:], 9, name=b"x"))
+    for chunk in (1 << 24, 1000, 7):
+        assert H.source_probe(multi, chunk, len(text) + 64) == text
+    assert H.fastx_scan(multi)[2] == 2
+    # damage
+    gz = _gzip_member(text[:30000], 6)
+    for cut in list(range(2, 40)) + list(range(40, len(gz) - 1, 97)) + [len(gz) - 9, len(gz) - 5, len(gz) - 1]:
+        with pytest.raises(FinchError, match="corrupt"):  # (below two bytes there is no gzip magic to sniff)
+            H.source_probe(gz[:cut], 1 << 20, 40000)
+    caught = 0
+    for trial in range(400):
+        b = bytearray(gz)
+        i = int(rng.integers(10, len(b)))
+        b[i] ^= 1 << int(rng.integers(0, 8))
+        try:
+            got = H.source_probe(bytes(b), 1 << 20, 40000)
+            assert False, "a flipped bit at %d went unnoticed (%d bytes delivered)" % (i, len(got))
+        except FinchError:
+            caught += 1
+    assert caught == 400
+    for tail in (b"\0", b"garbage", b"\x1f\x8b\x08"):
+        with pytest.raises(FinchError, match="corrupt"):
+            H.source_probe(gz + tail, 1 << 20, 40000)
+    with pytest.raises(FinchError, match="corrupt"):
+        H.source_probe(gz[:3] + b"\xe0" + gz[4:], 1 << 20, 40000)  # reserved FLG bits
+    # and the zlib-based reader (FINCH_ZLIB_INFLATE=1) is still there for A/B runs: same bytes (checked in a child process:
+    # the switch is read once per process)
+    import subprocess, sys, os
+    code = ("import sys; sys.path.insert(0, %r); from finch_rs_amd import host as H; d = open(sys.argv[1], 'rb').read(); "
+            "sys.stdout.buffer.write(H.source_probe(d, 100000, 1 << 20))" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".gz") as f:
+        f.write(multi)
+        f.flush()
+        env = dict(os.environ, FINCH_ZLIB_INFLATE="1", FINCH_BGZF_THREADS="1")
+        assert subprocess.run([sys.executable, "-c", code, f.name], env=env, stdout=subprocess.PIPE, check=True).stdout == text
