@@ -147,6 +147,10 @@ struct fh_sketcher {
     uint64_t tau_lo = 0;    // != 0 while a block is re-read for the hashes above a speculative threshold
     bool no_spec = false;   // test knob: disable the speculative first pass
     uint64_t n_spec = 0, n_spec_fallback = 0;
+    // sampling pre-pass of large sketches (fh_kernels.hip, k_sample_hashes): buffers allocated on first use
+    uint64_t *smp_keys = nullptr;
+    uint32_t *smp_counts = nullptr, *smp_hist = nullptr, *h_smp_hist = nullptr; // h_: pinned
+    uint64_t n_sampled = 0; // blocks whose threshold came from a sample
     // observed novelty: new hashes per position over the last completed range (admitted occurrences of hashes that are
     // already in the table cost time, but they do not fill it)
     uint64_t ins_seen = 0;
@@ -163,6 +167,8 @@ struct fh_sketcher {
     // device-side FASTQ packing (fh_text.hip): packed output + block scan scratch per staging slot
     uint8_t *d_packed[N_STAGE] = {nullptr, nullptr};
     uint32_t *d_blk_a[N_STAGE] = {nullptr, nullptr}, *d_blk_b[N_STAGE] = {nullptr, nullptr};
+    uint32_t *d_lines = nullptr; // fh_push_fastq_text: where every text line of the chunk ends (one u32 per line)
+    uint32_t line_cap = 0;
     const uint8_t *dprev_ptr = nullptr; // fh_push_fasta_text: the previous chunk's packed range (device), for the
     uint64_t dprev_len = 0;             // K-1 bytes a k-mer may span across chunks
     uint32_t *d_text_tot = nullptr; // [0] newlines, [1] packed bytes, [2] error flag
@@ -522,13 +528,103 @@ int speculative_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, 
     return FH_OK;
 }
 
+// Large sketches (kmers_to_sketch in the tens of thousands to millions: the CLI's oversketch) on a large first block: take
+// the threshold from a sample of the block instead of discovering it by filling the table (see k_sample_hashes).  On
+// success the whole block has been sketched in one launch at a threshold a little above its final one; if the estimate
+// was too tight -- fewer than `size` hashes live at the end -- everything at or below it is in the table with exact counts
+// and the block is re-read for the hashes above it, exactly like a failed speculation.
+constexpr uint32_t SAMPLE_CAP = 1u << 21; // slots of the sample table (expected load <= 0.2)
+int sampled_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos, uint64_t n_pos, bool *attempted,
+                        bool *done) {
+    *attempted = *done = false;
+    static const bool off = getenv("FH_NO_SAMPLE") != nullptr;
+    static const uint64_t min_pos = [] {
+        const char *e = getenv("FH_SAMPLE_MIN_POS"); // test knob
+        return e ? strtoull(e, nullptr, 10) : (64ull << 20);
+    }();
+    static const double scale_knob = [] {
+        const char *e = getenv("FH_SAMPLE_SCALE"); // test knob: multiply the estimated threshold (< 1 forces the repair pass)
+        return e ? atof(e) : 1.0;
+    }();
+    if (off || s->no_spec || s->max_range || s->p.hash_mask || !s->big_mode || s->p.kind != FH_KIND_MASH || s->p.size < 16384 ||
+        n_pos < min_pos || (double)n_pos < 8.0 * (double)s->p.size)
+        return FH_OK;
+    if (!s->smp_keys) {
+        HIP_TRY(dev_malloc(&s->smp_keys, (size_t)SAMPLE_CAP * sizeof(uint64_t)));
+        HIP_TRY(dev_malloc(&s->smp_counts, (size_t)SAMPLE_CAP * sizeof(uint32_t)));
+        HIP_TRY(dev_malloc(&s->smp_hist, (768 + 4) * sizeof(uint32_t)));
+        HIP_TRY(host_malloc(&s->h_smp_hist, (768 + 4) * sizeof(uint32_t)));
+    }
+    // one run of 64 positions every run_stride: about 8192 * 64 / size of all positions, between 1/1024 and 1/64 of them
+    uint64_t run_stride = std::min<uint64_t>(std::max<uint64_t>(s->p.size / 128, 4096), 65536);
+    const uint64_t n_runs = std::min<uint64_t>(n_pos / run_stride, 1ull << 30);
+    if (n_runs < 1024) return FH_OK;
+    const double n_samples = (double)n_runs * 64.0;
+    const double cap_frac = std::min(0.5, 400000.0 / n_samples); // ~400 k sampled occurrences at most reach the table
+    const uint64_t tau_cap = (uint64_t)(cap_frac * 18446744073709551616.0);
+    HIP_TRY(launch_sample(d_seq, n_pos, (uint32_t)n_runs, (uint32_t)run_stride, (int)s->p.k, s->p.seed, tau_cap, s->smp_keys,
+                          s->smp_counts, SAMPLE_CAP, s->smp_hist, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_smp_hist, s->smp_hist, (768 + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const uint32_t *H = s->h_smp_hist;
+    if (H[768]) return FH_OK; // sample table overflowed (a stream of few, very frequent k-mers): no estimate, and none needed
+    // smallest quarter-octave edge below which the whole block is estimated to hold 1.25 x size distinct hashes
+    const double want = 1.25 * (double)s->p.size;
+    double S = 0, c1 = 0, c2 = 0;
+    uint64_t tau_guess = 0;
+    const uint32_t q_cap = qoct_index(tau_cap);
+    for (uint32_t q = 0; q < 256 && q < q_cap; ++q) { // (the bucket that holds the cap is only partly sampled)
+        S += H[q];
+        c1 += H[256 + q];
+        c2 += H[512 + q];
+        const double unseen = c2 > 0 ? c1 * c1 / (2.0 * c2) : c1 * (c1 - 1.0) / 2.0;
+        if (S >= 256 && S + unseen >= want) {
+            tau_guess = qoct_upper_edge(q);
+            break;
+        }
+    }
+    static const bool trace = getenv("FH_TRACE") != nullptr;
+    if (trace)
+        fprintf(stderr, "[fh] sample: %llu runs every %llu positions, cap %.3e: S %.0f c1 %.0f c2 %.0f -> tau %.3e (%s)\n",
+                (unsigned long long)n_runs, (unsigned long long)run_stride, (double)tau_cap, S, c1, c2, (double)tau_guess,
+                tau_guess ? "guess" : "none");
+    if (!tau_guess) return FH_OK;
+    if (scale_knob != 1.0) tau_guess = (uint64_t)std::min(1.8e19, std::max(1.0, (double)tau_guess * scale_knob));
+    *attempted = true;
+    s->n_sampled++;
+    if (int rc = set_tau(s, tau_guess)) return rc;
+    const bool was_open = s->open_loop;
+    s->open_loop = true; // one range for the whole block; waves stop by themselves if the live set fills up after all
+    if (int rc = start_range(s, d_seq, len, base_pos, 0, n_pos)) return rc;
+    if (int rc = drain(s)) return rc;
+    s->open_loop = was_open;
+    if (int rc = big_prune(s, false)) return rc;
+    if ((uint64_t)s->last_live >= s->p.size) {
+        s->positions_done += n_pos;
+        *done = true;
+        return FH_OK;
+    }
+    // too tight: everything <= tau_guess is in the table with exact counts; re-read the block for the rest
+    s->n_spec_fallback++;
+    s->tau_lo = tau_guess;
+    if (int rc = set_tau(s, EMPTY64)) return rc;
+    return FH_OK;
+}
+
 int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos) {
     if (int rc = drain(s)) return rc;
     if (len < s->p.k) return FH_OK;
     const uint64_t n_pos = len - s->p.k + 1; // windows that fit
     uint64_t pos = 0;
     uint64_t lo_end = 0; // a failed speculation re-reads [0, lo_end) for the hashes above its guess only
+    bool sampled = false;
     if (s->positions_done == 0 && s->tau_lo == 0) {
+        bool done = false;
+        if (int rc = sampled_first_block(s, d_seq, len, base_pos, n_pos, &sampled, &done)) return rc;
+        if (sampled && done) return FH_OK;
+        if (sampled) lo_end = n_pos; // (tau_lo is set: the loop below re-reads the block for the hashes above the estimate)
+    }
+    if (!sampled && s->positions_done == 0 && s->tau_lo == 0) {
         // a large first block speculates on its first 32 M positions only: a wrong guess then costs a second pass
         // over that prefix (0.1 ms), a right one replaces the ten closed-loop warm-up ranges and their round trips
         const uint64_t spec_pos = n_pos <= SPEC_MAX_POS ? n_pos : SPEC_PREFIX_POS;
@@ -876,7 +972,7 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
                 g_pool.erase(g_pool.begin() + (long)i);
                 // fh_free left it reset; only the per-handle statistics are still the previous owner's
                 s->n_launches = s->n_relaunches = s->n_big_prunes = 0;
-                s->n_spec = s->n_spec_fallback = 0;
+                s->n_spec = s->n_spec_fallback = s->n_sampled = 0;
                 s->profiling = false;
                 // the environment knobs a handle reads at creation are the new owner's to set
                 s->no_spec = getenv("FH_NO_SPEC") != nullptr;
@@ -1034,6 +1130,7 @@ void destroy_handle(fh_sketcher *s) {
         (void)hipFree(s->d_blk_b[i]);
     }
     (void)hipFree(s->d_text_tot);
+    (void)hipFree(s->d_lines);
     if (s->h_text_tot) (void)hipHostFree(s->h_text_tot);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     if (s->h_out) (void)hipHostFree(s->h_out);
@@ -1056,6 +1153,10 @@ void destroy_handle(fh_sketcher *s) {
     (void)hipFree(s->o_kmer);
     (void)hipFree(s->o_kmer_hi);
     (void)hipFree(s->kmer_hi);
+    (void)hipFree(s->smp_keys);
+    (void)hipFree(s->smp_counts);
+    (void)hipFree(s->smp_hist);
+    if (s->h_smp_hist) (void)hipHostFree(s->h_smp_hist);
     (void)hipFree(s->o_pos);
     (void)hipFree(s->o_count);
     (void)hipFree(s->o_extra);
@@ -1258,6 +1359,10 @@ int fh_push_fastq_text(fh_sketcher *s, uint64_t len) {
         HIP_TRY(dev_malloc((void **)&s->d_text_tot, 4 * sizeof(uint32_t)));
         HIP_TRY(host_malloc((void **)&s->h_text_tot, 4 * sizeof(uint32_t)));
     }
+    if (!s->d_lines) { // a record is four lines; below 8 bytes per line on average the host parser takes the file
+        s->line_cap = (uint32_t)std::min<uint64_t>(s->stage_bytes / 8 + 64, 0x7FFFFFFFull);
+        HIP_TRY(dev_malloc(&s->d_lines, (size_t)s->line_cap * sizeof(uint32_t)));
+    }
     // the packed buffer of this slot may still feed a pending range
     if (int rc = drain(s)) return rc;
     HIP_TRY(hipMemsetAsync(s->d_text_tot, 0, 4 * sizeof(uint32_t), s->stream));
@@ -1265,10 +1370,12 @@ int fh_push_fastq_text(fh_sketcher *s, uint64_t len) {
     HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
     s->stage_busy[b] = true;
     HIP_TRY(launch_fastq_pack(s->d_stage[b], len, s->d_packed[b], s->d_blk_a[b], s->d_blk_b[b], s->d_text_tot, s->ctl,
-                              s->d_text_tot + 2, s->stream));
+                              s->d_text_tot + 2, s->d_lines, s->line_cap, s->stream));
     HIP_TRY(hipMemcpyAsync(s->h_text_tot, s->d_text_tot, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    if (s->h_text_tot[2]) return fail(FH_ERR_INVALID, "not plain 4-line FASTQ text (header without '@' or separator without '+')");
+    if (s->h_text_tot[2])
+        return fail(FH_ERR_INVALID, "not plain 4-line FASTQ text (header without '@', separator without '+', blanks inside a "
+                                    "sequence line, or sequence and quality lengths differ)");
     const uint64_t n_packed = s->h_text_tot[1];
     s->stage_next = (b + 1) % N_STAGE;
     s->carry_len = 0; // every sequence line ends with its breaker: nothing spans chunks
@@ -1691,7 +1798,7 @@ int fh_debug_counters(fh_sketcher *s, uint64_t *launches, uint64_t *relaunches, 
 
 int fh_debug_speculation(fh_sketcher *s, uint64_t *first_pass, uint64_t *second_pass) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
-    if (first_pass) *first_pass = s->n_spec;
+    if (first_pass) *first_pass = s->n_spec + s->n_sampled; // (blocks sketched at a guessed threshold: by length or by sample)
     if (second_pass) *second_pass = s->n_spec_fallback;
     return FH_OK;
 }

@@ -28,6 +28,10 @@ hipError_t launch_clear_slots(Entry *table, uint64_t cap, const uint32_t *live, 
 hipError_t launch_gather(const Entry *table, const uint32_t *live, const Ctl *ctl, int k, uint64_t *o_hash,
                          uint32_t *o_count, uint32_t *o_extra, uint64_t *o_kmer, uint64_t *o_kmer_hi, uint64_t *o_pos,
                          uint32_t cap_out, hipStream_t st);
+// sampling pre-pass of large sketches (fh_kernels.hip): keys / counts = an open-addressing table of `cap` (power of two) slots,
+// hist_and_stat = 3 x 256 bucket counters (distinct, seen once, seen twice per quarter-octave of hash value) + 4 status words
+hipError_t launch_sample(const uint8_t *seq, uint64_t n_pos, uint32_t n_runs, uint32_t run_stride, int k, uint64_t seed,
+                         uint64_t tau_cap, uint64_t *keys, uint32_t *counts, uint32_t cap, uint32_t *hist_and_stat, hipStream_t st);
 // fh_big.hip
 hipError_t big_sort_tmp_bytes(uint32_t M, size_t *bytes);
 hipError_t launch_big_prune(Entry *table, uint32_t *live, uint32_t *dead, uint32_t dead_cap, Ctl *ctl, uint32_t M,
@@ -42,8 +46,9 @@ hipError_t launch_big_prune_select(Entry *table, uint32_t *live, uint32_t *dead,
 hipError_t launch_rehash(const Entry *src, const uint32_t *src_live, uint32_t M, Entry *dst, uint32_t dst_cap,
                          uint32_t *dst_live, Ctl *ctl, const uint64_t *src_hi, uint64_t *dst_hi, hipStream_t st);
 // fh_text.hip
+// (line_end: scratch for one u32 per text line, line_cap entries; more lines than that -> the error flag)
 hipError_t launch_fastq_pack(const uint8_t *text, uint64_t len, uint8_t *out, uint32_t *blk_a, uint32_t *blk_b,
-                             uint32_t *totals, Ctl *ctl, uint32_t *err, hipStream_t st);
+                             uint32_t *totals, Ctl *ctl, uint32_t *err, uint32_t *line_end, uint32_t line_cap, hipStream_t st);
 hipError_t launch_fasta_pack(const uint8_t *text, uint64_t len, uint32_t start_state, uint8_t *out, uint32_t *blk_a,
                              uint32_t *blk_b, uint32_t *totals, hipStream_t st);
 hipError_t launch_fill_table(Entry *table, uint64_t cap, hipStream_t st);

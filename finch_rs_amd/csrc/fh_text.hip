@@ -11,6 +11,12 @@
 //   pass C  recompute flags, block-local scan, scatter the kept bytes
 // Each pass streams the chunk once with 16-byte loads; at 3 reads + ~0.5 writes per text byte this is HBM bound
 // and costs a few percent of the time the sketch kernel spends on the same reads.
+// What needletail checks per record is checked here too, so that a file the reference refuses (or reads differently) never
+// yields a sketch silently: header lines begin with '@', separator lines with '+', a sequence line holds no blank, tab or
+// interior CR (normalize(false) would DROP those and let k-mers span them; the packed stream would break k-mers there),
+// and every record's sequence and quality lines are equally long (pass C notes where every line ends, k1_check_records
+// compares).  Any violation sets the error flag; the host layer then re-reads the file through its own parser, which
+// reproduces needletail's behaviour case by case (FINCH_DEVICE_PARSE=1: the error is returned instead).
 #include <hip/hip_runtime.h>
 
 #include "fh_core.h"
@@ -111,10 +117,11 @@ struct Keep16 {
     u32 mask;  // bit i: byte i is emitted
     u32 zmask; // bit i: byte i is emitted as the '\0' breaker (end of a sequence line)
     u32 n_nl;
-    u32 bad;   // structure violation seen (header not '@' / separator not '+')
+    u32 bad;   // structure violation seen (header not '@' / separator not '+' / whitespace inside a sequence line)
 };
 
-__device__ __forceinline__ Keep16 decide16(const uint8_t b[16], int nv, u32 line0, bool first_is_line_start) {
+// `next` = the byte after the 16 (0 past the end of the chunk): a CR only ends a line if a newline follows it
+__device__ __forceinline__ Keep16 decide16(const uint8_t b[16], int nv, u32 line0, bool first_is_line_start, uint8_t next) {
     Keep16 k{0u, 0u, 0u, 0u};
     u32 line = line0;
     bool at_start = first_is_line_start;
@@ -136,7 +143,15 @@ __device__ __forceinline__ Keep16 decide16(const uint8_t b[16], int nv, u32 line
             k.n_nl++;
             at_start = true;
         } else {
-            if (ph == 1u && c != '\r') k.mask |= 1u << i;
+            if (ph == 1u) {
+                if (c == '\r') { // a line-ending CR is dropped (and not a base); anywhere else it is not for this path
+                    const uint8_t nx = (i + 1 < nv) ? b[(i + 1) & 15] : next;
+                    if (nx != '\n') k.bad = 1u;
+                } else {
+                    if (c == ' ' || c == '\t') k.bad = 1u;
+                    k.mask |= 1u << i;
+                }
+            }
             at_start = false;
         }
     }
@@ -145,7 +160,8 @@ __device__ __forceinline__ Keep16 decide16(const uint8_t b[16], int nv, u32 line
 
 template <bool WRITE>
 __global__ __launch_bounds__(TB) void k1_pack(const uint8_t *text, u64 len, const u32 *blk_nl_ex, u32 *blk_keep,
-                                              const u32 *blk_keep_ex, uint8_t *out, Ctl *ctl, u32 *err) {
+                                              const u32 *blk_keep_ex, uint8_t *out, Ctl *ctl, u32 *err, u32 *line_end,
+                                              u32 line_cap) {
     __shared__ u32 sm[4];
     const u64 off = ((u64)blockIdx.x * TB + threadIdx.x) * BPT;
     uint8_t b[16];
@@ -156,8 +172,22 @@ __global__ __launch_bounds__(TB) void k1_pack(const uint8_t *text, u64 len, cons
     u32 tot;
     const u32 nl_before = blk_nl_ex[blockIdx.x] + block_exscan(c, sm, &tot);
     const bool starts_line = (off == 0) || (off < len + 1 && off > 0 && text[off - 1] == '\n');
-    const Keep16 k = decide16(b, nv, nl_before, starts_line);
+    const uint8_t next = (nv == 16 && off + 16 < len) ? text[off + 16] : (uint8_t)0;
+    const Keep16 k = decide16(b, nv, nl_before, starts_line, next);
     if (k.bad) atomicExch(err, 1u);
+    if (WRITE && k.n_nl) { // where line j ends: (position << 1) | "a CR precedes the newline"
+        u32 line = nl_before;
+        uint8_t prev = off ? text[off - 1] : (uint8_t)0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i < nv && b[i] == '\n') {
+                if (line < line_cap) line_end[line] = ((u32)(off + i) << 1) | (prev == '\r' ? 1u : 0u);
+                else atomicExch(err, 1u); // more lines than the index holds (records of a few bytes): host parser
+                line++;
+            }
+            prev = b[i];
+        }
+    }
     const u32 nkeep = (u32)__popc(k.mask);
     u32 ktot;
     const u32 kpre = block_exscan(nkeep, sm, &ktot);
@@ -340,17 +370,36 @@ hipError_t launch_fasta_pack(const uint8_t *text, u64 len, u32 start_state, uint
     return hipGetLastError();
 }
 
+// one thread per record: sequence and quality line equally long (CRs before the newlines not counted); the chunk may end
+// without the last quality line's newline
+__global__ __launch_bounds__(256) void k1_check_records(const u32 *line_end, const u32 *n_lines_p, u64 len, const uint8_t *text,
+                                                        u32 line_cap, u32 *err) {
+    const u32 n_lines = *n_lines_p < line_cap ? *n_lines_p : line_cap;
+    const u32 n_rec = (n_lines + 1u) / 4u; // 4r + 3 newlines make record r complete if the text goes on to its end
+    for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_rec; r += gridDim.x * blockDim.x) {
+        const u32 a = line_end[4u * r], b = line_end[4u * r + 1u], c = line_end[4u * r + 2u];
+        u32 d;
+        if (4u * r + 3u < n_lines) d = line_end[4u * r + 3u];
+        else d = ((u32)len << 1) | ((len && text[len - 1] == '\r') ? 1u : 0u);
+        const u32 seq_len = (b >> 1) - (a >> 1) - 1u - (b & 1u), qual_len = (d >> 1) - (c >> 1) - 1u - (d & 1u);
+        if (seq_len != qual_len) atomicExch(err, 1u);
+    }
+}
+
 hipError_t launch_fastq_pack(const uint8_t *text, u64 len, uint8_t *out, u32 *blk_a, u32 *blk_b, u32 *totals, Ctl *ctl,
-                             u32 *err, hipStream_t st) {
+                             u32 *err, u32 *line_end, u32 line_cap, hipStream_t st) {
     if (len == 0) return hipSuccess;
+    if (len >= (1ull << 31)) return hipErrorInvalidValue;
     const u32 nblk = (u32)((len + BLK_BYTES - 1) / BLK_BYTES);
     hipLaunchKernelGGL(k1_count_newlines, dim3(nblk), dim3(TB), 0, st, text, len, blk_a);
     hipLaunchKernelGGL(k1_scan, dim3(1), dim3(1024), 0, st, blk_a, nblk, totals);
     hipLaunchKernelGGL((k1_pack<false>), dim3(nblk), dim3(TB), 0, st, text, len, (const u32 *)blk_a, blk_b,
-                       (const u32 *)nullptr, (uint8_t *)nullptr, ctl, err);
+                       (const u32 *)nullptr, (uint8_t *)nullptr, ctl, err, (u32 *)nullptr, 0u);
     hipLaunchKernelGGL(k1_scan, dim3(1), dim3(1024), 0, st, blk_b, nblk, totals + 1);
     hipLaunchKernelGGL((k1_pack<true>), dim3(nblk), dim3(TB), 0, st, text, len, (const u32 *)blk_a, (u32 *)nullptr,
-                       (const u32 *)blk_b, out, ctl, err);
+                       (const u32 *)blk_b, out, ctl, err, line_end, line_cap);
+    hipLaunchKernelGGL(k1_check_records, dim3(256), dim3(256), 0, st, (const u32 *)line_end, (const u32 *)totals, len, text,
+                       line_cap, err);
     return hipGetLastError();
 }
 

@@ -202,6 +202,48 @@ try:
 except S.FinchError as e:
     assert "FASTQ" in str(e)
 os.environ.pop("FINCH_DEVICE_PARSE")
+# what needletail checks per record, the device pass checks too: blanks / tabs / an interior CR inside a sequence line
+# (normalize(false) drops them, k-mers span them) and unequal sequence / quality lengths send the file to the host
+# parser -- same sketch as the oracle, or the reference's error
+recs = fq(b"\n").split(b"\n@r")
+def damage(i, r):
+    if i % 11 == 5:
+        lines = r.split(b"\n")
+        s_, q_ = lines[1], lines[3]
+        if len(s_) > 20:
+            cut = 7 + i % 9
+            ch = [b" ", b"\t", b"\r"][i % 3]
+            lines[1] = s_[:cut] + ch + s_[cut:]
+            lines[3] = q_[:cut] + b"#" + q_[cut:]
+        return b"\n".join(lines)
+    return r
+ws = os.path.join(sys.argv[1], "ws.fastq")
+data = b"\n@r".join(damage(i, r) for i, r in enumerate(recs))
+open(ws, "wb").write(data)
+b = H.sketch_files([ws], p, f).sketch(0)   # default mode: device pass refuses, host parser reads
+assert vs_oracle(b, data, p, "blanks inside sequence lines")
+os.environ["FINCH_DEVICE_PARSE"] = "1"
+try:
+    H.sketch_files([ws], p, f)
+    raise SystemExit("expected an error")
+except S.FinchError as e:
+    assert "FASTQ" in str(e)
+os.environ.pop("FINCH_DEVICE_PARSE")
+mm = os.path.join(sys.argv[1], "mismatch.fastq")
+lines = fq(b"\n").split(b"\n")
+lines[4 * 777 + 3] = lines[4 * 777 + 3][:-1]          # one quality line a byte short
+open(mm, "wb").write(b"\n".join(lines))
+for mode in (None, "1", "0"):
+    if mode is None:
+        os.environ.pop("FINCH_DEVICE_PARSE", None)
+    else:
+        os.environ["FINCH_DEVICE_PARSE"] = mode
+    try:
+        H.sketch_files([mm], p, f)
+        raise SystemExit("expected an error (mode %r)" % mode)
+    except S.FinchError as e:
+        assert ("lengths differ" in str(e)) if mode != "1" else ("FASTQ" in str(e)), (mode, str(e))
+os.environ.pop("FINCH_DEVICE_PARSE", None)
 # ... and a well-formed file takes the device path by default with the host parser's result
 good = os.path.join(sys.argv[1], "lf.fastq")
 b = H.sketch_files([good], p, f).sketch(0)

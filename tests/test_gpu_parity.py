@@ -508,6 +508,53 @@ def test_the_one_64mer_whose_low_word_looks_unclaimed():
             assert_same(sk, ora, "special 64-mer, mask %x" % mask)
 
 
+def test_large_sketch_takes_its_threshold_from_a_sample():
+    """kmers_to_sketch in the tens of thousands on a large first block: the threshold is estimated from a sparse sample of
+    the block (k_sample_hashes) and the block sketched in one launch; an estimate that is too tight is repaired by a
+    second pass for the hashes above it; one that is far too loose only costs time.  Bit-exact in every case, also for
+    streams the estimator cannot read (few distinct k-mers).  The knobs are read once per process: child processes."""
+    code = r'''
+import os, numpy as np
+import finch_rs_amd as F
+from finch_rs_amd import sketch_schemes as S
+from oracle import oracle as O
+g = S.synth_genome_host(1_000_000, 77)
+reads = S.synth_reads_host(g, 0, 200000, 150, 77, 10000, 500)   # 30 Mbase, 30 x coverage, 1 % errors
+db = F.DeviceBuffer(len(reads) + 64); db.upload(reads)
+expect = os.environ["EXPECT"]
+for k, n in ((21, 20000), (31, 100000), (48, 30000)):
+    sk = F.SketchParams.mash(n, n, True, k, 0).create_sketcher()
+    sk.push_device(db.ptr, len(reads))
+    kc, km, _ = sk.to_arrays()
+    ora = O.OracleSketcher(O.MASH, n, k, 0); ora.process_packed(reads, 0)
+    okc, okm = ora.to_vec()
+    assert np.array_equal(kc, okc) and np.array_equal(km, okm) and sk.finish()[1] == ora.total_bases_and_kmers()[1], (k, n)
+    c = sk.debug_counters()
+    if expect == "hit":
+        assert c["spec"] == 1 and c["spec_second_pass"] == 0 and c["launches"] <= 3, c
+    elif expect == "repair":
+        assert c["spec"] == 1 and c["spec_second_pass"] == 1, c
+    elif expect == "off":
+        assert c["spec_second_pass"] == 0 and c["launches"] > 3, c
+# a stream of few distinct k-mers (one read over and over): nothing to estimate from, same result
+rep = np.tile(reads[:151 * 40], 4000)
+db2 = F.DeviceBuffer(len(rep) + 64); db2.upload(rep)
+sk = F.SketchParams.mash(20000, 20000, True, 21, 0).create_sketcher()
+sk.push_device(db2.ptr, len(rep))
+ora = O.OracleSketcher(O.MASH, 20000, 21, 0); ora.process_packed(rep, 0)
+kc, km, _ = sk.to_arrays(); okc, okm = ora.to_vec()
+assert np.array_equal(kc, okc) and np.array_equal(km, okm)
+print("child ok")
+'''
+    import subprocess, sys
+    for env in ({"EXPECT": "hit"}, {"EXPECT": "repair", "FH_SAMPLE_SCALE": "0.02"}, {"EXPECT": "loose", "FH_SAMPLE_SCALE": "30"},
+                {"EXPECT": "off", "FH_NO_SAMPLE": "1"}):
+        e = dict(os.environ, FH_SAMPLE_MIN_POS="1000000", **env)
+        r = subprocess.run([sys.executable, "-c", code], env=e, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0 and "child ok" in r.stdout, (env, r.stdout[-3000:])
+
+
 def test_handle_cache_returns_a_clean_sketcher():
     """fh_free parks the reset handle, fh_new with the same parameters takes it over: the second owner must see a
     fresh sketcher (empty, counters at zero, same results as a brand-new one); different parameters get their own
