@@ -148,8 +148,8 @@ struct fh_sketcher {
     bool no_spec = false;   // test knob: disable the speculative first pass
     uint64_t n_spec = 0, n_spec_fallback = 0;
     // sampling pre-pass of large sketches (fh_kernels.hip, k_sample_hashes): buffers allocated on first use
-    uint64_t *smp_keys = nullptr;
-    uint32_t *smp_counts = nullptr, *smp_hist = nullptr, *h_smp_hist = nullptr; // h_: pinned
+    uint32_t *smp_list = nullptr, *smp_hist = nullptr, *h_smp_hist = nullptr; // tile runs; histograms (h_: pinned)
+    uint64_t smp_list_cap = 0;
     uint64_t n_sampled = 0; // blocks whose threshold came from a sample
     // observed novelty: new hashes per position over the last completed range (admitted occurrences of hashes that are
     // already in the table cost time, but they do not fill it)
@@ -529,46 +529,107 @@ int speculative_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, 
 }
 
 // Large sketches (kmers_to_sketch in the tens of thousands to millions: the CLI's oversketch) on a large first block: take
-// the threshold from a sample of the block instead of discovering it by filling the table (see k_sample_hashes).  On
-// success the whole block has been sketched in one launch at a threshold a little above its final one; if the estimate
-// was too tight -- fewer than `size` hashes live at the end -- everything at or below it is in the table with exact counts
-// and the block is re-read for the hashes above it, exactly like a failed speculation.
-constexpr uint32_t SAMPLE_CAP = 1u << 21; // slots of the sample table (expected load <= 0.2)
+// the threshold from a sample of the block instead of discovering it by filling the table (fh_kernels.hip,
+// "sampling pre-pass").  The sample pass is the sketch kernel itself over one run of SAMPLE_RUN_TILES tiles in every
+// 64 runs' worth (1/64 of the positions, ~1.6 % of a pass), at a cap threshold; the table then holds the sample's hashes
+// with their sample multiplicities, is read out into three histograms, and cleared again.  On success the whole block is
+// sketched in ONE launch at a threshold a little above its final one.  If the estimate was too tight -- fewer than `size`
+// hashes live at the end -- everything at or below it is in the table with exact counts and the block is re-read for the
+// hashes above it, exactly like a failed speculation.
+constexpr uint32_t SAMPLE_RUN_TILES = 8, SAMPLE_ONE_IN = 64;
 int sampled_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos, uint64_t n_pos, bool *attempted,
                         bool *done) {
     *attempted = *done = false;
     static const bool off = getenv("FH_NO_SAMPLE") != nullptr;
     static const uint64_t min_pos = [] {
         const char *e = getenv("FH_SAMPLE_MIN_POS"); // test knob
-        return e ? strtoull(e, nullptr, 10) : (64ull << 20);
+        return e ? strtoull(e, nullptr, 10) : (256ull << 20);
     }();
     static const double scale_knob = [] {
         const char *e = getenv("FH_SAMPLE_SCALE"); // test knob: multiply the estimated threshold (< 1 forces the repair pass)
         return e ? atof(e) : 1.0;
     }();
     if (off || s->no_spec || s->max_range || s->p.hash_mask || !s->big_mode || s->p.kind != FH_KIND_MASH || s->p.size < 16384 ||
-        n_pos < min_pos || (double)n_pos < 8.0 * (double)s->p.size)
+        n_pos < min_pos || (double)n_pos < 64.0 * (double)s->p.size)
         return FH_OK;
-    if (!s->smp_keys) {
-        HIP_TRY(dev_malloc(&s->smp_keys, (size_t)SAMPLE_CAP * sizeof(uint64_t)));
-        HIP_TRY(dev_malloc(&s->smp_counts, (size_t)SAMPLE_CAP * sizeof(uint32_t)));
-        HIP_TRY(dev_malloc(&s->smp_hist, (768 + 4) * sizeof(uint32_t)));
-        HIP_TRY(host_malloc(&s->h_smp_hist, (768 + 4) * sizeof(uint32_t)));
+    const uint64_t tiles = (n_pos + TILE_POS - 1) / TILE_POS;
+    const uint32_t stride = SAMPLE_RUN_TILES * SAMPLE_ONE_IN;
+    const uint64_t n_runs = tiles / stride;
+    if (n_runs < 64 || tiles >= (1ull << 31)) return FH_OK;
+    if (!s->smp_hist) {
+        HIP_TRY(dev_malloc(&s->smp_hist, 768 * sizeof(uint32_t)));
+        HIP_TRY(host_malloc(&s->h_smp_hist, 768 * sizeof(uint32_t)));
     }
-    // one run of 64 positions every run_stride: about 8192 * 64 / size of all positions, between 1/1024 and 1/64 of them
-    uint64_t run_stride = std::min<uint64_t>(std::max<uint64_t>(s->p.size / 128, 4096), 65536);
-    const uint64_t n_runs = std::min<uint64_t>(n_pos / run_stride, 1ull << 30);
-    if (n_runs < 1024) return FH_OK;
-    const double n_samples = (double)n_runs * 64.0;
-    const double cap_frac = std::min(0.5, 400000.0 / n_samples); // ~400 k sampled occurrences at most reach the table
+    if (n_runs > s->smp_list_cap) {
+        (void)hipFree(s->smp_list);
+        s->smp_list = nullptr;
+        s->smp_list_cap = 0;
+        HIP_TRY(dev_malloc(&s->smp_list, (size_t)n_runs * 2 * sizeof(uint32_t)));
+        s->smp_list_cap = n_runs;
+    }
+    // cap: the sample may put about 2 x size occurrences into the table (half its soft limit); the estimate has to reach
+    // 1.25 x size distinct k-mers BELOW the cap, and an occurrence sample sees a k-mer of multiplicity m with probability
+    // ~m / 64 only
+    const double n_samples = (double)n_runs * SAMPLE_RUN_TILES * TILE_POS;
+    const double cap_frac = std::min(0.25, 2.0 * (double)s->p.size / n_samples);
     const uint64_t tau_cap = (uint64_t)(cap_frac * 18446744073709551616.0);
-    HIP_TRY(launch_sample(d_seq, n_pos, (uint32_t)n_runs, (uint32_t)run_stride, (int)s->p.k, s->p.seed, tau_cap, s->smp_keys,
-                          s->smp_counts, SAMPLE_CAP, s->smp_hist, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->h_smp_hist, s->smp_hist, (768 + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    const uint32_t *H = s->h_smp_hist;
-    if (H[768]) return FH_OK; // sample table overflowed (a stream of few, very frequent k-mers): no estimate, and none needed
+    // ---- the sample pass: the sketch kernel over the tile runs, handed over as a "leftover" list ----
+    if (int rc = set_tau(s, tau_cap)) return rc;
+    HIP_TRY(launch_fill_tile_runs(s->smp_list, (uint32_t)n_runs, stride, SAMPLE_RUN_TILES, (uint32_t)tiles, s->stream));
+    HIP_TRY(launch_queue_reset(s->ctl, 1u, soft_limit_of(s), 1u, s->stream));
+    {
+        SketchArgs a{};
+        a.seq = d_seq;
+        a.len_total = len;
+        a.p_begin = 0;
+        a.p_end = n_pos;
+        a.base_pos = base_pos;
+        a.seed = s->p.seed;
+        a.hash_mask = ~0ull;
+        a.tau_lo = 0;
+        a.ctl = s->ctl;
+        a.tiles_total = (uint32_t)tiles;
+        a.n_units = 0; // nothing but the list
+        a.n_left_in = (uint32_t)n_runs;
+        a.left_in = s->smp_list;
+        a.left_out = s->left_buf[0];
+        const uint64_t waves = std::max<uint64_t>(1, std::min<uint64_t>(n_runs, s->max_waves));
+        a.n_waves = (uint32_t)waves;
+        a.wave_budget = WAVE_BUDGET;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (s->profiling) {
+            if (s->prof_used == s->prof_events.size()) {
+                hipEvent_t a0, a1;
+                HIP_TRY(hipEventCreate(&a0));
+                HIP_TRY(hipEventCreate(&a1));
+                s->prof_events.emplace_back(a0, a1);
+            }
+            e0 = s->prof_events[s->prof_used].first;
+            e1 = s->prof_events[s->prof_used].second;
+            s->prof_used++;
+            HIP_TRY(hipEventRecord(e0, s->stream));
+        }
+        HIP_TRY(launch_k2((int)s->p.k, a, (int)((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), s->stream));
+        if (s->profiling) {
+            HIP_TRY(hipEventRecord(e1, s->stream));
+            s->prof_launches++;
+            s->prof_positions += (uint64_t)n_samples;
+        }
+        s->n_launches++;
+    }
+    HIP_TRY(launch_live_flatten(s->ctl, s->stream));
+    HIP_TRY(launch_live_count_hist(s->table, s->live, s->ctl, s->smp_hist, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_smp_hist, s->smp_hist, 768 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    if (int rc = check_ctl(s)) return rc; // (synchronises)
+    const bool sample_clean = !s->h_ctl->stopped && s->h_ctl->n_left_out == 0;
+    // the table goes back to empty: the sample's counts are sample counts
+    HIP_TRY(launch_clear_slots(s->table, s->cap, s->live, s->dead, s->ctl, s->stream));
+    HIP_TRY(launch_init_ctl(s->ctl, initial_tau(s), s->stream, true));
+    s->last_tau = initial_tau(s);
+    s->last_live = 0;
+    if (!sample_clean) return FH_OK; // (a stream of few, very frequent k-mers filled a wave's budget: nothing to estimate)
     // smallest quarter-octave edge below which the whole block is estimated to hold 1.25 x size distinct hashes
+    const uint32_t *H = s->h_smp_hist;
     const double want = 1.25 * (double)s->p.size;
     double S = 0, c1 = 0, c2 = 0;
     uint64_t tau_guess = 0;
@@ -577,17 +638,16 @@ int sampled_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
         S += H[q];
         c1 += H[256 + q];
         c2 += H[512 + q];
-        const double unseen = c2 > 0 ? c1 * c1 / (2.0 * c2) : c1 * (c1 - 1.0) / 2.0;
-        if (S >= 256 && S + unseen >= want) {
+        if (S < 1024 || c2 < 32) continue; // too few doubletons to say anything about the unseen
+        if (S + c1 * c1 / (2.0 * c2) >= want) {
             tau_guess = qoct_upper_edge(q);
             break;
         }
     }
     static const bool trace = getenv("FH_TRACE") != nullptr;
     if (trace)
-        fprintf(stderr, "[fh] sample: %llu runs every %llu positions, cap %.3e: S %.0f c1 %.0f c2 %.0f -> tau %.3e (%s)\n",
-                (unsigned long long)n_runs, (unsigned long long)run_stride, (double)tau_cap, S, c1, c2, (double)tau_guess,
-                tau_guess ? "guess" : "none");
+        fprintf(stderr, "[fh] sample: %llu runs of %u tiles, cap %.3e: S %.0f c1 %.0f c2 %.0f -> tau %.3e (%s)\n",
+                (unsigned long long)n_runs, SAMPLE_RUN_TILES, (double)tau_cap, S, c1, c2, (double)tau_guess, tau_guess ? "guess" : "none");
     if (!tau_guess) return FH_OK;
     if (scale_knob != 1.0) tau_guess = (uint64_t)std::min(1.8e19, std::max(1.0, (double)tau_guess * scale_knob));
     *attempted = true;
@@ -1153,8 +1213,7 @@ void destroy_handle(fh_sketcher *s) {
     (void)hipFree(s->o_kmer);
     (void)hipFree(s->o_kmer_hi);
     (void)hipFree(s->kmer_hi);
-    (void)hipFree(s->smp_keys);
-    (void)hipFree(s->smp_counts);
+    (void)hipFree(s->smp_list);
     (void)hipFree(s->smp_hist);
     if (s->h_smp_hist) (void)hipHostFree(s->h_smp_hist);
     (void)hipFree(s->o_pos);

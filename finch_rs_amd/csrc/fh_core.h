@@ -830,68 +830,8 @@ FH_HD uint8_t kmer_base(u64 lo, u64 hi, int k, int b) {
     return (uint8_t) "ACGT"[code];
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// murmurhash3_x64_128(ascii(k-mer), seed).0 for a run-time K (1..64), straight from the definition (hashing.rs:10-12 over
-// murmurhash3 0.0.5): no tables, 64-bit multiplies.  Used where K is not a template parameter and speed is secondary: the
-// sampling pre-pass of large sketches (fh_kernels.hip, k_sample_hashes).  The k-mer comes as two m-form words (hi = the
-// first K - 32 bases when K > 32).
-// ------------------------------------------------------------------------------------------------------------------
-FH_HD u64 kmer_ascii_word(u64 lo, u64 hi, int K, int first, int n) { // key bytes [first, first + n), n <= 8, little endian
-    u64 w = 0;
-    for (int i = 0; i < n; ++i) {
-        const int d = K - 1 - (first + i); // digit of base first + i, counted from the k-mer's last base
-        const u32 code = (u32)(((d >= 32) ? (hi >> (2 * (d - 32))) : (lo >> (2 * d))) & 3u);
-        const u64 ch = code == 0 ? 0x41u : code == 1 ? 0x43u : code == 2 ? 0x47u : 0x54u;
-        w |= ch << (8 * i);
-    }
-    return w;
-}
-
-FH_HD u64 murmur_h1_generic(u64 lo, u64 hi, int K, u64 seed) {
-    u64 h1 = seed, h2 = seed;
-    const int nblocks = K / 16, tail = K & 15;
-    for (int b = 0; b < nblocks; ++b) {
-        u64 k1 = kmer_ascii_word(lo, hi, K, 16 * b, 8), k2 = kmer_ascii_word(lo, hi, K, 16 * b + 8, 8);
-        k1 *= MURMUR_C1;
-        k1 = rotl64(k1, 31);
-        k1 *= MURMUR_C2;
-        h1 ^= k1;
-        h1 = rotl64(h1, 27);
-        h1 += h2;
-        h1 = h1 * 5 + 0x52dce729ULL;
-        k2 *= MURMUR_C2;
-        k2 = rotl64(k2, 33);
-        k2 *= MURMUR_C1;
-        h2 ^= k2;
-        h2 = rotl64(h2, 31);
-        h2 += h1;
-        h2 = h2 * 5 + 0x38495ab5ULL;
-    }
-    if (tail > 8) {
-        u64 k2 = kmer_ascii_word(lo, hi, K, 16 * nblocks + 8, tail - 8);
-        k2 *= MURMUR_C2;
-        k2 = rotl64(k2, 33);
-        k2 *= MURMUR_C1;
-        h2 ^= k2;
-    }
-    if (tail > 0) {
-        u64 k1 = kmer_ascii_word(lo, hi, K, 16 * nblocks, tail > 8 ? 8 : tail);
-        k1 *= MURMUR_C1;
-        k1 = rotl64(k1, 31);
-        k1 *= MURMUR_C2;
-        h1 ^= k1;
-    }
-    h1 ^= (u64)K;
-    h2 ^= (u64)K;
-    h1 += h2;
-    h2 += h1;
-    h1 = fmix64(h1);
-    h2 = fmix64(h2);
-    return h1 + h2;
-}
-
-// Quarter-octave index of a hash value (floor(4 log2 x), x >= 1): the sampling pre-pass histograms sample hashes by it, and
-// the host turns a bucket back into its upper edge
+// Quarter-octave index of a hash value (floor(4 log2 x), x >= 4): the sampling pre-pass of large sketches histograms the
+// sample's hashes by it (fh_kernels.hip, k_live_count_hist), and the host turns a bucket back into its upper edge
 FH_HD u32 qoct_index(u64 x) {
     if (x < 4) return (u32)x; // (below the first quarter-octave: one bucket per value)
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -368,25 +368,28 @@ struct FastGzSource : ByteSource {
     std::vector<uint8_t> inbuf; // compressed bytes [in_lo, in_hi), 16 bytes of zero padding behind in_hi
     size_t in_lo = 0, in_hi = 0;
     bool in_eof = false;
-    // inflated bytes pass through a window: [0, w_have) valid, [w_out, w_have) not yet delivered, the last 32 KiB stay
-    // as match history when the window is recycled
-    static constexpr size_t HIST = 32768, WIN = (size_t)1 << 20;
-    std::vector<uint8_t> win;
-    size_t w_have = 0, w_out = 0, w_member = 0; // w_member: where the current member's output starts (a match may not reach before it)
+    // Large requests are decoded straight into the caller's buffer (the 64 MiB pinned staging buffers of the device-side
+    // text paths, the parser's 8 MiB buffer); what a request leaves over (< one match) and small requests go through
+    // `win`.  Either way the last 32 KiB of the stream so far are kept in `hist`: that is where a match may reach when it
+    // starts before the buffer at hand.
+    static constexpr size_t HIST = 32768, WIN = (size_t)1 << 18, DIRECT_MIN = (size_t)1 << 16;
+    std::vector<uint8_t> win, hist;
+    size_t w_have = 0, w_out = 0, hist_len = 0;
+    uint64_t member_out = 0; // bytes of the current member produced so far (a match may not reach before its start)
     enum { GZ_HEADER, BODY, TRAILER, END } st = GZ_HEADER;
     uint32_t crc = 0;
-    uint64_t isize = 0;
     bool bad = false, any_member = false;
 
     explicit FastGzSource(std::unique_ptr<ByteSource> in)
-        : inner(std::move(in)), dec(new inf::Decoder()), inbuf(((size_t)1 << 20) + 16), win(HIST + WIN + (size_t)inf::OUT_MARGIN) {}
+        : inner(std::move(in)), dec(new inf::Decoder()), inbuf(((size_t)1 << 20) + 16), win(WIN), hist(HIST) {}
     bool failed() const override { return bad; }
     bool can_rewind() const override { return inner->can_rewind(); }
     bool rewind() override {
         if (!inner->rewind()) return false;
         in_lo = in_hi = 0;
         in_eof = bad = any_member = false;
-        w_have = w_out = w_member = 0;
+        w_have = w_out = hist_len = 0;
+        member_out = 0;
         st = GZ_HEADER;
         return true;
     }
@@ -439,96 +442,113 @@ struct FastGzSource : ByteSource {
         in_lo += off;
         return 1;
     }
-    // produce more inflated bytes into the window; false = end of stream or error
-    bool produce() {
+    void push_hist(const uint8_t *p, size_t n) { // the stream went on by p[0, n)
+        if (n >= HIST) {
+            memcpy(hist.data(), p + n - HIST, HIST);
+            hist_len = HIST;
+            return;
+        }
+        const size_t keep = std::min(hist_len, HIST - n);
+        memmove(hist.data(), hist.data() + hist_len - keep, keep);
+        memcpy(hist.data() + keep, p, n);
+        hist_len = keep + n;
+    }
+    // inflate into buf[0, room): as much as fits / as the input holds; the bytes join the stream (hist) on return
+    size_t produce_into(uint8_t *buf, size_t room) {
+        uint8_t *op = buf;
+        uint8_t *const oe = buf + room;
+        const uint8_t *floor = buf;                                           // matches reach back to here in this buffer ...
+        size_t ext = (size_t)std::min<uint64_t>(hist_len, member_out);        // ... and this far into hist before it
         for (;;) {
-            if (st == END || bad) return false;
+            if (st == END || bad) break;
             if (st == GZ_HEADER) {
                 if (in_hi == in_lo && !refill()) { // clean end of input between members
                     if (!any_member) bad = true;  // (an empty file is not gzip)
                     st = END;
-                    return false;
+                    break;
                 }
                 const int r = parse_header();
                 if (r < 0) {
                     bad = true;
-                    return false;
+                    break;
                 }
                 if (r == 0) {
-                    if (!refill()) { // the input ends inside a header
-                        bad = true;
-                        return false;
-                    }
+                    if (!refill()) bad = true; // the input ends inside a header
                     continue;
                 }
                 dec->reset();
                 crc = 0;
-                isize = 0;
-                w_member = w_have;
+                member_out = 0;
+                floor = op;
+                ext = 0;
                 any_member = true;
                 st = BODY;
             }
             if (st == BODY) {
-                if (w_out == w_have && w_have > HIST) { // everything delivered: recycle the window, keeping the history
-                    const size_t shift = w_have - HIST;
-                    memmove(win.data(), win.data() + shift, HIST);
-                    w_have = w_out = HIST;
-                    w_member = w_member > shift ? w_member - shift : 0;
-                }
+                dec->ext_end = hist.data() + hist_len;
+                dec->ext_len = ext;
                 const uint8_t *ip = inbuf.data() + in_lo;
-                uint8_t *op = win.data() + w_have;
-                const inf::Status s = dec->run(ip, inbuf.data() + in_hi, op, win.data() + win.size(), win.data() + w_member);
+                uint8_t *const before = op;
+                const inf::Status s = dec->run(ip, inbuf.data() + in_hi, op, oe, floor);
                 in_lo = (size_t)(ip - inbuf.data());
-                const size_t fresh = (size_t)(op - (win.data() + w_have));
+                const size_t fresh = (size_t)(op - before);
                 if (fresh) {
-                    crc = inf::crc32_fast(crc, win.data() + w_have, fresh);
-                    isize += fresh;
-                    w_have += fresh;
+                    crc = inf::crc32_fast(crc, before, fresh);
+                    member_out += fresh;
                 }
                 if (s == inf::BAD) {
                     bad = true;
-                    return false;
-                }
-                if (s == inf::STREAM_END) {
+                } else if (s == inf::STREAM_END) {
                     in_lo -= (size_t)(dec->bitcnt >> 3); // whole bytes still in the bit buffer belong to the trailer
                     st = TRAILER;
                 } else if (s == inf::NEED_INPUT) {
-                    if (!refill()) { // the input ends inside a member: truncated
-                        bad = true;
-                        return false;
-                    }
+                    if (!refill()) bad = true; // the input ends inside a member: truncated
+                } else if (s == inf::NEED_OUTPUT) {
+                    break;
                 }
-                if (fresh) return true; // (NEED_OUTPUT: the caller drains the window and comes back)
                 continue;
             }
             if (st == TRAILER) {
                 if (in_hi - in_lo < 8) {
-                    if (!refill()) {
-                        bad = true;
-                        return false;
-                    }
+                    if (!refill()) bad = true;
                     continue;
                 }
                 const uint8_t *p = inbuf.data() + in_lo;
                 const uint32_t want_crc = p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
                 const uint32_t want_len = p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
                 in_lo += 8;
-                if (want_crc != crc || want_len != (uint32_t)isize) {
-                    bad = true;
-                    return false;
-                }
+                if (want_crc != crc || want_len != (uint32_t)member_out) bad = true;
                 st = GZ_HEADER;
             }
         }
+        const size_t n = (size_t)(op - buf);
+        if (n) push_hist(buf, n);
+        return n;
     }
     size_t read(uint8_t *dst, size_t cap) override {
         size_t n = 0;
         while (n < cap) {
-            if (w_out == w_have && !produce()) break;
-            const size_t m = std::min(cap - n, w_have - w_out);
-            memcpy(dst + n, win.data() + w_out, m);
-            w_out += m;
-            n += m;
+            if (w_out < w_have) {
+                const size_t m = std::min(cap - n, w_have - w_out);
+                memcpy(dst + n, win.data() + w_out, m);
+                w_out += m;
+                n += m;
+                continue;
+            }
+            if (st == END || bad) break;
+            if (cap - n >= DIRECT_MIN) {
+                const size_t got = produce_into(dst + n, cap - n);
+                n += got;
+                if (got == 0 && st != END && !bad) { // the next symbol needs more room than is left: through the window
+                    w_have = produce_into(win.data(), win.size());
+                    w_out = 0;
+                    if (w_have == 0) break;
+                }
+            } else {
+                w_have = produce_into(win.data(), win.size());
+                w_out = 0;
+                if (w_have == 0) break;
+            }
         }
         return n;
     }

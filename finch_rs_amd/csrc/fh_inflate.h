@@ -285,8 +285,15 @@ struct Decoder {
     bool final_block = false;
     uint32_t stored_left = 0;
     uint32_t lit[LIT_TABLE_MAX], dist[DIST_TABLE_MAX];
+    // History that is not in front of the output buffer: the ext_len bytes that END at ext_end precede win_start in the
+    // stream (a caller that decodes straight into successive destination buffers keeps the last 32 KiB of what it has
+    // delivered here).  A match may reach into it.
+    const uint8_t *ext_end = nullptr;
+    size_t ext_len = 0;
 
     void reset() {
+        ext_end = nullptr;
+        ext_len = 0;
         bitbuf = 0;
         bitcnt = 0;
         state = HEADER;
@@ -517,8 +524,18 @@ struct Decoder {
                 bb >>= dtotal;
                 bc -= (int)dtotal;
                 if (__builtin_expect((size_t)(out - win_start) < distance, 0)) {
-                    result = BAD; // reaches before the start of the stream
-                    goto done;
+                    // reaches before this buffer: into the external history, or before the start of the stream
+                    const size_t back = distance - (size_t)(out - win_start);
+                    if (back > ext_len) {
+                        result = BAD;
+                        goto done;
+                    }
+                    const uint8_t *sp = ext_end - back;
+                    uint32_t i = 0;
+                    for (; i < length && i < back; ++i) out[i] = sp[i];
+                    for (; i < length; ++i) out[i] = win_start[i - back];
+                    out += length;
+                    goto next_symbol;
                 }
                 const uint8_t *src = out - distance;
                 uint8_t *const end = out + length;
@@ -647,7 +664,8 @@ struct Decoder {
             }
             const uint32_t dnx = (d >> 8) & 15u;
             const uint32_t distance = (d >> 16) + (uint32_t)((bb >> (dused - (int)dnx)) & ((1u << dnx) - 1u));
-            if ((size_t)(out - win_start) < distance) {
+            const size_t have = (size_t)(out - win_start);
+            if (have < distance && distance - have > ext_len) {
                 result = BAD;
                 break;
             }
@@ -657,8 +675,16 @@ struct Decoder {
             }
             bb >>= dused;
             bc -= dused;
-            const uint8_t *src = out - distance;
-            for (uint32_t i = 0; i < length; ++i) out[i] = src[i];
+            if (have < distance) { // the match starts in the external history
+                const size_t back = distance - have;
+                const uint8_t *sp = ext_end - back;
+                uint32_t i = 0;
+                for (; i < length && i < back; ++i) out[i] = sp[i];
+                for (; i < length; ++i) out[i] = win_start[i - back];
+            } else {
+                const uint8_t *src = out - distance;
+                for (uint32_t i = 0; i < length; ++i) out[i] = src[i];
+            }
             out += length;
         }
     done:

@@ -28,10 +28,11 @@ hipError_t launch_clear_slots(Entry *table, uint64_t cap, const uint32_t *live, 
 hipError_t launch_gather(const Entry *table, const uint32_t *live, const Ctl *ctl, int k, uint64_t *o_hash,
                          uint32_t *o_count, uint32_t *o_extra, uint64_t *o_kmer, uint64_t *o_kmer_hi, uint64_t *o_pos,
                          uint32_t cap_out, hipStream_t st);
-// sampling pre-pass of large sketches (fh_kernels.hip): keys / counts = an open-addressing table of `cap` (power of two) slots,
-// hist_and_stat = 3 x 256 bucket counters (distinct, seen once, seen twice per quarter-octave of hash value) + 4 status words
-hipError_t launch_sample(const uint8_t *seq, uint64_t n_pos, uint32_t n_runs, uint32_t run_stride, int k, uint64_t seed,
-                         uint64_t tau_cap, uint64_t *keys, uint32_t *counts, uint32_t cap, uint32_t *hist_and_stat, hipStream_t st);
+// sampling pre-pass of large sketches (fh_kernels.hip): tile runs [i * stride, i * stride + run_tiles) as a leftover list for the
+// sketch kernel; histograms of the live entries by quarter-octave of hash value (3 x 256: entries, one occurrence, two)
+hipError_t launch_fill_tile_runs(uint32_t *list, uint32_t n_runs, uint32_t stride, uint32_t run_tiles, uint32_t tiles_total,
+                                 hipStream_t st);
+hipError_t launch_live_count_hist(const Entry *table, const uint32_t *live, const Ctl *ctl, uint32_t *hist, hipStream_t st);
 // fh_big.hip
 hipError_t big_sort_tmp_bytes(uint32_t M, size_t *bytes);
 hipError_t launch_big_prune(Entry *table, uint32_t *live, uint32_t *dead, uint32_t dead_cap, Ctl *ctl, uint32_t M,
@@ -52,7 +53,8 @@ hipError_t launch_fastq_pack(const uint8_t *text, uint64_t len, uint8_t *out, ui
 hipError_t launch_fasta_pack(const uint8_t *text, uint64_t len, uint32_t start_state, uint8_t *out, uint32_t *blk_a,
                              uint32_t *blk_b, uint32_t *totals, hipStream_t st);
 hipError_t launch_fill_table(Entry *table, uint64_t cap, hipStream_t st);
-hipError_t launch_init_ctl(Ctl *ctl, uint64_t tau0, hipStream_t st);
+// (keep_text_bases: everything but the count of sequence bytes the text packers have emitted so far)
+hipError_t launch_init_ctl(Ctl *ctl, uint64_t tau0, hipStream_t st, bool keep_text_bases = false);
 hipError_t launch_set_tau(Ctl *ctl, uint64_t tau, hipStream_t st);
 hipError_t launch_set_table(Ctl *ctl, Entry *table, uint32_t *live, CollRec *clog, uint32_t cap, uint32_t live_cap,
                             uint32_t clog_cap, uint32_t *shard_cnt, uint32_t *shard_buf, uint32_t shard_cap, uint64_t *kmer_hi,

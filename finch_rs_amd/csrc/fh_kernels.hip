@@ -309,82 +309,54 @@ hipError_t launch_gather(const Entry *table, const u32 *live, const Ctl *ctl, in
 // ------------------------------------------------------------------------------------------------
 // sampling pre-pass of large sketches: where will the threshold of a kmers_to_sketch-hash sketch of this block end up?
 // ------------------------------------------------------------------------------------------------
-// A sketch of millions of hashes (the CLI's 200-fold oversketch, cli.rs:187-192) used to find its threshold by filling
-// the table: thresholds of 24 %, 17 %, 3 % ... of all positions, 90 M upserts for the 2 M hashes that stay.  Instead, a
-// sparse sample of the block's k-mer OCCURRENCES (runs of 64 consecutive start positions, one wave each, every
-// `run_stride` positions) is hashed, the sample's hashes below a cap are counted in a small open-addressing table, and the
-// host estimates from the multiplicities how many DISTINCT k-mers of the whole block lie below each candidate threshold
-// (Chao's lower bound S + c1^2 / 2 c2 on the number of species, from the distinct sample hashes S and those seen exactly
-// once / twice: an occurrence sample misses most k-mers that occur once, the singletons-to-doubletons ratio says how
-// many).  The estimate errs low, i.e. the threshold comes out loose, which costs a few percent more upserts; a guess that
-// turns out too tight is caught after the pass (fewer than `size` hashes live) and repaired by the second pass of
-// speculative_first_block's machinery.  Exactness of the sketch never depends on the estimate.
-__global__ __launch_bounds__(256) void k_sample_hashes(const uint8_t *seq, u64 n_pos, u32 n_runs, u32 run_stride, int K, u64 seed,
-                                                       u64 tau_cap, u64 *keys, u32 *counts, u32 cap_mask, u32 *stat) {
-    typedef unsigned __int128 u128;
-    const u32 lane = threadIdx.x & 63u;
-    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-    const u128 top = (u128)3 << (2 * (K - 1));
-    for (u32 run = wave; run < n_runs; run += n_waves) {
-        const u64 p = (u64)run * run_stride + lane;
-        if (p >= n_pos) continue; // (n_pos = last start position + 1: the K bytes behind every p < n_pos are readable)
-        u128 fwd = 0, rc = 0;
-        bool ok = true;
-        for (int j = 0; j < K; ++j) {
-            const u32 c = seq[p + j] & 0xDFu; // fold case (needletail normalize: acgt -> ACGT, u/U -> T)
-            const u32 code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : (c == 'T' || c == 'U') ? 3u : 4u;
-            ok = ok && code < 4u && (seq[p + j] & 0x80u) == 0u;
-            fwd = (fwd << 2) | (code & 3u);
-            rc = (rc >> 2) | ((u128)(3u - (code & 3u)) << (2 * (K - 1)));
-        }
-        (void)top;
-        if (K < 64) fwd &= (((u128)1) << (2 * K)) - 1;
-        const u128 cm = fwd < rc ? fwd : rc;
-        const u64 h = murmur_h1_generic((u64)cm, (u64)(cm >> 64), K, seed);
-        if (!ok || h > tau_cap) continue;
-        u32 slot = (u32)((h * 0x9E3779B97F4A7C15ULL) >> 32) & cap_mask;
-        bool placed = false;
-        for (int probe = 0; probe < 128; ++probe) {
-            const unsigned long long old = atomicCAS((unsigned long long *)&keys[slot], (unsigned long long)EMPTY64, (unsigned long long)h);
-            if (old == EMPTY64 || old == h) {
-                atomicAdd(&counts[slot], 1u);
-                placed = true;
-                break;
-            }
-            slot = (slot + 1u) & cap_mask;
-        }
-        if (!placed) atomicExch(&stat[0], 1u); // table too full to trust: no estimate
+// A sketch of millions of hashes (the CLI's 200-fold oversketch, cli.rs:187-192) finds its threshold by filling the
+// table: at stream position x everything below n / distinct(x) has to be admitted, ~n ln(D / n) upserts more than a
+// pass that knew the final threshold from the start.  So the block is SAMPLED first: the sketch kernel itself runs over
+// one run of RUN_TILES tiles out of every `stride` (an occurrence sample, uniform over the block whatever its order) at
+// a cap threshold, which leaves the sample's hashes with their sample multiplicities in the table; k_live_count_hist
+// turns the live entries into three histograms over hash value (distinct sample hashes, those seen once, those seen
+// twice), and the host estimates from them how many DISTINCT k-mers of the whole block lie below each candidate
+// threshold: Chao's lower bound S + c1^2 / (2 c2) on the number of species -- an occurrence sample misses most k-mers
+// that occur a few times, the singleton / doubleton ratio says how many.  The bound errs low, so the threshold comes out
+// loose (more upserts, still far fewer than without); a guess that is too tight after all is caught after the pass
+// (fewer than `size` hashes live) and repaired by a second pass for the hashes above it.  The sketch never depends on
+// the estimate being right.
+__global__ void k_fill_tile_runs(u32 *list, u32 n_runs, u32 stride, u32 run_tiles, u32 tiles_total) {
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += gridDim.x * blockDim.x) {
+        const u32 t0 = i * stride, t1 = t0 + run_tiles;
+        list[2u * i] = t0;
+        list[2u * i + 1u] = t1 < tiles_total ? t1 : tiles_total;
     }
 }
 
-// per quarter-octave of hash value: distinct sample hashes, those seen once, those seen twice
-__global__ __launch_bounds__(256) void k_sample_hist(const u64 *keys, const u32 *counts, u32 cap, u32 *hist /* [3][256] */) {
+hipError_t launch_fill_tile_runs(u32 *list, u32 n_runs, u32 stride, u32 run_tiles, u32 tiles_total, hipStream_t st) {
+    hipLaunchKernelGGL(k_fill_tile_runs, dim3((n_runs + 255u) / 256u), dim3(256), 0, st, list, n_runs, stride, run_tiles, tiles_total);
+    return hipGetLastError();
+}
+
+// per quarter-octave of hash value (qoct_index): live entries, those with one occurrence, those with two
+__global__ __launch_bounds__(256) void k_live_count_hist(const Entry *table, const u32 *live, const Ctl *ctl, u32 *hist /* [3][256] */) {
     __shared__ u32 lh[3][256];
     for (int i = threadIdx.x; i < 768; i += blockDim.x) (&lh[0][0])[i] = 0;
     __syncthreads();
-    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
-        const u64 k = keys[i];
-        if (k == EMPTY64) continue;
-        const u32 q = qoct_index(k), c = counts[i];
+    const u32 n = ctl->n_live;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Entry e = table[live[i]];
+        const u32 q = qoct_index(e.hash);
+        const u64 c = e.count + e.extra;
         atomicAdd(&lh[0][q], 1u);
-        if (c == 1u) atomicAdd(&lh[1][q], 1u);
-        if (c == 2u) atomicAdd(&lh[2][q], 1u);
+        if (c == 1ull) atomicAdd(&lh[1][q], 1u);
+        if (c == 2ull) atomicAdd(&lh[2][q], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 768; i += blockDim.x)
         if ((&lh[0][0])[i]) atomicAdd(&hist[i], (&lh[0][0])[i]);
 }
 
-hipError_t launch_sample(const uint8_t *seq, u64 n_pos, u32 n_runs, u32 run_stride, int k, u64 seed, u64 tau_cap, u64 *keys,
-                         u32 *counts, u32 cap, u32 *hist_and_stat, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(keys, 0xFF, (size_t)cap * sizeof(u64), st);
+hipError_t launch_live_count_hist(const Entry *table, const u32 *live, const Ctl *ctl, u32 *hist, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(hist, 0, 768 * sizeof(u32), st);
     if (e != hipSuccess) return e;
-    if ((e = hipMemsetAsync(counts, 0, (size_t)cap * sizeof(u32), st)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(hist_and_stat, 0, (768 + 4) * sizeof(u32), st)) != hipSuccess) return e;
-    const u32 waves = n_runs < 16384u ? n_runs : 16384u;
-    hipLaunchKernelGGL(k_sample_hashes, dim3((waves + 3u) / 4u), dim3(256), 0, st, seq, n_pos, n_runs, run_stride, k, seed, tau_cap,
-                       keys, counts, cap - 1u, hist_and_stat + 768);
-    hipLaunchKernelGGL(k_sample_hist, dim3(512), dim3(256), 0, st, keys, counts, cap, hist_and_stat);
+    hipLaunchKernelGGL(k_live_count_hist, dim3(512), dim3(256), 0, st, table, live, ctl, hist);
     return hipGetLastError();
 }
 
@@ -520,7 +492,7 @@ hipError_t launch_live_flatten(Ctl *ctl, hipStream_t st) {
     return hipGetLastError();
 }
 
-__global__ void k_init_ctl(Ctl *ctl, u64 tau0) {
+__global__ void k_init_ctl(Ctl *ctl, u64 tau0, u32 keep_text_bases) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         ctl->tau = tau0;
         ctl->inserted_total = 0;
@@ -546,7 +518,7 @@ __global__ void k_init_ctl(Ctl *ctl, u64 tau0) {
         ctl->sp_kmer = EMPTY64;
     }
     for (int i = threadIdx.x; i < 256; i += blockDim.x) ctl->kmer_counts[i] = 0;
-    if (threadIdx.x == 0) ctl->text_bases = 0;
+    if (threadIdx.x == 0 && !keep_text_bases) ctl->text_bases = 0;
 }
 
 // new range: empty queue; relaunch of a stopped range: keep next_chunk, swap leftover lists
@@ -582,8 +554,8 @@ hipError_t launch_set_tau(Ctl *ctl, u64 tau, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_init_ctl(Ctl *ctl, u64 tau0, hipStream_t st) {
-    hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, st, ctl, tau0);
+hipError_t launch_init_ctl(Ctl *ctl, u64 tau0, hipStream_t st, bool keep_text_bases) {
+    hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(256), 0, st, ctl, tau0, keep_text_bases ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -151,8 +151,6 @@ extern "C" int fhcore_positions_w(const uint8_t *seq, uint64_t len, int k, uint6
     return dispatch_w<64>(k, seq, len, seed, hashes, valid, isrc, canon);
 }
 
-// the run-time-K hash of the sampling pre-pass against nothing but the k-mer's two words (the test compares with the oracle)
-extern "C" uint64_t fhcore_murmur_generic(uint64_t lo, uint64_t hi, int k, uint64_t seed) { return murmur_h1_generic(lo, hi, k, seed); }
 extern "C" uint32_t fhcore_qoct_index(uint64_t x) { return qoct_index(x); }
 extern "C" uint64_t fhcore_qoct_upper_edge(uint32_t q) { return qoct_upper_edge(q); }
 
