@@ -1371,6 +1371,22 @@ int fh_text_buffer(fh_sketcher *s, uint8_t **buf, uint64_t *cap) {
     return FH_OK;
 }
 
+int fh_text_buffers(fh_sketcher *s, uint8_t *bufs[2], uint64_t *cap, int *next) {
+    if (!s || !bufs || !cap || !next) return fail(FH_ERR_INVALID, "null argument");
+    if (int rc = set_device(s)) return rc;
+    if (int rc = ensure_stage(s)) return rc;
+    for (int i = 0; i < N_STAGE; ++i) {
+        if (s->stage_busy[i]) {
+            HIP_TRY(hipEventSynchronize(s->stage_done[i]));
+            s->stage_busy[i] = false;
+        }
+        bufs[i] = s->h_stage[i] + STAGE_HEADROOM;
+    }
+    *cap = s->stage_bytes;
+    *next = s->stage_next;
+    return FH_OK;
+}
+
 int fh_push_staged(fh_sketcher *s, uint64_t len, uint32_t flags) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");

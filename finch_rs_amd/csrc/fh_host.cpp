@@ -1205,54 +1205,8 @@ static fh_params to_fh(const finch_sketch_params &sp, uint64_t max_launch, uint6
 // into the sketcher's pinned staging buffer and only looks for a record boundary near the end of each chunk.
 // A line is a header iff it starts with '@' and the line two below starts with '+' (a quality line may start
 // with '@', but then the line two below is a sequence line).
-static int fastq_text_to_device(ByteSource &src, fh_sketcher *h) {
-    std::vector<uint8_t> left; // tail of the previous chunk after its last complete record
-    bool eof = false;
-    while (!eof || !left.empty()) {
-        uint8_t *buf = nullptr;
-        uint64_t cap = 0;
-        if (int rc = fh_text_buffer(h, &buf, &cap)) return hfail(rc, "%s", fh_last_error());
-        if (left.size() >= cap) return hfail(FH_ERR_INVALID, "FASTQ record longer than the staging buffer");
-        memcpy(buf, left.data(), left.size());
-        size_t fill = left.size();
-        left.clear();
-        while (!eof && fill < cap) {
-            const size_t got = src.read(buf + fill, cap - fill);
-            if (got == 0) eof = true;
-            fill += got;
-        }
-        if (fill == 0) break;
-        size_t cut = fill;
-        if (!eof) {
-            // starts of the last few lines, newest first (a line starts at 0 or right after a '\n')
-            size_t ls[16];
-            int n = 0;
-            size_t pos = fill; // look for newlines in [0, pos)
-            while (n < 16) {
-                const uint8_t *nl = pos > 0 ? (const uint8_t *)memrchr(buf, '\n', pos) : nullptr;
-                const size_t start = nl ? (size_t)(nl - buf) + 1 : 0;
-                if (start < fill) ls[n++] = start; // skip the empty "line" after a trailing newline
-                if (!nl) break;
-                pos = (size_t)(nl - buf);
-            }
-            cut = 0;
-            bool found = false;
-            for (int i = 2; i < n && !found; ++i) { // ls[i] is two lines above ls[i-2]
-                if (buf[ls[i]] == '@' && buf[ls[i - 2]] == '+') {
-                    cut = ls[i];
-                    found = true;
-                }
-            }
-            if (!found) return hfail(FH_ERR_INVALID, "no FASTQ record boundary found in a %zu byte chunk", fill);
-            left.assign(buf + cut, buf + fill);
-        }
-        if (cut)
-            if (int rc = fh_push_fastq_text(h, cut)) return hfail(rc, "%s", fh_last_error());
-        if (eof && left.empty()) break;
-    }
-    if (src.failed()) return hfail(FH_ERR_INVALID, "read error or corrupt compressed stream");
-    return FH_OK;
-}
+static int pump_text_to_device(ByteSource &src, fh_sketcher *h, bool fastq, uint32_t k, struct FastxStats &st);
+static int fastq_text_to_device(ByteSource &src, fh_sketcher *h, uint32_t k);
 
 // Device-side FASTA (fh_push_fasta_text): the host reads raw file bytes into the pinned staging buffer, cuts chunks
 // after a newline and does the bookkeeping that needs no per-base work: the record count and total_bases =
@@ -1319,40 +1273,10 @@ struct FastaCounter {
     }
 };
 
-static int fasta_text_to_device(ByteSource &src, fh_sketcher *h, FastxStats &st) {
-    FastaCounter fc;
-    std::vector<uint8_t> left; // tail of the previous chunk after its last newline
-    bool eof = false, first = true;
-    while (!eof || !left.empty()) {
-        uint8_t *buf = nullptr;
-        uint64_t cap = 0;
-        if (int rc = fh_text_buffer(h, &buf, &cap)) return hfail(rc, "%s", fh_last_error());
-        cap = std::min<uint64_t>(cap, (1ull << 30) - 1);
-        size_t fill = std::min<size_t>(left.size(), cap);
-        memcpy(buf, left.data(), fill);
-        left.erase(left.begin(), left.begin() + fill);
-        while (!eof && fill < cap) {
-            const size_t got = src.read(buf + fill, cap - fill);
-            if (got == 0) eof = true;
-            fill += got;
-        }
-        if (fill == 0) break;
-        size_t cut = fill;
-        if (!eof || !left.empty()) {
-            const uint8_t *nl = (const uint8_t *)memrchr(buf, '\n', fill);
-            if (nl) cut = (size_t)(nl - buf) + 1; // else: one line longer than the buffer, cut anywhere
-            left.insert(left.begin(), buf + cut, buf + fill);
-        }
-        const uint32_t state = fc.start_state();
-        fc.feed(buf, cut);
-        if (int rc = fh_push_fasta_text(h, cut, state, first ? 0u : FH_PUSH_CONTINUE)) return hfail(rc, "%s", fh_last_error());
-        first = false;
-    }
-    if (src.failed()) return hfail(FH_ERR_INVALID, "read error or corrupt compressed stream");
-    fc.finish();
-    st.total_bases = fc.total_bases;
-    st.n_records = fc.n_records;
-    return FH_OK;
+static int fasta_text_to_device(ByteSource &src, fh_sketcher *h, FastxStats &st, uint32_t k) { return pump_text_to_device(src, h, false, k, st); }
+static int fastq_text_to_device(ByteSource &src, fh_sketcher *h, uint32_t k) {
+    FastxStats st;
+    return pump_text_to_device(src, h, true, k, st);
 }
 
 // The sketchers of one worker.  With filtering off, a Mash sketch of `kmers_to_sketch` hashes that is then truncated to
@@ -1453,7 +1377,7 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
         // loud), a file the device pass rejects is read again through the host parser, which is the judge of what
         // needletail accepts (blank lines between records, ...); sources that cannot rewind start on the host.
         st.format = 2;
-        const int rc = fastq_text_to_device(*src, h);
+        const int rc = fastq_text_to_device(*src, h, sp.kmer_length);
         if (rc != FH_OK) {
             if (dp_on || rc != FH_ERR_INVALID || !src->rewind()) return rc;
             if (int r2 = fh_reset(h)) return hfail(r2, "%s", fh_last_error());
@@ -1462,7 +1386,7 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     }
     if (device_parse && first == '>') {
         st.format = 1;
-        if (int rc = fasta_text_to_device(*src, h, st)) return rc;
+        if (int rc = fasta_text_to_device(*src, h, st, sp.kmer_length)) return rc;
     } else if (!device_parse) {
         DeviceSink sink(h);
         if (int rc = parse_fastx(*src, sink, st)) return rc;
@@ -1489,8 +1413,16 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
 // across a cut are formed exactly once, on the device that takes the later chunk.  Then: fh_finish per handle,
 // fh_merge into the first, filters, Sketch.
 // ---------------------------------------------------------------------------------------------
+struct TextBuf { // a chunk buffer of the text readers: heap memory, or one of a sketcher's pinned staging buffers
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+    int id = 0;
+    uint8_t *data() const { return p; }
+    size_t size() const { return cap; }
+};
+
 struct ShardWork {
-    std::vector<uint8_t> *buf = nullptr;
+    TextBuf *buf = nullptr;
     size_t len = 0;
     uint64_t text_off = 0;
     uint32_t start_state = 0;
@@ -1552,7 +1484,7 @@ static int shard_reader(ByteSource &src_ref, bool fastq, uint32_t K, Take take_b
         uint8_t halo[64];
         uint32_t halo_len = 0;
         while ((!eof || !left.empty()) && !abort) {
-            std::vector<uint8_t> *b = take_buf();
+            TextBuf *b = take_buf();
             uint8_t *buf = b->data();
             const size_t cap = b->size();
             if (left.size() >= cap && fastq) {
@@ -1640,6 +1572,86 @@ static int shard_reader(ByteSource &src_ref, bool fastq, uint32_t K, Take take_b
     return rrc;
 }
 
+// The device-side text paths of ONE sketcher (finch_sketch_files / finch_sketch_buffer): the reader -- file reads, inflate,
+// the search for a record boundary, the FASTA bookkeeping -- runs on a thread of its own and fills one of the sketcher's
+// two pinned staging buffers while the calling thread has the other one copied to the device, split into records and
+// sketched (fh_push_fastq_text / fh_push_fasta_text synchronise with the device once per chunk).  Compressed input gains
+// most: the inflate no longer waits for the pushes.  Chunks of a FASTA file continue each other on the same sketcher
+// (FH_PUSH_CONTINUE carries the k-1 bases on the device; the halo shard_reader computes is for the sharded path).
+static int pump_text_to_device(ByteSource &src, fh_sketcher *h, bool fastq, uint32_t k, FastxStats &st) {
+    uint8_t *raw[2] = {nullptr, nullptr};
+    uint64_t cap = 0;
+    int next = 0;
+    if (int rc = fh_text_buffers(h, raw, &cap, &next)) return hfail(rc, "%s", fh_last_error());
+    if (!fastq) cap = std::min<uint64_t>(cap, (1ull << 30) - 1);
+    TextBuf tb[2] = {TextBuf{raw[0], (size_t)cap, 0}, TextBuf{raw[1], (size_t)cap, 1}};
+    std::mutex mu;
+    std::condition_variable cv;
+    bool is_free[2] = {true, true}, producer_done = false;
+    int fill = next; // the slot the next chunk goes to: pushes consume the slots alternately, starting with `next`
+    std::vector<ShardWork> ready;
+    std::atomic<bool> abort{false};
+    int prc = FH_OK;
+    std::string pmsg;
+    FastxStats pst;
+    std::thread producer([&] {
+        const int rc = shard_reader(
+            src, fastq, k,
+            [&] {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return is_free[fill] || abort.load(); });
+                is_free[fill] = false;
+                return &tb[fill];
+            },
+            [&](TextBuf *b) { // taken but not used
+                std::lock_guard<std::mutex> g(mu);
+                is_free[b->id] = true;
+            },
+            [&](const ShardWork &job) {
+                std::lock_guard<std::mutex> g(mu);
+                ready.push_back(job);
+                fill ^= 1;
+                cv.notify_all();
+            },
+            abort, pst);
+        std::lock_guard<std::mutex> g(mu);
+        prc = rc;
+        if (rc != FH_OK) pmsg = g_host_err; // (thread-local: carried over to the caller's thread below)
+        producer_done = true;
+        cv.notify_all();
+    });
+    int rc = FH_OK;
+    std::string msg;
+    bool first = true;
+    for (;;) {
+        ShardWork job;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !ready.empty() || producer_done; });
+            if (ready.empty()) break;
+            job = ready.front();
+            ready.erase(ready.begin());
+        }
+        if (rc == FH_OK) {
+            rc = fastq ? fh_push_fastq_text(h, job.len) : fh_push_fasta_text(h, job.len, job.start_state, first ? 0u : FH_PUSH_CONTINUE);
+            if (rc != FH_OK) {
+                msg = fh_last_error();
+                abort = true;
+            }
+            first = false;
+        }
+        std::lock_guard<std::mutex> g(mu);
+        is_free[job.buf->id] = true;
+        cv.notify_all();
+    }
+    producer.join();
+    if (rc != FH_OK) return hfail(rc, "%s", msg.c_str());
+    if (prc != FH_OK) return hfail(prc, "%s", pmsg.c_str());
+    st.total_bases = pst.total_bases;
+    st.n_records = pst.n_records;
+    return FH_OK;
+}
+
 static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::string &name, const finch_sketch_params &sp,
                                  const finch_filter_params &filters, const std::vector<int> &devs, uint64_t chunk_bytes,
                                  Sketch &out) {
@@ -1700,14 +1712,16 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
     // chunk buffers circulate between the reader and the workers
     std::mutex free_mu;
     std::condition_variable free_cv;
-    std::vector<std::unique_ptr<std::vector<uint8_t>>> bufs;
-    std::vector<std::vector<uint8_t> *> free_list;
-    for (size_t i = 0; i < 2 * n_w + 1; ++i) {
-        bufs.push_back(std::make_unique<std::vector<uint8_t>>(stage));
-        free_list.push_back(bufs.back().get());
+    std::vector<std::unique_ptr<uint8_t[]>> mem;
+    std::vector<TextBuf> bufs(2 * n_w + 1);
+    std::vector<TextBuf *> free_list;
+    for (size_t i = 0; i < bufs.size(); ++i) {
+        mem.emplace_back(new uint8_t[stage]);
+        bufs[i] = TextBuf{mem.back().get(), (size_t)stage, (int)i};
+        free_list.push_back(&bufs[i]);
     }
     std::atomic<bool> abort{false};
-    auto give_back = [&](std::vector<uint8_t> *b) {
+    auto give_back = [&](TextBuf *b) {
         std::lock_guard<std::mutex> g(free_mu);
         free_list.push_back(b);
         free_cv.notify_one();
@@ -1757,7 +1771,7 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
     auto take_buf = [&]() {
         std::unique_lock<std::mutex> lk(free_mu);
         free_cv.wait(lk, [&] { return !free_list.empty(); });
-        std::vector<uint8_t> *b = free_list.back();
+        TextBuf *b = free_list.back();
         free_list.pop_back();
         return b;
     };
@@ -2142,11 +2156,12 @@ int finch_shard_probe(const uint8_t *data, uint64_t len, uint32_t k, uint64_t ch
     int first = -1;
     if (int rc = open_source(std::make_unique<MemSource>(data, (size_t)len), src, nullptr, &first)) return rc;
     if (first != '>' && first != '@') return hfail(FH_ERR_INVALID, "not a FASTA/FASTQ file");
-    std::vector<uint8_t> buf((size_t)chunk_bytes);
+    std::vector<uint8_t> mem((size_t)chunk_bytes);
+    TextBuf buf{mem.data(), mem.size(), 0};
     std::atomic<bool> abort{false};
     FastxStats st;
     uint64_t n = 0;
-    const int rc = shard_reader(*src, first == '@', k, [&] { return &buf; }, [](std::vector<uint8_t> *) {},
+    const int rc = shard_reader(*src, first == '@', k, [&] { return &buf; }, [](TextBuf *) {},
                                 [&](const ShardWork &job) {
                                     if (n < max_chunks) {
                                         if (meta) {

