@@ -351,20 +351,21 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
         s.set_profiling(True)
         best, best_after = 1e30, 1e30
         kms = kl = kp = 0
-        for it in range(warmup + steps):
+        for it in range(warmup + steps + (1 if after is not None else 0)):
             t0 = time.perf_counter()
             s.reset()
             s.push_device(buf.ptr, reads * rec)
             arrs = s.to_arrays()
             tk = s.finish()[1]
             t1 = time.perf_counter()
-            if after is not None:
-                after(p, arrs, tk)
-            t2 = time.perf_counter()
             ms, nl, npos = s.kernel_time()
-            if it >= warmup:
-                best, best_after = min(best, t1 - t0), min(best_after, t2 - t0)
+            if it >= warmup + steps:  # one more pass, with the host-side post-processing behind it
+                after(p, arrs, tk)
+                best_after = time.perf_counter() - t0
+            elif it >= warmup:
+                best = min(best, t1 - t0)
                 kms += ms; kl += nl; kp += npos
+            del arrs
         dbg = s.debug_counters()
         s.close()
         r = {"ms_per_pass": round(best * 1e3, 3), "gbases_per_s": round(reads * READ_LEN / best / 1e9, 2),
@@ -431,7 +432,7 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
     def e2e():
         ns = min(n_reads, 4_000_000)
         reads = dr.download(ns * rec).reshape(ns, rec)[:, :READ_LEN]
-        w = 11 + READ_LEN + 3 + READ_LEN + 1  # "@r%09d\n" seq "\n+\n" qual "\n"
+        w = 12 + READ_LEN + 3 + READ_LEN + 1  # "@r%09d\n" seq "\n+\n" qual "\n"
         txt = np.empty((ns, w), np.uint8)
         txt[:, 0], txt[:, 1] = ord("@"), ord("r")
         idx = np.arange(ns, dtype=np.int64)
@@ -466,7 +467,7 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
         import zlib
         ns = min(n_reads, 1_000_000)
         reads = dr.download(ns * rec).reshape(ns, rec)[:, :READ_LEN]
-        w = 11 + READ_LEN + 3 + READ_LEN + 1
+        w = 12 + READ_LEN + 3 + READ_LEN + 1
         txt = np.empty((ns, w), np.uint8)
         txt[:, 0], txt[:, 1] = ord("@"), ord("r")
         idx = np.arange(ns, dtype=np.int64)

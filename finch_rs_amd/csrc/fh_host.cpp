@@ -2296,6 +2296,33 @@ int finch_distance(const finch_sketches *a, uint32_t ia, const finch_sketches *b
     return FH_OK;
 }
 
+// statistics.rs:8-23: the k-minimum-values estimate, in the reference's f32 arithmetic (`as u64` saturates, NaN -> 0)
+int finch_sketch_cardinality(const finch_sketches *s, uint32_t i, uint64_t *out) {
+    if (!s || i >= s->v.size() || !out) return hfail(FH_ERR_INVALID, "bad argument");
+    const std::vector<KmerCount> &h = s->v[i].hashes;
+    if (h.empty()) {
+        *out = 0;
+        return FH_OK;
+    }
+    const float ratio = (float)h.back().hash / 18446744073709551616.0f; // usize::MAX as f32 rounds to 2^64
+    const float est = (float)(h.size() - 1) / ratio;
+    *out = est != est ? 0ull : (est >= 18446744073709551616.0f ? UINT64_MAX : (est <= 0.0f ? 0ull : (uint64_t)est));
+    return FH_OK;
+}
+
+// statistics.rs:30-47 (hist): out[c - 1] = number of hashes with count c, for c = 1..max count; *n = max count.  Call with
+// out = NULL to learn *n.
+int finch_sketch_hist(const finch_sketches *s, uint32_t i, uint64_t *out, uint64_t cap, uint64_t *n) {
+    if (!s || i >= s->v.size() || !n) return hfail(FH_ERR_INVALID, "bad argument");
+    const std::vector<uint64_t> hd = hist(s->v[i].hashes);
+    *n = hd.size();
+    if (out) {
+        if (cap < hd.size()) return hfail(FH_ERR_INVALID, "histogram of %zu entries does not fit %llu", hd.size(), (unsigned long long)cap);
+        memcpy(out, hd.data(), hd.size() * sizeof(uint64_t));
+    }
+    return FH_OK;
+}
+
 uint32_t finch_guess_filter_threshold(const uint32_t *counts, uint64_t n, double filter_level) {
     if (n && !counts) {
         hfail(FH_ERR_INVALID, "null argument");

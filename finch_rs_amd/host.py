@@ -84,6 +84,8 @@ _SYMS = {
     "finch_sketch_set_comment": (C.c_int, [_P, C.c_uint32, C.c_char_p]),
     "finch_sketches_append": (C.c_int, [_P, _P]),
     "finch_filter_sketch": (C.c_int, [_P, C.c_uint32, C.POINTER(CFilterParams)]),
+    "finch_sketch_cardinality": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint64)]),
+    "finch_sketch_hist": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "finch_sketches_free": (None, [_P]),
     "finch_sketches_len": (C.c_uint32, [_P]),
     "finch_sketch_name": (C.c_char_p, [_P, C.c_uint32]),
@@ -225,6 +227,20 @@ class Sketches:
         """FilterParams::filter_sketch (filtering.rs:20-54)"""
         c = filters.to_c()
         _check(lib().finch_filter_sketch(self._p, i, C.byref(c)))
+
+    def cardinality(self, i: int) -> int:
+        """statistics.rs:8-23"""
+        out = C.c_uint64()
+        _check(lib().finch_sketch_cardinality(self._p, i, C.byref(out)))
+        return out.value
+
+    def hist(self, i: int) -> np.ndarray:
+        """statistics.rs:30-47"""
+        n = C.c_uint64()
+        _check(lib().finch_sketch_hist(self._p, i, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.uint64)
+        _check(lib().finch_sketch_hist(self._p, i, out.ctypes.data, n.value, C.byref(n)))
+        return out
 
     def to_list(self) -> List[Sketch]:
         return [self.sketch(i) for i in range(len(self))]

@@ -147,6 +147,10 @@ int finch_sketches_from_arrays(const char *name, uint64_t seq_length, uint64_t n
 /* filter_counts (filtering.rs:60-87) + process_post_filter (mod.rs:115-128) applied in place to sketch i;
  * `filters` is updated exactly as the reference updates its FilterParams. */
 int finch_apply_filters(finch_sketches *s, uint32_t i, finch_filter_params *filters);
+/* statistics.rs: cardinality (8-23: k-minimum-values estimate of the number of distinct k-mers, the reference's f32
+ * arithmetic) and hist (30-47: out[c - 1] = hashes with count c; out == NULL only reports *n = the largest count) */
+int finch_sketch_cardinality(const finch_sketches *s, uint32_t i, uint64_t *out);
+int finch_sketch_hist(const finch_sketches *s, uint32_t i, uint64_t *out, uint64_t cap, uint64_t *n);
 /* guess_filter_threshold (filtering.rs:154-195); counts must be >= 1.  Returns 0 (never a valid threshold) and sets
  * finch_last_error for a null array or a zero count. */
 uint32_t finch_guess_filter_threshold(const uint32_t *counts, uint64_t n, double filter_level);

@@ -143,6 +143,32 @@ def test_records_no_sketcher_can_emit_are_rejected_at_the_abi():
     sk.apply_filters(0, H.FilterParams(True, (None, None), 0.5, 0.1))
 
 
+def test_hist_and_cardinality_reference_known_answers():
+    """statistics.rs:53-129 (hist, incl. the issue-63 regression) and the k-minimum-values cardinality (8-23)"""
+    p = SketchParams.mash(10, 10, True, 4, 0)
+    km = np.full((5, 4), ord("A"), np.uint8)
+    a = kc_of([1, 1, 1])
+    sk = H.sketches_from_arrays("a", 1, 1, a, km[:3], p, H.FilterParams(False))
+    assert sk.hist(0).tolist() == [3]
+    b = kc_of([4, 2, 4, 3, 126497])
+    b["hash"] = [1, 2, 3, 4, 5]
+    sk = H.sketches_from_arrays("b", 1, 1, b, km, p, H.FilterParams(False))
+    hd = sk.hist(0)
+    assert len(hd) == 126497 and (hd[0], hd[1], hd[2], hd[3], hd[126496]) == (0, 1, 1, 2, 1) and hd.sum() == 5
+    # cardinality: (len - 1) / (last hash / 2^64) in f32, `as u64`
+    c = kc_of([1] * 4)
+    c["hash"] = [10, 20, 30, 2**63]
+    sk = H.sketches_from_arrays("c", 1, 1, c, km[:4], p, H.FilterParams(False))
+    assert sk.cardinality(0) == int(np.float32(3) / (np.float32(2**63) / np.float32(2**64))) == 6
+    e = kc_of([])
+    assert H.sketches_from_arrays("e", 0, 0, e, km[:0], p, H.FilterParams(False)).cardinality(0) == 0
+    z = kc_of([1, 1])
+    z["hash"] = [0, 5]
+    sk = H.sketches_from_arrays("z", 1, 1, z, km[:2], p, H.FilterParams(False))
+    want = np.float32(1) / (np.float32(5) / np.float32(2**64))
+    assert sk.cardinality(0) == min(int(want), 2**64 - 1)
+
+
 def test_sk_json_writer_format():
     kc = kc_of([3, 1], [1, 0])
     kc["hash"] = [12345678901234567890, 18446744073709551615]
