@@ -2181,6 +2181,22 @@ int finch_shard_probe(const uint8_t *data, uint64_t len, uint32_t k, uint64_t ch
     return FH_OK;
 }
 
+// The tail of sketch_stream (lib.rs:70-93) for a caller that drove the device engine itself (fh_push_* on `h`): to_vec ->
+// filter_counts -> process_post_filter -> Sketch.  `format`: 1 FASTA, 2 FASTQ (decides the filtering default when
+// filters->filter_on is None, lib.rs:70-76).
+int finch_sketch_from_sketcher(fh_sketcher *h, const char *name, uint64_t seq_length, int format, const finch_sketch_params *sp,
+                               const finch_filter_params *filters, finch_sketches **out) {
+    if (!h || !sp || !filters || !out) return hfail(FH_ERR_INVALID, "null argument");
+    FastxStats st;
+    st.total_bases = seq_length;
+    st.format = format;
+    auto res = std::make_unique<finch_sketches>();
+    res->v.resize(1);
+    if (int rc = finish_sketch(h, name ? name : "", *sp, *filters, st, res->v[0])) return rc;
+    *out = res.release();
+    return FH_OK;
+}
+
 void finch_sketches_free(finch_sketches *s) { delete s; }
 uint32_t finch_sketches_len(const finch_sketches *s) { return s ? (uint32_t)s->v.size() : 0; }
 const char *finch_sketch_name(const finch_sketches *s, uint32_t i) { return (s && i < s->v.size()) ? s->v[i].name.c_str() : ""; }

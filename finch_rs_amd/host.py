@@ -86,6 +86,8 @@ _SYMS = {
     "finch_filter_sketch": (C.c_int, [_P, C.c_uint32, C.POINTER(CFilterParams)]),
     "finch_sketch_cardinality": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint64)]),
     "finch_sketch_hist": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "finch_sketch_from_sketcher": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.c_int, C.POINTER(CSketchParams), C.POINTER(CFilterParams),
+                                             C.POINTER(_P)]),
     "finch_sketches_free": (None, [_P]),
     "finch_sketches_len": (C.c_uint32, [_P]),
     "finch_sketch_name": (C.c_char_p, [_P, C.c_uint32]),
@@ -348,6 +350,14 @@ def sketches_from_json(text) -> Sketches:
 def open_sketch_file(path: str) -> Sketches:
     """finch::open_sketch_file (lib.rs:96-118)"""
     return _loaded(lib().finch_open_sketch_file, path.encode())
+
+
+def sketch_from_sketcher(sketcher, name: str, seq_length: int, fmt: int, sketch_params: SketchParams, filters: FilterParams) -> Sketches:
+    """the tail of sketch_stream (lib.rs:70-93) on a HipSketcher the caller fed itself: to_vec -> filters -> post filter"""
+    sp, fp = _params_c(sketch_params), filters.to_c()
+    out = _P()
+    _check(lib().finch_sketch_from_sketcher(sketcher._h, name.encode(), seq_length, fmt, C.byref(sp), C.byref(fp), C.byref(out)))
+    return Sketches(out, sketch_params)
 
 
 def sketches_from_arrays(name, seq_length, num_valid_kmers, kc, km, sketch_params: SketchParams, filters: FilterParams) -> Sketches:

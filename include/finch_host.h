@@ -80,6 +80,11 @@ int finch_sketch_file_sharded(const char *filename, const finch_sketch_params *s
 int finch_sketch_buffer_sharded(const uint8_t *data, uint64_t len, const char *name, const finch_sketch_params *sketch_params,
                                 const finch_filter_params *filters, const int *devices, uint32_t n_devices, uint64_t chunk_bytes,
                                 finch_sketches **out);
+/* The tail of sketch_stream (lib.rs:70-93) for a caller that fed a sketcher of include/finch_hip.h itself: fh_finish, to_vec,
+ * filter_counts, process_post_filter -> one Sketch.  format: 1 FASTA, 2 FASTQ (the filtering default, lib.rs:70-76). */
+struct fh_sketcher;
+int finch_sketch_from_sketcher(struct fh_sketcher *h, const char *name, uint64_t seq_length, int format,
+                               const finch_sketch_params *sketch_params, const finch_filter_params *filters, finch_sketches **out);
 void finch_sketches_free(finch_sketches *s);
 
 uint32_t finch_sketches_len(const finch_sketches *s);

@@ -134,6 +134,11 @@ def test_config3_oversketch_and_filtering_vs_sharded_oracle():
     assert fp.abun_filter == (cutoff, None)
     assert len(got.hashes) == final
     assert np.array_equal(got.arrays[0], b[:final]) and np.array_equal(got.arrays[1], bk[:final])
+    # the same straight off the sketcher (the tail of sketch_stream, lib.rs:70-93, for a caller that fed the device itself)
+    direct = H.sketch_from_sketcher(sk, "c3", n_reads * RL, 2, params, H.FilterParams(None, (None, None), 0.31, 0.1)).sketch(0)
+    assert direct.filter_params.filter_on is True and direct.filter_params.abun_filter == (cutoff, None)  # FASTQ: filtering on by default
+    assert np.array_equal(direct.arrays[0], b[:final]) and np.array_equal(direct.arrays[1], bk[:final])
+    assert (direct.seq_length, direct.num_valid_kmers) == (n_reads * RL, tk)
 
 
 def test_c4_50gbase_sharded_read_blocks_and_host_merge():
