@@ -12,6 +12,7 @@
 #include <atomic>
 #include <cerrno>
 #include <charconv>
+#include <chrono>
 #include <condition_variable>
 #include <cmath>
 #include <cstdarg>
@@ -615,8 +616,19 @@ struct BgzfSource : ByteSource {
     struct Member { size_t in_off, in_len, out_off; uint32_t isize, crc; };
     // inflate the next batch of members into out[0, out_cap) (>= 64 KiB: room for any one member); false = end of
     // input or error; *produced may be 0 for a batch of empty members
+    // FH_TRACE: where a BGZF reader's time goes (compressed reads / member scan / parallel inflate), printed at the end
+    double t_read = 0, t_scan = 0, t_inflate = 0;
+    uint64_t n_batches = 0, n_members = 0;
+    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    ~BgzfSource() override {
+        static const bool trace = getenv("FH_TRACE") != nullptr;
+        if (trace && n_batches)
+            fprintf(stderr, "[finch] bgzf: %llu batches, %llu members, %u threads: read %.1f ms, scan %.1f ms, inflate %.1f ms\n",
+                    (unsigned long long)n_batches, (unsigned long long)n_members, n_thr, t_read * 1e3, t_scan * 1e3, t_inflate * 1e3);
+    }
     bool refill(uint8_t *out, size_t out_cap, size_t *produced) {
         *produced = 0;
+        const double tr0 = now_s();
         std::vector<Member> ms;
         size_t out_total = 0, scan = 0; // scan: offset from c_lo of the next member header
         // (a plain gzip file also lands here when several threads are available: look at its first header before
@@ -634,6 +646,8 @@ struct BgzfSource : ByteSource {
         }
         // top the buffer up once, then take the members that are completely in it
         if (confirmed) fill_compressed(cbuf.size() - (cbuf.size() >> 3));
+        const double tr1 = now_s();
+        t_read += tr1 - tr0;
         while (ms.size() < BATCH) {
             if (c_hi - c_lo - scan < 18) {
                 if (scan == 0 && c_hi - c_lo > 0 && in_eof) bad = true; // trailing garbage / truncated header
@@ -675,6 +689,10 @@ struct BgzfSource : ByteSource {
             scan += tot;
         }
         if (ms.empty()) return false;
+        const double tr2 = now_s();
+        t_scan += tr2 - tr1;
+        n_batches++;
+        n_members += ms.size();
         std::atomic<bool> ok{true};
         const unsigned nt = (unsigned)std::min<size_t>(n_thr, ms.size());
         static const bool zl = use_zlib_inflate();
@@ -709,6 +727,7 @@ struct BgzfSource : ByteSource {
         for (unsigned t = 1; t < nt; ++t) th.emplace_back(job, t);
         job(0);
         for (auto &x : th) x.join();
+        t_inflate += now_s() - tr2;
         if (!ok) { bad = true; return false; }
         c_lo += scan;
         *produced = out_total;
