@@ -88,39 +88,40 @@ static uint32_t guess_filter_threshold(const std::vector<KC> &sketch, double fil
 }
 
 // filtering.rs:413-432
+// (in place: a 2 M-record oversketch is filtered without a second copy of it)
 template <class KC>
-static std::vector<KC> filter_strands(const std::vector<KC> &sketch, double ratio_cutoff) {
-    std::vector<KC> filtered;
-    filtered.reserve(sketch.size());
-    for (const auto &kmer : sketch) {
-        if (kmer.count < 16) {
-            filtered.push_back(kmer);
-            continue;
-        }
-        // (extra_count <= count for everything a sketcher emits and everything the C ABI lets in)
-        const uint32_t lowest = std::min(kmer.extra_count, kmer.count - std::min(kmer.extra_count, kmer.count));
-        if (((double)lowest / (double)kmer.count) >= ratio_cutoff) filtered.push_back(kmer);
-    }
-    return filtered;
+static void filter_strands(std::vector<KC> &sketch, double ratio_cutoff) {
+    sketch.erase(std::remove_if(sketch.begin(), sketch.end(),
+                                [&](const KC &kmer) {
+                                    if (kmer.count < 16) return false;
+                                    // (extra_count <= count for everything a sketcher emits and everything the C ABI lets in)
+                                    const uint32_t lowest = std::min(kmer.extra_count, kmer.count - std::min(kmer.extra_count, kmer.count));
+                                    return !(((double)lowest / (double)kmer.count) >= ratio_cutoff);
+                                }),
+                 sketch.end());
 }
 
 // filtering.rs:329-343
+// `keep_at_most`: the caller truncates to this many records afterwards (process_post_filter on a Mash sketch): records are
+// ascending and the test is per record, so nothing behind that many survivors needs to be looked at
 template <class KC>
-static std::vector<KC> filter_abundance(const std::vector<KC> &sketch, bool has_lo, uint32_t lo, bool has_hi, uint32_t hi) {
+static void filter_abundance(std::vector<KC> &sketch, bool has_lo, uint32_t lo, bool has_hi, uint32_t hi, size_t keep_at_most = SIZE_MAX) {
     const uint32_t lo_t = has_lo ? lo : 0u, hi_t = has_hi ? hi : UINT32_MAX;
-    std::vector<KC> filtered;
-    filtered.reserve(sketch.size());
-    for (const auto &kmer : sketch)
-        if (lo_t <= kmer.count && kmer.count <= hi_t) filtered.push_back(kmer);
-    return filtered;
+    size_t m = 0;
+    for (size_t i = 0; i < sketch.size() && m < keep_at_most; ++i)
+        if (lo_t <= sketch[i].count && sketch[i].count <= hi_t) {
+            if (m != i) sketch[m] = std::move(sketch[i]);
+            ++m;
+        }
+    sketch.resize(m);
 }
 
 // FilterParams::filter_counts (filtering.rs:60-87); updates `fp` like the reference updates self
 template <class KC>
-static std::vector<KC> filter_counts(finch_filter_params &fp, std::vector<KC> hashes) { // (by value: callers that are done with it move it in)
+static std::vector<KC> filter_counts(finch_filter_params &fp, std::vector<KC> hashes, size_t keep_at_most = SIZE_MAX) { // (by value: callers that are done with it move it in)
     const bool filter_on = fp.filter_on == 1;
     std::vector<KC> filtered = std::move(hashes);
-    if (filter_on && fp.strand_filter > 0.0) filtered = filter_strands(filtered, fp.strand_filter);
+    if (filter_on && fp.strand_filter > 0.0) filter_strands(filtered, fp.strand_filter);
     if (filter_on && fp.err_filter > 0.0) {
         const uint32_t cutoff = guess_filter_threshold(filtered, fp.err_filter);
         if (fp.has_abun_lo) {
@@ -131,7 +132,7 @@ static std::vector<KC> filter_counts(finch_filter_params &fp, std::vector<KC> ha
         }
     }
     if (filter_on && (fp.has_abun_lo || fp.has_abun_hi))
-        filtered = filter_abundance(filtered, fp.has_abun_lo, fp.abun_lo, fp.has_abun_hi, fp.abun_hi);
+        filter_abundance(filtered, fp.has_abun_lo, fp.abun_lo, fp.has_abun_hi, fp.abun_hi, keep_at_most);
     return filtered;
 }
 
@@ -1337,14 +1338,19 @@ static int finish_sketch(fh_sketcher *h, const std::string &name, const finch_sk
     if (n > UINT32_MAX) return hfail(FH_ERR_UNSUPPORTED, "sketch of %llu hashes", (unsigned long long)n);
     // (arrays the library fills completely: allocated without zeroing -- 2 M hashes are 100 MB here)
     std::unique_ptr<fh_kmer_count[]> recs(new fh_kmer_count[n ? n : 1]);
-    std::unique_ptr<uint8_t[]> km(new uint8_t[n * (size_t)k + 1]);
-    if (int rc = fh_copy_out_records(h, recs.get(), km.get(), nullptr)) return hfail(rc, "%s", fh_last_error());
-    std::vector<KmerRef> hashes;
-    hashes.reserve(n);
-    for (uint64_t i = 0; i < n; ++i) hashes.push_back(KmerRef{recs[i].hash, recs[i].count, recs[i].extra_count, (uint32_t)i});
+    if (int rc = fh_copy_out_records(h, recs.get(), nullptr, nullptr)) return hfail(rc, "%s", fh_last_error());
+    std::vector<KmerRef> hashes(n);
+    for (uint64_t i = 0; i < n; ++i) hashes[i] = KmerRef{recs[i].hash, recs[i].count, recs[i].extra_count, (uint32_t)i};
     recs.reset();
-    std::vector<KmerRef> filtered = filter_counts(fp, std::move(hashes)); // lib.rs:82
-    if (int rc = process_post_filter(sp, filtered, name)) return rc;      // lib.rs:83
+    // (a Mash sketch is cut to final_size right after the filters: the abundance pass may stop there)
+    const size_t keep = sp.kind == 0 ? (size_t)sp.final_size : SIZE_MAX;
+    std::vector<KmerRef> filtered = filter_counts(fp, std::move(hashes), keep); // lib.rs:82
+    if (int rc = process_post_filter(sp, filtered, name)) return rc;            // lib.rs:83
+    // the k-mer bytes of what is left (10 000 of a 2 M-hash oversketch)
+    std::vector<uint32_t> rows(filtered.size());
+    for (size_t i = 0; i < filtered.size(); ++i) rows[i] = filtered[i].row;
+    std::unique_ptr<uint8_t[]> km(new uint8_t[filtered.size() * (size_t)k + 1]);
+    if (int rc = fh_copy_out_kmers(h, rows.data(), rows.size(), km.get())) return hfail(rc, "%s", fh_last_error());
     out.name = name;
     out.seq_length = st.total_bases;
     out.num_valid_kmers = total_kmers;
@@ -1352,7 +1358,7 @@ static int finish_sketch(fh_sketcher *h, const std::string &name, const finch_sk
     out.hashes.resize(filtered.size());
     for (size_t i = 0; i < filtered.size(); ++i) {
         const KmerRef &r = filtered[i];
-        out.hashes[i] = KmerCount{r.hash, std::string((const char *)km.get() + (size_t)r.row * k, k), r.count, r.extra_count};
+        out.hashes[i] = KmerCount{r.hash, std::string((const char *)km.get() + i * (size_t)k, k), r.count, r.extra_count};
     }
     out.filter_params = fp;
     out.sketch_params = sp;

@@ -159,6 +159,10 @@ typedef struct fh_kmer_count {
 } fh_kmer_count;
 int fh_copy_out_records(fh_sketcher *s, fh_kmer_count *records, uint8_t *kmers, uint64_t *first_pos);
 
+/* The k-mer bytes of selected records only (rows = indices into the ascending sketch): a caller that filters a 2 M-hash
+ * oversketch down to 10 000 hashes (filter_counts + truncate, lib.rs:82-83) needs the bytes of the survivors, not of all. */
+int fh_copy_out_kmers(fh_sketcher *s, const uint32_t *rows, uint64_t n_rows, uint8_t *kmers);
+
 /* Host-side merge of partial sketches (multi-GPU read-block sharding): union, counts
  * summed (saturating), k-mer of the smallest first_pos, re-select per kind.  Both must be finished.
  * After the call dst holds the merged sketch (fh_copy_out works on it); dst's total_kmers += src's. */
