@@ -22,6 +22,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <future>
 #include <thread>
 #include <vector>
 
@@ -569,10 +570,25 @@ static bool use_zlib_inflate() {
 // threads at once -- what a single zlib stream cannot offer (plain gzip stays at inflate speed, ~0.3 Gbases/s).
 // Every member's CRC-32 and length are checked as zlib's gzip wrapper would; a member without the subfield hands the
 // rest of the input to the sequential GzSource.
+// A byte buffer whose pages are not touched until they are used (a std::vector would zero all of it first).
+struct RawBuf {
+    uint8_t *p = nullptr;
+    size_t n = 0;
+    explicit RawBuf(size_t bytes) : p((uint8_t *)malloc(bytes)), n(bytes) {
+        if (!p) throw std::bad_alloc();
+    }
+    ~RawBuf() { free(p); }
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    uint8_t *data() const { return p; }
+    size_t size() const { return n; }
+    void swap(RawBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
+};
+
 struct BgzfSource : ByteSource {
     std::unique_ptr<ByteSource> inner;
     unsigned n_thr;
-    std::vector<uint8_t> cbuf; // compressed bytes [c_lo, c_hi) not yet consumed
+    RawBuf cbuf; // compressed bytes [c_lo, c_hi) not yet consumed
     size_t c_lo = 0, c_hi = 0;
     std::vector<uint8_t> obuf; // inflated bytes [o_lo, o_hi) not yet delivered
     size_t o_lo = 0, o_hi = 0;
@@ -586,10 +602,46 @@ struct BgzfSource : ByteSource {
     // (once the sequential reader has taken over it owns the input: no way back from there)
     bool can_rewind() const override { return !tail && inner && inner->can_rewind(); }
     bool rewind() override {
-        if (!can_rewind() || !inner->rewind()) return false;
+        if (!can_rewind()) return false;
+        join_prefetch();
+        if (!inner->rewind()) return false;
         c_lo = c_hi = o_lo = o_hi = 0;
+        last_scan = 0;
         in_eof = bad = false;
         return true;
+    }
+
+    // The compressed bytes of the NEXT batch are read by a helper thread while this batch inflates: it appends behind
+    // c_hi (the inflate threads only read below it), and refill() collects it before it looks at the buffer again.
+    struct Prefetched { size_t got; bool eof; };
+    std::future<Prefetched> pending;
+    size_t last_scan = 0; // compressed bytes the previous batch took
+    void join_prefetch() {
+        if (!pending.valid()) return;
+        const Prefetched r = pending.get();
+        c_hi += r.got;
+        if (r.eof) in_eof = true;
+    }
+    size_t batch_target() const { // compressed bytes worth having ahead: two batches at the ratio seen so far
+        return std::min(cbuf.size() / 2, std::max<size_t>(2 * last_scan, (size_t)8 << 20));
+    }
+    void start_prefetch(size_t scan) {
+        if (in_eof || n_thr < 2) return;
+        const size_t ahead = c_hi - c_lo - scan, target = batch_target();
+        if (ahead >= target) return;
+        const size_t want = std::min(cbuf.size() - c_hi, target - ahead);
+        if (want < ((size_t)1 << 20)) return; // no room behind c_hi: the next refill compacts and reads in line
+        uint8_t *p = cbuf.data() + c_hi;
+        ByteSource *src = inner.get();
+        pending = std::async(std::launch::async, [p, want, src]() {
+            Prefetched r{0, false};
+            while (r.got < want) {
+                const size_t g = src->read(p + r.got, want - r.got);
+                if (g == 0) { r.eof = true; break; }
+                r.got += g;
+            }
+            return r;
+        });
     }
 
     // total size of the BGZF member starting at p (0 = not a BGZF member); needs 18 readable bytes
@@ -602,13 +654,15 @@ struct BgzfSource : ByteSource {
     }
     bool fill_compressed(size_t need) { // make [c_lo, c_hi) hold at least `need` bytes if the input has them
         if (c_hi - c_lo >= need) return true;
-        if (c_lo && (cbuf.size() - c_lo < need || c_hi == c_lo)) {
+        // (move the rest down as soon as that costs less than what has been consumed: the buffer is sized for the
+        // worst case and most of it should never be touched)
+        if (c_lo && (cbuf.size() - c_lo < need || c_hi - c_lo <= c_lo)) {
             memmove(cbuf.data(), cbuf.data() + c_lo, c_hi - c_lo);
             c_hi -= c_lo;
             c_lo = 0;
         }
         while (!in_eof && c_hi - c_lo < need) {
-            const size_t got = inner->read(cbuf.data() + c_hi, cbuf.size() - c_hi);
+            const size_t got = inner->read(cbuf.data() + c_hi, std::min(cbuf.size() - c_hi, need - (c_hi - c_lo)));
             if (got == 0) in_eof = true;
             c_hi += got;
         }
@@ -622,6 +676,7 @@ struct BgzfSource : ByteSource {
     uint64_t n_batches = 0, n_members = 0;
     static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     ~BgzfSource() override {
+        if (pending.valid()) pending.wait();
         static const bool trace = getenv("FH_TRACE") != nullptr;
         if (trace && n_batches)
             fprintf(stderr, "[finch] bgzf: %llu batches, %llu members, %u threads: read %.1f ms, scan %.1f ms, inflate %.1f ms\n",
@@ -630,6 +685,7 @@ struct BgzfSource : ByteSource {
     bool refill(uint8_t *out, size_t out_cap, size_t *produced) {
         *produced = 0;
         const double tr0 = now_s();
+        join_prefetch();
         std::vector<Member> ms;
         size_t out_total = 0, scan = 0; // scan: offset from c_lo of the next member header
         // (a plain gzip file also lands here when several threads are available: look at its first header before
@@ -638,7 +694,7 @@ struct BgzfSource : ByteSource {
             uint32_t hdr = 0;
             if (member_size(cbuf.data() + c_lo, &hdr)) {
                 confirmed = true;
-                std::vector<uint8_t> big(BATCH * 65536 + 65536);
+                RawBuf big(2 * (BATCH * 65536 + 65536)); // a worst-case batch, and the next one behind it
                 memcpy(big.data(), cbuf.data() + c_lo, c_hi - c_lo);
                 c_hi -= c_lo;
                 c_lo = 0;
@@ -646,7 +702,7 @@ struct BgzfSource : ByteSource {
             }
         }
         // top the buffer up once, then take the members that are completely in it
-        if (confirmed) fill_compressed(cbuf.size() - (cbuf.size() >> 3));
+        if (confirmed) fill_compressed(batch_target());
         const double tr1 = now_s();
         t_read += tr1 - tr0;
         while (ms.size() < BATCH) {
@@ -694,6 +750,8 @@ struct BgzfSource : ByteSource {
         t_scan += tr2 - tr1;
         n_batches++;
         n_members += ms.size();
+        last_scan = scan;
+        start_prefetch(scan);
         std::atomic<bool> ok{true};
         const unsigned nt = (unsigned)std::min<size_t>(n_thr, ms.size());
         static const bool zl = use_zlib_inflate();
