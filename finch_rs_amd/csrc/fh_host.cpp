@@ -557,6 +557,13 @@ struct FastGzSource : ByteSource {
     }
 };
 
+// Threads one input may use for large reads and BGZF members: FINCH_READ_THREADS, else a sixteenth of the machine's
+// hardware threads (a GPU node has ~32 cores per GPU and other ranks beside this one), between 8 and 16.
+static unsigned read_threads_total(const char *env) {
+    if (env) return (unsigned)std::min(64, std::max(1, atoi(env)));
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::min(16u, std::max(8u, hw / 16u));
+}
 static bool use_zlib_inflate() {
     static const bool v = [] {
         const char *e = getenv("FINCH_ZLIB_INFLATE");
@@ -1677,13 +1684,21 @@ static int pump_text_to_device(ByteSource &src, fh_sketcher *h, bool fastq, uint
     int prc = FH_OK;
     std::string pmsg;
     FastxStats pst;
+    // FH_TRACE: how long each side waited for the other, and what the pushes took
+    static const bool trace = getenv("FH_TRACE") != nullptr;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now_s();
+    double t_reader_waits = 0, t_pusher_waits = 0, t_push = 0;
+    unsigned n_chunks = 0;
     std::thread producer([&] {
         const int rc = shard_reader(
             src, fastq, k,
             [&] {
+                const double t0 = trace ? now_s() : 0;
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return is_free[fill] || abort.load(); });
                 is_free[fill] = false;
+                if (trace) t_reader_waits += now_s() - t0;
                 return &tb[fill];
             },
             [&](TextBuf *b) { // taken but not used
@@ -1708,6 +1723,7 @@ static int pump_text_to_device(ByteSource &src, fh_sketcher *h, bool fastq, uint
     bool first = true;
     for (;;) {
         ShardWork job;
+        const double tw0 = trace ? now_s() : 0;
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return !ready.empty() || producer_done; });
@@ -1715,8 +1731,12 @@ static int pump_text_to_device(ByteSource &src, fh_sketcher *h, bool fastq, uint
             job = ready.front();
             ready.erase(ready.begin());
         }
+        const double tw1 = trace ? now_s() : 0;
+        t_pusher_waits += tw1 - tw0;
+        n_chunks++;
         if (rc == FH_OK) {
             rc = fastq ? fh_push_fastq_text(h, job.len) : fh_push_fasta_text(h, job.len, job.start_state, first ? 0u : FH_PUSH_CONTINUE);
+            if (trace) t_push += now_s() - tw1;
             if (rc != FH_OK) {
                 msg = fh_last_error();
                 abort = true;
@@ -1728,6 +1748,9 @@ static int pump_text_to_device(ByteSource &src, fh_sketcher *h, bool fastq, uint
         cv.notify_all();
     }
     producer.join();
+    if (trace)
+        fprintf(stderr, "[finch] text pump: %u chunks of <= %.0f MiB in %.1f ms: reader waited %.1f ms for a buffer, pushes took %.1f ms and waited %.1f ms for text\n",
+                n_chunks, cap / 1048576.0, (now_s() - t_begin) * 1e3, t_reader_waits * 1e3, t_push * 1e3, t_pusher_waits * 1e3);
     if (rc != FH_OK) return hfail(rc, "%s", msg.c_str());
     if (prc != FH_OK) return hfail(prc, "%s", pmsg.c_str());
     st.total_bases = pst.total_bases;
@@ -2148,7 +2171,7 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
     }
     // threads for the large reads of plain files, shared among the workers (a batch of genomes reads with one each)
     const char *rt_env = getenv("FINCH_READ_THREADS");
-    const unsigned read_total = std::min(rt_env ? (unsigned)std::max(1, atoi(rt_env)) : 8u, 16u);
+    const unsigned read_total = read_threads_total(rt_env);
     const unsigned read_threads = std::max(1u, read_total / n_threads);
     auto worker = [&](uint32_t w) {
         HandleSet handles;
@@ -2205,7 +2228,7 @@ int finch_sketch_file_sharded(const char *filename, const finch_sketch_params *s
     FILE *f = fn == "-" ? stdin : fopen(fn.c_str(), "rb");
     if (!f) return hfail(FH_ERR_INVALID, "%s: %s (os error %d)", fn.c_str(), strerror(errno), errno);
     const char *rt_env = getenv("FINCH_READ_THREADS");
-    const unsigned read_threads = std::min(rt_env ? (unsigned)std::max(1, atoi(rt_env)) : 8u, 16u);
+    const unsigned read_threads = read_threads_total(rt_env);
     auto res = std::make_unique<finch_sketches>();
     res->v.resize(1);
     const int rc = sketch_stream_sharded(std::make_unique<FileSource>(f, f != stdin, read_threads), fn, *sp, *filters, devs, chunk_bytes,
