@@ -502,17 +502,24 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
                             body + struct.pack("<II", zlib.crc32(ch), len(ch)))
             p = F.SketchParams.mash(1000, 1000, True, 21, 0)
             out = {"what": "finch_sketch_files on one %.0f MB FASTQ (%d reads) compressed with zlib level 1: as a single gzip stream "
-                           "(one host thread inflates) and as BGZF (members inflated by the call's read threads); k=21 n=1000"
+                           "(one host thread inflates) and as BGZF (members inflated on the device, one wavefront each; bgzf_host_inflate: by the "
+                           "call's read threads instead); k=21 n=1000"
                            % (len(raw) / 1e6, ns)}
-            for key, path in (("gzip", gzp), ("bgzf", bgp)):
-                best = 1e30
-                for _ in range(3):
-                    t0 = time.perf_counter()
-                    res = H.sketch_files([path], p, H.FilterParams(False), devices=[dev])
-                    best = min(best, time.perf_counter() - t0)
-                    assert H.lib().finch_sketch_seq_length(res._p, 0) == ns * READ_LEN
+            for key, path, env in (("gzip", gzp, None), ("bgzf", bgp, None), ("bgzf_host_inflate", bgp, "0")):
+                if env is not None:
+                    os.environ["FINCH_DEVICE_INFLATE"] = env
+                try:
+                    best = 1e30
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        res = H.sketch_files([path], p, H.FilterParams(False), devices=[dev])
+                        best = min(best, time.perf_counter() - t0)
+                        assert H.lib().finch_sketch_seq_length(res._p, 0) == ns * READ_LEN
+                finally:
+                    os.environ.pop("FINCH_DEVICE_INFLATE", None)
                 out[key + "_gbases_per_s"] = round(ns * READ_LEN / best / 1e9, 3)
                 out[key + "_text_GBps"] = round(len(raw) / best / 1e9, 3)
+            out["bgzf_inflated_on_device"] = H.debug_device_inflate()[0] > 0
             return out
         finally:
             shutil.rmtree(d, ignore_errors=True)

@@ -27,7 +27,7 @@ if "FH_K2_FLAGS" in os.environ:  # A/B builds of the sketch kernel only
     K2_FLAGS = os.environ["FH_K2_FLAGS"].split()
 OUT = os.environ.get("FH_OUT", OUT)
 
-SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2_common.h", "fh_k2w.hip", "fh_k2.hip", "fh_kernels.hip", "fh_big.hip", "fh_text.hip", "fh_api.hip", "fh_host.cpp",
+SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2_common.h", "fh_k2w.hip", "fh_k2.hip", "fh_kernels.hip", "fh_big.hip", "fh_text.hip", "fh_bgzf.hip", "fh_api.hip", "fh_host.cpp",
            "fh_host_model.h", "fh_serial.cpp", os.path.join("..", "..", "include", "finch_host.h"),
            os.path.join("..", "..", "include", "finch_hip.h")]
 
@@ -66,6 +66,7 @@ def _build_locked(verbose):
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_kernels.hip", "-o", os.path.join(OBJ, "fh_kernels.o")])
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_big.hip", "-o", os.path.join(OBJ, "fh_big.o")])
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_text.hip", "-o", os.path.join(OBJ, "fh_text.o")])
+    jobs.append([HIPCC] + FLAGS + ["-c", "fh_bgzf.hip", "-o", os.path.join(OBJ, "fh_bgzf.o")])
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_api.hip", "-o", os.path.join(OBJ, "fh_api.o")])
     jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-c", "fh_host.cpp", "-o", os.path.join(OBJ, "fh_host.o")])
     jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-c", "fh_serial.cpp", "-o", os.path.join(OBJ, "fh_serial.o")])

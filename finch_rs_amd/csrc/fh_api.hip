@@ -165,6 +165,10 @@ struct fh_sketcher {
     int stage_next = 0;
     uint64_t stage_bytes = 0;
     // device-side FASTQ packing (fh_text.hip): packed output + block scan scratch per staging slot
+    uint8_t *d_comp = nullptr;            // fh_push_bgzf_fastq: the batch as it came (member table + DEFLATE bytes)
+    uint32_t *d_bz_status = nullptr, *h_bz_status = nullptr;
+    const uint8_t *bgzf_left_ptr = nullptr; // text behind the last whole record of the previous batch (in a d_stage slot)
+    uint64_t bgzf_left_len = 0;
     uint8_t *d_packed[N_STAGE] = {nullptr, nullptr};
     uint32_t *d_blk_a[N_STAGE] = {nullptr, nullptr}, *d_blk_b[N_STAGE] = {nullptr, nullptr};
     uint32_t *d_lines = nullptr; // fh_push_fastq_text: where every text line of the chunk ends (one u32 per line)
@@ -245,6 +249,7 @@ int init_state(fh_sketcher *s) {
     s->tau_lo = 0;
     s->carry_len = 0;
     s->dprev_len = 0;
+    s->bgzf_left_len = 0;
     s->halo_len = 0;
     s->live_target = s->big_mode ? std::max<uint64_t>(4 * s->p.size, 1ull << 16) : (uint64_t)SMALL_MAX;
     s->finished = false;
@@ -1003,6 +1008,7 @@ uint64_t pool_max_bytes() {
 uint64_t handle_bytes(const fh_sketcher *s) {
     uint64_t b = (uint64_t)s->cap * (sizeof(Entry) + (s->kmer_hi ? 8 : 0)) + (uint64_t)s->live_cap * 8 + (uint64_t)s->shard_cap * N_SHARDS * 4;
     for (int i = 0; i < N_STAGE; ++i) b += 2 * s->stage_cap[i];
+    if (s->d_comp) b += s->stage_bytes;
     return b + (uint64_t)s->out_cap * 32 + (uint64_t)s->big_cap * 24;
 }
 bool same_params(const fh_params &a, const fh_params &b) {
@@ -1191,6 +1197,9 @@ void destroy_handle(fh_sketcher *s) {
     }
     (void)hipFree(s->d_text_tot);
     (void)hipFree(s->d_lines);
+    (void)hipFree(s->d_comp);
+    (void)hipFree(s->d_bz_status);
+    if (s->h_bz_status) (void)hipHostFree(s->h_bz_status);
     if (s->h_text_tot) (void)hipHostFree(s->h_text_tot);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
     if (s->h_out) (void)hipHostFree(s->h_out);
@@ -1416,14 +1425,8 @@ int fh_push_staged(fh_sketcher *s, uint64_t len, uint32_t flags) {
     return FH_OK;
 }
 
-int fh_push_fastq_text(fh_sketcher *s, uint64_t len) {
-    if (!s) return fail(FH_ERR_INVALID, "null handle");
-    if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
-    if (len > s->stage_bytes) return fail(FH_ERR_INVALID, "text longer than the staging buffer");
-    if (int rc = set_device(s)) return rc;
-    if (int rc = ensure_stage(s)) return rc;
-    if (len == 0) return FH_OK;
-    const int b = s->stage_next;
+// scratch the device-side FASTQ splitter needs for slot b
+static int ensure_fastq_scratch(fh_sketcher *s, int b) {
     const uint64_t nblk = (s->stage_bytes + 4095) / 4096 + 1;
     if (!s->d_packed[b]) {
         HIP_TRY(dev_malloc((void **)&s->d_packed[b], s->stage_bytes + 64));
@@ -1438,12 +1441,12 @@ int fh_push_fastq_text(fh_sketcher *s, uint64_t len) {
         s->line_cap = (uint32_t)std::min<uint64_t>(s->stage_bytes / 8 + 64, 0x7FFFFFFFull);
         HIP_TRY(dev_malloc(&s->d_lines, (size_t)s->line_cap * sizeof(uint32_t)));
     }
-    // the packed buffer of this slot may still feed a pending range
-    if (int rc = drain(s)) return rc;
+    return FH_OK;
+}
+
+// d_stage[b][0, len) holds whole 4-line FASTQ records (or is being filled on the stream): split, check, sketch
+static int fastq_text_on_device(fh_sketcher *s, int b, uint64_t len) {
     HIP_TRY(hipMemsetAsync(s->d_text_tot, 0, 4 * sizeof(uint32_t), s->stream));
-    HIP_TRY(hipMemcpyAsync(s->d_stage[b], s->h_stage[b] + STAGE_HEADROOM, len, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
-    s->stage_busy[b] = true;
     HIP_TRY(launch_fastq_pack(s->d_stage[b], len, s->d_packed[b], s->d_blk_a[b], s->d_blk_b[b], s->d_text_tot, s->ctl,
                               s->d_text_tot + 2, s->d_lines, s->line_cap, s->stream));
     HIP_TRY(hipMemcpyAsync(s->h_text_tot, s->d_text_tot, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -1458,6 +1461,84 @@ int fh_push_fastq_text(fh_sketcher *s, uint64_t len) {
     const int rc = sketch_device_range(s, s->d_packed[b], n_packed, s->stream_off);
     s->stream_off += n_packed;
     return rc;
+}
+
+int fh_push_fastq_text(fh_sketcher *s, uint64_t len) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    if (len > s->stage_bytes) return fail(FH_ERR_INVALID, "text longer than the staging buffer");
+    if (int rc = set_device(s)) return rc;
+    if (int rc = ensure_stage(s)) return rc;
+    s->bgzf_left_len = 0;
+    if (len == 0) return FH_OK;
+    const int b = s->stage_next;
+    if (int rc = ensure_fastq_scratch(s, b)) return rc;
+    // the packed buffer of this slot may still feed a pending range
+    if (int rc = drain(s)) return rc;
+    HIP_TRY(hipMemcpyAsync(s->d_stage[b], s->h_stage[b] + STAGE_HEADROOM, len, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+    s->stage_busy[b] = true;
+    return fastq_text_on_device(s, b, len);
+}
+
+static_assert(sizeof(fh_bgzf_member) == sizeof(BgzfMember) && offsetof(fh_bgzf_member, crc32) == offsetof(BgzfMember, crc),
+              "the ABI's member record is what the kernels read");
+// BGZF members of FASTQ text, inflated on the device (fh_bgzf.hip).  The caller has put, into the text buffer of
+// fh_text_buffers, `n_members` fh_bgzf_member records followed by the members' DEFLATE bytes (`bytes` in all; in_off
+// counts from the start of the buffer).  The text of a batch rarely ends with a record: what follows its last whole
+// record stays on the device and leads the text of the next push; FH_BGZF_LAST says there is no next push.
+int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint32_t flags) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    if (bytes > s->stage_bytes) return fail(FH_ERR_INVALID, "batch longer than the staging buffer");
+    if ((uint64_t)n_members * sizeof(fh_bgzf_member) > bytes) return fail(FH_ERR_INVALID, "member table longer than the batch");
+    if (int rc = set_device(s)) return rc;
+    if (int rc = ensure_stage(s)) return rc;
+    const int b = s->stage_next;
+    const fh_bgzf_member *mt = (const fh_bgzf_member *)(s->h_stage[b] + STAGE_HEADROOM);
+    uint64_t text = 0;
+    for (uint32_t i = 0; i < n_members; ++i) {
+        const fh_bgzf_member &m = mt[i];
+        if (m.in_off < (uint64_t)n_members * sizeof(fh_bgzf_member) || (uint64_t)m.in_off + m.in_len > bytes || m.isize > 65536u ||
+            m.out_off != text)
+            return fail(FH_ERR_INVALID, "BGZF member %u: bad table entry", i);
+        text += m.isize;
+    }
+    const uint64_t left = s->bgzf_left_len, total = left + text;
+    if (total > s->stage_bytes || total >= (1ull << 31))
+        return fail(FH_ERR_INVALID, "a FASTQ record and a batch of BGZF text do not fit the staging buffer together");
+    if (int rc = ensure_fastq_scratch(s, b)) return rc;
+    if (!s->d_comp) {
+        HIP_TRY(dev_malloc((void **)&s->d_comp, s->stage_bytes + 4096));
+        HIP_TRY(dev_malloc((void **)&s->d_bz_status, 4 * sizeof(uint32_t)));
+        HIP_TRY(host_malloc((void **)&s->h_bz_status, 4 * sizeof(uint32_t)));
+    }
+    if (int rc = drain(s)) return rc;
+    if (left) HIP_TRY(hipMemcpyAsync(s->d_stage[b], s->bgzf_left_ptr, left, hipMemcpyDeviceToDevice, s->stream));
+    s->bgzf_left_len = 0;
+    if (total == 0) return FH_OK;
+    HIP_TRY(hipMemsetAsync(s->d_bz_status, 0, 4 * sizeof(uint32_t), s->stream));
+    if (bytes) HIP_TRY(hipMemcpyAsync(s->d_comp, s->h_stage[b] + STAGE_HEADROOM, bytes, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+    s->stage_busy[b] = true;
+    HIP_TRY(launch_bgzf_inflate(s->d_comp, (const BgzfMember *)s->d_comp, n_members, s->d_stage[b] + left, s->d_bz_status, s->stream));
+    HIP_TRY(launch_fastq_cut(s->d_stage[b], (uint32_t)total, (flags & FH_BGZF_LAST) ? 1u : 0u, s->d_bz_status + 1, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_bz_status, s->d_bz_status, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (const uint32_t st = s->h_bz_status[0]) {
+        static const char *const why[] = {"", "bad block header", "invalid code", "distance too far back", "size differs from ISIZE",
+                                          "stream longer or shorter than the member", "CRC-32 differs"};
+        return fail(FH_ERR_INVALID, "BGZF member %u of the batch: %s", st >> 8, (st & 255u) < 7u ? why[st & 255u] : "corrupt");
+    }
+    if (s->h_bz_status[2]) return fail(FH_ERR_INVALID, "no FASTQ record boundary at the end of a batch of BGZF text");
+    const uint64_t cut = s->h_bz_status[1];
+    s->bgzf_left_ptr = s->d_stage[b] + cut;
+    s->bgzf_left_len = total - cut;
+    if (cut == 0) { // one record longer than the batch so far: keep collecting (the text moves on to the next slot)
+        s->stage_next = (b + 1) % N_STAGE;
+        return FH_OK;
+    }
+    return fastq_text_on_device(s, b, cut);
 }
 
 // Device-side FASTA: the staged chunk is raw file text (header lines, wrapped sequence lines); which bytes are

@@ -1,0 +1,578 @@
+// fh_bgzf.hip -- BGZF members inflated on the device (gfx950).
+//
+// needletail hands finch decompressed text whatever the file holds (lib.rs:60), and sequencing reads mostly arrive
+// compressed.  A BGZF file (bgzip, every BAM toolchain) is a chain of independent gzip members of at most 64 KiB of text,
+// each carrying its compressed size in the header, so the members of a batch can be inflated side by side: on the host
+// that is what the read threads of fh_host.cpp do (16 of them reach ~12 GB/s of text); here one wavefront takes one
+// member, the compressed bytes cross PCIe instead of the text (4-5x fewer), and the text is born where the FASTQ
+// splitter (fh_text.hip) reads it.
+//
+//   k_bgzf_inflate   one 64-lane workgroup per member.  DEFLATE's symbol stream is serial, so the decode itself is written
+//                    wave-uniform: bit buffer, table lookups and the symbol dispatch live in scalar registers, the lanes
+//                    serve as (a) the input window -- lane i holds word i of the current 256 bytes, one v_readlane per
+//                    32 bits consumed, the next 256 bytes already in flight --, (b) the builders of the Huffman tables
+//                    (canonical codes assigned with ballots, replicated entries filled in parallel) and (c) the LZ77
+//                    copier: decoded symbols are queued one per lane and resolved 64 at a time, every lane
+//                    copying its own match; a match whose source lies inside the group waits for the round in which
+//                    everything before it has been written.
+//   k_bgzf_crc       CRC-32 of every member's text against its trailer: 64 slices per member hashed with slicing-by-4
+//                    tables in LDS, joined with the x^n mod P operators of zlib's crc32_combine.
+//   k_fastq_cut      where the last whole FASTQ record of the inflated text ends (the rest waits for the next batch).
+//
+// Damage stays loud: any code zlib would reject, a size or checksum that differs from the member's trailer, or a read
+// past the member's bytes sets the status word and the push fails (fh_api.hip), after which the host layer reads the
+// file again through its own inflate.
+#include <hip/hip_runtime.h>
+
+#include "fh_core.h"
+#include "fh_kernels.h"
+
+namespace fh {
+
+namespace {
+
+constexpr int LIT_BITS = 10, DIST_BITS = 9, CL_BITS = 7;
+constexpr u32 KIND_LIT = 0, KIND_BASE = 1, KIND_EOB = 2, KIND_LONG = 3;
+
+// table entry: bits 0-3 code length (0 = no such code), 4-7 extra bits, 8-9 kind, 16-31 literal / base value / symbol
+__device__ __forceinline__ u32 make_entry(u32 nbits, u32 extra, u32 kind, u32 value) {
+    return nbits | (extra << 4) | (kind << 8) | (value << 16);
+}
+__device__ __forceinline__ u32 litlen_entry(u32 sym, u32 nbits) {
+    if (sym < 256u) return make_entry(nbits, 0, KIND_LIT, sym);
+    if (sym == 256u) return make_entry(nbits, 0, KIND_EOB, 0);
+    const u32 i = sym - 257u;
+    if (i >= 29u) return 0u; // 286, 287: in the fixed code's space, never valid
+    if (i < 8u) return make_entry(nbits, 0, KIND_BASE, 3u + i);
+    if (i == 28u) return make_entry(nbits, 0, KIND_BASE, 258u);
+    const u32 extra = (i - 4u) >> 2;
+    return make_entry(nbits, extra, KIND_BASE, 3u + ((4u + (i & 3u)) << extra));
+}
+__device__ __forceinline__ u32 dist_entry(u32 sym, u32 nbits) {
+    if (sym >= 30u) return 0u;
+    if (sym < 4u) return make_entry(nbits, 0, KIND_BASE, 1u + sym);
+    const u32 extra = (sym - 2u) >> 1;
+    return make_entry(nbits, extra, KIND_BASE, 1u + ((2u + (sym & 1u)) << extra));
+}
+__device__ __forceinline__ u32 symbol_entry(int which, u32 sym, u32 nbits) {
+    return which == 0 ? litlen_entry(sym, nbits) : which == 1 ? dist_entry(sym, nbits) : make_entry(nbits, 0, KIND_LIT, sym);
+}
+
+struct CodeSet { // the canonical code itself, for the codes longer than the table's index
+    u32 count[16], first[16], offs[16];
+    uint16_t sorted[288];
+};
+struct Lds {
+    u32 lit[1 << LIT_BITS];
+    u32 dist[1 << DIST_BITS]; // (its first 128 entries hold the code-length code while a dynamic header is read)
+    CodeSet cs[2];
+    uint8_t lens[320];
+    uint8_t cl_lens[32];
+};
+
+__device__ __forceinline__ u32 rfl(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Huffman table of the n code lengths at `lens`: root table of 2^R entries (codes longer than R bits: KIND_LONG, decoded
+// from `cs`).  false: over-subscribed lengths.
+__device__ bool build_table(const uint8_t *lens, u32 n, int R, u32 *table, CodeSet &cs, int which, u32 lane) {
+    if (lane < 16u) cs.count[lane] = 0u;
+    for (u32 i = lane; i < (1u << R); i += 64u) table[i] = 0u;
+    __syncthreads();
+    for (u32 s = lane; s < n; s += 64u) {
+        const u32 l = lens[s];
+        if (l) atomicAdd(&cs.count[l], 1u);
+    }
+    __syncthreads();
+    bool ok = true;
+    {
+        u32 code = 0, off = 0;
+        int left = 1;
+        for (u32 b = 1; b <= 15u; ++b) {
+            const u32 c = cs.count[b];
+            if (lane == 0) {
+                cs.first[b] = code;
+                cs.offs[b] = off;
+            }
+            code = (code + c) << 1;
+            off += c;
+            left = left * 2 - (int)c;
+            if (left < 0) ok = false;
+        }
+    }
+    __syncthreads();
+    if (!ok) return false;
+    u32 runv = 0; // lane b: symbols of length b seen so far
+    for (u32 base = 0; base < n; base += 64u) {
+        const u32 s = base + lane;
+        const u32 l = s < n ? lens[s] : 0u;
+        u32 rank = 0;
+        for (u32 b = 1; b <= 15u; ++b) {
+            const unsigned long long m = __ballot(l == b);
+            if (m == 0ull) continue;
+            const u32 run = (u32)__builtin_amdgcn_readlane((int)runv, (int)b);
+            if (l == b) rank = run + (u32)__popcll(m & ((1ull << lane) - 1ull));
+            if (lane == b) runv += (u32)__popcll(m);
+        }
+        if (l) {
+            const u32 code = cs.first[l] + rank;
+            cs.sorted[cs.offs[l] + rank] = (uint16_t)s;
+            const u32 rev = __brev(code) >> (32u - l); // the order the bits arrive in
+            if (l <= (u32)R) {
+                const u32 e = symbol_entry(which, s, l);
+                for (u32 i = rev; i < (1u << R); i += (1u << l)) table[i] = e;
+            } else {
+                table[rev & ((1u << R) - 1u)] = make_entry((u32)R, 0, KIND_LONG, 0);
+            }
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
+// a code longer than the table's index, bit by bit from the canonical description (v: the next bits, first bit lowest)
+__device__ u32 decode_long(const CodeSet &cs, int R, int which, u32 v) {
+    u32 code = __brev(v & ((1u << R) - 1u)) >> (32 - R);
+    for (u32 l = (u32)R + 1u; l <= 15u; ++l) {
+        code = (code << 1) | ((v >> (l - 1u)) & 1u);
+        const u32 idx = code - cs.first[l];
+        if (idx < cs.count[l]) return symbol_entry(which, cs.sorted[cs.offs[l] + idx], l);
+    }
+    return 0u;
+}
+
+// The compressed bytes of one member as a bit stream.  All of it wave-uniform except win / nxt (lane i: word i of the
+// current / the next 256 bytes).
+struct Reader {
+    const u32 *words;
+    u32 n_words; // words that may be read (the member's bytes, rounded out): beyond them the stream reads as zeros
+    u32 win, nxt, widx;
+    u64 bb, base_bits; // base_bits: bits of the member consumed before `words` was (re)positioned
+    u32 bc, skip0;
+};
+__device__ __forceinline__ u32 rd_load(const Reader &r, u32 w) { return w < r.n_words ? r.words[w] : 0u; }
+__device__ void rd_init(Reader &r, const uint8_t *comp, u64 byte_off, u64 byte_end, u64 base_bits, u32 lane) {
+    const u64 a = byte_off & ~3ull;
+    r.base_bits = base_bits;
+    r.words = (const u32 *)(comp + a);
+    r.n_words = (u32)((byte_end - a + 3ull) >> 2);
+    r.win = rd_load(r, lane);
+    r.nxt = rd_load(r, 64u + lane);
+    r.skip0 = (u32)(byte_off & 3ull) * 8u;
+    const u32 w0 = (u32)__builtin_amdgcn_readlane((int)r.win, 0);
+    r.widx = 1;
+    r.bb = (u64)(w0 >> r.skip0);
+    r.bc = 32u - r.skip0;
+}
+__device__ __forceinline__ void rd_fill(Reader &r, u32 lane) { // at least 32 bits in bb
+    if (r.bc < 32u) {
+        const u32 w = (u32)__builtin_amdgcn_readlane((int)r.win, (int)(r.widx & 63u));
+        r.widx++;
+        if ((r.widx & 63u) == 0u) {
+            r.win = r.nxt;
+            r.nxt = rd_load(r, r.widx + 64u + lane);
+        }
+        r.bb |= (u64)w << r.bc;
+        r.bc += 32u;
+    }
+}
+__device__ __forceinline__ u32 rd_take(Reader &r, u32 n) {
+    const u32 v = (u32)r.bb & ((1u << n) - 1u);
+    r.bb >>= n;
+    r.bc -= n;
+    return v;
+}
+__device__ __forceinline__ u64 rd_used_bits(const Reader &r) { return r.base_bits + (u64)r.widx * 32u - r.bc - r.skip0; }
+
+// One match: `len` bytes from `dist` bytes back.  Nothing else writes either range while this runs.
+__device__ __forceinline__ void copy_match(uint8_t *d, const uint8_t *s, u32 len, u32 dist) {
+    if (dist >= len) { // apart: loads first, stores after, 16 bytes at a time
+        u32 j = 0;
+        for (; j + 16u <= len; j += 16u) {
+            u64 a, b;
+            __builtin_memcpy(&a, s + j, 8);
+            __builtin_memcpy(&b, s + j + 8u, 8);
+            __builtin_memcpy(d + j, &a, 8);
+            __builtin_memcpy(d + j + 8u, &b, 8);
+        }
+        if (j + 8u <= len) {
+            u64 a;
+            __builtin_memcpy(&a, s + j, 8);
+            __builtin_memcpy(d + j, &a, 8);
+            j += 8u;
+        }
+        for (; j < len; ++j) d[j] = s[j];
+    } else if (dist >= 8u) { // overlapping, period >= 8: a word never reads bytes of its own store
+        u32 j = 0;
+        for (; j + 8u <= len; j += 8u) {
+            u64 a;
+            __builtin_memcpy(&a, s + j, 8);
+            __builtin_memcpy(d + j, &a, 8);
+        }
+        for (; j < len; ++j) d[j] = s[j];
+    } else { // a run of period < 8: the pattern is read once and replayed from registers
+        u64 pat = 0;
+        for (u32 q = 0; q < dist; ++q) pat |= (u64)s[q] << (8u * q);
+        u32 ph = 0;
+        for (u32 j = 0; j < len; ++j) {
+            d[j] = (uint8_t)(pat >> (8u * ph));
+            ph = ph + 1u == dist ? 0u : ph + 1u;
+        }
+    }
+}
+
+// The queued symbols of one group, one per lane, written out.  pos / info: the lane's token (info: low 9 bits match
+// length, 0 = literal; high half the distance or the literal byte).  A lane copies when everything its match reads
+// has been written: sources below `W`, the output position of the first token not yet written.
+__device__ void resolve_group(uint8_t *out, u32 tpos, u32 tinfo, u32 ntok, u32 lane) {
+    const u32 len = tinfo & 0x1FFu, hi = tinfo >> 16;
+    bool done = lane >= ntok;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // earlier groups' bytes
+    for (;;) {
+        const unsigned long long pending = __ballot(!done);
+        if (pending == 0ull) break;
+        const u32 W = (u32)__builtin_amdgcn_readlane((int)tpos, (int)__builtin_ctzll(pending));
+        if (!done) {
+            if (len == 0u) {
+                out[tpos] = (uint8_t)hi;
+                done = true;
+            } else {
+                const u32 src = tpos - hi;
+                const u32 src_end = src + (len < hi ? len : hi); // (an overlapping match re-reads its own bytes)
+                if (src_end <= W) {
+                    copy_match(out + tpos, out + src, len, hi);
+                    done = true;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+}
+
+} // namespace
+
+// status[0]: 0, or (member index << 8 | reason) of a failed member (the largest such word wins)
+enum BgzfFail : u32 {
+    BZ_BAD_BLOCK = 1,  // block type 3, stored length check, code lengths that over-subscribe or repeat from nothing
+    BZ_BAD_CODE = 2,   // a bit pattern no code of the block's tables has, or an undefined symbol
+    BZ_BAD_MATCH = 3,  // distance reaches before the member's first byte
+    BZ_BAD_SIZE = 4,   // the text is not `isize` bytes long
+    BZ_OVERRUN = 5,    // the stream goes on past the member's last byte, or stops short of it
+    BZ_BAD_CRC = 6,
+};
+
+__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const BgzfMember *members, u32 n_members,
+                                                     uint8_t *text, u32 *status) {
+    __shared__ Lds L;
+    const u32 mi = blockIdx.x, lane = threadIdx.x;
+    if (mi >= n_members) return;
+    const BgzfMember m = members[mi];
+    uint8_t *out = text + m.out_off;
+    const u32 isize = m.isize;
+    Reader r;
+    rd_init(r, comp, m.in_off, (u64)m.in_off + m.in_len, 0, lane);
+    u32 fail = 0, pos = 0, ntok = 0, tpos = 0, tinfo = 0;
+    bool final_block = false;
+    const u64 in_bits = (u64)m.in_len * 8u;
+    while (!final_block && !fail) {
+        if (rd_used_bits(r) > in_bits) {
+            fail = BZ_OVERRUN;
+            break;
+        }
+        rd_fill(r, lane);
+        final_block = rd_take(r, 1) != 0u;
+        const u32 type = rd_take(r, 2);
+        if (type == 3u) {
+            fail = BZ_BAD_BLOCK;
+            break;
+        }
+        if (type == 0u) { // stored: LEN, ~LEN, then the bytes themselves
+            rd_take(r, r.bc & 7u);
+            rd_fill(r, lane);
+            const u32 len = rd_take(r, 16), nlen = rd_take(r, 16);
+            const u64 used = rd_used_bits(r) >> 3;
+            if ((len ^ 0xFFFFu) != nlen || used + len > m.in_len || pos + len > isize) {
+                fail = BZ_BAD_BLOCK;
+                break;
+            }
+            resolve_group(out, tpos, tinfo, ntok, lane);
+            ntok = 0;
+            const uint8_t *src = comp + m.in_off + used;
+            for (u32 j = lane; j < len; j += 64u) out[pos + j] = src[j];
+            pos += len;
+            rd_init(r, comp, (u64)m.in_off + used + len, (u64)m.in_off + m.in_len, (used + len) * 8u, lane);
+            continue;
+        }
+        u32 hlit = 288, hdist = 32;
+        if (type == 1u) { // the fixed code
+            for (u32 s = lane; s < 288u; s += 64u) L.lens[s] = s < 144u ? 8 : s < 256u ? 9 : s < 280u ? 7 : 8;
+            if (lane < 32u) L.lens[288u + lane] = 5;
+        } else {
+            hlit = rd_take(r, 5) + 257u;
+            hdist = rd_take(r, 5) + 1u;
+            const u32 hclen = rd_take(r, 4) + 4u;
+            if (lane < 32u) L.cl_lens[lane] = 0;
+            __syncthreads();
+            // the order the code-length code's own lengths come in: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+            const u64 ord_lo = 16ull | (17ull << 5) | (18ull << 10) | (0ull << 15) | (8ull << 20) | (7ull << 25) | (9ull << 30) |
+                               (6ull << 35) | (10ull << 40) | (5ull << 45) | (11ull << 50) | (4ull << 55);
+            const u64 ord_hi = 12ull | (3ull << 5) | (13ull << 10) | (2ull << 15) | (14ull << 20) | (1ull << 25) | (15ull << 30);
+            for (u32 i = 0; i < hclen; ++i) {
+                rd_fill(r, lane);
+                const u32 v = rd_take(r, 3);
+                const u32 sym = (u32)((i < 12u ? ord_lo >> (5u * i) : ord_hi >> (5u * (i - 12u))) & 31ull);
+                if (lane == 0) L.cl_lens[sym] = (uint8_t)v;
+            }
+            __syncthreads();
+            if (!build_table(L.cl_lens, 19, CL_BITS, L.dist, L.cs[1], 2, lane)) {
+                fail = BZ_BAD_BLOCK;
+                break;
+            }
+            const u32 n = hlit + hdist;
+            u32 i = 0, prev = 0;
+            while (i < n && !fail) {
+                rd_fill(r, lane);
+                const u32 e = rfl(L.dist[(u32)r.bb & ((1u << CL_BITS) - 1u)]);
+                const u32 nb = e & 15u;
+                if (nb == 0u) {
+                    fail = BZ_BAD_CODE;
+                    break;
+                }
+                rd_take(r, nb);
+                const u32 sym = e >> 16;
+                if (sym < 16u) {
+                    if (lane == 0) L.lens[i] = (uint8_t)sym;
+                    prev = sym;
+                    i++;
+                } else {
+                    u32 rep, val = 0;
+                    if (sym == 16u) {
+                        if (i == 0u) {
+                            fail = BZ_BAD_BLOCK;
+                            break;
+                        }
+                        rep = 3u + rd_take(r, 2);
+                        val = prev;
+                    } else if (sym == 17u) {
+                        rep = 3u + rd_take(r, 3);
+                    } else {
+                        rep = 11u + rd_take(r, 7);
+                    }
+                    if (i + rep > n) {
+                        fail = BZ_BAD_BLOCK;
+                        break;
+                    }
+                    for (u32 j = lane; j < rep; j += 64u) L.lens[i + j] = (uint8_t)val;
+                    prev = val;
+                    i += rep;
+                }
+            }
+            if (fail) break;
+            __syncthreads();
+            if (L.lens[256] == 0) { // no end-of-block code
+                fail = BZ_BAD_BLOCK;
+                break;
+            }
+        }
+        __syncthreads();
+        if (!build_table(L.lens, hlit, LIT_BITS, L.lit, L.cs[0], 0, lane) ||
+            !build_table(L.lens + hlit, hdist, DIST_BITS, L.dist, L.cs[1], 1, lane)) {
+            fail = BZ_BAD_BLOCK;
+            break;
+        }
+        for (;;) { // the block's symbols
+            rd_fill(r, lane);
+            u32 e = rfl(L.lit[(u32)r.bb & ((1u << LIT_BITS) - 1u)]);
+            if (((e >> 8) & 3u) == KIND_LONG) e = rfl(decode_long(L.cs[0], LIT_BITS, 0, (u32)r.bb));
+            const u32 nb = e & 15u;
+            if (nb == 0u) {
+                fail = BZ_BAD_CODE;
+                break;
+            }
+            rd_take(r, nb);
+            const u32 kind = (e >> 8) & 3u;
+            if (kind == KIND_EOB) break;
+            u32 info, adv;
+            if (kind == KIND_LIT) {
+                info = (e >> 16) << 16;
+                adv = 1;
+            } else {
+                const u32 len = (e >> 16) + rd_take(r, (e >> 4) & 15u);
+                rd_fill(r, lane);
+                u32 d = rfl(L.dist[(u32)r.bb & ((1u << DIST_BITS) - 1u)]);
+                if (((d >> 8) & 3u) == KIND_LONG) d = rfl(decode_long(L.cs[1], DIST_BITS, 1, (u32)r.bb));
+                const u32 db = d & 15u;
+                if (db == 0u) {
+                    fail = BZ_BAD_CODE;
+                    break;
+                }
+                rd_take(r, db);
+                const u32 dist = (d >> 16) + rd_take(r, (d >> 4) & 15u);
+                if (dist > pos) {
+                    fail = BZ_BAD_MATCH;
+                    break;
+                }
+                info = (dist << 16) | len;
+                adv = len;
+            }
+            if (pos + adv > isize) {
+                fail = BZ_BAD_SIZE;
+                break;
+            }
+            if (lane == ntok) { // the queue: token i sits in lane i
+                tpos = pos;
+                tinfo = info;
+            }
+            pos += adv;
+            if (++ntok == 64u) {
+                resolve_group(out, tpos, tinfo, ntok, lane);
+                ntok = 0;
+                if (rd_used_bits(r) > in_bits + 64u) { // (a damaged stream wandering off: stop before the table walk is long)
+                    fail = BZ_OVERRUN;
+                    break;
+                }
+            }
+        }
+    }
+    resolve_group(out, tpos, tinfo, ntok, lane);
+    if (!fail && pos != isize) fail = BZ_BAD_SIZE;
+    if (!fail && ((rd_used_bits(r) + 7u) >> 3) != m.in_len) fail = BZ_OVERRUN;
+    if (fail && lane == 0) atomicMax(status, (mi << 8) | fail);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// CRC-32 (IEEE 802.3, reflected) of each member's text
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr u32 CRC_POLY = 0xEDB88320u;
+// a(x) * b(x) mod P, reflected representation (bit 31 = x^0): the multiplication of zlib's crc32_combine
+__host__ __device__ inline u32 crc_multmodp(u32 a, u32 b) {
+    u32 m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1u)) == 0u) break;
+        }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ CRC_POLY : b >> 1;
+    }
+    return p;
+}
+struct X2N {
+    u32 t[32]; // x^(2^k) mod P
+};
+__device__ inline u32 crc_x2nmodp(const X2N &x, u32 n, u32 k) { // x^(n * 2^k) mod P
+    u32 p = 1u << 31;
+    while (n) {
+        if (n & 1u) p = crc_multmodp(x.t[k & 31u], p);
+        n >>= 1;
+        k++;
+    }
+    return p;
+}
+} // namespace
+
+__global__ __launch_bounds__(256) void k_bgzf_crc(const BgzfMember *members, u32 n_members, const uint8_t *text, X2N x2n,
+                                                  u32 *status) {
+    __shared__ u32 T[4][256];
+    {
+        u32 c = threadIdx.x;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
+        T[0][threadIdx.x] = c;
+    }
+    __syncthreads();
+    for (int t = 1; t < 4; ++t) {
+        const u32 prev = T[t - 1][threadIdx.x];
+        T[t][threadIdx.x] = (prev >> 8) ^ T[0][prev & 0xFFu];
+        __syncthreads();
+    }
+    const u32 lane = threadIdx.x & 63u;
+    const u32 mi = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (mi >= n_members) return;
+    const BgzfMember m = members[mi];
+    const u32 slice = (((m.isize + 63u) >> 6) + 3u) & ~3u;
+    const u32 lo = lane * slice < m.isize ? lane * slice : m.isize;
+    const u32 hi = lo + slice < m.isize ? lo + slice : m.isize;
+    const uint8_t *p = text + m.out_off;
+    u32 c = 0xFFFFFFFFu, i = lo;
+    for (; i < hi && ((uintptr_t)(p + i) & 3u); ++i) c = (c >> 8) ^ T[0][(c ^ p[i]) & 0xFFu];
+    for (; i + 4u <= hi; i += 4u) {
+        c ^= *(const u32 *)(p + i);
+        c = T[3][c & 0xFFu] ^ T[2][(c >> 8) & 0xFFu] ^ T[1][(c >> 16) & 0xFFu] ^ T[0][c >> 24];
+    }
+    for (; i < hi; ++i) c = (c >> 8) ^ T[0][(c ^ p[i]) & 0xFFu];
+    c ^= 0xFFFFFFFFu;
+    // crc(A || B) = crc(A) * x^(8 |B|) + crc(B): every slice shifted past what follows it
+    u32 part = hi > lo ? crc_multmodp(crc_x2nmodp(x2n, m.isize - hi, 3), c) : 0u;
+    for (int off = 32; off > 0; off >>= 1) part ^= __shfl_xor(part, off);
+    if (lane == 0 && part != m.crc) atomicMax(status, (mi << 8) | (u32)BZ_BAD_CRC);
+}
+
+// out[0] = offset of the last header line whose line two below is a '+' line (what fh_host.cpp's reader cuts a FASTQ
+// chunk at), or `total` for the last text of a file; out[1] = 1 when no such line is in the last 16.
+__global__ __launch_bounds__(64) void k_fastq_cut(const uint8_t *text, u32 total, u32 last, u32 *out) {
+    const u32 lane = threadIdx.x;
+    if (last || total == 0u) {
+        if (lane == 0) {
+            out[0] = total;
+            out[1] = 0;
+        }
+        return;
+    }
+    __shared__ u32 ls[16];
+    u32 n = 0, scan_hi = total;
+    while (n < 16u && scan_hi > 0u) {
+        const u32 lo = scan_hi >= 64u ? scan_hi - 64u : 0u;
+        const u32 idx = lo + lane;
+        const bool nl = idx < scan_hi && text[idx] == '\n';
+        unsigned long long mask = __ballot(nl);
+        while (mask && n < 16u) {
+            const u32 b = 63u - (u32)__builtin_clzll(mask);
+            mask &= ~(1ull << b);
+            const u32 start = lo + b + 1u;
+            if (start < total) {
+                if (lane == 0) ls[n] = start;
+                n++;
+            }
+        }
+        scan_hi = lo;
+    }
+    if (n < 16u && scan_hi == 0u) {
+        if (lane == 0) ls[n] = 0u;
+        n++;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        u32 cut = 0, bad = 1;
+        for (u32 i = 2; i < n; ++i)
+            if (text[ls[i]] == '@' && text[ls[i - 2]] == '+') {
+                cut = ls[i];
+                bad = 0;
+                break;
+            }
+        out[0] = cut;
+        out[1] = bad;
+    }
+}
+
+hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfMember *members, uint32_t n_members, uint8_t *text,
+                               uint32_t *status, hipStream_t st) {
+    if (n_members == 0) return hipSuccess;
+    static const X2N x2n = [] {
+        X2N x;
+        u32 p = 1u << 30; // x^1
+        x.t[0] = p;
+        for (int k = 1; k < 32; ++k) x.t[k] = p = crc_multmodp(p, p);
+        return x;
+    }();
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_members), dim3(64), 0, st, comp, members, n_members, text, status);
+    hipLaunchKernelGGL(k_bgzf_crc, dim3((n_members + 3u) / 4u), dim3(256), 0, st, members, n_members, (const uint8_t *)text,
+                       x2n, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_fastq_cut(const uint8_t *text, uint32_t total, uint32_t last, uint32_t *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_fastq_cut, dim3(1), dim3(64), 0, st, text, total, last, out);
+    return hipGetLastError();
+}
+
+} // namespace fh

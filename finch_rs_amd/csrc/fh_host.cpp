@@ -675,6 +675,72 @@ struct BgzfSource : ByteSource {
         }
         return c_hi - c_lo >= need;
     }
+    // ---- the device-side inflate (fh_push_bgzf_fastq) takes the members as they are ----
+    // First byte of the file's text without consuming anything; -1: first member not BGZF, empty or damaged.
+    int peek_first_text_byte() {
+        join_prefetch();
+        if (!fill_compressed(18)) return -1;
+        uint32_t hdr = 0;
+        const uint32_t tot = member_size(cbuf.data() + c_lo, &hdr);
+        if (tot < hdr + 10u || !fill_compressed(tot)) return -1;
+        const uint8_t *p = cbuf.data() + c_lo;
+        const uint32_t isize = p[tot - 4] | ((uint32_t)p[tot - 3] << 8) | ((uint32_t)p[tot - 2] << 16) | ((uint32_t)p[tot - 1] << 24);
+        if (isize == 0 || isize > 65536u) return -1;
+        std::vector<uint8_t> text(isize);
+        std::unique_ptr<inf::Decoder> dec(new inf::Decoder());
+        if (!inf::inflate_exact(*dec, p + hdr, tot - hdr - 8, text.data(), isize)) return -1;
+        return text[0];
+    }
+    // Whole members into dst: a table of n records at the front (room for max_members), their bytes behind it; members
+    // are taken while the table, the bytes (dst_cap) and the text they inflate to (text_budget) have room.  *eof: the
+    // input ended with the last member taken.  false: a member that is not BGZF, a truncated one, or one too large.
+    bool raw_batch(uint8_t *dst, size_t dst_cap, uint32_t max_members, uint64_t text_budget, fh_bgzf_member *table, uint32_t *n_out,
+                   uint64_t *bytes_out, uint64_t *text_out, bool *eof) {
+        join_prefetch();
+        if (cbuf.size() < ((size_t)16 << 20)) { // large reads from here on
+            RawBuf big((size_t)16 << 20);
+            memcpy(big.data(), cbuf.data() + c_lo, c_hi - c_lo);
+            c_hi -= c_lo;
+            c_lo = 0;
+            cbuf.swap(big);
+        }
+        size_t w = (size_t)max_members * sizeof(fh_bgzf_member); // write position in dst
+        uint32_t n = 0;
+        uint64_t text = 0;
+        *eof = false;
+        for (;;) {
+            if (c_hi - c_lo < 18 && !fill_compressed(18)) {
+                if (c_hi - c_lo == 0 && in_eof) { *eof = true; break; }
+                return false; // a few stray bytes at the end
+            }
+            uint32_t hdr = 0;
+            const uint32_t tot = member_size(cbuf.data() + c_lo, &hdr);
+            if (tot < hdr + 10u) return false;
+            if (c_hi - c_lo < tot && !fill_compressed(tot)) return false; // truncated
+            const uint8_t *p = cbuf.data() + c_lo;
+            const uint32_t isize = p[tot - 4] | ((uint32_t)p[tot - 3] << 8) | ((uint32_t)p[tot - 2] << 16) | ((uint32_t)p[tot - 1] << 24);
+            if (isize > 65536u) return false;
+            const size_t in_len = tot - hdr - 8;
+            if (n == max_members || w + in_len + 8 > dst_cap || text + isize > text_budget) break;
+            memcpy(dst + w, p + hdr, in_len);
+            table[n].in_off = (uint32_t)w;
+            table[n].in_len = (uint32_t)in_len;
+            table[n].out_off = (uint32_t)text;
+            table[n].isize = isize;
+            table[n].crc32 = p[tot - 8] | ((uint32_t)p[tot - 7] << 8) | ((uint32_t)p[tot - 6] << 16) | ((uint32_t)p[tot - 5] << 24);
+            w += (in_len + 3) & ~(size_t)3;
+            text += isize;
+            n++;
+            c_lo += tot;
+            // keep the buffer topped up in large reads (the memcpy above is all the work there is per member)
+            if (c_hi - c_lo < (1u << 16) && !in_eof) fill_compressed(std::min<size_t>(cbuf.size() / 2, (size_t)8 << 20));
+        }
+        *n_out = n;
+        *bytes_out = w;
+        *text_out = text;
+        return n > 0 || *eof;
+    }
+
     struct Member { size_t in_off, in_len, out_off; uint32_t isize, crc; };
     // inflate the next batch of members into out[0, out_cap) (>= 64 KiB: room for any one member); false = end of
     // input or error; *produced may be 0 for a batch of empty members
@@ -1291,6 +1357,8 @@ static fh_params to_fh(const finch_sketch_params &sp, uint64_t max_launch, uint6
 // A line is a header iff it starts with '@' and the line two below starts with '+' (a quality line may start
 // with '@', but then the line two below is a sequence line).
 static int pump_text_to_device(ByteSource &src, fh_sketcher *h, bool fastq, uint32_t k, struct FastxStats &st);
+static int bgzf_fastq_to_device(struct BgzfSource &bz, fh_sketcher *h);
+static std::atomic<uint64_t> g_bgzf_on_device{0}, g_bgzf_reread{0};
 static int fastq_text_to_device(ByteSource &src, fh_sketcher *h, uint32_t k);
 
 // Device-side FASTA (fh_push_fasta_text): the host reads raw file bytes into the pinned staging buffer, cuts chunks
@@ -1442,7 +1510,17 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     // fallback, see below); 1 = on the device, no fallback; 0 = on the host.  Compressed input is inflated on the host
     // and its text treated the same way.
     const bool dp_on = dp && dp[0] == '1', dp_off = dp && dp[0] == '0';
-    if (is_gz) {
+    // FINCH_DEVICE_INFLATE: unset / 1 = BGZF-compressed FASTQ is inflated on the device (with the host-side inflate as the
+    // fallback whenever the device pass refuses the file); 0 = always on the host
+    BgzfSource *bgzf_dev = nullptr;
+    if (is_gz && !dp_off) {
+        const char *di = getenv("FINCH_DEVICE_INFLATE");
+        BgzfSource *bz = dynamic_cast<BgzfSource *>(src.get());
+        if (bz && !(di && di[0] == '0') && src->can_rewind() && bz->peek_first_text_byte() == '@') bgzf_dev = bz;
+    }
+    if (bgzf_dev) {
+        first = '@';
+    } else if (is_gz) {
         // compressed: the format shows in the first inflated byte; what follows it reaches the staging buffer straight
         // from the decompressor, so the host only inflates (gzip: one thread, BGZF: the call's read threads)
         uint8_t b = 0;
@@ -1460,6 +1538,19 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     fh_sketcher *h = handles.get(small);
     if (!h) return hfail(FH_ERR_NO_DEVICE, "%s", fh_last_error());
     if (int rc = fh_reset(h)) return hfail(rc, "%s", fh_last_error());
+    if (bgzf_dev) {
+        st.format = 2;
+        const int rc = bgzf_fastq_to_device(*bgzf_dev, h);
+        if (rc == FH_OK) {
+            g_bgzf_on_device++;
+            if (int r2 = fh_text_bases(h, &st.total_bases)) return hfail(r2, "%s", fh_last_error());
+            return finish_sketch(h, name, sp, filters, st, out);
+        }
+        if (rc != FH_ERR_INVALID || !src->rewind()) return rc;
+        g_bgzf_reread++;
+        if (int r2 = fh_reset(h)) return hfail(r2, "%s", fh_last_error());
+        // (the text now comes through the host-side inflate; its first byte is known)
+    }
     bool device_parse = !dp_off && (first == '>' || first == '@');
     if (device_parse && first == '@' && !dp_on && !src->can_rewind()) device_parse = false; // no second chance: host parser
     if (device_parse && first == '@') {
@@ -1755,6 +1846,108 @@ static int pump_text_to_device(ByteSource &src, fh_sketcher *h, bool fastq, uint
     if (prc != FH_OK) return hfail(prc, "%s", pmsg.c_str());
     st.total_bases = pst.total_bases;
     st.n_records = pst.n_records;
+    return FH_OK;
+}
+
+// BGZF-compressed FASTQ with the inflate on the device (fh_push_bgzf_fastq): the reader thread only moves whole members
+// from the file into the sketcher's pinned buffers -- a table of them in front, their DEFLATE bytes behind -- while the
+// calling thread has the previous batch copied over, inflated, CRC-checked, split and sketched.  The compressed bytes
+// cross PCIe instead of the text, and no host core inflates anything.  Any failure (a member that is not BGZF, damage,
+// text that is not plain 4-line FASTQ, a record longer than the buffers' spare room) is FH_ERR_INVALID: the caller
+// reads the file again through the host-side inflate, whose errors are the ones reported.
+static int bgzf_fastq_to_device(BgzfSource &bz, fh_sketcher *h) {
+    uint8_t *raw[2] = {nullptr, nullptr};
+    uint64_t cap = 0;
+    int next = 0;
+    if (int rc = fh_text_buffers(h, raw, &cap, &next)) return hfail(rc, "%s", fh_last_error());
+    const uint32_t max_members = (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(1, cap / 8192));
+    // what follows the last whole record of a batch joins the next batch's text: leave it room
+    const uint64_t text_budget = cap - std::min<uint64_t>(cap / 8, (uint64_t)8 << 20);
+    struct Job {
+        int slot;
+        uint64_t bytes;
+        uint32_t n;
+        bool last;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    bool is_free[2] = {true, true}, producer_done = false, producer_ok = true;
+    std::vector<Job> ready;
+    std::atomic<bool> abort{false};
+    static const bool trace = getenv("FH_TRACE") != nullptr;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now_s();
+    double t_reader_waits = 0, t_pusher_waits = 0, t_push = 0, t_read = 0;
+    uint64_t n_members = 0, n_bytes = 0;
+    unsigned n_batches = 0;
+    std::thread producer([&] {
+        int slot = next;
+        for (;;) {
+            {
+                const double t0 = trace ? now_s() : 0;
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return is_free[slot] || abort.load(); });
+                if (trace) t_reader_waits += now_s() - t0;
+                if (abort) break;
+                is_free[slot] = false;
+            }
+            Job job{slot, 0, 0, false};
+            uint64_t text = 0;
+            const double t0 = trace ? now_s() : 0;
+            const bool ok = bz.raw_batch(raw[slot], cap, max_members, text_budget, (fh_bgzf_member *)raw[slot], &job.n, &job.bytes, &text,
+                                         &job.last);
+            if (trace) t_read += now_s() - t0;
+            std::lock_guard<std::mutex> g(mu);
+            if (!ok) {
+                producer_ok = false;
+                break;
+            }
+            if (job.n == 0) job.bytes = 0;
+            n_members += job.n;
+            n_bytes += job.bytes;
+            ready.push_back(job);
+            cv.notify_all();
+            if (job.last) break;
+            slot ^= 1;
+        }
+        std::lock_guard<std::mutex> g(mu);
+        producer_done = true;
+        cv.notify_all();
+    });
+    int rc = FH_OK;
+    std::string msg;
+    for (;;) {
+        Job job;
+        const double tw0 = trace ? now_s() : 0;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !ready.empty() || producer_done; });
+            if (ready.empty()) break;
+            job = ready.front();
+            ready.erase(ready.begin());
+        }
+        const double tw1 = trace ? now_s() : 0;
+        t_pusher_waits += tw1 - tw0;
+        n_batches++;
+        if (rc == FH_OK) {
+            rc = fh_push_bgzf_fastq(h, job.bytes, job.n, job.last ? FH_BGZF_LAST : 0u);
+            if (trace) t_push += now_s() - tw1;
+            if (rc != FH_OK) {
+                msg = fh_last_error();
+                abort = true;
+            }
+        }
+        std::lock_guard<std::mutex> g(mu);
+        is_free[job.slot] = true;
+        cv.notify_all();
+    }
+    producer.join();
+    if (trace)
+        fprintf(stderr, "[finch] bgzf on the device: %u batches, %llu members, %.1f MB in %.1f ms: reads %.1f ms, reader waited %.1f ms for a buffer, pushes took %.1f ms and waited %.1f ms for members\n",
+                n_batches, (unsigned long long)n_members, n_bytes / 1e6, (now_s() - t_begin) * 1e3, t_read * 1e3, t_reader_waits * 1e3,
+                t_push * 1e3, t_pusher_waits * 1e3);
+    if (rc != FH_OK) return hfail(rc == FH_ERR_INVALID ? FH_ERR_INVALID : rc, "%s", msg.c_str());
+    if (!producer_ok) return hfail(FH_ERR_INVALID, "not a plain chain of BGZF members");
     return FH_OK;
 }
 
@@ -2097,6 +2290,11 @@ static int to_json(const std::vector<Sketch> &sketches, std::string &o) {
 using namespace finch;
 
 extern "C" {
+
+void finch_debug_device_inflate(uint64_t *files_on_device, uint64_t *files_reread) {
+    if (files_on_device) *files_on_device = finch::g_bgzf_on_device.load();
+    if (files_reread) *files_reread = finch::g_bgzf_reread.load();
+}
 
 const char *finch_last_error(void) { return g_host_err.c_str(); }
 

@@ -52,6 +52,16 @@ hipError_t launch_fastq_pack(const uint8_t *text, uint64_t len, uint8_t *out, ui
                              uint32_t *totals, Ctl *ctl, uint32_t *err, uint32_t *line_end, uint32_t line_cap, hipStream_t st);
 hipError_t launch_fasta_pack(const uint8_t *text, uint64_t len, uint32_t start_state, uint8_t *out, uint32_t *blk_a,
                              uint32_t *blk_b, uint32_t *totals, hipStream_t st);
+// fh_bgzf.hip: the members of a BGZF batch inflated and CRC-checked, one wavefront each.  in_off / in_len: the member's
+// DEFLATE bytes within `comp` (4-byte aligned buffer; reads stay inside the member); out_off: where its isize bytes of
+// text go in `text`.  status[0] stays 0 or becomes (member << 8 | reason).
+struct BgzfMember {
+    uint32_t in_off, in_len, out_off, isize, crc;
+};
+hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfMember *members, uint32_t n_members, uint8_t *text,
+                               uint32_t *status, hipStream_t st);
+// out[0]: where the last whole FASTQ record of text[0, total) ends (`last`: total); out[1]: 1 if no boundary was found
+hipError_t launch_fastq_cut(const uint8_t *text, uint32_t total, uint32_t last, uint32_t *out, hipStream_t st);
 hipError_t launch_fill_table(Entry *table, uint64_t cap, hipStream_t st);
 // (keep_text_bases: everything but the count of sequence bytes the text packers have emitted so far)
 hipError_t launch_init_ctl(Ctl *ctl, uint64_t tau0, hipStream_t st, bool keep_text_bases = false);

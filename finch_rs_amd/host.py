@@ -106,6 +106,7 @@ _SYMS = {
     "finch_fasta_count_chunked": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "finch_read_file_probe": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "finch_source_probe": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "finch_debug_device_inflate": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
 }
 class CDistance(C.Structure):
     _fields_ = [("containment", C.c_double), ("jaccard", C.c_double), ("mash_distance", C.c_double),
@@ -391,6 +392,13 @@ def fasta_count_chunked(data: bytes, chunk: int):
     buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
     _check(lib().finch_fasta_count_chunked(buf.ctypes.data, len(data), chunk, C.byref(n), C.byref(tb)))
     return n.value, tb.value
+
+
+def debug_device_inflate():
+    """(inputs sketched with the BGZF inflate on the device, inputs re-read through the host inflate) -- test hook"""
+    a, b = C.c_uint64(), C.c_uint64()
+    lib().finch_debug_device_inflate(C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def source_probe(data: bytes, chunk: int, cap: int) -> bytes:

@@ -181,6 +181,11 @@ int finch_source_probe(const uint8_t *data, uint64_t len, uint64_t chunk, uint8_
 int finch_shard_probe(const uint8_t *data, uint64_t len, uint32_t k, uint64_t chunk_bytes, uint64_t max_chunks, uint64_t *meta,
                       uint8_t *halos, uint64_t *n_chunks, uint64_t *n_records, uint64_t *total_bases);
 
+/* Test hook: inputs this process has sketched with the BGZF inflate on the device (finch_sketch_files /
+ * finch_sketch_buffer: bgzip'd FASTQ unless FINCH_DEVICE_INFLATE=0), and how many of them it had to read again through the
+ * host-side inflate because the device pass refused them. */
+void finch_debug_device_inflate(uint64_t *files_on_device, uint64_t *files_reread);
+
 #ifdef __cplusplus
 }
 #endif
