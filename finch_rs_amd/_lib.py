@@ -42,6 +42,7 @@ SYMBOLS = {
     "fh_text_buffers": (C.c_int, [_P, C.POINTER(_P), _U64P, C.POINTER(C.c_int)]),
     "fh_push_fastq_text": (C.c_int, [_P, C.c_uint64]),
     "fh_push_bgzf_fastq": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32]),
+    "fh_bgzf_text_capacity": (C.c_int, [_P, _U64P]),
     "fh_push_fasta_text": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32]),
     "fh_push_staged": (C.c_int, [_P, C.c_uint64, C.c_uint32]),
     "fh_set_text_halo": (C.c_int, [_P, _P, C.c_uint32]),

@@ -165,9 +165,16 @@ struct fh_sketcher {
     int stage_next = 0;
     uint64_t stage_bytes = 0;
     // device-side FASTQ packing (fh_text.hip): packed output + block scan scratch per staging slot
-    uint8_t *d_comp = nullptr;            // fh_push_bgzf_fastq: the batch as it came (member table + DEFLATE bytes)
+    // fh_push_bgzf_fastq: the batch as it came (member table + DEFLATE bytes), and text / packed buffers of its own:
+    // a wavefront per member only fills the chip with thousands of members in flight, i.e. hundreds of MB of text per batch
+    uint8_t *d_comp = nullptr;
     uint32_t *d_bz_status = nullptr, *h_bz_status = nullptr;
-    const uint8_t *bgzf_left_ptr = nullptr; // text behind the last whole record of the previous batch (in a d_stage slot)
+    uint64_t bz_text_cap = 0;
+    uint8_t *bz_text[2] = {nullptr, nullptr}, *bz_packed[2] = {nullptr, nullptr};
+    uint32_t *bz_blk_a[2] = {nullptr, nullptr}, *bz_blk_b[2] = {nullptr, nullptr}, *bz_lines = nullptr;
+    uint32_t bz_line_cap = 0;
+    int bz_next = 0;
+    const uint8_t *bgzf_left_ptr = nullptr; // text behind the last whole record of the previous batch (in the other bz_text)
     uint64_t bgzf_left_len = 0;
     uint8_t *d_packed[N_STAGE] = {nullptr, nullptr};
     uint32_t *d_blk_a[N_STAGE] = {nullptr, nullptr}, *d_blk_b[N_STAGE] = {nullptr, nullptr};
@@ -1008,7 +1015,7 @@ uint64_t pool_max_bytes() {
 uint64_t handle_bytes(const fh_sketcher *s) {
     uint64_t b = (uint64_t)s->cap * (sizeof(Entry) + (s->kmer_hi ? 8 : 0)) + (uint64_t)s->live_cap * 8 + (uint64_t)s->shard_cap * N_SHARDS * 4;
     for (int i = 0; i < N_STAGE; ++i) b += 2 * s->stage_cap[i];
-    if (s->d_comp) b += s->stage_bytes;
+    if (s->bz_text_cap) b += s->stage_bytes + 4 * s->bz_text_cap + s->bz_text_cap / 2;
     return b + (uint64_t)s->out_cap * 32 + (uint64_t)s->big_cap * 24;
 }
 bool same_params(const fh_params &a, const fh_params &b) {
@@ -1199,6 +1206,13 @@ void destroy_handle(fh_sketcher *s) {
     (void)hipFree(s->d_lines);
     (void)hipFree(s->d_comp);
     (void)hipFree(s->d_bz_status);
+    (void)hipFree(s->bz_lines);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipFree(s->bz_text[i]);
+        (void)hipFree(s->bz_packed[i]);
+        (void)hipFree(s->bz_blk_a[i]);
+        (void)hipFree(s->bz_blk_b[i]);
+    }
     if (s->h_bz_status) (void)hipHostFree(s->h_bz_status);
     if (s->h_text_tot) (void)hipHostFree(s->h_text_tot);
     if (s->h_ctl) (void)hipHostFree(s->h_ctl);
@@ -1444,21 +1458,20 @@ static int ensure_fastq_scratch(fh_sketcher *s, int b) {
     return FH_OK;
 }
 
-// d_stage[b][0, len) holds whole 4-line FASTQ records (or is being filled on the stream): split, check, sketch
-static int fastq_text_on_device(fh_sketcher *s, int b, uint64_t len) {
+// text[0, len) holds whole 4-line FASTQ records (or is being filled on the stream): split, check, sketch
+static int fastq_text_on_device(fh_sketcher *s, const uint8_t *text, uint64_t len, uint8_t *packed, uint32_t *blk_a, uint32_t *blk_b,
+                                uint32_t *lines, uint32_t line_cap) {
     HIP_TRY(hipMemsetAsync(s->d_text_tot, 0, 4 * sizeof(uint32_t), s->stream));
-    HIP_TRY(launch_fastq_pack(s->d_stage[b], len, s->d_packed[b], s->d_blk_a[b], s->d_blk_b[b], s->d_text_tot, s->ctl,
-                              s->d_text_tot + 2, s->d_lines, s->line_cap, s->stream));
+    HIP_TRY(launch_fastq_pack(text, len, packed, blk_a, blk_b, s->d_text_tot, s->ctl, s->d_text_tot + 2, lines, line_cap, s->stream));
     HIP_TRY(hipMemcpyAsync(s->h_text_tot, s->d_text_tot, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->h_text_tot[2])
         return fail(FH_ERR_INVALID, "not plain 4-line FASTQ text (header without '@', separator without '+', blanks inside a "
                                     "sequence line, or sequence and quality lengths differ)");
     const uint64_t n_packed = s->h_text_tot[1];
-    s->stage_next = (b + 1) % N_STAGE;
     s->carry_len = 0; // every sequence line ends with its breaker: nothing spans chunks
     s->dprev_len = 0;
-    const int rc = sketch_device_range(s, s->d_packed[b], n_packed, s->stream_off);
+    const int rc = sketch_device_range(s, packed, n_packed, s->stream_off);
     s->stream_off += n_packed;
     return rc;
 }
@@ -1478,7 +1491,8 @@ int fh_push_fastq_text(fh_sketcher *s, uint64_t len) {
     HIP_TRY(hipMemcpyAsync(s->d_stage[b], s->h_stage[b] + STAGE_HEADROOM, len, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
     s->stage_busy[b] = true;
-    return fastq_text_on_device(s, b, len);
+    s->stage_next = (b + 1) % N_STAGE;
+    return fastq_text_on_device(s, s->d_stage[b], len, s->d_packed[b], s->d_blk_a[b], s->d_blk_b[b], s->d_lines, s->line_cap);
 }
 
 static_assert(sizeof(fh_bgzf_member) == sizeof(BgzfMember) && offsetof(fh_bgzf_member, crc32) == offsetof(BgzfMember, crc),
@@ -1487,6 +1501,38 @@ static_assert(sizeof(fh_bgzf_member) == sizeof(BgzfMember) && offsetof(fh_bgzf_m
 // fh_text_buffers, `n_members` fh_bgzf_member records followed by the members' DEFLATE bytes (`bytes` in all; in_off
 // counts from the start of the buffer).  The text of a batch rarely ends with a record: what follows its last whole
 // record stays on the device and leads the text of the next push; FH_BGZF_LAST says there is no next push.
+// buffers of the device-side BGZF path: text of up to 8 staging buffers' worth per batch (1 GiB at most)
+static int ensure_bgzf_buffers(fh_sketcher *s) {
+    if (s->bz_text_cap) return FH_OK;
+    const uint64_t cap = std::min<uint64_t>(8 * s->stage_bytes, 1ull << 30);
+    const uint64_t nblk = (cap + 4095) / 4096 + 1;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(dev_malloc((void **)&s->bz_text[i], cap + 128));
+        HIP_TRY(dev_malloc((void **)&s->bz_packed[i], cap + 64));
+        HIP_TRY(dev_malloc((void **)&s->bz_blk_a[i], nblk * sizeof(uint32_t)));
+        HIP_TRY(dev_malloc((void **)&s->bz_blk_b[i], nblk * sizeof(uint32_t)));
+    }
+    s->bz_line_cap = (uint32_t)std::min<uint64_t>(cap / 8 + 64, 0x7FFFFFFFull);
+    HIP_TRY(dev_malloc((void **)&s->bz_lines, (size_t)s->bz_line_cap * sizeof(uint32_t)));
+    HIP_TRY(dev_malloc((void **)&s->d_comp, s->stage_bytes + 4096));
+    HIP_TRY(dev_malloc((void **)&s->d_bz_status, 4 * sizeof(uint32_t)));
+    HIP_TRY(host_malloc((void **)&s->h_bz_status, 4 * sizeof(uint32_t)));
+    if (!s->d_text_tot) {
+        HIP_TRY(dev_malloc((void **)&s->d_text_tot, 4 * sizeof(uint32_t)));
+        HIP_TRY(host_malloc((void **)&s->h_text_tot, 4 * sizeof(uint32_t)));
+    }
+    s->bz_text_cap = cap;
+    return FH_OK;
+}
+
+int fh_bgzf_text_capacity(fh_sketcher *s, uint64_t *cap) {
+    if (!s || !cap) return fail(FH_ERR_INVALID, "null argument");
+    if (int rc = set_device(s)) return rc;
+    if (int rc = ensure_bgzf_buffers(s)) return rc;
+    *cap = s->bz_text_cap;
+    return FH_OK;
+}
+
 int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint32_t flags) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
@@ -1494,7 +1540,8 @@ int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint3
     if ((uint64_t)n_members * sizeof(fh_bgzf_member) > bytes) return fail(FH_ERR_INVALID, "member table longer than the batch");
     if (int rc = set_device(s)) return rc;
     if (int rc = ensure_stage(s)) return rc;
-    const int b = s->stage_next;
+    if (int rc = ensure_bgzf_buffers(s)) return rc;
+    const int b = s->stage_next, t = s->bz_next;
     const fh_bgzf_member *mt = (const fh_bgzf_member *)(s->h_stage[b] + STAGE_HEADROOM);
     uint64_t text = 0;
     for (uint32_t i = 0; i < n_members; ++i) {
@@ -1505,24 +1552,21 @@ int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint3
         text += m.isize;
     }
     const uint64_t left = s->bgzf_left_len, total = left + text;
-    if (total > s->stage_bytes || total >= (1ull << 31))
-        return fail(FH_ERR_INVALID, "a FASTQ record and a batch of BGZF text do not fit the staging buffer together");
-    if (int rc = ensure_fastq_scratch(s, b)) return rc;
-    if (!s->d_comp) {
-        HIP_TRY(dev_malloc((void **)&s->d_comp, s->stage_bytes + 4096));
-        HIP_TRY(dev_malloc((void **)&s->d_bz_status, 4 * sizeof(uint32_t)));
-        HIP_TRY(host_malloc((void **)&s->h_bz_status, 4 * sizeof(uint32_t)));
-    }
+    if (total > s->bz_text_cap || total >= (1ull << 31))
+        return fail(FH_ERR_INVALID, "a FASTQ record and a batch of BGZF text do not fit the text buffer together");
+    // the packed buffer of this slot may still feed a pending range
     if (int rc = drain(s)) return rc;
-    if (left) HIP_TRY(hipMemcpyAsync(s->d_stage[b], s->bgzf_left_ptr, left, hipMemcpyDeviceToDevice, s->stream));
+    if (left) HIP_TRY(hipMemcpyAsync(s->bz_text[t], s->bgzf_left_ptr, left, hipMemcpyDeviceToDevice, s->stream));
     s->bgzf_left_len = 0;
     if (total == 0) return FH_OK;
     HIP_TRY(hipMemsetAsync(s->d_bz_status, 0, 4 * sizeof(uint32_t), s->stream));
     if (bytes) HIP_TRY(hipMemcpyAsync(s->d_comp, s->h_stage[b] + STAGE_HEADROOM, bytes, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
     s->stage_busy[b] = true;
-    HIP_TRY(launch_bgzf_inflate(s->d_comp, (const BgzfMember *)s->d_comp, n_members, s->d_stage[b] + left, s->d_bz_status, s->stream));
-    HIP_TRY(launch_fastq_cut(s->d_stage[b], (uint32_t)total, (flags & FH_BGZF_LAST) ? 1u : 0u, s->d_bz_status + 1, s->stream));
+    s->stage_next = (b + 1) % N_STAGE;
+    s->bz_next = t ^ 1;
+    HIP_TRY(launch_bgzf_inflate(s->d_comp, (const BgzfMember *)s->d_comp, n_members, s->bz_text[t] + left, s->d_bz_status, s->stream));
+    HIP_TRY(launch_fastq_cut(s->bz_text[t], (uint32_t)total, (flags & FH_BGZF_LAST) ? 1u : 0u, s->d_bz_status + 1, s->stream));
     HIP_TRY(hipMemcpyAsync(s->h_bz_status, s->d_bz_status, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (const uint32_t st = s->h_bz_status[0]) {
@@ -1532,13 +1576,10 @@ int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint3
     }
     if (s->h_bz_status[2]) return fail(FH_ERR_INVALID, "no FASTQ record boundary at the end of a batch of BGZF text");
     const uint64_t cut = s->h_bz_status[1];
-    s->bgzf_left_ptr = s->d_stage[b] + cut;
+    s->bgzf_left_ptr = s->bz_text[t] + cut;
     s->bgzf_left_len = total - cut;
-    if (cut == 0) { // one record longer than the batch so far: keep collecting (the text moves on to the next slot)
-        s->stage_next = (b + 1) % N_STAGE;
-        return FH_OK;
-    }
-    return fastq_text_on_device(s, b, cut);
+    if (cut == 0) return FH_OK; // one record longer than the text so far: keep collecting (it moves on to the other buffer)
+    return fastq_text_on_device(s, s->bz_text[t], cut, s->bz_packed[t], s->bz_blk_a[t], s->bz_blk_b[t], s->bz_lines, s->bz_line_cap);
 }
 
 // Device-side FASTA: the staged chunk is raw file text (header lines, wrapped sequence lines); which bytes are

@@ -1860,9 +1860,11 @@ static int bgzf_fastq_to_device(BgzfSource &bz, fh_sketcher *h) {
     uint64_t cap = 0;
     int next = 0;
     if (int rc = fh_text_buffers(h, raw, &cap, &next)) return hfail(rc, "%s", fh_last_error());
-    const uint32_t max_members = (uint32_t)std::min<uint64_t>(8192, std::max<uint64_t>(1, cap / 8192));
+    uint64_t text_cap = 0;
+    if (int rc = fh_bgzf_text_capacity(h, &text_cap)) return hfail(rc, "%s", fh_last_error());
+    const uint32_t max_members = (uint32_t)std::min<uint64_t>(16384, std::max<uint64_t>(1, cap / 4096));
     // what follows the last whole record of a batch joins the next batch's text: leave it room
-    const uint64_t text_budget = cap - std::min<uint64_t>(cap / 8, (uint64_t)8 << 20);
+    const uint64_t text_budget = text_cap - std::min<uint64_t>(text_cap / 4, (uint64_t)32 << 20);
     struct Job {
         int slot;
         uint64_t bytes;

@@ -117,7 +117,7 @@ int fh_push_fastq_text(fh_sketcher *s, uint64_t len);
  * (`bytes` in all): in_off / in_len = a member's DEFLATE data counted from the start of the buffer (after the 18-byte BGZF
  * header, before the 8-byte trailer), out_off = the running sum of the isize before it, isize and crc32 = its trailer.
  * The inflated text of a batch need not end with a record: what follows the last whole one waits on the device for
- * the next push (so a batch's text plus one record must fit stage_bytes); FH_BGZF_LAST = the file ends here.  Replaces
+ * the next push (so a batch's text plus one record must fit fh_bgzf_text_capacity); FH_BGZF_LAST = the file ends here.  Replaces
  * the decompress-then-parse step of needletail's reader (lib.rs:60) for bgzip'd reads.  FH_ERR_INVALID: damaged
  * member (named in fh_last_error) or text that is not plain 4-line FASTQ; the sketcher has to be reset then. */
 typedef struct fh_bgzf_member {
@@ -125,6 +125,9 @@ typedef struct fh_bgzf_member {
 } fh_bgzf_member;
 #define FH_BGZF_LAST 1u
 int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint32_t flags);
+/* Text one batch may inflate to, the carried-over partial record included (8 x stage_bytes, at most 1 GiB: a wavefront
+ * per member only fills the device with thousands of members in flight). */
+int fh_bgzf_text_capacity(fh_sketcher *s, uint64_t *cap);
 /* Device-side FASTA parsing: the staged text is raw (multi-line) FASTA.  A line that begins with '>' is a header
  * (dropped; it ends the previous record: one breaker byte is emitted), every other line is sequence: its bytes are
  * kept except ' ', '\t', '\r' and the newline itself, so k-mers span line breaks exactly as they do after
