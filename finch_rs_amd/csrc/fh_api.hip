@@ -168,6 +168,17 @@ struct fh_sketcher {
     // fh_push_bgzf_fastq: the batch as it came (member table + DEFLATE bytes), and text / packed buffers of its own:
     // a wavefront per member only fills the chip with thousands of members in flight, i.e. hundreds of MB of text per batch
     uint8_t *d_comp = nullptr;
+    BgzfMember *d_bz_members = nullptr;
+    uint64_t bz_comp_cap = 0, bz_acc_bytes = 0, bz_acc_text = 0; // FH_BGZF_MORE: what has been collected for the next launch
+    uint32_t bz_acc_n = 0;
+    uint64_t bz_batch_left = 0; // bytes of the previous launch's text that lead this one's
+    // every push of a batch inflates on a side stream of its own while the host reads the next members; the push
+    // without FH_BGZF_MORE joins them
+    static constexpr int BZ_STREAMS = 4;
+    hipStream_t bz_stream[BZ_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t bz_done[BZ_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+    bool bz_used[BZ_STREAMS] = {false, false, false, false};
+    int bz_q = 0;
     uint32_t *d_bz_status = nullptr, *h_bz_status = nullptr;
     uint64_t bz_text_cap = 0;
     uint8_t *bz_text[2] = {nullptr, nullptr}, *bz_packed[2] = {nullptr, nullptr};
@@ -243,6 +254,16 @@ int set_device(const fh_sketcher *s) {
     return FH_OK;
 }
 
+// the inflate launches of an abandoned batch may still be running
+static void bgzf_quiesce(fh_sketcher *s) {
+    for (int q = 0; q < fh_sketcher::BZ_STREAMS; ++q)
+        if (s->bz_stream[q] && s->bz_used[q]) {
+            (void)hipStreamSynchronize(s->bz_stream[q]);
+            s->bz_used[q] = false;
+        }
+    s->bz_acc_n = 0;
+    s->bz_acc_bytes = s->bz_acc_text = 0;
+}
 int init_state(fh_sketcher *s) {
     HIP_TRY(launch_init_ctl(s->ctl, initial_tau(s), s->stream));
     s->stream_off = 0;
@@ -257,6 +278,7 @@ int init_state(fh_sketcher *s) {
     s->carry_len = 0;
     s->dprev_len = 0;
     s->bgzf_left_len = 0;
+    bgzf_quiesce(s);
     s->halo_len = 0;
     s->live_target = s->big_mode ? std::max<uint64_t>(4 * s->p.size, 1ull << 16) : (uint64_t)SMALL_MAX;
     s->finished = false;
@@ -1015,7 +1037,7 @@ uint64_t pool_max_bytes() {
 uint64_t handle_bytes(const fh_sketcher *s) {
     uint64_t b = (uint64_t)s->cap * (sizeof(Entry) + (s->kmer_hi ? 8 : 0)) + (uint64_t)s->live_cap * 8 + (uint64_t)s->shard_cap * N_SHARDS * 4;
     for (int i = 0; i < N_STAGE; ++i) b += 2 * s->stage_cap[i];
-    if (s->bz_text_cap) b += s->stage_bytes + 4 * s->bz_text_cap + s->bz_text_cap / 2;
+    if (s->bz_text_cap) b += s->bz_comp_cap + 4 * s->bz_text_cap + s->bz_text_cap / 2;
     return b + (uint64_t)s->out_cap * 32 + (uint64_t)s->big_cap * 24;
 }
 bool same_params(const fh_params &a, const fh_params &b) {
@@ -1204,7 +1226,15 @@ void destroy_handle(fh_sketcher *s) {
     }
     (void)hipFree(s->d_text_tot);
     (void)hipFree(s->d_lines);
+    for (int q = 0; q < fh_sketcher::BZ_STREAMS; ++q) {
+        if (s->bz_stream[q]) {
+            (void)hipStreamSynchronize(s->bz_stream[q]);
+            (void)hipStreamDestroy(s->bz_stream[q]);
+        }
+        if (s->bz_done[q]) (void)hipEventDestroy(s->bz_done[q]);
+    }
     (void)hipFree(s->d_comp);
+    (void)hipFree(s->d_bz_members);
     (void)hipFree(s->d_bz_status);
     (void)hipFree(s->bz_lines);
     for (int i = 0; i < 2; ++i) {
@@ -1501,6 +1531,7 @@ static_assert(sizeof(fh_bgzf_member) == sizeof(BgzfMember) && offsetof(fh_bgzf_m
 // fh_text_buffers, `n_members` fh_bgzf_member records followed by the members' DEFLATE bytes (`bytes` in all; in_off
 // counts from the start of the buffer).  The text of a batch rarely ends with a record: what follows its last whole
 // record stays on the device and leads the text of the next push; FH_BGZF_LAST says there is no next push.
+constexpr uint32_t BZ_MAX_MEMBERS = 1u << 16; // members one launch may take (8 GB of text at bgzip's member size)
 // buffers of the device-side BGZF path: text of up to 8 staging buffers' worth per batch (1 GiB at most)
 static int ensure_bgzf_buffers(fh_sketcher *s) {
     if (s->bz_text_cap) return FH_OK;
@@ -1514,16 +1545,24 @@ static int ensure_bgzf_buffers(fh_sketcher *s) {
     }
     s->bz_line_cap = (uint32_t)std::min<uint64_t>(cap / 8 + 64, 0x7FFFFFFFull);
     HIP_TRY(dev_malloc((void **)&s->bz_lines, (size_t)s->bz_line_cap * sizeof(uint32_t)));
-    HIP_TRY(dev_malloc((void **)&s->d_comp, s->stage_bytes + 4096));
+    // (DEFLATE never grows data by more than a few bytes per block: a batch's members are about as large as its text at worst)
+    s->bz_comp_cap = cap + cap / 64 + s->stage_bytes;
+    HIP_TRY(dev_malloc((void **)&s->d_comp, s->bz_comp_cap + 4096));
+    HIP_TRY(dev_malloc((void **)&s->d_bz_members, (size_t)BZ_MAX_MEMBERS * sizeof(BgzfMember)));
     HIP_TRY(dev_malloc((void **)&s->d_bz_status, 4 * sizeof(uint32_t)));
     HIP_TRY(host_malloc((void **)&s->h_bz_status, 4 * sizeof(uint32_t)));
     if (!s->d_text_tot) {
         HIP_TRY(dev_malloc((void **)&s->d_text_tot, 4 * sizeof(uint32_t)));
         HIP_TRY(host_malloc((void **)&s->h_text_tot, 4 * sizeof(uint32_t)));
     }
+    for (int q = 0; q < fh_sketcher::BZ_STREAMS; ++q) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->bz_stream[q], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s->bz_done[q], hipEventDisableTiming));
+    }
     s->bz_text_cap = cap;
     return FH_OK;
 }
+
 
 int fh_bgzf_text_capacity(fh_sketcher *s, uint64_t *cap) {
     if (!s || !cap) return fail(FH_ERR_INVALID, "null argument");
@@ -1542,7 +1581,7 @@ int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint3
     if (int rc = ensure_stage(s)) return rc;
     if (int rc = ensure_bgzf_buffers(s)) return rc;
     const int b = s->stage_next, t = s->bz_next;
-    const fh_bgzf_member *mt = (const fh_bgzf_member *)(s->h_stage[b] + STAGE_HEADROOM);
+    fh_bgzf_member *mt = (fh_bgzf_member *)(s->h_stage[b] + STAGE_HEADROOM);
     uint64_t text = 0;
     for (uint32_t i = 0; i < n_members; ++i) {
         const fh_bgzf_member &m = mt[i];
@@ -1551,21 +1590,64 @@ int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint3
             return fail(FH_ERR_INVALID, "BGZF member %u: bad table entry", i);
         text += m.isize;
     }
-    const uint64_t left = s->bgzf_left_len, total = left + text;
-    if (total > s->bz_text_cap || total >= (1ull << 31))
+    const bool first_of_batch = s->bz_acc_n == 0 && s->bz_acc_bytes == 0;
+    const uint64_t left = first_of_batch ? s->bgzf_left_len : s->bz_batch_left;
+    if (left + s->bz_acc_text + text > s->bz_text_cap || left + s->bz_acc_text + text >= (1ull << 31))
         return fail(FH_ERR_INVALID, "a FASTQ record and a batch of BGZF text do not fit the text buffer together");
-    // the packed buffer of this slot may still feed a pending range
-    if (int rc = drain(s)) return rc;
-    if (left) HIP_TRY(hipMemcpyAsync(s->bz_text[t], s->bgzf_left_ptr, left, hipMemcpyDeviceToDevice, s->stream));
-    s->bgzf_left_len = 0;
+    if (s->bz_acc_bytes + bytes > s->bz_comp_cap || (uint64_t)s->bz_acc_n + n_members > BZ_MAX_MEMBERS)
+        return fail(FH_ERR_INVALID, "too many BGZF members collected with FH_BGZF_MORE");
+    if (first_of_batch) {
+        // the packed buffer of this slot may still feed a pending range
+        if (int rc = drain(s)) return rc;
+        s->bz_batch_left = left;
+        s->bgzf_left_len = 0;
+        HIP_TRY(hipMemsetAsync(s->d_bz_status, 0, 4 * sizeof(uint32_t), s->stream));
+        if (left) HIP_TRY(hipMemcpyAsync(s->bz_text[t], s->bgzf_left_ptr, left, hipMemcpyDeviceToDevice, s->stream));
+    }
+    if (n_members) {
+        // the members join those of the batch's earlier pushes: their offsets now count from the start of the device-side
+        // byte and text areas; they are copied and inflated on a side stream while the caller reads on
+        for (uint32_t i = 0; i < n_members; ++i) {
+            mt[i].in_off += (uint32_t)s->bz_acc_bytes;
+            mt[i].out_off += (uint32_t)s->bz_acc_text;
+        }
+        const int q = s->bz_q;
+        s->bz_q = (q + 1) % fh_sketcher::BZ_STREAMS;
+        hipStream_t st = s->bz_stream[q];
+        // (the copies go through the main stream, which is idle while a batch collects: behind the side stream's previous
+        // kernel they would hold the caller's buffer for as long as that runs)
+        HIP_TRY(hipMemcpyAsync(s->d_bz_members + s->bz_acc_n, mt, (size_t)n_members * sizeof(fh_bgzf_member), hipMemcpyHostToDevice,
+                               s->stream));
+        HIP_TRY(hipMemcpyAsync(s->d_comp + s->bz_acc_bytes, s->h_stage[b] + STAGE_HEADROOM, bytes, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+        HIP_TRY(hipStreamWaitEvent(st, s->stage_done[b], 0));
+        s->stage_busy[b] = true;
+        s->stage_next = (b + 1) % N_STAGE;
+        HIP_TRY(launch_bgzf_inflate(s->d_comp, s->d_bz_members + s->bz_acc_n, n_members, s->bz_text[t] + left, s->d_bz_status, st));
+        HIP_TRY(hipEventRecord(s->bz_done[q], st));
+        s->bz_used[q] = true;
+        s->bz_acc_n += n_members;
+        s->bz_acc_bytes += (bytes + 255) & ~255ull;
+        s->bz_acc_text += text;
+    }
+    if (flags & FH_BGZF_MORE) {
+        if (flags & FH_BGZF_LAST) return fail(FH_ERR_INVALID, "FH_BGZF_MORE and FH_BGZF_LAST exclude each other");
+        if (s->stage_busy[b]) { // the caller refills this buffer next
+            HIP_TRY(hipEventSynchronize(s->stage_done[b]));
+            s->stage_busy[b] = false;
+        }
+        return FH_OK;
+    }
+    const uint64_t total = left + s->bz_acc_text;
+    s->bz_acc_n = 0;
+    s->bz_acc_bytes = s->bz_acc_text = 0;
+    for (int q = 0; q < fh_sketcher::BZ_STREAMS; ++q)
+        if (s->bz_used[q]) {
+            HIP_TRY(hipStreamWaitEvent(s->stream, s->bz_done[q], 0));
+            s->bz_used[q] = false;
+        }
     if (total == 0) return FH_OK;
-    HIP_TRY(hipMemsetAsync(s->d_bz_status, 0, 4 * sizeof(uint32_t), s->stream));
-    if (bytes) HIP_TRY(hipMemcpyAsync(s->d_comp, s->h_stage[b] + STAGE_HEADROOM, bytes, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
-    s->stage_busy[b] = true;
-    s->stage_next = (b + 1) % N_STAGE;
     s->bz_next = t ^ 1;
-    HIP_TRY(launch_bgzf_inflate(s->d_comp, (const BgzfMember *)s->d_comp, n_members, s->bz_text[t] + left, s->d_bz_status, s->stream));
     HIP_TRY(launch_fastq_cut(s->bz_text[t], (uint32_t)total, (flags & FH_BGZF_LAST) ? 1u : 0u, s->d_bz_status + 1, s->stream));
     HIP_TRY(hipMemcpyAsync(s->h_bz_status, s->d_bz_status, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));

@@ -691,54 +691,92 @@ struct BgzfSource : ByteSource {
         if (!inf::inflate_exact(*dec, p + hdr, tot - hdr - 8, text.data(), isize)) return -1;
         return text[0];
     }
-    // Whole members into dst: a table of n records at the front (room for max_members), their bytes behind it; members
-    // are taken while the table, the bytes (dst_cap) and the text they inflate to (text_budget) have room.  *eof: the
-    // input ended with the last member taken.  false: a member that is not BGZF, a truncated one, or one too large.
+    // Whole members into dst: a table of n records at the front (room for max_members), the members behind it exactly as
+    // they lie in the file -- the file is read straight into dst, large reads split over the source's threads, and the
+    // table points at the DEFLATE bytes between each member's header and trailer.  Members are taken while the table, dst
+    // and the text they inflate to (text_budget; *budget_hit: that was what stopped it) have room; what was read beyond the
+    // last one taken waits in cbuf for the next call.  *eof: the input ended with the last member taken.  false: a member
+    // that is not BGZF, a truncated one, or one too large.
+    uint64_t raw_text_seen = 0, raw_comp_seen = 0;
     bool raw_batch(uint8_t *dst, size_t dst_cap, uint32_t max_members, uint64_t text_budget, fh_bgzf_member *table, uint32_t *n_out,
-                   uint64_t *bytes_out, uint64_t *text_out, bool *eof) {
+                   uint64_t *bytes_out, uint64_t *text_out, bool *eof, bool *budget_hit) {
+        *budget_hit = false;
+        *eof = false;
+        *n_out = 0;
+        *bytes_out = *text_out = 0;
         join_prefetch();
-        if (cbuf.size() < ((size_t)16 << 20)) { // large reads from here on
-            RawBuf big((size_t)16 << 20);
-            memcpy(big.data(), cbuf.data() + c_lo, c_hi - c_lo);
-            c_hi -= c_lo;
-            c_lo = 0;
-            cbuf.swap(big);
-        }
-        size_t w = (size_t)max_members * sizeof(fh_bgzf_member); // write position in dst
+        const size_t w0 = ((size_t)max_members * sizeof(fh_bgzf_member) + 255) & ~(size_t)255;
+        if (dst_cap < w0 + 2 * 65536 + 64) return false;
+        // what an earlier call (or the first-byte probe) read but did not hand out comes first
+        size_t fill = c_hi - c_lo;
+        if (fill > dst_cap - w0) return false;
+        memcpy(dst + w0, cbuf.data() + c_lo, fill);
+        c_lo = c_hi = 0;
         uint32_t n = 0;
         uint64_t text = 0;
-        *eof = false;
-        for (;;) {
-            if (c_hi - c_lo < 18 && !fill_compressed(18)) {
-                if (c_hi - c_lo == 0 && in_eof) { *eof = true; break; }
-                return false; // a few stray bytes at the end
+        size_t off = 0; // bytes of dst + w0 consumed by the members taken
+        bool stop = false;
+        while (!stop) {
+            // members completely in [off, fill)
+            while (fill - off >= 18) {
+                const uint8_t *p = dst + w0 + off;
+                uint32_t hdr = 0;
+                const uint32_t tot = member_size(p, &hdr);
+                if (tot < hdr + 10u) return false;
+                if (fill - off < tot) break;
+                const uint32_t isize = p[tot - 4] | ((uint32_t)p[tot - 3] << 8) | ((uint32_t)p[tot - 2] << 16) | ((uint32_t)p[tot - 1] << 24);
+                if (isize > 65536u) return false;
+                if (text + isize > text_budget) {
+                    *budget_hit = true;
+                    stop = true;
+                    break;
+                }
+                if (n == max_members) {
+                    stop = true;
+                    break;
+                }
+                table[n].in_off = (uint32_t)(w0 + off + hdr);
+                table[n].in_len = tot - hdr - 8;
+                table[n].out_off = (uint32_t)text;
+                table[n].isize = isize;
+                table[n].crc32 = p[tot - 8] | ((uint32_t)p[tot - 7] << 8) | ((uint32_t)p[tot - 6] << 16) | ((uint32_t)p[tot - 5] << 24);
+                text += isize;
+                n++;
+                off += tot;
+                raw_text_seen += isize;
+                raw_comp_seen += tot;
             }
-            uint32_t hdr = 0;
-            const uint32_t tot = member_size(cbuf.data() + c_lo, &hdr);
-            if (tot < hdr + 10u) return false;
-            if (c_hi - c_lo < tot && !fill_compressed(tot)) return false; // truncated
-            const uint8_t *p = cbuf.data() + c_lo;
-            const uint32_t isize = p[tot - 4] | ((uint32_t)p[tot - 3] << 8) | ((uint32_t)p[tot - 2] << 16) | ((uint32_t)p[tot - 1] << 24);
-            if (isize > 65536u) return false;
-            const size_t in_len = tot - hdr - 8;
-            if (n == max_members || w + in_len + 8 > dst_cap || text + isize > text_budget) break;
-            memcpy(dst + w, p + hdr, in_len);
-            table[n].in_off = (uint32_t)w;
-            table[n].in_len = (uint32_t)in_len;
-            table[n].out_off = (uint32_t)text;
-            table[n].isize = isize;
-            table[n].crc32 = p[tot - 8] | ((uint32_t)p[tot - 7] << 8) | ((uint32_t)p[tot - 6] << 16) | ((uint32_t)p[tot - 5] << 24);
-            w += (in_len + 3) & ~(size_t)3;
-            text += isize;
-            n++;
-            c_lo += tot;
-            // keep the buffer topped up in large reads (the memcpy above is all the work there is per member)
-            if (c_hi - c_lo < (1u << 16) && !in_eof) fill_compressed(std::min<size_t>(cbuf.size() / 2, (size_t)8 << 20));
+            if (stop) break;
+            // more of the file: all dst has room for, in one read (a member needs at most 64 KiB + a header's worth)
+            const size_t room = dst_cap - w0 - fill;
+            if (in_eof || room < 65536 + 64) break;
+            // (read about what the text budget will take, going by the members seen so far: what is read beyond it has to be
+            // carried over to the next call)
+            const double per_text = raw_text_seen ? (double)raw_comp_seen / (double)raw_text_seen : 0.35;
+            const uint64_t text_left = text_budget > text ? text_budget - text : 0;
+            const size_t want = (size_t)std::min<uint64_t>(room, (uint64_t)((double)text_left * per_text * 1.03) + (256u << 10));
+            const size_t got = inner->read(dst + w0 + fill, want);
+            if (got == 0) in_eof = true;
+            fill += got;
+        }
+        if (in_eof && off == fill) *eof = true;
+        else if (in_eof && !stop && fill - off > 0 && n == 0) return false; // a truncated member or stray bytes at the end
+        else if (in_eof && !stop && fill - off > 0) { /* the tail is looked at again by the next call, which fails as above */ }
+        // the rest goes back to cbuf
+        const size_t rest = fill - off;
+        if (rest) {
+            if (cbuf.size() < rest) {
+                RawBuf big(std::max(rest, (size_t)1 << 20));
+                cbuf.swap(big);
+            }
+            memcpy(cbuf.data(), dst + w0 + off, rest);
+            c_lo = 0;
+            c_hi = rest;
         }
         *n_out = n;
-        *bytes_out = w;
+        *bytes_out = w0 + off;
         *text_out = text;
-        return n > 0 || *eof;
+        return n > 0 || *eof || *budget_hit;
     }
 
     struct Member { size_t in_off, in_len, out_off; uint32_t isize, crc; };
@@ -1869,11 +1907,15 @@ static int bgzf_fastq_to_device(BgzfSource &bz, fh_sketcher *h) {
         int slot;
         uint64_t bytes;
         uint32_t n;
-        bool last;
+        bool last, more; // more: only copied over; inflated together with the jobs that follow (FH_BGZF_MORE)
     };
     std::mutex mu;
     std::condition_variable cv;
     bool is_free[2] = {true, true}, producer_done = false, producer_ok = true;
+    constexpr uint32_t MAX_LAUNCH_MEMBERS = 1u << 16; // (fh_push_bgzf_fastq's limit)
+    // members are handed over ~1500 at a time (96 MiB of text): each push starts inflating at once, on one of four side
+    // streams, while the next ones are still being read, so the device fills up as the file comes in
+    constexpr uint64_t PUSH_TEXT = (uint64_t)96 << 20;
     std::vector<Job> ready;
     std::atomic<bool> abort{false};
     static const bool trace = getenv("FH_TRACE") != nullptr;
@@ -1884,6 +1926,8 @@ static int bgzf_fastq_to_device(BgzfSource &bz, fh_sketcher *h) {
     unsigned n_batches = 0;
     std::thread producer([&] {
         int slot = next;
+        uint64_t acc_text = 0; // text of the members handed over since the last launch
+        uint32_t acc_n = 0;
         for (;;) {
             {
                 const double t0 = trace ? now_s() : 0;
@@ -1893,12 +1937,20 @@ static int bgzf_fastq_to_device(BgzfSource &bz, fh_sketcher *h) {
                 if (abort) break;
                 is_free[slot] = false;
             }
-            Job job{slot, 0, 0, false};
+            Job job{slot, 0, 0, false, false};
             uint64_t text = 0;
+            bool budget_hit = false;
             const double t0 = trace ? now_s() : 0;
-            const bool ok = bz.raw_batch(raw[slot], cap, max_members, text_budget, (fh_bgzf_member *)raw[slot], &job.n, &job.bytes, &text,
-                                         &job.last);
+            const bool ok = bz.raw_batch(raw[slot], cap, std::min(max_members, MAX_LAUNCH_MEMBERS - acc_n),
+                                         std::min(text_budget - acc_text, PUSH_TEXT),
+                                         (fh_bgzf_member *)raw[slot], &job.n, &job.bytes, &text, &job.last, &budget_hit);
             if (trace) t_read += now_s() - t0;
+            // the push is full before the text budget is: the members that follow join the same batch of text
+            acc_text += text;
+            acc_n += job.n;
+            if (budget_hit && acc_text + 65536 <= text_budget) budget_hit = false; // (only this push's share was used up)
+            job.more = ok && !job.last && !budget_hit && job.n > 0 && acc_n < MAX_LAUNCH_MEMBERS;
+            if (!job.more) acc_text = acc_n = 0;
             std::lock_guard<std::mutex> g(mu);
             if (!ok) {
                 producer_ok = false;
@@ -1932,7 +1984,7 @@ static int bgzf_fastq_to_device(BgzfSource &bz, fh_sketcher *h) {
         t_pusher_waits += tw1 - tw0;
         n_batches++;
         if (rc == FH_OK) {
-            rc = fh_push_bgzf_fastq(h, job.bytes, job.n, job.last ? FH_BGZF_LAST : 0u);
+            rc = fh_push_bgzf_fastq(h, job.bytes, job.n, job.last ? FH_BGZF_LAST : job.more ? FH_BGZF_MORE : 0u);
             if (trace) t_push += now_s() - tw1;
             if (rc != FH_OK) {
                 msg = fh_last_error();

@@ -124,6 +124,9 @@ typedef struct fh_bgzf_member {
     uint32_t in_off, in_len, out_off, isize, crc32;
 } fh_bgzf_member;
 #define FH_BGZF_LAST 1u
+#define FH_BGZF_MORE 2u /* only copy these members over: they are inflated together with those of the following pushes, by the
+                         * first one without this flag (a pinned buffer of poorly compressed members holds too few of them to
+                         * fill the device); the table entries in the buffer are rewritten by the call */
 int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint32_t flags);
 /* Text one batch may inflate to, the carried-over partial record included (8 x stage_bytes, at most 1 GiB: a wavefront
  * per member only fills the device with thousands of members in flight). */

@@ -17,7 +17,7 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-FH_BGZF_LAST = 1
+FH_BGZF_LAST, FH_BGZF_MORE = 1, 2
 
 
 def deflate_raw(chunk: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, mem_level=8) -> bytes:
@@ -50,8 +50,10 @@ def fastq_text(n_reads, seed, rl_lo=30, rl_hi=300, noisy_quals=True):
     return b"".join(recs)
 
 
-def push_members(sk, chunks, deflated, batch_members, crc_of=None):
-    """feed (text chunk, its raw DEFLATE bytes) pairs to fh_push_bgzf_fastq, batch_members at a time"""
+def push_members(sk, chunks, deflated, batch_members, crc_of=None, launch_every=1):
+    """feed (text chunk, its raw DEFLATE bytes) pairs to fh_push_bgzf_fastq, batch_members at a time; only every
+    launch_every-th push (and the last) inflates, the others hand their members over with FH_BGZF_MORE"""
+    n_push = 0
     L, h = sk._L, sk._h
     bufs = (C.c_void_p * 2)()
     cap, nxt = C.c_uint64(), C.c_int()
@@ -77,7 +79,8 @@ def push_members(sk, chunks, deflated, batch_members, crc_of=None):
         blob = bytes(table) + bytes(body)
         assert len(blob) <= cap.value
         C.memmove(bufs[slot], blob, len(blob))
-        S.check(L.fh_push_bgzf_fastq(h, len(blob), len(take), FH_BGZF_LAST if last else 0))
+        n_push += 1
+        S.check(L.fh_push_bgzf_fastq(h, len(blob), len(take), FH_BGZF_LAST if last else (FH_BGZF_MORE if n_push % launch_every else 0)))
         slot ^= 1
         if last:
             break
@@ -115,11 +118,11 @@ def test_device_inflate_reproduces_the_text_for_every_block_type(mode):
     k, size = 21, 500
     o = O.OracleSketcher(O.MASH, size, k, 0, 0.001)
     assert o.sketch_stream(text) == 2
-    for block, batch in ((65280, 7), (4001, 64), (65280, 1000)):
+    for block, batch, every in ((65280, 7, 1), (4001, 64, 3), (65280, 1000, 1), (20000, 5, 1000)):
         chunks = [text[i:i + block] for i in range(0, len(text), block)] + [b""]
         deflated = [deflate_raw(c, **kw) for c in chunks]
         sk = new_sketcher(size, k)
-        push_members(sk, chunks, deflated, batch)
+        push_members(sk, chunks, deflated, batch, launch_every=every)
         assert_is_oracle_sketch(sk, o)
         sk.close()
 
