@@ -31,6 +31,9 @@ namespace fh {
 
 namespace {
 
+#ifndef BZ_FENCE_SCOPE
+#define BZ_FENCE_SCOPE "workgroup"
+#endif
 constexpr int LIT_BITS = 10, DIST_BITS = 9, CL_BITS = 7;
 constexpr u32 KIND_LIT = 0, KIND_BASE = 1, KIND_EOB = 2, KIND_LONG = 3;
 
@@ -129,6 +132,32 @@ __device__ bool build_table(const uint8_t *lens, u32 n, int R, u32 *table, CodeS
     return true;
 }
 
+// Second pass over the literal/length table: where a literal's code leaves room in the index for another whole literal
+// code, the entry takes both (bit 10 set, code lengths summed in bits 0-3, the first one's kept in bits 4-7, the second
+// byte in bits 24-31) -- sequence and quality lines that found no match are runs of literals with short codes.
+constexpr u32 PAIR_FLAG = 1u << 10;
+__device__ void pair_literals(u32 *lit, u32 lane) {
+    u32 upd[(1 << LIT_BITS) / 64];
+#pragma unroll
+    for (int r = 0; r < (1 << LIT_BITS) / 64; ++r) {
+        const u32 i = (u32)r * 64u + lane;
+        const u32 e1 = lit[i];
+        const u32 nb1 = e1 & 15u;
+        u32 out = e1;
+        if (((e1 >> 8) & 3u) == KIND_LIT && nb1 != 0u && nb1 < (u32)LIT_BITS) {
+            const u32 e2 = lit[i >> nb1]; // the bits behind the first code, zeros beyond the index: valid if its code ends inside it
+            const u32 nb2 = e2 & 15u;
+            if (((e2 >> 8) & 3u) == KIND_LIT && nb2 != 0u && nb1 + nb2 <= (u32)LIT_BITS)
+                out = (nb1 + nb2) | (nb1 << 4) | (KIND_LIT << 8) | PAIR_FLAG | (((e1 >> 16) & 0xFFu) << 16) | (((e2 >> 16) & 0xFFu) << 24);
+        }
+        upd[r] = out;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < (1 << LIT_BITS) / 64; ++r) lit[(u32)r * 64u + lane] = upd[r];
+    __syncthreads();
+}
+
 // a code longer than the table's index, bit by bit from the canonical description (v: the next bits, first bit lowest)
 __device__ u32 decode_long(const CodeSet &cs, int R, int which, u32 v) {
     u32 code = __brev(v & ((1u << R) - 1u)) >> (32 - R);
@@ -185,22 +214,23 @@ __device__ __forceinline__ u64 rd_used_bits(const Reader &r) { return r.base_bit
 
 // One match: `len` bytes from `dist` bytes back.  Nothing else writes either range while this runs.
 __device__ __forceinline__ void copy_match(uint8_t *d, const uint8_t *s, u32 len, u32 dist) {
-    if (dist >= len) { // apart: loads first, stores after, 16 bytes at a time
-        u32 j = 0;
-        for (; j + 16u <= len; j += 16u) {
-            u64 a, b;
-            __builtin_memcpy(&a, s + j, 8);
-            __builtin_memcpy(&b, s + j + 8u, 8);
-            __builtin_memcpy(d + j, &a, 8);
-            __builtin_memcpy(d + j + 8u, &b, 8);
+    if (dist >= len) { // apart: up to 64 bytes are loaded before the first of them is stored (one wait, not one per word)
+        for (u32 j = 0; j < len; j += 64u) {
+            const u32 n = len - j < 64u ? len - j : 64u;
+            u64 r[8];
+#pragma unroll
+            for (u32 q = 0; q < 8u; ++q)
+                if (8u * q < n) __builtin_memcpy(&r[q], s + j + 8u * q, 8); // (may read up to 7 bytes past the match: never stored)
+#pragma unroll
+            for (u32 q = 0; q < 8u; ++q) {
+                if (8u * q + 8u <= n) {
+                    __builtin_memcpy(d + j + 8u * q, &r[q], 8);
+                } else if (8u * q < n) {
+                    u64 w = r[q];
+                    for (u32 t = 8u * q; t < n; ++t, w >>= 8) d[j + t] = (uint8_t)w;
+                }
+            }
         }
-        if (j + 8u <= len) {
-            u64 a;
-            __builtin_memcpy(&a, s + j, 8);
-            __builtin_memcpy(d + j, &a, 8);
-            j += 8u;
-        }
-        for (; j < len; ++j) d[j] = s[j];
     } else if (dist >= 8u) { // overlapping, period >= 8: a word never reads bytes of its own store
         u32 j = 0;
         for (; j + 8u <= len; j += 8u) {
@@ -221,12 +251,12 @@ __device__ __forceinline__ void copy_match(uint8_t *d, const uint8_t *s, u32 len
 }
 
 // The queued symbols of one group, one per lane, written out.  pos / info: the lane's token (info: low 9 bits match
-// length, 0 = literal; high half the distance or the literal byte).  A lane copies when everything its match reads
+// length, 0 = literal; high half the distance, or the literal byte -- two of them if bit 9 is set).  A lane copies when everything its match reads
 // has been written: sources below `W`, the output position of the first token not yet written.
 __device__ void resolve_group(uint8_t *out, u32 tpos, u32 tinfo, u32 ntok, u32 lane) {
     const u32 len = tinfo & 0x1FFu, hi = tinfo >> 16;
     bool done = lane >= ntok;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // earlier groups' bytes
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, BZ_FENCE_SCOPE); // earlier groups' bytes
     for (;;) {
         const unsigned long long pending = __ballot(!done);
         if (pending == 0ull) break;
@@ -234,6 +264,7 @@ __device__ void resolve_group(uint8_t *out, u32 tpos, u32 tinfo, u32 ntok, u32 l
         if (!done) {
             if (len == 0u) {
                 out[tpos] = (uint8_t)hi;
+                if (tinfo & 0x200u) out[tpos + 1u] = (uint8_t)(hi >> 8);
                 done = true;
             } else {
                 const u32 src = tpos - hi;
@@ -244,7 +275,7 @@ __device__ void resolve_group(uint8_t *out, u32 tpos, u32 tinfo, u32 ntok, u32 l
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, BZ_FENCE_SCOPE);
     }
 }
 
@@ -379,6 +410,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const 
             fail = BZ_BAD_BLOCK;
             break;
         }
+        pair_literals(L.lit, lane);
         for (;;) { // the block's symbols
             rd_fill(r, lane);
             u32 e = rfl(L.lit[(u32)r.bb & ((1u << LIT_BITS) - 1u)]);
@@ -393,8 +425,12 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const 
             if (kind == KIND_EOB) break;
             u32 info, adv;
             if (kind == KIND_LIT) {
-                info = (e >> 16) << 16;
+                info = (e >> 16) << 16; // one byte, or two with the flag in bit 9
                 adv = 1;
+                if (e & PAIR_FLAG) {
+                    info |= 0x200u;
+                    adv = 2;
+                }
             } else {
                 const u32 len = (e >> 16) + rd_take(r, (e >> 4) & 15u);
                 rd_fill(r, lane);
