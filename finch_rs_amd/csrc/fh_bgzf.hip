@@ -36,6 +36,9 @@ namespace {
 #endif
 constexpr int LIT_BITS = 10, DIST_BITS = 9, CL_BITS = 7;
 constexpr u32 KIND_LIT = 0, KIND_BASE = 1, KIND_EOB = 2, KIND_LONG = 3;
+// "no such code" in the literal/length table: the kind of the end-of-block symbol with a length of 0, so that the symbol
+// loop's common cases (literal, match) need no validity test of their own
+constexpr u32 LIT_STOP = KIND_EOB << 8;
 
 // table entry: bits 0-3 code length (0 = no such code), 4-7 extra bits, 8-9 kind, 16-31 literal / base value / symbol
 __device__ __forceinline__ u32 make_entry(u32 nbits, u32 extra, u32 kind, u32 value) {
@@ -45,7 +48,7 @@ __device__ __forceinline__ u32 litlen_entry(u32 sym, u32 nbits) {
     if (sym < 256u) return make_entry(nbits, 0, KIND_LIT, sym);
     if (sym == 256u) return make_entry(nbits, 0, KIND_EOB, 0);
     const u32 i = sym - 257u;
-    if (i >= 29u) return 0u; // 286, 287: in the fixed code's space, never valid
+    if (i >= 29u) return LIT_STOP; // 286, 287: in the fixed code's space, never valid
     if (i < 8u) return make_entry(nbits, 0, KIND_BASE, 3u + i);
     if (i == 28u) return make_entry(nbits, 0, KIND_BASE, 258u);
     const u32 extra = (i - 4u) >> 2;
@@ -74,12 +77,15 @@ struct Lds {
 };
 
 __device__ __forceinline__ u32 rfl(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
+// v_writelane_b32 (clang has no builtin of that name; the LLVM intrinsic takes care of M0 for the lane select)
+extern "C" __device__ int fh_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ u32 writelane(u32 value, u32 lane_idx, u32 vec) { return (u32)fh_llvm_writelane((int)value, (int)lane_idx, (int)vec); }
 
 // Huffman table of the n code lengths at `lens`: root table of 2^R entries (codes longer than R bits: KIND_LONG, decoded
 // from `cs`).  false: over-subscribed lengths.
 __device__ bool build_table(const uint8_t *lens, u32 n, int R, u32 *table, CodeSet &cs, int which, u32 lane) {
     if (lane < 16u) cs.count[lane] = 0u;
-    for (u32 i = lane; i < (1u << R); i += 64u) table[i] = 0u;
+    for (u32 i = lane; i < (1u << R); i += 64u) table[i] = which == 0 ? LIT_STOP : 0u;
     __syncthreads();
     for (u32 s = lane; s < n; s += 64u) {
         const u32 l = lens[s];
@@ -166,7 +172,7 @@ __device__ u32 decode_long(const CodeSet &cs, int R, int which, u32 v) {
         const u32 idx = code - cs.first[l];
         if (idx < cs.count[l]) return symbol_entry(which, cs.sorted[cs.offs[l] + idx], l);
     }
-    return 0u;
+    return which == 0 ? LIT_STOP : 0u;
 }
 
 // The compressed bytes of one member as a bit stream.  All of it wave-uniform except win / nxt (lane i: word i of the
@@ -414,24 +420,18 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const 
         for (;;) { // the block's symbols
             rd_fill(r, lane);
             u32 e = rfl(L.lit[(u32)r.bb & ((1u << LIT_BITS) - 1u)]);
-            if (((e >> 8) & 3u) == KIND_LONG) e = rfl(decode_long(L.cs[0], LIT_BITS, 0, (u32)r.bb));
-            const u32 nb = e & 15u;
-            if (nb == 0u) {
-                fail = BZ_BAD_CODE;
-                break;
+            u32 kind = (e >> 8) & 3u;
+            if (kind == KIND_LONG) {
+                e = rfl(decode_long(L.cs[0], LIT_BITS, 0, (u32)r.bb));
+                kind = (e >> 8) & 3u;
             }
-            rd_take(r, nb);
-            const u32 kind = (e >> 8) & 3u;
-            if (kind == KIND_EOB) break;
             u32 info, adv;
-            if (kind == KIND_LIT) {
-                info = (e >> 16) << 16; // one byte, or two with the flag in bit 9
-                adv = 1;
-                if (e & PAIR_FLAG) {
-                    info |= 0x200u;
-                    adv = 2;
-                }
-            } else {
+            if (kind == KIND_LIT) { // one byte, or two (PAIR_FLAG, which becomes bit 9 of the token)
+                rd_take(r, e & 15u);
+                info = (e & 0xFFFF0000u) | ((e & PAIR_FLAG) >> 1);
+                adv = 1u + ((e >> 10) & 1u);
+            } else if (kind == KIND_BASE) {
+                rd_take(r, e & 15u);
                 const u32 len = (e >> 16) + rd_take(r, (e >> 4) & 15u);
                 rd_fill(r, lane);
                 u32 d = rfl(L.dist[(u32)r.bb & ((1u << DIST_BITS) - 1u)]);
@@ -449,28 +449,27 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const 
                 }
                 info = (dist << 16) | len;
                 adv = len;
-            }
-            if (pos + adv > isize) {
-                fail = BZ_BAD_SIZE;
+            } else { // end of block, or a bit pattern without a code
+                if ((e & 15u) == 0u) fail = BZ_BAD_CODE;
+                rd_take(r, e & 15u);
                 break;
             }
-            if (lane == ntok) { // the queue: token i sits in lane i
-                tpos = pos;
-                tinfo = info;
-            }
+            tpos = writelane(pos, ntok, tpos); // the queue: token i sits in lane i
+            tinfo = writelane(info, ntok, tinfo);
             pos += adv;
             if (++ntok == 64u) {
-                resolve_group(out, tpos, tinfo, ntok, lane);
-                ntok = 0;
-                if (rd_used_bits(r) > in_bits + 64u) { // (a damaged stream wandering off: stop before the table walk is long)
-                    fail = BZ_OVERRUN;
+                // (nothing has been written for these tokens yet: sizes are checked once per group)
+                if (pos > isize || rd_used_bits(r) > in_bits + 64u) {
+                    fail = pos > isize ? BZ_BAD_SIZE : BZ_OVERRUN;
                     break;
                 }
+                resolve_group(out, tpos, tinfo, ntok, lane);
+                ntok = 0;
             }
         }
     }
-    resolve_group(out, tpos, tinfo, ntok, lane);
     if (!fail && pos != isize) fail = BZ_BAD_SIZE;
+    if (!fail) resolve_group(out, tpos, tinfo, ntok, lane);
     if (!fail && ((rd_used_bits(r) + 7u) >> 3) != m.in_len) fail = BZ_OVERRUN;
     if (fail && lane == 0) atomicMax(status, (mi << 8) | fail);
 }

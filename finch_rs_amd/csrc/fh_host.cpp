@@ -2752,6 +2752,44 @@ int finch_read_file_probe(const char *path, uint64_t chunk, uint32_t read_thread
 
 // What the parsers and the device-side text paths read from an input image after magic-byte sniffing and decompression,
 // requested `chunk` bytes at a time (large requests take BgzfSource's inflate-into-the-caller's-buffer route).
+int finch_bgzf_batch_probe(const uint8_t *data, uint64_t len, uint64_t buf_bytes, uint32_t max_members, uint64_t text_budget,
+                           uint8_t *text_out, uint64_t text_cap, uint64_t *text_len, uint64_t *n_batches, int *first_byte) {
+    if ((!data && len) || !text_out || !text_len || !n_batches || !first_byte) return hfail(FH_ERR_INVALID, "bad argument");
+    std::unique_ptr<ByteSource> src;
+    setenv("FINCH_BGZF_THREADS", "2", 0); // (a BgzfSource only stands in front of gzip input when it may use threads)
+    if (int rc = open_source(std::make_unique<MemSource>(data, (size_t)len), src)) return rc;
+    finch::BgzfSource *bz = dynamic_cast<finch::BgzfSource *>(src.get());
+    if (!bz) return hfail(FH_ERR_INVALID, "not gzip input");
+    *first_byte = bz->peek_first_text_byte();
+    std::vector<uint8_t> buf(buf_bytes);
+    uint64_t out = 0, batches = 0;
+    std::unique_ptr<finch::inf::Decoder> dec(new finch::inf::Decoder());
+    for (;;) {
+        uint32_t n = 0;
+        uint64_t bytes = 0, text = 0;
+        bool eof = false, budget_hit = false;
+        if (!bz->raw_batch(buf.data(), buf.size(), max_members, text_budget, (fh_bgzf_member *)buf.data(), &n, &bytes, &text, &eof, &budget_hit))
+            return hfail(FH_ERR_INVALID, "not a plain chain of BGZF members");
+        batches++;
+        const fh_bgzf_member *mt = (const fh_bgzf_member *)buf.data();
+        for (uint32_t i = 0; i < n; ++i) { // what the device would do with the table: inflate every member where it says
+            const fh_bgzf_member &m = mt[i];
+            if ((uint64_t)m.in_off + m.in_len + 8 > bytes + 8 || out + m.out_off + m.isize > text_cap) return hfail(FH_ERR_INVALID, "bad table entry");
+            std::vector<uint8_t> in(buf.begin() + m.in_off, buf.begin() + m.in_off + m.in_len);
+            in.resize(in.size() + 16);
+            if (!finch::inf::inflate_exact(*dec, in.data(), m.in_len, text_out + out + m.out_off, m.isize) ||
+                finch::inf::crc32_fast(0, text_out + out + m.out_off, m.isize) != m.crc32)
+                return hfail(FH_ERR_INVALID, "member %u of batch %llu does not inflate to its trailer", i, (unsigned long long)batches);
+        }
+        out += text;
+        if (eof) break;
+        if (n == 0 && !budget_hit) return hfail(FH_ERR_INVALID, "no progress");
+    }
+    *text_len = out;
+    *n_batches = batches;
+    return FH_OK;
+}
+
 int finch_source_probe(const uint8_t *data, uint64_t len, uint64_t chunk, uint8_t *dst, uint64_t cap, uint64_t *got) {
     if ((!data && len) || !dst || !got || chunk == 0) return hfail(FH_ERR_INVALID, "bad argument");
     std::unique_ptr<ByteSource> src;

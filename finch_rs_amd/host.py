@@ -107,6 +107,8 @@ _SYMS = {
     "finch_read_file_probe": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "finch_source_probe": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "finch_debug_device_inflate": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "finch_bgzf_batch_probe": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
 }
 class CDistance(C.Structure):
     _fields_ = [("containment", C.c_double), ("jaccard", C.c_double), ("mash_distance", C.c_double),
@@ -392,6 +394,16 @@ def fasta_count_chunked(data: bytes, chunk: int):
     buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
     _check(lib().finch_fasta_count_chunked(buf.ctypes.data, len(data), chunk, C.byref(n), C.byref(tb)))
     return n.value, tb.value
+
+
+def bgzf_batch_probe(data: bytes, buf_bytes: int, max_members: int, text_budget: int, cap: int):
+    """(text, batches, first byte) as the device-inflate reader would deal a BGZF image out, inflated on the host (test hook)"""
+    src = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+    out = np.zeros(max(cap, 1), np.uint8)
+    n, nb, fb = C.c_uint64(), C.c_uint64(), C.c_int()
+    _check(lib().finch_bgzf_batch_probe(src.ctypes.data, len(data), buf_bytes, max_members, text_budget, out.ctypes.data, cap,
+                                        C.byref(n), C.byref(nb), C.byref(fb)))
+    return out[:n.value].tobytes(), nb.value, fb.value
 
 
 def debug_device_inflate():

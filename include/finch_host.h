@@ -181,6 +181,12 @@ int finch_source_probe(const uint8_t *data, uint64_t len, uint64_t chunk, uint8_
 int finch_shard_probe(const uint8_t *data, uint64_t len, uint32_t k, uint64_t chunk_bytes, uint64_t max_chunks, uint64_t *meta,
                       uint8_t *halos, uint64_t *n_chunks, uint64_t *n_records, uint64_t *total_bases);
 
+/* Test hook (no device): the batches finch_sketch_files' reader hands to fh_push_bgzf_fastq for a BGZF image -- member
+ * tables and bytes in a buffer of buf_bytes, at most max_members / text_budget bytes of text per batch --, inflated on
+ * the host exactly where the tables say; text_out receives the whole text, *first_byte the reader's probe of it. */
+int finch_bgzf_batch_probe(const uint8_t *data, uint64_t len, uint64_t buf_bytes, uint32_t max_members, uint64_t text_budget,
+                           uint8_t *text_out, uint64_t text_cap, uint64_t *text_len, uint64_t *n_batches, int *first_byte);
+
 /* Test hook: inputs this process has sketched with the BGZF inflate on the device (finch_sketch_files /
  * finch_sketch_buffer: bgzip'd FASTQ unless FINCH_DEVICE_INFLATE=0), and how many of them it had to read again through the
  * host-side inflate because the device pass refused them. */

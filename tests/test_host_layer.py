@@ -512,3 +512,29 @@ def test_the_library_s_own_inflate_decodes_what_zlib_writes(monkeypatch):
         f.flush()
         env = dict(os.environ, FINCH_ZLIB_INFLATE="1", FINCH_BGZF_THREADS="1")
         assert subprocess.run([sys.executable, "-c", code, f.name], env=env, stdout=subprocess.PIPE, check=True).stdout == text
+
+
+def test_bgzf_reader_for_the_device_side_inflate():
+    """the member tables fh_push_bgzf_fastq is fed (BgzfSource::raw_batch): every member inflates, where the table says, to
+    the text -- whatever limit ends a batch (buffer, member count, text budget), for tiny and full-size members, with and
+    without the EOF marker; damage and foreign members are refused"""
+    rng = np.random.default_rng(21)
+    text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=120)),
+                                              bytes(rng.integers(35, 74, size=120, dtype=np.uint8))) for i in range(12000))  # ~3 MB
+    for block, eof_marker in ((60000, True), (65280, False), (1500, True)):
+        z = _bgzf(text, block, eof_marker)
+        for buf_bytes, max_members, budget in ((1 << 20, 4096, 1 << 30), (300_000, 3, 1 << 30), (1 << 20, 4096, 200_000), (4 << 20, 16384, 70_000)):
+            got, batches, fb = H.bgzf_batch_probe(z, buf_bytes, max_members, budget, len(text) + 65536)
+            assert got == text and fb == ord("@"), (block, buf_bytes, max_members, budget)
+            assert batches > 1
+    z = _bgzf(text, 60000)
+    with pytest.raises(FinchError):  # a plain gzip member behind BGZF ones
+        H.bgzf_batch_probe(z + gzip.compress(b"@x\nA\n+\nI\n"), 1 << 20, 4096, 1 << 30, len(text) + 65536)
+    with pytest.raises(FinchError):  # truncated
+        H.bgzf_batch_probe(z[:len(z) // 2], 1 << 20, 4096, 1 << 30, len(text) + 65536)
+    with pytest.raises(FinchError):  # stray bytes at the end
+        H.bgzf_batch_probe(z + b"\x1f\x8b\x08", 1 << 20, 4096, 1 << 30, len(text) + 65536)
+    dmg = bytearray(z)
+    dmg[len(dmg) // 3] ^= 0x40
+    with pytest.raises(FinchError):
+        H.bgzf_batch_probe(bytes(dmg), 1 << 20, 4096, 1 << 30, len(text) + 65536)
