@@ -501,6 +501,9 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
                     f.write(b"\x1f\x8b\x08\x04\0\0\0\0\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(body) + 25) +
                             body + struct.pack("<II", zlib.crc32(ch), len(ch)))
             p = F.SketchParams.mash(1000, 1000, True, 21, 0)
+            # (the sketchers the earlier lines parked fill the handle cache: without room there every call would allocate and
+            # pin its buffers anew, which is not what a process that reads compressed files does)
+            H._lib.load().fh_release_cached()
             out = {"what": "finch_sketch_files on one %.0f MB FASTQ (%d reads) compressed with zlib level 1: as a single gzip stream "
                            "(one host thread inflates) and as BGZF (members inflated on the device, one wavefront each; bgzf_host_inflate: by the "
                            "call's read threads instead); k=21 n=1000"

@@ -375,7 +375,7 @@ struct FastGzSource : ByteSource {
     // text paths, the parser's 8 MiB buffer); what a request leaves over (< one match) and small requests go through
     // `win`.  Either way the last 32 KiB of the stream so far are kept in `hist`: that is where a match may reach when it
     // starts before the buffer at hand.
-    static constexpr size_t HIST = 32768, WIN = (size_t)1 << 18, DIRECT_MIN = (size_t)1 << 16;
+    static constexpr size_t HIST = 32768, WIN = (size_t)1 << 18, DIRECT_MIN = (size_t)1 << 16, CRC_SLICE = (size_t)1 << 18;
     std::vector<uint8_t> win, hist;
     size_t w_have = 0, w_out = 0, hist_len = 0;
     uint64_t member_out = 0; // bytes of the current member produced so far (a match may not reach before its start)
@@ -492,7 +492,11 @@ struct FastGzSource : ByteSource {
                 dec->ext_len = ext;
                 const uint8_t *ip = inbuf.data() + in_lo;
                 uint8_t *const before = op;
-                const inf::Status s = dec->run(ip, inbuf.data() + in_hi, op, oe, floor);
+                // (in slices of 256 KiB, so that the checksum reads what the decoder has just written from the cache: the
+                // CRC of a multi-megabyte span long after it was produced costs a tenth of the inflate time)
+                uint8_t *const slice_end = (size_t)(oe - op) > CRC_SLICE + inf::OUT_MARGIN ? op + CRC_SLICE + inf::OUT_MARGIN : oe;
+                inf::Status s = dec->run(ip, inbuf.data() + in_hi, op, slice_end, floor);
+                if (s == inf::NEED_OUTPUT && slice_end != oe) s = inf::MORE_SLICES;
                 in_lo = (size_t)(ip - inbuf.data());
                 const size_t fresh = (size_t)(op - before);
                 if (fresh) {
@@ -508,7 +512,7 @@ struct FastGzSource : ByteSource {
                     if (!refill()) bad = true; // the input ends inside a member: truncated
                 } else if (s == inf::NEED_OUTPUT) {
                     break;
-                }
+                } // (MORE_SLICES: go on where the slice ended)
                 continue;
             }
             if (st == TRAILER) {

@@ -273,7 +273,7 @@ static inline void pair_literals(uint32_t *table) {
 // ---------------------------------------------------------------------------------------------------------------------
 // the decoder
 // ---------------------------------------------------------------------------------------------------------------------
-enum Status { OK = 0, NEED_INPUT, NEED_OUTPUT, STREAM_END, BAD };
+enum Status { OK = 0, NEED_INPUT, NEED_OUTPUT, STREAM_END, BAD, MORE_SLICES /* callers that run() a buffer piecewise: not a run() result */ };
 constexpr ptrdiff_t OUT_MARGIN = 258 + 16 + 80; // longest match + copy overshoot + the literals of one refill (<= 2 per 2 bits)
 
 struct Decoder {
