@@ -28,6 +28,7 @@
 
 #include "fh_host_model.h"
 #include "fh_inflate.h"
+#include "fh_pargz.h"
 
 namespace finch {
 
@@ -596,6 +597,9 @@ struct RawBuf {
     void swap(RawBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
 };
 
+// (defined behind ParGzSource) the reader of gzip input that is not BGZF, given `threads` to work with
+static std::unique_ptr<ByteSource> make_gzip_reader(std::unique_ptr<ByteSource> in, unsigned threads);
+
 struct BgzfSource : ByteSource {
     std::unique_ptr<ByteSource> inner;
     unsigned n_thr;
@@ -835,8 +839,7 @@ struct BgzfSource : ByteSource {
                 pre->prefix.assign(cbuf.data() + c_lo, cbuf.data() + c_hi);
                 pre->inner = std::move(inner);
                 c_lo = c_hi = 0;
-                if (use_zlib_inflate()) tail = std::make_unique<GzSource>(std::move(pre));
-                else tail = std::make_unique<FastGzSource>(std::move(pre));
+                tail = make_gzip_reader(std::move(pre), n_thr);
                 return true;
             }
             if (tot < hdr + 8u + 2u) { bad = true; return false; }
@@ -1096,6 +1099,323 @@ struct XzSource : ByteSource {
         return (size_t)(ls.next_out - dst);
     }
 };
+
+// A gzip file whose first member is decoded by several threads (fh_pargz.h); members after the first, and anything the
+// parallel pass cannot make sense of, go through the sequential reader.  FINCH_PARGZ=0 turns it off; FINCH_PARGZ_CHUNK sets
+// the compressed bytes per thread and batch (default 4 MiB).
+struct ParGzSource : ByteSource {
+    std::unique_ptr<ByteSource> inner;
+    unsigned n_thr;
+    size_t chunk_bytes;
+    std::vector<uint8_t> cb; // compressed bytes [0, c_n) of the current batch (+ 64 bytes of zeros), decoding starts at bit c_bit
+    size_t c_n = 0;
+    uint64_t c_bit = 0;
+    bool in_eof = false, started = false, member_done = false, bad = false;
+    std::vector<uint8_t> window; // the last <= 32 KiB of text delivered: what the next batch's first chunk may refer to
+    uint32_t crc = 0;
+    uint64_t member_len = 0, delivered = 0;
+    std::vector<pargz::Chunk> ready; // text of the current batch, in order
+    size_t r_chunk = 0, r_off = 0;
+    std::unique_ptr<ByteSource> tail; // the sequential reader, once it has taken over
+    uint64_t n_batches = 0, n_chunks = 0, n_false_starts = 0, sym_total = 0;
+
+    ParGzSource(std::unique_ptr<ByteSource> in, unsigned threads) : inner(std::move(in)), n_thr(std::max(2u, threads)) {
+        const char *e = getenv("FINCH_PARGZ_CHUNK");
+        chunk_bytes = e ? (size_t)std::max(4096ll, atoll(e)) : ((size_t)4 << 20);
+    }
+    ~ParGzSource() override {
+        static const bool trace = getenv("FH_TRACE") != nullptr;
+        if (trace && n_batches)
+            fprintf(stderr, "[finch] parallel gzip: %llu batches, %llu chunks (%llu false starts), %.1f %% of the text decoded with markers, %u threads%s\n",
+                    (unsigned long long)n_batches, (unsigned long long)n_chunks, (unsigned long long)n_false_starts,
+                    100.0 * (double)sym_total / (double)std::max<uint64_t>(1, delivered), n_thr, tail ? "; sequential reader took over" : "");
+    }
+    bool failed() const override { return bad || (tail && tail->failed()); }
+    bool can_rewind() const override { return inner ? inner->can_rewind() : (tail && tail->can_rewind()); }
+    bool rewind() override {
+        if (!inner || !inner->rewind()) return false; // (once the sequential reader owns the input there is no way back)
+        c_n = 0;
+        c_bit = 0;
+        in_eof = started = member_done = bad = false;
+        window.clear();
+        crc = 0;
+        member_len = delivered = 0;
+        ready.clear();
+        r_chunk = r_off = 0;
+        tail.reset();
+        return true;
+    }
+    unsigned threads_hint() const override { return n_thr; }
+
+    void fill_to(size_t want) { // cb holds at least `want` bytes (+ padding) if the input has them
+        if (cb.size() < want + 64) cb.resize(want + 64);
+        while (!in_eof && c_n < want) {
+            const size_t got = inner->read(cb.data() + c_n, want - c_n);
+            if (got == 0) in_eof = true;
+            c_n += got;
+        }
+        memset(cb.data() + c_n, 0, 64);
+    }
+    // RFC 1952 header at cb[0, c_n): its length, 0 if more bytes are needed, -1 if it is not one
+    long header_len() const {
+        const uint8_t *p = cb.data();
+        const size_t n = c_n;
+        if (n < 10) return 0;
+        if (p[0] != 0x1F || p[1] != 0x8B || p[2] != 8 || (p[3] & 0xE0)) return -1;
+        const uint8_t flg = p[3];
+        size_t off = 10;
+        if (flg & 4) {
+            if (n < off + 2) return 0;
+            const size_t xlen = p[off] | ((size_t)p[off + 1] << 8);
+            off += 2 + xlen;
+            if (n < off) return 0;
+        }
+        for (int bit : {8, 16})
+            if (flg & bit) {
+                const void *z = off < n ? memchr(p + off, 0, n - off) : nullptr;
+                if (!z) return n > ((size_t)1 << 20) ? -1 : 0;
+                off = (size_t)((const uint8_t *)z - p) + 1;
+            }
+        if (flg & 2) off += 2;
+        return n < off ? 0 : (long)off;
+    }
+    // Everything from the start of the file again through the sequential reader, minus what has been delivered already.
+    bool fall_back() {
+        ready.clear();
+        r_chunk = r_off = 0;
+        if (!inner->can_rewind() || !inner->rewind()) {
+            bad = true;
+            return false;
+        }
+        tail = std::make_unique<FastGzSource>(std::move(inner));
+        std::vector<uint8_t> skip((size_t)1 << 20);
+        uint64_t left = delivered;
+        while (left) {
+            const size_t g = tail->read(skip.data(), (size_t)std::min<uint64_t>(left, skip.size()));
+            if (g == 0) {
+                bad = true;
+                return false;
+            }
+            left -= g;
+        }
+        return true;
+    }
+    template <class F>
+    void parallel(size_t n, F f) { // f(i) for i in [0, n) on up to n_thr threads
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= n) break;
+                f(i);
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < std::min<size_t>(n_thr, n); ++t) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    }
+
+    // decode the next batch into `ready`; false: nothing more from this reader (end, error, or `tail` has taken over)
+    bool next_batch() {
+        ready.clear();
+        r_chunk = r_off = 0;
+        if (member_done || bad) return false;
+        const size_t batch_bytes = chunk_bytes * n_thr;
+        fill_to(batch_bytes);
+        if (!started) {
+            long h = header_len();
+            if (h == 0 && !in_eof) { // (a header longer than a batch: not worth a special case)
+                h = -1;
+            }
+            if (h <= 0) {
+                bad = true;
+                return false;
+            }
+            c_bit = (uint64_t)h * 8u;
+            started = true;
+        }
+        if ((c_bit >> 3) >= c_n) { // no block in sight
+            bad = true;
+            return false;
+        }
+        n_batches++;
+        const size_t n_c = std::max<size_t>(1, std::min<size_t>(n_thr, c_n / chunk_bytes));
+        std::vector<pargz::Chunk> ch(n_c);
+        ch[0].start_bit = c_bit;
+        ch[0].known_window = true;
+        const uint8_t *base = cb.data();
+        const size_t n = c_n;
+        // 1. where the other chunks begin
+        parallel(n_c - 1, [&](size_t k) {
+            const size_t i = k + 1;
+            std::unique_ptr<inf::Decoder> scratch(new inf::Decoder());
+            const uint64_t from = std::max<uint64_t>((uint64_t)i * chunk_bytes * 8u, c_bit + 1);
+            ch[i].start_bit = pargz::find_block_start(base, n, from, (uint64_t)(i + 1) * chunk_bytes * 8u, *scratch);
+        });
+        // 2. decode
+        parallel(n_c, [&](size_t i) {
+            if (ch[i].start_bit != UINT64_MAX) pargz::decode_chunk(base, n, ch, i, window.data(), window.size());
+        });
+        // 3. the chain of chunks that really follow each other
+        std::vector<size_t> live;
+        for (size_t i = 0; i < n_c;) {
+            live.push_back(i);
+            const pargz::Chunk &c = ch[i];
+            if (!c.ok || c.member_end || c.out_of_input) break;
+            size_t j = i + 1;
+            while (j < n_c && ch[j].start_bit != c.end_bit) j++;
+            if (j == n_c) { // (decode_chunk stops only where one of these holds)
+                bad = true;
+                return false;
+            }
+            for (size_t k = i + 1; k < j; ++k) n_false_starts += ch[k].start_bit != UINT64_MAX;
+            i = j;
+        }
+        n_chunks += live.size();
+        if (getenv("FH_TRACE_PARGZ"))
+            for (size_t li : live)
+                fprintf(stderr, "[pargz] batch %llu chunk %zu: bits %llu..%llu text %zu (+%zu sym) ok %d end %d ooi %d\n", (unsigned long long)n_batches, li,
+                        (unsigned long long)ch[li].start_bit, (unsigned long long)ch[li].end_bit, ch[li].n_bytes, ch[li].n_sym, ch[li].ok,
+                        ch[li].member_end, ch[li].out_of_input);
+        if (!ch[live.back()].ok) return fall_back();
+        // windows, then the markers (chunks with less than a window of marker-free text behind them need the text before)
+        std::vector<std::vector<uint8_t>> win_in(live.size());
+        std::vector<char> resolved(live.size(), 0);
+        std::vector<uint8_t> win = window;
+        bool ok = true;
+        for (size_t li = 0; li < live.size(); ++li) {
+            pargz::Chunk &c = ch[live[li]];
+            win_in[li] = win;
+            if (c.n_bytes >= pargz::WINDOW) {
+                win.assign(c.bytes.data() + c.n_bytes - pargz::WINDOW, c.bytes.data() + c.n_bytes);
+                continue;
+            }
+            ok = pargz::resolve_chunk(c, win_in[li].data() + win_in[li].size(), win_in[li].size()) && ok;
+            resolved[li] = 1;
+            win.insert(win.end(), c.head.begin(), c.head.end());
+            win.insert(win.end(), c.bytes.begin(), c.bytes.begin() + (long)c.n_bytes);
+            if (win.size() > pargz::WINDOW) win.erase(win.begin(), win.end() - pargz::WINDOW);
+        }
+        std::atomic<bool> all_ok{ok};
+        parallel(live.size(), [&](size_t li) {
+            if (resolved[li]) return;
+            pargz::Chunk &c = ch[live[li]];
+            if (!pargz::resolve_chunk(c, win_in[li].data() + win_in[li].size(), win_in[li].size())) all_ok = false;
+        });
+        if (!all_ok) return fall_back();
+        window = win;
+        for (size_t li : live) {
+            pargz::Chunk &c = ch[li];
+            crc = (uint32_t)crc32_combine(crc, c.crc, (z_off_t)c.text_len());
+            member_len += c.text_len();
+            sym_total += c.head.size();
+        }
+        // 4. where the batch ended
+        const pargz::Chunk &last = ch[live.back()];
+        if (last.member_end) {
+            size_t t = (size_t)((last.end_bit + 7) >> 3);
+            if (c_n < t + 8) fill_to(t + 8 + 65536);
+            if (c_n < t + 8) return fall_back(); // (truncated: the sequential reader reports it)
+            const uint8_t *p = cb.data() + t;
+            const uint32_t want_crc = p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+            const uint32_t want_len = p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
+            if (want_crc != crc || want_len != (uint32_t)member_len) { // (text has gone out already: there is no quiet way back)
+                bad = true;
+                return false;
+            }
+            member_done = true;
+            t += 8;
+            if (c_n > t || !in_eof) { // more members: the sequential reader's
+                auto pre = std::make_unique<PrefixedSource>();
+                pre->prefix.assign(cb.data() + t, cb.data() + c_n);
+                pre->inner = std::move(inner);
+                // (a clean end right here must not count as "empty file": look for a byte first)
+                uint8_t b;
+                if (pre->read(&b, 1) == 1) {
+                    auto pre2 = std::make_unique<PrefixedSource>();
+                    pre2->prefix.assign(1, b);
+                    pre2->inner = std::move(pre);
+                    tail = std::make_unique<FastGzSource>(std::move(pre2));
+                }
+            }
+        } else if (last.out_of_input) {
+            // not one whole block in a batch's worth of bytes (or in the rest of the file: truncated): the sequential
+            // reader's case
+            if (live.size() == 1 && last.end_bit == c_bit) return fall_back();
+            const size_t keep_from = (size_t)(last.end_bit >> 3);
+            memmove(cb.data(), cb.data() + keep_from, c_n - keep_from);
+            c_n -= keep_from;
+            c_bit = last.end_bit & 7u;
+        } else {
+            bad = true;
+            return false;
+        }
+        ready.reserve(live.size());
+        for (size_t li : live) ready.push_back(std::move(ch[li]));
+        return true;
+    }
+
+    size_t read(uint8_t *dst, size_t cap) override {
+        size_t n = 0;
+        while (n < cap && !bad) {
+            if (tail && r_chunk >= ready.size()) { // (the last batch of the first member goes out first)
+                const size_t g = tail->read(dst + n, cap - n);
+                n += g;
+                delivered += g;
+                if (g == 0) break;
+                continue;
+            }
+            if (r_chunk < ready.size()) {
+                // segments of the ready text that fit the request, copied by several threads when there is much of it
+                struct Seg { const uint8_t *p; size_t len, at; };
+                std::vector<Seg> segs;
+                size_t m = 0;
+                while (r_chunk < ready.size() && n + m < cap) {
+                    const pargz::Chunk &c = ready[r_chunk];
+                    const size_t total = c.text_len();
+                    if (r_off >= total) {
+                        r_chunk++;
+                        r_off = 0;
+                        continue;
+                    }
+                    const bool in_head = r_off < c.head.size();
+                    const uint8_t *p = in_head ? c.head.data() + r_off : c.bytes.data() + (r_off - c.head.size());
+                    const size_t len = std::min(cap - n - m, (in_head ? c.head.size() : total) - r_off);
+                    segs.push_back(Seg{p, len, n + m});
+                    m += len;
+                    r_off += len;
+                }
+                if (m >= ((size_t)8 << 20) && n_thr > 1) {
+                    const size_t per = (m + n_thr - 1) / n_thr;
+                    parallel(n_thr, [&](size_t t) {
+                        const size_t lo = t * per, hi = std::min(m, lo + per);
+                        size_t pos = 0;
+                        for (const Seg &sg : segs) {
+                            const size_t a = std::max(lo, pos), b = std::min(hi, pos + sg.len);
+                            if (a < b) memcpy(dst + sg.at + (a - pos), sg.p + (a - pos), b - a);
+                            pos += sg.len;
+                        }
+                    });
+                } else {
+                    for (const Seg &sg : segs) memcpy(dst + sg.at, sg.p, sg.len);
+                }
+                n += m;
+                delivered += m;
+                continue;
+            }
+            if (!next_batch() && !tail) break;
+        }
+        return n;
+    }
+};
+
+static std::unique_ptr<ByteSource> make_gzip_reader(std::unique_ptr<ByteSource> in, unsigned threads) {
+    if (use_zlib_inflate()) return std::make_unique<GzSource>(std::move(in));
+    const char *e = getenv("FINCH_PARGZ");
+    if (threads > 1 && !(e && e[0] == '0')) return std::make_unique<ParGzSource>(std::move(in), threads);
+    return std::make_unique<FastGzSource>(std::move(in));
+}
 
 // needletail parse_fastx_reader: sniff two magic bytes (lib.rs:60)
 static int open_source(std::unique_ptr<ByteSource> raw, std::unique_ptr<ByteSource> &out, bool *is_gz = nullptr,

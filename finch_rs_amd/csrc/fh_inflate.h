@@ -273,7 +273,11 @@ static inline void pair_literals(uint32_t *table) {
 // ---------------------------------------------------------------------------------------------------------------------
 // the decoder
 // ---------------------------------------------------------------------------------------------------------------------
-enum Status { OK = 0, NEED_INPUT, NEED_OUTPUT, STREAM_END, BAD, MORE_SLICES /* callers that run() a buffer piecewise: not a run() result */ };
+enum Status {
+    OK = 0, NEED_INPUT, NEED_OUTPUT, STREAM_END, BAD,
+    MORE_SLICES, // callers that run() a buffer piecewise: not a run() result
+    BLOCK_END,   // run() with stop_at_block_end: a block has just ended (the last one too: DONE is reported by the next call)
+};
 constexpr ptrdiff_t OUT_MARGIN = 258 + 16 + 80; // longest match + copy overshoot + the literals of one refill (<= 2 per 2 bits)
 
 struct Decoder {
@@ -290,6 +294,18 @@ struct Decoder {
     // delivered here).  A match may reach into it.
     const uint8_t *ext_end = nullptr;
     size_t ext_len = 0;
+    bool stop_at_block_end = false; // (fh_pargz.h: a chunk ends where the next one was found to begin)
+
+    // start in the middle of a stream: the next bit to decode is bit (bit & 7) of *in; `in` is left behind that byte
+    void start_at_bit(const uint8_t *&in, unsigned bit) {
+        reset();
+        bitbuf = (uint64_t)(*in++ >> (bit & 7u));
+        bitcnt = 8 - (int)(bit & 7u);
+    }
+    // bits of the stream consumed so far, given where `in` stands relative to the start of the stream's buffer
+    uint64_t bit_position(const uint8_t *in, const uint8_t *base) const { return (uint64_t)(in - base) * 8u - (uint64_t)bitcnt; }
+    // the header of the next block alone (tables built, state CODES / STORED / DONE)
+    Status block_header(const uint8_t *&in, const uint8_t *in_end) { return header(in, in_end); }
 
     void reset() {
         ext_end = nullptr;
@@ -316,6 +332,7 @@ struct Decoder {
             if (state == HEADER) {
                 const Status s = header(in, in_end);
                 if (s != OK) return s;
+                if (stop_at_block_end && state != CODES && state != STORED) return BLOCK_END; // (an empty stored block)
                 continue;
             }
             if (state == STORED) {
@@ -339,10 +356,12 @@ struct Decoder {
                     stored_left -= (uint32_t)n;
                 }
                 state = final_block ? DONE : HEADER;
+                if (stop_at_block_end) return BLOCK_END;
                 continue;
             }
             const Status s = codes(in, in_end, out, out_end, win_start);
             if (s != OK) return s;
+            if (stop_at_block_end && state != CODES) return BLOCK_END;
         }
     }
 

@@ -538,3 +538,63 @@ def test_bgzf_reader_for_the_device_side_inflate():
     dmg[len(dmg) // 3] ^= 0x40
     with pytest.raises(FinchError):
         H.bgzf_batch_probe(bytes(dmg), 1 << 20, 4096, 1 << 30, len(text) + 65536)
+
+
+def test_one_gzip_member_decoded_by_several_threads(monkeypatch):
+    """plain gzip with read threads to spare (fh_pargz.h): block starts found by search, chunks decoded with markers for the
+    unknown window, stitched and checked against the member's CRC-32 -- the text must be zlib's for every chunk size,
+    compression level and request size, for several members, stored blocks, binary data (no block is ever found: one
+    thread decodes), and damage must stay loud"""
+    import zlib
+    rng = np.random.default_rng(33)
+    g = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=100_000)
+    recs = []
+    for i in range(30000):
+        st = int(rng.integers(0, len(g) - 150))
+        recs.append(b"@read%d\n%s\n+\n%s\n" % (i, g[st:st + 150].tobytes(), bytes(rng.integers(35, 74, size=150, dtype=np.uint8))))
+    text = b"".join(recs)  # ~9.5 MB
+    unique = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=3_000_000))  # markers fade quickly in this one
+    fasta = b">chr1 test\n" + b"\n".join(unique[i:i + 70] for i in range(0, len(unique), 70)) + b"\n"
+    monkeypatch.setenv("FINCH_BGZF_THREADS", "4")
+    for chunk in ("40000", "250000", "4194304"):
+        monkeypatch.setenv("FINCH_PARGZ_CHUNK", chunk)
+        for level in (1, 6, 9):
+            z = gzip.compress(text, level)
+            for req in (4096, (5 << 20) + 13, 64 << 20):
+                assert H.source_probe(z, req, len(text) + 4096) == text, (chunk, level, req)
+        assert H.source_probe(gzip.compress(fasta, 6), 1 << 20, len(fasta) + 4096) == fasta
+        # members behind the first go through the sequential reader; an empty one in between is fine
+        multi = gzip.compress(text[:4_000_000], 6) + gzip.compress(b"") + gzip.compress(text[4_000_000:], 1)
+        assert H.source_probe(multi, 1 << 20, len(text) + 4096) == text
+        # stored blocks only, the fixed code only, and a mix of both with dynamic blocks
+        for kw in (dict(level=0), dict(level=6, strategy=zlib.Z_FIXED)):
+            co = zlib.compressobj(kw.get("level", 6), zlib.DEFLATED, 31, 8, kw.get("strategy", zlib.Z_DEFAULT_STRATEGY))
+            z = co.compress(text[:3_000_000]) + co.flush()
+            assert H.source_probe(z, 1 << 20, len(text)) == text[:3_000_000], kw
+        co = zlib.compressobj(6, zlib.DEFLATED, 31)
+        z = co.compress(text[:2_000_000]) + co.flush(zlib.Z_FULL_FLUSH) + co.compress(text[2_000_000:5_000_000]) + co.flush(zlib.Z_SYNC_FLUSH) + \
+            co.compress(text[5_000_000:]) + co.flush()
+        assert H.source_probe(z, 1 << 20, len(text) + 4096) == text
+        # not text: the search finds no block it believes in, the first thread decodes everything
+        blob = bytes(rng.integers(0, 256, size=1_500_000, dtype=np.uint8)) + bytes(2_000_000) + text[:1_000_000]
+        assert H.source_probe(gzip.compress(blob, 6), 1 << 20, len(blob) + 4096) == blob
+        # damage: a flipped bit somewhere in the middle, a cut, a wrong checksum
+        z = bytearray(gzip.compress(text, 6))
+        for cut in (len(z) // 2, len(z) - 5):
+            with pytest.raises(FinchError):
+                H.source_probe(bytes(z[:cut]), 1 << 20, len(text) + 4096)
+        bad = bytearray(z)
+        bad[-6] ^= 1
+        with pytest.raises(FinchError):
+            H.source_probe(bytes(bad), 1 << 20, len(text) + 4096)
+        for where in (len(z) // 3, (2 * len(z)) // 3):
+            bad = bytearray(z)
+            bad[where] ^= 0x20
+            with pytest.raises(FinchError):
+                H.source_probe(bytes(bad), 1 << 20, len(text) + 4096)
+    # tiny inputs
+    for t in (b"", b"@r\nA\n+\nI\n", text[:70000]):
+        assert H.source_probe(gzip.compress(t), 4096, len(t) + 64) == t
+    # the records are what the host parser makes of the plain text
+    monkeypatch.setenv("FINCH_PARGZ_CHUNK", "100000")
+    assert H.fastx_scan(gzip.compress(text, 6)) == H.fastx_scan(text)
