@@ -1118,6 +1118,8 @@ struct ParGzSource : ByteSource {
     size_t r_chunk = 0, r_off = 0;
     std::unique_ptr<ByteSource> tail; // the sequential reader, once it has taken over
     uint64_t n_batches = 0, n_chunks = 0, n_false_starts = 0, sym_total = 0;
+    double t_fill = 0, t_find = 0, t_decode = 0, t_resolve = 0, t_deliver = 0; // FH_TRACE
+    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
     ParGzSource(std::unique_ptr<ByteSource> in, unsigned threads) : inner(std::move(in)), n_thr(std::max(2u, threads)) {
         const char *e = getenv("FINCH_PARGZ_CHUNK");
@@ -1128,7 +1130,9 @@ struct ParGzSource : ByteSource {
         if (trace && n_batches)
             fprintf(stderr, "[finch] parallel gzip: %llu batches, %llu chunks (%llu false starts), %.1f %% of the text decoded with markers, %u threads%s\n",
                     (unsigned long long)n_batches, (unsigned long long)n_chunks, (unsigned long long)n_false_starts,
-                    100.0 * (double)sym_total / (double)std::max<uint64_t>(1, delivered), n_thr, tail ? "; sequential reader took over" : "");
+                    100.0 * (double)sym_total / (double)std::max<uint64_t>(1, delivered), n_thr, tail ? "; sequential reader took over" : ""),
+            fprintf(stderr, "[finch] parallel gzip: read %.1f ms, block search %.1f ms, decode %.1f ms, markers + CRC %.1f ms, hand-over %.1f ms\n",
+                    t_fill * 1e3, t_find * 1e3, t_decode * 1e3, t_resolve * 1e3, t_deliver * 1e3);
     }
     bool failed() const override { return bad || (tail && tail->failed()); }
     bool can_rewind() const override { return inner ? inner->can_rewind() : (tail && tail->can_rewind()); }
@@ -1222,7 +1226,10 @@ struct ParGzSource : ByteSource {
         r_chunk = r_off = 0;
         if (member_done || bad) return false;
         const size_t batch_bytes = chunk_bytes * n_thr;
+        const double t0 = now_s();
         fill_to(batch_bytes);
+        const double t1 = now_s();
+        t_fill += t1 - t0;
         if (!started) {
             long h = header_len();
             if (h == 0 && !in_eof) { // (a header longer than a batch: not worth a special case)
@@ -1253,10 +1260,14 @@ struct ParGzSource : ByteSource {
             const uint64_t from = std::max<uint64_t>((uint64_t)i * chunk_bytes * 8u, c_bit + 1);
             ch[i].start_bit = pargz::find_block_start(base, n, from, (uint64_t)(i + 1) * chunk_bytes * 8u, *scratch);
         });
+        const double t2 = now_s();
+        t_find += t2 - t1;
         // 2. decode
         parallel(n_c, [&](size_t i) {
             if (ch[i].start_bit != UINT64_MAX) pargz::decode_chunk(base, n, ch, i, window.data(), window.size());
         });
+        const double t3 = now_s();
+        t_decode += t3 - t2;
         // 3. the chain of chunks that really follow each other
         std::vector<size_t> live;
         for (size_t i = 0; i < n_c;) {
@@ -1279,37 +1290,30 @@ struct ParGzSource : ByteSource {
                         (unsigned long long)ch[li].start_bit, (unsigned long long)ch[li].end_bit, ch[li].n_bytes, ch[li].n_sym, ch[li].ok,
                         ch[li].member_end, ch[li].out_of_input);
         if (!ch[live.back()].ok) return fall_back();
-        // windows, then the markers (chunks with less than a window of marker-free text behind them need the text before)
+        // the window in front of every live chunk (in order: a chunk's own tail may still hold markers), then the markers
+        // and checksums of all of them side by side
         std::vector<std::vector<uint8_t>> win_in(live.size());
-        std::vector<char> resolved(live.size(), 0);
         std::vector<uint8_t> win = window;
         bool ok = true;
         for (size_t li = 0; li < live.size(); ++li) {
-            pargz::Chunk &c = ch[live[li]];
             win_in[li] = win;
-            if (c.n_bytes >= pargz::WINDOW) {
-                win.assign(c.bytes.data() + c.n_bytes - pargz::WINDOW, c.bytes.data() + c.n_bytes);
-                continue;
-            }
-            ok = pargz::resolve_chunk(c, win_in[li].data() + win_in[li].size(), win_in[li].size()) && ok;
-            resolved[li] = 1;
-            win.insert(win.end(), c.head.begin(), c.head.end());
-            win.insert(win.end(), c.bytes.begin(), c.bytes.begin() + (long)c.n_bytes);
-            if (win.size() > pargz::WINDOW) win.erase(win.begin(), win.end() - pargz::WINDOW);
+            std::vector<uint8_t> nxt;
+            ok = pargz::window_behind(ch[live[li]], win_in[li], nxt) && ok;
+            win.swap(nxt);
         }
         std::atomic<bool> all_ok{ok};
         parallel(live.size(), [&](size_t li) {
-            if (resolved[li]) return;
             pargz::Chunk &c = ch[live[li]];
             if (!pargz::resolve_chunk(c, win_in[li].data() + win_in[li].size(), win_in[li].size())) all_ok = false;
         });
         if (!all_ok) return fall_back();
+        t_resolve += now_s() - t3;
         window = win;
         for (size_t li : live) {
             pargz::Chunk &c = ch[li];
             crc = (uint32_t)crc32_combine(crc, c.crc, (z_off_t)c.text_len());
             member_len += c.text_len();
-            sym_total += c.head.size();
+            sym_total += c.n_head;
         }
         // 4. where the batch ended
         const pargz::Chunk &last = ch[live.back()];
@@ -1368,6 +1372,7 @@ struct ParGzSource : ByteSource {
             }
             if (r_chunk < ready.size()) {
                 // segments of the ready text that fit the request, copied by several threads when there is much of it
+                const double td0 = now_s();
                 struct Seg { const uint8_t *p; size_t len, at; };
                 std::vector<Seg> segs;
                 size_t m = 0;
@@ -1379,9 +1384,9 @@ struct ParGzSource : ByteSource {
                         r_off = 0;
                         continue;
                     }
-                    const bool in_head = r_off < c.head.size();
-                    const uint8_t *p = in_head ? c.head.data() + r_off : c.bytes.data() + (r_off - c.head.size());
-                    const size_t len = std::min(cap - n - m, (in_head ? c.head.size() : total) - r_off);
+                    const bool in_head = r_off < c.n_head;
+                    const uint8_t *p = in_head ? c.head.data() + r_off : c.bytes.data() + (r_off - c.n_head);
+                    const size_t len = std::min(cap - n - m, (in_head ? c.n_head : total) - r_off);
                     segs.push_back(Seg{p, len, n + m});
                     m += len;
                     r_off += len;
@@ -1402,6 +1407,7 @@ struct ParGzSource : ByteSource {
                 }
                 n += m;
                 delivered += m;
+                t_deliver += now_s() - td0;
                 continue;
             }
             if (!next_batch() && !tail) break;

@@ -22,7 +22,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 #include <memory>
 #include <vector>
 
@@ -128,16 +130,57 @@ static inline uint64_t find_block_start(const uint8_t *base, size_t n, uint64_t 
 // ---------------------------------------------------------------------------------------------------------------------
 // a chunk's output
 // ---------------------------------------------------------------------------------------------------------------------
+// Storage that grows without being zeroed or copied element by element (std::vector does both; realloc of a large block
+// remaps its pages).
+template <class T>
+struct GrowBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    GrowBuf() = default;
+    GrowBuf(const GrowBuf &) = delete;
+    GrowBuf &operator=(const GrowBuf &) = delete;
+    GrowBuf(GrowBuf &&o) noexcept : p(o.p), cap(o.cap) {
+        o.p = nullptr;
+        o.cap = 0;
+    }
+    GrowBuf &operator=(GrowBuf &&o) noexcept {
+        if (this != &o) {
+            free(p);
+            p = o.p;
+            cap = o.cap;
+            o.p = nullptr;
+            o.cap = 0;
+        }
+        return *this;
+    }
+    ~GrowBuf() { free(p); }
+    T *data() const { return p; }
+    size_t size() const { return cap; }
+    void reserve(size_t n) {
+        if (n <= cap) return;
+        T *q = (T *)realloc(p, n * sizeof(T));
+        if (!q) throw std::bad_alloc();
+        p = q;
+        cap = n;
+    }
+    void release() {
+        free(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 struct Chunk {
     uint64_t start_bit = UINT64_MAX, end_bit = 0;
     bool known_window = false; // the first chunk of a batch: decoded as bytes from the start
     bool ok = true;            // false: a code that cannot be, a match reaching beyond the window
     bool member_end = false;   // the final block ended at end_bit
     bool out_of_input = false; // the batch's bytes ended inside the block that starts at end_bit
-    std::vector<uint16_t> sym; // symbols while the unknown window can still show through (WINDOW marker slots in front)
+    GrowBuf<uint16_t> sym;     // symbols while the unknown window can still show through (WINDOW marker slots in front)
     size_t n_sym = 0;          // symbols behind the WINDOW slots
-    std::vector<uint8_t> head; // sym resolved (pass 3)
-    std::vector<uint8_t> bytes;
+    GrowBuf<uint8_t> head;     // sym resolved (pass 3): n_sym bytes
+    size_t n_head = 0;
+    GrowBuf<uint8_t> bytes;
     size_t n_bytes = 0;
     uint32_t crc = 0;
     size_t text_len() const { return n_sym + n_bytes; }
@@ -157,7 +200,7 @@ static inline inf::Status marker_codes(inf::Decoder &dec, const uint8_t *&in_ref
             result = inf::NEED_INPUT;
             break;
         }
-        if (o + 600 > c.sym.size()) c.sym.resize(c.sym.size() + c.sym.size() / 2 + 65536);
+        if (o + 600 > c.sym.size()) c.sym.reserve(c.sym.size() + c.sym.size() / 2 + 65536);
         uint16_t *const out = c.sym.data();
         bb |= inf::Decoder::load64(in) << bc;
         in += (63 - bc) >> 3;
@@ -259,15 +302,15 @@ static inline void decode_chunk(const uint8_t *base, size_t n, std::vector<Chunk
     uint8_t pre[WINDOW]; // the WINDOW bytes in front of `bytes` once the markers have faded
     size_t last_marker = 0;
     if (!clean) {
-        c.sym.resize(WINDOW + ((size_t)1 << 20));
-        for (uint32_t i = 0; i < WINDOW; ++i) c.sym[i] = (uint16_t)(MARK | i);
+        c.sym.reserve(WINDOW + std::max<size_t>((size_t)1 << 20, (n / std::max<size_t>(1, chunks.size())) * 6));
+        for (uint32_t i = 0; i < WINDOW; ++i) c.sym.data()[i] = (uint16_t)(MARK | i);
         last_marker = 0;
         // (the window slots count as markers at "position 0": clean once WINDOW symbols without one have been produced)
     } else {
         dec->ext_end = window + window_len;
         dec->ext_len = window_len;
     }
-    c.bytes.resize((size_t)4 << 20);
+    c.bytes.reserve((size_t)4 << 20);
     for (;;) {
         // ---- one block ----
         const uint64_t block_start = dec->bit_position(in, base);
@@ -279,16 +322,16 @@ static inline void decode_chunk(const uint8_t *base, size_t n, std::vector<Chunk
                 s = marker_codes(*dec, in, in_end, c, last_marker);
             } else if (s == inf::OK && dec->state == inf::Decoder::STORED) { // literal bytes, byte aligned
                 while (dec->stored_left && s == inf::OK) {
-                    if (WINDOW + c.n_sym + 8 > c.sym.size()) c.sym.resize(c.sym.size() + c.sym.size() / 2 + 65536);
+                    if (WINDOW + c.n_sym + 8 > c.sym.size()) c.sym.reserve(c.sym.size() + c.sym.size() / 2 + 65536);
                     if (dec->bitcnt) {
-                        c.sym[WINDOW + c.n_sym++] = (uint16_t)(dec->bitbuf & 0xFFu);
+                        c.sym.data()[WINDOW + c.n_sym++] = (uint16_t)(dec->bitbuf & 0xFFu);
                         dec->bitbuf >>= 8;
                         dec->bitcnt -= 8;
                         dec->stored_left--;
                     } else if (in >= in_end) {
                         s = inf::NEED_INPUT;
                     } else {
-                        c.sym[WINDOW + c.n_sym++] = *in++;
+                        c.sym.data()[WINDOW + c.n_sym++] = *in++;
                         dec->stored_left--;
                     }
                 }
@@ -297,7 +340,7 @@ static inline void decode_chunk(const uint8_t *base, size_t n, std::vector<Chunk
             if (s == inf::OK) s = inf::BLOCK_END;
         } else {
             for (;;) {
-                if (c.bytes.size() - c.n_bytes < (size_t)1 << 20) c.bytes.resize(c.bytes.size() + c.bytes.size() / 2);
+                if (c.bytes.size() - c.n_bytes < (size_t)1 << 20) c.bytes.reserve(c.bytes.size() + c.bytes.size() / 2);
                 uint8_t *op = c.bytes.data() + c.n_bytes;
                 s = dec->run(in, in_end, op, c.bytes.data() + c.bytes.size(), c.bytes.data());
                 c.n_bytes = (size_t)(op - c.bytes.data());
@@ -338,28 +381,57 @@ static inline void decode_chunk(const uint8_t *base, size_t n, std::vector<Chunk
     }
 }
 
-// pass 3 for one chunk: its markers looked up in the window in front of it (window_len bytes ending at window_end; a
-// marker that points before them means a stream that reached before its own start)
+// one symbol of a chunk given the window in front of it (window_len bytes ending at window_end)
+static inline bool resolve_symbol(uint16_t v, const uint8_t *window_end, size_t window_len, uint8_t *out) {
+    if (!(v & MARK)) {
+        *out = (uint8_t)v;
+        return true;
+    }
+    const size_t back = WINDOW - (size_t)(v & 0x7FFFu); // 1 = the byte right in front of the chunk
+    if (back > window_len) { // a stream that reaches before its own start
+        *out = 0;
+        return false;
+    }
+    *out = window_end[-(ptrdiff_t)back];
+    return true;
+}
+
+// The window behind chunk c -- the last WINDOW bytes of (window in front of it + its text) -- without resolving all of it.
+static inline bool window_behind(const Chunk &c, const std::vector<uint8_t> &win_in, std::vector<uint8_t> &win_out) {
+    const size_t total = c.n_sym + c.n_bytes;
+    const size_t take = std::min<size_t>(WINDOW, total);
+    std::vector<uint8_t> w;
+    w.reserve(WINDOW);
+    if (take < WINDOW) { // (a short chunk: the older window shows through)
+        const size_t old = std::min<size_t>(WINDOW - take, win_in.size());
+        w.insert(w.end(), win_in.end() - (long)old, win_in.end());
+    }
+    bool ok = true;
+    const uint8_t *we = win_in.data() + win_in.size();
+    for (size_t i = total - take; i < total; ++i) {
+        uint8_t b;
+        if (i < c.n_sym) ok = resolve_symbol(c.sym.data()[WINDOW + i], we, win_in.size(), &b) && ok;
+        else b = c.bytes.data()[i - c.n_sym];
+        w.push_back(b);
+    }
+    win_out.swap(w);
+    return ok;
+}
+
+// pass 3 for one chunk: its markers looked up in the window in front of it, then its CRC-32
 static inline bool resolve_chunk(Chunk &c, const uint8_t *window_end, size_t window_len) {
-    c.head.resize(c.n_sym);
+    c.head.reserve(c.n_sym + 8);
+    c.n_head = c.n_sym;
     const uint16_t *s = c.sym.data() + WINDOW;
+    uint8_t *h = c.head.data();
     bool ok = true;
     for (size_t i = 0; i < c.n_sym; ++i) {
         const uint16_t v = s[i];
-        if (v & MARK) {
-            const size_t back = WINDOW - (size_t)(v & 0x7FFFu); // 1 = the byte right in front of the chunk
-            if (back > window_len) {
-                ok = false;
-                c.head[i] = 0;
-            } else {
-                c.head[i] = window_end[-(ptrdiff_t)back];
-            }
-        } else {
-            c.head[i] = (uint8_t)v;
-        }
+        if (__builtin_expect((v & MARK) != 0, 0)) ok = resolve_symbol(v, window_end, window_len, h + i) && ok;
+        else h[i] = (uint8_t)v;
     }
-    std::vector<uint16_t>().swap(c.sym);
-    c.crc = inf::crc32_fast(0, c.head.data(), c.head.size());
+    c.sym.release();
+    c.crc = inf::crc32_fast(0, c.head.data(), c.n_head);
     c.crc = inf::crc32_fast(c.crc, c.bytes.data(), c.n_bytes);
     return ok;
 }
