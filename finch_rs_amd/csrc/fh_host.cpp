@@ -1102,7 +1102,7 @@ struct XzSource : ByteSource {
 
 // A gzip file whose first member is decoded by several threads (fh_pargz.h); members after the first, and anything the
 // parallel pass cannot make sense of, go through the sequential reader.  FINCH_PARGZ=0 turns it off; FINCH_PARGZ_CHUNK sets
-// the compressed bytes per thread and batch (default 4 MiB).
+// the compressed bytes per chunk (default 1 MiB; a batch is four chunks per thread).
 struct ParGzSource : ByteSource {
     std::unique_ptr<ByteSource> inner;
     unsigned n_thr;
@@ -1116,14 +1116,23 @@ struct ParGzSource : ByteSource {
     uint64_t member_len = 0, delivered = 0;
     std::vector<pargz::Chunk> ready; // text of the current batch, in order
     size_t r_chunk = 0, r_off = 0;
+    // the chunks' buffers go round from batch to batch: fresh memory costs a page fault per 4 KiB, a good part of a decode
+    std::vector<pargz::GrowBuf<uint16_t>> pool_sym;
+    std::vector<pargz::GrowBuf<uint8_t>> pool_bytes;
+    void recycle(pargz::Chunk &c) {
+        if (c.sym.size()) pool_sym.push_back(std::move(c.sym));
+        if (c.head.size()) pool_bytes.push_back(std::move(c.head));
+        if (c.bytes.size()) pool_bytes.push_back(std::move(c.bytes));
+    }
     std::unique_ptr<ByteSource> tail; // the sequential reader, once it has taken over
     uint64_t n_batches = 0, n_chunks = 0, n_false_starts = 0, sym_total = 0;
+    static constexpr size_t CHUNKS_PER_THREAD = 4; // (chunks differ in how long they take: several per thread even that out)
     double t_fill = 0, t_find = 0, t_decode = 0, t_resolve = 0, t_deliver = 0; // FH_TRACE
     static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
     ParGzSource(std::unique_ptr<ByteSource> in, unsigned threads) : inner(std::move(in)), n_thr(std::max(2u, threads)) {
         const char *e = getenv("FINCH_PARGZ_CHUNK");
-        chunk_bytes = e ? (size_t)std::max(4096ll, atoll(e)) : ((size_t)4 << 20);
+        chunk_bytes = e ? (size_t)std::max(4096ll, atoll(e)) : ((size_t)1 << 20);
     }
     ~ParGzSource() override {
         static const bool trace = getenv("FH_TRACE") != nullptr;
@@ -1222,10 +1231,11 @@ struct ParGzSource : ByteSource {
 
     // decode the next batch into `ready`; false: nothing more from this reader (end, error, or `tail` has taken over)
     bool next_batch() {
+        for (auto &c : ready) recycle(c);
         ready.clear();
         r_chunk = r_off = 0;
         if (member_done || bad) return false;
-        const size_t batch_bytes = chunk_bytes * n_thr;
+        const size_t batch_bytes = chunk_bytes * n_thr * CHUNKS_PER_THREAD;
         const double t0 = now_s();
         fill_to(batch_bytes);
         const double t1 = now_s();
@@ -1247,10 +1257,21 @@ struct ParGzSource : ByteSource {
             return false;
         }
         n_batches++;
-        const size_t n_c = std::max<size_t>(1, std::min<size_t>(n_thr, c_n / chunk_bytes));
+        const size_t n_c = std::max<size_t>(1, std::min<size_t>((size_t)n_thr * CHUNKS_PER_THREAD, c_n / chunk_bytes));
         std::vector<pargz::Chunk> ch(n_c);
         ch[0].start_bit = c_bit;
         ch[0].known_window = true;
+        for (size_t i = 0; i < n_c; ++i) { // (largest first: they went back in the order they were used)
+            if (i > 0 && !pool_sym.empty()) {
+                ch[i].sym = std::move(pool_sym.back());
+                pool_sym.pop_back();
+            }
+            for (auto *b : {&ch[i].bytes, &ch[i].head})
+                if (!pool_bytes.empty()) {
+                    *b = std::move(pool_bytes.back());
+                    pool_bytes.pop_back();
+                }
+        }
         const uint8_t *base = cb.data();
         const size_t n = c_n;
         // 1. where the other chunks begin
@@ -1356,7 +1377,11 @@ struct ParGzSource : ByteSource {
             return false;
         }
         ready.reserve(live.size());
-        for (size_t li : live) ready.push_back(std::move(ch[li]));
+        for (size_t li : live) {
+            if (ch[li].sym.size()) pool_sym.push_back(std::move(ch[li].sym));
+            ready.push_back(std::move(ch[li]));
+        }
+        for (auto &c : ch) recycle(c); // (the chunks that began at false starts; moved-from ones hold nothing)
         return true;
     }
 

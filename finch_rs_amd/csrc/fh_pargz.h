@@ -425,12 +425,20 @@ static inline bool resolve_chunk(Chunk &c, const uint8_t *window_end, size_t win
     const uint16_t *s = c.sym.data() + WINDOW;
     uint8_t *h = c.head.data();
     bool ok = true;
-    for (size_t i = 0; i < c.n_sym; ++i) {
-        const uint16_t v = s[i];
-        if (__builtin_expect((v & MARK) != 0, 0)) ok = resolve_symbol(v, window_end, window_len, h + i) && ok;
-        else h[i] = (uint8_t)v;
+    size_t i = 0;
+#if defined(__SSE2__)
+    // sixteen symbols at a time: narrowed as they are when none of them is a marker (markers are few and far between
+    // once a chunk is a few hundred kilobytes in)
+    for (; i + 16 <= c.n_sym; i += 16) {
+        const __m128i a = _mm_loadu_si128((const __m128i *)(s + i)), b = _mm_loadu_si128((const __m128i *)(s + i + 8));
+        if (__builtin_expect(_mm_movemask_epi8(_mm_or_si128(a, b)) & 0xAAAA, 0)) { // a top bit set: a marker among them
+            for (size_t j = i; j < i + 16; ++j) ok = resolve_symbol(s[j], window_end, window_len, h + j) && ok;
+        } else {
+            _mm_storeu_si128((__m128i *)(h + i), _mm_packus_epi16(a, b));
+        }
     }
-    c.sym.release();
+#endif
+    for (; i < c.n_sym; ++i) ok = resolve_symbol(s[i], window_end, window_len, h + i) && ok;
     c.crc = inf::crc32_fast(0, c.head.data(), c.n_head);
     c.crc = inf::crc32_fast(c.crc, c.bytes.data(), c.n_bytes);
     return ok;
