@@ -614,10 +614,17 @@ struct BgzfSource : ByteSource {
     bool confirmed = false;              // the first member was BGZF: the batch buffer is worth allocating
     BgzfSource(std::unique_ptr<ByteSource> in, unsigned threads) : inner(std::move(in)), n_thr(std::max(1u, threads)), cbuf(1 << 16) {}
     bool failed() const override { return bad || (tail && tail->failed()); }
-    // (once the sequential reader has taken over it owns the input: no way back from there)
-    bool can_rewind() const override { return !tail && inner && inner->can_rewind(); }
+    // (once another gzip reader has taken over it owns the input; rewound, it starts at the first byte of the file and
+    // reads the BGZF members in front of its own as the gzip members they are)
+    bool can_rewind() const override { return tail ? tail->can_rewind() : (inner && inner->can_rewind()); }
     bool rewind() override {
         if (!can_rewind()) return false;
+        if (tail) {
+            if (!tail->rewind()) return false;
+            o_lo = o_hi = 0;
+            bad = false;
+            return true;
+        }
         join_prefetch();
         if (!inner->rewind()) return false;
         c_lo = c_hi = o_lo = o_hi = 0;
@@ -1146,7 +1153,17 @@ struct ParGzSource : ByteSource {
     bool failed() const override { return bad || (tail && tail->failed()); }
     bool can_rewind() const override { return inner ? inner->can_rewind() : (tail && tail->can_rewind()); }
     bool rewind() override {
-        if (!inner || !inner->rewind()) return false; // (once the sequential reader owns the input there is no way back)
+        if (!inner) { // the sequential reader owns the input: it starts over at the first byte of the file
+            if (!tail || !tail->rewind()) return false;
+            for (auto &c : ready) recycle(c);
+            ready.clear();
+            r_chunk = r_off = 0;
+            member_done = true;
+            bad = false;
+            delivered = 0;
+            return true;
+        }
+        if (!inner->rewind()) return false;
         c_n = 0;
         c_bit = 0;
         in_eof = started = member_done = bad = false;

@@ -252,3 +252,31 @@ def test_bgzipped_fastq_files_take_the_device_inflate(tmp_path, monkeypatch):
     assert o3.sketch_stream(lt) == 2
     oh, ok = o3.to_vec()
     assert np.array_equal(r3.sketch(0).arrays[0], oh) and np.array_equal(r3.sketch(0).arrays[1], ok)
+
+
+def test_plain_gzip_with_read_threads_goes_through_the_device_splitter_and_can_fall_back(tmp_path, monkeypatch):
+    """plain gzip decoded by several threads (fh_pargz.h) feeds the device-side FASTQ splitter like any text; a file the
+    splitter refuses is rewound -- through the parallel reader -- and parsed on the host"""
+    import gzip
+    monkeypatch.setenv("FINCH_READ_THREADS", "4")
+    monkeypatch.setenv("FINCH_PARGZ_CHUNK", "200000")
+    text = fastq_text(30000, 5, rl_lo=100, rl_hi=151)
+    params = SketchParams.mash(2000, 2000, True, 21, 0)
+    filt = H.FilterParams(False)
+    loose = text.replace(b"\n@read7/", b"\n\n@read7/")
+    assert loose != text
+    multi = gzip.compress(text[:len(text) // 2], 6) + gzip.compress(text[len(text) // 2:], 1)
+    files = {"a.fastq.gz": gzip.compress(text, 6), "loose.fastq.gz": gzip.compress(loose, 6), "multi.fastq.gz": multi}
+    paths = []
+    for name, img in files.items():
+        p = tmp_path / name
+        p.write_bytes(img)
+        paths.append(str(p))
+    res = H.sketch_files(paths, params, filt, n_threads=1)
+    for i, t in enumerate((text, loose, text)):
+        o = O.OracleSketcher(O.MASH, 2000, 21, 0, 0.001)
+        assert o.sketch_stream(t) == 2
+        okc, okm = o.to_vec()
+        sk = res.sketch(i)
+        assert np.array_equal(sk.arrays[0], okc) and np.array_equal(sk.arrays[1], okm), paths[i]
+        assert (sk.seq_length, sk.num_valid_kmers) == o.total_bases_and_kmers()
