@@ -1123,13 +1123,12 @@ struct ParGzSource : ByteSource {
     uint64_t member_len = 0, delivered = 0;
     std::vector<pargz::Chunk> ready; // text of the current batch, in order
     size_t r_chunk = 0, r_off = 0;
-    // the chunks' buffers go round from batch to batch: fresh memory costs a page fault per 4 KiB, a good part of a decode
-    std::vector<pargz::GrowBuf<uint16_t>> pool_sym;
-    std::vector<pargz::GrowBuf<uint8_t>> pool_bytes;
-    void recycle(pargz::Chunk &c) {
-        if (c.sym.size()) pool_sym.push_back(std::move(c.sym));
-        if (c.head.size()) pool_bytes.push_back(std::move(c.head));
-        if (c.bytes.size()) pool_bytes.push_back(std::move(c.bytes));
+    // (the chunks' buffers come from and go back to pargz::BufPool)
+    static void recycle(pargz::Chunk &c) {
+        pargz::BufPool &pool = pargz::BufPool::global();
+        pool.put(pargz::rebind<uint8_t>(std::move(c.sym)));
+        pool.put(std::move(c.head));
+        pool.put(std::move(c.bytes));
     }
     std::unique_ptr<ByteSource> tail; // the sequential reader, once it has taken over
     uint64_t n_batches = 0, n_chunks = 0, n_false_starts = 0, sym_total = 0;
@@ -1142,6 +1141,7 @@ struct ParGzSource : ByteSource {
         chunk_bytes = e ? (size_t)std::max(4096ll, atoll(e)) : ((size_t)1 << 20);
     }
     ~ParGzSource() override {
+        for (auto &c : ready) recycle(c);
         static const bool trace = getenv("FH_TRACE") != nullptr;
         if (trace && n_batches)
             fprintf(stderr, "[finch] parallel gzip: %llu batches, %llu chunks (%llu false starts), %.1f %% of the text decoded with markers, %u threads%s\n",
@@ -1252,7 +1252,9 @@ struct ParGzSource : ByteSource {
         ready.clear();
         r_chunk = r_off = 0;
         if (member_done || bad) return false;
-        const size_t batch_bytes = chunk_bytes * n_thr * CHUNKS_PER_THREAD;
+        // (the first batch is a short one: nothing is sketched before it is through)
+        const size_t per_thread = n_batches == 0 ? 1 : CHUNKS_PER_THREAD;
+        const size_t batch_bytes = chunk_bytes * n_thr * per_thread;
         const double t0 = now_s();
         fill_to(batch_bytes);
         const double t1 = now_s();
@@ -1274,20 +1276,15 @@ struct ParGzSource : ByteSource {
             return false;
         }
         n_batches++;
-        const size_t n_c = std::max<size_t>(1, std::min<size_t>((size_t)n_thr * CHUNKS_PER_THREAD, c_n / chunk_bytes));
+        const size_t n_c = std::max<size_t>(1, std::min<size_t>((size_t)n_thr * per_thread, c_n / chunk_bytes));
         std::vector<pargz::Chunk> ch(n_c);
         ch[0].start_bit = c_bit;
         ch[0].known_window = true;
-        for (size_t i = 0; i < n_c; ++i) { // (largest first: they went back in the order they were used)
-            if (i > 0 && !pool_sym.empty()) {
-                ch[i].sym = std::move(pool_sym.back());
-                pool_sym.pop_back();
-            }
-            for (auto *b : {&ch[i].bytes, &ch[i].head})
-                if (!pool_bytes.empty()) {
-                    *b = std::move(pool_bytes.back());
-                    pool_bytes.pop_back();
-                }
+        for (size_t i = 0; i < n_c; ++i) {
+            pargz::BufPool &pool = pargz::BufPool::global();
+            if (i > 0) ch[i].sym = pargz::rebind<uint16_t>(pool.get());
+            else ch[i].bytes = pool.get(); // (the first chunk decodes to bytes from the start)
+            ch[i].head = pool.get();
         }
         const uint8_t *base = cb.data();
         const size_t n = c_n;
@@ -1395,7 +1392,7 @@ struct ParGzSource : ByteSource {
         }
         ready.reserve(live.size());
         for (size_t li : live) {
-            if (ch[li].sym.size()) pool_sym.push_back(std::move(ch[li].sym));
+            pargz::BufPool::global().put(pargz::rebind<uint8_t>(std::move(ch[li].sym)));
             ready.push_back(std::move(ch[li]));
         }
         for (auto &c : ch) recycle(c); // (the chunks that began at false starts; moved-from ones hold nothing)

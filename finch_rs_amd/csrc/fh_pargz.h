@@ -26,6 +26,7 @@
 #include <cstring>
 #include <new>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "fh_inflate.h"
@@ -167,6 +168,52 @@ struct GrowBuf {
         free(p);
         p = nullptr;
         cap = 0;
+    }
+};
+
+template <class T, class U>
+static inline GrowBuf<T> rebind(GrowBuf<U> &&b) { // the same memory as elements of another type
+    GrowBuf<T> r;
+    r.p = (T *)b.p;
+    r.cap = b.cap * sizeof(U) / sizeof(T);
+    b.p = nullptr;
+    b.cap = 0;
+    return r;
+}
+
+// Buffers the chunks of finished batches (and finished files) leave behind, for the next ones: fresh memory costs a
+// page fault per 4 KiB when it is first written and another system call's worth when it is returned -- together about
+// as much as decoding into it.  At most FINCH_PARGZ_POOL_MB (default 2048) are kept.
+struct BufPool {
+    std::mutex mu;
+    std::vector<GrowBuf<uint8_t>> free_list;
+    size_t held = 0, limit;
+    BufPool() {
+        const char *e = getenv("FINCH_PARGZ_POOL_MB");
+        limit = (size_t)(e ? std::max(0ll, atoll(e)) : 2048ll) << 20;
+    }
+    static BufPool &global() {
+        static BufPool p;
+        return p;
+    }
+    GrowBuf<uint8_t> get() { // the largest one there is, or an empty one
+        std::lock_guard<std::mutex> g(mu);
+        if (free_list.empty()) return GrowBuf<uint8_t>();
+        size_t best = 0;
+        for (size_t i = 1; i < free_list.size(); ++i)
+            if (free_list[i].cap > free_list[best].cap) best = i;
+        GrowBuf<uint8_t> b = std::move(free_list[best]);
+        free_list[best] = std::move(free_list.back());
+        free_list.pop_back();
+        held -= b.cap;
+        return b;
+    }
+    void put(GrowBuf<uint8_t> &&b) {
+        if (!b.cap) return;
+        std::lock_guard<std::mutex> g(mu);
+        if (held + b.cap > limit) return; // (b is freed by its destructor)
+        held += b.cap;
+        free_list.push_back(std::move(b));
     }
 };
 
