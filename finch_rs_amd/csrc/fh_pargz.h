@@ -443,40 +443,14 @@ static inline bool resolve_symbol(uint16_t v, const uint8_t *window_end, size_t 
     return true;
 }
 
-// The window behind chunk c -- the last WINDOW bytes of (window in front of it + its text) -- without resolving all of it.
-static inline bool window_behind(const Chunk &c, const std::vector<uint8_t> &win_in, std::vector<uint8_t> &win_out) {
-    const size_t total = c.n_sym + c.n_bytes;
-    const size_t take = std::min<size_t>(WINDOW, total);
-    std::vector<uint8_t> w;
-    w.reserve(WINDOW);
-    if (take < WINDOW) { // (a short chunk: the older window shows through)
-        const size_t old = std::min<size_t>(WINDOW - take, win_in.size());
-        w.insert(w.end(), win_in.end() - (long)old, win_in.end());
-    }
-    bool ok = true;
-    const uint8_t *we = win_in.data() + win_in.size();
-    for (size_t i = total - take; i < total; ++i) {
-        uint8_t b;
-        if (i < c.n_sym) ok = resolve_symbol(c.sym.data()[WINDOW + i], we, win_in.size(), &b) && ok;
-        else b = c.bytes.data()[i - c.n_sym];
-        w.push_back(b);
-    }
-    win_out.swap(w);
-    return ok;
-}
-
-// pass 3 for one chunk: its markers looked up in the window in front of it, then its CRC-32
-static inline bool resolve_chunk(Chunk &c, const uint8_t *window_end, size_t window_len) {
-    c.head.reserve(c.n_sym + 8);
-    c.n_head = c.n_sym;
-    const uint16_t *s = c.sym.data() + WINDOW;
-    uint8_t *h = c.head.data();
+// n symbols narrowed to bytes, markers looked up in the window (window_len bytes ending at window_end)
+static inline bool resolve_span(const uint16_t *s, size_t n, const uint8_t *window_end, size_t window_len, uint8_t *h) {
     bool ok = true;
     size_t i = 0;
 #if defined(__SSE2__)
     // sixteen symbols at a time: narrowed as they are when none of them is a marker (markers are few and far between
     // once a chunk is a few hundred kilobytes in)
-    for (; i + 16 <= c.n_sym; i += 16) {
+    for (; i + 16 <= n; i += 16) {
         const __m128i a = _mm_loadu_si128((const __m128i *)(s + i)), b = _mm_loadu_si128((const __m128i *)(s + i + 8));
         if (__builtin_expect(_mm_movemask_epi8(_mm_or_si128(a, b)) & 0xAAAA, 0)) { // a top bit set: a marker among them
             for (size_t j = i; j < i + 16; ++j) ok = resolve_symbol(s[j], window_end, window_len, h + j) && ok;
@@ -485,7 +459,30 @@ static inline bool resolve_chunk(Chunk &c, const uint8_t *window_end, size_t win
         }
     }
 #endif
-    for (; i < c.n_sym; ++i) ok = resolve_symbol(s[i], window_end, window_len, h + i) && ok;
+    for (; i < n; ++i) ok = resolve_symbol(s[i], window_end, window_len, h + i) && ok;
+    return ok;
+}
+
+// The window behind chunk c -- the last WINDOW bytes of (window in front of it + its text) -- without resolving all of it.
+static inline bool window_behind(const Chunk &c, const std::vector<uint8_t> &win_in, std::vector<uint8_t> &win_out) {
+    const size_t total = c.n_sym + c.n_bytes;
+    const size_t take = std::min<size_t>(WINDOW, total);
+    const size_t old = take < WINDOW ? std::min<size_t>(WINDOW - take, win_in.size()) : 0; // (a short chunk: the older window shows through)
+    std::vector<uint8_t> w(old + take);
+    if (old) memcpy(w.data(), win_in.data() + win_in.size() - old, old);
+    const size_t first = total - take; // of the chunk's text
+    const size_t from_sym = first < c.n_sym ? c.n_sym - first : 0;
+    const bool ok = resolve_span(c.sym.data() + WINDOW + first, from_sym, win_in.data() + win_in.size(), win_in.size(), w.data() + old);
+    if (take > from_sym) memcpy(w.data() + old + from_sym, c.bytes.data() + (first + from_sym - c.n_sym), take - from_sym);
+    win_out.swap(w);
+    return ok;
+}
+
+// pass 3 for one chunk: its markers looked up in the window in front of it, then its CRC-32
+static inline bool resolve_chunk(Chunk &c, const uint8_t *window_end, size_t window_len) {
+    c.head.reserve(c.n_sym + 8);
+    c.n_head = c.n_sym;
+    const bool ok = resolve_span(c.sym.data() + WINDOW, c.n_sym, window_end, window_len, c.head.data());
     c.crc = inf::crc32_fast(0, c.head.data(), c.n_head);
     c.crc = inf::crc32_fast(c.crc, c.bytes.data(), c.n_bytes);
     return ok;

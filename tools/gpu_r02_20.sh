@@ -1,0 +1,5 @@
+#!/bin/bash
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+( for mode in "" "--noisy"; do for lvl in 1 6; do FH_TRACE=1 timeout 600 python tools/gz_parallel_file.py $mode --level $lvl 2>&1 | grep "threads:\|text as\|read .*ms\|text pump" | awk '!seen[$0]++'; done; done ) | tee gpurun_out/r02q_gz_parallel.txt | grep "threads:\|text as\|16 thr" 
+grep -B6 "16 threads" gpurun_out/r02q_gz_parallel.txt | grep "pump\|read" | tail -24
