@@ -505,8 +505,8 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
             # pin its buffers anew, which is not what a process that reads compressed files does)
             H._lib.load().fh_release_cached()
             out = {"what": "finch_sketch_files on one %.0f MB FASTQ (%d reads) compressed with zlib level 1: as a single gzip stream "
-                           "(one host thread inflates) and as BGZF (members inflated on the device, one wavefront each; bgzf_host_inflate: by the "
-                           "call's read threads instead); k=21 n=1000"
+                           "(decoded by the call's read threads together, fh_pargz.h) and as BGZF (members inflated on the device, one wavefront "
+                           "each; bgzf_host_inflate: by the read threads instead); k=21 n=1000"
                            % (len(raw) / 1e6, ns)}
             for key, path, env in (("gzip", gzp, None), ("bgzf", bgp, None), ("bgzf_host_inflate", bgp, "0")):
                 if env is not None:
