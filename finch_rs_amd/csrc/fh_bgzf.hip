@@ -7,14 +7,15 @@
 // member, the compressed bytes cross PCIe instead of the text (4-5x fewer), and the text is born where the FASTQ
 // splitter (fh_text.hip) reads it.
 //
-//   k_bgzf_inflate   one 64-lane workgroup per member.  DEFLATE's symbol stream is serial, so the decode itself is written
-//                    wave-uniform: bit buffer, table lookups and the symbol dispatch live in scalar registers, the lanes
-//                    serve as (a) the input window -- lane i holds word i of the current 256 bytes, one v_readlane per
-//                    32 bits consumed, the next 256 bytes already in flight --, (b) the builders of the Huffman tables
-//                    (canonical codes assigned with ballots, replicated entries filled in parallel) and (c) the LZ77
-//                    copier: decoded symbols are queued one per lane and resolved 64 at a time, every lane
-//                    copying its own match; a match whose source lies inside the group waits for the round in which
-//                    everything before it has been written.
+//   k_bgzf_inflate   one 64-lane workgroup per member.  The symbols of a block are decoded 64 bit offsets at a time: every
+//                    lane decodes the symbol that would start at its own offset, the lanes where symbols really start are
+//                    found by following the lengths from the first one (a scalar chase, one v_readlane per symbol), output
+//                    positions are a DPP prefix sum over those lanes, and their tokens join a queue in LDS.  Block headers
+//                    are parsed wave-uniform (bit buffer in scalar registers; lane i holds word i of the current 256 input
+//                    bytes), the lanes build the Huffman tables (canonical codes assigned with ballots, replicated entries
+//                    filled in parallel), and the queued tokens are written out 64 at a time, every lane copying its own
+//                    match; a match whose source lies inside the group waits for the round in which everything before it
+//                    has been written.
 //   k_bgzf_crc       CRC-32 of every member's text against its trailer: 64 slices per member hashed with slicing-by-4
 //                    tables in LDS, joined with the x^n mod P operators of zlib's crc32_combine.
 //   k_fastq_cut      where the last whole FASTQ record of the inflated text ends (the rest waits for the next batch).
@@ -23,6 +24,8 @@
 // past the member's bytes sets the status word and the push fails (fh_api.hip), after which the host layer reads the
 // file again through its own inflate.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "fh_core.h"
 #include "fh_kernels.h"
@@ -39,6 +42,8 @@ constexpr u32 KIND_LIT = 0, KIND_BASE = 1, KIND_EOB = 2, KIND_LONG = 3;
 // "no such code" in the literal/length table: the kind of the end-of-block symbol with a length of 0, so that the symbol
 // loop's common cases (literal, match) need no validity test of their own
 constexpr u32 LIT_STOP = KIND_EOB << 8;
+// (reasons of failure, see BgzfFail)
+constexpr u32 BZ_BAD_CODE_ = 2, BZ_BAD_MATCH_ = 3, BZ_BAD_SIZE_ = 4, BZ_OVERRUN_ = 5;
 
 // table entry: bits 0-3 code length (0 = no such code), 4-7 extra bits, 8-9 kind, 16-31 literal / base value / symbol
 __device__ __forceinline__ u32 make_entry(u32 nbits, u32 extra, u32 kind, u32 value) {
@@ -74,6 +79,7 @@ struct Lds {
     CodeSet cs[2];
     uint8_t lens[320];
     uint8_t cl_lens[32];
+    u32 qpos[128], qinfo[128]; // (the lane-parallel symbol loop) tokens waiting for a full group of 64
 };
 
 __device__ __forceinline__ u32 rfl(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -287,6 +293,131 @@ __device__ void resolve_group(uint8_t *out, u32 tpos, u32 tinfo, u32 ntok, u32 l
 
 } // namespace
 
+// inclusive prefix sum over the 64 lanes, in registers (row shifts, then the two row broadcasts gfx9 has for this)
+__device__ __forceinline__ u32 wave_scan_add(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// write out the queued tokens, 64 at a time (`all`: the rest too)
+__device__ void flush_queue(Lds &L, uint8_t *out, u32 &qn, u32 lane, bool all) {
+    while (qn >= 64u || (all && qn > 0u)) {
+        const u32 n = qn < 64u ? qn : 64u;
+        __syncthreads();
+        const u32 tpos = L.qpos[lane], tinfo = L.qinfo[lane];
+        resolve_group(out, tpos, tinfo, n, lane);
+        const u32 rest = qn - n;
+        const u32 p1 = L.qpos[64u + lane], i1 = L.qinfo[64u + lane];
+        __syncthreads();
+        if (lane < rest) {
+            L.qpos[lane] = p1;
+            L.qinfo[lane] = i1;
+        }
+        qn = rest;
+    }
+    __syncthreads();
+}
+
+// The symbols of one block, 64 bit offsets at a time: every lane decodes the symbol that would start at its offset --
+// literal/length lookup, extra bits, distance lookup, all of it -- and the lanes where symbols really start are found by
+// following the lengths from the first one (a scalar chase of one v_readlane per symbol).  Output positions come from a
+// prefix sum over those lanes; their tokens join the queue.  mbits: bits of the member consumed (in: where the block's
+// symbols begin, out: behind its end-of-block code).  Returns 0 or the reason of failure.
+__device__ u32 block_symbols_parallel(Lds &L, const uint8_t *mbase, u64 in_bits, u32 isize, uint8_t *out, u64 &mbits_ref, u32 &pos_ref,
+                                      u32 &qn_ref, u32 lane) {
+    u64 mbits = mbits_ref;
+    u32 pos = pos_ref, qn = qn_ref, fail = 0;
+    for (;;) {
+        if (mbits > in_bits + 64u) {
+            fail = BZ_OVERRUN_;
+            break;
+        }
+        const u64 my = mbits + lane;
+        u64 b;
+        __builtin_memcpy(&b, mbase + (my >> 3), 8); // (reads at most 24 bytes past the member: inside the buffer's padding)
+        b >>= (u32)(my & 7u);
+        u32 e = L.lit[(u32)b & ((1u << LIT_BITS) - 1u)];
+        u32 kind = (e >> 8) & 3u;
+        if (kind == KIND_LONG) {
+            e = decode_long(L.cs[0], LIT_BITS, 0, (u32)b);
+            kind = (e >> 8) & 3u;
+        }
+        const u32 nb = e & 15u;
+        u32 t = nb, info = 0, adv = 0, st = 0; // st: 0 a token, 1 end of block, 2 no such code
+        if (kind == KIND_LIT) {
+            info = (e & 0xFFFF0000u) | ((e & PAIR_FLAG) >> 1);
+            adv = 1u + ((e >> 10) & 1u);
+        } else if (kind == KIND_BASE) {
+            const u32 ex = (e >> 4) & 15u;
+            const u32 len = (e >> 16) + ((u32)(b >> nb) & ((1u << ex) - 1u));
+            t += ex;
+            u32 d = L.dist[(u32)(b >> t) & ((1u << DIST_BITS) - 1u)];
+            if (((d >> 8) & 3u) == KIND_LONG) d = decode_long(L.cs[1], DIST_BITS, 1, (u32)(b >> t));
+            const u32 db = d & 15u, dex = (d >> 4) & 15u;
+            if (db == 0u) st = 2;
+            const u32 dist = (d >> 16) + ((u32)(b >> (t + db)) & ((1u << dex) - 1u));
+            t += db + dex;
+            info = (dist << 16) | len;
+            adv = len;
+        } else {
+            st = nb ? 1u : 2u;
+        }
+        const u32 tl = st ? 128u : t;
+        // the chain of symbol starts
+        unsigned long long marks = 0ull;
+        u32 s = 0, stop = 64u;
+        while (s < 64u) {
+            marks |= 1ull << s;
+            const u32 v = (u32)__builtin_amdgcn_readlane((int)tl, (int)s);
+            if (v & 128u) {
+                stop = s;
+                break;
+            }
+            s += v;
+        }
+        if (stop < 64u) marks &= ~(1ull << stop);
+        const bool tok = (marks >> lane) & 1ull;
+        const u32 a = tok ? adv : 0u;
+        const u32 incl = wave_scan_add(a);
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        const u32 mypos = pos + incl - a;
+        if (__ballot(tok && (info & 0x1FFu) != 0u && (info >> 16) > mypos)) {
+            fail = BZ_BAD_MATCH_;
+            break;
+        }
+        if (pos + total > isize) {
+            fail = BZ_BAD_SIZE_;
+            break;
+        }
+        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(marks >> 32), __builtin_amdgcn_mbcnt_lo((u32)marks, 0u));
+        if (tok) {
+            L.qpos[qn + rank] = mypos;
+            L.qinfo[qn + rank] = info;
+        }
+        qn += (u32)__popcll(marks);
+        pos += total;
+        if (qn >= 64u) flush_queue(L, out, qn, lane, false);
+        if (stop < 64u) {
+            if ((u32)__builtin_amdgcn_readlane((int)st, (int)stop) != 1u) {
+                fail = BZ_BAD_CODE_;
+                break;
+            }
+            mbits += stop + (u32)__builtin_amdgcn_readlane((int)nb, (int)stop);
+            break;
+        }
+        mbits += s;
+    }
+    mbits_ref = mbits;
+    pos_ref = pos;
+    qn_ref = qn;
+    return fail;
+}
+
 // status[0]: 0, or (member index << 8 | reason) of a failed member (the largest such word wins)
 enum BgzfFail : u32 {
     BZ_BAD_BLOCK = 1,  // block type 3, stored length check, code lengths that over-subscribe or repeat from nothing
@@ -297,6 +428,8 @@ enum BgzfFail : u32 {
     BZ_BAD_CRC = 6,
 };
 
+// PAR: the symbols of a block are decoded 64 bit offsets at a time (block_symbols_parallel) instead of one by one
+template <bool PAR>
 __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const BgzfMember *members, u32 n_members,
                                                      uint8_t *text, u32 *status) {
     __shared__ Lds L;
@@ -307,7 +440,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const 
     const u32 isize = m.isize;
     Reader r;
     rd_init(r, comp, m.in_off, (u64)m.in_off + m.in_len, 0, lane);
-    u32 fail = 0, pos = 0, ntok = 0, tpos = 0, tinfo = 0;
+    u32 fail = 0, pos = 0, ntok = 0, tpos = 0, tinfo = 0, qn = 0;
     bool final_block = false;
     const u64 in_bits = (u64)m.in_len * 8u;
     while (!final_block && !fail) {
@@ -331,7 +464,8 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const 
                 fail = BZ_BAD_BLOCK;
                 break;
             }
-            resolve_group(out, tpos, tinfo, ntok, lane);
+            if (PAR) flush_queue(L, out, qn, lane, true);
+            else resolve_group(out, tpos, tinfo, ntok, lane);
             ntok = 0;
             const uint8_t *src = comp + m.in_off + used;
             for (u32 j = lane; j < len; j += 64u) out[pos + j] = src[j];
@@ -417,6 +551,16 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const 
             break;
         }
         pair_literals(L.lit, lane);
+        if (PAR) {
+            u64 mb = rd_used_bits(r);
+            fail = block_symbols_parallel(L, comp + m.in_off, in_bits, isize, out, mb, pos, qn, lane);
+            if (fail) break;
+            // the bit reader again, behind the end-of-block code
+            rd_init(r, comp, (u64)m.in_off + (mb >> 3), (u64)m.in_off + m.in_len, (mb >> 3) * 8u, lane);
+            rd_fill(r, lane);
+            rd_take(r, (u32)(mb & 7u));
+            continue;
+        }
         for (;;) { // the block's symbols
             rd_fill(r, lane);
             u32 e = rfl(L.lit[(u32)r.bb & ((1u << LIT_BITS) - 1u)]);
@@ -469,7 +613,10 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const 
         }
     }
     if (!fail && pos != isize) fail = BZ_BAD_SIZE;
-    if (!fail) resolve_group(out, tpos, tinfo, ntok, lane);
+    if (!fail) {
+        if (PAR) flush_queue(L, out, qn, lane, true);
+        else resolve_group(out, tpos, tinfo, ntok, lane);
+    }
     if (!fail && ((rd_used_bits(r) + 7u) >> 3) != m.in_len) fail = BZ_OVERRUN;
     if (fail && lane == 0) atomicMax(status, (mi << 8) | fail);
 }
@@ -599,7 +746,9 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfMember *members, u
         for (int k = 1; k < 32; ++k) x.t[k] = p = crc_multmodp(p, p);
         return x;
     }();
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3(n_members), dim3(64), 0, st, comp, members, n_members, text, status);
+    static const bool serial = getenv("FH_BGZF_SERIAL") != nullptr; // A/B: one symbol at a time
+    if (serial) hipLaunchKernelGGL(k_bgzf_inflate<false>, dim3(n_members), dim3(64), 0, st, comp, members, n_members, text, status);
+    else hipLaunchKernelGGL(k_bgzf_inflate<true>, dim3(n_members), dim3(64), 0, st, comp, members, n_members, text, status);
     hipLaunchKernelGGL(k_bgzf_crc, dim3((n_members + 3u) / 4u), dim3(256), 0, st, members, n_members, (const uint8_t *)text,
                        x2n, status);
     return hipGetLastError();
