@@ -305,10 +305,20 @@ static inline inf::Status marker_codes(inf::Decoder &dec, const uint8_t *&in_ref
             // (distance <= 32768 = the marker slots in front: the source always exists)
             const uint16_t *src = out + o - distance;
             uint16_t any = 0;
-            if (distance >= length) {
-                memcpy(out + o, src, (size_t)length * 2);
-                for (uint32_t i = 0; i < length; ++i) any |= src[i];
-            } else {
+#if defined(__SSE2__)
+            if (distance >= 8) { // eight symbols a step (a step may run up to seven past the match: room is kept, and what
+                                 // it drags along can only make `any` see a marker early)
+                __m128i acc = _mm_setzero_si128();
+                uint16_t *dst = out + o;
+                for (uint32_t i = 0; i < length; i += 8) {
+                    const __m128i v = _mm_loadu_si128((const __m128i *)(src + i));
+                    _mm_storeu_si128((__m128i *)(dst + i), v);
+                    acc = _mm_or_si128(acc, v);
+                }
+                any = (uint16_t)((_mm_movemask_epi8(acc) & 0xAAAA) ? MARK : 0);
+            } else
+#endif
+            {
                 for (uint32_t i = 0; i < length; ++i) {
                     out[o + i] = src[i];
                     any |= src[i];
