@@ -280,3 +280,16 @@ def test_plain_gzip_with_read_threads_goes_through_the_device_splitter_and_can_f
         sk = res.sketch(i)
         assert np.array_equal(sk.arrays[0], okc) and np.array_equal(sk.arrays[1], okm), paths[i]
         assert (sk.seq_length, sk.num_valid_kmers) == o.total_bases_and_kmers()
+
+
+def test_the_one_symbol_at_a_time_loop_still_decodes():
+    """FH_BGZF_SERIAL=1 (read once per process, hence the child): the A/B variant of the inflate kernel's symbol loop"""
+    import subprocess
+    import sys
+    if os.environ.get("FH_BGZF_SERIAL"):
+        pytest.skip("this is the child")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_bgzf_device.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "every_block_type or long_codes or damage"], env=dict(os.environ, FH_BGZF_SERIAL="1"), cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
