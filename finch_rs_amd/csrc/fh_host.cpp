@@ -1109,7 +1109,7 @@ struct XzSource : ByteSource {
 
 // A gzip file whose first member is decoded by several threads (fh_pargz.h); members after the first, and anything the
 // parallel pass cannot make sense of, go through the sequential reader.  FINCH_PARGZ=0 turns it off; FINCH_PARGZ_CHUNK sets
-// the compressed bytes per chunk (default 1 MiB; a batch is four chunks per thread).
+// the compressed bytes per chunk (default 1 MiB; a batch is two chunks per thread, and the next batch is decoded while one is handed out).
 struct ParGzSource : ByteSource {
     std::unique_ptr<ByteSource> inner;
     unsigned n_thr;
@@ -1132,7 +1132,7 @@ struct ParGzSource : ByteSource {
     }
     std::unique_ptr<ByteSource> tail; // the sequential reader, once it has taken over
     uint64_t n_batches = 0, n_chunks = 0, n_false_starts = 0, sym_total = 0;
-    static constexpr size_t CHUNKS_PER_THREAD = 4; // (chunks differ in how long they take: several per thread even that out)
+    static constexpr size_t CHUNKS_PER_THREAD = 2; // (chunks differ in how long they take: more than one per thread evens that out)
     double t_fill = 0, t_find = 0, t_decode = 0, t_resolve = 0, t_deliver = 0; // FH_TRACE
     static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -1141,6 +1141,7 @@ struct ParGzSource : ByteSource {
         chunk_bytes = e ? (size_t)std::max(4096ll, atoll(e)) : ((size_t)1 << 20);
     }
     ~ParGzSource() override {
+        drop_prefetch();
         for (auto &c : ready) recycle(c);
         static const bool trace = getenv("FH_TRACE") != nullptr;
         if (trace && n_batches)
@@ -1153,6 +1154,7 @@ struct ParGzSource : ByteSource {
     bool failed() const override { return bad || (tail && tail->failed()); }
     bool can_rewind() const override { return inner ? inner->can_rewind() : (tail && tail->can_rewind()); }
     bool rewind() override {
+        drop_prefetch();
         if (!inner) { // the sequential reader owns the input: it starts over at the first byte of the file
             if (!tail || !tail->rewind()) return false;
             for (auto &c : ready) recycle(c);
@@ -1246,12 +1248,18 @@ struct ParGzSource : ByteSource {
         for (auto &x : th) x.join();
     }
 
-    // decode the next batch into `ready`; false: nothing more from this reader (end, error, or `tail` has taken over)
-    bool next_batch() {
-        for (auto &c : ready) recycle(c);
-        ready.clear();
-        r_chunk = r_off = 0;
-        if (member_done || bad) return false;
+    // The next batch, decoded.  Runs on a thread of its own while the batch before it is handed out: it owns the compressed
+    // side of the reader (inner, cb, window, crc, member_len) and touches nothing of the hand-over side.
+    enum class Prep { BATCH, END, FALLBACK, BAD };
+    struct Prepared {
+        Prep st = Prep::END;
+        std::vector<pargz::Chunk> chunks;
+        std::unique_ptr<ByteSource> tail; // the reader of the members behind the first, if there are any
+        bool more = false;                // another batch follows
+    };
+    Prepared prepare() {
+        Prepared out;
+        if (member_done) return out;
         // (the first batch is a short one: nothing is sketched before it is through)
         const size_t per_thread = n_batches == 0 ? 1 : CHUNKS_PER_THREAD;
         const size_t batch_bytes = chunk_bytes * n_thr * per_thread;
@@ -1265,15 +1273,15 @@ struct ParGzSource : ByteSource {
                 h = -1;
             }
             if (h <= 0) {
-                bad = true;
-                return false;
+                out.st = Prep::BAD;
+                return out;
             }
             c_bit = (uint64_t)h * 8u;
             started = true;
         }
         if ((c_bit >> 3) >= c_n) { // no block in sight
-            bad = true;
-            return false;
+            out.st = Prep::BAD;
+            return out;
         }
         n_batches++;
         const size_t n_c = std::max<size_t>(1, std::min<size_t>((size_t)n_thr * per_thread, c_n / chunk_bytes));
@@ -1312,8 +1320,8 @@ struct ParGzSource : ByteSource {
             size_t j = i + 1;
             while (j < n_c && ch[j].start_bit != c.end_bit) j++;
             if (j == n_c) { // (decode_chunk stops only where one of these holds)
-                bad = true;
-                return false;
+                out.st = Prep::BAD;
+                return out;
             }
             for (size_t k = i + 1; k < j; ++k) n_false_starts += ch[k].start_bit != UINT64_MAX;
             i = j;
@@ -1324,7 +1332,7 @@ struct ParGzSource : ByteSource {
                 fprintf(stderr, "[pargz] batch %llu chunk %zu: bits %llu..%llu text %zu (+%zu sym) ok %d end %d ooi %d\n", (unsigned long long)n_batches, li,
                         (unsigned long long)ch[li].start_bit, (unsigned long long)ch[li].end_bit, ch[li].n_bytes, ch[li].n_sym, ch[li].ok,
                         ch[li].member_end, ch[li].out_of_input);
-        if (!ch[live.back()].ok) return fall_back();
+        if (!ch[live.back()].ok) return fallback_result();
         // the window in front of every live chunk (in order: a chunk's own tail may still hold markers), then the markers
         // and checksums of all of them side by side
         std::vector<std::vector<uint8_t>> win_in(live.size());
@@ -1341,7 +1349,7 @@ struct ParGzSource : ByteSource {
             pargz::Chunk &c = ch[live[li]];
             if (!pargz::resolve_chunk(c, win_in[li].data() + win_in[li].size(), win_in[li].size())) all_ok = false;
         });
-        if (!all_ok) return fall_back();
+        if (!all_ok) return fallback_result();
         t_resolve += now_s() - t3;
         window = win;
         for (size_t li : live) {
@@ -1355,13 +1363,13 @@ struct ParGzSource : ByteSource {
         if (last.member_end) {
             size_t t = (size_t)((last.end_bit + 7) >> 3);
             if (c_n < t + 8) fill_to(t + 8 + 65536);
-            if (c_n < t + 8) return fall_back(); // (truncated: the sequential reader reports it)
+            if (c_n < t + 8) return fallback_result(); // (truncated: the sequential reader reports it)
             const uint8_t *p = cb.data() + t;
             const uint32_t want_crc = p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
             const uint32_t want_len = p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
             if (want_crc != crc || want_len != (uint32_t)member_len) { // (text has gone out already: there is no quiet way back)
-                bad = true;
-                return false;
+                out.st = Prep::BAD;
+                return out;
             }
             member_done = true;
             t += 8;
@@ -1375,27 +1383,59 @@ struct ParGzSource : ByteSource {
                     auto pre2 = std::make_unique<PrefixedSource>();
                     pre2->prefix.assign(1, b);
                     pre2->inner = std::move(pre);
-                    tail = std::make_unique<FastGzSource>(std::move(pre2));
+                    out.tail = std::make_unique<FastGzSource>(std::move(pre2));
                 }
             }
         } else if (last.out_of_input) {
             // not one whole block in a batch's worth of bytes (or in the rest of the file: truncated): the sequential
             // reader's case
-            if (live.size() == 1 && last.end_bit == c_bit) return fall_back();
+            if (live.size() == 1 && last.end_bit == c_bit) return fallback_result();
             const size_t keep_from = (size_t)(last.end_bit >> 3);
             memmove(cb.data(), cb.data() + keep_from, c_n - keep_from);
             c_n -= keep_from;
             c_bit = last.end_bit & 7u;
         } else {
-            bad = true;
-            return false;
+            out.st = Prep::BAD;
+            return out;
         }
-        ready.reserve(live.size());
+        out.chunks.reserve(live.size());
         for (size_t li : live) {
             pargz::BufPool::global().put(pargz::rebind<uint8_t>(std::move(ch[li].sym)));
-            ready.push_back(std::move(ch[li]));
+            out.chunks.push_back(std::move(ch[li]));
         }
         for (auto &c : ch) recycle(c); // (the chunks that began at false starts; moved-from ones hold nothing)
+        out.st = Prep::BATCH;
+        out.more = !member_done;
+        return out;
+    }
+
+    static Prepared fallback_result() {
+        Prepared p;
+        p.st = Prep::FALLBACK;
+        return p;
+    }
+    std::future<Prepared> fut;
+    void drop_prefetch() { // (rewind, destruction)
+        if (!fut.valid()) return;
+        Prepared p = fut.get();
+        for (auto &c : p.chunks) recycle(c);
+    }
+    // the next batch into `ready` (and the one after it into the making); false: nothing more from this reader
+    bool next_batch() {
+        for (auto &c : ready) recycle(c);
+        ready.clear();
+        r_chunk = r_off = 0;
+        if (bad) return false;
+        Prepared p = fut.valid() ? fut.get() : prepare();
+        ready = std::move(p.chunks);
+        if (p.tail) tail = std::move(p.tail);
+        switch (p.st) {
+        case Prep::BAD: bad = true; return false;
+        case Prep::FALLBACK: return fall_back();
+        case Prep::END: return false;
+        case Prep::BATCH: break;
+        }
+        if (p.more && n_thr > 1) fut = std::async(std::launch::async, [this] { return prepare(); });
         return true;
     }
 
