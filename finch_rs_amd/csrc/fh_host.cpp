@@ -1127,7 +1127,6 @@ struct ParGzSource : ByteSource {
     static void recycle(pargz::Chunk &c) {
         pargz::BufPool &pool = pargz::BufPool::global();
         pool.put(pargz::rebind<uint8_t>(std::move(c.sym)));
-        pool.put(std::move(c.head));
         pool.put(std::move(c.bytes));
     }
     std::unique_ptr<ByteSource> tail; // the sequential reader, once it has taken over
@@ -1148,7 +1147,7 @@ struct ParGzSource : ByteSource {
             fprintf(stderr, "[finch] parallel gzip: %llu batches, %llu chunks (%llu false starts), %.1f %% of the text decoded with markers, %u threads%s\n",
                     (unsigned long long)n_batches, (unsigned long long)n_chunks, (unsigned long long)n_false_starts,
                     100.0 * (double)sym_total / (double)std::max<uint64_t>(1, delivered), n_thr, tail ? "; sequential reader took over" : ""),
-            fprintf(stderr, "[finch] parallel gzip: read %.1f ms, block search %.1f ms, decode %.1f ms, markers + CRC %.1f ms, hand-over %.1f ms\n",
+            fprintf(stderr, "[finch] parallel gzip: read %.1f ms, block search %.1f ms, decode %.1f ms, windows %.1f ms, hand-over (markers, CRC) %.1f ms\n",
                     t_fill * 1e3, t_find * 1e3, t_decode * 1e3, t_resolve * 1e3, t_deliver * 1e3);
     }
     bool failed() const override { return bad || (tail && tail->failed()); }
@@ -1174,6 +1173,7 @@ struct ParGzSource : ByteSource {
         member_len = delivered = 0;
         ready.clear();
         r_chunk = r_off = 0;
+        crc_due = false;
         tail.reset();
         return true;
     }
@@ -1256,6 +1256,8 @@ struct ParGzSource : ByteSource {
         std::vector<pargz::Chunk> chunks;
         std::unique_ptr<ByteSource> tail; // the reader of the members behind the first, if there are any
         bool more = false;                // another batch follows
+        bool check_crc = false;           // the member ends with this batch: its CRC-32 is due when the text is out
+        uint32_t want_crc = 0;
     };
     Prepared prepare() {
         Prepared out;
@@ -1292,7 +1294,6 @@ struct ParGzSource : ByteSource {
             pargz::BufPool &pool = pargz::BufPool::global();
             if (i > 0) ch[i].sym = pargz::rebind<uint16_t>(pool.get());
             else ch[i].bytes = pool.get(); // (the first chunk decodes to bytes from the start)
-            ch[i].head = pool.get();
         }
         const uint8_t *base = cb.data();
         const size_t n = c_n;
@@ -1333,30 +1334,23 @@ struct ParGzSource : ByteSource {
                         (unsigned long long)ch[li].start_bit, (unsigned long long)ch[li].end_bit, ch[li].n_bytes, ch[li].n_sym, ch[li].ok,
                         ch[li].member_end, ch[li].out_of_input);
         if (!ch[live.back()].ok) return fallback_result();
-        // the window in front of every live chunk (in order: a chunk's own tail may still hold markers), then the markers
-        // and checksums of all of them side by side
-        std::vector<std::vector<uint8_t>> win_in(live.size());
+        // the window in front of every live chunk, in order (a chunk's own tail may still hold markers); the markers
+        // themselves are looked up when the text is handed out
         std::vector<uint8_t> win = window;
         bool ok = true;
         for (size_t li = 0; li < live.size(); ++li) {
-            win_in[li] = win;
+            pargz::Chunk &c = ch[live[li]];
+            c.win_in = win;
             std::vector<uint8_t> nxt;
-            ok = pargz::window_behind(ch[live[li]], win_in[li], nxt) && ok;
+            ok = pargz::window_behind(c, c.win_in, nxt) && ok;
             win.swap(nxt);
         }
-        std::atomic<bool> all_ok{ok};
-        parallel(live.size(), [&](size_t li) {
-            pargz::Chunk &c = ch[live[li]];
-            if (!pargz::resolve_chunk(c, win_in[li].data() + win_in[li].size(), win_in[li].size())) all_ok = false;
-        });
-        if (!all_ok) return fallback_result();
+        if (!ok) return fallback_result();
         t_resolve += now_s() - t3;
         window = win;
         for (size_t li : live) {
-            pargz::Chunk &c = ch[li];
-            crc = (uint32_t)crc32_combine(crc, c.crc, (z_off_t)c.text_len());
-            member_len += c.text_len();
-            sym_total += c.n_head;
+            member_len += ch[li].text_len();
+            sym_total += ch[li].n_sym;
         }
         // 4. where the batch ended
         const pargz::Chunk &last = ch[live.back()];
@@ -1367,10 +1361,12 @@ struct ParGzSource : ByteSource {
             const uint8_t *p = cb.data() + t;
             const uint32_t want_crc = p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
             const uint32_t want_len = p[4] | ((uint32_t)p[5] << 8) | ((uint32_t)p[6] << 16) | ((uint32_t)p[7] << 24);
-            if (want_crc != crc || want_len != (uint32_t)member_len) { // (text has gone out already: there is no quiet way back)
+            if (want_len != (uint32_t)member_len) { // (text has gone out already: there is no quiet way back)
                 out.st = Prep::BAD;
                 return out;
             }
+            out.check_crc = true; // (known once this batch's text has been handed out)
+            out.want_crc = want_crc;
             member_done = true;
             t += 8;
             if (c_n > t || !in_eof) { // more members: the sequential reader's
@@ -1399,10 +1395,7 @@ struct ParGzSource : ByteSource {
             return out;
         }
         out.chunks.reserve(live.size());
-        for (size_t li : live) {
-            pargz::BufPool::global().put(pargz::rebind<uint8_t>(std::move(ch[li].sym)));
-            out.chunks.push_back(std::move(ch[li]));
-        }
+        for (size_t li : live) out.chunks.push_back(std::move(ch[li]));
         for (auto &c : ch) recycle(c); // (the chunks that began at false starts; moved-from ones hold nothing)
         out.st = Prep::BATCH;
         out.more = !member_done;
@@ -1415,6 +1408,8 @@ struct ParGzSource : ByteSource {
         return p;
     }
     std::future<Prepared> fut;
+    bool crc_due = false; // the batch in `ready` ends the member
+    uint32_t crc_wanted = 0;
     void drop_prefetch() { // (rewind, destruction)
         if (!fut.valid()) return;
         Prepared p = fut.get();
@@ -1429,6 +1424,8 @@ struct ParGzSource : ByteSource {
         Prepared p = fut.valid() ? fut.get() : prepare();
         ready = std::move(p.chunks);
         if (p.tail) tail = std::move(p.tail);
+        crc_due = p.check_crc;
+        crc_wanted = p.want_crc;
         switch (p.st) {
         case Prep::BAD: bad = true; return false;
         case Prep::FALLBACK: return fall_back();
@@ -1450,9 +1447,15 @@ struct ParGzSource : ByteSource {
                 continue;
             }
             if (r_chunk < ready.size()) {
-                // segments of the ready text that fit the request, copied by several threads when there is much of it
+                // The segments of the ready text that fit the request: bytes are copied, symbols narrowed (markers looked up
+                // in the window in front of their chunk) -- by several threads when there is much of it, each of which also
+                // checksums the stretch it has just written.
                 const double td0 = now_s();
-                struct Seg { const uint8_t *p; size_t len, at; };
+                struct Seg {
+                    const pargz::Chunk *c;
+                    bool sym;
+                    size_t off, len; // within the chunk's symbols / bytes
+                };
                 std::vector<Seg> segs;
                 size_t m = 0;
                 while (r_chunk < ready.size() && n + m < cap) {
@@ -1463,30 +1466,57 @@ struct ParGzSource : ByteSource {
                         r_off = 0;
                         continue;
                     }
-                    const bool in_head = r_off < c.n_head;
-                    const uint8_t *p = in_head ? c.head.data() + r_off : c.bytes.data() + (r_off - c.n_head);
-                    const size_t len = std::min(cap - n - m, (in_head ? c.n_head : total) - r_off);
-                    segs.push_back(Seg{p, len, n + m});
+                    const bool in_sym = r_off < c.n_sym;
+                    const size_t len = std::min(cap - n - m, (in_sym ? c.n_sym : total) - r_off);
+                    segs.push_back(Seg{&c, in_sym, in_sym ? r_off : r_off - c.n_sym, len});
                     m += len;
                     r_off += len;
                 }
+                uint8_t *const base = dst + n;
+                std::atomic<bool> ok{true};
+                auto stretch = [&](size_t lo, size_t hi) { // text [lo, hi) of this hand-over; returns its CRC-32
+                    size_t pos = 0;
+                    for (const Seg &sg : segs) {
+                        const size_t a = std::max(lo, pos), b = std::min(hi, pos + sg.len);
+                        if (a < b) {
+                            const size_t o = sg.off + (a - pos);
+                            if (sg.sym) {
+                                const std::vector<uint8_t> &w = sg.c->win_in;
+                                if (!pargz::resolve_span(sg.c->sym.data() + pargz::WINDOW + o, b - a, w.data() + w.size(), w.size(), base + a)) ok = false;
+                            } else {
+                                memcpy(base + a, sg.c->bytes.data() + o, b - a);
+                            }
+                        }
+                        pos += sg.len;
+                    }
+                    return inf::crc32_fast(0, base + lo, hi - lo);
+                };
                 if (m >= ((size_t)8 << 20) && n_thr > 1) {
                     const size_t per = (m + n_thr - 1) / n_thr;
+                    std::vector<uint32_t> crcs(n_thr, 0);
                     parallel(n_thr, [&](size_t t) {
-                        const size_t lo = t * per, hi = std::min(m, lo + per);
-                        size_t pos = 0;
-                        for (const Seg &sg : segs) {
-                            const size_t a = std::max(lo, pos), b = std::min(hi, pos + sg.len);
-                            if (a < b) memcpy(dst + sg.at + (a - pos), sg.p + (a - pos), b - a);
-                            pos += sg.len;
-                        }
+                        const size_t lo = std::min(m, t * per), hi = std::min(m, lo + per);
+                        if (lo < hi) crcs[t] = stretch(lo, hi);
                     });
-                } else {
-                    for (const Seg &sg : segs) memcpy(dst + sg.at, sg.p, sg.len);
+                    for (size_t t = 0; t < n_thr; ++t) {
+                        const size_t lo = std::min(m, t * per), hi = std::min(m, lo + per);
+                        if (lo < hi) crc = (uint32_t)crc32_combine(crc, crcs[t], (z_off_t)(hi - lo));
+                    }
+                } else if (m) {
+                    crc = (uint32_t)crc32_combine(crc, stretch(0, m), (z_off_t)m);
                 }
+                if (!ok) bad = true; // a marker that points before the start of the stream
                 n += m;
                 delivered += m;
                 t_deliver += now_s() - td0;
+                if (r_chunk < ready.size() && r_off >= ready[r_chunk].text_len()) {
+                    r_chunk++;
+                    r_off = 0;
+                }
+                if (r_chunk >= ready.size() && crc_due) { // the member's text is out: its checksum
+                    crc_due = false;
+                    if (crc != crc_wanted) bad = true;
+                }
                 continue;
             }
             if (!next_batch() && !tail) break;

@@ -14,8 +14,9 @@
 //      the thread switches to the ordinary byte decoder (fh_inflate.h, full speed).  A thread stops at the block boundary
 //      where the next chunk was found to begin; if it runs past that offset instead, the "start" was not one, the next
 //      chunk's work is dropped and the thread carries on to the one after.
-//   3. In order: the window in front of chunk i is the last 32 KiB of the text up to it, which resolves chunk i's markers
-//      (in parallel again); CRC-32s of the chunks are computed in parallel and combined (crc32_combine).
+//   3. In order: the window in front of chunk i is the last 32 KiB of the text up to it (taken from the chunk tails alone).
+//      The markers are looked up when the text is handed out: symbols are narrowed straight into the caller's buffer by
+//      several threads, each of which checksums what it has just written; the CRC-32s are joined with crc32_combine.
 //
 // The member's CRC-32 and ISIZE are checked at its end as always, so a chunk stitched wrongly cannot go unnoticed.
 #pragma once
@@ -225,11 +226,9 @@ struct Chunk {
     bool out_of_input = false; // the batch's bytes ended inside the block that starts at end_bit
     GrowBuf<uint16_t> sym;     // symbols while the unknown window can still show through (WINDOW marker slots in front)
     size_t n_sym = 0;          // symbols behind the WINDOW slots
-    GrowBuf<uint8_t> head;     // sym resolved (pass 3): n_sym bytes
-    size_t n_head = 0;
+    std::vector<uint8_t> win_in; // (pass 3) the text in front of the chunk: what its markers point into
     GrowBuf<uint8_t> bytes;
     size_t n_bytes = 0;
-    uint32_t crc = 0;
     size_t text_len() const { return n_sym + n_bytes; }
 };
 
@@ -485,16 +484,6 @@ static inline bool window_behind(const Chunk &c, const std::vector<uint8_t> &win
     const bool ok = resolve_span(c.sym.data() + WINDOW + first, from_sym, win_in.data() + win_in.size(), win_in.size(), w.data() + old);
     if (take > from_sym) memcpy(w.data() + old + from_sym, c.bytes.data() + (first + from_sym - c.n_sym), take - from_sym);
     win_out.swap(w);
-    return ok;
-}
-
-// pass 3 for one chunk: its markers looked up in the window in front of it, then its CRC-32
-static inline bool resolve_chunk(Chunk &c, const uint8_t *window_end, size_t window_len) {
-    c.head.reserve(c.n_sym + 8);
-    c.n_head = c.n_sym;
-    const bool ok = resolve_span(c.sym.data() + WINDOW, c.n_sym, window_end, window_len, c.head.data());
-    c.crc = inf::crc32_fast(0, c.head.data(), c.n_head);
-    c.crc = inf::crc32_fast(c.crc, c.bytes.data(), c.n_bytes);
     return ok;
 }
 
