@@ -28,7 +28,7 @@ if "FH_K2_FLAGS" in os.environ:  # A/B builds of the sketch kernel only
 OUT = os.environ.get("FH_OUT", OUT)
 
 SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2_common.h", "fh_k2w.hip", "fh_k2.hip", "fh_kernels.hip", "fh_big.hip", "fh_text.hip", "fh_bgzf.hip", "fh_api.hip", "fh_host.cpp",
-           "fh_host_model.h", "fh_serial.cpp", os.path.join("..", "..", "include", "finch_host.h"),
+           "fh_host_model.h", "fh_inflate.h", "fh_pargz.h", "fh_serial.cpp", os.path.join("..", "..", "include", "finch_host.h"),
            os.path.join("..", "..", "include", "finch_hip.h")]
 
 

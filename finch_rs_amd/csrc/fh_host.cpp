@@ -1128,7 +1128,6 @@ struct ParGzSource : ByteSource {
         pargz::BufPool &pool = pargz::BufPool::global();
         pool.put(pargz::rebind<uint8_t>(std::move(c.sym)));
         pool.put(std::move(c.bytes));
-        c.dirty.release();
     }
     std::unique_ptr<ByteSource> tail; // the sequential reader, once it has taken over
     uint64_t n_batches = 0, n_chunks = 0, n_false_starts = 0, sym_total = 0;
@@ -1145,10 +1144,10 @@ struct ParGzSource : ByteSource {
         for (auto &c : ready) recycle(c);
         static const bool trace = getenv("FH_TRACE") != nullptr;
         if (trace && n_batches)
-            fprintf(stderr, "[finch] parallel gzip: %llu batches, %llu chunks (%llu false starts), %.1f %% of the text in words with marks, %u threads%s\n",
+            fprintf(stderr, "[finch] parallel gzip: %llu batches, %llu chunks (%llu false starts), %.1f %% of the text decoded with markers, %u threads%s\n",
                     (unsigned long long)n_batches, (unsigned long long)n_chunks, (unsigned long long)n_false_starts,
                     100.0 * (double)sym_total / (double)std::max<uint64_t>(1, delivered), n_thr, tail ? "; sequential reader took over" : ""),
-            fprintf(stderr, "[finch] parallel gzip: read %.1f ms, block search %.1f ms, decode %.1f ms, windows + marks %.1f ms, hand-over (copy, CRC) %.1f ms\n",
+            fprintf(stderr, "[finch] parallel gzip: read %.1f ms, block search %.1f ms, decode %.1f ms, windows %.1f ms, hand-over (markers, CRC) %.1f ms\n",
                     t_fill * 1e3, t_find * 1e3, t_decode * 1e3, t_resolve * 1e3, t_deliver * 1e3);
     }
     bool failed() const override { return bad || (tail && tail->failed()); }
@@ -1293,8 +1292,8 @@ struct ParGzSource : ByteSource {
         ch[0].known_window = true;
         for (size_t i = 0; i < n_c; ++i) {
             pargz::BufPool &pool = pargz::BufPool::global();
-            ch[i].bytes = pool.get();
-            if (i > 0) ch[i].sym = pargz::rebind<uint16_t>(pool.get()); // (the first chunk's window is known)
+            if (i > 0) ch[i].sym = pargz::rebind<uint16_t>(pool.get());
+            else ch[i].bytes = pool.get(); // (the first chunk decodes to bytes from the start)
         }
         const uint8_t *base = cb.data();
         const size_t n = c_n;
@@ -1331,12 +1330,12 @@ struct ParGzSource : ByteSource {
         n_chunks += live.size();
         if (getenv("FH_TRACE_PARGZ"))
             for (size_t li : live)
-                fprintf(stderr, "[pargz] batch %llu chunk %zu: bits %llu..%llu text %zu (%zu dirty words) ok %d end %d ooi %d\n", (unsigned long long)n_batches, li,
-                        (unsigned long long)ch[li].start_bit, (unsigned long long)ch[li].end_bit, ch[li].n_bytes, pargz::count_dirty_words(ch[li]), ch[li].ok,
+                fprintf(stderr, "[pargz] batch %llu chunk %zu: bits %llu..%llu text %zu (+%zu sym) ok %d end %d ooi %d\n", (unsigned long long)n_batches, li,
+                        (unsigned long long)ch[li].start_bit, (unsigned long long)ch[li].end_bit, ch[li].n_bytes, ch[li].n_sym, ch[li].ok,
                         ch[li].member_end, ch[li].out_of_input);
         if (!ch[live.back()].ok) return fallback_result();
-        // the window in front of every live chunk, in order (a chunk's own tail is put right on the way), then every chunk
-        // looks its marks up, side by side
+        // the window in front of every live chunk, in order (a chunk's own tail may still hold markers); the markers
+        // themselves are looked up when the text is handed out
         std::vector<uint8_t> win = window;
         bool ok = true;
         for (size_t li = 0; li < live.size(); ++li) {
@@ -1346,18 +1345,12 @@ struct ParGzSource : ByteSource {
             ok = pargz::window_behind(c, c.win_in, nxt) && ok;
             win.swap(nxt);
         }
-        std::atomic<bool> all_ok{ok};
-        parallel(live.size(), [&](size_t li) {
-            pargz::Chunk &c = ch[live[li]];
-            c.n_dirty_words = pargz::count_dirty_words(c);
-            if (!pargz::resolve_range(c, 0, c.text_len(), c.win_in.data() + c.win_in.size(), c.win_in.size())) all_ok = false;
-        });
-        if (!all_ok) return fallback_result();
+        if (!ok) return fallback_result();
         t_resolve += now_s() - t3;
         window = win;
         for (size_t li : live) {
             member_len += ch[li].text_len();
-            sym_total += ch[li].n_dirty_words * 8;
+            sym_total += ch[li].n_sym;
         }
         // 4. where the batch ended
         const pargz::Chunk &last = ch[live.back()];
@@ -1454,12 +1447,14 @@ struct ParGzSource : ByteSource {
                 continue;
             }
             if (r_chunk < ready.size()) {
-                // The segments of the ready text that fit the request, copied by several threads when there is much of it,
-                // each of which also checksums the stretch it has just written.
+                // The segments of the ready text that fit the request: bytes are copied, symbols narrowed (markers looked up
+                // in the window in front of their chunk) -- by several threads when there is much of it, each of which also
+                // checksums the stretch it has just written.
                 const double td0 = now_s();
                 struct Seg {
-                    const uint8_t *p;
-                    size_t len;
+                    const pargz::Chunk *c;
+                    bool sym;
+                    size_t off, len; // within the chunk's symbols / bytes
                 };
                 std::vector<Seg> segs;
                 size_t m = 0;
@@ -1471,17 +1466,27 @@ struct ParGzSource : ByteSource {
                         r_off = 0;
                         continue;
                     }
-                    const size_t len = std::min(cap - n - m, total - r_off);
-                    segs.push_back(Seg{c.text() + r_off, len});
+                    const bool in_sym = r_off < c.n_sym;
+                    const size_t len = std::min(cap - n - m, (in_sym ? c.n_sym : total) - r_off);
+                    segs.push_back(Seg{&c, in_sym, in_sym ? r_off : r_off - c.n_sym, len});
                     m += len;
                     r_off += len;
                 }
                 uint8_t *const base = dst + n;
+                std::atomic<bool> ok{true};
                 auto stretch = [&](size_t lo, size_t hi) { // text [lo, hi) of this hand-over; returns its CRC-32
                     size_t pos = 0;
                     for (const Seg &sg : segs) {
                         const size_t a = std::max(lo, pos), b = std::min(hi, pos + sg.len);
-                        if (a < b) memcpy(base + a, sg.p + (a - pos), b - a);
+                        if (a < b) {
+                            const size_t o = sg.off + (a - pos);
+                            if (sg.sym) {
+                                const std::vector<uint8_t> &w = sg.c->win_in;
+                                if (!pargz::resolve_span(sg.c->sym.data() + pargz::WINDOW + o, b - a, w.data() + w.size(), w.size(), base + a)) ok = false;
+                            } else {
+                                memcpy(base + a, sg.c->bytes.data() + o, b - a);
+                            }
+                        }
                         pos += sg.len;
                     }
                     return inf::crc32_fast(0, base + lo, hi - lo);
@@ -1500,6 +1505,7 @@ struct ParGzSource : ByteSource {
                 } else if (m) {
                     crc = (uint32_t)crc32_combine(crc, stretch(0, m), (z_off_t)m);
                 }
+                if (!ok) bad = true; // a marker that points before the start of the stream
                 n += m;
                 delivered += m;
                 t_deliver += now_s() - td0;

@@ -8,18 +8,15 @@
 //   1. The compressed bytes are cut into chunks.  In each chunk but the first, a thread looks for the start of a DEFLATE
 //      block: it tries every bit offset as the header of a dynamic-Huffman block and keeps the first one whose three codes
 //      are complete and whose first symbols decode to text (FASTA / FASTQ is all this reader serves).
-//   2. Every thread decodes from its start.  What lies before it is unknown: a byte copied from there is a mark, 0x8000 + i
-//      for "byte i of the 32 KiB window in front of this chunk", and copying a match copies marks along.  pugz and
-//      rapidgzip decode to 16-bit symbols for that; on sequencing reads marks never die out (every header line is a copy of
-//      a copy of ... a header in the unknown window), so here the text is decoded to bytes at once and the marks are kept on
-//      the side, sparsely: one bit per 8-byte word says whether the word holds anything of the unknown window, and only such
-//      words have their positions written as 16-bit symbols too.  A match whose source words are all clean -- one 64-bit
-//      look at the bitmap -- is the ordinary byte copy; 5-50 % of the words are dirty, depending on the data.  A thread
-//      stops at the block boundary where the next chunk was found to begin; if it runs past that offset instead, the
-//      "start" was not one, the next chunk's work is dropped and the thread carries on to the one after.
-//   3. In order: the window in front of chunk i is the last 32 KiB of the text up to it (a chunk's tail is put right
-//      first), then every chunk looks its marks up in its window, side by side.  The text is handed out by several threads,
-//      each of which checksums what it has just copied; the CRC-32s are joined with crc32_combine.
+//   2. Every thread decodes from its start.  What lies before it is unknown, so the output is 16-bit symbols: a byte, or
+//      0x8000 + i for "byte i of the 32 KiB window in front of this chunk"; copying a match copies such markers along.
+//      As soon as the last 32 KiB produced hold no marker, everything after them is independent of the unknown window and
+//      the thread switches to the ordinary byte decoder (fh_inflate.h, full speed).  A thread stops at the block boundary
+//      where the next chunk was found to begin; if it runs past that offset instead, the "start" was not one, the next
+//      chunk's work is dropped and the thread carries on to the one after.
+//   3. In order: the window in front of chunk i is the last 32 KiB of the text up to it (taken from the chunk tails alone).
+//      The markers are looked up when the text is handed out: symbols are narrowed straight into the caller's buffer by
+//      several threads, each of which checksums what it has just written; the CRC-32s are joined with crc32_combine.
 //
 // The member's CRC-32 and ISIZE are checked at its end as always, so a chunk stitched wrongly cannot go unnoticed.
 #pragma once
@@ -221,71 +218,36 @@ struct BufPool {
     }
 };
 
-// A chunk's text.  A chunk that starts at a known window (the first of a batch) is plain bytes.  Any other one is decoded
-// into bytes too, with what the unknown window shows through kept on the side: `dirty` has one bit per 8-byte word of the
-// text (the WINDOW bytes in front of it included), and where a word's bit is set, `sym` holds all its positions as 16-bit
-// symbols -- a byte, or MARK + i for byte i of the window.  Everything else in `sym` is never touched (no memory behind it).
 struct Chunk {
     uint64_t start_bit = UINT64_MAX, end_bit = 0;
-    bool known_window = false; // the first chunk of a batch
+    bool known_window = false; // the first chunk of a batch: decoded as bytes from the start
     bool ok = true;            // false: a code that cannot be, a match reaching beyond the window
     bool member_end = false;   // the final block ended at end_bit
     bool out_of_input = false; // the batch's bytes ended inside the block that starts at end_bit
-    size_t lead = 0;           // bytes in front of the text in `bytes` (WINDOW when the window is unknown)
+    GrowBuf<uint16_t> sym;     // symbols while the unknown window can still show through (WINDOW marker slots in front)
+    size_t n_sym = 0;          // symbols behind the WINDOW slots
+    std::vector<uint8_t> win_in; // (pass 3) the text in front of the chunk: what its markers point into
     GrowBuf<uint8_t> bytes;
-    size_t n_bytes = 0;        // length of the text
-    GrowBuf<uint16_t> sym;     // (same indexing as bytes)
-    GrowBuf<uint8_t> dirty;    // bit w: word w of `bytes` holds something of the unknown window
-    size_t n_dirty_words = 0;  // (statistics)
-    std::vector<uint8_t> win_in; // the text in front of the chunk, once it is known
-    size_t text_len() const { return n_bytes; }
-    const uint8_t *text() const { return bytes.data() + lead; }
+    size_t n_bytes = 0;
+    size_t text_len() const { return n_sym + n_bytes; }
 };
 
-static inline bool bit_at(const uint8_t *bm, size_t i) { return (bm[i >> 3] >> (i & 7)) & 1u; }
-static inline void set_bits(uint8_t *bm, size_t lo, size_t hi) { // [lo, hi]
-    for (size_t i = lo; i <= hi; ++i) bm[i >> 3] |= (uint8_t)(1u << (i & 7));
-}
-
-// room for `want` positions in all three arrays (GrowBuf::size() is the capacity)
-static inline void grow_sparse(Chunk &c, size_t want) {
-    const size_t old = c.bytes.size();
-    if (want + 64 > old) c.bytes.reserve(std::max(want + 64, old + old / 2 + 65536));
-    c.sym.reserve(c.bytes.size());
-    const size_t old_bm = c.dirty.size(), bm = c.bytes.size() / 64 + 64;
-    if (bm > old_bm) {
-        c.dirty.reserve(bm);
-        memset(c.dirty.data() + old_bm, 0, c.dirty.size() - old_bm);
-    }
-}
-
-static inline size_t count_dirty_words(const Chunk &c) {
-    if (c.known_window) return 0;
-    size_t n = 0;
-    const size_t w0 = c.lead >> 3, w1 = (c.lead + c.n_bytes + 7) >> 3;
-    for (size_t w = w0; w < w1; ++w) n += bit_at(c.dirty.data(), w);
-    return n;
-}
-
-// The symbols of the block at hand (dec.state == CODES) into the chunk.  o: index of the next output position in
-// c.bytes (lead included); fix_until: positions below it lie in a word that is already dirty, so whatever is written there
-// goes into c.sym as well.  OK at the end of the block.
-static inline inf::Status sparse_codes(inf::Decoder &dec, const uint8_t *&in_ref, const uint8_t *in_end, Chunk &c, size_t &o_ref, size_t &fix_ref) {
+// Symbols of the block at hand (dec.state == CODES) as 16-bit values behind c.sym[WINDOW + c.n_sym).  last_marker: index
+// (in symbols behind the window slots) just past the latest marker written.  OK at the end of the block.
+static inline inf::Status marker_codes(inf::Decoder &dec, const uint8_t *&in_ref, const uint8_t *in_end, Chunk &c, size_t &last_marker) {
     const uint8_t *in = in_ref;
     uint64_t bb = dec.bitbuf;
     int bc = dec.bitcnt;
     const uint32_t *const LT = dec.lit, *const DT = dec.dist;
-    size_t o = o_ref, fix_until = fix_ref;
+    size_t o = WINDOW + c.n_sym;
     inf::Status result = inf::OK;
     for (;;) {
         if (in > in_end) { // (into the padding: the block does not end in this buffer)
             result = inf::NEED_INPUT;
             break;
         }
-        if (o + 764 > c.bytes.size()) grow_sparse(c, o + 764);
-        uint8_t *const o8 = c.bytes.data();
-        uint16_t *const o16 = c.sym.data();
-        uint8_t *const bm = c.dirty.data();
+        if (o + 600 > c.sym.size()) c.sym.reserve(c.sym.size() + c.sym.size() / 2 + 65536);
+        uint16_t *const out = c.sym.data();
         bb |= inf::Decoder::load64(in) << bc;
         in += (63 - bc) >> 3;
         bc |= 56;
@@ -297,12 +259,8 @@ static inline inf::Status sparse_codes(inf::Decoder &dec, const uint8_t *&in_ref
                 e = LT[(e >> 16) + (uint32_t)(bb & ((1u << ((e >> 8) & 15u)) - 1u))];
             }
             if (!(e & inf::K_LITERAL)) break;
-            o8[o] = (uint8_t)(e >> 16);
-            o8[o + 1] = (uint8_t)(e >> 24);
-            if (__builtin_expect(o < fix_until, 0)) {
-                o16[o] = (uint8_t)(e >> 16);
-                o16[o + 1] = (uint8_t)(e >> 24);
-            }
+            out[o] = (uint16_t)((e >> 16) & 0xFFu);
+            out[o + 1] = (uint16_t)(e >> 24);
             o += 1 + (((e >> 8) & 15u) != 0u);
             bb >>= (e & 0xFFu);
             bc -= (int)(e & 0xFFu);
@@ -343,56 +301,30 @@ static inline inf::Status sparse_codes(inf::Decoder &dec, const uint8_t *&in_ref
             const uint32_t distance = (d >> 16) + (uint32_t)((bb >> (dtotal - dnx)) & ((1u << dnx) - 1u));
             bb >>= dtotal;
             bc -= (int)dtotal;
-            // (distance <= 32768 <= lead: the source always exists)
-            const size_t src = o - distance;
-            // does the part of the source that exists already touch a dirty word?  (<= 34 words: one 64-bit look)
-            const uint32_t span = length < distance ? length : distance;
-            const size_t ws = src >> 3, nw = ((src + span - 1) >> 3) - ws + 1;
-            const uint64_t bits = (inf::Decoder::load64(bm + (ws >> 3)) >> (ws & 7u)) & ((1ull << nw) - 1ull);
-            if (__builtin_expect(bits == 0, 1)) {
-                const uint8_t *sp = o8 + src;
-                uint8_t *op = o8 + o, *const end = op + length;
-                if (distance >= 16) {
-                    do {
-                        memcpy(op, sp, 16);
-                        op += 16;
-                        sp += 16;
-                    } while (op < end);
-                } else if (distance >= 8) {
-                    do {
-                        memcpy(op, sp, 8);
-                        op += 8;
-                        sp += 8;
-                    } while (op < end);
-                } else if (distance == 1) {
-                    const uint64_t v = 0x0101010101010101ull * sp[0];
-                    do {
-                        memcpy(op, &v, 8);
-                        op += 8;
-                    } while (op < end);
-                } else {
-                    do *op++ = *sp++;
-                    while (op < end);
+            // (distance <= 32768 = the marker slots in front: the source always exists)
+            const uint16_t *src = out + o - distance;
+            uint16_t any = 0;
+#if defined(__SSE2__)
+            if (distance >= 8) { // eight symbols a step (a step may run up to seven past the match: room is kept, and what
+                                 // it drags along can only make `any` see a marker early)
+                __m128i acc = _mm_setzero_si128();
+                uint16_t *dst = out + o;
+                for (uint32_t i = 0; i < length; i += 8) {
+                    const __m128i v = _mm_loadu_si128((const __m128i *)(src + i));
+                    _mm_storeu_si128((__m128i *)(dst + i), v);
+                    acc = _mm_or_si128(acc, v);
                 }
-                if (__builtin_expect(o < fix_until, 0)) {
-                    const size_t lim = std::min<size_t>(o + length, fix_until);
-                    for (size_t p2 = o; p2 < lim; ++p2) o16[p2] = o8[p2];
-                }
-                o += length;
-            } else {
-                const size_t w0 = o >> 3, w1 = (o + length - 1) >> 3;
-                if (!bit_at(bm, w0))
-                    for (size_t p2 = w0 << 3; p2 < o; ++p2) o16[p2] = o8[p2]; // what the first word holds so far
-                set_bits(bm, w0, w1);
+                any = (uint16_t)((_mm_movemask_epi8(acc) & 0xAAAA) ? MARK : 0);
+            } else
+#endif
+            {
                 for (uint32_t i = 0; i < length; ++i) {
-                    const size_t p2 = src + i;
-                    const uint16_t v = bit_at(bm, p2 >> 3) ? o16[p2] : (uint16_t)o8[p2];
-                    o16[o + i] = v;
-                    o8[o + i] = (uint8_t)v;
+                    out[o + i] = src[i];
+                    any |= src[i];
                 }
-                o += length;
-                fix_until = (w1 + 1) << 3;
             }
+            o += length;
+            if (any & MARK) last_marker = o - WINDOW;
         }
     next_symbol:;
     }
@@ -400,14 +332,13 @@ static inline inf::Status sparse_codes(inf::Decoder &dec, const uint8_t *&in_ref
     dec.bitbuf = bb;
     dec.bitcnt = bc;
     in_ref = in;
-    o_ref = o;
-    fix_ref = fix_until;
+    c.n_sym = o - WINDOW;
     return result;
 }
 
-// Decode chunk `ci` of the batch base[0, n) (n bytes + 64 bytes of zero padding) from its start_bit.  It stops at the first
-// block boundary where a later chunk was found to begin (start_bit; UINT64_MAX: nowhere); starts it runs past were not
-// starts.  With a known window (the first chunk of a batch) `window` holds the text in front of it.
+// Decode chunk `ci` of the batch base[0, n) (n bytes + 64 bytes of zero padding) from its start_bit.  It stops at the first block
+// boundary where a later chunk was found to begin (start_bit; UINT64_MAX: nowhere); starts it runs past were not starts.  With a known
+// window (the first chunk of a batch) `window` holds the text in front of it.
 static inline void decode_chunk(const uint8_t *base, size_t n, std::vector<Chunk> &chunks, size_t ci, const uint8_t *window, size_t window_len) {
     Chunk &c = chunks[ci];
     std::unique_ptr<inf::Decoder> dec(new inf::Decoder());
@@ -423,56 +354,46 @@ static inline void decode_chunk(const uint8_t *base, size_t n, std::vector<Chunk
     // (a chunk that began at a false start decodes noise until a code fails or this much has come out of it)
     const size_t text_cap = std::max<size_t>((size_t)64 << 20, (n / std::max<size_t>(1, chunks.size())) * 256);
     c.end_bit = c.start_bit;
-    const size_t guess = std::max<size_t>((size_t)1 << 20, (n / std::max<size_t>(1, chunks.size())) * 6);
-    size_t o = 0, fix_until = 0;
-    if (c.known_window) {
-        c.lead = 0;
-        c.bytes.reserve(guess);
+    bool clean = c.known_window;
+    uint8_t pre[WINDOW]; // the WINDOW bytes in front of `bytes` once the markers have faded
+    size_t last_marker = 0;
+    if (!clean) {
+        c.sym.reserve(WINDOW + std::max<size_t>((size_t)1 << 20, (n / std::max<size_t>(1, chunks.size())) * 6));
+        for (uint32_t i = 0; i < WINDOW; ++i) c.sym.data()[i] = (uint16_t)(MARK | i);
+        last_marker = 0;
+        // (the window slots count as markers at "position 0": clean once WINDOW symbols without one have been produced)
+    } else {
         dec->ext_end = window + window_len;
         dec->ext_len = window_len;
-    } else {
-        c.lead = WINDOW;
-        c.dirty.release();
-        grow_sparse(c, WINDOW + guess);
-        memset(c.dirty.data(), 0, c.dirty.size());
-        memset(c.dirty.data(), 0xFF, WINDOW / 64); // every word of the window is "dirty"
-        for (uint32_t i = 0; i < WINDOW; ++i) c.sym.data()[i] = (uint16_t)(MARK | i);
-        memset(c.bytes.data(), 0, WINDOW);
-        o = WINDOW;
-        fix_until = WINDOW;
     }
+    c.bytes.reserve((size_t)4 << 20);
     for (;;) {
         // ---- one block ----
         const uint64_t block_start = dec->bit_position(in, base);
-        const size_t sv_o = o, sv_bytes = c.n_bytes, sv_fix = fix_until;
+        const size_t sv_sym = c.n_sym, sv_bytes = c.n_bytes;
         inf::Status s;
-        if (!c.known_window) {
+        if (!clean) {
             s = dec->block_header(in, in_end);
             if (s == inf::OK && dec->state == inf::Decoder::CODES) {
-                s = sparse_codes(*dec, in, in_end, c, o, fix_until);
+                s = marker_codes(*dec, in, in_end, c, last_marker);
             } else if (s == inf::OK && dec->state == inf::Decoder::STORED) { // literal bytes, byte aligned
                 while (dec->stored_left && s == inf::OK) {
-                    if (o + 128 > c.bytes.size()) grow_sparse(c, o + 65536);
-                    uint8_t b;
+                    if (WINDOW + c.n_sym + 8 > c.sym.size()) c.sym.reserve(c.sym.size() + c.sym.size() / 2 + 65536);
                     if (dec->bitcnt) {
-                        b = (uint8_t)(dec->bitbuf & 0xFFu);
+                        c.sym.data()[WINDOW + c.n_sym++] = (uint16_t)(dec->bitbuf & 0xFFu);
                         dec->bitbuf >>= 8;
                         dec->bitcnt -= 8;
+                        dec->stored_left--;
                     } else if (in >= in_end) {
                         s = inf::NEED_INPUT;
-                        break;
                     } else {
-                        b = *in++;
+                        c.sym.data()[WINDOW + c.n_sym++] = *in++;
+                        dec->stored_left--;
                     }
-                    c.bytes.data()[o] = b;
-                    if (o < fix_until) c.sym.data()[o] = b;
-                    o++;
-                    dec->stored_left--;
                 }
                 if (s == inf::OK) dec->state = dec->final_block ? inf::Decoder::DONE : inf::Decoder::HEADER;
             }
             if (s == inf::OK) s = inf::BLOCK_END;
-            c.n_bytes = o - WINDOW;
         } else {
             for (;;) {
                 if (c.bytes.size() - c.n_bytes < (size_t)1 << 20) c.bytes.reserve(c.bytes.size() + c.bytes.size() / 2);
@@ -484,10 +405,8 @@ static inline void decode_chunk(const uint8_t *base, size_t n, std::vector<Chunk
             if (s == inf::STREAM_END) s = inf::BLOCK_END; // (cannot happen: DONE is checked below)
         }
         if (s == inf::NEED_INPUT || (s == inf::BLOCK_END && dec->bit_position(in, base) > (uint64_t)n * 8u)) {
-            // the batch ends inside this block: it belongs to the next batch.  (What the block wrote stays behind the
-            // text's end; dirty bits it set there are beyond what anyone looks at.)
-            o = sv_o;
-            fix_until = sv_fix;
+            // the batch ends inside this block: it belongs to the next batch
+            c.n_sym = sv_sym;
             c.n_bytes = sv_bytes;
             c.end_bit = block_start;
             c.out_of_input = true;
@@ -508,47 +427,62 @@ static inline void decode_chunk(const uint8_t *base, size_t n, std::vector<Chunk
             c.ok = false;
             return;
         }
+        if (!clean && c.n_sym >= last_marker + WINDOW) { // no marker in the last WINDOW symbols: bytes from here on
+            const uint16_t *tail = c.sym.data() + WINDOW + c.n_sym - WINDOW;
+            for (uint32_t i = 0; i < WINDOW; ++i) pre[i] = (uint8_t)tail[i];
+            dec->ext_end = pre + WINDOW;
+            dec->ext_len = WINDOW;
+            clean = true;
+        }
     }
 }
 
-// The window marks of text positions [lo, hi) of chunk c put right, given the window in front of it (window_len bytes
-// ending at window_end).  false: a mark that points before the start of the stream.
-static inline bool resolve_range(Chunk &c, size_t lo, size_t hi, const uint8_t *window_end, size_t window_len) {
-    if (c.known_window || lo >= hi) return true;
+// one symbol of a chunk given the window in front of it (window_len bytes ending at window_end)
+static inline bool resolve_symbol(uint16_t v, const uint8_t *window_end, size_t window_len, uint8_t *out) {
+    if (!(v & MARK)) {
+        *out = (uint8_t)v;
+        return true;
+    }
+    const size_t back = WINDOW - (size_t)(v & 0x7FFFu); // 1 = the byte right in front of the chunk
+    if (back > window_len) { // a stream that reaches before its own start
+        *out = 0;
+        return false;
+    }
+    *out = window_end[-(ptrdiff_t)back];
+    return true;
+}
+
+// n symbols narrowed to bytes, markers looked up in the window (window_len bytes ending at window_end)
+static inline bool resolve_span(const uint16_t *s, size_t n, const uint8_t *window_end, size_t window_len, uint8_t *h) {
     bool ok = true;
-    uint8_t *const o8 = c.bytes.data();
-    const uint16_t *const o16 = c.sym.data();
-    const uint8_t *const bm = c.dirty.data();
-    const size_t a = c.lead + lo, b = c.lead + hi;
-    for (size_t w = a >> 3; w <= (b - 1) >> 3; ++w) {
-        if ((w & 7) == 0 && bm[w >> 3] == 0 && w + 8 <= ((b - 1) >> 3)) { // eight clean words at once
-            w += 7;
-            continue;
-        }
-        if (!bit_at(bm, w)) continue;
-        const size_t p0 = std::max(a, w << 3), p1 = std::min(b, (w + 1) << 3);
-        for (size_t p = p0; p < p1; ++p) {
-            const uint16_t v = o16[p];
-            if (v & MARK) {
-                const size_t back = WINDOW - (size_t)(v & 0x7FFFu); // 1 = the byte right in front of the chunk
-                if (back > window_len) ok = false;
-                else o8[p] = window_end[-(ptrdiff_t)back];
-            }
+    size_t i = 0;
+#if defined(__SSE2__)
+    // sixteen symbols at a time: narrowed as they are when none of them is a marker (markers are few and far between
+    // once a chunk is a few hundred kilobytes in)
+    for (; i + 16 <= n; i += 16) {
+        const __m128i a = _mm_loadu_si128((const __m128i *)(s + i)), b = _mm_loadu_si128((const __m128i *)(s + i + 8));
+        if (__builtin_expect(_mm_movemask_epi8(_mm_or_si128(a, b)) & 0xAAAA, 0)) { // a top bit set: a marker among them
+            for (size_t j = i; j < i + 16; ++j) ok = resolve_symbol(s[j], window_end, window_len, h + j) && ok;
+        } else {
+            _mm_storeu_si128((__m128i *)(h + i), _mm_packus_epi16(a, b));
         }
     }
+#endif
+    for (; i < n; ++i) ok = resolve_symbol(s[i], window_end, window_len, h + i) && ok;
     return ok;
 }
 
-// The window behind chunk c -- the last WINDOW bytes of (window in front of it + its text).  Puts the marks of the chunk's
-// own last WINDOW bytes right on the way.
-static inline bool window_behind(Chunk &c, const std::vector<uint8_t> &win_in, std::vector<uint8_t> &win_out) {
-    const size_t total = c.text_len();
+// The window behind chunk c -- the last WINDOW bytes of (window in front of it + its text) -- without resolving all of it.
+static inline bool window_behind(const Chunk &c, const std::vector<uint8_t> &win_in, std::vector<uint8_t> &win_out) {
+    const size_t total = c.n_sym + c.n_bytes;
     const size_t take = std::min<size_t>(WINDOW, total);
-    const bool ok = resolve_range(c, total - take, total, win_in.data() + win_in.size(), win_in.size());
     const size_t old = take < WINDOW ? std::min<size_t>(WINDOW - take, win_in.size()) : 0; // (a short chunk: the older window shows through)
     std::vector<uint8_t> w(old + take);
     if (old) memcpy(w.data(), win_in.data() + win_in.size() - old, old);
-    if (take) memcpy(w.data() + old, c.text() + (total - take), take);
+    const size_t first = total - take; // of the chunk's text
+    const size_t from_sym = first < c.n_sym ? c.n_sym - first : 0;
+    const bool ok = resolve_span(c.sym.data() + WINDOW + first, from_sym, win_in.data() + win_in.size(), win_in.size(), w.data() + old);
+    if (take > from_sym) memcpy(w.data() + old + from_sym, c.bytes.data() + (first + from_sym - c.n_sym), take - from_sym);
     win_out.swap(w);
     return ok;
 }
