@@ -53,6 +53,8 @@ SYMBOLS = {
     "fh_copy_out": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "fh_copy_out_records": (C.c_int, [_P, _P, _P, _P]),
     "fh_copy_out_kmers": (C.c_int, [_P, _P, C.c_uint64, _P]),
+    "fh_copy_out_rows": (C.c_int, [_P, _P, C.c_uint64, _P, _P]),
+    "fh_result_counts": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), _U64P]),
     "fh_merge": (C.c_int, [_P, _P]),
     "fh_merge_arrays": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, C.c_uint64]),
     "fh_merge_partials": (C.c_int, [C.c_uint32, C.c_uint64, C.c_double, C.c_uint32,

@@ -1925,6 +1925,35 @@ int fh_copy_out_kmers(fh_sketcher *s, const uint32_t *rows, uint64_t n_rows, uin
     return FH_OK;
 }
 
+int fh_copy_out_rows(fh_sketcher *s, const uint32_t *rows, uint64_t n_rows, fh_kmer_count *records, uint8_t *kmers) {
+    if (!s || (n_rows && !rows)) return fail(FH_ERR_INVALID, "null argument");
+    if (!s->finished) return fail(FH_ERR_STATE, "fh_copy_out before fh_finish");
+    const int k = (int)s->p.k;
+    const size_t n = result_count(s);
+    for (uint64_t i = 0; i < n_rows; ++i) {
+        const size_t r = rows[i];
+        if (r >= n) return fail(FH_ERR_INVALID, "row %zu of a sketch of %zu hashes", r, n);
+        if (s->res_built) {
+            if (records) records[i] = fh_kmer_count{s->res[r].hash, s->res[r].count, s->res[r].extra};
+            if (kmers) kmer_ascii(s->res[r].kmer, s->res[r].kmer_hi, k, kmers + i * (size_t)k);
+        } else {
+            if (records) records[i] = fh_kmer_count{s->r_hash[r], s->r_count[r], s->r_extra[r]};
+            if (kmers) kmer_ascii(s->r_kmer[r], s->r_kmer_hi ? s->r_kmer_hi[r] : 0ull, k, kmers + i * (size_t)k);
+        }
+    }
+    return FH_OK;
+}
+
+int fh_result_counts(fh_sketcher *s, const uint32_t **counts, const uint32_t **extra_counts, uint64_t *n) {
+    if (!s || !counts || !extra_counts || !n) return fail(FH_ERR_INVALID, "null argument");
+    if (!s->finished) return fail(FH_ERR_STATE, "fh_result_counts before fh_finish");
+    if (s->res_built) return fail(FH_ERR_STATE, "the result of a merge is a record vector: use fh_copy_out");
+    *counts = s->r_count;
+    *extra_counts = s->r_extra;
+    *n = s->r_n;
+    return FH_OK;
+}
+
 int fh_merge_arrays(fh_sketcher *dst, uint64_t n, const uint64_t *hashes, const uint32_t *counts,
                     const uint32_t *extra_counts, const uint8_t *kmers, const uint64_t *first_pos,
                     uint64_t total_kmers) {

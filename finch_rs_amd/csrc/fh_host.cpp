@@ -57,10 +57,13 @@ static std::vector<uint64_t> hist(const std::vector<KC> &sketch) {
     return counts;
 }
 
-// filtering.rs:154-195
+// filtering.rs:154-195, from the histogram on
+static uint32_t guess_filter_threshold_hist(const std::vector<uint64_t> &hist_data, double filter_level);
 template <class KC>
 static uint32_t guess_filter_threshold(const std::vector<KC> &sketch, double filter_level) {
-    const std::vector<uint64_t> hist_data = hist(sketch);
+    return guess_filter_threshold_hist(hist(sketch), filter_level);
+}
+static uint32_t guess_filter_threshold_hist(const std::vector<uint64_t> &hist_data, double filter_level) {
     uint64_t total = 0;
     for (size_t i = 0; i < hist_data.size(); ++i) total += (uint64_t)(i + 1) * hist_data[i];
     const double total_counts = (double)total;
@@ -1937,6 +1940,105 @@ struct HandleSet {
 
 // to_vec -> filter_counts -> process_post_filter -> Sketch (lib.rs:70-93) from a sketcher that holds the whole input
 // (one handle, or the merge of the partial sketches of a sharded input)
+// f(lo, hi) over [0, n) on a few threads (the passes over a 2 M-hash oversketch)
+template <class F>
+static void host_parallel(size_t n, F f) {
+    const unsigned t_max = (unsigned)std::min<size_t>(8, std::max<size_t>(1, n >> 16));
+    if (t_max <= 1) {
+        f(0, 0, n);
+        return;
+    }
+    const size_t per = (n + t_max - 1) / t_max;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < t_max; ++t) th.emplace_back([=] { f(t, std::min(n, t * per), std::min(n, (t + 1) * per)); });
+    f(0, 0, std::min(n, per));
+    for (auto &x : th) x.join();
+}
+
+// FilterParams::filter_counts + process_post_filter (filtering.rs:60-87, mod.rs:115-128) for a Mash sketch, without a copy
+// of the oversketch: the filters are per-record tests plus one histogram, and only the first final_size survivors (in
+// hash order) are ever wanted -- so the count columns are read where the sketcher left them (fh_result_counts), the strand
+// test and the histogram run on a few threads, and the scan for survivors stops when it has final_size of them.  configs[2]:
+// 2 M hashes -> 10 000.  `fp` is updated like the reference updates it.
+static int finish_mash_in_place(fh_sketcher *h, const std::string &name, const finch_sketch_params &sp, finch_filter_params &fp,
+                                const FastxStats &st, uint64_t n, uint64_t total_kmers, Sketch &out) {
+    const uint32_t *cnt = nullptr, *ext = nullptr;
+    uint64_t n_view = 0;
+    if (fh_result_counts(h, &cnt, &ext, &n_view) != FH_OK || n_view != n) return FH_ERR_STATE;
+    const bool filter_on = fp.filter_on == 1;
+    std::vector<uint8_t> dropped; // by the strand filter (filtering.rs:413-432)
+    if (filter_on && fp.strand_filter > 0.0) {
+        dropped.assign(n, 0);
+        const double cutoff = fp.strand_filter;
+        uint8_t *d = dropped.data();
+        host_parallel(n, [=](unsigned, size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                const uint32_t c = cnt[i], e = ext[i];
+                if (c < 16) continue;
+                const uint32_t lowest = std::min(e, c - std::min(e, c));
+                d[i] = !(((double)lowest / (double)c) >= cutoff);
+            }
+        });
+    }
+    const uint8_t *d = dropped.empty() ? nullptr : dropped.data();
+    if (filter_on && fp.err_filter > 0.0) { // guess_filter_threshold on what the strand filter left (filtering.rs:154-195)
+        uint32_t maxes[8] = {0};
+        host_parallel(n, [&](unsigned t, size_t lo, size_t hi) {
+            uint32_t m = 0;
+            for (size_t i = lo; i < hi; ++i)
+                if (!(d && d[i])) m = std::max(m, cnt[i]);
+            maxes[t] = m;
+        });
+        uint32_t max_count = 0;
+        for (uint32_t m : maxes) max_count = std::max(max_count, m);
+        std::vector<uint64_t> hist_data(max_count, 0);
+        if (max_count <= (1u << 22)) {
+            std::vector<std::vector<uint64_t>> part(8);
+            host_parallel(n, [&](unsigned t, size_t lo, size_t hi) {
+                std::vector<uint64_t> &p = part[t];
+                p.assign(max_count, 0);
+                for (size_t i = lo; i < hi; ++i)
+                    if (!(d && d[i]) && cnt[i]) p[cnt[i] - 1] += 1;
+            });
+            for (const auto &p : part)
+                for (size_t j = 0; j < p.size(); ++j) hist_data[j] += p[j];
+        } else {
+            for (size_t i = 0; i < n; ++i)
+                if (!(d && d[i]) && cnt[i]) hist_data[cnt[i] - 1] += 1;
+        }
+        const uint32_t cutoff = guess_filter_threshold_hist(hist_data, fp.err_filter);
+        if (fp.has_abun_lo) {
+            if (cutoff > fp.abun_lo) fp.abun_lo = cutoff;
+        } else {
+            fp.has_abun_lo = 1;
+            fp.abun_lo = cutoff;
+        }
+    }
+    // the abundance filter (filtering.rs:329-343) and the cut to final_size, in one scan that stops when it has enough
+    const bool abun = filter_on && (fp.has_abun_lo || fp.has_abun_hi);
+    const uint32_t lo_t = (abun && fp.has_abun_lo) ? fp.abun_lo : 0u, hi_t = (abun && fp.has_abun_hi) ? fp.abun_hi : UINT32_MAX;
+    std::vector<uint32_t> rows;
+    rows.reserve((size_t)std::min<uint64_t>(n, sp.final_size));
+    for (size_t i = 0; i < n && rows.size() < sp.final_size; ++i)
+        if (!(d && d[i]) && lo_t <= cnt[i] && cnt[i] <= hi_t) rows.push_back((uint32_t)i);
+    if (!sp.no_strict && rows.size() < sp.final_size)
+        return hfail(FH_ERR_INVALID, "%s had too few kmers (%zu) to sketch", name.c_str(), rows.size());
+    const uint32_t k = sp.kmer_length;
+    std::unique_ptr<fh_kmer_count[]> recs(new fh_kmer_count[rows.size() + 1]);
+    std::unique_ptr<uint8_t[]> km(new uint8_t[rows.size() * (size_t)k + 1]);
+    if (int rc = fh_copy_out_rows(h, rows.data(), rows.size(), recs.get(), km.get())) return hfail(rc, "%s", fh_last_error());
+    out.name = name;
+    out.seq_length = st.total_bases;
+    out.num_valid_kmers = total_kmers;
+    out.comment = "";
+    out.hashes.resize(rows.size());
+    for (size_t i = 0; i < rows.size(); ++i)
+        out.hashes[i] = KmerCount{recs[i].hash, std::string((const char *)km.get() + i * (size_t)k, k), recs[i].count, recs[i].extra_count};
+    out.filter_params = fp;
+    out.sketch_params = sp;
+    return FH_OK;
+}
+
 static int finish_sketch(fh_sketcher *h, const std::string &name, const finch_sketch_params &sp, const finch_filter_params &filters,
                          const FastxStats &st, Sketch &out) {
     finch_filter_params fp = filters;
@@ -1946,6 +2048,10 @@ static int finish_sketch(fh_sketcher *h, const std::string &name, const finch_sk
     if (int rc = fh_finish(h, &n, &total_kmers)) return hfail(rc, "%s", fh_last_error());
     const uint32_t k = sp.kmer_length;
     if (n > UINT32_MAX) return hfail(FH_ERR_UNSUPPORTED, "sketch of %llu hashes", (unsigned long long)n);
+    if (sp.kind == 0) { // a Mash sketch: cut to final_size right behind the filters
+        const int rc = finish_mash_in_place(h, name, sp, fp, st, n, total_kmers, out);
+        if (rc != FH_ERR_STATE) return rc; // (FH_ERR_STATE: the result is not laid out as columns; the general way below)
+    }
     // (arrays the library fills completely: allocated without zeroing -- 2 M hashes are 100 MB here)
     std::unique_ptr<fh_kmer_count[]> recs(new fh_kmer_count[n ? n : 1]);
     if (int rc = fh_copy_out_records(h, recs.get(), nullptr, nullptr)) return hfail(rc, "%s", fh_last_error());

@@ -181,6 +181,12 @@ int fh_copy_out_records(fh_sketcher *s, fh_kmer_count *records, uint8_t *kmers, 
 /* The k-mer bytes of selected records only (rows = indices into the ascending sketch): a caller that filters a 2 M-hash
  * oversketch down to 10 000 hashes (filter_counts + truncate, lib.rs:82-83) needs the bytes of the survivors, not of all. */
 int fh_copy_out_kmers(fh_sketcher *s, const uint32_t *rows, uint64_t n_rows, uint8_t *kmers);
+/* The same for whole records: records[i] / kmers[i*k..] = row rows[i] of the result (either may be NULL). */
+int fh_copy_out_rows(fh_sketcher *s, const uint32_t *rows, uint64_t n_rows, fh_kmer_count *records, uint8_t *kmers);
+/* The finished result's count columns where they lie (n entries each, ascending by hash like every copy-out; valid until
+ * the next fh_reset / fh_free / merge): what a filter pass over a 2 M-hash oversketch reads, without a copy of it.
+ * FH_ERR_STATE after a merge (the result is a record vector then: use fh_copy_out). */
+int fh_result_counts(fh_sketcher *s, const uint32_t **counts, const uint32_t **extra_counts, uint64_t *n);
 
 /* Host-side merge of partial sketches (multi-GPU read-block sharding): union, counts
  * summed (saturating), k-mer of the smallest first_pos, re-select per kind.  Both must be finished.
