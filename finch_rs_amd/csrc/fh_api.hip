@@ -1474,7 +1474,7 @@ static int ensure_fastq_scratch(fh_sketcher *s, int b) {
     const uint64_t nblk = (s->stage_bytes + 4095) / 4096 + 1;
     if (!s->d_packed[b]) {
         HIP_TRY(dev_malloc((void **)&s->d_packed[b], s->stage_bytes + 64));
-        HIP_TRY(dev_malloc((void **)&s->d_blk_a[b], nblk * sizeof(uint32_t)));
+        HIP_TRY(dev_malloc((void **)&s->d_blk_a[b], 5 * nblk * sizeof(uint32_t))); // (FASTQ: newlines + four class counts per block)
         HIP_TRY(dev_malloc((void **)&s->d_blk_b[b], nblk * sizeof(uint32_t)));
     }
     if (!s->d_text_tot) {
@@ -1540,7 +1540,7 @@ static int ensure_bgzf_buffers(fh_sketcher *s) {
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(dev_malloc((void **)&s->bz_text[i], cap + 128));
         HIP_TRY(dev_malloc((void **)&s->bz_packed[i], cap + 64));
-        HIP_TRY(dev_malloc((void **)&s->bz_blk_a[i], nblk * sizeof(uint32_t)));
+        HIP_TRY(dev_malloc((void **)&s->bz_blk_a[i], 5 * nblk * sizeof(uint32_t)));
         HIP_TRY(dev_malloc((void **)&s->bz_blk_b[i], nblk * sizeof(uint32_t)));
     }
     s->bz_line_cap = (uint32_t)std::min<uint64_t>(cap / 8 + 64, 0x7FFFFFFFull);
@@ -1684,7 +1684,7 @@ int fh_push_fasta_text(fh_sketcher *s, uint64_t len, uint32_t start_state, uint3
     const uint64_t nblk = (s->stage_bytes + 4095) / 4096 + 1;
     if (!s->d_packed[b]) {
         HIP_TRY(dev_malloc((void **)&s->d_packed[b], s->stage_bytes + 64));
-        HIP_TRY(dev_malloc((void **)&s->d_blk_a[b], nblk * sizeof(uint32_t)));
+        HIP_TRY(dev_malloc((void **)&s->d_blk_a[b], 5 * nblk * sizeof(uint32_t))); // (FASTQ: newlines + four class counts per block)
         HIP_TRY(dev_malloc((void **)&s->d_blk_b[b], nblk * sizeof(uint32_t)));
     }
     if (!s->d_text_tot) {

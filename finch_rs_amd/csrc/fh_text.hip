@@ -6,11 +6,11 @@
 // is decided here.  A byte belongs to a sequence line iff the number of newlines before it is 1 mod 4.
 // Sequence bytes are copied (CR dropped), the newline that ends a sequence line becomes the '\0' record
 // breaker, everything else (headers, '+' lines, qualities) is dropped -- a stream compaction:
-//   pass A  newlines per 4 KiB block            -> exclusive scan (one workgroup)
-//   pass B  kept bytes per block (needs A)      -> exclusive scan
-//   pass C  recompute flags, block-local scan, scatter the kept bytes
-// Each pass streams the chunk once with 16-byte loads; at 3 reads + ~0.5 writes per text byte this is HBM bound
-// and costs a few percent of the time the sketch kernel spends on the same reads.
+//   pass A  per 4 KiB block: newlines, and the bytes it will emit for each of the four line phases it might start in
+//           -> exclusive scan of the newlines (one workgroup), pick each block's class, exclusive scan of those
+//   pass C  recompute the flags, block-local scan, scatter the kept bytes
+// Two passes over the chunk with 16-byte loads; a thread whose sixteen bytes hold no newline (four of five) decides them
+// as one, a thread that keeps all sixteen stores four words.
 // What needletail checks per record is checked here too, so that a file the reference refuses (or reads differently) never
 // yields a sketch silently: header lines begin with '@', separator lines with '+', a sequence line holds no blank, tab or
 // interior CR (normalize(false) would DROP those and let k-mers span them; the packed stream would break k-mers there),
@@ -44,14 +44,20 @@ __device__ __forceinline__ int load16(const uint8_t *text, u64 len, u64 off, uin
 }
 
 // block-wide exclusive scan of one u32 per thread (256 threads); returns the exclusive prefix, total in *tot
+// inclusive prefix sum over the 64 lanes of a wave, in registers (row shifts, then gfx9's two row broadcasts)
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31
+    return v;
+}
+
 __device__ __forceinline__ u32 block_exscan(u32 v, u32 *smem /* >= 4 */, u32 *tot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    u32 inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const u32 t = __shfl_up(inc, off);
-        if (lane >= off) inc += t;
-    }
+    const u32 inc = wave_incl_scan(v);
     if (lane == 63) smem[wave] = inc;
     __syncthreads();
     u32 wbase = 0, total = 0;
@@ -66,17 +72,40 @@ __device__ __forceinline__ u32 block_exscan(u32 v, u32 *smem /* >= 4 */, u32 *to
     return wbase + inc - v;
 }
 
-__global__ __launch_bounds__(TB) void k1_count_newlines(const uint8_t *text, u64 len, u32 *blk_nl) {
+// Pass A of the FASTQ splitter, with pass B folded in: newlines per block, and -- for each of the four line phases the
+// block might start in -- how many of its bytes the packer will emit.  A byte is emitted iff its line is a sequence line
+// (phase 1) and it is not a CR, the terminating newline included (it becomes the breaker): that depends on the block's
+// starting phase only through a rotation, so the count is taken per class of "newlines before the byte within the block,
+// mod 4" and the class that applies is picked once the scan of the newline counts is known (k1_pick_keep).
+__global__ __launch_bounds__(TB) void k1_count_classes(const uint8_t *text, u64 len, u32 *blk_nl, u32 *blk_keep4) {
     __shared__ u32 sm[4];
+    __shared__ u32 cls[4];
+    if (threadIdx.x < 4) cls[threadIdx.x] = 0;
     const u64 off = ((u64)blockIdx.x * TB + threadIdx.x) * BPT;
     uint8_t b[16];
     const int nv = load16(text, len, off, b);
-    u32 c = 0;
+    u32 c = 0, k4[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 16; ++i) c += (i < nv && b[i] == '\n');
+    for (int i = 0; i < 16; ++i) {
+        if (i < nv) {
+            k4[c & 3u] += b[i] != '\r';
+            c += b[i] == '\n';
+        }
+    }
     u32 tot;
-    (void)block_exscan(c, sm, &tot);
+    const u32 base = block_exscan(c, sm, &tot); // (its barriers also order the zeroing of cls before the adds)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (k4[q]) atomicAdd(&cls[(q + base) & 3u], k4[q]);
+    __syncthreads();
     if (threadIdx.x == 0) blk_nl[blockIdx.x] = tot;
+    if (threadIdx.x < 4) blk_keep4[4u * blockIdx.x + threadIdx.x] = cls[threadIdx.x];
+}
+
+// blk_keep[i] = the emitted-byte count of block i for the phase it really starts in (nl_ex: exclusive scan of the newlines)
+__global__ __launch_bounds__(256) void k1_pick_keep(const u32 *nl_ex, const u32 *blk_keep4, u32 *blk_keep, u32 nblk) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nblk) blk_keep[i] = blk_keep4[4u * i + ((1u - (nl_ex[i] & 3u)) & 3u)];
 }
 
 // single workgroup exclusive scan of n values (n up to a few 100k), in place; total -> *total_out
@@ -158,10 +187,8 @@ __device__ __forceinline__ Keep16 decide16(const uint8_t b[16], int nv, u32 line
     return k;
 }
 
-template <bool WRITE>
-__global__ __launch_bounds__(TB) void k1_pack(const uint8_t *text, u64 len, const u32 *blk_nl_ex, u32 *blk_keep,
-                                              const u32 *blk_keep_ex, uint8_t *out, Ctl *ctl, u32 *err, u32 *line_end,
-                                              u32 line_cap) {
+__global__ __launch_bounds__(TB) void k1_pack(const uint8_t *text, u64 len, const u32 *blk_nl_ex, const u32 *blk_keep_ex, uint8_t *out,
+                                              u32 *err, u32 *line_end, u32 line_cap) {
     __shared__ u32 sm[4];
     const u64 off = ((u64)blockIdx.x * TB + threadIdx.x) * BPT;
     uint8_t b[16];
@@ -173,9 +200,29 @@ __global__ __launch_bounds__(TB) void k1_pack(const uint8_t *text, u64 len, cons
     const u32 nl_before = blk_nl_ex[blockIdx.x] + block_exscan(c, sm, &tot);
     const bool starts_line = (off == 0) || (off < len + 1 && off > 0 && text[off - 1] == '\n');
     const uint8_t next = (nv == 16 && off + 16 < len) ? text[off + 16] : (uint8_t)0;
-    const Keep16 k = decide16(b, nv, nl_before, starts_line, next);
+    Keep16 k;
+    if (c == 0u && nv == 16) {
+        // no line ends inside these sixteen bytes (four of five threads): one phase for all of them
+        const u32 ph = nl_before & 3u;
+        k = Keep16{0u, 0u, 0u, 0u};
+        if (starts_line && ((ph == 0u && b[0] != '@' && b[0] != '\r') || (ph == 2u && b[0] != '+'))) k.bad = 1u;
+        if (ph == 1u) {
+            u32 m = 0xFFFFu;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (b[i] == ' ' || b[i] == '\t') k.bad = 1u;
+                if (b[i] == '\r') { // only the CR of a CR LF pair may be here, i.e. the last byte with the newline next
+                    m &= ~(1u << i);
+                    if (i != 15 || next != '\n') k.bad = 1u;
+                }
+            }
+            k.mask = m;
+        }
+    } else {
+        k = decide16(b, nv, nl_before, starts_line, next);
+    }
     if (k.bad) atomicExch(err, 1u);
-    if (WRITE && k.n_nl) { // where line j ends: (position << 1) | "a CR precedes the newline"
+    if (k.n_nl) { // where line j ends: (position << 1) | "a CR precedes the newline"
         u32 line = nl_before;
         uint8_t prev = off ? text[off - 1] : (uint8_t)0;
 #pragma unroll
@@ -191,20 +238,35 @@ __global__ __launch_bounds__(TB) void k1_pack(const uint8_t *text, u64 len, cons
     const u32 nkeep = (u32)__popc(k.mask);
     u32 ktot;
     const u32 kpre = block_exscan(nkeep, sm, &ktot);
-    if (!WRITE) {
-        if (threadIdx.x == 0) blk_keep[blockIdx.x] = ktot;
-        return;
-    }
     u64 o = (u64)blk_keep_ex[blockIdx.x] + kpre;
+    if (k.mask == 0xFFFFu) {
+        // all sixteen bytes lie on a sequence line (four of ten threads of a 150-base FASTQ; half keep nothing at all):
+        // four word stores -- the target is wherever the compaction puts it, rarely aligned -- instead of sixteen byte stores
+        u32 w[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        if ((k.mask >> i) & 1u) out[o++] = ((k.zmask >> i) & 1u) ? (uint8_t)0 : b[i];
+        for (int q = 0; q < 4; ++q) {
+            u32 v = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = 4 * q + j;
+                v |= (((k.zmask >> i) & 1u) ? 0u : (u32)b[i]) << (8 * j);
+            }
+            w[q] = v;
+        }
+        __builtin_memcpy(out + o, w, 16);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if ((k.mask >> i) & 1u) out[o++] = ((k.zmask >> i) & 1u) ? (uint8_t)0 : b[i];
+        }
     }
-    // bases = emitted bytes that are not breakers (what total_bases counts for FASTQ, mash.rs:72)
-    const u32 nb = nkeep - (u32)__popc(k.zmask);
-    u32 btot;
-    (void)block_exscan(nb, sm, &btot);
-    if (threadIdx.x == 0 && btot) atomicAdd((unsigned long long *)&ctl->text_bases, (unsigned long long)btot);
+}
+
+// bases = emitted bytes that are not breakers (what total_bases counts for FASTQ, mash.rs:72).  A chunk starts at a record,
+// so the newlines that end sequence lines are those with index 1 mod 4: (L + 2) / 4 of L -- no need to count them with
+// atomics (one per workgroup on a single address was a good part of the packer's time).  totals: [0] newlines, [1] emitted.
+__global__ void k1_add_bases(Ctl *ctl, const u32 *totals) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctl->text_bases += (u64)totals[1] - (u64)((totals[0] + 2u) / 4u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -391,13 +453,15 @@ hipError_t launch_fastq_pack(const uint8_t *text, u64 len, uint8_t *out, u32 *bl
     if (len == 0) return hipSuccess;
     if (len >= (1ull << 31)) return hipErrorInvalidValue;
     const u32 nblk = (u32)((len + BLK_BYTES - 1) / BLK_BYTES);
-    hipLaunchKernelGGL(k1_count_newlines, dim3(nblk), dim3(TB), 0, st, text, len, blk_a);
+    // (blk_a holds 5 values per block: the newline count, then -- behind all of those -- the four class counts)
+    u32 *keep4 = blk_a + nblk;
+    hipLaunchKernelGGL(k1_count_classes, dim3(nblk), dim3(TB), 0, st, text, len, blk_a, keep4);
     hipLaunchKernelGGL(k1_scan, dim3(1), dim3(1024), 0, st, blk_a, nblk, totals);
-    hipLaunchKernelGGL((k1_pack<false>), dim3(nblk), dim3(TB), 0, st, text, len, (const u32 *)blk_a, blk_b,
-                       (const u32 *)nullptr, (uint8_t *)nullptr, ctl, err, (u32 *)nullptr, 0u);
+    hipLaunchKernelGGL(k1_pick_keep, dim3((nblk + 255u) / 256u), dim3(256), 0, st, (const u32 *)blk_a, (const u32 *)keep4, blk_b, nblk);
     hipLaunchKernelGGL(k1_scan, dim3(1), dim3(1024), 0, st, blk_b, nblk, totals + 1);
-    hipLaunchKernelGGL((k1_pack<true>), dim3(nblk), dim3(TB), 0, st, text, len, (const u32 *)blk_a, (u32 *)nullptr,
-                       (const u32 *)blk_b, out, ctl, err, line_end, line_cap);
+    hipLaunchKernelGGL(k1_add_bases, dim3(1), dim3(64), 0, st, ctl, (const u32 *)totals);
+    hipLaunchKernelGGL(k1_pack, dim3(nblk), dim3(TB), 0, st, text, len, (const u32 *)blk_a, (const u32 *)blk_b, out, err, line_end,
+                       line_cap);
     hipLaunchKernelGGL(k1_check_records, dim3(256), dim3(256), 0, st, (const u32 *)line_end, (const u32 *)totals, len, text,
                        line_cap, err);
     return hipGetLastError();
