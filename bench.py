@@ -551,7 +551,7 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
                 best = min(best, time.perf_counter() - t0)
                 assert len(res) == nf
             return {"what": "ONE finch_sketch_files call over %d synthetic FASTA files (log-uniform 1-10 Mb, 70-column lines, "
-                            "%.2f Gbases, page cache / tmpfs), library defaults (k=21 n=1000), 8 worker threads on one GPU" % (nf, tot / 1e9),
+                            "%.2f Gbases, page cache / tmpfs), library defaults (k=21 n=1000, 12 worker threads per GPU)" % (nf, tot / 1e9),
                     "seconds": round(best, 4), "files_per_s": round(nf / best, 1), "gbases_per_s": round(tot / best / 1e9, 2)}
         finally:
             shutil.rmtree(d, ignore_errors=True)

@@ -2942,7 +2942,7 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
     std::vector<int> devs;
     if (devices && n_devices) devs.assign(devices, devices + n_devices);
     else devs.push_back(0);
-    if (n_threads == 0) n_threads = 8 * (uint32_t)devs.size(); // measured sweet spot: 8 host workers per GPU
+    if (n_threads == 0) n_threads = 12 * (uint32_t)devs.size(); // measured sweet spot: 12 host workers per GPU (tools/batch_threads.py; a worker spends most of a small file copying it out of the page cache)
     n_threads = std::max<uint32_t>(1, std::min<uint32_t>(n_threads, std::max<uint32_t>(n_files, 1)));
     auto res = std::make_unique<finch_sketches>();
     res->v.resize(n_files);
