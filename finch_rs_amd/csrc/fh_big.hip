@@ -2,13 +2,12 @@
 // millions: the CLI's oversketch x200, mod cli.rs:187-192; scaled sketches, scaled.rs).
 //
 // Same rule as k3_prune_small (fh_kernels.hip), but the sort of (hash, slot) pairs is device-wide:
-// gather keys -> radix sort (rocPRIM's device radix sort is used as a plain library primitive here; this
-// step runs a handful of times per stream, never in the per-base hot loop) -> pick tau / keep -> write the
-// (now sorted) live list back and append the dropped slots to the dead list.
+// gather keys -> radix sort (below: eight stable passes of eight bits; this step runs a handful of times per
+// stream, never in the per-base hot loop) -> pick tau / keep -> write the (now sorted) live list back and append
+// the dropped slots to the dead list.
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include "fh_core.h"
 #include "fh_device.h"
@@ -78,12 +77,152 @@ __global__ void k_big_writeback(const u32 *slots_sorted, u32 M, const u32 *keep_
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->n_dead = fits ? nd0 + ndrop : 0xFFFFFFFFu;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Radix sort of (u64 key, u32 value) pairs: least significant byte first, every pass stable.
+//   k_rs_hist      digit counts of each 2048-pair tile                    -> hist[digit][tile]
+//   k_rs_scan_rows exclusive scan along every digit's row, row totals     -> hist (in place), tot[digit]
+//   k_rs_scan_tot  exclusive scan of the 256 totals
+//   k_rs_scatter   the tile again, in the same order: a pair's place is tot[d] + hist[d][tile] + the pairs of digit d before
+//                  it in the tile.  That last term keeps the pass stable: the tile is walked 256 pairs at a time (thread
+//                  order = pair order), lanes with the same digit find each other with eight ballots, a lane's rank in its
+//                  wave is the population count of the lanes below it, waves are ranked through LDS.
+// Eight passes return the data to the buffers it came in.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr u32 RS_TILE = 2048;
+
+__global__ __launch_bounds__(256) void k_rs_hist(const u64 *keys, u32 M, int shift, u32 *hist, u32 ntile) {
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (u32 j = 0; j < RS_TILE / 256; ++j) {
+        const u32 i = base + j * 256 + threadIdx.x;
+        if (i < M) atomicAdd(&h[(u32)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * ntile + blockIdx.x] = h[threadIdx.x];
+}
+
+__device__ __forceinline__ u32 rs_wave_incl_scan(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// block d: exclusive scan of hist[d * ntile, +ntile) in place, its total to tot[d]
+__global__ __launch_bounds__(256) void k_rs_scan_rows(u32 *hist, u32 ntile, u32 *tot) {
+    __shared__ u32 sm[4];
+    __shared__ u32 carry;
+    u32 *row = hist + (size_t)blockIdx.x * ntile;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (u32 base = 0; base < ntile; base += 256) {
+        const u32 i = base + threadIdx.x;
+        const u32 v = i < ntile ? row[i] : 0u;
+        const u32 inc = rs_wave_incl_scan(v);
+        if (lane == 63) sm[wave] = inc;
+        __syncthreads();
+        u32 wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const u32 x = sm[w];
+            if (w < wave) wbase += x;
+            total += x;
+        }
+        const u32 c = carry;
+        if (i < ntile) row[i] = c + wbase + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tot[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_rs_scan_tot(u32 *tot) {
+    __shared__ u32 sm[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 v = tot[threadIdx.x];
+    const u32 inc = rs_wave_incl_scan(v);
+    if (lane == 63) sm[wave] = inc;
+    __syncthreads();
+    u32 wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += sm[w];
+    tot[threadIdx.x] = wbase + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_rs_scatter(const u64 *keys, const u32 *vals, u32 M, int shift, const u32 *hist, const u32 *tot,
+                                                    u32 ntile, u64 *keys_out, u32 *vals_out) {
+    __shared__ u32 run[256];    // where the next pair of each digit goes
+    __shared__ u32 cnt[4][256]; // pairs of each digit in each wave of the current 256
+    const u32 t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    run[t] = tot[t] + hist[t * ntile + blockIdx.x];
+    const u32 base = blockIdx.x * RS_TILE;
+    for (u32 j = 0; j < RS_TILE / 256; ++j) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) cnt[w][t] = 0;
+        __syncthreads();
+        const u32 i = base + j * 256 + t;
+        const bool valid = i < M;
+        const u64 key = valid ? keys[i] : 0ull;
+        const u32 val = valid ? vals[i] : 0u;
+        const u32 d = (u32)(key >> shift) & 255u;
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bit = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? bit : ~bit;
+        }
+        const u32 rank = (u32)__popcll(same & ((1ull << lane) - 1ull));
+        if (valid && rank == 0u) cnt[wave][d] = (u32)__popcll(same); // (the lowest lane of each digit's group)
+        __syncthreads();
+        if (valid) {
+            u32 off = 0;
+            for (u32 w = 0; w < wave; ++w) off += cnt[w][d];
+            const u32 pos = run[d] + off + rank;
+            keys_out[pos] = key;
+            vals_out[pos] = val;
+        }
+        __syncthreads();
+        run[t] += cnt[0][t] + cnt[1][t] + cnt[2][t] + cnt[3][t];
+        __syncthreads();
+    }
+}
+
+static inline u32 rs_ntile(u32 M) { return (M + RS_TILE - 1) / RS_TILE; }
+
 hipError_t big_sort_tmp_bytes(u32 M, size_t *bytes) {
-    size_t b = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, b, (const u64 *)nullptr, (u64 *)nullptr, (const u32 *)nullptr,
-                                             (u32 *)nullptr, (size_t)M, 0, 64, nullptr);
-    *bytes = b;
-    return e;
+    *bytes = ((size_t)256 * rs_ntile(M ? M : 1u) + 256) * sizeof(u32);
+    return hipSuccess;
+}
+
+// ascending by key; the sorted pairs end up where they came from (keys, vals); keys_tmp / vals_tmp are scratch
+static hipError_t sort_pairs(void *tmp, size_t tmp_bytes, u64 *keys, u64 *keys_tmp, u32 *vals, u32 *vals_tmp, u32 M, hipStream_t st) {
+    const u32 ntile = rs_ntile(M);
+    if (tmp_bytes < ((size_t)256 * ntile + 256) * sizeof(u32)) return hipErrorInvalidValue;
+    u32 *hist = (u32 *)tmp, *tot = hist + (size_t)256 * ntile;
+    u64 *ka = keys, *kb = keys_tmp;
+    u32 *va = vals, *vb = vals_tmp;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 8 * pass;
+        hipLaunchKernelGGL(k_rs_hist, dim3(ntile), dim3(256), 0, st, (const u64 *)ka, M, shift, hist, ntile);
+        hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, st, hist, ntile, tot);
+        hipLaunchKernelGGL(k_rs_scan_tot, dim3(1), dim3(256), 0, st, tot);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(ntile), dim3(256), 0, st, (const u64 *)ka, (const u32 *)va, M, shift, (const u32 *)hist,
+                           (const u32 *)tot, ntile, kb, vb);
+        u64 *tk = ka;
+        ka = kb;
+        kb = tk;
+        u32 *tv = va;
+        va = vb;
+        vb = tv;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_big_prune(Entry *table, u32 *live, u32 *dead, u32 dead_cap, Ctl *ctl, u32 M, u32 n_dead_now, u32 kind,
@@ -92,11 +231,10 @@ hipError_t launch_big_prune(Entry *table, u32 *live, u32 *dead, u32 dead_cap, Ct
     if (M == 0) return hipSuccess;
     const int blocks = (int)((M + 255u) / 256u < 4096u ? (M + 255u) / 256u : 4096u);
     hipLaunchKernelGGL(k_big_gather_keys, dim3(blocks), dim3(256), 0, st, table, live, M, keys_a, slots_a);
-    hipError_t e = rocprim::radix_sort_pairs(tmp, tmp_bytes, (const u64 *)keys_a, keys_b, (const u32 *)slots_a, slots_b,
-                                             (size_t)M, 0, 64, st);
+    hipError_t e = sort_pairs(tmp, tmp_bytes, keys_a, keys_b, slots_a, slots_b, M, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_big_select, dim3(1), dim3(64), 0, st, keys_b, M, ctl, kind, size, max_hash, keep_dev);
-    hipLaunchKernelGGL(k_big_writeback, dim3(blocks), dim3(256), 0, st, slots_b, M, keep_dev, live, dead, dead_cap, ctl,
+    hipLaunchKernelGGL(k_big_select, dim3(1), dim3(64), 0, st, (const u64 *)keys_a, M, ctl, kind, size, max_hash, keep_dev);
+    hipLaunchKernelGGL(k_big_writeback, dim3(blocks), dim3(256), 0, st, (const u32 *)slots_a, M, keep_dev, live, dead, dead_cap, ctl,
                        n_dead_now);
     return hipGetLastError();
 }
