@@ -598,3 +598,36 @@ def test_one_gzip_member_decoded_by_several_threads(monkeypatch):
     # the records are what the host parser makes of the plain text
     monkeypatch.setenv("FINCH_PARGZ_CHUNK", "100000")
     assert H.fastx_scan(gzip.compress(text, 6)) == H.fastx_scan(text)
+
+
+def test_gzip_header_fields_in_front_of_a_member_decoded_in_parallel(monkeypatch):
+    """RFC 1952 header variants (FNAME as `gzip file` writes it, FEXTRA that is not BGZF's, FCOMMENT, FHCRC) in front of a
+    member the parallel reader takes"""
+    import struct
+    import zlib
+    monkeypatch.setenv("FINCH_BGZF_THREADS", "4")
+    monkeypatch.setenv("FINCH_PARGZ_CHUNK", "60000")
+    rng = np.random.default_rng(1)
+    text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=100)),
+                                              bytes(rng.integers(35, 74, size=100, dtype=np.uint8))) for i in range(20000))
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = co.compress(text) + co.flush()
+    trailer = struct.pack("<II", zlib.crc32(text), len(text))
+
+    def hdr(flg, extra=b"", name=b"", comment=b""):
+        h = b"\x1f\x8b\x08" + bytes([flg]) + b"\0\0\0\0\x00\x03"
+        if flg & 4:
+            h += struct.pack("<H", len(extra)) + extra
+        if flg & 8:
+            h += name + b"\0"
+        if flg & 16:
+            h += comment + b"\0"
+        if flg & 2:
+            h += struct.pack("<H", zlib.crc32(h) & 0xFFFF)
+        return h
+
+    for h in (hdr(0), hdr(8, name=b"reads.fastq"), hdr(4, extra=b"XY\x03\0abc"),
+              hdr(4 | 8 | 16 | 2, extra=b"AB\x02\0zz", name=b"x" * 300, comment=b"made by a test")):
+        z = h + body + trailer
+        assert zlib.decompress(z, 31) == text
+        assert H.source_probe(z, 1 << 20, len(text) + 4096) == text
