@@ -37,7 +37,7 @@ namespace {
 #ifndef BZ_FENCE_SCOPE
 #define BZ_FENCE_SCOPE "workgroup"
 #endif
-constexpr int LIT_BITS = 10, DIST_BITS = 9, CL_BITS = 7;
+constexpr int LIT_BITS = 10, DIST_BITS = 8, CL_BITS = 7;
 constexpr u32 KIND_LIT = 0, KIND_BASE = 1, KIND_EOB = 2, KIND_LONG = 3;
 // "no such code" in the literal/length table: the kind of the end-of-block symbol with a length of 0, so that the symbol
 // loop's common cases (literal, match) need no validity test of their own
@@ -79,7 +79,8 @@ struct Lds {
     CodeSet cs[2];
     uint8_t lens[320];
     uint8_t cl_lens[32];
-    u32 qpos[128], qinfo[128]; // (the lane-parallel symbol loop) tokens waiting for a full group of 64
+    u32 qinfo[128];   // (the lane-parallel symbol loop) tokens waiting for a full group of 64 ...
+    uint16_t qpos[128]; // ... and where they go (a member's text is at most 65536 bytes, a token starts below that)
 };
 
 __device__ __forceinline__ u32 rfl(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -315,7 +316,7 @@ __device__ void flush_queue(Lds &L, uint8_t *out, u32 &qn, u32 lane, bool all) {
         const u32 p1 = L.qpos[64u + lane], i1 = L.qinfo[64u + lane];
         __syncthreads();
         if (lane < rest) {
-            L.qpos[lane] = p1;
+            L.qpos[lane] = (uint16_t)p1;
             L.qinfo[lane] = i1;
         }
         qn = rest;
@@ -396,7 +397,7 @@ __device__ u32 block_symbols_parallel(Lds &L, const uint8_t *mbase, u64 in_bits,
         }
         const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(marks >> 32), __builtin_amdgcn_mbcnt_lo((u32)marks, 0u));
         if (tok) {
-            L.qpos[qn + rank] = mypos;
+            L.qpos[qn + rank] = (uint16_t)mypos;
             L.qinfo[qn + rank] = info;
         }
         qn += (u32)__popcll(marks);
@@ -430,7 +431,7 @@ enum BgzfFail : u32 {
 
 // PAR: the symbols of a block are decoded 64 bit offsets at a time (block_symbols_parallel) instead of one by one
 template <bool PAR>
-__global__ __launch_bounds__(64) void k_bgzf_inflate(const uint8_t *comp, const BgzfMember *members, u32 n_members,
+__global__ __launch_bounds__(64, 5) void k_bgzf_inflate(const uint8_t *comp, const BgzfMember *members, u32 n_members,
                                                      uint8_t *text, u32 *status) {
     __shared__ Lds L;
     const u32 mi = blockIdx.x, lane = threadIdx.x;
