@@ -567,12 +567,7 @@ FH_HD u64 key_word_mix(const KeyWords<K> &w, int i) {
 // The hash is produced in two steps so that the hot loop can reject on high words alone.  `HashParts` are the two
 // fmix64 states short of their last multiply and xor-shift:  a = ka * M2, b = kb * M2,
 // hash = (a ^ a>>33) + (b ^ b>>33).  The final xor-shifts only touch the low words, so hi(hash) is hi(a) + hi(b)
-// or that plus one, and
-//     hash <= tau  =>  hi(a) + hi(b) + 1  (mod 2^32)  <=  hi(tau) + 1
-// (for hi(tau) != 2^32-1; the wrap of the left side to 0 covers hi(a)+hi(b) = 2^32-1 with a carry).  Multiplication
-// by M2 is linear mod 2^32 in the cross terms, so the sum of the two high words needs two mul_hi and two mul_lo
-// instead of two full 64-bit products:
-//     hi(a) + hi(b) = mulhi(ka.lo, M2.lo) + mulhi(kb.lo, M2.lo) + (ka.lo + kb.lo) * M2.hi + (ka.hi + kb.hi) * M2.lo
+// or that plus one (parts_hi_plus1 is the test the hot loop makes).
 struct HashParts {
     u64 ka, kb;
 };
@@ -595,11 +590,15 @@ FH_HD u64 parts_hash(HashParts p) {
     return add64(a ^ (a >> 33), b ^ (b >> 33));
 }
 FH_HD u32 parts_hi_plus1(HashParts p) {
+    // a + b = (ka + kb) * M2 =: P (mod 2^64), and hi(a) + hi(b) = hi(P) - carry(a.lo + b.lo): one 64-bit add in front of
+    // ONE high-word product instead of two.  hi(hash) is hi(P) - 1, hi(P) or hi(P) + 1, so
+    //     hash <= tau  =>  hi(P) + 1  (mod 2^32)  <=  hi(tau) + 2
     constexpr u32 M2L = (u32)FMIX_M2, M2H = (u32)(FMIX_M2 >> 32);
-    const u32 al = (u32)p.ka, ah = (u32)(p.ka >> 32), bl = (u32)p.kb, bh = (u32)(p.kb >> 32);
-    return mulhi32(al, M2L) + mulhi32(bl, M2L) + (al + bl) * M2H + (ah + bh) * M2L + 1u;
+    const u64 s = add64(p.ka, p.kb);
+    const u32 sl = (u32)s, sh = (u32)(s >> 32);
+    return mulhi32(sl, M2L) + sl * M2H + sh * M2L + 1u;
 }
-FH_HD u32 tau_hi_bound(u64 tau) { return (u32)(tau >> 32) == 0xFFFFFFFFu ? 0xFFFFFFFFu : (u32)(tau >> 32) + 1u; }
+FH_HD u32 tau_hi_bound(u64 tau) { return (u32)(tau >> 32) >= 0xFFFFFFFEu ? 0xFFFFFFFFu : (u32)(tau >> 32) + 2u; }
 
 template <int K, bool SEED0>
 FH_HD HashParts murmur_finish_parts(const KeyWords<K> &w, u64 seed) {
