@@ -442,7 +442,9 @@ FH_HD Rec4 lut_rec_A(u32 q, bool k2) {
 }
 FH_HD Rec2 lut_rec_B(u32 q, int nb, bool k2) {
     const u32 v = (u32)(ascii_group_n(q, nb) * (k2 ? MURMUR_C2 : MURMUR_C1));
-    return Rec2{v, v << 31};
+    // k1 words need v << 31 as the addend of a multiply-add (key_word_mix): it comes first, so that the register pair the
+    // record is loaded into is that instruction's accumulator as it stands; k2 words only ever read v
+    return k2 ? Rec2{v, v << 31} : Rec2{v << 31, v};
 }
 // xr: a constant folded in by xor (the key length, which murmur3 xors into h1 / h2 right after the tail words)
 FH_HD Rec2 lut_rec_S(u32 q, int nb, bool k2, u64 xr) {
@@ -530,8 +532,8 @@ FH_HD void murmur_lookup(u64 cm, const LutTables &T, KeyWords<K> &w) { // cm = c
             w.a0[i] = ra.x;
             w.a1[i] = ra.y;
             w.a2[i] = ra.z;
-            w.b0[i] = rb.x;
-            w.b1[i] = rb.y;
+            w.b0[i] = g.is_k2 ? rb.x : rb.y;
+            w.b1[i] = g.is_k2 ? rb.y : rb.x;
         }
     }
 }
@@ -560,7 +562,14 @@ FH_HD u64 key_word_mix(const KeyWords<K> &w, int i) {
         return mad64(ww, (u32)M, acc) + ((u64)(ww * (u32)(M >> 32)) << 32);
     }
     const u32 y = ww >> 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // high word = hi(y * C.lo + acc) + y * C.hi + b1: the last two are the low word of a second multiply-add on the B record
+    const u64 t = mad64(y, (u32)MURMUR_C2, acc);
+    const u64 q = mad64(y, (u32)(MURMUR_C2 >> 32), ((u64)w.b0[i] << 32) | w.b1[i]);
+    return ((u64)((u32)(t >> 32) + (u32)q) << 32) | (u32)t;
+#else
     return mad64(y, (u32)MURMUR_C2, acc) + ((u64)(y * (u32)(MURMUR_C2 >> 32) + w.b1[i]) << 32);
+#endif
 }
 
 // SEED0: compile-time knowledge that seed == 0 (the default; drops three 64-bit ops).
@@ -573,10 +582,21 @@ struct HashParts {
 };
 constexpr u64 FMIX_M1 = 0xff51afd7ed558ccdULL, FMIX_M2 = 0xc4ceb9fe1a85ec53ULL;
 FH_HD u64 fmix64_head(u64 k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // k * M1 as three multiplier instructions and a plain add: the cross terms lo * M1.hi + hi * M1.lo are the low word
+    // of a v_mad_u64_u32 whose accumulator carries the first product (its high half is whatever the pair holds)
+    constexpr u32 ML = (u32)FMIX_M1, MH = (u32)(FMIX_M1 >> 32);
+    const u32 hi = (u32)(k >> 32), lo = (u32)k ^ (hi >> 1);
+    const u64 t = (u64)lo * ML;
+    const u64 q = mad64(hi, ML, ((u64)hi << 32) | (lo * MH));
+    const u32 nh = (u32)(t >> 32) + (u32)q;
+    return ((u64)nh << 32) | ((u32)t ^ (nh >> 1));
+#else
     k ^= k >> 33;
     k *= FMIX_M1;
     k ^= k >> 33;
     return k;
+#endif
 }
 FH_HD u32 mulhi32(u32 x, u32 y) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -596,7 +616,13 @@ FH_HD u32 parts_hi_plus1(HashParts p) {
     constexpr u32 M2L = (u32)FMIX_M2, M2H = (u32)(FMIX_M2 >> 32);
     const u64 s = add64(p.ka, p.kb);
     const u32 sl = (u32)s, sh = (u32)(s >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 z, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 1" : "=v"(z), "=s"(carry) : "v"(sl), "s"(M2H)); // low word: sl * M2H + 1
+    return mulhi32(sl, M2L) + (u32)mad64(sh, M2L, z);
+#else
     return mulhi32(sl, M2L) + sl * M2H + sh * M2L + 1u;
+#endif
 }
 FH_HD u32 tau_hi_bound(u64 tau) { return (u32)(tau >> 32) >= 0xFFFFFFFEu ? 0xFFFFFFFFu : (u32)(tau >> 32) + 2u; }
 
@@ -809,8 +835,8 @@ FH_HD void murmur_lookup_w(const u32 *cm, const LutTables &T, KeyWords<K> &w) { 
             w.a0[i] = ra.x;
             w.a1[i] = ra.y;
             w.a2[i] = ra.z;
-            w.b0[i] = rb.x;
-            w.b1[i] = rb.y;
+            w.b0[i] = g.is_k2 ? rb.x : rb.y;
+            w.b1[i] = g.is_k2 ? rb.y : rb.x;
         }
     }
 }
