@@ -366,6 +366,17 @@ FH_HD u64 add64(u64 a, u64 b) {
 #endif
 }
 
+// a ^ b ^ c with c confined to the low word
+FH_HD u64 xor3_lo(u64 a, u64 b, u32 c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 lo;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(lo) : "v"((u32)a), "v"((u32)b), "v"(c));
+    return ((u64)((u32)(a >> 32) ^ (u32)(b >> 32)) << 32) | lo;
+#else
+    return a ^ b ^ (u64)c;
+#endif
+}
+
 FH_HD u64 mul5_add(u64 h, u64 c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     u64 t;
@@ -559,7 +570,8 @@ FH_HD u64 key_word_mix(const KeyWords<K> &w, int i) {
     const u32 ww = w.a2[i] + w.b0[i];
     if (g.is_k2) {
         constexpr u64 M = MURMUR_C1 << 1;
-        return mad64(ww, (u32)M, acc) + ((u64)(ww * (u32)(M >> 32)) << 32);
+        const u64 t = mad64(ww, (u32)M, acc);
+        return ((u64)((u32)(t >> 32) + ww * (u32)(M >> 32)) << 32) | (u32)t; // only the high word takes the cross term
     }
     const u32 y = ww >> 1;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -647,18 +659,23 @@ FH_HD HashParts murmur_finish_parts(const KeyWords<K> &w, u64 seed) {
         h2 = add64(h2, h1);
         h2 = mul5_add(h2, 0x38495ab5ULL);
     }
+    // the tail words and the key length go in by xor: where both apply to a state, one three-input v_bitop3_b32 on
+    // the low word (the length is < 2^32) instead of two v_xor_b32
+    bool len1 = !len_folded(K, false), len2 = !len_folded(K, true);
     if (TAIL > 8) {
         u64 k2 = key_word_mix<K>(w, 2 * NB + 1);
         if (SEED0 && NB == 0) h2 = k2;
+        else if (len2) h2 = xor3_lo(h2, k2, (u32)K), len2 = false;
         else h2 ^= k2;
     }
     if (TAIL > 0) {
         u64 k1 = key_word_mix<K>(w, 2 * NB);
         if (SEED0 && NB == 0) h1 = k1;
+        else if (len1) h1 = xor3_lo(h1, k1, (u32)K), len1 = false;
         else h1 ^= k1;
     }
-    if (!len_folded(K, false)) h1 ^= (u64)K;
-    if (!len_folded(K, true)) h2 ^= (u64)K;
+    if (len1) h1 ^= (u64)K;
+    if (len2) h2 ^= (u64)K;
     h1 = add64(h1, h2);
     h2 = add64(h2, h1);
     return HashParts{fmix64_head(h1), fmix64_head(h2)};
