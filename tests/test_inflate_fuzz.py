@@ -26,3 +26,30 @@ def test_mutated_deflate_streams_under_sanitizers(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
     assert "undamaged streams reproduced by all three decoders" in r.stdout
     assert "done: 800 mutated streams" in r.stdout
+
+
+def test_mutated_fastx_images_under_sanitizers(tmp_path):
+    """tools/fuzz_fastx.cpp: the whole reader stack of fh_host.cpp (sniffing, gzip / BGZF containers, the serial and the
+    multi-threaded inflate sources, the FASTA / FASTQ parser) through finch_fastx_scan, rebuilt with ASan + UBSan; the
+    device engine comes from libfinch_hip.so and is never called."""
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    from finch_rs_amd import _lib
+    _lib.load()  # (builds the library if it is missing)
+    so_dir = os.path.dirname(_lib.SO_PATH)
+    exe = str(tmp_path / "fuzz_fastx")
+    csrc = os.path.join(ROOT, "finch_rs_amd", "csrc")
+    cmd = [gxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-I" + os.path.join(ROOT, "include"), "-I" + csrc, os.path.join(ROOT, "tools", "fuzz_fastx.cpp"),
+           os.path.join(csrc, "fh_host.cpp"), os.path.join(csrc, "fh_serial.cpp"), "-L" + so_dir, "-lfinch_hip",
+           "-Wl,-rpath," + so_dir, "-lz", "-ldl", "-lpthread", "-o", exe]
+    b = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if b.returncode != 0 and "asan" in b.stdout.lower():
+        pytest.skip("sanitizer runtime not installed")
+    assert b.returncode == 0, b.stdout[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([exe, "400", "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "undamaged inputs scanned right with 1 and 4 inflate threads" in r.stdout
+    assert "done: 400 mutated inputs" in r.stdout
