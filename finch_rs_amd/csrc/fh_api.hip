@@ -85,7 +85,7 @@ const uint64_t STAGE_BYTES_ENV = [] {
     return v >= 4096 ? v : 0ull;
 }();
 constexpr uint64_t STAGE_BYTES_DEFAULT = 64ull << 20;
-constexpr uint64_t STAGE_HEADROOM = 32;
+constexpr uint64_t STAGE_HEADROOM = 64; // bytes in front of a staging buffer's data: fh_push_staged puts the K-1 <= 63 carried bytes there
 constexpr int N_STAGE = 2;
 
 struct ResultRec {
@@ -1452,6 +1452,7 @@ int fh_push_staged(fh_sketcher *s, uint64_t len, uint32_t flags) {
     const int b = s->stage_next;
     const uint32_t K = s->p.k;
     const uint32_t carry_len = s->carry_len;
+    static_assert(STAGE_HEADROOM >= sizeof(fh_sketcher::carry) - 1, "the carried bytes must fit in front of the staged data");
     uint8_t *src = s->h_stage[b] + STAGE_HEADROOM - carry_len;
     memcpy(src, s->carry, carry_len);
     const uint64_t m = carry_len + len;

@@ -265,8 +265,19 @@ __global__ __launch_bounds__(TB) void k1_pack(const uint8_t *text, u64 len, cons
 // bases = emitted bytes that are not breakers (what total_bases counts for FASTQ, mash.rs:72).  A chunk starts at a record,
 // so the newlines that end sequence lines are those with index 1 mod 4: (L + 2) / 4 of L -- no need to count them with
 // atomics (one per workgroup on a single address was a good part of the packer's time).  totals: [0] newlines, [1] emitted.
-__global__ void k1_add_bases(Ctl *ctl, const u32 *totals) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) ctl->text_bases += (u64)totals[1] - (u64)((totals[0] + 2u) / 4u);
+// The same thread judges the shape of the chunk's end.  A chunk is whole records, so its L newlines are 4 per record
+// with nothing behind them, or 3 mod 4 when the last record's quality line has no newline (or is not there at all: an
+// empty quality line, which k1_check_records then holds against the sequence).  Anything else -- a record cut off after
+// its header or its sequence line, a header begun behind the last record, blank lines at the end -- is for the host
+// parser to accept or to refuse with needletail's error ("truncated FASTQ record"); silently sketching what is there
+// would not be the reference's behaviour.
+__global__ void k1_add_bases(Ctl *ctl, const u32 *totals, const uint8_t *text, u64 len, u32 *err) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        ctl->text_bases += (u64)totals[1] - (u64)((totals[0] + 2u) / 4u);
+        const u32 m = totals[0] & 3u;
+        const bool open_line = text[len - 1] != '\n'; // bytes behind the last newline
+        if (!((m == 0u && !open_line) || m == 3u)) atomicExch(err, 1u);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -459,7 +470,7 @@ hipError_t launch_fastq_pack(const uint8_t *text, u64 len, uint8_t *out, u32 *bl
     hipLaunchKernelGGL(k1_scan, dim3(1), dim3(1024), 0, st, blk_a, nblk, totals);
     hipLaunchKernelGGL(k1_pick_keep, dim3((nblk + 255u) / 256u), dim3(256), 0, st, (const u32 *)blk_a, (const u32 *)keep4, blk_b, nblk);
     hipLaunchKernelGGL(k1_scan, dim3(1), dim3(1024), 0, st, blk_b, nblk, totals + 1);
-    hipLaunchKernelGGL(k1_add_bases, dim3(1), dim3(64), 0, st, ctl, (const u32 *)totals);
+    hipLaunchKernelGGL(k1_add_bases, dim3(1), dim3(64), 0, st, ctl, (const u32 *)totals, text, len, err);
     hipLaunchKernelGGL(k1_pack, dim3(nblk), dim3(TB), 0, st, text, len, (const u32 *)blk_a, (const u32 *)blk_b, out, err, line_end,
                        line_cap);
     hipLaunchKernelGGL(k1_check_records, dim3(256), dim3(256), 0, st, (const u32 *)line_end, (const u32 *)totals, len, text,

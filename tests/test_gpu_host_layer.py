@@ -136,6 +136,73 @@ print("child ok")
         assert "child ok" in _run_child(code, env)
 
 
+def test_wide_kmers_span_staging_slices_on_every_path():
+    """k = 34..64 carry up to 63 bytes from one staging slice to the next: records longer than a 4 KiB slice through the
+    host parser (staged pushes: the carry sits in front of the staged data), through the device-side FASTA splitter and
+    through the FASTQ path with its fallback, against the oracle.  (The room in front of the staging buffer was once 32
+    bytes: k >= 34 wrote before the allocation.)"""
+    code = r'''
+import os, numpy as np
+from finch_rs_amd import host as H, sketch_schemes as S
+from oracle import oracle as O
+seq = bytes(S.synth_genome_host(60000, 21))
+fa = b">a long one\n" + b"\n".join(seq[j:j+70] for j in range(0, 40000, 70)) + b"\n>b\n" + seq[40000:52000] + b"\n"
+reads = [seq[i * 700:i * 700 + (3000 if i % 5 == 0 else 150)] for i in range(60)]
+fq = b"".join(b"@r%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n" for i, r in enumerate(reads))
+for k in (33, 34, 48, 63, 64):
+    p = S.SketchParams.mash(200, 200, True, k, 0)
+    for data in (fa, fq):
+        o = O.OracleSketcher(O.MASH, 200, k, 0)
+        assert o.sketch_stream(data) > 0
+        okc, okm = o.to_vec()
+        for mode in ("0", "1", None):
+            if mode is None:
+                os.environ.pop("FINCH_DEVICE_PARSE", None)
+            else:
+                os.environ["FINCH_DEVICE_PARSE"] = mode
+            if mode == "1" and data is fq:
+                continue  # (device only: a 3000-base record does not fit a 4 KiB slice -- an error by design)
+            sk = H.sketch_stream(data, "x", p, H.FilterParams(False)).sketch(0)
+            assert np.array_equal(sk.arrays[0], okc) and np.array_equal(sk.arrays[1], okm), (k, mode)
+            assert (sk.seq_length, sk.num_valid_kmers) == o.total_bases_and_kmers(), (k, mode)
+print("child ok")
+'''
+    assert "child ok" in _run_child(code, {"FH_STAGE_BYTES": "4096"})
+    assert "child ok" in _run_child(code, {"FH_STAGE_BYTES": "5001"})
+
+
+def test_fastq_cut_off_inside_a_record_is_the_reference_error_on_every_path():
+    """needletail refuses a FASTQ file that ends inside a record ("truncated FASTQ record"); the device-side splitter
+    hands such a chunk to the host parser instead of sketching what is there"""
+    g = bytes(S.synth_genome_host(5000, 3))
+    whole = b"".join(b"@r%d\n" % i + g[i * 100:i * 100 + 150] + b"\n+\n" + b"I" * 150 + b"\n" for i in range(20))
+    p = S.SketchParams.mash(100, 100, True, 21, 0)
+    good = H.sketch_stream(whole, "x", p, H.FilterParams(False)).sketch(0)
+    for tail in (b"@last\n", b"@last", b"@last\nACGTACGTACGTACGTACGTACGT\n", b"@last\nACGTACGTACGTACGTACGTACGT", b"@last\nACGT\n+"):
+        for mode in ("0", None, "1"):
+            if mode is None:
+                os.environ.pop("FINCH_DEVICE_PARSE", None)
+            else:
+                os.environ["FINCH_DEVICE_PARSE"] = mode
+            try:
+                with pytest.raises(FinchError):
+                    H.sketch_stream(whole + tail, "x", p, H.FilterParams(False))
+            finally:
+                os.environ.pop("FINCH_DEVICE_PARSE", None)
+    # the last record without its quality line's newline, and with an empty quality line for an empty sequence, are fine
+    for tail in (b"@last\nACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIII", b"@last\n\n+\n"):
+        for mode in ("0", None):
+            if mode is None:
+                os.environ.pop("FINCH_DEVICE_PARSE", None)
+            else:
+                os.environ["FINCH_DEVICE_PARSE"] = mode
+            try:
+                sk = H.sketch_stream(whole + tail, "x", p, H.FilterParams(False)).sketch(0)
+            finally:
+                os.environ.pop("FINCH_DEVICE_PARSE", None)
+            assert sk.seq_length == good.seq_length + (24 if b"ACGT" in tail else 0)
+
+
 def test_device_side_fastq_parsing_matches_host_parser(tmp_path):
     """SURVEY 8f N3: with FINCH_DEVICE_PARSE=1 the sequence lines of plain FASTQ are found on the device
     (fh_text.hip); same sketch, seq_length and numValidKmers as the host parser, incl. CRLF, a last line

@@ -1,0 +1,103 @@
+"""Extended randomised comparison of the device-side record splitters (fh_text.hip) with the host parser and the oracle.
+    python tools/fuzz_device_text.py [cases [seed]]       (on an MI355X; FH_STAGE_BYTES=4096 makes the cuts land everywhere)
+FASTA: random FASTA-shaped text (arbitrary bytes, '>' anywhere, LF / CRLF, blank lines, ragged lines, empty records).
+FASTQ: four-line records with damage sprinkled in (blank lines, CRLF, '@' / '+' starting quality lines, a missing last newline,
+sequence / quality lengths that differ, truncated records): the default path (device, host parser as the fallback) must give
+what the host parser alone gives -- the same sketch or an error -- and, where the oracle's parser accepts the text, the
+oracle's sketch."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from finch_rs_amd import host as H, sketch_schemes as S
+from oracle import oracle as O
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 77000
+
+
+def run(data, p, mode):
+    if mode is None:
+        os.environ.pop("FINCH_DEVICE_PARSE", None)
+    else:
+        os.environ["FINCH_DEVICE_PARSE"] = mode
+    try:
+        return H.sketch_stream(data, "x", p, H.FilterParams(False)).sketch(0), None
+    except Exception as e:  # noqa
+        return None, str(e)
+
+
+def same(a, b):
+    return (np.array_equal(a.arrays[0], b.arrays[0]) and np.array_equal(a.arrays[1], b.arrays[1])
+            and (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers))
+
+
+def vs_oracle(b, data, p):
+    o = O.OracleSketcher(O.MASH, p.kmers_to_sketch, p.kmer_length, 0)
+    if o.sketch_stream(data) <= 0:
+        return False
+    okc, okm = o.to_vec()
+    assert np.array_equal(b.arrays[0], okc) and np.array_equal(b.arrays[1], okm)
+    assert (b.seq_length, b.num_valid_kmers) == o.total_bases_and_kmers()
+    return True
+
+
+alpha = np.frombuffer(b"ACGTACGTACGTACGTacgtNnuU>>- \t\r\xff*@+", dtype=np.uint8)
+qual = np.frombuffer(bytes(range(33, 100)), dtype=np.uint8)
+n_fa = n_fq = n_fq_err = n_or = 0
+verbose = os.environ.get("FUZZ_VERBOSE") is not None
+for case in range(n_cases):
+    if verbose:
+        print("case", case, flush=True)
+    rng = np.random.default_rng(seed0 + case)
+    k = int(rng.choice([3, 11, 16, 21, 31, 33, 48]))
+    p = S.SketchParams.mash(50, 50, True, k, 0)
+    if case % 2 == 0:
+        lines = []
+        for i in range(int(rng.choice([1, 5, 60, 800, 4000]))):
+            r = rng.random()
+            if i == 0 or r < 0.08:
+                lines.append(b">" + bytes(rng.choice(alpha, size=int(rng.integers(0, 40)))))
+            elif r < 0.12:
+                lines.append(b"")
+            else:
+                lines.append(bytes(rng.choice(alpha, size=int(rng.choice([1, 7, 60, 70, 500, 6000])))))
+        eol = [b"\n", b"\r\n"][int(rng.integers(0, 2))]
+        data = eol.join(lines) + (eol if rng.random() < 0.7 else b"")
+        a, ea = run(data, p, "0")
+        b, eb = run(data, p, "1")
+        assert (a is None) == (b is None), (case, ea, eb)
+        if a is not None:
+            assert same(a, b), ("fasta", case)
+            n_or += vs_oracle(b, data, p)
+        n_fa += 1
+    else:
+        eol = [b"\n", b"\r\n"][int(rng.integers(0, 2))]
+        recs = []
+        n_rec = int(rng.choice([1, 3, 40, 700]))
+        damage = rng.random() < 0.6
+        for i in range(n_rec):
+            L = int(rng.choice([0, 1, 20, 150, 151, 3000])) if rng.random() < 0.3 else 150
+            seq = bytes(rng.choice(alpha[:24], size=L))
+            q = bytes(rng.choice(qual, size=L))
+            if damage and rng.random() < 0.03:
+                q = q[:-1] if L else b"I"                      # lengths differ
+            if damage and rng.random() < 0.05 and L:
+                q = bytes([64 if rng.random() < 0.5 else 43]) + q[1:]   # quality line starting with '@' / '+'
+            rec = [b"@r%d" % i, seq, b"+" if rng.random() < 0.8 else b"+r%d" % i, q]
+            if damage and rng.random() < 0.02:
+                rec = rec[:int(rng.integers(1, 4))]            # truncated record
+            recs.append(eol.join(rec))
+            if damage and rng.random() < 0.03:
+                recs.append(b"")                               # blank line between records
+        data = eol.join(recs) + (eol if rng.random() < 0.7 else b"")
+        a, ea = run(data, p, "0")
+        b, eb = run(data, p, None)
+        assert (a is None) == (b is None), (case, ea, eb)
+        if a is not None:
+            assert same(a, b), ("fastq", case)
+            n_or += vs_oracle(b, data, p)
+        else:
+            n_fq_err += 1
+        n_fq += 1
+print("fuzz_device_text: %d FASTA texts, %d FASTQ texts (%d refused by both parsers), %d also checked against the oracle: all agree"
+      % (n_fa, n_fq, n_fq_err, n_or))
