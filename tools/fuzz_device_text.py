@@ -4,7 +4,10 @@ FASTA: random FASTA-shaped text (arbitrary bytes, '>' anywhere, LF / CRLF, blank
 FASTQ: four-line records with damage sprinkled in (blank lines, CRLF, '@' / '+' starting quality lines, a missing last newline,
 sequence / quality lengths that differ, truncated records): the default path (device, host parser as the fallback) must give
 what the host parser alone gives -- the same sketch or an error -- and, where the oracle's parser accepts the text, the
-oracle's sketch."""
+oracle's sketch.
+FUZZ_FILES=1: every text is also written as a plain file, a gzip file and a bgzip-style BGZF file and sketched through
+sketch_files (device-side splitting, the inflate sources, BGZF members inflated on the device for FASTQ): each must give what
+the text gave -- the same sketch, or an error."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -41,6 +44,41 @@ def vs_oracle(b, data, p):
     return True
 
 
+import gzip, struct, zlib
+FILES = os.environ.get("FUZZ_FILES") is not None
+n_files = 0
+
+
+def bgzf(data, block=65280):
+    out = []
+    for i in list(range(0, len(data), block)) + [None]:
+        ch = b"" if i is None else data[i:i + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        d = co.compress(ch) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(d) + 25) + d + struct.pack("<II", zlib.crc32(ch), len(ch)))
+    return b"".join(out)
+
+
+def check_files(ref, data, p, case):
+    """ref: the sketch of the text through sketch_stream (None: it was refused)"""
+    global n_files
+    os.environ.pop("FINCH_DEVICE_PARSE", None)
+    for ext, img in ((".txt", data), (".gz", gzip.compress(data, 1)), (".bgzf.gz", bgzf(data))):
+        path = "/dev/shm/fuzz_text_%d%s" % (os.getpid(), ext)
+        with open(path, "wb") as f:
+            f.write(img)
+        try:
+            r = H.sketch_files([path], p, H.FilterParams(False), n_threads=1).sketch(0)
+        except Exception as e:  # noqa
+            r = None
+        finally:
+            os.remove(path)
+        assert (r is None) == (ref is None), (case, ext, "file refused" if r is None else "file accepted")
+        if r is not None:
+            assert same(r, ref), (case, ext)
+        n_files += 1
+
+
 alpha = np.frombuffer(b"ACGTACGTACGTACGTacgtNnuU>>- \t\r\xff*@+", dtype=np.uint8)
 qual = np.frombuffer(bytes(range(33, 100)), dtype=np.uint8)
 n_fa = n_fq = n_fq_err = n_or = 0
@@ -69,6 +107,8 @@ for case in range(n_cases):
         if a is not None:
             assert same(a, b), ("fasta", case)
             n_or += vs_oracle(b, data, p)
+        if FILES:
+            check_files(a, data, p, case)
         n_fa += 1
     else:
         eol = [b"\n", b"\r\n"][int(rng.integers(0, 2))]
@@ -98,6 +138,8 @@ for case in range(n_cases):
             n_or += vs_oracle(b, data, p)
         else:
             n_fq_err += 1
+        if FILES:
+            check_files(a, data, p, case)
         n_fq += 1
-print("fuzz_device_text: %d FASTA texts, %d FASTQ texts (%d refused by both parsers), %d also checked against the oracle: all agree"
-      % (n_fa, n_fq, n_fq_err, n_or))
+print("fuzz_device_text: %d FASTA texts, %d FASTQ texts (%d refused by both parsers), %d also checked against the oracle, %d files: all agree"
+      % (n_fa, n_fq, n_fq_err, n_or, n_files))
