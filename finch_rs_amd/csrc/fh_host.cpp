@@ -2550,9 +2550,13 @@ static int bgzf_fastq_to_device(BgzfSource &bz, fh_sketcher *h) {
     return FH_OK;
 }
 
+// *device_rejected: the input is FASTQ and the device-side splitter refused a chunk of it (not strictly 4-line, a record
+// longer than a chunk): the caller sends the file through the single-handle path, whose host parser is the judge of
+// what needletail accepts.
 static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::string &name, const finch_sketch_params &sp,
                                  const finch_filter_params &filters, const std::vector<int> &devs, uint64_t chunk_bytes,
-                                 Sketch &out) {
+                                 Sketch &out, bool *device_rejected) {
+    *device_rejected = false;
     std::unique_ptr<ByteSource> src;
     bool compressed = false;
     int first = -1;
@@ -2580,7 +2584,7 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
                        getenv("FINCH_NO_SMALL_SKETCHER") == nullptr;
     finch_sketch_params sp_dev = sp;
     if (small) sp_dev.kmers_to_sketch = sp.final_size; // (see HandleSet)
-    const uint64_t stage = chunk_bytes ? std::max<uint64_t>(chunk_bytes, 4096) : (32ull << 20);
+    uint64_t stage = chunk_bytes ? std::max<uint64_t>(chunk_bytes, 4096) : (32ull << 20);
     const fh_params fp = to_fh(sp_dev, env_max_launch_value(), stage);
     const uint32_t K = sp.kmer_length;
     if (K < 1 || K > 64) return hfail(FH_ERR_UNSUPPORTED, "kmer_length %u", K);
@@ -2606,6 +2610,13 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
         W[d]->h = fh_new(&fp, devs[d]);
         if (!W[d]->h) return hfail(FH_ERR_NO_DEVICE, "%s", fh_last_error());
         if (int rc = fh_reset(W[d]->h)) return hfail(rc, "%s", fh_last_error());
+    }
+    { // (the handles' staging buffers may be smaller than asked for -- the FH_STAGE_BYTES test knob: cut chunks that fit)
+        uint8_t *raw2[2] = {nullptr, nullptr};
+        uint64_t cap = 0;
+        int next = 0;
+        if (int rc = fh_text_buffers(W[0]->h, raw2, &cap, &next)) return hfail(rc, "%s", fh_last_error());
+        stage = std::min(stage, cap);
     }
     // chunk buffers circulate between the reader and the workers
     std::mutex free_mu;
@@ -2639,7 +2650,8 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
                 uint8_t *dst = nullptr;
                 uint64_t cap = 0;
                 int rc = fh_text_buffer(w->h, &dst, &cap);
-                if (rc == FH_OK && job.len > cap) rc = FH_ERR_INVALID;
+                const bool too_long = rc == FH_OK && job.len > cap;
+                if (too_long) rc = FH_ERR_INVALID;
                 if (rc == FH_OK) {
                     memcpy(dst, job.buf->data(), job.len);
                     rc = fh_set_stream_offset(w->h, job.text_off);
@@ -2651,7 +2663,7 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
                 }
                 if (rc != FH_OK) {
                     w->rc = rc;
-                    w->msg = fh_last_error();
+                    w->msg = too_long ? "chunk longer than the staging buffer" : fh_last_error();
                     abort = true;
                 }
             }
@@ -2686,9 +2698,15 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
         send(d, stop);
     }
     for (auto &w : W) w->th.join();
-    if (rrc != FH_OK) return rrc;
+    if (rrc != FH_OK) {
+        *device_rejected = fastq && rrc == FH_ERR_INVALID;
+        return rrc;
+    }
     for (auto &w : W)
-        if (w->rc != FH_OK) return hfail(w->rc, "%s", w->msg.c_str());
+        if (w->rc != FH_OK) {
+            *device_rejected = fastq && w->rc == FH_ERR_INVALID;
+            return hfail(w->rc, "%s", w->msg.c_str());
+        }
     // ---- partial sketches -> one ----
     uint64_t text_bases = 0;
     for (size_t d = 0; d < n_w; ++d) {
@@ -3028,8 +3046,20 @@ int finch_sketch_file_sharded(const char *filename, const finch_sketch_params *s
     const unsigned read_threads = read_threads_total(rt_env);
     auto res = std::make_unique<finch_sketches>();
     res->v.resize(1);
-    const int rc = sketch_stream_sharded(std::make_unique<FileSource>(f, f != stdin, read_threads), fn, *sp, *filters, devs, chunk_bytes,
-                                         res->v[0]);
+    bool rejected = false;
+    int rc = sketch_stream_sharded(std::make_unique<FileSource>(f, f != stdin, read_threads), fn, *sp, *filters, devs, chunk_bytes,
+                                   res->v[0], &rejected);
+    if (rc != FH_OK && rejected && f != stdin) {
+        // FASTQ the device-side splitter does not take (blank lines between records, ...): one handle, host parser
+        FILE *f2 = fopen(fn.c_str(), "rb");
+        if (!f2) return hfail(FH_ERR_INVALID, "%s: %s (os error %d)", fn.c_str(), strerror(errno), errno);
+        HandleSet handles;
+        handles.full = to_fh(*sp, env_max_launch());
+        handles.final_size = sp->final_size;
+        handles.device = devs[0];
+        res->v[0] = Sketch();
+        rc = sketch_stream(std::make_unique<FileSource>(f2, true, read_threads), fn, *sp, *filters, handles, res->v[0]);
+    }
     if (rc != FH_OK) return rc;
     *out = res.release();
     return FH_OK;
@@ -3043,8 +3073,17 @@ int finch_sketch_buffer_sharded(const uint8_t *data, uint64_t len, const char *n
     if (int rc = sharded_devices(devices, n_devices, devs)) return rc;
     auto res = std::make_unique<finch_sketches>();
     res->v.resize(1);
-    const int rc = sketch_stream_sharded(std::make_unique<MemSource>(data, (size_t)len), name ? name : "", *sp, *filters, devs,
-                                         chunk_bytes, res->v[0]);
+    bool rejected = false;
+    int rc = sketch_stream_sharded(std::make_unique<MemSource>(data, (size_t)len), name ? name : "", *sp, *filters, devs, chunk_bytes,
+                                   res->v[0], &rejected);
+    if (rc != FH_OK && rejected) { // (see finch_sketch_file_sharded)
+        HandleSet handles;
+        handles.full = to_fh(*sp, env_max_launch());
+        handles.final_size = sp->final_size;
+        handles.device = devs[0];
+        res->v[0] = Sketch();
+        rc = sketch_stream(std::make_unique<MemSource>(data, (size_t)len), name ? name : "", *sp, *filters, handles, res->v[0]);
+    }
     if (rc != FH_OK) return rc;
     *out = res.release();
     return FH_OK;

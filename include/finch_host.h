@@ -73,8 +73,9 @@ int finch_sketch_buffer(const uint8_t *data, uint64_t len, const char *name, con
  * repeat: several handles on one GPU); every handle splits and sketches its chunks on its device at the chunks' own
  * stream offsets, FASTA records that span a cut hand their last k-1 bases over as a halo; the partial sketches are
  * merged on the host (fh_merge), then filters / post filter as in sketch_stream.  The result is the Sketch
- * finch_sketch_files returns for the same file.  FASTQ must be plain 4-line FASTQ (anything else: FH_ERR_INVALID;
- * use finch_sketch_files, whose host parser is the judge of what needletail accepts). */
+ * finch_sketch_files returns for the same file.  FASTQ the device-side splitter refuses (not plain 4-line FASTQ: blank
+ * lines between records, a record longer than a chunk, ...) is read again through ONE handle and the host parser, which is
+ * the judge of what needletail accepts (stdin, which cannot be read twice: FH_ERR_INVALID). */
 int finch_sketch_file_sharded(const char *filename, const finch_sketch_params *sketch_params, const finch_filter_params *filters,
                               const int *devices, uint32_t n_devices, uint64_t chunk_bytes, finch_sketches **out);
 int finch_sketch_buffer_sharded(const uint8_t *data, uint64_t len, const char *name, const finch_sketch_params *sketch_params,

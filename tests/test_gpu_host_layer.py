@@ -589,9 +589,20 @@ def test_one_input_across_several_device_handles(tmp_path):
     res = H.sketch_stream_sharded(fa, "mem", SketchParams.scaled(100, 21, 0.01, 0), H.FilterParams(None), [0, 0, 0], 8192)
     o, _ = oracle_sketch(fa, O.SCALED, 100, 21, 0, 0.01)
     same(res.sketch(0), o)
-    # not 4-line FASTQ: loud error (finch_sketch_files is the path with the host parser behind it)
+    # FASTQ the device-side splitter does not take but needletail does (blank lines between records): the file goes
+    # through one handle and the host parser, as it does in finch_sketch_files; what no parser takes is an error
+    odd = tmp_path / "odd.fastq"
+    odd.write_bytes(b"".join(b"@r%d\n" % i + g[i * 90:i * 90 + 120] + b"\n+\n" + b"I" * 120 + b"\n\n" for i in range(300)))
+    pp = SketchParams.mash(100, 100, True, 21, 0)
+    ref = H.sketch_files([str(odd)], pp, H.FilterParams(False)).sketch(0)
+    for devs, chunk in (([0, 0], 4096), ([0, 0, 0], 0)):
+        sk = H.sketch_file_sharded(str(odd), pp, H.FilterParams(False), devs, chunk).sketch(0)
+        assert np.array_equal(sk.arrays[0], ref.arrays[0]) and np.array_equal(sk.arrays[1], ref.arrays[1])
+        assert (sk.seq_length, sk.num_valid_kmers) == (ref.seq_length, ref.num_valid_kmers) and ref.seq_length == 300 * 120
+    sk = H.sketch_stream_sharded(odd.read_bytes(), "mem", pp, H.FilterParams(False), [0, 0], 4096).sketch(0)
+    assert np.array_equal(sk.arrays[0], ref.arrays[0])
     bad = tmp_path / "bad.fastq"
-    bad.write_bytes(b"@r1\nACGT\n+\nIIII\n\n@r2\nACGT\n+\nIIII\n" * 100)
+    bad.write_bytes(b"@r1\nACGT\n+\nIII\n@r2\nACGT\n+\nIIII\n" * 100)
     with pytest.raises(FinchError, match="FASTQ"):
         H.sketch_file_sharded(str(bad), SketchParams.mash(10, 10, True, 21, 0), H.FilterParams(False), [0, 0], 4096)
     with pytest.raises(FinchError, match="No such file"):

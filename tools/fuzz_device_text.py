@@ -7,7 +7,9 @@ what the host parser alone gives -- the same sketch or an error -- and, where th
 oracle's sketch.
 FUZZ_FILES=1: every text is also written as a plain file, a gzip file and a bgzip-style BGZF file and sketched through
 sketch_files (device-side splitting, the inflate sources, BGZF members inflated on the device for FASTQ): each must give what
-the text gave -- the same sketch, or an error."""
+the text gave -- the same sketch, or an error.
+FUZZ_SHARDED=1: every text also through sketch_stream_sharded over three handles on device 0 with chunks of 16-40 KB
+(one input across several devices: record-aligned chunks dealt round-robin, the k-1 base halo across FASTA cuts)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -57,6 +59,25 @@ def bgzf(data, block=65280):
         d = co.compress(ch) + co.flush()
         out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(d) + 25) + d + struct.pack("<II", zlib.crc32(ch), len(ch)))
     return b"".join(out)
+
+
+SHARDED = os.environ.get("FUZZ_SHARDED") is not None
+n_sharded = 0
+
+
+def check_sharded(ref, data, p, case, rng):
+    global n_sharded
+    os.environ.pop("FINCH_DEVICE_PARSE", None)
+    for chunk in (int(rng.integers(16000, 40000)), 0):  # (a FASTQ record -- up to 6 KB here -- has to fit a chunk)
+        try:
+            r = H.sketch_stream_sharded(data, "x", p, H.FilterParams(False), [0, 0, 0], chunk).sketch(0)
+            err = None
+        except Exception as e:  # noqa
+            r, err = None, str(e)
+        assert (r is None) == (ref is None), (case, chunk, "sharded refused: %s" % err if r is None else "sharded accepted")
+        if r is not None:
+            assert same(r, ref), (case, chunk)
+        n_sharded += 1
 
 
 def check_files(ref, data, p, case):
@@ -109,6 +130,8 @@ for case in range(n_cases):
             n_or += vs_oracle(b, data, p)
         if FILES:
             check_files(a, data, p, case)
+        if SHARDED:
+            check_sharded(a, data, p, case, rng)
         n_fa += 1
     else:
         eol = [b"\n", b"\r\n"][int(rng.integers(0, 2))]
@@ -140,6 +163,8 @@ for case in range(n_cases):
             n_fq_err += 1
         if FILES:
             check_files(a, data, p, case)
+        if SHARDED:
+            check_sharded(a, data, p, case, rng)
         n_fq += 1
-print("fuzz_device_text: %d FASTA texts, %d FASTQ texts (%d refused by both parsers), %d also checked against the oracle, %d files: all agree"
-      % (n_fa, n_fq, n_fq_err, n_or, n_files))
+print("fuzz_device_text: %d FASTA texts, %d FASTQ texts (%d refused by both parsers), %d also checked against the oracle, %d files, %d sharded runs: all agree"
+      % (n_fa, n_fq, n_fq_err, n_or, n_files, n_sharded))
