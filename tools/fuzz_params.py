@@ -3,12 +3,14 @@
 host parser (FINCH_DEVICE_PARSE=0), device-side splitting (default), the full-size sketcher instead of the small one
 (FINCH_NO_SMALL_SKETCHER=1), three handles on one device (sketch_stream_sharded), a gzip and a BGZF file through
 sketch_files -- all must give the same Sketch (hashes, k-mers, counts, totals, filter parameters) or the same refusal
-(strict mode with too few k-mers).  The routes share the filters and the post filter; what differs is who parses, how the
+(strict mode with too few k-mers); with filtering off the Sketch is also held against the oracle's sketcher (first
+final_size entries of its kmers_to_sketch).  The routes share the filters and the post filter; what differs is who parses, how the
 text is cut, which sketcher size runs and whether partial sketches are merged -- none of which may show."""
 import gzip, os, struct, sys, zlib
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from finch_rs_amd import host as H, sketch_schemes as S
+from oracle import oracle as O
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
@@ -33,7 +35,7 @@ def result(fn):
         return ("err", m[m.index("had too few"):] if "had too few" in m else m)  # (the message starts with the sketch's name)
 
 
-n_err = 0
+n_err = n_oracle = 0
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
     k = int(rng.choice([4, 11, 16, 21, 24, 31, 32, 33, 47, 64]))
@@ -77,5 +79,15 @@ for case in range(n_cases):
         finally:
             os.remove(path)
         assert r == ref, (case, ext, r[0], ref[0], r[1:] if r[0] == "err" else "", ref[1:] if ref[0] == "err" else "")
+    filtering = fastq if fo is None else fo
+    if ref[0] == "ok" and not filtering:
+        o = O.OracleSketcher(O.SCALED if p.kind == "scaled" else O.MASH, p.kmers_to_sketch, k, seed, p.scale if p.kind == "scaled" else 0.001)
+        assert o.sketch_stream(data) > 0
+        okc, okm = o.to_vec()
+        if p.kind != "scaled":
+            okc, okm = okc[:p.final_size], okm[:p.final_size]
+        assert ref[1] == okc.tobytes() and ref[2] == okm.tobytes(), (case, "oracle", len(ref[1]), okc.nbytes)
+        assert (ref[3], ref[4]) == o.total_bases_and_kmers(), (case, "oracle totals")
+        n_oracle += 1
     n_err += ref[0] == "err"
-print("fuzz_params: %d parameter sets x 6 routes agree (%d of them refusals)" % (n_cases, n_err))
+print("fuzz_params: %d parameter sets x 6 routes agree (%d of them refusals), %d also equal to the oracle's sketch" % (n_cases, n_err, n_oracle))
