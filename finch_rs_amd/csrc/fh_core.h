@@ -285,6 +285,23 @@ struct Windows {
         const u64 r = field(nC, 2 * j);
         return (K % 2 == 0) ? (r & ~((1ULL << PRE) - 1ULL)) : r;
     }
+    // Move the lane's view R positions on (R = 8 or 16): afterwards window j of this object is what window j + R was.  The
+    // kernels of K >= 25 run 32 / R rounds of R unrolled positions, so the bit-field offsets stay compile-time constants
+    // while only R positions' worth of lookups and hash states are in flight (register budget: fh_k2.hip).  nC moves down 2R
+    // bits, D up 2R bits; window j reads bits below 128 - 2j of D and nothing a later window needs leaves at the top.
+    template <int R>
+    FH_HDM void advance() {
+        static_assert(R == 8 || R == 16, "rounds of 8 or 16 positions");
+        if (R == 16) {
+            nC[0] = nC[1], nC[1] = nC[2], nC[2] = nC[3], nC[3] = nC[4], nC[4] = 0;
+            D[3] = D[2], D[2] = D[1], D[1] = D[0], D[0] = 0;
+        } else {
+            for (int i = 0; i < 4; ++i) nC[i] = alignbit_b32(nC[i + 1], nC[i], 16);
+            nC[4] >>= 16;
+            for (int i = 3; i > 0; --i) D[i] = alignbit_b32(D[i], D[i - 1], 16);
+            D[0] <<= 16;
+        }
+    }
     // the canonical m-form word << PRE
     FH_HDM u64 canonical(int j, bool &is_rc) const {
         const u64 f = fwd(j), r = rc(j);

@@ -52,6 +52,14 @@ constexpr int UNROLL_J = FH_UNROLL;
 #define FH_MINW_SMALL 4
 #endif
 constexpr int k2_min_waves(int K) { return K <= 21 ? FH_MINW_SMALL : FH_MINW_BIG; }
+// positions per unrolled round of the lane's 32 (see the loop): 32 = one pass
+#ifndef FH_ROUND_BIG
+#define FH_ROUND_BIG 8
+#endif
+#ifndef FH_ROUND_FROM
+#define FH_ROUND_FROM 25
+#endif
+constexpr int k2_round(int K) { return K >= FH_ROUND_FROM ? FH_ROUND_BIG : 32; }
 template <int K, bool MASKED, bool SEED0, bool HASLO>
 __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchArgs a) {
     // murmur3 lookup tables with the second stage folded in (fh_core.h): A / B records of two-group key words,
@@ -169,20 +177,26 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
         Windows<K> win;
         win.init(clo, chi);
 
-        // software pipeline: the table lookups of position j+1 are issued before the dependent multiply chain of
-        // position j runs, so their LDS latency is hidden inside the wave
+        // The lane's 32 positions in rounds of R (k2_round: 32 = one fully unrolled pass for K <= 24; 8 for the register-hungry
+        // K >= 25, with the two strings moved on between rounds so that every bit-field offset stays a compile-time constant).
+        // software pipeline: the table lookups of position u+1 are issued before the dependent multiply chain of
+        // position u runs, so their LDS latency is hidden inside the wave
+        constexpr int R = k2_round(K);
+        u32 Wc = W; // valid bits of the current round in its low R bits
+#pragma unroll 1
+        for (int c = 0; c < LANE_POS / R; ++c) {
         auto window = [&](int j, u64 &cm, bool &is_rc) { cm = win.canonical(j, is_rc); };
         u64 cm_cur;
         bool rc_cur;
         KeyWords<K> kw_cur;
         window(0, cm_cur, rc_cur);
         murmur_lookup<K>(cm_cur, LT, kw_cur);
-#pragma unroll(UNROLL_J)
-        for (int j = 0; j < LANE_POS; ++j) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
             u64 cm_nxt = 0;
             bool rc_nxt = false;
             KeyWords<K> kw_nxt;
-            if (j + 1 < LANE_POS) {
+            if (j + 1 < R) {
                 window(j + 1, cm_nxt, rc_nxt);
                 murmur_lookup<K>(cm_nxt, LT, kw_nxt);
             }
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
             if (__builtin_expect(__any(cand), 0)) { // wave-uniform branch
                 u64 h = parts_hash(hp);
                 if (MASKED) h &= a.hash_mask; // test hook only
-                const bool take = (h <= tau) && ((W >> j) & 1u) && (!HASLO || h > a.tau_lo);
+                const bool take = (h <= tau) && ((Wc >> j) & 1u) && (!HASLO || h > a.tau_lo);
                 const u64 mask = __ballot(take);
                 const u32 cnt = (u32)__popcll(mask);
                 if (cnt) {
@@ -211,17 +225,22 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
                         // rather than a 64-bit per-lane value kept alive -- i.e. spilled -- across the loop
                         u32 lane_here; // (volatile: or the compiler hoists it out of the loop and spills it after all)
                         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_here));
-                        const u64 pos = tile_stream_pos + (u64)(lane_here * (u32)LANE_POS + (u32)j);
+                        const u64 pos = tile_stream_pos + (u64)(lane_here * (u32)LANE_POS + (u32)(c * R + j));
                         queue->p[my] = pos | ((u64)(is_rc ? 1u : 0u) << 63);
                     }
                     qn += cnt;
                 }
             }
-            if (j + 1 < LANE_POS) {
+            if (j + 1 < R) {
                 cm_cur = cm_nxt;
                 rc_cur = rc_nxt;
                 kw_cur = kw_nxt;
             }
+        }
+        if (R < LANE_POS) {
+            win.template advance<(R < LANE_POS ? R : 8)>();
+            Wc >>= (R & 31);
+        }
         }
         __builtin_amdgcn_wave_barrier();
         if (qn >= (u32)(QCAP / 2) || (qn && t + 1 == rt1)) { // drain when half full or at the end of the pulled range
@@ -278,8 +297,12 @@ static hipError_t launch_k2_t(const SketchArgs &a, int blocks, hipStream_t st) {
     return hipGetLastError();
 }
 
+#ifdef FH_ONLY_K // development builds: one K per translation unit (tools/k2_regs.py)
+constexpr int PART_LO = FH_ONLY_K, PART_HI = FH_ONLY_K;
+#else
 constexpr int PART_LO = FH_PART * (32 / FH_NPARTS) + 1;
 constexpr int PART_HI = (FH_PART + 1) * (32 / FH_NPARTS);
+#endif
 
 template <int K>
 static hipError_t launch_k2_dispatch(int k, const SketchArgs &a, int blocks, hipStream_t st) {

@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/config_fingerprints.json: the fingerprint of the sketch the REFERENCE ALGORITHM gives for
+BASELINE.json's configurations, computed on the CPU from the oracle alone (no GPU, no libfinch_hip kernel).
+
+    python tests/golden/make_config_fingerprints.py [--only c2_k21_n1000,...] [--procs P]
+
+How: the synthetic read set of SURVEY.md 8d M4 (host generator, seed 20250620) is cut into contiguous read blocks; every block is
+sketched by the oracle (oracle/finch_oracle.c = mash.rs:34-63 restated) in its own process; the block sketches are merged with the
+size-independent property of SURVEY 8e (global bottom-n = bottom-n of the union, counts summed, the k-mer of the first block in
+stream order) in numpy -- the merge of tests/test_gpu_full_size.py, not the product's.  bench.py prints the same seven numbers
+for the sketch the GPUs produced ("sketch_check") and exits non-zero if they differ from this file.
+
+The fingerprint: n_hashes, min_hash, max_hash, hash_xor (xor of all hashes), count_sum, extra_sum, kmer_byte_sum (sum of all
+k-mer bytes) -- together with total_kmers (mash.rs:35).  50 Gbase takes ~5 minutes on 8 cores.
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED, GL, RL, SUB_PPM, N_PPM = 20250620, 5_000_000, 150, 10_000, 500
+
+CONFIGS = {
+    # name: (gbases, k, n)
+    "c2_k21_n1000": (10.0, 21, 1000),   # BASELINE configs[1]
+    "c4_k21_n1000": (50.0, 21, 1000),   # BASELINE configs[3]
+    "c2_k31_n1000": (10.0, 31, 1000),   # configs[1]'s stream at k = 31 (bench.py extras)
+}
+
+_G = {}
+
+
+def _shard(job):
+    from finch_rs_amd import sketch_schemes as S
+    from oracle import oracle as O
+    first, count, k, n = job
+    o = O.OracleSketcher(O.MASH, n, k, 0)
+    step = 200_000  # reads per generated piece: keeps a worker's footprint at ~30 MB
+    for f in range(first, first + count, step):
+        c = min(step, first + count - f)
+        o.process_packed(S.synth_reads_host(_G["genome"], f, c, RL, SEED, SUB_PPM, N_PPM), 0)
+    kc, km = o.to_vec()
+    return kc, km, o.total_bases_and_kmers()[1]
+
+
+def merge_numpy(parts, n):
+    kc = np.concatenate([p[0] for p in parts])
+    km = np.concatenate([p[1] for p in parts])
+    order = np.argsort(kc["hash"], kind="stable")  # stable: block order == stream order within equal hashes
+    kc, km = kc[order], km[order]
+    uniq, start = np.unique(kc["hash"], return_index=True)
+    counts = np.add.reduceat(kc["count"].astype(np.uint64), start)
+    extra = np.add.reduceat(kc["extra_count"].astype(np.uint64), start)
+    out = np.zeros(len(uniq), dtype=kc.dtype)
+    out["hash"] = uniq
+    out["count"] = np.minimum(counts, 2**32 - 1)
+    out["extra_count"] = np.minimum(extra, 2**32 - 1)
+    return out[:n], km[start][:n], sum(p[2] for p in parts)
+
+
+def fingerprint(kc, km, total_kmers=None):
+    fp = {"n_hashes": int(len(kc)), "min_hash": int(kc["hash"][0]) if len(kc) else None,
+          "max_hash": int(kc["hash"][-1]) if len(kc) else None,
+          "hash_xor": int(np.bitwise_xor.reduce(kc["hash"])) if len(kc) else 0,
+          "count_sum": int(kc["count"].astype(np.uint64).sum()),
+          "extra_sum": int(kc["extra_count"].astype(np.uint64).sum()),
+          "kmer_byte_sum": int(np.asarray(km).astype(np.uint64).sum())}
+    if total_kmers is not None:
+        fp["total_kmers"] = int(total_kmers)
+    return fp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--procs", type=int, default=len(os.sched_getaffinity(0)))
+    ap.add_argument("--out", default=os.path.join(HERE, "config_fingerprints.json"))
+    args = ap.parse_args()
+    from finch_rs_amd import sketch_schemes as S
+    _G["genome"] = S.synth_genome_host(GL, SEED)
+    names = args.only.split(",") if args.only else list(CONFIGS)
+    try:
+        out = json.load(open(args.out))
+    except Exception:
+        out = {}
+    out["_generator"] = ("tests/golden/make_config_fingerprints.py: host read generator (seed %d, genome %d, %d bp, sub %d ppm, "
+                         "N %d ppm) -> oracle per read block -> numpy merge" % (SEED, GL, RL, SUB_PPM, N_PPM))
+    with mp.get_context("fork").Pool(args.procs) as pool:
+        for name in names:
+            gb, k, n = CONFIGS[name]
+            reads = int(np.ceil(gb * 1e9 / RL))
+            blocks = args.procs * 8
+            b = np.linspace(0, reads, blocks + 1).astype(np.int64)
+            t0 = time.time()
+            parts = pool.map(_shard, [(int(b[i]), int(b[i + 1] - b[i]), k, n) for i in range(blocks)], chunksize=1)
+            kc, km, tk = merge_numpy(parts, n)
+            fp = fingerprint(kc, km, tk)
+            fp.update({"gbases": gb, "reads": reads, "k": k, "n": n, "read_blocks": blocks})
+            out[name] = fp
+            print("%s: %.0f s %s" % (name, time.time() - t0, json.dumps(fp)), flush=True)
+            json.dump(out, open(args.out, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
