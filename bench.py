@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- bases/sec sketched (k=21, n=1000) on N x MI355X, with the kernel's HBM roofline
-fraction and the CPU baseline timed beside it (BASELINE.json metric).
+"""bench.py -- bases/sec sketched (k=21, n=1000) on N x MI355X, with the kernel's HBM roofline fraction, the CPU baseline
+timed beside it and a self-check of the sketch against the oracle's golden fingerprint (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4] [--gbases G]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2|c5] [--gbases G]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
 
-Workloads (synthetic 150 bp FASTQ-shaped read sets, SURVEY.md 8d M4, already resident in HBM as the packed
-sequence stream -- 150 bases + 1 breaker byte per read -- when the timed region starts; Mash sketch k=21,
-kmers_to_sketch=1000, seed 0):
-  c2  BASELINE.json configs[1]: 10 Gbase on one GPU.  The default for N = 1 (the configuration the metric is quoted on).
-      With N > 1 every rank gets its own 10 Gbase (weak scaling).
-  c4  BASELINE.json configs[3]: 50 Gbase IN TOTAL, the reads split into N contiguous read blocks (shard_bounds), one
-      per GPU, partial sketches merged on the host of rank 0 -- strong scaling.  The default for N > 1.
-A step = one full pass: reset, sketch every base of the rank's read block, finish (bottom-n select, copy-out of the
-<= 1000 records to the host) and -- for N > 1 -- the host-side merge of the partial sketches on rank 0 (no data-path
-collective; read blocks are independent).  value = total bases of all ranks * K / max-over-ranks time.
+How the N GPUs are driven.  Launched by torch.distributed.run (WORLD_SIZE in the environment): one process per GPU, rank r
+sketches read block r, rank 0 gathers the <= n-record partial sketches and merges them on the host.  Launched plainly with
+--gpus N > 1: ONE process, one host thread and one sketcher handle per device (the reference's own shape -- finch is one
+process, lib.rs:34-36 -- and SURVEY section 7 step 5), the main thread merging the partial sketches.  Either way there is no
+data-path collective: read blocks are independent and the merge is O(N n).
 
-After the timed region rank 0 of an N = 1 run also measures, OUTSIDE `value` (key "extras"): the same stream at k=31,
-BASELINE's configs[2] sketch (k=31, 2 M hashes, host filters), the CLI-default oversketch (n=200 000), configs[3] on one
-GPU (50 Gbase), the end-to-end rate from FASTQ text in host memory and a batch of FASTA files through
-finch_sketch_files (configs[4]'s shape on one GPU).  --no-extras skips them.
+Workloads (synthetic 150 bp FASTQ-shaped read sets of SURVEY.md 8d M4, already resident in HBM as the packed sequence stream
+-- 150 bases + 1 breaker byte per read -- when the timed region starts; Mash sketch k=21, kmers_to_sketch=1000, seed 0):
+  c4  BASELINE.json configs[3], the default for EVERY N: 50 Gbase IN TOTAL, the reads split into N contiguous read blocks
+      (shard_bounds), one per GPU, partial sketches merged on the host -- strong scaling; at N = 1 the whole 50.3 GB stream
+      sits on the one GPU.  This is the workload north_star's 1/2/4/8-GPU target is stated on.
+  c2  BASELINE.json configs[1]: 10 Gbase per GPU (weak scaling when N > 1).
+  c5  BASELINE.json configs[4]: a batch of synthetic RefSeq-sized FASTA files (log-uniform 1-10 Mb, 70-column lines) in
+      tmpfs through ONE finch_sketch_files call with devices = [0..N-1] (lib.rs:29-49); --files F (default 10000, cut to what
+      the tmpfs holds and said so).  Under torch.distributed.run rank r takes files r, r+N, ...
+A step = one full pass: reset, sketch every base of the block, finish (bottom-n select, copy-out of the <= 1000 records to
+the host) and -- for N > 1 -- the host-side merge.  value = total bases of all GPUs * K / max-over-ranks time.
+
+Self-check: the seven-number fingerprint of the final sketch (+ total_kmers) is compared with
+tests/golden/config_fingerprints.json, which the ORACLE produced on the CPU (tests/golden/make_config_fingerprints.py);
+"sketch_check.matches_golden" is true / false / null (no golden for a non-default size), and the exit code is 3 when false.
+
+After the timed region an N = 1 run also measures, OUTSIDE `value` (key "extras"): configs[1] (the first 10 Gbase of the same
+stream), k=31, configs[2] (k=31, 2 M hashes, host filters), the CLI-default oversketch (n=200 000), a two-word k-mer length,
+the end-to-end rate from FASTQ text in host memory, compressed input and a batch of FASTA files.  --no-extras skips them.
 """
 import argparse
 import json
@@ -37,8 +47,10 @@ if ROOT not in sys.path:
 SEED = 20250620
 GENOME_LEN = 5_000_000
 READ_LEN = 150
+REC = READ_LEN + 1
 SUB_PPM, N_PPM = 10_000, 500
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+C5_SAMPLE = 256        # files 0..255 of the batch carry a golden fingerprint
 
 
 _SHARED = {}  # inherited by fork()ed workers: no pickling of the sample
@@ -72,30 +84,14 @@ def _oracle_shard_job(job):
     return len(o.to_vec()[0])
 
 
-def _splitmix64(x):
-    x = (x + 0x9E3779B97F4A7C15) & (2**64 - 1)
-    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
-    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
-    return x ^ (x >> 31)
-
-
 def _write_fasta_job(job):
     """one synthetic genome as a 70-column FASTA file (log-uniform 1..10 Mb from the per-file seed)"""
     from finch_rs_amd import sketch_schemes as S
     d, i = job
-    u = (_splitmix64(SEED + 7919 * i) >> 11) / float(1 << 53)
-    L = int(1e6 * 10.0 ** u)
-    g = S.synth_genome_host(L, SEED + 1000003 * (i + 1))
-    rows = (L + 69) // 70
-    a = np.full((rows, 71), 10, np.uint8)
-    gp = np.zeros(rows * 70, np.uint8)
-    gp[:L] = g
-    a[:, :70] = gp.reshape(rows, 70)
     path = os.path.join(d, "g%05d.fa" % i)
     with open(path, "wb") as f:
-        f.write(b">genome_%05d len=%d\n" % (i, L))
-        f.write(a.reshape(-1)[:(rows - 1) * 71 + L - (rows - 1) * 70].tobytes() + b"\n")
-    return path, L
+        f.write(S.synth_fasta_file(i, SEED))
+    return path, S.synth_fasta_length(i, SEED)
 
 
 def _pmc_derived(key):
@@ -107,13 +103,68 @@ def _pmc_derived(key):
         return None
 
 
+def _golden(key):
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "config_fingerprints.json"))).get(key)
+    except Exception:
+        return None
+
+
+FP_KEYS = ("n_hashes", "min_hash", "max_hash", "hash_xor", "count_sum", "extra_sum", "kmer_byte_sum", "total_kmers")
+
+
+def fingerprint(kc, km, total_kmers):
+    return {"n_hashes": int(len(kc)), "min_hash": int(kc["hash"][0]) if len(kc) else None,
+            "max_hash": int(kc["hash"][-1]) if len(kc) else None,
+            "hash_xor": int(np.bitwise_xor.reduce(kc["hash"])) if len(kc) else 0,
+            "count_sum": int(kc["count"].astype(np.uint64).sum()),
+            "extra_sum": int(kc["extra_count"].astype(np.uint64).sum()),
+            "kmer_byte_sum": int(np.asarray(km).astype(np.uint64).sum()),
+            "total_kmers": int(total_kmers)}
+
+
+def check_golden(fp, key):
+    """-> (fingerprint + matches_golden, ok) ; matches_golden is None when the golden file has no entry for this workload"""
+    g = _golden(key)
+    out = dict(fp)
+    out["golden"] = ("tests/golden/config_fingerprints.json[%s] (oracle, CPU)" % key) if g else None
+    out["matches_golden"] = None if g is None else all(fp[k] == g[k] for k in FP_KEYS)
+    return out, out["matches_golden"] is not False
+
+
+class Shard:
+    """one device's read block: resident synthetic input + a sketcher handle"""
+
+    def __init__(self, F, S, device, first_read, n_reads, params, max_launch, profiling):
+        self.device, self.first_read, self.n_reads = device, first_read, n_reads
+        self.nbytes = n_reads * REC
+        self.dg = F.DeviceBuffer(GENOME_LEN, device=device)
+        self.dr = F.DeviceBuffer(self.nbytes + 64, device=device)
+        S.synth_genome_device(self.dg, GENOME_LEN, SEED)
+        S.synth_reads_device(self.dr, self.dg, GENOME_LEN, first_read, n_reads, READ_LEN, SEED, SUB_PPM, N_PPM)
+        self.sk = params.create_sketcher(device=device, max_launch=max_launch)
+        if profiling:
+            self.sk.set_profiling(True)
+
+    def step(self):
+        sk = self.sk
+        sk.reset()
+        sk.set_stream_offset(self.first_read * REC)
+        sk.push_device(self.dr.ptr, self.nbytes)
+        kc, km, pos = sk.to_arrays()
+        return kc, km, pos, sk.finish()[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["c2", "c4"], default=None, help="default: c2 for --gpus 1, c4 otherwise")
+    ap.add_argument("--workload", choices=["c2", "c4", "c5"], default="c4",
+                    help="c4 (default, every N): BASELINE configs[3], 50 Gbase in total; c2: configs[1], 10 Gbase per GPU; "
+                         "c5: configs[4], batch of FASTA files through finch_sketch_files")
     ap.add_argument("--gbases", type=float, default=None, help="c2: Gbases per GPU (default 10); c4: Gbases in total (default 50)")
+    ap.add_argument("--files", type=int, default=10000, help="c5: number of FASTA files")
     ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--n", type=int, default=1000)
     ap.add_argument("--cpu-sample-mbases", type=float, default=450.0)
@@ -123,22 +174,22 @@ def main():
                     help="Mbases per process for the extra all-cores CPU figure (0 = skip)")
     ap.add_argument("--max-launch", type=int, default=0)
     ap.add_argument("--backend", default="gloo",
-                    help="torch.distributed backend for N>1.  The data path has no collective (read blocks are "
-                         "independent; SURVEY 8e): the only traffic is the control-plane gather of one <= 40 KB partial "
-                         "sketch per rank plus the timing reduction, which gloo carries as CPU tensors.  'nccl' (= RCCL) "
+                    help="torch.distributed backend when launched by torch.distributed.run.  The data path has no collective "
+                         "(read blocks are independent; SURVEY 8e): the only traffic is the control-plane gather of one <= 40 KB "
+                         "partial sketch per rank plus the timing reduction, which gloo carries as CPU tensors.  'nccl' (= RCCL) "
                          "moves the same gather onto the GPUs.")
     ap.add_argument("--share-gpu", action="store_true",
-                    help="debug: map every rank to cuda:0 (with --backend gloo) to exercise the N>1 flow on a 1-GPU box")
+                    help="debug: map every rank / thread to device 0 to exercise the N > 1 flow on a 1-GPU box")
     args = ap.parse_args()
 
+    launched = "WORLD_SIZE" in os.environ  # torch.distributed.run: one process per GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else args.gpus
+    if launched and world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    workload = args.workload or ("c2" if world == 1 else "c4")
+    threads_mode = not launched and world > 1
+    workload = args.workload
     gbases = args.gbases if args.gbases is not None else (10.0 if workload == "c2" else 50.0)
 
     import torch
@@ -148,11 +199,19 @@ def main():
 
     if not torch.cuda.is_available() or F.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: libfinch_hip has no CPU path")
+    if not args.share_gpu and not launched and F.device_count() < world:
+        raise SystemExit("--gpus %d but only %d device(s) visible" % (world, F.device_count()))
     if args.share_gpu:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    # devices this PROCESS drives
+    if threads_mode:
+        my_devices = [0 if args.share_gpu else d for d in range(world)]
+        my_ranks = list(range(world))
+    else:
+        my_devices, my_ranks = [local_rank], [rank]
+    torch.cuda.set_device(my_devices[0])
     dist = None
-    if world > 1:
+    if launched and world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "gloo" and os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
@@ -167,45 +226,46 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        for d in sorted(set(my_devices)):
+            torch.cuda.synchronize(d)
+
+    if workload == "c5":
+        return run_c5(args, F, S, dist, barrier, rank, world, my_devices, launched, gather_device)
 
     # ---- resident synthetic input (not timed) ----
-    rec = READ_LEN + 1
-    if workload == "c2":
-        n_reads = int(np.ceil(gbases * 1e9 / READ_LEN))  # per GPU
-        first_read = rank * n_reads
-        total_reads = world * n_reads
-    else:
-        total_reads = int(np.ceil(gbases * 1e9 / READ_LEN))  # in total: contiguous read blocks, one per rank
-        first_read, hi = SH.shard_bounds(total_reads, rank, world)
-        n_reads = hi - first_read
-    nbytes = n_reads * rec
-    dg = F.DeviceBuffer(GENOME_LEN, device=local_rank)
-    dr = F.DeviceBuffer(nbytes + 64, device=local_rank)
-    S.synth_genome_device(dg, GENOME_LEN, SEED)
-    S.synth_reads_device(dr, dg, GENOME_LEN, first_read, n_reads, READ_LEN, SEED, SUB_PPM, N_PPM)
-
     params = F.SketchParams.mash(args.n, args.n, True, args.k, 0)
-    sk = params.create_sketcher(device=local_rank, max_launch=args.max_launch)
-    sk.set_profiling(True)
+    if workload == "c2":
+        per = int(np.ceil(gbases * 1e9 / READ_LEN))  # per GPU
+        total_reads = world * per
+        bounds = {r: (r * per, (r + 1) * per) for r in my_ranks}
+    else:
+        total_reads = int(np.ceil(gbases * 1e9 / READ_LEN))  # in total: contiguous read blocks, one per GPU
+        bounds = {r: SH.shard_bounds(total_reads, r, world) for r in my_ranks}
+    shards = [Shard(F, S, d, bounds[r][0], bounds[r][1] - bounds[r][0], params, args.max_launch, profiling=(r == 0))
+              for r, d in zip(my_ranks, my_devices)]
+    pool = None
+    if threads_mode:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=world)  # ctypes releases the GIL inside every library call
 
     gathered = None
 
     def step():
         nonlocal gathered
-        sk.reset()
-        sk.set_stream_offset(first_read * rec)
-        sk.push_device(dr.ptr, nbytes)
-        kc, km, pos = sk.to_arrays()
-        tk = sk.finish()[1]
-        if dist is not None:
-            # partial sketches are <= n records: ship them to rank 0 (one small fixed-size tensor per rank)
-            # and merge on the host, O(N*n) -- finch_rs_amd/sharding.py
-            merged = SH.gather_and_merge(dist, params, (kc, km, pos, tk), args.n, device=gather_device)
-            if rank == 0:
-                gathered = merged[:3]
+        if threads_mode:
+            parts = list(pool.map(lambda s: s.step(), shards))  # returns when every device has its partial sketch on the host
+            bufs = [SH.pack_partial(kc, km, pos, tk, args.n, args.k) for (kc, km, pos, tk) in parts]
+            gathered = SH.merge_wire(params, bufs, args.n)
         else:
-            gathered = (kc, km, pos)
+            part = shards[0].step()
+            if dist is not None:
+                # partial sketches are <= n records: ship them to rank 0 (one small fixed-size tensor per rank)
+                # and merge on the host, O(N*n) -- finch_rs_amd/sharding.py
+                merged = SH.gather_and_merge(dist, params, part, args.n, device=gather_device)
+                if rank == 0:
+                    gathered = merged
+            else:
+                gathered = part
 
     for _ in range(args.warmup):
         step()
@@ -215,8 +275,9 @@ def main():
     kernel_ms, kernel_launches, kernel_pos = 0.0, 0, 0
     for _ in range(args.steps):
         step()
-        ms, nl, npos = sk.kernel_time()
-        kernel_ms += ms; kernel_launches += nl; kernel_pos += npos
+        if rank == 0:
+            ms, nl, npos = shards[0].sk.kernel_time()
+            kernel_ms += ms; kernel_launches += nl; kernel_pos += npos
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -227,12 +288,14 @@ def main():
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
-        return
+        return 0
 
+    n_reads = shards[0].n_reads
+    dr, dg = shards[0].dr, shards[0].dg
     value = total_reads * READ_LEN * args.steps / elapsed
     # dominant kernel: k2_sketch.  Algorithmic bytes = 1 byte per k-mer start position it covers
     # (= 151/150 B per base for 150 bp reads), measured with HIP events on the
-    # library's own stream around every launch (rank 0).
+    # library's own stream around every launch (rank 0 / device 0).
     achieved = (kernel_pos / 1e9) / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
@@ -243,23 +306,19 @@ def main():
                                     "not HBM -- see pmc"}
     # counter-derived figures come from the committed rocprofv3 PMC passes over exactly this command (profiles/README.md says
     # how each was collected); they are attached to the workload they were measured on and to no other
-    is_default = (workload, gbases, args.k, args.n, world) == ("c2", 10.0, 21, 1000, 1)
-    pmc = _pmc_derived("c2_k%d_n%d" % (args.k, args.n)) if (workload, gbases, world) == ("c2", 10.0, 1) else None
+    is_default = (workload, gbases, args.k, args.n, world) == ("c4", 50.0, 21, 1000, 1)
+    std_size = (workload, gbases) in (("c2", 10.0), ("c4", 50.0))
+    pmc = _pmc_derived("%s_k%d_n%d" % (workload, args.k, args.n)) if (std_size and world == 1) else None
     if pmc:
-        roofline["traffic"] = pmc.get("hbm_bytes_per_launch")
-        roofline["pmc"] = {k: pmc.get(k) for k in ("valu_per_wave_iter", "valu_busy", "cycles_per_wave_iter", "cycles_per_valu_inst",
+        # HBM bytes the counters saw per algorithmic byte, applied to this run's launch size
+        roofline["traffic"] = int(pmc["hbm_bytes_per_position"] * roofline["alg_bytes_per_launch"])
+        roofline["pmc"] = {k: pmc.get(k) for k in ("valu_per_wave_iter", "cycles_per_wave_iter", "cycles_per_valu_inst", "valu_issue_model",
                                                    "lds_active_per_wave_iter", "lds_bank_conflict_per_wave_iter",
                                                    "hbm_bytes_per_position", "source")}
-    elif is_default:
-        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        try:
-            roofline["traffic"] = json.load(open(prof)).get("k2_hbm_bytes_per_launch")
-        except Exception:
-            pass
 
     # measured streaming-read peak of this box next to the spec peak; not in the timed region
     try:
-        roofline["measured_stream_read_GBps"] = round(S.measure_read_bandwidth(dr, min(nbytes, 4 << 30) // 16 * 16), 1)
+        roofline["measured_stream_read_GBps"] = round(S.measure_read_bandwidth(dr, min(shards[0].nbytes, 4 << 30) // 16 * 16), 1)
     except Exception:
         roofline["measured_stream_read_GBps"] = None
 
@@ -269,7 +328,7 @@ def main():
         from oracle import oracle as O  # the checker, timed as the reported CPU baseline ("port")
         flags = O.use_native()  # compiled on this box with -march=native
         ns = min(n_reads, int(args.cpu_sample_mbases * 1e6 / READ_LEN))
-        sample = dr.download(ns * rec)
+        sample = dr.download(ns * REC)
         ora = O.OracleSketcher(O.MASH, args.n, args.k, 0)
         c0 = time.perf_counter()
         ora.process_packed(sample, 0)
@@ -285,12 +344,12 @@ def main():
             ncpu = max(1, min(_usable_cpus(), 256))
             per = min(n_reads // ncpu, int(args.cpu_allcores_mbases * 1e6 / READ_LEN), int(3e9 / READ_LEN) // ncpu)
             if per > 0:
-                _SHARED["big"] = dr.download(ncpu * per * rec)
-                jobs = [(i, per * rec, args.n, args.k) for i in range(ncpu)]
-                with mp.get_context("fork").Pool(ncpu) as pool:
-                    pool.map(_oracle_shard_job, [(0, 151 * 64, args.n, args.k)] * ncpu, chunksize=1)  # start the workers
+                _SHARED["big"] = dr.download(ncpu * per * REC)
+                jobs = [(i, per * REC, args.n, args.k) for i in range(ncpu)]
+                with mp.get_context("fork").Pool(ncpu) as p2:
+                    p2.map(_oracle_shard_job, [(0, 151 * 64, args.n, args.k)] * ncpu, chunksize=1)  # start the workers
                     c0 = time.perf_counter()
-                    pool.map(_oracle_shard_job, jobs, chunksize=1)
+                    p2.map(_oracle_shard_job, jobs, chunksize=1)
                     ct = time.perf_counter() - c0
                 _SHARED.clear()
                 cpu_all = {"value": round(ncpu * per * READ_LEN / ct, 1), "unit": "bases/s", "cores": ncpu, "kind": "port",
@@ -299,17 +358,24 @@ def main():
 
     extras = None
     if world == 1 and not args.no_extras and is_default:
-        extras = measure_extras(F, S, dr, dg, n_reads, nbytes, local_rank)
+        extras = measure_extras(F, S, dr, dg, min(n_reads, int(np.ceil(10e9 / READ_LEN))), my_devices[0])
 
+    drive = ("one process per GPU (torch.distributed.run, %s)" % args.backend if launched and world > 1 else
+             "one process, one host thread + handle per GPU" if threads_mode else "one process, one GPU")
     if workload == "c2":
         wl = ("%.1f Gbase synthetic 150 bp reads per GPU (%s), mash k=%d n=%d seed 0, input resident in HBM as packed stream"
-              % (gbases, "configs[1]" if (gbases, args.k, args.n) == (10.0, 21, 1000) else "configs[1] generator, non-default "
+              % (gbases, "BASELINE configs[1]" if (gbases, args.k, args.n) == (10.0, 21, 1000) else "configs[1] generator, non-default "
                  "size/sketch", args.k, args.n))
+        gkey = "c2_k%d_n%d" % (args.k, args.n) if (gbases, world) == (10.0, 1) else None
     else:
-        wl = ("%.1f Gbase synthetic 150 bp reads in total (%s), split into %d contiguous read blocks (one per GPU), mash k=%d "
+        wl = ("%.1f Gbase synthetic 150 bp reads in total (%s), split into %d contiguous read block%s (one per GPU), mash k=%d "
               "n=%d seed 0, blocks resident in HBM as packed stream, partial sketches merged on the host"
-              % (gbases, "configs[3]" if (gbases, args.k, args.n) == (50.0, 21, 1000) else "configs[3] generator, non-default "
-                 "size/sketch", world, args.k, args.n))
+              % (gbases, "BASELINE configs[3]" if (gbases, args.k, args.n) == (50.0, 21, 1000) else "configs[3] generator, non-default "
+                 "size/sketch", world, "" if world == 1 else "s", args.k, args.n))
+        gkey = "c4_k%d_n%d" % (args.k, args.n) if gbases == 50.0 else None  # the same sketch whatever N
+    # fingerprint of the final (merged) sketch: N GPUs over their read blocks must give what the oracle gives on the union
+    check, ok = check_golden(fingerprint(gathered[0], gathered[1], gathered[3]), gkey) if gkey else \
+        (dict(fingerprint(gathered[0], gathered[1], gathered[3]), golden=None, matches_golden=None), True)
     out = {
         "metric": "bases/sec sketched (k=%d, n=%d)" % (args.k, args.n),
         "value": round(value, 1), "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -317,63 +383,141 @@ def main():
         "scaling": "weak" if workload == "c2" else "strong",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": wl, "reads_per_gpu": n_reads, "reads_total": total_reads,
-                   "parallelism": "read-block sharding x%d, host merge" % world},
+                   "parallelism": "read-block sharding x%d, host merge; %s" % (world, drive)},
         "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all,
-        # fingerprint of the final (merged) sketch: N ranks over their read blocks must give what one rank gives on the union
-        "sketch_check": {"n_hashes": int(len(gathered[0])), "min_hash": int(gathered[0]["hash"][0]) if len(gathered[0]) else None,
-                         "max_hash": int(gathered[0]["hash"][-1]) if len(gathered[0]) else None,
-                         "hash_xor": int(np.bitwise_xor.reduce(gathered[0]["hash"])) if len(gathered[0]) else 0,
-                         "count_sum": int(gathered[0]["count"].astype(np.uint64).sum()),
-                         "extra_sum": int(gathered[0]["extra_count"].astype(np.uint64).sum()),
-                         "kmer_byte_sum": int(gathered[1].astype(np.uint64).sum())},
+        "sketch_check": check,
     }
     if extras is not None:
         out["extras"] = extras
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return 0 if ok else 3
 
 
-def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
-    """Measurements next to the headline one (same box, same run, OUTSIDE `value`): the other BASELINE configurations and the
-    end-to-end rates.  Every entry says what it timed; a failing entry reports its error instead of taking the run down."""
+def run_c5(args, F, S, dist, barrier, rank, world, my_devices, launched, gather_device):
+    """BASELINE configs[4]: a batch of FASTA files through finch_sketch_files (lib.rs:29-49), files mapped to GPUs"""
+    import multiprocessing as mp
+    import shutil
+    import tempfile
+    import torch
     from finch_rs_amd import host as H
-    rec = READ_LEN + 1
+    cands = [d for d in ("/dev/shm", tempfile.gettempdir()) if os.path.isdir(d)]
+    base = max(cands, key=lambda d: shutil.disk_usage(d).free)
+    free = shutil.disk_usage(base).free
+    if base == "/dev/shm":  # tmpfs pages are RAM: leave room for the processes
+        try:
+            import psutil
+            free = min(free, psutil.virtual_memory().available - (24 << 30))
+        except Exception:
+            pass
+    nf = max(1, min(args.files, int(0.8 * free / (3.95e6 * 1.015))))  # mean of the log-uniform lengths + newlines
+    d = os.path.join(base, "finch_bench_c5_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
+    try:
+        if rank == 0:
+            os.makedirs(d, exist_ok=True)
+            with mp.get_context("fork").Pool(max(1, min(_usable_cpus(), 64))) as p2:
+                made = p2.map(_write_fasta_job, [(d, i) for i in range(nf)], chunksize=8)
+        barrier()
+        paths = [os.path.join(d, "g%05d.fa" % i) for i in range(nf)]
+        lens = [S.synth_fasta_length(i, SEED) for i in range(nf)]
+        mine = list(range(rank, nf, world)) if launched else list(range(nf))
+        params, filt = F.SketchParams.default(), H.FilterParams(None)
+        res = None
+
+        def step():
+            nonlocal res
+            res = H.sketch_files([paths[i] for i in mine], params, filt, devices=my_devices)
+            assert len(res) == len(mine)
+
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # fingerprint of the sample: files 0..255 (each rank contributes the ones it sketched)
+        fx, tk, cs = 0, 0, 0
+        for j, i in enumerate(mine):
+            if i < C5_SAMPLE:
+                sk = res.sketch(j)
+                fx ^= int(np.bitwise_xor.reduce(sk.arrays[0]["hash"]))
+                cs += int(sk.arrays[0]["count"].astype(np.uint64).sum())
+                tk += int(sk.num_valid_kmers)
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            parts = [None] * world
+            dist.all_gather_object(parts, (fx, tk, cs))
+            fx, tk, cs = 0, 0, 0
+            for a, b, c in parts:
+                fx ^= a; tk += b; cs += c
+        if rank != 0:
+            return 0
+        tot = sum(lens)
+        g = _golden("c5_files_0_255") if nf >= C5_SAMPLE else None
+        fp = {"sample_files": min(nf, C5_SAMPLE), "hash_xor": fx, "count_sum": cs, "total_kmers": tk,
+              "golden": "tests/golden/config_fingerprints.json[c5_files_0_255] (oracle, CPU)" if g else None,
+              "matches_golden": None if g is None else all(g[k] == v for k, v in (("hash_xor", fx), ("count_sum", cs), ("total_kmers", tk)))}
+        out = {"metric": "bases/sec sketched (k=21, n=1000)", "value": round(tot * args.steps / elapsed, 1), "unit": "bases/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[4]: %d synthetic FASTA files (log-uniform 1-10 Mb, 70-column lines, %.2f Gbases, %s) "
+                                      "through finch_sketch_files, library defaults (k=21 n=1000), files mapped to %d GPU%s%s"
+                                      % (nf, tot / 1e9, base, world, "" if world == 1 else "s",
+                                         "" if nf == args.files else "; %d asked for, cut to what %s holds" % (args.files, base)),
+                          "files": nf, "files_per_s": round(nf * args.steps / elapsed, 1),
+                          "parallelism": "file -> GPU mapping x%d (%s)" % (world, "one call per rank" if launched and world > 1 else "one call, devices=[0..%d]" % (world - 1))},
+               "roofline": None, "cpu_baseline": None, "sketch_check": fp}
+        print(json.dumps(out), flush=True)
+        return 0 if fp["matches_golden"] is not False else 3
+    finally:
+        res = None
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            shutil.rmtree(d, ignore_errors=True)
+        if dist is not None:
+            dist.destroy_process_group()
+
+
+def measure_extras(F, S, dr, dg, n_reads, dev):
+    """Measurements next to the headline one (same box, same run, OUTSIDE `value`): the other BASELINE configurations and the
+    end-to-end rates, on the first `n_reads` reads (10 Gbase = configs[1]'s read set) of the resident stream.  Every entry says
+    what it timed; a failing entry reports its error instead of taking the run down."""
+    from finch_rs_amd import host as H
     bases = n_reads * READ_LEN
     ex = {}
 
-    def resident(k, n, steps, warmup=1, after=None, buf=None, reads=None):
-        """passes over a resident stream with a fresh sketcher; -> per-pass ms (best of `steps`), kernel GB/s, launches per pass"""
-        buf = buf or dr
-        reads = reads or n_reads
+    def resident(k, n, steps, warmup=1, gkey=None):
+        """passes over the resident reads with a fresh sketcher; -> per-pass ms (best of `steps`), kernel GB/s, launches per pass"""
         p = F.SketchParams.mash(n, n, True, k, 0)
         s = p.create_sketcher(device=dev)
         s.set_profiling(True)
-        best, best_after = 1e30, 1e30
+        best = 1e30
         kms = kl = kp = 0
-        for it in range(warmup + steps + (1 if after is not None else 0)):
+        arrs, tk = None, 0
+        for it in range(warmup + steps):
             t0 = time.perf_counter()
             s.reset()
-            s.push_device(buf.ptr, reads * rec)
+            s.push_device(dr.ptr, n_reads * REC)
             arrs = s.to_arrays()
             tk = s.finish()[1]
             t1 = time.perf_counter()
             ms, nl, npos = s.kernel_time()
-            if it >= warmup + steps:  # one more pass, with the host-side post-processing behind it
-                after(p, arrs, tk)
-                best_after = time.perf_counter() - t0
-            elif it >= warmup:
+            if it >= warmup:
                 best = min(best, t1 - t0)
                 kms += ms; kl += nl; kp += npos
-            del arrs
         dbg = s.debug_counters()
         s.close()
-        r = {"ms_per_pass": round(best * 1e3, 3), "gbases_per_s": round(reads * READ_LEN / best / 1e9, 2),
+        r = {"ms_per_pass": round(best * 1e3, 3), "gbases_per_s": round(bases / best / 1e9, 2),
              "kernel_GBps": round(kp / 1e9 / (kms / 1e3), 2) if kms else None, "kernel_launches_per_pass": kl / max(steps, 1),
              "roofline_frac": round(kp / 1e9 / (kms / 1e3) / HBM_PEAK_GBS, 5) if kms else None, "big_prunes": dbg["big_prunes"]}
-        if after is not None:
-            r["ms_per_pass_with_host_filters"] = round(best_after * 1e3, 3)
-            r["gbases_per_s_with_host_filters"] = round(reads * READ_LEN / best_after / 1e9, 2)
+        if gkey and bases == 66666667 * READ_LEN:
+            r["sketch_check"] = check_golden(fingerprint(arrs[0], arrs[1], tk), gkey)[0]
         return r
 
     def guarded(name, fn):
@@ -382,13 +526,29 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
         except Exception as e:  # noqa: BLE001 -- an extra must not take the headline number down
             ex[name] = {"error": "%s: %s" % (type(e).__name__, e)}
 
-    # -- the same 10 Gbase stream, other sketches --
+    # -- BASELINE configs[1]: the first 10 Gbase of the stream on this one GPU --
+    def c2():
+        r = resident(21, 1000, 5, gkey="c2_k21_n1000")
+        r["what"] = "BASELINE configs[1]: 10 Gbase (the first 66 666 667 reads of the stream), mash k=21 n=1000 (what `--workload c2` times)"
+        r["pmc"] = _pmc_derived("c2_k21_n1000")
+        return r
+    guarded("c2_10gbase_k21_n1000", c2)
+
+    # -- the same 10 Gbase, other sketches --
     def k31():
-        r = resident(31, 1000, 3)
-        r["what"] = "configs[1]'s stream, mash k=31 n=1000 (bound by the LDS pipe: 6-8 table lookups per position)"
+        r = resident(31, 1000, 3, gkey="c2_k31_n1000")
+        r["what"] = ("configs[1]'s stream, mash k=31 n=1000 (at the VALU-issue AND the LDS-pipe ceiling: 78 VALU instructions and 8 table "
+                     "lookups per position, DESIGN.md 5)")
         r["pmc"] = _pmc_derived("c2_k31_n1000")
         return r
     guarded("k31_n1000", k31)
+
+    def k33():
+        r = resident(33, 1000, 3)
+        r["what"] = "configs[1]'s stream, mash k=33 n=1000: two-word k-mers (fh_k2w.hip)"
+        r["pmc"] = _pmc_derived("c2_k33_n1000")
+        return r
+    guarded("k33_n1000", k33)
 
     def n200k():
         r = resident(21, 200_000, 3)
@@ -408,7 +568,7 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
         for _ in range(3):
             t0 = time.perf_counter()
             s.reset()
-            s.push_device(dr.ptr, n_reads * rec)
+            s.push_device(dr.ptr, n_reads * REC)
             res = H.sketch_from_sketcher(s, "c3", bases, 2, pp, filt)
             best = min(best, time.perf_counter() - t0)
             assert H.lib().finch_sketch_n_hashes(res._p, 0) == 10_000
@@ -420,24 +580,8 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
         return r
     guarded("c3", c3)
 
-    # -- configs[3] on one GPU: the 50 Gbase stream resident --
-    def c4():
-        reads50 = int(np.ceil(50e9 / READ_LEN))
-        d50 = F.DeviceBuffer(reads50 * rec + 64, device=dev)
-        try:
-            S.synth_reads_device(d50, dg, GENOME_LEN, 0, reads50, READ_LEN, SEED, SUB_PPM, N_PPM)
-            r = resident(21, 1000, 2, buf=d50, reads=reads50)
-        finally:
-            d50.free()
-        r["what"] = "BASELINE configs[3] on ONE GPU: 50 Gbase resident, mash k=21 n=1000 (what `--gpus 1 --workload c4` times)"
-        return r
-    guarded("c4_50gbase_1gpu", c4)
-
-    # -- end to end from FASTQ text in host memory (SURVEY 8d M1's separate line; PCIe and the device-side record
-    #    splitting included; never `value`) --
-    def e2e():
-        ns = min(n_reads, 4_000_000)
-        reads = dr.download(ns * rec).reshape(ns, rec)[:, :READ_LEN]
+    def fastq_text(ns):
+        reads = dr.download(ns * REC).reshape(ns, REC)[:, :READ_LEN]
         w = 12 + READ_LEN + 3 + READ_LEN + 1  # "@r%09d\n" seq "\n+\n" qual "\n"
         txt = np.empty((ns, w), np.uint8)
         txt[:, 0], txt[:, 1] = ord("@"), ord("r")
@@ -449,8 +593,13 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
         txt[:, 12 + READ_LEN:15 + READ_LEN] = np.frombuffer(b"\n+\n", np.uint8)
         txt[:, 15 + READ_LEN:15 + 2 * READ_LEN] = ord("I")
         txt[:, w - 1] = 10
-        data = txt.reshape(-1)
-        del txt
+        return txt.reshape(-1)
+
+    # -- end to end from FASTQ text in host memory (SURVEY 8d M1's separate line; PCIe and the device-side record
+    #    splitting included; never `value`) --
+    def e2e():
+        ns = min(n_reads, 4_000_000)
+        data = fastq_text(ns)
         p = F.SketchParams.mash(1000, 1000, True, 21, 0)
         best = 1e30
         for _ in range(3):
@@ -458,8 +607,8 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
             res = H.sketch_stream(data, "fastq", p, H.FilterParams(False), device=dev)
             best = min(best, time.perf_counter() - t0)
             assert H.lib().finch_sketch_seq_length(res._p, 0) == ns * READ_LEN
-        return {"what": "finch_sketch_buffer on a %.2f GB plain FASTQ image in host memory (%d reads): copy into the pinned staging "
-                        "buffer, H2D, record splitting on the device (fh_push_fastq_text), sketch k=21 n=1000, finish"
+        return {"what": "finch_sketch_buffer on a %.2f GB plain FASTQ image in host memory (%d reads): staging into pinned buffers, "
+                        "H2D, record splitting on the device (fh_push_fastq_text), sketch k=21 n=1000, finish"
                         % (data.size / 1e9, ns),
                 "seconds": round(best, 4), "gbases_per_s": round(ns * READ_LEN / best / 1e9, 2),
                 "text_GBps": round(data.size / best / 1e9, 2)}
@@ -472,20 +621,7 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
         import tempfile
         import zlib
         ns = min(n_reads, 1_000_000)
-        reads = dr.download(ns * rec).reshape(ns, rec)[:, :READ_LEN]
-        w = 12 + READ_LEN + 3 + READ_LEN + 1
-        txt = np.empty((ns, w), np.uint8)
-        txt[:, 0], txt[:, 1] = ord("@"), ord("r")
-        idx = np.arange(ns, dtype=np.int64)
-        for d in range(9):
-            txt[:, 10 - d] = 48 + (idx // 10 ** d) % 10
-        txt[:, 11] = 10
-        txt[:, 12:12 + READ_LEN] = reads
-        txt[:, 12 + READ_LEN:15 + READ_LEN] = np.frombuffer(b"\n+\n", np.uint8)
-        txt[:, 15 + READ_LEN:15 + 2 * READ_LEN] = ord("I")
-        txt[:, w - 1] = 10
-        raw = txt.tobytes()
-        del txt
+        raw = fastq_text(ns).tobytes()
         d = tempfile.mkdtemp(prefix="finch_bench_gz_")
         try:
             co = zlib.compressobj(1, zlib.DEFLATED, 31)
@@ -528,7 +664,8 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
             shutil.rmtree(d, ignore_errors=True)
     guarded("compressed_fastq", gz)
 
-    # -- configs[4]'s shape on one GPU: a batch of FASTA files through ONE finch_sketch_files call --
+    # -- configs[4]'s shape on one GPU: a batch of FASTA files through ONE finch_sketch_files call (`--workload c5` times the
+    #    full 10 000) --
     def c5():
         import multiprocessing as mp
         import shutil
@@ -560,4 +697,4 @@ def measure_extras(F, S, dr, dg, n_reads, nbytes, dev):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

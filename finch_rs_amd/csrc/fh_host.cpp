@@ -1139,6 +1139,7 @@ struct ParGzSource : ByteSource {
     static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
     ParGzSource(std::unique_ptr<ByteSource> in, unsigned threads) : inner(std::move(in)), n_thr(std::max(2u, threads)) {
+        rewindable = inner && inner->can_rewind();
         const char *e = getenv("FINCH_PARGZ_CHUNK");
         chunk_bytes = e ? (size_t)std::max(4096ll, atoll(e)) : ((size_t)1 << 20);
     }
@@ -1154,7 +1155,10 @@ struct ParGzSource : ByteSource {
                     t_fill * 1e3, t_find * 1e3, t_decode * 1e3, t_resolve * 1e3, t_deliver * 1e3);
     }
     bool failed() const override { return bad || (tail && tail->failed()); }
-    bool can_rewind() const override { return inner ? inner->can_rewind() : (tail && tail->can_rewind()); }
+    // (answered from what the input said when the reader was made: `inner` belongs to the prefetch thread while a batch
+    //  is in the making -- it may be handing it to the reader of the members behind the first at this very moment)
+    bool rewindable = false;
+    bool can_rewind() const override { return rewindable; }
     bool rewind() override {
         drop_prefetch();
         if (!inner) { // the sequential reader owns the input: it starts over at the first byte of the file
@@ -1383,6 +1387,9 @@ struct ParGzSource : ByteSource {
                     pre2->prefix.assign(1, b);
                     pre2->inner = std::move(pre);
                     out.tail = std::make_unique<FastGzSource>(std::move(pre2));
+                } else {
+                    inner = std::move(pre->inner); // nothing behind the member after all: the input stays here (rewind)
+                    in_eof = true;
                 }
             }
         } else if (last.out_of_input) {
@@ -1417,6 +1424,7 @@ struct ParGzSource : ByteSource {
         if (!fut.valid()) return;
         Prepared p = fut.get();
         for (auto &c : p.chunks) recycle(c);
+        if (p.tail) tail = std::move(p.tail); // (it owns the input now: rewind() goes through it)
     }
     // the next batch into `ready` (and the one after it into the making); false: nothing more from this reader
     bool next_batch() {
@@ -2939,7 +2947,7 @@ static uint64_t env_max_launch() {
 }
 
 int finch_sketch_buffer(const uint8_t *data, uint64_t len, const char *name, const finch_sketch_params *sp,
-                        const finch_filter_params *filters, int device, finch_sketches **out) {
+                        const finch_filter_params *filters, int device, finch_sketches **out) try {
     if ((!data && len) || !sp || !filters || !out) return hfail(FH_ERR_INVALID, "null argument");
     HandleSet handles;
     handles.full = to_fh(*sp, env_max_launch());
@@ -2951,11 +2959,11 @@ int finch_sketch_buffer(const uint8_t *data, uint64_t len, const char *name, con
     if (rc != FH_OK) return rc;
     *out = res.release();
     return FH_OK;
-}
+} FINCH_CATCH
 
 int finch_sketch_files(const char *const *filenames, uint32_t n_files, const finch_sketch_params *sp,
                        const finch_filter_params *filters, const int *devices, uint32_t n_devices, uint32_t n_threads,
-                       finch_sketches **out) {
+                       finch_sketches **out) try {
     if (!filenames || !sp || !filters || !out) return hfail(FH_ERR_INVALID, "null argument");
     std::vector<int> devs;
     if (devices && n_devices) devs.assign(devices, devices + n_devices);
@@ -3025,7 +3033,7 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
     if (first_err_code != FH_OK) return hfail(first_err_code, "%s", first_err_msg.c_str());
     *out = res.release();
     return FH_OK;
-}
+} FINCH_CATCH
 
 static int sharded_devices(const int *devices, uint32_t n_devices, std::vector<int> &devs) {
     if (devices && n_devices) devs.assign(devices, devices + n_devices);
@@ -3035,7 +3043,7 @@ static int sharded_devices(const int *devices, uint32_t n_devices, std::vector<i
 }
 
 int finch_sketch_file_sharded(const char *filename, const finch_sketch_params *sp, const finch_filter_params *filters,
-                              const int *devices, uint32_t n_devices, uint64_t chunk_bytes, finch_sketches **out) {
+                              const int *devices, uint32_t n_devices, uint64_t chunk_bytes, finch_sketches **out) try {
     if (!filename || !sp || !filters || !out) return hfail(FH_ERR_INVALID, "null argument");
     std::vector<int> devs;
     if (int rc = sharded_devices(devices, n_devices, devs)) return rc;
@@ -3063,11 +3071,11 @@ int finch_sketch_file_sharded(const char *filename, const finch_sketch_params *s
     if (rc != FH_OK) return rc;
     *out = res.release();
     return FH_OK;
-}
+} FINCH_CATCH
 
 int finch_sketch_buffer_sharded(const uint8_t *data, uint64_t len, const char *name, const finch_sketch_params *sp,
                                 const finch_filter_params *filters, const int *devices, uint32_t n_devices, uint64_t chunk_bytes,
-                                finch_sketches **out) {
+                                finch_sketches **out) try {
     if ((!data && len) || !sp || !filters || !out) return hfail(FH_ERR_INVALID, "null argument");
     std::vector<int> devs;
     if (int rc = sharded_devices(devices, n_devices, devs)) return rc;
@@ -3087,12 +3095,12 @@ int finch_sketch_buffer_sharded(const uint8_t *data, uint64_t len, const char *n
     if (rc != FH_OK) return rc;
     *out = res.release();
     return FH_OK;
-}
+} FINCH_CATCH
 
 // Test hook (no device): the chunks the sharded reader would deal out for an input image -- per chunk 4 words
 // (text offset, length, FASTA start state, halo length) in `meta` and 64 halo bytes in `halos`.
 int finch_shard_probe(const uint8_t *data, uint64_t len, uint32_t k, uint64_t chunk_bytes, uint64_t max_chunks, uint64_t *meta,
-                      uint8_t *halos, uint64_t *n_chunks, uint64_t *n_records, uint64_t *total_bases) {
+                      uint8_t *halos, uint64_t *n_chunks, uint64_t *n_records, uint64_t *total_bases) try {
     if ((!data && len) || !n_chunks || k < 1 || k > 64 || chunk_bytes < 16) return hfail(FH_ERR_INVALID, "bad argument");
     std::unique_ptr<ByteSource> src;
     int first = -1;
@@ -3121,13 +3129,13 @@ int finch_shard_probe(const uint8_t *data, uint64_t len, uint32_t k, uint64_t ch
     if (n_records) *n_records = st.n_records;
     if (total_bases) *total_bases = st.total_bases;
     return FH_OK;
-}
+} FINCH_CATCH
 
 // The tail of sketch_stream (lib.rs:70-93) for a caller that drove the device engine itself (fh_push_* on `h`): to_vec ->
 // filter_counts -> process_post_filter -> Sketch.  `format`: 1 FASTA, 2 FASTQ (decides the filtering default when
 // filters->filter_on is None, lib.rs:70-76).
 int finch_sketch_from_sketcher(fh_sketcher *h, const char *name, uint64_t seq_length, int format, const finch_sketch_params *sp,
-                               const finch_filter_params *filters, finch_sketches **out) {
+                               const finch_filter_params *filters, finch_sketches **out) try {
     if (!h || !sp || !filters || !out) return hfail(FH_ERR_INVALID, "null argument");
     FastxStats st;
     st.total_bases = seq_length;
@@ -3137,7 +3145,7 @@ int finch_sketch_from_sketcher(fh_sketcher *h, const char *name, uint64_t seq_le
     if (int rc = finish_sketch(h, name ? name : "", *sp, *filters, st, res->v[0])) return rc;
     *out = res.release();
     return FH_OK;
-}
+} FINCH_CATCH
 
 void finch_sketches_free(finch_sketches *s) { delete s; }
 uint32_t finch_sketches_len(const finch_sketches *s) { return s ? (uint32_t)s->v.size() : 0; }
@@ -3148,14 +3156,14 @@ uint64_t finch_sketch_num_valid_kmers(const finch_sketches *s, uint32_t i) {
 }
 uint64_t finch_sketch_n_hashes(const finch_sketches *s, uint32_t i) { return (s && i < s->v.size()) ? s->v[i].hashes.size() : 0; }
 
-int finch_sketch_filter_params(const finch_sketches *s, uint32_t i, finch_filter_params *out) {
+int finch_sketch_filter_params(const finch_sketches *s, uint32_t i, finch_filter_params *out) try {
     if (!s || i >= s->v.size() || !out) return hfail(FH_ERR_INVALID, "bad argument");
     *out = s->v[i].filter_params;
     return FH_OK;
-}
+} FINCH_CATCH
 
 int finch_sketch_copy(const finch_sketches *s, uint32_t i, uint64_t *hashes, uint32_t *counts, uint32_t *extra_counts,
-                      uint8_t *kmers) {
+                      uint8_t *kmers) try {
     if (!s || i >= s->v.size()) return hfail(FH_ERR_INVALID, "bad argument");
     const Sketch &sk = s->v[i];
     const size_t k = sk.sketch_params.kmer_length;
@@ -3166,9 +3174,9 @@ int finch_sketch_copy(const finch_sketches *s, uint32_t i, uint64_t *hashes, uin
         if (kmers) memcpy(kmers + j * k, sk.hashes[j].kmer.data(), std::min(k, sk.hashes[j].kmer.size()));
     }
     return FH_OK;
-}
+} FINCH_CATCH
 
-int finch_sketches_to_json(const finch_sketches *s, char **out, uint64_t *len) {
+int finch_sketches_to_json(const finch_sketches *s, char **out, uint64_t *len) try {
     if (!s || !out) return hfail(FH_ERR_INVALID, "null argument");
     std::string o;
     if (int rc = to_json(s->v, o)) return rc;
@@ -3179,14 +3187,14 @@ int finch_sketches_to_json(const finch_sketches *s, char **out, uint64_t *len) {
     *out = p;
     if (len) *len = o.size();
     return FH_OK;
-}
+} FINCH_CATCH
 
 void finch_free_string(char *p) { free(p); }
 
 int finch_sketches_from_arrays(const char *name, uint64_t seq_length, uint64_t num_valid_kmers, uint64_t n,
                                const uint64_t *hashes, const uint32_t *counts, const uint32_t *extra_counts,
                                const uint8_t *kmers, const finch_sketch_params *sp, const finch_filter_params *filters,
-                               finch_sketches **out) {
+                               finch_sketches **out) try {
     if (!sp || !filters || !out || (n && (!hashes || !counts || !extra_counts))) return hfail(FH_ERR_INVALID, "null argument");
     // KmerCount invariants of the reference's sketchers (mash.rs:45-56: count starts at 1, extra_count is bumped with it):
     // the filters index a histogram by count - 1 and subtract extra_count from count
@@ -3210,9 +3218,9 @@ int finch_sketches_from_arrays(const char *name, uint64_t seq_length, uint64_t n
                                 extra_counts[i]};
     *out = res.release();
     return FH_OK;
-}
+} FINCH_CATCH
 
-int finch_apply_filters(finch_sketches *s, uint32_t i, finch_filter_params *filters) {
+int finch_apply_filters(finch_sketches *s, uint32_t i, finch_filter_params *filters) try {
     if (!s || i >= s->v.size() || !filters) return hfail(FH_ERR_INVALID, "bad argument");
     Sketch &sk = s->v[i];
     std::vector<KmerCount> f = filter_counts(*filters, sk.hashes);
@@ -3220,18 +3228,18 @@ int finch_apply_filters(finch_sketches *s, uint32_t i, finch_filter_params *filt
     sk.hashes.swap(f);
     sk.filter_params = *filters;
     return FH_OK;
-}
+} FINCH_CATCH
 
 int finch_raw_distance(const uint64_t *query, uint64_t nq, const uint64_t *ref, uint64_t nr, double scale,
-                       finch_distance_out *out) {
+                       finch_distance_out *out) try {
     if (!out || (nq && !query) || (nr && !ref)) return hfail(FH_ERR_INVALID, "null argument");
     raw_distance(query, nq, ref, nr, scale, out->containment, out->jaccard, out->common_hashes, out->total_hashes);
     out->mash_distance = 0.;
     return FH_OK;
-}
+} FINCH_CATCH
 
 int finch_distance(const finch_sketches *a, uint32_t ia, const finch_sketches *b, uint32_t ib, int old_mode,
-                   finch_distance_out *out) {
+                   finch_distance_out *out) try {
     if (!a || !b || !out || ia >= a->v.size() || ib >= b->v.size()) return hfail(FH_ERR_INVALID, "bad argument");
     const Sketch &qs = a->v[ia], &rs = b->v[ib];
     std::vector<uint64_t> q(qs.hashes.size()), r(rs.hashes.size());
@@ -3252,10 +3260,10 @@ int finch_distance(const finch_sketches *a, uint32_t ia, const finch_sketches *b
     const double md = -1.0 * std::log((2.0 * out->jaccard) / (1.0 + out->jaccard)) / k; // distance.rs:37
     out->mash_distance = std::min(1.0, std::max(0.0, md));
     return FH_OK;
-}
+} FINCH_CATCH
 
 // statistics.rs:8-23: the k-minimum-values estimate, in the reference's f32 arithmetic (`as u64` saturates, NaN -> 0)
-int finch_sketch_cardinality(const finch_sketches *s, uint32_t i, uint64_t *out) {
+int finch_sketch_cardinality(const finch_sketches *s, uint32_t i, uint64_t *out) try {
     if (!s || i >= s->v.size() || !out) return hfail(FH_ERR_INVALID, "bad argument");
     const std::vector<KmerCount> &h = s->v[i].hashes;
     if (h.empty()) {
@@ -3266,11 +3274,11 @@ int finch_sketch_cardinality(const finch_sketches *s, uint32_t i, uint64_t *out)
     const float est = (float)(h.size() - 1) / ratio;
     *out = est != est ? 0ull : (est >= 18446744073709551616.0f ? UINT64_MAX : (est <= 0.0f ? 0ull : (uint64_t)est));
     return FH_OK;
-}
+} FINCH_CATCH
 
 // statistics.rs:30-47 (hist): out[c - 1] = number of hashes with count c, for c = 1..max count; *n = max count.  Call with
 // out = NULL to learn *n.
-int finch_sketch_hist(const finch_sketches *s, uint32_t i, uint64_t *out, uint64_t cap, uint64_t *n) {
+int finch_sketch_hist(const finch_sketches *s, uint32_t i, uint64_t *out, uint64_t cap, uint64_t *n) try {
     if (!s || i >= s->v.size() || !n) return hfail(FH_ERR_INVALID, "bad argument");
     const std::vector<uint64_t> hd = hist(s->v[i].hashes);
     *n = hd.size();
@@ -3279,7 +3287,7 @@ int finch_sketch_hist(const finch_sketches *s, uint32_t i, uint64_t *out, uint64
         memcpy(out, hd.data(), hd.size() * sizeof(uint64_t));
     }
     return FH_OK;
-}
+} FINCH_CATCH
 
 uint32_t finch_guess_filter_threshold(const uint32_t *counts, uint64_t n, double filter_level) {
     if (n && !counts) {
@@ -3296,7 +3304,7 @@ uint32_t finch_guess_filter_threshold(const uint32_t *counts, uint64_t n, double
     return guess_filter_threshold(v, filter_level);
 }
 
-int finch_fastx_scan(const uint8_t *data, uint64_t len, uint64_t *n_records, uint64_t *total_bases, int *format) {
+int finch_fastx_scan(const uint8_t *data, uint64_t len, uint64_t *n_records, uint64_t *total_bases, int *format) try {
     if (!data && len) return hfail(FH_ERR_INVALID, "null argument");
     std::unique_ptr<ByteSource> src;
     if (int rc = open_source(std::make_unique<MemSource>(data, (size_t)len), src)) return rc;
@@ -3307,11 +3315,11 @@ int finch_fastx_scan(const uint8_t *data, uint64_t len, uint64_t *n_records, uin
     if (total_bases) *total_bases = st.total_bases;
     if (format) *format = st.format;
     return FH_OK;
-}
+} FINCH_CATCH
 
 // Reads a file the way the text paths do (FileSource::read in `chunk`-byte requests, 2 sniffed bytes first, large
 // requests split over `read_threads` threads): lets the host-only tests compare the bytes with the file's.
-int finch_read_file_probe(const char *path, uint64_t chunk, uint32_t read_threads, uint8_t *dst, uint64_t cap, uint64_t *got) {
+int finch_read_file_probe(const char *path, uint64_t chunk, uint32_t read_threads, uint8_t *dst, uint64_t cap, uint64_t *got) try {
     if (!path || !dst || !got || chunk == 0) return hfail(FH_ERR_INVALID, "bad argument");
     FILE *f = fopen(path, "rb");
     if (!f) return hfail(FH_ERR_INVALID, "%s: %s", path, strerror(errno));
@@ -3332,12 +3340,12 @@ int finch_read_file_probe(const char *path, uint64_t chunk, uint32_t read_thread
     }
     *got = n;
     return FH_OK;
-}
+} FINCH_CATCH
 
 // What the parsers and the device-side text paths read from an input image after magic-byte sniffing and decompression,
 // requested `chunk` bytes at a time (large requests take BgzfSource's inflate-into-the-caller's-buffer route).
 int finch_bgzf_batch_probe(const uint8_t *data, uint64_t len, uint64_t buf_bytes, uint32_t max_members, uint64_t text_budget,
-                           uint8_t *text_out, uint64_t text_cap, uint64_t *text_len, uint64_t *n_batches, int *first_byte) {
+                           uint8_t *text_out, uint64_t text_cap, uint64_t *text_len, uint64_t *n_batches, int *first_byte) try {
     if ((!data && len) || !text_out || !text_len || !n_batches || !first_byte) return hfail(FH_ERR_INVALID, "bad argument");
     std::unique_ptr<ByteSource> src;
     setenv("FINCH_BGZF_THREADS", "2", 0); // (a BgzfSource only stands in front of gzip input when it may use threads)
@@ -3372,9 +3380,9 @@ int finch_bgzf_batch_probe(const uint8_t *data, uint64_t len, uint64_t buf_bytes
     *text_len = out;
     *n_batches = batches;
     return FH_OK;
-}
+} FINCH_CATCH
 
-int finch_source_probe(const uint8_t *data, uint64_t len, uint64_t chunk, uint8_t *dst, uint64_t cap, uint64_t *got) {
+int finch_source_probe(const uint8_t *data, uint64_t len, uint64_t chunk, uint8_t *dst, uint64_t cap, uint64_t *got) try {
     if ((!data && len) || !dst || !got || chunk == 0) return hfail(FH_ERR_INVALID, "bad argument");
     std::unique_ptr<ByteSource> src;
     if (int rc = open_source(std::make_unique<MemSource>(data, (size_t)len), src)) return rc;
@@ -3387,11 +3395,11 @@ int finch_source_probe(const uint8_t *data, uint64_t len, uint64_t chunk, uint8_
     if (src->failed()) return hfail(FH_ERR_INVALID, "corrupt compressed stream");
     *got = n;
     return FH_OK;
-}
+} FINCH_CATCH
 
 // The record / total_bases bookkeeping of the device-side FASTA path (FastaCounter), fed in chunks of `chunk` bytes cut
 // the way fasta_text_to_device cuts them: lets the host-only tests check it against finch_fastx_scan without a GPU.
-int finch_fasta_count_chunked(const uint8_t *data, uint64_t len, uint64_t chunk, uint64_t *n_records, uint64_t *total_bases) {
+int finch_fasta_count_chunked(const uint8_t *data, uint64_t len, uint64_t chunk, uint64_t *n_records, uint64_t *total_bases) try {
     if ((!data && len) || chunk == 0) return hfail(FH_ERR_INVALID, "bad argument");
     FastaCounter fc;
     uint64_t off = 0;
@@ -3408,6 +3416,6 @@ int finch_fasta_count_chunked(const uint8_t *data, uint64_t len, uint64_t chunk,
     if (n_records) *n_records = fc.n_records;
     if (total_bases) *total_bases = fc.total_bases;
     return FH_OK;
-}
+} FINCH_CATCH
 
 } // extern "C"

@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <exception>
+#include <new>
 #include <vector>
 
 #include "../../include/finch_hip.h"
@@ -16,6 +18,14 @@ namespace finch {
 
 extern thread_local std::string g_host_err;
 int hfail(int code, const char *fmt, ...);
+
+// No exception crosses the C ABI: every `int finch_*` entry point is a function-try-block ending in this.  (An allocation a
+// crafted input talks the library into, or one the machine cannot serve, is an error return -- the reference's readers
+// return Err there too -- not std::terminate in the caller's process.)
+#define FINCH_CATCH                                                                                            \
+    catch (const std::bad_alloc &) { return finch::hfail(FH_ERR_CAPACITY, "out of host memory"); }              \
+    catch (const std::exception &e) { return finch::hfail(FH_ERR_INVALID, "internal error: %s", e.what()); }    \
+    catch (...) { return finch::hfail(FH_ERR_INVALID, "internal error"); }
 
 struct KmerCount {
     uint64_t hash;

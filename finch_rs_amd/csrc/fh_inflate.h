@@ -436,9 +436,15 @@ struct Decoder {
             if (!build_table(cl, 19, 7, cltab, 128, [](int s) { return ((uint32_t)s << 16) | K_LITERAL; })) return BAD;
             int i = 0;
             while (i < hlit + hdist) {
-                if (!fill(in, in_end, 14) && bitcnt < 7) return need_input(); // (a code is <= 7 bits, its extra bits <= 7)
+                // (a code is <= 7 bits, its extra bits <= 7.  With fewer than 14 bits left -- the last block of a member may end
+                // within a byte or two of its header -- the entry is looked up on what there is, the missing bits reading as 0:
+                // whether that was enough is decided by the entry's own length below, not before looking)
+                const bool full = fill(in, in_end, 14);
                 const uint32_t e = cltab[bitbuf & 127u];
-                if (!(e & K_LITERAL)) return BAD;
+                if (!(e & K_LITERAL)) {
+                    if (!full && bitcnt < 7) return need_input();
+                    return BAD;
+                }
                 const int l = (int)(e & 0xFFu), sym = (int)(e >> 16);
                 const int extra = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
                 if (bitcnt < l + extra) return need_input();

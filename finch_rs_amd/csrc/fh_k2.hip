@@ -54,7 +54,7 @@ constexpr int UNROLL_J = FH_UNROLL;
 constexpr int k2_min_waves(int K) { return K <= 21 ? FH_MINW_SMALL : FH_MINW_BIG; }
 // positions per unrolled round of the lane's 32 (see the loop): 32 = one pass
 #ifndef FH_ROUND_BIG
-#define FH_ROUND_BIG 8
+#define FH_ROUND_BIG 16
 #endif
 #ifndef FH_ROUND_FROM
 #define FH_ROUND_FROM 25

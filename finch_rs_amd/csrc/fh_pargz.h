@@ -423,7 +423,10 @@ static inline void decode_chunk(const uint8_t *base, size_t n, std::vector<Chunk
             return;
         }
         if (at_boundary(pos)) return;
-        if (c.text_len() > text_cap) {
+        // (a guard against false starts -- a speculative start that happens to decode keeps producing garbage.  A chunk
+        //  whose window is known starts where its predecessor really ended: whatever it inflates to, a run of 300 MB of 'N'
+        //  included, is the stream's own text)
+        if (!c.known_window && c.text_len() > text_cap) {
             c.ok = false;
             return;
         }

@@ -306,6 +306,21 @@ struct Walker {
         out.assign(p, n);
         return true;
     }
+    // A list about to be read as List(struct): its encoding must be one a struct list can have (element size 64-bit,
+    // pointer, or composite -- void / bit / sub-word lists cannot be upgraded), and elements that occupy no words at all
+    // (composite with an empty struct) are charged one word each against a traversal budget, as the capnp runtime does: a
+    // 24-byte message must not be able to claim 2^29 elements and have the reader allocate for them.
+    static constexpr uint64_t TRAVERSAL_WORDS = 8ull << 20; // capnp's default ReaderOptions::traversal_limit_in_words
+    bool struct_list(const ListR &l) {
+        if (!l.m) return true;
+        if (l.elem < 5) return m.fail("list of structs stored with sub-word elements");
+        if (l.elem == 7 && (uint32_t)l.data_words + l.n_ptrs == 0) {
+            amplified += l.count;
+            if (amplified > TRAVERSAL_WORDS) return m.fail("read limit exceeded (zero-sized list elements)");
+        }
+        return true;
+    }
+    uint64_t amplified = 0;
     // element i of a List(struct); lists of primitives / pointers upgraded to structs read through the same view
     bool element(const ListR &l, uint32_t i, StructR &out) {
         out = StructR{};
@@ -422,7 +437,7 @@ static int read_bsk(const uint8_t *data, uint64_t len, std::vector<Sketch> &out)
     capnp::StructR root;
     if (!w.get_struct(0, 0, root)) return bad();
     capnp::ListR sl;
-    if (!w.field_list(root, 0, sl)) return bad();
+    if (!w.field_list(root, 0, sl) || !w.struct_list(sl)) return bad();
     out.clear();
     out.resize(sl.m ? sl.count : 0);
     for (uint32_t i = 0; i < out.size(); ++i) {
@@ -433,7 +448,7 @@ static int read_bsk(const uint8_t *data, uint64_t len, std::vector<Sketch> &out)
         s.seq_length = cs.word(0);
         s.num_valid_kmers = cs.word(1);
         capnp::ListR hl;
-        if (!w.field_list(cs, 2, hl)) return bad();
+        if (!w.field_list(cs, 2, hl) || !w.struct_list(hl)) return bad();
         s.hashes.resize(hl.m ? hl.count : 0);
         for (uint32_t j = 0; j < s.hashes.size(); ++j) {
             capnp::StructR ch;
@@ -552,6 +567,7 @@ static int read_msh(const uint8_t *data, uint64_t len, std::vector<Sketch> &out)
     if (!w.field_list(rl_new, 0, refs)) return bad();
     if (!refs.m) // mash.rs:85-89: has_references() ? new : old
         if (!w.field_list(rl_old, 0, refs)) return bad();
+    if (!w.struct_list(refs)) return bad();
     out.clear();
     out.resize(refs.m ? refs.count : 0);
     for (uint32_t i = 0; i < out.size(); ++i) {
@@ -980,19 +996,19 @@ using namespace finch;
 
 extern "C" {
 
-int finch_sketches_to_bsk(const finch_sketches *s, uint8_t **out, uint64_t *len) {
+int finch_sketches_to_bsk(const finch_sketches *s, uint8_t **out, uint64_t *len) try {
     if (!s || !out) return hfail(FH_ERR_INVALID, "null argument");
     std::string o;
     if (int rc = write_bsk(s->v, o)) return rc;
     return bytes_out(o, out, len);
-}
+} FINCH_CATCH
 
-int finch_sketches_to_msh(const finch_sketches *s, uint8_t **out, uint64_t *len) {
+int finch_sketches_to_msh(const finch_sketches *s, uint8_t **out, uint64_t *len) try {
     if (!s || !out) return hfail(FH_ERR_INVALID, "null argument");
     std::string o;
     if (int rc = write_msh(s->v, o)) return rc;
     return bytes_out(o, out, len);
-}
+} FINCH_CATCH
 
 void finch_free_bytes(uint8_t *p) { free(p); }
 
@@ -1003,29 +1019,29 @@ static int wrap(std::vector<Sketch> &v, finch_sketches **out) {
     return FH_OK;
 }
 
-int finch_sketches_from_bsk(const uint8_t *data, uint64_t len, finch_sketches **out) {
+int finch_sketches_from_bsk(const uint8_t *data, uint64_t len, finch_sketches **out) try {
     if ((!data && len) || !out) return hfail(FH_ERR_INVALID, "null argument");
     std::vector<Sketch> v;
     if (int rc = read_bsk(data, len, v)) return rc;
     return wrap(v, out);
-}
+} FINCH_CATCH
 
-int finch_sketches_from_msh(const uint8_t *data, uint64_t len, finch_sketches **out) {
+int finch_sketches_from_msh(const uint8_t *data, uint64_t len, finch_sketches **out) try {
     if ((!data && len) || !out) return hfail(FH_ERR_INVALID, "null argument");
     std::vector<Sketch> v;
     if (int rc = read_msh(data, len, v)) return rc;
     return wrap(v, out);
-}
+} FINCH_CATCH
 
-int finch_sketches_from_json(const uint8_t *data, uint64_t len, finch_sketches **out) {
+int finch_sketches_from_json(const uint8_t *data, uint64_t len, finch_sketches **out) try {
     if ((!data && len) || !out) return hfail(FH_ERR_INVALID, "null argument");
     std::vector<Sketch> v;
     if (int rc = read_sk(data, len, v)) return rc;
     return wrap(v, out);
-}
+} FINCH_CATCH
 
 // open_sketch_file (lib.rs:96-118): the format is taken from the file name
-int finch_open_sketch_file(const char *path, finch_sketches **out) {
+int finch_open_sketch_file(const char *path, finch_sketches **out) try {
     if (!path || !out) return hfail(FH_ERR_INVALID, "null argument");
     const std::string fn = file_name_of(path);
     if (fn.empty()) return hfail(FH_ERR_INVALID, "Path does not have a filename: \"%s\"", path);
@@ -1046,10 +1062,10 @@ int finch_open_sketch_file(const char *path, finch_sketches **out) {
     }
     if (rc != FH_OK) return rc;
     return wrap(v, out);
-}
+} FINCH_CATCH
 
 // the `sketch` subcommand's output step (cli/src/main.rs:53-70, 225-231): binary / Mash / JSON by file name
-int finch_write_sketch_file(const finch_sketches *s, const char *path) {
+int finch_write_sketch_file(const finch_sketches *s, const char *path) try {
     if (!s || !path) return hfail(FH_ERR_INVALID, "null argument");
     const std::string fn = file_name_of(path);
     std::string o;
@@ -1071,33 +1087,33 @@ int finch_write_sketch_file(const finch_sketches *s, const char *path) {
     const bool ok = fwrite(o.data(), 1, o.size(), f) == o.size();
     if (fclose(f) != 0 || !ok) return hfail(FH_ERR_INVALID, "%s: write failed", path);
     return FH_OK;
-}
+} FINCH_CATCH
 
-int finch_sketch_params_of(const finch_sketches *s, uint32_t i, finch_sketch_params *out) {
+int finch_sketch_params_of(const finch_sketches *s, uint32_t i, finch_sketch_params *out) try {
     if (!s || i >= s->v.size() || !out) return hfail(FH_ERR_INVALID, "bad argument");
     *out = s->v[i].sketch_params;
     return FH_OK;
-}
+} FINCH_CATCH
 
 const char *finch_sketch_comment(const finch_sketches *s, uint32_t i) { return (s && i < s->v.size()) ? s->v[i].comment.c_str() : ""; }
 
-int finch_sketch_set_comment(finch_sketches *s, uint32_t i, const char *comment) {
+int finch_sketch_set_comment(finch_sketches *s, uint32_t i, const char *comment) try {
     if (!s || i >= s->v.size()) return hfail(FH_ERR_INVALID, "bad argument");
     s->v[i].comment = comment ? comment : "";
     return FH_OK;
-}
+} FINCH_CATCH
 
 // Vec<Sketch> concatenation (the CLI collects the sketches of all inputs before it writes one file, main.rs:60-70)
-int finch_sketches_append(finch_sketches *dst, const finch_sketches *src) {
+int finch_sketches_append(finch_sketches *dst, const finch_sketches *src) try {
     if (!dst || !src) return hfail(FH_ERR_INVALID, "null argument");
     dst->v.insert(dst->v.end(), src->v.begin(), src->v.end());
     return FH_OK;
-}
+} FINCH_CATCH
 
 // FilterParams::filter_sketch (filtering.rs:20-54) as the reference has it: the sketch's filter parameters take the
 // stricter of their own and `filters`' values; the hashes are NOT touched (the reference computes the filtered list
 // and drops it, filtering.rs:24).
-int finch_filter_sketch(finch_sketches *s, uint32_t i, const finch_filter_params *filters) {
+int finch_filter_sketch(finch_sketches *s, uint32_t i, const finch_filter_params *filters) try {
     if (!s || i >= s->v.size() || !filters) return hfail(FH_ERR_INVALID, "bad argument");
     finch_filter_params &fp = s->v[i].filter_params;
     const finch_filter_params &f = *filters;
@@ -1110,6 +1126,6 @@ int finch_filter_sketch(finch_sketches *s, uint32_t i, const finch_filter_params
     fp.err_filter = std::max(fp.err_filter, f.err_filter);
     fp.strand_filter = std::max(fp.strand_filter, f.strand_filter);
     return FH_OK;
-}
+} FINCH_CATCH
 
 } // extern "C"

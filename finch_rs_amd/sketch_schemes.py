@@ -232,6 +232,33 @@ def synth_reads_host(genome: np.ndarray, first_read: int, n_reads: int, read_len
     return out
 
 
+def _splitmix64(x: int) -> int:
+    m = 2**64 - 1
+    x = (x + 0x9E3779B97F4A7C15) & m
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+    return x ^ (x >> 31)
+
+
+def synth_fasta_length(i: int, seed: int, scale: float = 1.0) -> int:
+    """length of synthetic genome file i (SURVEY 8d M4, configs[4]): log-uniform 1..10 Mb from the per-file seed"""
+    u = (_splitmix64(seed + 7919 * i) >> 11) / float(1 << 53)
+    return max(1000, int(1e6 * 10.0 ** u * scale))
+
+
+def synth_fasta_file(i: int, seed: int, scale: float = 1.0) -> bytes:
+    """synthetic genome file i as FASTA text: one record, 70-column lines, header '>genome_<i> len=<L>'"""
+    L = synth_fasta_length(i, seed, scale)
+    g = synth_genome_host(L, seed + 1000003 * (i + 1))
+    rows = (L + 69) // 70
+    a = np.full((rows, 71), ord("\n"), np.uint8)
+    gp = np.zeros(rows * 70, np.uint8)
+    gp[:L] = g
+    a[:, :70] = gp.reshape(rows, 70)
+    last = L - (rows - 1) * 70
+    return b">genome_%05d len=%d\n" % (i, L) + a.reshape(-1)[:(rows - 1) * 71 + last].tobytes() + b"\n"
+
+
 def synth_genome_device(buf: DeviceBuffer, length: int, seed: int):
     check(_lib.load().fh_synth_genome_device(buf.device, C.c_void_p(buf.ptr), length, seed))
 

@@ -52,6 +52,15 @@ def _shard(job):
     return kc, km, o.total_bases_and_kmers()[1]
 
 
+def _c5_file(i):
+    from finch_rs_amd import sketch_schemes as S
+    from oracle import oracle as O
+    o = O.OracleSketcher(O.MASH, 1000, 21, 0)
+    assert o.sketch_stream(S.synth_fasta_file(i, SEED)) == 1  # the oracle's own FASTA reader (lib.rs:51-94 restated)
+    kc, _ = o.to_vec()
+    return int(np.bitwise_xor.reduce(kc["hash"])), int(kc["count"].astype(np.uint64).sum()), int(o.total_bases_and_kmers()[1])
+
+
 def merge_numpy(parts, n):
     kc = np.concatenate([p[0] for p in parts])
     km = np.concatenate([p[1] for p in parts])
@@ -95,7 +104,15 @@ def main():
     out["_generator"] = ("tests/golden/make_config_fingerprints.py: host read generator (seed %d, genome %d, %d bp, sub %d ppm, "
                          "N %d ppm) -> oracle per read block -> numpy merge" % (SEED, GL, RL, SUB_PPM, N_PPM))
     with mp.get_context("fork").Pool(args.procs) as pool:
-        for name in names:
+        if args.only is None or "c5_files_0_255" in names:
+            # BASELINE configs[4]: files 0..255 of the synthetic FASTA batch (bench.py --workload c5), library defaults
+            fx = cs = tk = 0
+            for a, b, c in pool.map(_c5_file, range(256), chunksize=4):
+                fx ^= a; cs += b; tk += c
+            out["c5_files_0_255"] = {"sample_files": 256, "hash_xor": fx, "count_sum": cs, "total_kmers": tk, "k": 21, "n": 1000}
+            print("c5_files_0_255:", json.dumps(out["c5_files_0_255"]), flush=True)
+            json.dump(out, open(args.out, "w"), indent=1, sort_keys=True)
+        for name in [n for n in names if n in CONFIGS]:
             gb, k, n = CONFIGS[name]
             reads = int(np.ceil(gb * 1e9 / RL))
             blocks = args.procs * 8

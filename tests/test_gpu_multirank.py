@@ -1,6 +1,9 @@
-"""bench.py's N > 1 flow on a 1-GPU box: two and three ranks share cuda:0 (--share-gpu), each sketches its own read
-block, rank 0 gathers and merges.  The merged sketch of N ranks x G Gbase must be the sketch one rank computes on
-N*G Gbase (same read indices): SURVEY 8e through the real launcher, timing protocol and JSON contract included."""
+"""bench.py's N > 1 flows on a 1-GPU box (--share-gpu maps every rank / thread to device 0):
+  * launched plainly (`python bench.py --gpus N`): one process, one host thread + sketcher handle per device;
+  * launched by torch.distributed.run: one process per rank, rank 0 gathers and merges.
+Each rank sketches its own read block; the merged sketch of N ranks must be the sketch one rank computes on the union (same read
+indices): SURVEY 8e through the real launchers, timing protocol and JSON contract included -- and, at BASELINE configs[3]'s
+full size, it must be the sketch the ORACLE computed on the CPU (tests/golden/config_fingerprints.json)."""
 import json
 import os
 import socket
@@ -11,6 +14,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FP = ("n_hashes", "min_hash", "max_hash", "hash_xor", "count_sum", "extra_sum", "kmer_byte_sum", "total_kmers")
 
 
 def _free_port():
@@ -21,46 +25,82 @@ def _free_port():
     return p
 
 
-def _bench(args, world=1):
-    if world > 1:
+def _bench(args, world=1, launcher=True, rc=0):
+    env = dict(os.environ)
+    if world > 1 and launcher:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", str(world), "--share-gpu"]
     else:
-        cmd = [sys.executable, "bench.py"]
-    r = subprocess.run(cmd + args, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
+        cmd = [sys.executable, "bench.py"] + (["--gpus", str(world), "--share-gpu"] if world > 1 else [])
+        for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):  # a plain launch: nothing of a launcher in the environment
+            env.pop(v, None)
+    r = subprocess.run(cmd + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert r.returncode == rc, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
     return json.loads(lines[0])
 
 
+def _fp(d):
+    return {k: d["sketch_check"][k] for k in FP}
+
+
+@pytest.mark.parametrize("launcher", [False, True], ids=["threads", "torchrun"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_ranks_times_block_equals_one_rank_on_everything(world):
+def test_ranks_times_block_equals_one_rank_on_everything(world, launcher):
     """--workload c2 (weak scaling): every rank its own G Gbase"""
     g = 0.06
-    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
-    multi = _bench(["--workload", "c2", "--gbases", str(g)] + common, world)
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--workload", "c2"]
+    multi = _bench(["--gbases", str(g)] + common, world, launcher)
     single = _bench(["--gbases", str(g * world)] + common, 1)
     assert multi["n_gpus"] == world and multi["steps"] == 2 and multi["scaling"] == "weak"
     assert multi["unit"] == "bases/s" and multi["value"] > 0 and multi["roofline"]["bound"] == "hbm"
-    assert multi["sketch_check"]["n_hashes"] == 1000
-    assert multi["sketch_check"] == single["sketch_check"]
+    assert multi["sketch_check"]["n_hashes"] == 1000 and multi["sketch_check"]["matches_golden"] is None
+    assert _fp(multi) == _fp(single)
 
 
+@pytest.mark.parametrize("launcher", [False, True], ids=["threads", "torchrun"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_c4_workload_splits_one_read_set_into_read_blocks(world):
-    """the default for N > 1 is BASELINE configs[3]'s shape (strong scaling): G Gbase IN TOTAL, rank r takes the read
-    block shard_bounds(R, r, N); the merged sketch must be the one a single rank computes on all R reads, and `value`
+def test_c4_workload_splits_one_read_set_into_read_blocks(world, launcher):
+    """the default workload is BASELINE configs[3]'s shape (strong scaling) for every N: G Gbase IN TOTAL, rank r takes the
+    read block shard_bounds(R, r, N); the merged sketch must be the one a single rank computes on all R reads, and `value`
     counts the total once."""
     g = 0.2
     common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--gbases", str(g)]
-    multi = _bench(common, world)  # (--workload defaults to c4 when N > 1)
-    single = _bench(["--workload", "c4"] + common, 1)
+    multi = _bench(common, world, launcher)  # (--workload defaults to c4 for every N)
+    single = _bench(common, 1)
     assert multi["n_gpus"] == world and multi["scaling"] == "strong" and single["scaling"] == "strong"
     assert "configs[3] generator" in multi["config"]["workload"] and "%d contiguous read blocks" % world in multi["config"]["workload"]
+    assert ("one host thread + handle per GPU" in multi["config"]["parallelism"]) == (not launcher)
     assert multi["config"]["reads_total"] == single["config"]["reads_total"] == single["config"]["reads_per_gpu"]
     assert abs(multi["config"]["reads_per_gpu"] * world - multi["config"]["reads_total"]) <= world
     assert multi["sketch_check"]["n_hashes"] == 1000
-    assert multi["sketch_check"] == single["sketch_check"]
+    assert _fp(multi) == _fp(single)
     # value = total bases * steps / time, not per-rank bases
     assert abs(multi["value"] * multi["ms_per_step"] / 1e3 - multi["config"]["reads_total"] * 150) < 1e-3 * multi["config"]["reads_total"] * 150
+
+
+def test_driver_shaped_launch_of_two_gpus_matches_the_oracle_golden_at_full_size():
+    """`python bench.py --gpus 2` exactly as the driver would type it (no launcher in front), BASELINE configs[3] at its full
+    50 Gbase, the two read blocks resident on the one GPU of this box: the line must name configs[3] and carry
+    matches_golden = true (the fingerprint the oracle computed on the CPU for the whole read set)."""
+    out = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], 2, launcher=False)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert "BASELINE configs[3]" in out["config"]["workload"] and out["config"]["reads_total"] == 333333334
+    assert out["sketch_check"]["matches_golden"] is True and out["sketch_check"]["golden"]
+
+
+def test_single_gpu_default_is_configs3_and_checks_itself():
+    out = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], 1)
+    assert "BASELINE configs[3]" in out["config"]["workload"] and out["n_gpus"] == 1 and out["scaling"] == "strong"
+    assert out["sketch_check"]["matches_golden"] is True
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["kernel"] == "k2_sketch<21>"
+
+
+def test_c5_workload_two_handles_one_call():
+    """--workload c5 on a cut-down batch (300 files: the 256 golden ones + a tail), devices = [0, 0] in ONE finch_sketch_files
+    call: per-file sketches of the sample must give the oracle's fingerprint"""
+    out = _bench(["--workload", "c5", "--files", "300", "--steps", "1", "--warmup", "0"], 2, launcher=False)
+    assert out["config"]["files"] == 300 and out["n_gpus"] == 2
+    assert out["sketch_check"]["sample_files"] == 256 and out["sketch_check"]["matches_golden"] is True
+    assert out["value"] > 0 and out["config"]["files_per_s"] > 0

@@ -631,3 +631,82 @@ def test_gzip_header_fields_in_front_of_a_member_decoded_in_parallel(monkeypatch
         z = h + body + trailer
         assert zlib.decompress(z, 31) == text
         assert H.source_probe(z, 1 << 20, len(text) + 4096) == text
+
+
+def _tiny_dynamic_block(extra_hclen):
+    """raw DEFLATE: ONE final dynamic-Huffman block holding the literal 'A', written so that the header's last code-length
+    code sits within a few bits of the end of the stream (1-bit literal, 1-bit end-of-block, one distance code of length 0).
+    extra_hclen more (zero) entries of the code-length-code table move the bit alignment of everything behind them."""
+    bits = []
+
+    def put(v, n):  # LSB first
+        for i in range(n):
+            bits.append((v >> i) & 1)
+
+    def code(c, n):  # Huffman codes go MSB first
+        for i in range(n - 1, -1, -1):
+            bits.append((c >> i) & 1)
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    cl = {18: 1, 0: 2, 1: 2}  # code-length alphabet: 18 -> '0', 0 -> '10', 1 -> '11'
+    hclen = 18 + min(extra_hclen, 1)  # symbol 1 is entry 17 of `order`: at least 18 entries
+    put(1, 1); put(2, 2)  # BFINAL, BTYPE = dynamic
+    put(0, 5); put(0, 5); put(hclen - 4, 4)  # HLIT = 257, HDIST = 1
+    for s in order[:hclen]:
+        put(cl.get(s, 0), 3)
+    canon = {18: (0, 1), 0: (2, 2), 1: (3, 2)}
+    def z(n):  # n zeros, 11..138
+        code(*canon[18]); put(n - 11, 7)
+    z(65); code(*canon[1]); z(138); z(52); code(*canon[1])  # lengths of literals 0..256: 'A' and end-of-block get 1 bit
+    code(*canon[0])                                           # the one distance code: length 0
+    code(0, 1); code(1, 1)                                    # 'A', end of block
+    while len(bits) % 8:
+        bits.append(0)
+    return bytes(sum(b << i for i, b in enumerate(bits[j:j + 8])) for j in range(0, len(bits), 8))
+
+
+def test_dynamic_block_that_ends_within_bits_of_its_header(monkeypatch):
+    """fh_inflate.h used to ask for more input when fewer than 7 bits were left in front of a code-length code -- before
+    looking at the code -- and rejected members zlib accepts: a BGZF member's input ends exactly where its DEFLATE stream does"""
+    import struct
+    import zlib
+    monkeypatch.setenv("FINCH_BGZF_THREADS", "4")
+    for extra in (0, 1):
+        raw = _tiny_dynamic_block(extra)
+        d = zlib.decompressobj(-15)
+        assert d.decompress(raw) == b"A" and d.eof
+        # several members: a FASTQ record split over members, the tiny dynamic block being one of them
+        parts = [b"@r\nAC", b"A", b"GT\n+\nIIII\n"]
+        bg = b""
+        for i, t in enumerate(parts):
+            if i == 1:
+                body = raw
+            else:
+                c = zlib.compressobj(6, zlib.DEFLATED, -15)
+                body = c.compress(t) + c.flush()
+            bg += (b"\x1f\x8b\x08\x04\0\0\0\0\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(body) + 25) + body +
+                   struct.pack("<II", zlib.crc32(t), len(t)))
+        bg += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")  # BGZF end-of-file marker
+        assert zlib.decompress(bg[:len(bg) - 28], 31) == parts[0]  # (framing sanity: the first member is a gzip member)
+        assert H.source_probe(bg, 1 << 16, 4096) == b"".join(parts)
+
+
+def test_parallel_gzip_keeps_going_through_a_very_compressible_member(tmp_path):
+    """the guard against false starts (a chunk that inflates past 64 MiB and 256x its compressed size) must not fire on a
+    chunk whose start is known: 70 MB of N inflate from ~70 KB, and the parallel reader must neither hand the stream to the
+    sequential one (everything decoded twice) nor -- on a pipe -- call it corrupt"""
+    import os
+    import subprocess
+    import sys
+    text = b">n\n" + b"N" * (70 << 20) + b"\n"
+    z = gzip.compress(text, 6)
+    p = tmp_path / "n.fa.gz"
+    p.write_bytes(z)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys, hashlib; sys.path.insert(0, %r)\nfrom finch_rs_amd import host as H\n"
+            "d = H.source_probe(open(%r, 'rb').read(), 1 << 22, %d)\nprint(len(d), hashlib.md5(d).hexdigest())" % (root, str(p), len(text) + 64))
+    r = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, FH_TRACE="1", FINCH_BGZF_THREADS="4"), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True)
+    import hashlib
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split() == [str(len(text)), hashlib.md5(text).hexdigest()]
+    assert "parallel gzip" in r.stderr and "sequential reader took over" not in r.stderr, r.stderr[-2000:]

@@ -373,6 +373,24 @@ def test_malformed_messages_are_errors_not_crashes(golden_dir):
             H.sketches_from_bsk(data)
         with pytest.raises(FinchError):
             H.sketches_from_msh(data)
+    # lists that claim elements without bytes behind them: a void list / bit list / composite list of empty structs with
+    # a count of 2^29 - 1 fits a 24 .. 40-byte message.  Errors -- the capnp runtime charges such elements against its
+    # traversal limit -- never an allocation for half a billion sketches (which used to end in std::terminate)
+    def seg(*words):
+        body = b"".join(struct.pack("<Q", w) for w in words)
+        return struct.pack("<II", 0, len(body) // 8) + body
+    huge = (1 << 29) - 1
+    root = 0 | (0 << 32) | (1 << 48)  # struct pointer: offset 0, no data words, one pointer
+    bombs = [seg(root, 1 | (0 << 32) | (huge << 35)),                      # List(Void)
+             seg(root, 1 | (1 << 32) | (7 << 35)),                         # List(Bool) -- cannot be a struct list
+             seg(root, 1 | (7 << 32) | (0 << 35), (huge << 2)),            # composite, tag says 2^29-1 elements of 0 words
+             seg(root, 1 | (2 << 32) | (16 << 35), 0, 0)]                  # List(UInt8)
+    for data in bombs:
+        for fn in (H.sketches_from_bsk, H.sketches_from_msh):
+            with pytest.raises(FinchError):
+                got = fn(data)
+                if len(got) == 0:  # (a message that decodes to nothing is fine too)
+                    raise FinchError("empty")
     # the wrong schema behind the right framing: whatever it decodes to, or a clean error -- never a crash
     for fn, blob in ((H.sketches_from_msh, raw), (H.sketches_from_bsk, rawm)):
         try:
