@@ -1,14 +1,13 @@
 #!/bin/bash
 # full-size bench + rocprofv3 kernel stats + PMC passes for the roofline block
 # usage: bash tools/gpu_bench_full.sh <tag> [<pmc key> [bench args...]]   -> gpurun_out/<tag>_*
-#   default: configs[1] (10 Gbase, k=21, n=1000), key c2_k21_n1000
-#   e.g.     bash tools/gpu_bench_full.sh r02a_k31 c2_k31_n1000 --k 31
-TAG=${1:-r02}; KEY=${2:-c2_k21_n1000}; shift; shift
+#   default: configs[3] (50 Gbase, k=21, n=1000), key c4_k21_n1000
+#   e.g.     bash tools/gpu_bench_full.sh r03_k31 c2_k31_n1000 --workload c2 --k 31
+TAG=${1:-r03}; KEY=${2:-c4_k21_n1000}; shift; shift
 ARGS="$@"
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-if [ -z "$ARGS" ]; then python bench.py --steps 5 --warmup 1 2>&1 | tail -1 | tee gpurun_out/${TAG}_bench_10G.json
-else python bench.py --steps 5 --warmup 1 --no-extras $ARGS 2>&1 | tail -1 | tee gpurun_out/${TAG}_bench_10G.json; fi
+python bench.py --steps 5 --warmup 1 --no-extras --no-cpu-baseline $ARGS 2>&1 | tail -1 | tee gpurun_out/${TAG}_bench.json
 cd /tmp
 B="python $R/bench.py --no-cpu-baseline --no-extras $ARGS"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o stats --output-format csv -- $B --steps 5 --warmup 1 > $R/gpurun_out/${TAG}_stats.log 2>&1
@@ -41,5 +40,9 @@ json.dump(out,open("gpurun_out/%s_pmc_k2.json"%tag,"w"),indent=1)
 print(json.dumps(out,indent=1))
 PY
 head -6 gpurun_out/${TAG}_stats/stats_kernel_stats.csv
-cp gpurun_out/${TAG}_stats/stats_kernel_stats.csv gpurun_out/${TAG}_kernel_stats_bench10G.csv
-echo "KEY=$KEY positions=$(python -c "import json;print(json.load(open('gpurun_out/${TAG}_pmc_k2.json')).get('positions'))")"
+cp gpurun_out/${TAG}_stats/stats_kernel_stats.csv gpurun_out/${TAG}_kernel_stats.csv
+POS=$(python -c "import json;print(json.load(open('gpurun_out/${TAG}_pmc_k2.json')).get('positions'))")
+echo "KEY=$KEY positions=$POS"
+# per-wave-iteration summary of this set -> gpurun_out/${TAG}_pmc_summary.json (merge into profiles/pmc_summary.json with
+#   python tools/pmc_summary.py $KEY profiles/${TAG}_pmc_k2.json $POS   after copying the counter file to profiles/)
+python tools/pmc_summary.py $KEY gpurun_out/${TAG}_pmc_k2.json $POS --out gpurun_out/${TAG}_pmc_summary.json

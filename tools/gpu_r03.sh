@@ -9,5 +9,17 @@ ab_rounds)   # parity of the round structure + A/B of the variants
   timeout 900 python tools/ab_k.py --libs base=build/ab/base.so,r8=finch_rs_amd/libfinch_hip.so,r16=build/ab/r16.so,r8w5=build/ab/r8w5.so,r8from22=build/ab/r8from22.so \
       --ks 21,22,24,25,28,31,32 2>&1 | tee gpurun_out/r03_ab_rounds.txt
   ;;
+suite)       # box facts, the whole GPU suite, the default bench line, the driver-shaped 2-"GPU" launch
+  (nproc; free -g | head -2; df -h /dev/shm /tmp | cat; rocm-smi --showmeminfo vram 2>/dev/null | head -8) > gpurun_out/r03_box.txt 2>&1
+  timeout 2400 python -m pytest tests -x -q -m gpu -rs --durations=15 2>&1 | tail -40 | tee gpurun_out/r03_pytest_gpu_tail.txt
+  timeout 900 python bench.py --steps 10 --warmup 2 > gpurun_out/r03_bench_default.json 2> gpurun_out/r03_bench_default.err; echo "bench rc=$?"
+  timeout 600 python bench.py --gpus 2 --share-gpu --steps 5 --warmup 1 > gpurun_out/r03_bench_gpus2_share.json 2> gpurun_out/r03_bench_gpus2_share.err; echo "bench2 rc=$?"
+  ;;
+pmc)         # rocprofv3 kernel stats + PMC passes: configs[3] (headline), k=31 (spill-free now), and the two-word kernels
+  bash tools/gpu_bench_full.sh r03_c4 c4_k21_n1000
+  bash tools/gpu_bench_full.sh r03_k31 c2_k31_n1000 --workload c2 --k 31
+  bash tools/gpu_bench_full.sh r03_k33 c2_k33_n1000 --workload c2 --k 33
+  bash tools/gpu_bench_full.sh r03_k64 c2_k64_n1000 --workload c2 --k 64
+  ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac

@@ -47,6 +47,35 @@ def compile_one(src, defs, flags, asm=None):
     return notes(elf)
 
 
+FAST = {"v_and_b32", "v_or_b32", "v_xor_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_lshrrev_b32", "v_mov_b32", "v_not_b32",
+        "v_bitop3_b32", "v_accvgpr_read_b32", "v_accvgpr_write_b32"}  # ~2.4 cycles per wave64 instruction (profiles/r01_ubench_valu_rates.txt)
+
+
+def hot_mix(asm_path, kernel_substr):
+    """VALU / LDS instructions per position in the hot loop of a sketch kernel: the stretch of code between the first and the
+    last per-position reject test (v_cmp_ge_u32 vcc, s.., v.. ; s_cbranch_vccnz -> the out-of-line admit path), divided by the
+    number of tests in it.  Classes by issue cost on gfx950: fast ~2.4 cycles (FAST above), slow ~4.15 (everything else)."""
+    txt = open(asm_path).read()
+    for f in re.split(r"\n(?=[0-9a-f]+ <[^>]+>:)", txt):
+        m = re.match(r"[0-9a-f]+ <([^>]+)>:", f)
+        if not m or kernel_substr not in m.group(1):
+            continue
+        ops = [ln.split()[0] for ln in (x.strip() for x in f.split("\n")[1:]) if ln and not ln.startswith("//")]
+        lines = [ln.strip() for ln in f.split("\n")[1:] if ln.strip() and not ln.strip().startswith("//")]
+        tests = [i for i, ln in enumerate(lines) if ln.startswith("s_cbranch_vccnz") and i >= 1 and
+                 any(l2.startswith("v_cmp_ge_u32_e32 vcc, s") for l2 in lines[max(0, i - 3):i])]
+        if len(tests) < 2:
+            return None
+        seg = ops[tests[0] + 1:tests[-1] + 1]
+        n = len(tests) - 1
+        valu = [o for o in seg if o.startswith("v_") and not o.startswith("v_readlane") and not o.startswith("v_readfirstlane")]
+        fast = sum(1 for o in valu if re.sub(r"_e(32|64)$", "", o) in FAST)
+        lds = sum(1 for o in seg if o.startswith("ds_"))
+        return {"positions": n, "valu": round(len(valu) / n, 2), "valu_fast": round(fast / n, 2), "valu_slow": round((len(valu) - fast) / n, 2),
+                "lds": round(lds / n, 2), "issue_cycles": round((fast * 2.4 + (len(valu) - fast) * 4.15) / n, 1)}
+    return None
+
+
 def pretty(name):
     m = re.match(r"_ZN2fh9k2_sketchILi(\d+)ELb(\d)ELb(\d)ELb(\d)EEE", name)
     if m:
@@ -70,9 +99,12 @@ def main():
     ap.add_argument("--flags", default=None, help="replaces the build's extra flags for the sketch kernel")
     ap.add_argument("-D", action="append", default=[])
     ap.add_argument("--all-variants", action="store_true", help="list the masked / seeded / re-read variants too")
+    ap.add_argument("--mix", action="store_true", help="with --k: VALU instruction classes per position of the hot loop (static, from the ISA)")
     args = ap.parse_args()
     kflags = args.flags.split() if args.flags is not None else list(B.K2_FLAGS)
     rows = []
+    if args.k is not None and args.mix and not args.asm:
+        args.asm = os.path.join(tempfile.mkdtemp(prefix="k2mix_"), "k.s")
     if args.k is not None:
         if args.k <= 32:
             rows = compile_one("fh_k2.hip", ["FH_PART=0", "FH_ONLY_K=%d" % args.k] + args.D, kflags, args.asm)
@@ -95,6 +127,11 @@ def main():
     print("%-28s %5s %6s %8s %5s %6s" % ("kernel", "VGPR", "spill", "scratch", "SGPR", "LDS"))
     for r in sorted(rows, key=key):
         print("%-28s %5s %6s %8s %5s %6s" % (pretty(r["name"]), r["vgpr"], r["spill"], r["scratch"], r["sgpr"], r["lds"]))
+
+
+    if args.mix and args.k is not None:
+        sub = "k2_sketchILi%dELb0ELb1ELb0E" % args.k if args.k <= 32 else "k2_sketch_wILi%dE" % args.k
+        print("hot loop per position:", hot_mix(args.asm, sub))
 
 
 if __name__ == "__main__":

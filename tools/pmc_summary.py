@@ -25,6 +25,11 @@ def main():
     def c(name):
         v = d.get(name)
         return float(v["sum"]) if isinstance(v, dict) else (float(v) if v is not None else None)
+    outp = None
+    if "--out" in sys.argv:
+        i = sys.argv.index("--out")
+        outp = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     launches = int(sys.argv[4]) if len(sys.argv) > 4 else int(d["SQ_INSTS_VALU"]["dispatches"])
     wi = positions / 64.0
     cycles = c("GRBM_GUI_ACTIVE") / XCDS  # device cycles while the launches ran
@@ -40,15 +45,37 @@ def main():
         # plain 32-bit and/or/xor/add/sub/shift-right, profiles/r01_ubench_valu_rates.txt)
         "cycles_per_wave_iter": round(cycles * SIMDS / wi, 1),
         "cycles_per_valu_inst": round(cycles * SIMDS / c("SQ_INSTS_VALU"), 3),
-        # rocprof's VALUBusy: 4 cycles per VALU instruction over the SIMD cycles available
-        "valu_busy": round(4.0 * c("SQ_ACTIVE_INST_VALU") / SIMDS / cycles, 3) if c("SQ_ACTIVE_INST_VALU") else None,
         "wait_any_frac_of_wave_cycles": round(c("SQ_WAIT_ANY") / c("SQ_WAVE_CYCLES"), 3) if c("SQ_WAIT_ANY") and c("SQ_WAVE_CYCLES") else None,
     }
+    # The issue-cycle model of the hot loop: its VALU instructions per position counted in the ISA (tools/k2_regs.py --mix),
+    # priced at what gfx950 issues them at (~2.4 cycles the plain and/or/xor/add/shift-right/mov, ~4.15 everything else:
+    # profiles/r01_ubench_valu_rates.txt) -- the share of the measured cycles per wave-iteration that is pure VALU issue.
+    try:
+        import re
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import k2_regs
+        K = int(re.search(r"_k(\d+)_", key).group(1))
+        if K <= 32:
+            asm = os.path.join(tempfile.mkdtemp(prefix="pmcmix_"), "k.s")
+            sys.path.insert(0, k2_regs.CSRC)
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("fh_build", os.path.join(k2_regs.CSRC, "build.py"))
+            B = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(B)
+            k2_regs.compile_one("fh_k2.hip", ["FH_PART=0", "FH_ONLY_K=%d" % K], list(B.K2_FLAGS), asm)
+            mix = k2_regs.hot_mix(asm, "k2_sketchILi%dELb0ELb1ELb0E" % K)
+            if mix:
+                out["valu_issue_model"] = {"hot_loop_valu_fast_per_position": mix["valu_fast"], "hot_loop_valu_slow_per_position": mix["valu_slow"],
+                                           "hot_loop_lds_per_position": mix["lds"], "issue_cycles_per_wave_iter": mix["issue_cycles"],
+                                           "frac_of_measured_cycles": round(mix["issue_cycles"] / out["cycles_per_wave_iter"], 3)}
+    except Exception as e:  # noqa: BLE001 -- no compiler here: the counters stand on their own
+        out["valu_issue_model"] = {"error": str(e)[:200]}
     if c("FETCH_SIZE") is not None:
         hbm = 2.0 * c("FETCH_SIZE") * 1024.0 + (c("WRITE_SIZE") or 0.0) * 1024.0
         out["hbm_bytes_per_launch"] = int(hbm / launches)
         out["hbm_bytes_per_position"] = round(hbm / positions, 4)
-    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    p = outp or os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
         allp = json.load(open(p))
     except Exception:
