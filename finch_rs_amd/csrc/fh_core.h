@@ -304,6 +304,10 @@ struct Windows {
     }
     // the canonical m-form word << PRE
     FH_HDM u64 canonical(int j, bool &is_rc) const {
+#ifdef FH_EXP_FWD_ONLY // measurement only -- WRONG sketches: the ceiling of any cheaper strand decision (profiles/r03_*)
+        is_rc = false;
+        return fwd(j);
+#endif
         const u64 f = fwd(j), r = rc(j);
         is_rc = !(f < r);
         return is_rc ? r : f;
@@ -533,6 +537,18 @@ FH_HD u32 field_off(u32 cml, u32 cmh, int shift, int nb, int lg) {
     return (cml << (-sh)) & fm;
 }
 
+// one A record as ONE 16-byte load (a vector load: the compiler splits a load of the struct into an 8- and a 4-byte -- or two
+// 8-byte -- LDS reads when it sees that the fourth dword is unused, and every one of those costs what the 16-byte read does)
+FH_HD Rec4 load_rec4(const Rec4 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = *(const u32x4 *)p;
+    return Rec4{v.x, v.y, v.z, v.w};
+#else
+    return *p;
+#endif
+}
+
 template <int K>
 FH_HD void murmur_lookup(u64 cm, const LutTables &T, KeyWords<K> &w) { // cm = canonical word << pre_shift(K)
     constexpr int PRE = pre_shift(K);
@@ -548,7 +564,7 @@ FH_HD void murmur_lookup(u64 cm, const LutTables &T, KeyWords<K> &w) { // cm = c
             w.a0[i] = r.x;
             w.a1[i] = r.y;
         } else if (g.kind == 2) {
-            const Rec4 ra = *(const Rec4 *)((const char *)(g.is_k2 ? T.A2 : T.A1) + field_off(cml, cmh, g.shiftA + PRE, 4, 4));
+            const Rec4 ra = load_rec4((const Rec4 *)((const char *)(g.is_k2 ? T.A2 : T.A1) + field_off(cml, cmh, g.shiftA + PRE, 4, 4)));
 #if defined(__HIP_DEVICE_COMPILE__)
             // A 16-byte LDS read costs 9.5 cycles per wave, the 12-byte read the compiler narrows this to costs 16
             // (tools/ubench_lds.hip), so the unused fourth dword is kept "live".  Measured: k = 14-16 +3 %, k = 21 +2.7 %,
@@ -557,6 +573,11 @@ FH_HD void murmur_lookup(u64 cm, const LutTables &T, KeyWords<K> &w) { // cm = c
 #endif
             const Rec2 *TB = g.partial ? T.P : (g.is_k2 ? T.B2 : T.B1);
             const Rec2 rb = *(const Rec2 *)((const char *)TB + field_off(cml, cmh, g.shiftB + PRE, g.nbB, 3));
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FH_NO_B64_KEEP)
+            // likewise an 8-byte read (6.5 cycles per wave under random-index bank conflicts) beats the 4-byte one (9) the
+            // compiler narrows a k2 word's B record to -- only its first dword is used there (tools/ubench_lds.hip)
+            if (g.is_k2) asm volatile("" ::"v"(rb.y));
+#endif
             w.a0[i] = ra.x;
             w.a1[i] = ra.y;
             w.a2[i] = ra.z;
@@ -863,9 +884,16 @@ FH_HD void murmur_lookup_w(const u32 *cm, const LutTables &T, KeyWords<K> &w) { 
             w.a0[i] = r.x;
             w.a1[i] = r.y;
         } else if (g.kind == 2) {
-            const Rec4 ra = *(const Rec4 *)((const char *)(g.is_k2 ? T.A2 : T.A1) + field_off_w(cm, g.shiftA + PRE, 4, 4));
+            const Rec4 ra = load_rec4((const Rec4 *)((const char *)(g.is_k2 ? T.A2 : T.A1) + field_off_w(cm, g.shiftA + PRE, 4, 4)));
             const Rec2 *TB = g.partial ? T.P : (g.is_k2 ? T.B2 : T.B1);
             const Rec2 rb = *(const Rec2 *)((const char *)TB + field_off_w(cm, g.shiftB + PRE, g.nbB, 3));
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FH_NO_B64_KEEP)
+            // one 16-byte and one 8-byte LDS read per word, as in murmur_lookup: left alone the compiler splits the A record
+            // into an 8- and a 4-byte read (its fourth dword is unused) and narrows a k2 word's B record to 4 bytes -- 13 LDS
+            // instructions per position at K = 33 on a kernel that lives off the LDS pipe (profiles/r03_k33_*)
+            asm volatile("" ::"v"(ra.w));
+            if (g.is_k2) asm volatile("" ::"v"(rb.y));
+#endif
             w.a0[i] = ra.x;
             w.a1[i] = ra.y;
             w.a2[i] = ra.z;

@@ -211,21 +211,41 @@ struct ByteSource {
     virtual unsigned threads_hint() const { return 1; } // host threads the reader of this source may use
 };
 
+static unsigned read_threads_total(const char *env);
+
 struct MemSource : ByteSource {
     const uint8_t *p;
     size_t n, off = 0;
-    MemSource(const uint8_t *p_, size_t n_) : p(p_), n(n_) {}
+    unsigned n_thr; // threads a large read may use (finch_sketch_buffer: FINCH_READ_THREADS)
+    MemSource(const uint8_t *p_, size_t n_, unsigned read_threads = 1) : p(p_), n(n_), n_thr(std::max(1u, read_threads)) {}
     bool can_rewind() const override { return true; }
     bool rewind() override {
         off = 0;
         return true;
     }
+    // A large read is a copy into a pinned staging buffer: one thread moves ~10 GB/s, less than half of what the PCIe link
+    // behind it takes, so the 64 MiB chunks of the device-side text paths are copied by a few threads (as FileSource reads).
     size_t read(uint8_t *dst, size_t cap) override {
         const size_t m = std::min(cap, n - off);
-        memcpy(dst, p + off, m);
+        const size_t PAR_MIN = (size_t)16 << 20;
+        if (m < PAR_MIN || n_thr < 2) {
+            memcpy(dst, p + off, m);
+        } else {
+            const size_t per = ((m + n_thr - 1) / n_thr + 4095) & ~(size_t)4095;
+            const uint8_t *src = p + off;
+            auto job = [=](unsigned t) {
+                const size_t lo = std::min(m, (size_t)t * per), hi = std::min(m, lo + per);
+                if (lo < hi) memcpy(dst + lo, src + lo, hi - lo);
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < n_thr; ++t) th.emplace_back(job, t);
+            job(0);
+            for (auto &x : th) x.join();
+        }
         off += m;
         return m;
     }
+    unsigned threads_hint() const override { return n_thr; }
 };
 
 struct FileSource : ByteSource {
@@ -2955,7 +2975,8 @@ int finch_sketch_buffer(const uint8_t *data, uint64_t len, const char *name, con
     handles.device = device;
     auto res = std::make_unique<finch_sketches>();
     res->v.resize(1);
-    const int rc = sketch_stream(std::make_unique<MemSource>(data, (size_t)len), name ? name : "", *sp, *filters, handles, res->v[0]);
+    const int rc = sketch_stream(std::make_unique<MemSource>(data, (size_t)len, read_threads_total(getenv("FINCH_READ_THREADS"))),
+                                 name ? name : "", *sp, *filters, handles, res->v[0]);
     if (rc != FH_OK) return rc;
     *out = res.release();
     return FH_OK;

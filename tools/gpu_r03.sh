@@ -21,5 +21,14 @@ pmc)         # rocprofv3 kernel stats + PMC passes: configs[3] (headline), k=31 
   bash tools/gpu_bench_full.sh r03_k33 c2_k33_n1000 --workload c2 --k 33
   bash tools/gpu_bench_full.sh r03_k64 c2_k64_n1000 --workload c2 --k 64
   ;;
+ab_lds)      # wide LDS reads (16-byte A records, 8-byte B records everywhere) vs round 2's build and vs 4-byte B reads; fwd-only ceiling
+  timeout 900 python tools/ab_k.py --libs r02=build/ab/base.so,cur=finch_rs_amd/libfinch_hip.so,nob64=build/ab/nob64.so,fwdonly=build/ab/fwdonly.so \
+      --ks 16,21,24,27,31,32,33,48,64 2>&1 | tee gpurun_out/r03_ab_lds.txt
+  ;;
+e2e)         # where the end-to-end paths spend their time
+  python tools/e2e_trace.py 4000000 1,4,8,16 > gpurun_out/r03_e2e_trace.txt 2> gpurun_out/r03_e2e_trace.err
+  python tools/one_worker_trace.py > gpurun_out/r03_one_worker.txt 2>&1
+  python tools/batch_threads.py > gpurun_out/r03_batch_threads.txt 2>&1
+  ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
