@@ -40,6 +40,7 @@ SYMBOLS = {
     "fh_push_block_ex": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32]),
     "fh_text_buffer": (C.c_int, [_P, C.POINTER(_P), _U64P]),
     "fh_text_buffers": (C.c_int, [_P, C.POINTER(_P), _U64P, C.POINTER(C.c_int)]),
+    "fh_text_prefetch": (C.c_int, [_P, C.c_int, C.c_uint64]),
     "fh_push_fastq_text": (C.c_int, [_P, C.c_uint64]),
     "fh_push_bgzf_fastq": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32]),
     "fh_bgzf_text_capacity": (C.c_int, [_P, _U64P]),

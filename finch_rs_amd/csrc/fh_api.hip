@@ -160,6 +160,10 @@ struct fh_sketcher {
     uint8_t *h_stage[N_STAGE] = {nullptr, nullptr};
     uint8_t *d_stage[N_STAGE] = {nullptr, nullptr};
     hipEvent_t stage_done[N_STAGE] = {nullptr, nullptr};
+    // fh_text_prefetch: the copy stream (created on first use, by the reader's thread) and, per slot, the length whose
+    // host-to-device copy is already under way (0 = none)
+    hipStream_t copy_stream = nullptr;
+    uint64_t stage_prefetched[N_STAGE] = {0, 0};
     bool stage_busy[N_STAGE] = {false, false};
     uint64_t stage_cap[N_STAGE] = {0, 0}; // bytes a slot can hold (<= stage_bytes; slots grow with the pushes they serve)
     int stage_next = 0;
@@ -279,6 +283,11 @@ int init_state(fh_sketcher *s) {
     s->dprev_len = 0;
     s->bgzf_left_len = 0;
     bgzf_quiesce(s);
+    for (int i = 0; i < N_STAGE; ++i) // a copy fh_text_prefetch started for a stream that was then abandoned
+        if (s->stage_prefetched[i]) {
+            (void)hipEventSynchronize(s->stage_done[i]);
+            s->stage_prefetched[i] = 0;
+        }
     s->halo_len = 0;
     s->live_target = s->big_mode ? std::max<uint64_t>(4 * s->p.size, 1ull << 16) : (uint64_t)SMALL_MAX;
     s->finished = false;
@@ -601,12 +610,17 @@ int sampled_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
         HIP_TRY(dev_malloc(&s->smp_list, (size_t)n_runs * 2 * sizeof(uint32_t)));
         s->smp_list_cap = n_runs;
     }
-    // cap: the sample may put about 2 x size occurrences into the table (half its soft limit); the estimate has to reach
-    // 1.25 x size distinct k-mers BELOW the cap, and an occurrence sample sees a k-mer of multiplicity m with probability
-    // ~m / 64 only
+    // cap: the estimate has to reach `want` distinct k-mers BELOW the cap, and an occurrence sample sees a k-mer of
+    // multiplicity m with probability ~m / 64 only.  The pass is bound by its admits, not by the positions it reads, so it
+    // first runs at a cap that lets about size / 2 sample occurrences into the table (reads with sequencing errors: most
+    // distinct k-mers are singletons, and the estimate crosses `want` far below even that); only if the estimate does not
+    // get there is the pass repeated at 2 x size occurrences (half the table's soft limit).
     const double n_samples = (double)n_runs * SAMPLE_RUN_TILES * TILE_POS;
-    const double cap_frac = std::min(0.25, 2.0 * (double)s->p.size / n_samples);
-    const uint64_t tau_cap = (uint64_t)(cap_frac * 18446744073709551616.0);
+    uint64_t tau_guess = 0, tau_cap = 0;
+    double S = 0, c1 = 0, c2 = 0;
+    for (const double cap_occ : {0.5, 2.0}) {
+    const double cap_frac = std::min(0.25, cap_occ * (double)s->p.size / n_samples);
+    tau_cap = (uint64_t)(cap_frac * 18446744073709551616.0);
     // ---- the sample pass: the sketch kernel over the tile runs, handed over as a "leftover" list ----
     if (int rc = set_tau(s, tau_cap)) return rc;
     HIP_TRY(launch_fill_tile_runs(s->smp_list, (uint32_t)n_runs, stride, SAMPLE_RUN_TILES, (uint32_t)tiles, s->stream));
@@ -662,21 +676,36 @@ int sampled_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
     s->last_tau = initial_tau(s);
     s->last_live = 0;
     if (!sample_clean) return FH_OK; // (a stream of few, very frequent k-mers filled a wave's budget: nothing to estimate)
-    // smallest quarter-octave edge below which the whole block is estimated to hold 1.25 x size distinct hashes
+    // The threshold below which the whole block is estimated to hold `want` distinct hashes: the first quarter-octave
+    // bucket whose upper edge reaches the estimate, and within it the point where the estimate -- linear in the threshold
+    // inside a bucket, hashes being uniform -- crosses `want`.  (Taking the bucket's upper edge, a factor 2^(1/4) above its
+    // lower one, left up to 1.49 x size entries live where 1.25 x was asked for: round 2's configs[2].)  The estimator
+    // (Chao1: seen + singletons^2 / 2 doubletons) errs low, i.e. towards a threshold that is too high, never too tight.
+    static const double want_factor = [] {
+        const char *e = getenv("FH_SAMPLE_WANT"); // A/B knob
+        return e ? std::max(1.0, atof(e)) : 1.15;
+    }();
     const uint32_t *H = s->h_smp_hist;
-    const double want = 1.25 * (double)s->p.size;
-    double S = 0, c1 = 0, c2 = 0;
-    uint64_t tau_guess = 0;
+    const double want = want_factor * (double)s->p.size;
+    double est_prev = -1.0;
+    S = c1 = c2 = 0;
     const uint32_t q_cap = qoct_index(tau_cap);
     for (uint32_t q = 0; q < 256 && q < q_cap; ++q) { // (the bucket that holds the cap is only partly sampled)
         S += H[q];
         c1 += H[256 + q];
         c2 += H[512 + q];
         if (S < 1024 || c2 < 32) continue; // too few doubletons to say anything about the unseen
-        if (S + c1 * c1 / (2.0 * c2) >= want) {
-            tau_guess = qoct_upper_edge(q);
+        const double est = S + c1 * c1 / (2.0 * c2);
+        if (est >= want) {
+            const uint64_t hi = qoct_upper_edge(q), lo = q ? qoct_upper_edge(q - 1) : 0;
+            tau_guess = hi;
+            if (est_prev >= 0.0 && est > est_prev && want > est_prev)
+                tau_guess = lo + (uint64_t)((double)(hi - lo) * std::min(1.0, (want - est_prev) / (est - est_prev)));
             break;
         }
+        est_prev = est;
+    }
+    if (tau_guess || cap_frac >= 0.25) break;
     }
     static const bool trace = getenv("FH_TRACE") != nullptr;
     if (trace)
@@ -1272,6 +1301,10 @@ void destroy_handle(fh_sketcher *s) {
     (void)hipFree(s->o_pos);
     (void)hipFree(s->o_count);
     (void)hipFree(s->o_extra);
+    if (s->copy_stream) {
+        (void)hipStreamSynchronize(s->copy_stream);
+        (void)hipStreamDestroy(s->copy_stream);
+    }
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1415,9 +1448,10 @@ int fh_text_buffer(fh_sketcher *s, uint8_t **buf, uint64_t *cap) {
     if (int rc = set_device(s)) return rc;
     if (int rc = ensure_stage(s)) return rc;
     const int b = s->stage_next;
-    if (s->stage_busy[b]) {
+    if (s->stage_busy[b] || s->stage_prefetched[b]) {
         HIP_TRY(hipEventSynchronize(s->stage_done[b]));
         s->stage_busy[b] = false;
+        s->stage_prefetched[b] = 0;
     }
     *buf = s->h_stage[b] + STAGE_HEADROOM; // room in front for the K-1 carry bytes of fh_push_staged
     *cap = s->stage_bytes;
@@ -1429,9 +1463,10 @@ int fh_text_buffers(fh_sketcher *s, uint8_t *bufs[2], uint64_t *cap, int *next) 
     if (int rc = set_device(s)) return rc;
     if (int rc = ensure_stage(s)) return rc;
     for (int i = 0; i < N_STAGE; ++i) {
-        if (s->stage_busy[i]) {
+        if (s->stage_busy[i] || s->stage_prefetched[i]) { // (a prefetch nobody consumed: an aborted stream)
             HIP_TRY(hipEventSynchronize(s->stage_done[i]));
             s->stage_busy[i] = false;
+            s->stage_prefetched[i] = 0;
         }
         bufs[i] = s->h_stage[i] + STAGE_HEADROOM;
     }
@@ -1519,11 +1554,30 @@ int fh_push_fastq_text(fh_sketcher *s, uint64_t len) {
     if (int rc = ensure_fastq_scratch(s, b)) return rc;
     // the packed buffer of this slot may still feed a pending range
     if (int rc = drain(s)) return rc;
-    HIP_TRY(hipMemcpyAsync(s->d_stage[b], s->h_stage[b] + STAGE_HEADROOM, len, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+    if (s->stage_prefetched[b] == len) { // the reader's thread has the copy under way (fh_text_prefetch)
+        HIP_TRY(hipStreamWaitEvent(s->stream, s->stage_done[b], 0));
+    } else {
+        if (s->stage_prefetched[b]) HIP_TRY(hipEventSynchronize(s->stage_done[b])); // (a prefetch of something else: let it land first)
+        HIP_TRY(hipMemcpyAsync(s->d_stage[b], s->h_stage[b] + STAGE_HEADROOM, len, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+    }
+    s->stage_prefetched[b] = 0;
     s->stage_busy[b] = true;
     s->stage_next = (b + 1) % N_STAGE;
     return fastq_text_on_device(s, s->d_stage[b], len, s->d_packed[b], s->d_blk_a[b], s->d_blk_b[b], s->d_lines, s->line_cap);
+}
+
+// (called by the reader's thread: touches nothing but slot `slot`'s copy state and the copy stream.  The slot's device
+//  buffer is free: the push that last used it returned after its record-splitting kernel had read it.)
+int fh_text_prefetch(fh_sketcher *s, int slot, uint64_t len) {
+    if (!s || slot < 0 || slot >= N_STAGE) return fail(FH_ERR_INVALID, "bad argument");
+    if (len == 0 || len > s->stage_cap[slot] || !s->d_stage[slot] || !s->stage_done[slot] || s->stage_prefetched[slot]) return FH_OK; // the push will copy
+    if (int rc = set_device(s)) return rc;
+    if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipMemcpyAsync(s->d_stage[slot], s->h_stage[slot] + STAGE_HEADROOM, len, hipMemcpyHostToDevice, s->copy_stream));
+    HIP_TRY(hipEventRecord(s->stage_done[slot], s->copy_stream));
+    s->stage_prefetched[slot] = len;
+    return FH_OK;
 }
 
 static_assert(sizeof(fh_bgzf_member) == sizeof(BgzfMember) && offsetof(fh_bgzf_member, crc32) == offsetof(BgzfMember, crc),

@@ -2408,6 +2408,9 @@ static int pump_text_to_device(ByteSource &src, fh_sketcher *h, bool fastq, uint
                 is_free[b->id] = true;
             },
             [&](const ShardWork &job) {
+                // FASTQ: the chunk's copy to the device starts now, behind the previous chunk's, while that one's push is
+                // still busy with its record-splitting kernel -- the link never idles between pushes
+                if (fastq) (void)fh_text_prefetch(h, job.buf->id, job.len);
                 std::lock_guard<std::mutex> g(mu);
                 ready.push_back(job);
                 fill ^= 1;

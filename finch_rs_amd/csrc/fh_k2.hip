@@ -28,13 +28,7 @@
 #error "compile with -DFH_PART=<0..FH_NPARTS-1>"
 #endif
 
-#ifndef FH_UNROLL
-#define FH_UNROLL 32
-#endif
-
 namespace fh {
-
-constexpr int UNROLL_J = FH_UNROLL;
 
 // ------------------------------------------------------------------------------------------------
 // K2

@@ -112,6 +112,12 @@ int fh_text_buffer(fh_sketcher *s, uint8_t **buf, uint64_t *cap);
  * push of the other buffer is still running on another thread; the handle itself stays single-threaded. */
 int fh_text_buffers(fh_sketcher *s, uint8_t *bufs[2], uint64_t *cap, int *next);
 int fh_push_fastq_text(fh_sketcher *s, uint64_t len);
+/* Optional: start the host-to-device copy of staging buffer `slot` (0 / 1 of fh_text_buffers, filled with `len` bytes) right
+ * away, on the handle's copy stream -- the one call a SECOND thread (the reader that has just filled the buffer) may make
+ * while a push of the other buffer is running.  The fh_push_fastq_text that later consumes the slot with the same `len`
+ * finds its text already on the way; without the call the push copies by itself.  This is what keeps the PCIe link busy
+ * across pushes (a push also waits for its record-splitting kernel). */
+int fh_text_prefetch(fh_sketcher *s, int slot, uint64_t len);
 /* BGZF-compressed FASTQ, inflated on the device (one wavefront per member, CRC-32 checked there too).  The caller fills
  * the text buffer of fh_text_buffers with n_members fh_bgzf_member records followed by the members' raw DEFLATE bytes
  * (`bytes` in all): in_off / in_len = a member's DEFLATE data counted from the start of the buffer (after the 18-byte BGZF

@@ -30,5 +30,18 @@ e2e)         # where the end-to-end paths spend their time
   python tools/one_worker_trace.py > gpurun_out/r03_one_worker.txt 2>&1
   python tools/batch_threads.py > gpurun_out/r03_batch_threads.txt 2>&1
   ;;
+c3prof)      # configs[2] (k=31, 2 M hashes): phases, kernel timeline, counters of the sketch launches
+  FH_TRACE=1 python tools/phase_times.py --k 31 --n 2000000 --reps 3 > gpurun_out/r03_c3_phases.txt 2>&1
+  cd /tmp; rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/r03_c3_trace -o t --output-format csv -- python $GRAFT_REPO_ROOT/tools/phase_times.py --k 31 --n 2000000 --reps 2 > /dev/null 2>&1; cd $GRAFT_REPO_ROOT
+  python tools/kernel_timeline.py gpurun_out/r03_c3_trace --min-ms 0.05 > gpurun_out/r03_c3_kernel_timeline.txt 2>&1
+  bash tools/pmc_k2.sh r03_c3 python $GRAFT_REPO_ROOT/tools/phase_times.py --k 31 --n 2000000 --reps 1 > gpurun_out/r03_c3_pmc.txt 2>&1
+  ;;
+round2)      # after: interpolated sample threshold, H2D prefetch, wide LDS reads -- parity first, then the numbers
+  timeout 1800 python -m pytest tests/test_gpu_parity.py tests/test_gpu_host_layer.py tests/test_gpu_fuzz.py tests/test_gpu_errors.py -x -q -m gpu 2>&1 | tail -4 | tee gpurun_out/r03_round2_pytest.txt
+  python tools/e2e_trace.py 4000000 1,8 > gpurun_out/r03b_e2e_trace.txt 2> gpurun_out/r03b_e2e_trace.err
+  FH_TRACE=1 python tools/phase_times.py --k 31 --n 2000000 --reps 3 2>&1 | grep -v "launch " > gpurun_out/r03b_c3_phases.txt
+  FH_SAMPLE_WANT=1.25 FH_TRACE=1 python tools/phase_times.py --k 31 --n 2000000 --reps 3 2>&1 | grep -v "launch " > gpurun_out/r03b_c3_phases_want125.txt
+  bash tools/pmc_k2.sh r03b_c3 python $GRAFT_REPO_ROOT/tools/phase_times.py --k 31 --n 2000000 --reps 1 > gpurun_out/r03b_c3_pmc.txt 2>&1
+  ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
