@@ -122,6 +122,9 @@ struct fh_sketcher {
     uint64_t *kmer_hi = nullptr;   // K > 32 only: high words of the table's k-mers, one per slot (fh_device.h)
     uint32_t *o_count = nullptr, *o_extra = nullptr;
     uint32_t out_cap = 0;
+    // (the six arrays are slices of ONE allocation, out_stride entries apart: a small sketch goes to the host in one copy)
+    void *o_block = nullptr;
+    size_t out_stride = 0, o_block_bytes = 0;
     // device-wide selection (fh_big.hip), allocated on first use
     bool big_mode = false;        // live sets beyond the in-LDS sort (large kmers_to_sketch, scaled)
     uint64_t live_target = 0;     // prune when the live list reaches this
@@ -890,16 +893,23 @@ int grow_table(fh_sketcher *s, uint64_t new_live_cap) {
 int ensure_out(fh_sketcher *s, uint32_t n) {
     if (n <= s->out_cap) return FH_OK;
     HIP_TRY(hipStreamSynchronize(s->stream));
-    (void)hipFree(s->o_hash); (void)hipFree(s->o_kmer); (void)hipFree(s->o_pos); (void)hipFree(s->o_count); (void)hipFree(s->o_extra);
-    (void)hipFree(s->o_kmer_hi);
+    (void)hipFree(s->o_block);
+    s->o_block = nullptr;
     s->o_hash = s->o_kmer = s->o_pos = s->o_kmer_hi = nullptr; s->o_count = s->o_extra = nullptr;
+    s->out_cap = 0;
     const uint32_t cap = std::max<uint32_t>(n, (uint32_t)SMALL_MAX);
-    HIP_TRY(dev_malloc(&s->o_hash, (size_t)cap * 8));
-    HIP_TRY(dev_malloc(&s->o_kmer, (size_t)cap * 8));
-    if (s->p.k > 32) HIP_TRY(dev_malloc(&s->o_kmer_hi, (size_t)cap * 8));
-    HIP_TRY(dev_malloc(&s->o_pos, (size_t)cap * 8));
-    HIP_TRY(dev_malloc(&s->o_count, (size_t)cap * 4));
-    HIP_TRY(dev_malloc(&s->o_extra, (size_t)cap * 4));
+    const bool wide = s->p.k > 32;
+    const size_t stride = ((size_t)cap + 2) & ~(size_t)1; // one spare record (the special hash, host side), even
+    const size_t bytes = stride * (wide ? 40 : 32);
+    HIP_TRY(dev_malloc(&s->o_block, bytes));
+    s->o_hash = (uint64_t *)s->o_block;
+    s->o_kmer = s->o_hash + stride;
+    s->o_pos = s->o_kmer + stride;
+    s->o_kmer_hi = wide ? s->o_pos + stride : nullptr;
+    s->o_count = (uint32_t *)((wide ? s->o_kmer_hi : s->o_pos) + stride);
+    s->o_extra = s->o_count + stride;
+    s->out_stride = stride;
+    s->o_block_bytes = bytes;
     s->out_cap = cap;
     return FH_OK;
 }
@@ -1291,16 +1301,11 @@ void destroy_handle(fh_sketcher *s) {
     (void)hipFree(s->dead);
     (void)hipFree(s->ctl);
     (void)hipFree(s->clog);
-    (void)hipFree(s->o_hash);
-    (void)hipFree(s->o_kmer);
-    (void)hipFree(s->o_kmer_hi);
+    (void)hipFree(s->o_block);
     (void)hipFree(s->kmer_hi);
     (void)hipFree(s->smp_list);
     (void)hipFree(s->smp_hist);
     if (s->h_smp_hist) (void)hipHostFree(s->h_smp_hist);
-    (void)hipFree(s->o_pos);
-    (void)hipFree(s->o_count);
-    (void)hipFree(s->o_extra);
     if (s->copy_stream) {
         (void)hipStreamSynchronize(s->copy_stream);
         (void)hipStreamDestroy(s->copy_stream);
@@ -1840,9 +1845,11 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         const Ctl c = *s->h_ctl;
         const uint32_t n = c.n_live;
         // D2H through one pinned staging area (pageable destinations crawl at a few GB/s); one spare record for the
-        // special hash
-        const size_t cap = (size_t)n + 1;
+        // special hash.  A small sketch (the whole block of arrays under 1 MiB: n = 1000 is 32 KB) crosses in ONE copy, the
+        // host arrays the device's stride apart; a large one array by array, n entries each.
         const bool wide = s->p.k > 32;
+        const bool one_copy = s->o_block_bytes <= ((size_t)1 << 20);
+        const size_t cap = one_copy ? s->out_stride : (size_t)n + 1;
         const size_t need = cap * (wide ? 40 : 32) + 64;
         if (need > s->h_out_bytes) {
             if (s->h_out) (void)hipHostFree(s->h_out);
@@ -1854,7 +1861,9 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         uint64_t *hh = (uint64_t *)s->h_out, *kk = hh + cap, *pp = kk + cap;
         uint64_t *kh = wide ? pp + cap : nullptr;
         uint32_t *cc = (uint32_t *)(pp + cap + (wide ? cap : 0)), *ee = cc + cap;
-        if (n) {
+        if (n && one_copy) {
+            HIP_TRY(hipMemcpyAsync(hh, s->o_block, s->o_block_bytes, hipMemcpyDeviceToHost, s->stream));
+        } else if (n) {
             HIP_TRY(hipMemcpyAsync(hh, s->o_hash, n * 8ull, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipMemcpyAsync(kk, s->o_kmer, n * 8ull, hipMemcpyDeviceToHost, s->stream));
             if (wide) HIP_TRY(hipMemcpyAsync(kh, s->o_kmer_hi, n * 8ull, hipMemcpyDeviceToHost, s->stream));

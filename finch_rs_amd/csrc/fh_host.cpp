@@ -209,6 +209,7 @@ struct ByteSource {
     virtual bool can_rewind() const { return false; } // regular files, memory
     virtual bool rewind() { return false; }           // back to the first byte
     virtual unsigned threads_hint() const { return 1; } // host threads the reader of this source may use
+    virtual uint64_t remaining_hint() const { return UINT64_MAX; } // bytes still to come, if the source knows (files, memory)
 };
 
 static unsigned read_threads_total(const char *env);
@@ -246,6 +247,7 @@ struct MemSource : ByteSource {
         return m;
     }
     unsigned threads_hint() const override { return n_thr; }
+    uint64_t remaining_hint() const override { return n - off; }
 };
 
 struct FileSource : ByteSource {
@@ -299,6 +301,12 @@ struct FileSource : ByteSource {
     }
     bool rewind() override { return can_rewind() && fseek(f, 0, SEEK_SET) == 0; }
     unsigned threads_hint() const override { return n_thr; }
+    uint64_t remaining_hint() const override {
+        struct stat sb;
+        if (!f || fstat(fileno(f), &sb) != 0 || !S_ISREG(sb.st_mode)) return UINT64_MAX;
+        const off_t pos = ftello(f);
+        return pos < 0 || pos > sb.st_size ? UINT64_MAX : (uint64_t)(sb.st_size - pos);
+    }
 };
 
 // prepends already-consumed sniff bytes
@@ -323,6 +331,10 @@ struct PrefixedSource : ByteSource {
     }
     unsigned threads_hint() const override { return inner->threads_hint(); }
     bool failed() const override { return inner->failed(); }
+    uint64_t remaining_hint() const override {
+        const uint64_t r = inner->remaining_hint();
+        return r == UINT64_MAX ? r : r + (prefix.size() - std::min(off, prefix.size()));
+    }
 };
 
 struct GzSource : ByteSource {
@@ -2392,6 +2404,35 @@ static int pump_text_to_device(ByteSource &src, fh_sketcher *h, bool fastq, uint
     const double t_begin = now_s();
     double t_reader_waits = 0, t_pusher_waits = 0, t_push = 0;
     unsigned n_chunks = 0;
+    if (src.remaining_hint() < cap) {
+        // The whole input fits one staging buffer (a genome of a batch: configs[4]): read it and push it right here -- no reader
+        // thread to start, hand over to and join per file.
+        int rc = FH_OK;
+        std::string msg;
+        const int prc1 = shard_reader(
+            src, fastq, k, [&] { return &tb[fill]; }, [&](TextBuf *) {},
+            [&](const ShardWork &job) {
+                n_chunks++;
+                const double tw1 = trace ? now_s() : 0;
+                if (rc == FH_OK) {
+                    rc = fastq ? fh_push_fastq_text(h, job.len) : fh_push_fasta_text(h, job.len, job.start_state, n_chunks == 1 ? 0u : FH_PUSH_CONTINUE);
+                    if (rc != FH_OK) {
+                        msg = fh_last_error();
+                        abort = true;
+                    }
+                }
+                if (trace) t_push += now_s() - tw1;
+                fill ^= 1;
+            },
+            abort, pst);
+        if (trace)
+            fprintf(stderr, "[finch] text pump (inline): %u chunk(s) in %.1f ms, pushes took %.1f ms\n", n_chunks, (now_s() - t_begin) * 1e3, t_push * 1e3);
+        if (rc != FH_OK) return hfail(rc, "%s", msg.c_str());
+        if (prc1 != FH_OK) return prc1;
+        st.total_bases = pst.total_bases;
+        st.n_records = pst.n_records;
+        return FH_OK;
+    }
     std::thread producer([&] {
         const int rc = shard_reader(
             src, fastq, k,

@@ -43,5 +43,34 @@ round2)      # after: interpolated sample threshold, H2D prefetch, wide LDS read
   FH_SAMPLE_WANT=1.25 FH_TRACE=1 python tools/phase_times.py --k 31 --n 2000000 --reps 3 2>&1 | grep -v "launch " > gpurun_out/r03b_c3_phases_want125.txt
   bash tools/pmc_k2.sh r03b_c3 python $GRAFT_REPO_ROOT/tools/phase_times.py --k 31 --n 2000000 --reps 1 > gpurun_out/r03b_c3_pmc.txt 2>&1
   ;;
+c5prof)      # what the GPU does per file of a batch (configs[4]'s shape)
+  for nt in 4 8 12 16 24; do python tools/batch_trace.py 512 $nt; done > gpurun_out/r03_c5_threads.txt 2>&1
+  cd /tmp; rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r03_c5_trace -o t --output-format csv -- python $GRAFT_REPO_ROOT/tools/batch_trace.py 512 12 > $GRAFT_REPO_ROOT/gpurun_out/r03_c5_trace.log 2>&1; cd $GRAFT_REPO_ROOT
+  cp gpurun_out/r03_c5_trace/t_kernel_stats.csv gpurun_out/r03_c5_kernel_stats.csv
+  python - <<'PY' > gpurun_out/r03_c5_busy.txt
+import csv
+rows = sorted(csv.DictReader(open("gpurun_out/r03_c5_trace/t_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
+ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows]
+# the timed call = the last 60 % of the trace's kernels; union of busy intervals over it
+ev = ev[len(ev) * 2 // 5:]
+t0, t1 = ev[0][0], max(e for _, e in ev)
+busy, cur_s, cur_e = 0, None, None
+for s, e in ev:
+    if cur_e is None or s > cur_e:
+        if cur_e is not None: busy += cur_e - cur_s
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+tot = sum(e - s for s, e in ev)
+print("kernels %d  span %.1f ms  union-busy %.1f ms (%.0f %%)  sum of durations %.1f ms (overlap factor %.2f)" % (len(ev), (t1 - t0) / 1e6, busy / 1e6, 100.0 * busy / (t1 - t0), tot / 1e6, tot / max(busy, 1)))
+PY
+  ;;
+round3)      # after: inline single-chunk pump, one-block copy-out, two-stage sample cap
+  timeout 1800 python -m pytest tests/test_gpu_parity.py tests/test_gpu_host_layer.py tests/test_gpu_fuzz.py tests/test_gpu_errors.py tests/test_gpu_bgzf_device.py -x -q -m gpu 2>&1 | tail -4 | tee gpurun_out/r03_round3_pytest.txt
+  for nt in 8 12 16; do python tools/batch_trace.py 512 $nt; done > gpurun_out/r03c_c5_threads.txt 2>&1
+  python tools/one_worker_trace.py 2>&1 | tail -4 > gpurun_out/r03c_one_worker.txt
+  FH_TRACE=1 python tools/phase_times.py --k 31 --n 2000000 --reps 3 2>&1 | grep -v "launch " > gpurun_out/r03c_c3_phases.txt
+  ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
