@@ -35,81 +35,37 @@ namespace finch {
 namespace inf {
 
 // ---------------------------------------------------------------------------------------------------------------------
-// CRC-32 (IEEE 802.3, reflected): folding with PCLMULQDQ ("Fast CRC Computation for Generic Polynomials Using PCLMULQDQ
-// Instruction", Gopal et al., Intel 2009); constants = x^(n) mod P for the fold distances, bit-reflected
+// CRC-32 (IEEE 802.3, reflected) by carry-less multiplication.  The method is Intel's ("Fast CRC Computation for Generic
+// Polynomials Using PCLMULQDQ Instruction", Gopal et al., 2009): a 128-bit accumulator A stands for A(x) mod P, and moving it
+// d bits up the message is  clmul(A.lo, x^(d+64) mod P) ^ clmul(A.hi, x^d mod P)  -- two multiplies and an xor with the data
+// d bits further on.  Four accumulators 512 bits apart run over the bulk, are folded into one (128 bits apart), and that one
+// walks the remaining 16-byte blocks.  The constants are the paper's (bit-reflected x^n mod P for n = 512+64, 512, 128+64,
+// 128).  What is left at the end is 16 bytes R congruent to the whole message; instead of the paper's 128 -> 64 -> 32 bit
+// Barrett steps they simply go through the ordinary byte-wise CRC once (zlib's, register 0 in, no inversions): that
+// computes R(x) * x^32 mod P, which is the definition of the remainder wanted.
 // ---------------------------------------------------------------------------------------------------------------------
 #if defined(__x86_64__)
+__attribute__((target("pclmul,sse4.1"))) static inline __m128i crc_fold(__m128i acc, __m128i k, __m128i data) {
+    return _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(acc, k, 0x00), _mm_clmulepi64_si128(acc, k, 0x11)), data);
+}
 __attribute__((target("pclmul,sse4.1"))) static inline uint32_t crc32_clmul(const uint8_t *buf, size_t len, uint32_t crc /* running, inverted */) {
     // len >= 64 and a multiple of 16
-    alignas(16) static const uint64_t k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull}; // fold by 512 bits
-    alignas(16) static const uint64_t k3k4[2] = {0x01751997d0ull, 0x00ccaa009eull}; // fold by 128 bits
-    alignas(16) static const uint64_t k5k0[2] = {0x0163cd6124ull, 0x0000000000ull}; // 96 -> 64 bits
-    alignas(16) static const uint64_t poly[2] = {0x01db710641ull, 0x01f7011641ull}; // P, floor(x^64 / P)
-    __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
-    x1 = _mm_loadu_si128((const __m128i *)(buf + 0x00));
-    x2 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
-    x3 = _mm_loadu_si128((const __m128i *)(buf + 0x20));
-    x4 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
-    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
-    x0 = _mm_load_si128((const __m128i *)k1k2);
-    buf += 64;
-    len -= 64;
-    while (len >= 64) {
-        x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
-        x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
-        x7 = _mm_clmulepi64_si128(x3, x0, 0x00);
-        x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
-        x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
-        x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
-        x3 = _mm_clmulepi64_si128(x3, x0, 0x11);
-        x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
-        y5 = _mm_loadu_si128((const __m128i *)(buf + 0x00));
-        y6 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
-        y7 = _mm_loadu_si128((const __m128i *)(buf + 0x20));
-        y8 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
-        x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5);
-        x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
-        x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7);
-        x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
-        buf += 64;
-        len -= 64;
-    }
-    x0 = _mm_load_si128((const __m128i *)k3k4);
-    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
-    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
-    x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
-    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
-    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
-    x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
-    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
-    x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
-    x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
-    while (len >= 16) {
-        x2 = _mm_loadu_si128((const __m128i *)buf);
-        x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
-        x1 = _mm_clmulepi64_si128(x1, x0, 0x11);
-        x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
-        buf += 16;
-        len -= 16;
-    }
-    // 128 -> 64 bits
-    x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
-    x3 = _mm_setr_epi32(~0, 0, ~0, 0);
-    x1 = _mm_srli_si128(x1, 8);
-    x1 = _mm_xor_si128(x1, x2);
-    x0 = _mm_loadl_epi64((const __m128i *)k5k0);
-    x2 = _mm_srli_si128(x1, 4);
-    x1 = _mm_and_si128(x1, x3);
-    x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
-    x1 = _mm_xor_si128(x1, x2);
-    // Barrett reduction to 32 bits
-    x0 = _mm_load_si128((const __m128i *)poly);
-    x2 = _mm_and_si128(x1, x3);
-    x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
-    x2 = _mm_and_si128(x2, x3);
-    x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
-    x1 = _mm_xor_si128(x1, x2);
-    return (uint32_t)_mm_extract_epi32(x1, 1);
+    const __m128i k512 = _mm_set_epi64x(0x01c6e41596ll, 0x0154442bd4ll); // {x^(512+64), x^512} mod P, reflected
+    const __m128i k128 = _mm_set_epi64x(0x00ccaa009ell, 0x01751997d0ll); // {x^(128+64), x^128} mod P, reflected
+    const __m128i *p = (const __m128i *)buf;
+    __m128i acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = _mm_loadu_si128(p + i);
+    acc[0] = _mm_xor_si128(acc[0], _mm_cvtsi32_si128((int)crc)); // the running register joins the first four message bytes
+    p += 4;
+    size_t blocks = len / 16 - 4; // 16-byte blocks still to take
+    for (; blocks >= 4; blocks -= 4, p += 4)
+        for (int i = 0; i < 4; ++i) acc[i] = crc_fold(acc[i], k512, _mm_loadu_si128(p + i));
+    __m128i a = acc[0];
+    for (int i = 1; i < 4; ++i) a = crc_fold(a, k128, acc[i]);
+    for (; blocks; --blocks, ++p) a = crc_fold(a, k128, _mm_loadu_si128(p));
+    alignas(16) uint8_t rest[16];
+    _mm_store_si128((__m128i *)rest, a);
+    return ~(uint32_t)::crc32(0xFFFFFFFFu, rest, 16); // (zlib inverts on the way in and out: register 0 in, raw register out)
 }
 #endif
 

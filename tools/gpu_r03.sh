@@ -72,5 +72,10 @@ round3)      # after: inline single-chunk pump, one-block copy-out, two-stage sa
   python tools/one_worker_trace.py 2>&1 | tail -4 > gpurun_out/r03c_one_worker.txt
   FH_TRACE=1 python tools/phase_times.py --k 31 --n 2000000 --reps 3 2>&1 | grep -v "launch " > gpurun_out/r03c_c3_phases.txt
   ;;
+c5bench)     # configs[4] at its size through bench.py (one GPU; and two handles on the one GPU), multirank tests
+  timeout 1500 python bench.py --workload c5 --steps 2 --warmup 1 > gpurun_out/r03_bench_c5.json 2> gpurun_out/r03_bench_c5.err; echo "c5 rc=$?"
+  timeout 900 python bench.py --workload c5 --files 2000 --gpus 2 --share-gpu --steps 2 --warmup 1 > gpurun_out/r03_bench_c5_gpus2_share.json 2> gpurun_out/r03_bench_c5_gpus2_share.err; echo "c5x2 rc=$?"
+  timeout 1500 python -m pytest tests/test_gpu_multirank.py -x -q -m gpu 2>&1 | tail -4 | tee gpurun_out/r03_multirank_pytest.txt
+  ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
