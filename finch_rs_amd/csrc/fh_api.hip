@@ -125,6 +125,13 @@ struct fh_sketcher {
     // (the six arrays are slices of ONE allocation, out_stride entries apart: a small sketch goes to the host in one copy)
     void *o_block = nullptr;
     size_t out_stride = 0, o_block_bytes = 0;
+    // A large Mash sketch's wide columns (hash, k-mer, first position: 24 B per record) stay on the device after fh_finish
+    // until somebody asks for them: the filters of configs[2] look at the counts of all 2 M records and then want 10 000 rows.
+    bool wide_pending = false;
+    uint32_t *d_rows = nullptr;   // fh_copy_out_rows by device-side gather: row indices, gathered words
+    uint64_t *d_rows_out = nullptr, *h_rows_out = nullptr;
+    uint32_t *h_rows = nullptr;
+    size_t rows_cap = 0;
     // device-wide selection (fh_big.hip), allocated on first use
     bool big_mode = false;        // live sets beyond the in-LDS sort (large kmers_to_sketch, scaled)
     uint64_t live_target = 0;     // prune when the live list reaches this
@@ -297,6 +304,7 @@ int init_state(fh_sketcher *s) {
     s->dirty = false;
     s->res.clear();
     s->res_built = false;
+    s->wide_pending = false;
     s->r_n = 0;
     s->total_kmers = 0;
     s->prof_used = 0;
@@ -894,6 +902,10 @@ int ensure_out(fh_sketcher *s, uint32_t n) {
     if (n <= s->out_cap) return FH_OK;
     HIP_TRY(hipStreamSynchronize(s->stream));
     (void)hipFree(s->o_block);
+    (void)hipFree(s->d_rows);
+    (void)hipFree(s->d_rows_out);
+    if (s->h_rows) (void)hipHostFree(s->h_rows);
+    if (s->h_rows_out) (void)hipHostFree(s->h_rows_out);
     s->o_block = nullptr;
     s->o_hash = s->o_kmer = s->o_pos = s->o_kmer_hi = nullptr; s->o_count = s->o_extra = nullptr;
     s->out_cap = 0;
@@ -1807,9 +1819,24 @@ int fh_sync(fh_sketcher *s) {
 
 static size_t result_count(const fh_sketcher *s) { return s->res_built ? s->res.size() : s->r_n; }
 
+// the wide columns of a large sketch, if fh_finish left them on the device
+static int ensure_wide(fh_sketcher *s) {
+    if (!s->wide_pending) return FH_OK;
+    if (int rc = set_device(s)) return rc;
+    const size_t n = s->r_n;
+    HIP_TRY(hipMemcpyAsync(s->r_hash, s->o_hash, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->r_kmer, s->o_kmer, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+    if (s->r_kmer_hi) HIP_TRY(hipMemcpyAsync(s->r_kmer_hi, s->o_kmer_hi, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->r_pos, s->o_pos, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->wide_pending = false;
+    return FH_OK;
+}
+
 // the record form of a finished sketch (merges work on it); built from the arrays fh_finish left behind
 static void ensure_records(fh_sketcher *s) {
     if (s->res_built) return;
+    (void)ensure_wide(s);
     s->res.resize(s->r_n);
     for (size_t i = 0; i < s->r_n; ++i)
         s->res[i] = ResultRec{s->r_hash[i], s->r_count[i], s->r_extra[i], s->r_kmer[i], s->r_pos[i], s->r_kmer_hi ? s->r_kmer_hi[i] : 0ull};
@@ -1861,13 +1888,19 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         uint64_t *hh = (uint64_t *)s->h_out, *kk = hh + cap, *pp = kk + cap;
         uint64_t *kh = wide ? pp + cap : nullptr;
         uint32_t *cc = (uint32_t *)(pp + cap + (wide ? cap : 0)), *ee = cc + cap;
+        // (nothing on the host side of this function needs the wide columns of a Mash sketch without collisions and without
+        //  the special hash: the final selection is "the first `size`")
+        static const bool lazy_off = getenv("FH_NO_LAZY_COPYOUT") != nullptr; // A/B knob
+        s->wide_pending = !lazy_off && !one_copy && n >= (1u << 17) && s->p.kind == FH_KIND_MASH && c.n_coll == 0 && c.sp_count == 0;
         if (n && one_copy) {
             HIP_TRY(hipMemcpyAsync(hh, s->o_block, s->o_block_bytes, hipMemcpyDeviceToHost, s->stream));
         } else if (n) {
-            HIP_TRY(hipMemcpyAsync(hh, s->o_hash, n * 8ull, hipMemcpyDeviceToHost, s->stream));
-            HIP_TRY(hipMemcpyAsync(kk, s->o_kmer, n * 8ull, hipMemcpyDeviceToHost, s->stream));
-            if (wide) HIP_TRY(hipMemcpyAsync(kh, s->o_kmer_hi, n * 8ull, hipMemcpyDeviceToHost, s->stream));
-            HIP_TRY(hipMemcpyAsync(pp, s->o_pos, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+            if (!s->wide_pending) {
+                HIP_TRY(hipMemcpyAsync(hh, s->o_hash, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+                HIP_TRY(hipMemcpyAsync(kk, s->o_kmer, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+                if (wide) HIP_TRY(hipMemcpyAsync(kh, s->o_kmer_hi, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+                HIP_TRY(hipMemcpyAsync(pp, s->o_pos, n * 8ull, hipMemcpyDeviceToHost, s->stream));
+            }
             HIP_TRY(hipMemcpyAsync(cc, s->o_count, n * 4ull, hipMemcpyDeviceToHost, s->stream));
             HIP_TRY(hipMemcpyAsync(ee, s->o_extra, n * 4ull, hipMemcpyDeviceToHost, s->stream));
         }
@@ -1940,6 +1973,7 @@ int fh_copy_out(fh_sketcher *s, uint64_t *hashes, uint32_t *counts, uint32_t *ex
         });
         return FH_OK;
     }
+    if (int rc = ensure_wide(s)) return rc;
     const uint64_t *hh = s->r_hash, *kk = s->r_kmer, *pp = s->r_pos, *kh = s->r_kmer_hi;
     const uint32_t *cc = s->r_count, *ee = s->r_extra;
     parallel_for(s->r_n, [=](size_t lo, size_t hi) {
@@ -1964,6 +1998,7 @@ int fh_copy_out_records(fh_sketcher *s, fh_kmer_count *records, uint8_t *kmers, 
                 for (size_t i = lo; i < hi; ++i) records[i] = fh_kmer_count{res[i].hash, res[i].count, res[i].extra};
             });
         } else {
+            if (int rc = ensure_wide(s)) return rc;
             const uint64_t *hh = s->r_hash;
             const uint32_t *cc = s->r_count, *ee = s->r_extra;
             parallel_for(s->r_n, [=](size_t lo, size_t hi) {
@@ -1980,6 +2015,8 @@ int fh_copy_out_kmers(fh_sketcher *s, const uint32_t *rows, uint64_t n_rows, uin
     if (!s->finished) return fail(FH_ERR_STATE, "fh_copy_out before fh_finish");
     const int k = (int)s->p.k;
     const size_t n = result_count(s);
+    if (!s->res_built)
+        if (int rc = ensure_wide(s)) return rc;
     for (uint64_t i = 0; i < n_rows; ++i) {
         const size_t r = rows[i];
         if (r >= n) return fail(FH_ERR_INVALID, "row %zu of a sketch of %zu hashes", r, n);
@@ -1994,6 +2031,42 @@ int fh_copy_out_rows(fh_sketcher *s, const uint32_t *rows, uint64_t n_rows, fh_k
     if (!s->finished) return fail(FH_ERR_STATE, "fh_copy_out before fh_finish");
     const int k = (int)s->p.k;
     const size_t n = result_count(s);
+    if (!s->res_built && s->wide_pending) {
+        // the wide columns are still on the device: a few rows of them are gathered there (2 M records: 48 MB stay where
+        // they are, 10 000 rows cross as 160 KB); most of a sketch: the columns come over after all
+        if (n_rows > n / 8 || n_rows > (1u << 22)) {
+            if (int rc = ensure_wide(s)) return rc;
+        } else if (n_rows) {
+            for (uint64_t i = 0; i < n_rows; ++i)
+                if (rows[i] >= n) return fail(FH_ERR_INVALID, "row %zu of a sketch of %zu hashes", (size_t)rows[i], n);
+            if (int rc = set_device(s)) return rc;
+            if (n_rows > s->rows_cap) {
+                (void)hipFree(s->d_rows); (void)hipFree(s->d_rows_out);
+                if (s->h_rows) (void)hipHostFree(s->h_rows);
+                if (s->h_rows_out) (void)hipHostFree(s->h_rows_out);
+                s->d_rows = nullptr; s->d_rows_out = nullptr; s->h_rows = nullptr; s->h_rows_out = nullptr;
+                s->rows_cap = 0;
+                const size_t cap = std::max<size_t>(n_rows, 16384);
+                HIP_TRY(dev_malloc(&s->d_rows, cap * 4));
+                HIP_TRY(dev_malloc(&s->d_rows_out, cap * 24));
+                HIP_TRY(host_malloc(&s->h_rows, cap * 4));
+                HIP_TRY(host_malloc(&s->h_rows_out, cap * 24));
+                s->rows_cap = cap;
+            }
+            memcpy(s->h_rows, rows, n_rows * 4);
+            HIP_TRY(hipMemcpyAsync(s->d_rows, s->h_rows, n_rows * 4, hipMemcpyHostToDevice, s->stream));
+            HIP_TRY(launch_gather_rows(s->o_hash, s->o_kmer, s->r_kmer_hi ? s->o_kmer_hi : nullptr, s->d_rows, (uint32_t)n_rows, s->d_rows_out, s->stream));
+            HIP_TRY(hipMemcpyAsync(s->h_rows_out, s->d_rows_out, n_rows * (s->r_kmer_hi ? 24 : 16), hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            const uint64_t *gh = s->h_rows_out, *gk = gh + n_rows, *gkh = s->r_kmer_hi ? gk + n_rows : nullptr;
+            for (uint64_t i = 0; i < n_rows; ++i) {
+                const size_t r = rows[i];
+                if (records) records[i] = fh_kmer_count{gh[i], s->r_count[r], s->r_extra[r]};
+                if (kmers) kmer_ascii(gk[i], gkh ? gkh[i] : 0ull, k, kmers + i * (size_t)k);
+            }
+            return FH_OK;
+        }
+    }
     for (uint64_t i = 0; i < n_rows; ++i) {
         const size_t r = rows[i];
         if (r >= n) return fail(FH_ERR_INVALID, "row %zu of a sketch of %zu hashes", r, n);

@@ -28,6 +28,8 @@ hipError_t launch_clear_slots(Entry *table, uint64_t cap, const uint32_t *live, 
 hipError_t launch_gather(const Entry *table, const uint32_t *live, const Ctl *ctl, int k, uint64_t *o_hash,
                          uint32_t *o_count, uint32_t *o_extra, uint64_t *o_kmer, uint64_t *o_kmer_hi, uint64_t *o_pos,
                          uint32_t cap_out, hipStream_t st);
+hipError_t launch_gather_rows(const uint64_t *hash, const uint64_t *kmer, const uint64_t *kmer_hi, const uint32_t *rows, uint32_t n,
+                              uint64_t *out, hipStream_t st);
 // sampling pre-pass of large sketches (fh_kernels.hip): tile runs [i * stride, i * stride + run_tiles) as a leftover list for the
 // sketch kernel; histograms of the live entries by quarter-octave of hash value (3 x 256: entries, one occurrence, two)
 hipError_t launch_fill_tile_runs(uint32_t *list, uint32_t n_runs, uint32_t stride, uint32_t run_tiles, uint32_t tiles_total,

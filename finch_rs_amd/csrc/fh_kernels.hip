@@ -306,6 +306,21 @@ hipError_t launch_gather(const Entry *table, const u32 *live, const Ctl *ctl, in
     return hipGetLastError();
 }
 
+// rows of a finished sketch's hash / k-mer columns (fh_copy_out_rows on a large sketch whose wide columns stayed on the
+// device: configs[2] keeps 10 000 of 2 000 000 records): out = n hashes, n k-mer words, [n high k-mer words]
+__global__ void k_gather_rows(const u64 *hash, const u64 *kmer, const u64 *kmer_hi, const u32 *rows, u32 n, u64 *out) {
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const u32 r = rows[i];
+        out[i] = hash[r];
+        out[(size_t)n + i] = kmer[r];
+        if (kmer_hi) out[2 * (size_t)n + i] = kmer_hi[r];
+    }
+}
+hipError_t launch_gather_rows(const u64 *hash, const u64 *kmer, const u64 *kmer_hi, const u32 *rows, u32 n, u64 *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_gather_rows, dim3((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), dim3(256), 0, st, hash, kmer, kmer_hi, rows, n, out);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // sampling pre-pass of large sketches: where will the threshold of a kmers_to_sketch-hash sketch of this block end up?
 // ------------------------------------------------------------------------------------------------

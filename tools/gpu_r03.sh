@@ -77,5 +77,10 @@ c5bench)     # configs[4] at its size through bench.py (one GPU; and two handles
   timeout 900 python bench.py --workload c5 --files 2000 --gpus 2 --share-gpu --steps 2 --warmup 1 > gpurun_out/r03_bench_c5_gpus2_share.json 2> gpurun_out/r03_bench_c5_gpus2_share.err; echo "c5x2 rc=$?"
   timeout 1500 python -m pytest tests/test_gpu_multirank.py -x -q -m gpu 2>&1 | tail -4 | tee gpurun_out/r03_multirank_pytest.txt
   ;;
+round4)      # after: lazy wide-column copy-out (+ device-side row gather)
+  timeout 1800 python -m pytest tests/test_gpu_parity.py tests/test_gpu_host_layer.py tests/test_gpu_full_size.py -x -q -m gpu -k "not c4 and not c5 and not c2" 2>&1 | tail -4 | tee gpurun_out/r03_round4_pytest.txt
+  python tools/c3_resident.py > gpurun_out/r03d_c3_resident.txt 2>&1
+  FH_NO_LAZY_COPYOUT=1 python tools/c3_resident.py > gpurun_out/r03d_c3_resident_nolazy.txt 2>&1
+  ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
