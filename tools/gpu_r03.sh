@@ -82,5 +82,13 @@ round4)      # after: lazy wide-column copy-out (+ device-side row gather)
   python tools/c3_resident.py > gpurun_out/r03d_c3_resident.txt 2>&1
   FH_NO_LAZY_COPYOUT=1 python tools/c3_resident.py > gpurun_out/r03d_c3_resident_nolazy.txt 2>&1
   ;;
+final)       # the state the round ends in
+  timeout 2400 python -m pytest tests -x -q -m gpu -rs --durations=8 2>&1 | tail -24 | tee gpurun_out/r03z_pytest_gpu_tail.txt
+  timeout 300 python __graft_entry__.py smoke 2>&1 | tail -2 | tee gpurun_out/r03z_smoke.txt
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03z_bench_default.json 2> gpurun_out/r03z_bench_default.err; echo "bench rc=$?"
+  timeout 600 python bench.py --gpus 2 --share-gpu --steps 5 --warmup 1 > gpurun_out/r03z_bench_gpus2_share.json 2> gpurun_out/r03z_bench_gpus2_share.err; echo "bench2 rc=$?"
+  cd /tmp; rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r03z_stats -o stats --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/r03z_stats.log 2>&1; cd $GRAFT_REPO_ROOT
+  cp gpurun_out/r03z_stats/stats_kernel_stats.csv gpurun_out/r03z_kernel_stats.csv
+  ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
