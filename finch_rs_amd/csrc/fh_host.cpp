@@ -2006,29 +2006,34 @@ static int finish_mash_in_place(fh_sketcher *h, const std::string &name, const f
     uint64_t n_view = 0;
     if (fh_result_counts(h, &cnt, &ext, &n_view) != FH_OK || n_view != n) return FH_ERR_STATE;
     const bool filter_on = fp.filter_on == 1;
-    std::vector<uint8_t> dropped; // by the strand filter (filtering.rs:413-432)
-    if (filter_on && fp.strand_filter > 0.0) {
-        dropped.assign(n, 0);
+    // pass 1: the strand filter (filtering.rs:413-432) and, for the error filter, the largest count among what it leaves
+    std::vector<uint8_t> dropped;
+    const bool strand = filter_on && fp.strand_filter > 0.0, errf = filter_on && fp.err_filter > 0.0;
+    uint32_t maxes[8] = {0};
+    if (strand || errf) {
+        if (strand) dropped.resize(n); // (every byte is written below)
         const double cutoff = fp.strand_filter;
-        uint8_t *d = dropped.data();
-        host_parallel(n, [=](unsigned, size_t lo, size_t hi) {
+        uint8_t *dw = strand ? dropped.data() : nullptr;
+        host_parallel(n, [&, dw, cutoff](unsigned t, size_t lo, size_t hi) {
+            uint32_t m = 0;
             for (size_t i = lo; i < hi; ++i) {
-                const uint32_t c = cnt[i], e = ext[i];
-                if (c < 16) continue;
-                const uint32_t lowest = std::min(e, c - std::min(e, c));
-                d[i] = !(((double)lowest / (double)c) >= cutoff);
+                const uint32_t c = cnt[i];
+                bool drop = false;
+                if (dw) {
+                    if (c >= 16) {
+                        const uint32_t e = ext[i];
+                        const uint32_t lowest = std::min(e, c - std::min(e, c));
+                        drop = !(((double)lowest / (double)c) >= cutoff);
+                    }
+                    dw[i] = drop;
+                }
+                if (!drop) m = std::max(m, c);
             }
+            maxes[t] = m;
         });
     }
     const uint8_t *d = dropped.empty() ? nullptr : dropped.data();
-    if (filter_on && fp.err_filter > 0.0) { // guess_filter_threshold on what the strand filter left (filtering.rs:154-195)
-        uint32_t maxes[8] = {0};
-        host_parallel(n, [&](unsigned t, size_t lo, size_t hi) {
-            uint32_t m = 0;
-            for (size_t i = lo; i < hi; ++i)
-                if (!(d && d[i])) m = std::max(m, cnt[i]);
-            maxes[t] = m;
-        });
+    if (errf) { // guess_filter_threshold on what the strand filter left (filtering.rs:154-195)
         uint32_t max_count = 0;
         for (uint32_t m : maxes) max_count = std::max(max_count, m);
         std::vector<uint64_t> hist_data(max_count, 0);
@@ -2054,13 +2059,28 @@ static int finish_mash_in_place(fh_sketcher *h, const std::string &name, const f
             fp.abun_lo = cutoff;
         }
     }
-    // the abundance filter (filtering.rs:329-343) and the cut to final_size, in one scan that stops when it has enough
+    // the abundance filter (filtering.rs:329-343) and the cut to final_size: every thread lists the survivors of its stretch
+    // (at most final_size of them -- the first final_size in hash order are all that is wanted), the lists are joined in order.
+    // (With the error filter on, most of a 2 M-hash oversketch of reads are error k-mers below the cutoff: the first 10 000
+    // survivors end somewhere around record 1.2 M, a millisecond as one serial scan.)
     const bool abun = filter_on && (fp.has_abun_lo || fp.has_abun_hi);
     const uint32_t lo_t = (abun && fp.has_abun_lo) ? fp.abun_lo : 0u, hi_t = (abun && fp.has_abun_hi) ? fp.abun_hi : UINT32_MAX;
     std::vector<uint32_t> rows;
-    rows.reserve((size_t)std::min<uint64_t>(n, sp.final_size));
-    for (size_t i = 0; i < n && rows.size() < sp.final_size; ++i)
-        if (!(d && d[i]) && lo_t <= cnt[i] && cnt[i] <= hi_t) rows.push_back((uint32_t)i);
+    {
+        std::vector<uint32_t> part[8];
+        const size_t want = (size_t)std::min<uint64_t>(n, sp.final_size);
+        host_parallel(n, [&](unsigned t, size_t lo, size_t hi) {
+            std::vector<uint32_t> &p = part[t];
+            for (size_t i = lo; i < hi && p.size() < want; ++i)
+                if (!(d && d[i]) && lo_t <= cnt[i] && cnt[i] <= hi_t) p.push_back((uint32_t)i);
+        });
+        rows.reserve(want);
+        for (const auto &p : part) // (host_parallel hands out the stretches in index order: part[0] is the lowest)
+            for (uint32_t r : p) {
+                if (rows.size() >= want) break;
+                rows.push_back(r);
+            }
+    }
     if (!sp.no_strict && rows.size() < sp.final_size)
         return hfail(FH_ERR_INVALID, "%s had too few kmers (%zu) to sketch", name.c_str(), rows.size());
     const uint32_t k = sp.kmer_length;

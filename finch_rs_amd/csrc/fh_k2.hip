@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
     __shared__ Rec2 sP[partial_entries(K)];
     __shared__ __attribute__((aligned(16))) u32 sCodes[WAVES_PER_BLOCK][256];
     __shared__ __attribute__((aligned(16))) u32 sGood[WAVES_PER_BLOCK][128];
-    __shared__ __attribute__((aligned(16))) AdmitQueue sQueue[WAVES_PER_BLOCK];
+    __shared__ __attribute__((aligned(16))) AdmitQueueT<false> sQueue[WAVES_PER_BLOCK];
 
     // the wave index is uniform, and saying so keeps everything derived from it (ring and queue addresses, shard) in
     // scalar registers instead of vector registers the hot loop would have to spill
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
 #endif
     u32 wave_inserts = 0; // new hashes this wave inserted in this launch (wave-uniform)
     u32 qn = 0;           // occupancy of the admit queue (wave-uniform)
-    AdmitQueue *queue = &sQueue[wave];
+    AdmitQueueT<false> *queue = &sQueue[wave];
     const u32 shard = gw & (u32)(N_SHARDS - 1);
     u32 last_unit = 0; // guides the pull size
     for (;;) {

@@ -179,22 +179,27 @@ __device__ __noinline__ u32 upsert_w(Ctl *ctl_v, u64 h, u64 kmer, u64 kmer_hi, u
 // wave-private LDS queue; the queue is drained with all 64 lanes active, so the round trips of the atomics
 // overlap instead of stalling the wave once per event.  Returns the number of NEW hashes inserted.
 constexpr int QCAP = 64;
-struct AdmitQueue {
+template <bool WIDE>
+struct AdmitQueueT {
     u64 h[QCAP], k[QCAP], p[QCAP];
-    u64 khi[QCAP]; // K > 32 only (fh_k2w.hip): the k-mer's high word
+    u64 khi[QCAP]; // K > 32 (fh_k2w.hip): the k-mer's high word
+};
+template <>
+struct AdmitQueueT<false> { // K <= 32: 1.5 KB per wave (the 2 KB saved per workgroup is what lets five of them share a CU's LDS)
+    u64 h[QCAP], k[QCAP], p[QCAP];
 };
 
 template <bool WIDE = false>
-__device__ __noinline__ u32 flush_queue(Ctl *ctl, const AdmitQueue *q_generic, u32 qn_v, u32 shard) {
+__device__ __noinline__ u32 flush_queue(Ctl *ctl, const AdmitQueueT<WIDE> *q_generic, u32 qn_v, u32 shard) {
     const u32 lane = threadIdx.x & 63u;
     u32 ins = 0u;
     // the queue lives in LDS: read it with ds_read, not through the generic (flat) pointer it arrives as
-    typedef __attribute__((address_space(3))) const AdmitQueue LdsQueue;
+    typedef __attribute__((address_space(3))) const AdmitQueueT<WIDE> LdsQueue;
     LdsQueue *q = (LdsQueue *)uniform_ptr(q_generic);
     const u32 qn = (u32)__builtin_amdgcn_readfirstlane((int)qn_v);
     if (lane < qn) {
         const u64 pp = q->p[lane];
-        if (WIDE) ins = upsert_w(ctl, q->h[lane], q->k[lane], q->khi[lane], pp & 0x7FFFFFFFFFFFFFFFull, (u32)(pp >> 63), shard);
+        if constexpr (WIDE) ins = upsert_w(ctl, q->h[lane], q->k[lane], q->khi[lane], pp & 0x7FFFFFFFFFFFFFFFull, (u32)(pp >> 63), shard);
         else ins = upsert(ctl, q->h[lane], q->k[lane], pp & 0x7FFFFFFFFFFFFFFFull, (u32)(pp >> 63), shard);
     }
     return (u32)__popcll(__ballot(ins != 0u));

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, 2) void k2_sketch_w(const SketchArgs a) {
     __shared__ Rec2 sP[partial_entries(K)];
     __shared__ __attribute__((aligned(16))) u32 sCodes[WAVES_PER_BLOCK][256];
     __shared__ __attribute__((aligned(16))) u32 sGood[WAVES_PER_BLOCK][128];
-    __shared__ __attribute__((aligned(16))) AdmitQueue sQueue[WAVES_PER_BLOCK];
+    __shared__ __attribute__((aligned(16))) AdmitQueueT<true> sQueue[WAVES_PER_BLOCK];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void k2_sketch_w(const SketchArgs a) {
     u32 nvalid = 0;
 #define FLUSHW(ctl_, q_, qn_, shard_) ((u32)__builtin_amdgcn_readfirstlane((int)flush_queue<true>(ctl_, q_, qn_, shard_)))
     u32 wave_inserts = 0, qn = 0;
-    AdmitQueue *queue = &sQueue[wave];
+    AdmitQueueT<true> *queue = &sQueue[wave];
     const u32 shard = gw & (u32)(N_SHARDS - 1);
     u32 last_unit = 0;
     for (;;) {

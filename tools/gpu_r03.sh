@@ -90,5 +90,15 @@ final)       # the state the round ends in
   cd /tmp; rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r03z_stats -o stats --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --steps 5 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/r03z_stats.log 2>&1; cd $GRAFT_REPO_ROOT
   cp gpurun_out/r03z_stats/stats_kernel_stats.csv gpurun_out/r03z_kernel_stats.csv
   ;;
+ab_waves)    # k <= 24 in rounds of 16 / 8 at four and five waves per SIMD (LDS 32 KB per workgroup makes five fit)
+  L=cur=finch_rs_amd/libfinch_hip.so,r16=build/ab/k21r16.so,r16w5=build/ab/k21r16w5.so,r8w5=build/ab/k21r8w5.so
+  timeout 900 python tools/ab_k.py --libs $L --ks 17,20,21,24,31 2>&1 | tee gpurun_out/r03_ab_waves.txt
+  timeout 900 python tools/ab_k.py --libs $L --ks 17,20,21,24,31 --env "FH_WAVES_PER_CU=20" 2>&1 | tee gpurun_out/r03_ab_waves_20percu.txt
+  ;;
+round5)      # after: fused filter passes (finish_mash_in_place)
+  timeout 1800 python -m pytest tests/test_gpu_host_layer.py tests/test_gpu_full_size.py tests/test_gpu_fuzz.py -x -q -m gpu -k "not c4 and not c5 and not c2" 2>&1 | tail -4 | tee gpurun_out/r03_round5_pytest.txt
+  python tools/c3_resident.py > gpurun_out/r03e_c3_resident.txt 2>&1
+  FUZZ_CASES=150 timeout 900 python tools/fuzz_params.py > gpurun_out/r03e_fuzz_params.txt 2>&1; tail -3 gpurun_out/r03e_fuzz_params.txt
+  ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
