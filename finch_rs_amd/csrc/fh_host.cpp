@@ -1995,6 +1995,28 @@ static void host_parallel(size_t n, F f) {
     for (auto &x : th) x.join();
 }
 
+// the same team of threads for several passes in a row: starting and joining a std::thread costs 50-100 us, which for three
+// passes over a 2 M-hash oversketch was more than the passes themselves.  f(t, n_threads, barrier) runs on every thread;
+// barrier() returns once all of them have called it.
+template <class F>
+static void host_team(size_t n, F f) {
+    const unsigned t_max = (unsigned)std::min<size_t>(8, std::max<size_t>(1, n >> 16));
+    std::atomic<unsigned> arrived{0}, generation{0};
+    auto barrier = [&] {
+        const unsigned g = generation.load(std::memory_order_acquire);
+        if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == t_max) {
+            arrived.store(0, std::memory_order_relaxed);
+            generation.store(g + 1, std::memory_order_release);
+        } else {
+            while (generation.load(std::memory_order_acquire) == g) std::this_thread::yield();
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < t_max; ++t) th.emplace_back([&, t] { f(t, t_max, barrier); });
+    f(0u, t_max, barrier);
+    for (auto &x : th) x.join();
+}
+
 // FilterParams::filter_counts + process_post_filter (filtering.rs:60-87, mod.rs:115-128) for a Mash sketch, without a copy
 // of the oversketch: the filters are per-record tests plus one histogram, and only the first final_size survivors (in
 // hash order) are ever wanted -- so the count columns are read where the sketcher left them (fh_result_counts), the strand
@@ -2006,15 +2028,31 @@ static int finish_mash_in_place(fh_sketcher *h, const std::string &name, const f
     uint64_t n_view = 0;
     if (fh_result_counts(h, &cnt, &ext, &n_view) != FH_OK || n_view != n) return FH_ERR_STATE;
     const bool filter_on = fp.filter_on == 1;
-    // pass 1: the strand filter (filtering.rs:413-432) and, for the error filter, the largest count among what it leaves
+    static const bool trace = getenv("FH_TRACE") != nullptr;
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tt0 = trace ? now_ms() : 0;
+    double tt1 = 0, tt2 = 0, tt3 = 0;
+    // Three passes by ONE team of threads, each thread over its own stretch of the records:
+    //   1. the strand filter (filtering.rs:413-432) and, for the error filter, the largest count among what it leaves;
+    //   2. the histogram of those counts per thread; thread 0 adds them up and runs guess_filter_threshold (filtering.rs:154-195);
+    //   3. the abundance filter (filtering.rs:329-343) and the cut to final_size: every thread lists the survivors of its
+    //      stretch (at most final_size -- the first final_size in hash order are all that is wanted); joined in order below.
+    //      (With the error filter on, most of a 2 M-hash oversketch of reads are error k-mers below the cutoff: the first
+    //      10 000 survivors end around record 1.2 M.)
     std::vector<uint8_t> dropped;
     const bool strand = filter_on && fp.strand_filter > 0.0, errf = filter_on && fp.err_filter > 0.0;
+    if (strand) dropped.resize(n); // (every byte is written in pass 1)
+    uint8_t *const dw = strand ? dropped.data() : nullptr;
+    const uint8_t *const d = dw;
+    const double strand_cutoff = fp.strand_filter;
     uint32_t maxes[8] = {0};
-    if (strand || errf) {
-        if (strand) dropped.resize(n); // (every byte is written below)
-        const double cutoff = fp.strand_filter;
-        uint8_t *dw = strand ? dropped.data() : nullptr;
-        host_parallel(n, [&, dw, cutoff](unsigned t, size_t lo, size_t hi) {
+    std::vector<uint64_t> hist_part[8];
+    std::vector<uint32_t> rows_part[8];
+    uint32_t max_count = 0, lo_t = 0, hi_t = UINT32_MAX;
+    const size_t want = (size_t)std::min<uint64_t>(n, sp.final_size);
+    host_team(n, [&](unsigned t, unsigned nt, const auto &barrier) {
+        const size_t per = (n + nt - 1) / nt, lo = std::min<size_t>(n, t * per), hi = std::min<size_t>(n, lo + per);
+        if (strand || errf) {
             uint32_t m = 0;
             for (size_t i = lo; i < hi; ++i) {
                 const uint32_t c = cnt[i];
@@ -2023,64 +2061,65 @@ static int finish_mash_in_place(fh_sketcher *h, const std::string &name, const f
                     if (c >= 16) {
                         const uint32_t e = ext[i];
                         const uint32_t lowest = std::min(e, c - std::min(e, c));
-                        drop = !(((double)lowest / (double)c) >= cutoff);
+                        drop = !(((double)lowest / (double)c) >= strand_cutoff);
                     }
                     dw[i] = drop;
                 }
                 if (!drop) m = std::max(m, c);
             }
             maxes[t] = m;
-        });
-    }
-    const uint8_t *d = dropped.empty() ? nullptr : dropped.data();
-    if (errf) { // guess_filter_threshold on what the strand filter left (filtering.rs:154-195)
-        uint32_t max_count = 0;
-        for (uint32_t m : maxes) max_count = std::max(max_count, m);
-        std::vector<uint64_t> hist_data(max_count, 0);
-        if (max_count <= (1u << 22)) {
-            std::vector<std::vector<uint64_t>> part(8);
-            host_parallel(n, [&](unsigned t, size_t lo, size_t hi) {
-                std::vector<uint64_t> &p = part[t];
+        }
+        if (errf) {
+            barrier();
+            if (t == 0) {
+                for (unsigned j = 0; j < nt; ++j) max_count = std::max(max_count, maxes[j]);
+            }
+            barrier();
+            if (max_count <= (1u << 22)) {
+                std::vector<uint64_t> &p = hist_part[t];
                 p.assign(max_count, 0);
                 for (size_t i = lo; i < hi; ++i)
                     if (!(d && d[i]) && cnt[i]) p[cnt[i] - 1] += 1;
-            });
-            for (const auto &p : part)
-                for (size_t j = 0; j < p.size(); ++j) hist_data[j] += p[j];
-        } else {
-            for (size_t i = 0; i < n; ++i)
-                if (!(d && d[i]) && cnt[i]) hist_data[cnt[i] - 1] += 1;
-        }
-        const uint32_t cutoff = guess_filter_threshold_hist(hist_data, fp.err_filter);
-        if (fp.has_abun_lo) {
-            if (cutoff > fp.abun_lo) fp.abun_lo = cutoff;
-        } else {
-            fp.has_abun_lo = 1;
-            fp.abun_lo = cutoff;
-        }
-    }
-    // the abundance filter (filtering.rs:329-343) and the cut to final_size: every thread lists the survivors of its stretch
-    // (at most final_size of them -- the first final_size in hash order are all that is wanted), the lists are joined in order.
-    // (With the error filter on, most of a 2 M-hash oversketch of reads are error k-mers below the cutoff: the first 10 000
-    // survivors end somewhere around record 1.2 M, a millisecond as one serial scan.)
-    const bool abun = filter_on && (fp.has_abun_lo || fp.has_abun_hi);
-    const uint32_t lo_t = (abun && fp.has_abun_lo) ? fp.abun_lo : 0u, hi_t = (abun && fp.has_abun_hi) ? fp.abun_hi : UINT32_MAX;
-    std::vector<uint32_t> rows;
-    {
-        std::vector<uint32_t> part[8];
-        const size_t want = (size_t)std::min<uint64_t>(n, sp.final_size);
-        host_parallel(n, [&](unsigned t, size_t lo, size_t hi) {
-            std::vector<uint32_t> &p = part[t];
-            for (size_t i = lo; i < hi && p.size() < want; ++i)
-                if (!(d && d[i]) && lo_t <= cnt[i] && cnt[i] <= hi_t) p.push_back((uint32_t)i);
-        });
-        rows.reserve(want);
-        for (const auto &p : part) // (host_parallel hands out the stretches in index order: part[0] is the lowest)
-            for (uint32_t r : p) {
-                if (rows.size() >= want) break;
-                rows.push_back(r);
             }
-    }
+            barrier();
+            if (t == 0) {
+                std::vector<uint64_t> hist_data(max_count, 0);
+                if (max_count <= (1u << 22)) {
+                    for (unsigned j = 0; j < nt; ++j)
+                        for (size_t q = 0; q < hist_part[j].size(); ++q) hist_data[q] += hist_part[j][q];
+                } else { // (counts beyond 4 M: one histogram, one thread)
+                    for (size_t i = 0; i < n; ++i)
+                        if (!(d && d[i]) && cnt[i]) hist_data[cnt[i] - 1] += 1;
+                }
+                const uint32_t cutoff = guess_filter_threshold_hist(hist_data, fp.err_filter);
+                if (fp.has_abun_lo) {
+                    if (cutoff > fp.abun_lo) fp.abun_lo = cutoff;
+                } else {
+                    fp.has_abun_lo = 1;
+                    fp.abun_lo = cutoff;
+                }
+            }
+        }
+        barrier();
+        if (t == 0) {
+            const bool abun = filter_on && (fp.has_abun_lo || fp.has_abun_hi);
+            lo_t = (abun && fp.has_abun_lo) ? fp.abun_lo : 0u;
+            hi_t = (abun && fp.has_abun_hi) ? fp.abun_hi : UINT32_MAX;
+        }
+        barrier();
+        std::vector<uint32_t> &p = rows_part[t];
+        for (size_t i = lo; i < hi && p.size() < want; ++i)
+            if (!(d && d[i]) && lo_t <= cnt[i] && cnt[i] <= hi_t) p.push_back((uint32_t)i);
+    });
+    if (trace) tt1 = tt2 = now_ms();
+    std::vector<uint32_t> rows;
+    rows.reserve(want);
+    for (const auto &p : rows_part) // (thread t took the t-th stretch: rows_part[0] is the lowest)
+        for (uint32_t r : p) {
+            if (rows.size() >= want) break;
+            rows.push_back(r);
+        }
+    if (trace) tt3 = now_ms();
     if (!sp.no_strict && rows.size() < sp.final_size)
         return hfail(FH_ERR_INVALID, "%s had too few kmers (%zu) to sketch", name.c_str(), rows.size());
     const uint32_t k = sp.kmer_length;
@@ -2096,6 +2135,9 @@ static int finish_mash_in_place(fh_sketcher *h, const std::string &name, const f
         out.hashes[i] = KmerCount{recs[i].hash, std::string((const char *)km.get() + i * (size_t)k, k), recs[i].count, recs[i].extra_count};
     out.filter_params = fp;
     out.sketch_params = sp;
+    if (trace)
+        fprintf(stderr, "[finch] filters in place (n=%llu): three passes %.2f ms, joining the survivors %.2f ms, rows+records %.2f ms\n",
+                (unsigned long long)n, tt1 - tt0, tt3 - tt2, now_ms() - tt3);
     return FH_OK;
 }
 
