@@ -22,7 +22,8 @@ Workloads (synthetic 150 bp FASTQ-shaped read sets of SURVEY.md 8d M4, already r
       tmpfs through ONE finch_sketch_files call with devices = [0..N-1] (lib.rs:29-49); --files F (default 10000, cut to what
       the tmpfs holds and said so).  Under torch.distributed.run rank r takes files r, r+N, ...
 A step = one full pass: reset, sketch every base of the block, finish (bottom-n select, copy-out of the <= 1000 records to
-the host) and -- for N > 1 -- the host-side merge.  value = total bases of all GPUs * K / max-over-ranks time.
+the host) and -- for N > 1 -- the host-side merge, which runs one step behind the sketching on a thread of its own (all K merges
+complete inside the timed region).  value = total bases of all GPUs * K / max-over-ranks time.
 
 Self-check: the seven-number fingerprint of the final sketch (+ total_kmers) is compared with
 tests/golden/config_fingerprints.json, which the ORACLE produced on the CPU (tests/golden/make_config_fingerprints.py);
@@ -130,6 +131,49 @@ def check_golden(fp, key):
     out["golden"] = ("tests/golden/config_fingerprints.json[%s] (oracle, CPU)" % key) if g else None
     out["matches_golden"] = None if g is None else all(fp[k] == g[k] for k in FP_KEYS)
     return out, out["matches_golden"] is not False
+
+
+class MergePipe:
+    """The host-side merge of a step's partial sketches, one step behind the sketching: a worker thread takes each step's partial
+    sketch(es) in order, gathers (launched by torch.distributed.run: one small tensor per rank to rank 0) and merges them while
+    the GPUs are already on the next step.  flush() returns when everything handed over has been merged -- the timed region
+    ends with one, so all K merges are inside it; at most two steps may be in flight."""
+
+    def __init__(self, fn, init=None):
+        import queue
+        import threading
+        self.fn, self.init, self.last, self.err = fn, init, None, None
+        self.q = queue.Queue(maxsize=2)
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        if self.init is not None:
+            self.init()  # (torch's current device is per thread)
+        while True:
+            item = self.q.get()
+            try:
+                if item is not None and self.err is None:
+                    self.last = self.fn(item)
+            except BaseException as e:  # noqa: BLE001 -- re-raised on the main thread by flush()
+                self.err = e
+            finally:
+                self.q.task_done()
+            if item is None:
+                return
+
+    def put(self, item):
+        self.q.put(item)
+
+    def flush(self):
+        self.q.join()
+        if self.err is not None:
+            raise self.err
+        return self.last
+
+    def close(self):
+        self.q.put(None)
+        self.t.join()
 
 
 class Shard:
@@ -248,27 +292,32 @@ def main():
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=world)  # ctypes releases the GIL inside every library call
 
-    gathered = None
+    # The merge of a step's partial sketches (<= n records per GPU, O(N n) on the host -- finch_rs_amd/sharding.py) runs one
+    # step behind the sketching (MergePipe): launched by torch.distributed.run every rank ships its partial sketch to rank 0 as
+    # one small fixed-size tensor; in the one-process mode the partial sketches are already here.
+    if threads_mode:
+        merge = MergePipe(lambda parts: SH.merge_wire(params, [SH.pack_partial(kc, km, pos, tk, args.n, args.k) for (kc, km, pos, tk) in parts], args.n))
+    elif dist is not None:
+        merge = MergePipe(lambda part: SH.gather_and_merge(dist, params, part, args.n, device=gather_device),
+                          init=lambda: torch.cuda.set_device(my_devices[0]))
+    else:
+        merge = None
+    single = [None]
 
     def step():
-        nonlocal gathered
         if threads_mode:
-            parts = list(pool.map(lambda s: s.step(), shards))  # returns when every device has its partial sketch on the host
-            bufs = [SH.pack_partial(kc, km, pos, tk, args.n, args.k) for (kc, km, pos, tk) in parts]
-            gathered = SH.merge_wire(params, bufs, args.n)
+            merge.put(list(pool.map(lambda s: s.step(), shards)))  # returns when every device has its partial sketch on the host
+        elif dist is not None:
+            merge.put(shards[0].step())
         else:
-            part = shards[0].step()
-            if dist is not None:
-                # partial sketches are <= n records: ship them to rank 0 (one small fixed-size tensor per rank)
-                # and merge on the host, O(N*n) -- finch_rs_amd/sharding.py
-                merged = SH.gather_and_merge(dist, params, part, args.n, device=gather_device)
-                if rank == 0:
-                    gathered = merged
-            else:
-                gathered = part
+            single[0] = shards[0].step()
+
+    def merged():
+        return merge.flush() if merge is not None else single[0]
 
     for _ in range(args.warmup):
         step()
+    merged()
     # kernel-time accounting restarts with the timed region (reset() zeroes it)
     barrier()
     t0 = time.perf_counter()
@@ -278,8 +327,11 @@ def main():
         if rank == 0:
             ms, nl, npos = shards[0].sk.kernel_time()
             kernel_ms += ms; kernel_launches += nl; kernel_pos += npos
+    gathered = merged()  # every step's merge is done: inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
+    if merge is not None:
+        merge.close()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
