@@ -137,3 +137,37 @@ def test_kway_merge_equals_the_chain_of_pairwise_merges(kind):
         assert a[3] == b[3]
         assert np.array_equal(a[0], b[0]), (trial, kind)
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (trial, kind)
+
+
+def test_bench_merge_pipe_keeps_order_and_reraises():
+    """bench.py's MergePipe: items are merged in the order they were put, flush() waits for all of them and hands back the last
+    result, an exception in the merge surfaces on the caller's thread, and close() ends the worker"""
+    import importlib.util
+    import threading
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen, inits = [], []
+
+    def fn(x):
+        time.sleep(0.01)
+        seen.append((x, threading.current_thread().name))
+        return x * 10
+    p = bench.MergePipe(fn, init=lambda: inits.append(threading.current_thread().name))
+    assert p.flush() is None  # nothing handed over yet
+    for i in range(7):
+        p.put(i)  # (blocks when two are in flight)
+    assert p.flush() == 60 and [s[0] for s in seen] == list(range(7))
+    assert len(inits) == 1 and all(s[1] == inits[0] for s in seen) and inits[0] != threading.current_thread().name
+    p.close()
+    assert not p.t.is_alive()
+
+    def boom(x):
+        raise ValueError("merge failed on %d" % x)
+    q = bench.MergePipe(boom)
+    q.put(3)
+    with pytest.raises(ValueError, match="merge failed on 3"):
+        q.flush()
+    q.close()
