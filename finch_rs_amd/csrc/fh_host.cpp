@@ -2724,12 +2724,19 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
     if (K < 1 || K > 64) return hfail(FH_ERR_UNSUPPORTED, "kmer_length %u", K);
 
     const size_t n_w = devs.size();
+    // The reader fills the workers' own pinned staging buffers (two per handle, fh_text_buffers) in turn, so a chunk is
+    // copied once -- source to pinned memory, by the call's read threads -- and, FASTQ, its host-to-device copy starts the
+    // moment it is complete (fh_text_prefetch).  (Until round 3 the chunks went through heap buffers and each worker copied
+    // its chunk again: 13-19 GB/s of text against 52 for the single-handle path on the same box.)
     struct Worker {
         fh_sketcher *h = nullptr;
         ShardQueue q;
         std::thread th;
         int rc = FH_OK;
         std::string msg;
+        TextBuf tb[2];
+        bool is_free[2] = {true, true};
+        int fill = 0; // the slot the reader fills next: pushes consume the slots alternately
     };
     std::vector<std::unique_ptr<Worker>> W;
     struct Cleanup {
@@ -2744,30 +2751,24 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
         W[d]->h = fh_new(&fp, devs[d]);
         if (!W[d]->h) return hfail(FH_ERR_NO_DEVICE, "%s", fh_last_error());
         if (int rc = fh_reset(W[d]->h)) return hfail(rc, "%s", fh_last_error());
-    }
-    { // (the handles' staging buffers may be smaller than asked for -- the FH_STAGE_BYTES test knob: cut chunks that fit)
+        // (the handles' staging buffers may be smaller than asked for -- the FH_STAGE_BYTES test knob: cut chunks that fit)
         uint8_t *raw2[2] = {nullptr, nullptr};
         uint64_t cap = 0;
         int next = 0;
-        if (int rc = fh_text_buffers(W[0]->h, raw2, &cap, &next)) return hfail(rc, "%s", fh_last_error());
+        if (int rc = fh_text_buffers(W[d]->h, raw2, &cap, &next)) return hfail(rc, "%s", fh_last_error());
         stage = std::min(stage, cap);
+        W[d]->fill = next;
+        for (int i = 0; i < 2; ++i) W[d]->tb[i] = TextBuf{raw2[i], 0, (int)(2 * d) + i};
     }
-    // chunk buffers circulate between the reader and the workers
+    for (auto &w : W)
+        for (auto &t : w->tb) t.cap = (size_t)stage;
     std::mutex free_mu;
     std::condition_variable free_cv;
-    std::vector<std::unique_ptr<uint8_t[]>> mem;
-    std::vector<TextBuf> bufs(2 * n_w + 1);
-    std::vector<TextBuf *> free_list;
-    for (size_t i = 0; i < bufs.size(); ++i) {
-        mem.emplace_back(new uint8_t[stage]);
-        bufs[i] = TextBuf{mem.back().get(), (size_t)stage, (int)i};
-        free_list.push_back(&bufs[i]);
-    }
     std::atomic<bool> abort{false};
-    auto give_back = [&](TextBuf *b) {
+    auto give_back = [&](TextBuf *b) { // (a buffer taken by the reader but not sent: free again, the same slot is next)
         std::lock_guard<std::mutex> g(free_mu);
-        free_list.push_back(b);
-        free_cv.notify_one();
+        W[(size_t)b->id / 2]->is_free[b->id & 1] = true;
+        free_cv.notify_all();
     };
     auto worker_main = [&](Worker *w) {
         for (;;) {
@@ -2781,15 +2782,7 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
             }
             if (job.stop) return;
             if (w->rc == FH_OK && !abort) {
-                uint8_t *dst = nullptr;
-                uint64_t cap = 0;
-                int rc = fh_text_buffer(w->h, &dst, &cap);
-                const bool too_long = rc == FH_OK && job.len > cap;
-                if (too_long) rc = FH_ERR_INVALID;
-                if (rc == FH_OK) {
-                    memcpy(dst, job.buf->data(), job.len);
-                    rc = fh_set_stream_offset(w->h, job.text_off);
-                }
+                int rc = fh_set_stream_offset(w->h, job.text_off);
                 if (rc == FH_OK && fastq) rc = fh_push_fastq_text(w->h, job.len);
                 if (rc == FH_OK && !fastq) {
                     if (job.halo_len) rc = fh_set_text_halo(w->h, job.halo, job.halo_len);
@@ -2797,11 +2790,11 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
                 }
                 if (rc != FH_OK) {
                     w->rc = rc;
-                    w->msg = too_long ? "chunk longer than the staging buffer" : fh_last_error();
+                    w->msg = fh_last_error();
                     abort = true;
                 }
             }
-            give_back(job.buf);
+            give_back(job.buf); // (the push is done with the host copy of its buffer when it returns)
         }
     };
     for (auto &w : W) w->th = std::thread(worker_main, w.get());
@@ -2812,18 +2805,25 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
         w->q.q.push_back(job);
         w->q.cv.notify_all();
     };
+    size_t next_w = 0; // the worker the next chunk goes to
     auto take_buf = [&]() {
+        Worker *w = W[next_w].get();
         std::unique_lock<std::mutex> lk(free_mu);
-        free_cv.wait(lk, [&] { return !free_list.empty(); });
-        TextBuf *b = free_list.back();
-        free_list.pop_back();
-        return b;
+        free_cv.wait(lk, [&] { return w->is_free[w->fill]; });
+        w->is_free[w->fill] = false;
+        return &w->tb[w->fill];
     };
 
     // ---- the reader ----
-    size_t next_w = 0;
     const int rrc = shard_reader(*src, fastq, K, take_buf, give_back, [&](const ShardWork &job) {
-        send(next_w, job);
+        Worker *w = W[next_w].get();
+        if (!abort) {
+            if (fastq) (void)fh_text_prefetch(w->h, job.buf->id & 1, job.len);
+            w->fill ^= 1;
+            send(next_w, job);
+        } else {
+            give_back(job.buf); // (a worker failed: nothing more is pushed; the same slot stays next)
+        }
         next_w = (next_w + 1) % n_w;
     }, abort, st);
     for (size_t d = 0; d < n_w; ++d) {
@@ -3209,7 +3209,8 @@ int finch_sketch_buffer_sharded(const uint8_t *data, uint64_t len, const char *n
     auto res = std::make_unique<finch_sketches>();
     res->v.resize(1);
     bool rejected = false;
-    int rc = sketch_stream_sharded(std::make_unique<MemSource>(data, (size_t)len), name ? name : "", *sp, *filters, devs, chunk_bytes,
+    const unsigned mem_threads = read_threads_total(getenv("FINCH_READ_THREADS"));
+    int rc = sketch_stream_sharded(std::make_unique<MemSource>(data, (size_t)len, mem_threads), name ? name : "", *sp, *filters, devs, chunk_bytes,
                                    res->v[0], &rejected);
     if (rc != FH_OK && rejected) { // (see finch_sketch_file_sharded)
         HandleSet handles;
@@ -3217,7 +3218,7 @@ int finch_sketch_buffer_sharded(const uint8_t *data, uint64_t len, const char *n
         handles.final_size = sp->final_size;
         handles.device = devs[0];
         res->v[0] = Sketch();
-        rc = sketch_stream(std::make_unique<MemSource>(data, (size_t)len), name ? name : "", *sp, *filters, handles, res->v[0]);
+        rc = sketch_stream(std::make_unique<MemSource>(data, (size_t)len, mem_threads), name ? name : "", *sp, *filters, handles, res->v[0]);
     }
     if (rc != FH_OK) return rc;
     *out = res.release();
