@@ -1769,8 +1769,14 @@ int fh_push_fasta_text(fh_sketcher *s, uint64_t len, uint32_t start_state, uint3
     const uint64_t carry_len = halo_len ? halo_len : std::min<uint64_t>(K - 1, s->dprev_len);
     uint8_t *dst = s->d_packed[b];
     HIP_TRY(hipMemsetAsync(s->d_text_tot, 0, 4 * sizeof(uint32_t), s->stream));
-    HIP_TRY(hipMemcpyAsync(s->d_stage[b], s->h_stage[b] + STAGE_HEADROOM, len, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+    if (s->stage_prefetched[b] == len) { // the reader's thread has the copy under way (fh_text_prefetch)
+        HIP_TRY(hipStreamWaitEvent(s->stream, s->stage_done[b], 0));
+    } else {
+        if (s->stage_prefetched[b]) HIP_TRY(hipEventSynchronize(s->stage_done[b])); // (a prefetch of something else: let it land first)
+        HIP_TRY(hipMemcpyAsync(s->d_stage[b], s->h_stage[b] + STAGE_HEADROOM, len, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+    }
+    s->stage_prefetched[b] = 0;
     s->stage_busy[b] = true;
     if (halo_len) // (the call synchronises the stream below, before s->halo can change)
         HIP_TRY(hipMemcpyAsync(dst, s->halo, halo_len, hipMemcpyHostToDevice, s->stream));

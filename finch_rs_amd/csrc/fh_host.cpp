@@ -1910,8 +1910,31 @@ struct FastaCounter {
     }
     // what fh_push_fasta_text has to be told about the point the next chunk starts at
     uint32_t start_state() const { return in_header ? 2u : (at_line_start ? 0u : 1u); }
-    void feed(const uint8_t *p, size_t n) {
-        size_t i = 0;
+    // every '>' of p[0, n), in order, found by `threads` threads (a 64 MiB chunk is 5 ms of memchr on one thread -- more than
+    // the chunk's copy to the device takes -- and holds a handful of them)
+    static void find_gt(const uint8_t *p, size_t n, unsigned threads, std::vector<size_t> &out, size_t min_piece = (size_t)4 << 20) {
+        out.clear();
+        const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, threads), std::max<size_t>(1, n / min_piece));
+        std::vector<std::vector<size_t>> part(nt);
+        const size_t per = (n + nt - 1) / nt;
+        auto job = [&](unsigned t) {
+            const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
+            for (size_t i = lo; i < hi;) {
+                const uint8_t *g = (const uint8_t *)memchr(p + i, '>', hi - i);
+                if (!g) break;
+                part[t].push_back((size_t)(g - p));
+                i = (size_t)(g - p) + 1;
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(job, t);
+        job(0);
+        for (auto &x : th) x.join();
+        for (auto &v : part) out.insert(out.end(), v.begin(), v.end());
+    }
+    // gts: the positions of every '>' in p[0, n) if the caller has them (find_gt), else they are searched for as the walk goes
+    void feed(const uint8_t *p, size_t n, const std::vector<size_t> *gts = nullptr) {
+        size_t i = 0, gc = 0;
         while (i < n) {
             if (in_header) {
                 const uint8_t *nl = (const uint8_t *)memchr(p + i, '\n', n - i);
@@ -1921,7 +1944,13 @@ struct FastaCounter {
                 at_line_start = true;
                 continue;
             }
-            const uint8_t *g = (const uint8_t *)memchr(p + i, '>', n - i);
+            const uint8_t *g;
+            if (gts) {
+                while (gc < gts->size() && (*gts)[gc] < i) ++gc;
+                g = gc < gts->size() ? p + (*gts)[gc] : nullptr;
+            } else {
+                g = (const uint8_t *)memchr(p + i, '>', n - i);
+            }
             const size_t gi = g ? (size_t)(g - p) : n;
             const bool line_start = g && (gi == i ? at_line_start : p[gi - 1] == '\n');
             if (g && !line_start) { // a '>' inside a line is sequence text
@@ -2347,6 +2376,7 @@ static int shard_reader(ByteSource &src_ref, bool fastq, uint32_t K, Take take_b
         bool eof = false;
         uint64_t text_off = 0; // offset of the next chunk's first byte in the decompressed text
         FastaCounter fc;
+        std::vector<size_t> gt_pos;
         uint8_t halo[64];
         uint32_t halo_len = 0;
         while ((!eof || !left.empty()) && !abort) {
@@ -2421,7 +2451,12 @@ static int shard_reader(ByteSource &src_ref, bool fastq, uint32_t K, Take take_b
                 uint8_t nh[64];
                 uint32_t nh_len = 0;
                 fasta_tail(buf, cut, job.start_state, K - 1, halo, (job.start_state != 2 && fc.have_record) ? halo_len : 0u, nh, &nh_len);
-                fc.feed(buf, cut);
+                if (cut >= ((size_t)8 << 20) && src->threads_hint() > 1) {
+                    FastaCounter::find_gt(buf, cut, src->threads_hint(), gt_pos);
+                    fc.feed(buf, cut, &gt_pos);
+                } else {
+                    fc.feed(buf, cut);
+                }
                 memcpy(halo, nh, nh_len);
                 halo_len = nh_len;
             }
@@ -2511,9 +2546,9 @@ static int pump_text_to_device(ByteSource &src, fh_sketcher *h, bool fastq, uint
                 is_free[b->id] = true;
             },
             [&](const ShardWork &job) {
-                // FASTQ: the chunk's copy to the device starts now, behind the previous chunk's, while that one's push is
-                // still busy with its record-splitting kernel -- the link never idles between pushes
-                if (fastq) (void)fh_text_prefetch(h, job.buf->id, job.len);
+                // the chunk's copy to the device starts now, behind the previous chunk's, while that one's push is still busy
+                // with its record-splitting kernel -- the link never idles between pushes
+                (void)fh_text_prefetch(h, job.buf->id, job.len);
                 std::lock_guard<std::mutex> g(mu);
                 ready.push_back(job);
                 fill ^= 1;
@@ -2818,7 +2853,7 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
     const int rrc = shard_reader(*src, fastq, K, take_buf, give_back, [&](const ShardWork &job) {
         Worker *w = W[next_w].get();
         if (!abort) {
-            if (fastq) (void)fh_text_prefetch(w->h, job.buf->id & 1, job.len);
+            (void)fh_text_prefetch(w->h, job.buf->id & 1, job.len);
             w->fill ^= 1;
             send(next_w, job);
         } else {
@@ -3529,7 +3564,8 @@ int finch_source_probe(const uint8_t *data, uint64_t len, uint64_t chunk, uint8_
 // the way fasta_text_to_device cuts them: lets the host-only tests check it against finch_fastx_scan without a GPU.
 int finch_fasta_count_chunked(const uint8_t *data, uint64_t len, uint64_t chunk, uint64_t *n_records, uint64_t *total_bases) try {
     if ((!data && len) || chunk == 0) return hfail(FH_ERR_INVALID, "bad argument");
-    FastaCounter fc;
+    FastaCounter fc, fc2;
+    std::vector<size_t> gts;
     uint64_t off = 0;
     while (off < len) {
         uint64_t n = std::min<uint64_t>(chunk, len - off);
@@ -3538,9 +3574,18 @@ int finch_fasta_count_chunked(const uint8_t *data, uint64_t len, uint64_t chunk,
             if (nl) n = (uint64_t)((const uint8_t *)nl - (data + off)) + 1;
         }
         fc.feed(data + off, (size_t)n);
+        // (the same chunk the way large chunks are fed: the '>' positions found beforehand, here by three threads on pieces
+        //  of >= 64 bytes so that small test inputs split too)
+        FastaCounter::find_gt(data + off, (size_t)n, 3, gts, 64);
+        fc2.feed(data + off, (size_t)n, &gts);
         off += n;
     }
     fc.finish();
+    fc2.finish();
+    if (fc2.n_records != fc.n_records || fc2.total_bases != fc.total_bases)
+        return hfail(FH_ERR_STATE, "FastaCounter: the two ways of feeding a chunk disagree (%llu / %llu records, %llu / %llu bases)",
+                     (unsigned long long)fc.n_records, (unsigned long long)fc2.n_records, (unsigned long long)fc.total_bases,
+                     (unsigned long long)fc2.total_bases);
     if (n_records) *n_records = fc.n_records;
     if (total_bases) *total_bases = fc.total_bases;
     return FH_OK;

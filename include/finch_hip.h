@@ -114,7 +114,7 @@ int fh_text_buffers(fh_sketcher *s, uint8_t *bufs[2], uint64_t *cap, int *next);
 int fh_push_fastq_text(fh_sketcher *s, uint64_t len);
 /* Optional: start the host-to-device copy of staging buffer `slot` (0 / 1 of fh_text_buffers, filled with `len` bytes) right
  * away, on the handle's copy stream -- the one call a SECOND thread (the reader that has just filled the buffer) may make
- * while a push of the other buffer is running.  The fh_push_fastq_text that later consumes the slot with the same `len`
+ * while a push of the other buffer is running.  The fh_push_fastq_text / fh_push_fasta_text that later consumes the slot with the same `len`
  * finds its text already on the way; without the call the push copies by itself.  This is what keeps the PCIe link busy
  * across pushes (a push also waits for its record-splitting kernel). */
 int fh_text_prefetch(fh_sketcher *s, int slot, uint64_t len);
