@@ -705,7 +705,9 @@ int sampled_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
         S += H[q];
         c1 += H[256 + q];
         c2 += H[512 + q];
-        if (S < 1024 || c2 < 32) continue; // too few doubletons to say anything about the unseen
+        // too few doubletons to say anything about the unseen (the low-cap pass asks for more of them: its estimate rests on a
+        // quarter of the sample, and a threshold that comes out too tight costs a second pass over the block)
+        if (S < 1024 || c2 < (cap_occ < 1.0 ? 128 : 32)) continue;
         const double est = S + c1 * c1 / (2.0 * c2);
         if (est >= want) {
             const uint64_t hi = qoct_upper_edge(q), lo = q ? qoct_upper_edge(q - 1) : 0;
