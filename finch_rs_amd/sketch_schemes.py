@@ -137,12 +137,17 @@ class HipSketcher:
         """mash.rs:82-84 (total_bases is a host counter; see include/finch_hip.h)"""
         return self.total_bases, self.finish()[1]
 
-    def to_arrays(self):
-        """-> (structured [hash,count,extra_count], kmers uint8 [n,k], first_pos uint64 [n]) ascending by hash"""
+    def to_arrays(self, out=None):
+        """-> (structured [hash,count,extra_count], kmers uint8 [n,k], first_pos uint64 [n]) ascending by hash.
+        `out`: arrays of an earlier call to fill again (a caller that keeps its buffers: 2 M records are 110 MB, and first
+        touching fresh pages costs several times what the copy does); used if they have room, views of them are returned."""
         n, _ = self.finish()
-        kc = np.empty(n, dtype=KC_DTYPE)  # = struct fh_kmer_count
-        km = np.empty((n, self.kmer_length), dtype=np.uint8)
-        ps = np.empty(n, dtype=np.uint64)
+        if out is not None and len(out[0]) >= n and out[1].shape[1] == self.kmer_length:
+            kc, km, ps = out[0][:n], out[1][:n], out[2][:n]
+        else:
+            kc = np.empty(n, dtype=KC_DTYPE)  # = struct fh_kmer_count
+            km = np.empty((n, self.kmer_length), dtype=np.uint8)
+            ps = np.empty(n, dtype=np.uint64)
         check(self._L.fh_copy_out_records(self._h, kc.ctypes.data_as(C.c_void_p), km.ctypes.data_as(C.c_void_p),
                                           ps.ctypes.data_as(C.c_void_p)))
         return kc, km, ps
