@@ -1050,7 +1050,7 @@ uint32_t sat_add(uint32_t a, uint32_t b) {
 
 extern "C" {
 
-int fh_abi_version(void) { return 2; }
+int fh_abi_version(void) { return 3; } // 3: fh_text_prefetch
 
 const char *fh_last_error(void) { return g_err.c_str(); }
 
