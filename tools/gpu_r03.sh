@@ -100,5 +100,11 @@ round5)      # after: fused filter passes (finish_mash_in_place)
   python tools/c3_resident.py > gpurun_out/r03e_c3_resident.txt 2>&1
   FUZZ_CASES=150 timeout 900 python tools/fuzz_params.py > gpurun_out/r03e_fuzz_params.txt 2>&1; tail -3 gpurun_out/r03e_fuzz_params.txt
   ;;
+fuzz)        # a fuzz campaign over the paths round 3 touched (inline pump, prefetch, sharded reader, copy-out forms, kernels)
+  ( timeout 2400 python tools/fuzz_params.py 1200 930001 2>&1 | tail -2
+    FUZZ_FILES=1 timeout 2400 python tools/fuzz_device_text.py 1200 930002 2>&1 | tail -2
+    FUZZ_SHARDED=1 timeout 2400 python tools/fuzz_device_text.py 1200 930003 2>&1 | tail -2
+    FH_FUZZ_CASES=2000 FH_FUZZ_SEED=31337 timeout 1500 python -m pytest tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -2 ) | tee gpurun_out/r03_fuzz_campaign.txt
+  ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
