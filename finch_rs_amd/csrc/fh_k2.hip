@@ -115,6 +115,12 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
     u32 wave_inserts = 0; // new hashes this wave inserted in this launch (wave-uniform)
     u32 qn = 0;           // occupancy of the admit queue (wave-uniform)
     AdmitQueueT<false> *queue = &sQueue[wave];
+    if (lane == 0) { // what the drain needs to finish the admit test
+        queue->tau = tau;
+        queue->tau_lo = HASLO ? a.tau_lo : 0ull;
+        queue->hash_mask = MASKED ? a.hash_mask : ~0ull;
+        queue->pre = (u32)pre_shift(K);
+    }
     const u32 shard = gw & (u32)(N_SHARDS - 1);
     u32 last_unit = 0; // guides the pull size
     for (;;) {
@@ -201,9 +207,8 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
             // windows that carry no k-mer hash garbage; they are rejected on the (rare) admit path only
             const bool cand = MASKED ? ((parts_hash(hp) & a.hash_mask) <= tau) : (parts_hi_plus1(hp) <= tau_hi1);
             if (__builtin_expect(__any(cand), 0)) { // wave-uniform branch
-                u64 h = parts_hash(hp);
-                if (MASKED) h &= a.hash_mask; // test hook only
-                const bool take = (h <= tau) && ((Wc >> j) & 1u) && (!HASLO || h > a.tau_lo);
+                // the candidate is parked with its hash unfinished; flush_queue completes and tests it (fh_k2_common.h)
+                const bool take = cand && ((Wc >> j) & 1u);
                 const u64 mask = __ballot(take);
                 const u32 cnt = (u32)__popcll(mask);
                 if (cnt) {
@@ -213,8 +218,9 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
                     }
                     const u32 my = qn + __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
                     if (take) {
-                        queue->h[my] = h;
-                        queue->k[my] = cm >> pre_shift(K); // the loop carries the canonical word pre-shifted (fh_core.h)
+                        queue->ka[my] = hp.ka;
+                        queue->kb[my] = hp.kb;
+                        queue->k[my] = cm; // as the loop carries it: pre-shifted (fh_core.h); the drain shifts
                         // position of this window, from scalars + the lane id recomputed here (two instructions)
                         // rather than a 64-bit per-lane value kept alive -- i.e. spilled -- across the loop
                         u32 lane_here; // (volatile: or the compiler hoists it out of the loop and spills it after all)

@@ -184,9 +184,15 @@ struct AdmitQueueT {
     u64 h[QCAP], k[QCAP], p[QCAP];
     u64 khi[QCAP]; // K > 32 (fh_k2w.hip): the k-mer's high word
 };
+// K <= 32: a candidate is parked UNHASHED -- the two fmix64 states the hot loop's high-word test was made on (HashParts), its
+// canonical word as the loop carries it and its position -- and the drain finishes the job for up to 64 of them at once:
+// last multiply and xor-shift of murmur3, the exact threshold test, the upsert.  In the hot loop that work would run on all
+// 64 lanes for the one lane that is a candidate (17 % of the wave-iterations of configs[2] have one: DESIGN.md 5.3).
 template <>
-struct AdmitQueueT<false> { // K <= 32: 1.5 KB per wave (the 2 KB saved per workgroup is what lets five of them share a CU's LDS)
-    u64 h[QCAP], k[QCAP], p[QCAP];
+struct AdmitQueueT<false> {
+    u64 ka[QCAP], kb[QCAP], k[QCAP], p[QCAP];
+    u64 tau, tau_lo, hash_mask; // the launch's thresholds and the test hook's mask (all ones otherwise): set once per wave
+    u32 pre, pad;               // pre_shift(K): the canonical word is parked as the loop carries it
 };
 
 template <bool WIDE = false>
@@ -199,8 +205,14 @@ __device__ __noinline__ u32 flush_queue(Ctl *ctl, const AdmitQueueT<WIDE> *q_gen
     const u32 qn = (u32)__builtin_amdgcn_readfirstlane((int)qn_v);
     if (lane < qn) {
         const u64 pp = q->p[lane];
-        if constexpr (WIDE) ins = upsert_w(ctl, q->h[lane], q->k[lane], q->khi[lane], pp & 0x7FFFFFFFFFFFFFFFull, (u32)(pp >> 63), shard);
-        else ins = upsert(ctl, q->h[lane], q->k[lane], pp & 0x7FFFFFFFFFFFFFFFull, (u32)(pp >> 63), shard);
+        if constexpr (WIDE) {
+            ins = upsert_w(ctl, q->h[lane], q->k[lane], q->khi[lane], pp & 0x7FFFFFFFFFFFFFFFull, (u32)(pp >> 63), shard);
+        } else {
+            const u64 h = parts_hash(HashParts{q->ka[lane], q->kb[lane]}) & q->hash_mask;
+            const u64 lo = q->tau_lo; // (non-zero only when a block is re-read for the hashes above a threshold that was too tight)
+            if (h <= q->tau && (lo == 0ull || h > lo))
+                ins = upsert(ctl, h, q->k[lane] >> q->pre, pp & 0x7FFFFFFFFFFFFFFFull, (u32)(pp >> 63), shard);
+        }
     }
     return (u32)__popcll(__ballot(ins != 0u));
 }
