@@ -303,9 +303,10 @@ struct Decoder {
                         continue;
                     }
                     size_t n = stored_left;
-                    if ((size_t)(in_end - in) < n) n = (size_t)(in_end - in);
+                    const size_t in_left = in < in_end ? (size_t)(in_end - in) : 0;
+                    if (in_left < n) n = in_left;
                     if ((size_t)(out_end - out) < n) n = (size_t)(out_end - out);
-                    if (n == 0) return in == in_end ? NEED_INPUT : NEED_OUTPUT;
+                    if (n == 0) return in_left == 0 ? NEED_INPUT : NEED_OUTPUT;
                     memcpy(out, in, n);
                     in += n;
                     out += n;
@@ -325,7 +326,7 @@ struct Decoder {
     // make at least `need` (<= 56) bits available if the input has them
     inline bool fill(const uint8_t *&in, const uint8_t *in_end, int need) {
         while (bitcnt < need) {
-            if (in == in_end) return false;
+            if (in >= in_end) return false; // (>=: the symbol loops of fh_pargz.h read ahead into the padding behind the input)
             bitbuf |= (uint64_t)*in++ << bitcnt;
             bitcnt += 8;
         }
@@ -556,7 +557,7 @@ struct Decoder {
             const uint8_t *const sv_in = in;
             auto more = [&](int need) { // >= need bits, byte by byte
                 while (bc < need) {
-                    if (in == in_end) return false;
+                    if (in >= in_end) return false;
                     bb |= (uint64_t)*in++ << bc;
                     bc += 8;
                 }
