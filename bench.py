@@ -9,7 +9,8 @@ timed beside it and a self-check of the sketch against the oracle's golden finge
 How the N GPUs are driven.  Launched by torch.distributed.run (WORLD_SIZE in the environment): one process per GPU, rank r
 sketches read block r, rank 0 gathers the <= n-record partial sketches and merges them on the host.  Launched plainly with
 --gpus N > 1: ONE process, one host thread and one sketcher handle per device (the reference's own shape -- finch is one
-process, lib.rs:34-36 -- and SURVEY section 7 step 5), the main thread merging the partial sketches.  Either way there is no
+process, lib.rs:34-36 -- and SURVEY section 7 step 5; ctypes releases the GIL inside every library call), the main thread
+merging the partial sketches.  Either way there is no
 data-path collective: read blocks are independent and the merge is O(N n).
 
 Workloads (synthetic 150 bp FASTQ-shaped read sets of SURVEY.md 8d M4, already resident in HBM as the packed sequence stream
@@ -134,10 +135,10 @@ def check_golden(fp, key):
 
 
 class MergePipe:
-    """The host-side merge of a step's partial sketches, one step behind the sketching: a worker thread takes each step's partial
-    sketch(es) in order, gathers (launched by torch.distributed.run: one small tensor per rank to rank 0) and merges them while
-    the GPUs are already on the next step.  flush() returns when everything handed over has been merged -- the timed region
-    ends with one, so all K merges are inside it; at most two steps may be in flight."""
+    """Launched by torch.distributed.run: the gather + host-side merge of a step's partial sketches, one step behind the
+    sketching -- a worker thread takes each step's partial sketch in order, ships it to rank 0 (one small tensor per rank) and
+    rank 0's merges them while the GPUs are already on the next step.  flush() returns when everything handed over has been
+    merged -- the timed region ends with one, so all K merges are inside it; at most two steps may be in flight."""
 
     def __init__(self, fn, init=None):
         import queue
@@ -287,49 +288,68 @@ def main():
         bounds = {r: SH.shard_bounds(total_reads, r, world) for r in my_ranks}
     shards = [Shard(F, S, d, bounds[r][0], bounds[r][1] - bounds[r][0], params, args.max_launch, profiling=(r == 0))
               for r, d in zip(my_ranks, my_devices)]
-    pool = None
-    if threads_mode:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=world)  # ctypes releases the GIL inside every library call
 
-    # The merge of a step's partial sketches (<= n records per GPU, O(N n) on the host -- finch_rs_amd/sharding.py) runs one
-    # step behind the sketching (MergePipe): launched by torch.distributed.run every rank ships its partial sketch to rank 0 as
-    # one small fixed-size tensor; in the one-process mode the partial sketches are already here.
-    if threads_mode:
-        merge = MergePipe(lambda parts: SH.merge_wire(params, [SH.pack_partial(kc, km, pos, tk, args.n, args.k) for (kc, km, pos, tk) in parts], args.n))
-    elif dist is not None:
+    # The merge of a step's partial sketches (<= n records per GPU, O(N n) on the host -- finch_rs_amd/sharding.py) runs behind
+    # the sketching.  Launched by torch.distributed.run: every rank ships its partial sketch to rank 0 as one small fixed-size
+    # tensor, on a thread of its own (MergePipe).  One process: every device has its own host thread that runs ITS K passes
+    # back to back (no per-step rendezvous of the devices; at most two partial sketches per device wait to be merged), and
+    # this thread merges step i as soon as all N partial sketches of step i are there.
+    kernel_acc = [0.0, 0, 0]  # ms, launches, positions of device 0's sketch launches
+
+    def run_steps(n_steps, timed):
+        if threads_mode:
+            import queue
+            import threading
+            qs = [queue.Queue(maxsize=2) for _ in shards]
+            errs = []
+
+            def device_loop(i):
+                try:
+                    for _ in range(n_steps):
+                        part = shards[i].step()
+                        if timed and i == 0:
+                            ms, nl, npos = shards[0].sk.kernel_time()
+                            kernel_acc[0] += ms; kernel_acc[1] += nl; kernel_acc[2] += npos
+                        qs[i].put(part)
+                except BaseException as e:  # noqa: BLE001 -- re-raised below
+                    errs.append(e)
+                    qs[i].put(None)
+            ths = [threading.Thread(target=device_loop, args=(i,), daemon=True) for i in range(len(shards))]
+            for t in ths:
+                t.start()
+            last = None
+            for _ in range(n_steps):
+                parts = [q.get() for q in qs]
+                if any(p is None for p in parts):
+                    raise errs[0]
+                last = SH.merge_wire(params, [SH.pack_partial(kc, km, pos, tk, args.n, args.k) for (kc, km, pos, tk) in parts], args.n)
+            for t in ths:
+                t.join()
+            return last
+        last = None
+        for _ in range(n_steps):
+            part = shards[0].step()
+            if timed and rank == 0:
+                ms, nl, npos = shards[0].sk.kernel_time()
+                kernel_acc[0] += ms; kernel_acc[1] += nl; kernel_acc[2] += npos
+            if merge is not None:
+                merge.put(part)
+            else:
+                last = part
+        return merge.flush() if merge is not None else last
+
+    merge = None
+    if dist is not None:
         merge = MergePipe(lambda part: SH.gather_and_merge(dist, params, part, args.n, device=gather_device),
                           init=lambda: torch.cuda.set_device(my_devices[0]))
-    else:
-        merge = None
-    single = [None]
-
-    def step():
-        if threads_mode:
-            merge.put(list(pool.map(lambda s: s.step(), shards)))  # returns when every device has its partial sketch on the host
-        elif dist is not None:
-            merge.put(shards[0].step())
-        else:
-            single[0] = shards[0].step()
-
-    def merged():
-        return merge.flush() if merge is not None else single[0]
-
-    for _ in range(args.warmup):
-        step()
-    merged()
+    run_steps(args.warmup, False)
     # kernel-time accounting restarts with the timed region (reset() zeroes it)
     barrier()
     t0 = time.perf_counter()
-    kernel_ms, kernel_launches, kernel_pos = 0.0, 0, 0
-    for _ in range(args.steps):
-        step()
-        if rank == 0:
-            ms, nl, npos = shards[0].sk.kernel_time()
-            kernel_ms += ms; kernel_launches += nl; kernel_pos += npos
-    gathered = merged()  # every step's merge is done: inside the timed region
+    gathered = run_steps(args.steps, True)  # returns when every step's merge is done: inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms, kernel_launches, kernel_pos = kernel_acc
     if merge is not None:
         merge.close()
     if dist is not None:
