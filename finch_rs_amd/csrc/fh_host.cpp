@@ -2027,23 +2027,35 @@ static void host_parallel(size_t n, F f) {
 // the same team of threads for several passes in a row: starting and joining a std::thread costs 50-100 us, which for three
 // passes over a 2 M-hash oversketch was more than the passes themselves.  f(t, n_threads, barrier) runs on every thread;
 // barrier() returns once all of them have called it.
+// barrier() returns false once any thread of the team has failed (an allocation, in practice): everybody then leaves at its
+// next barrier instead of waiting for a thread that is gone, and host_team reports the failure.
 template <class F>
-static void host_team(size_t n, F f) {
+static bool host_team(size_t n, F f) {
     const unsigned t_max = (unsigned)std::min<size_t>(8, std::max<size_t>(1, n >> 16));
     std::atomic<unsigned> arrived{0}, generation{0};
-    auto barrier = [&] {
+    std::atomic<bool> failed{false};
+    auto barrier = [&]() -> bool {
         const unsigned g = generation.load(std::memory_order_acquire);
         if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == t_max) {
             arrived.store(0, std::memory_order_relaxed);
             generation.store(g + 1, std::memory_order_release);
         } else {
-            while (generation.load(std::memory_order_acquire) == g) std::this_thread::yield();
+            while (generation.load(std::memory_order_acquire) == g && !failed.load(std::memory_order_acquire)) std::this_thread::yield();
+        }
+        return !failed.load(std::memory_order_acquire);
+    };
+    auto run = [&](unsigned t) {
+        try {
+            f(t, t_max, barrier);
+        } catch (...) {
+            failed.store(true, std::memory_order_release);
         }
     };
     std::vector<std::thread> th;
-    for (unsigned t = 1; t < t_max; ++t) th.emplace_back([&, t] { f(t, t_max, barrier); });
-    f(0u, t_max, barrier);
+    for (unsigned t = 1; t < t_max; ++t) th.emplace_back(run, t);
+    run(0u);
     for (auto &x : th) x.join();
+    return !failed.load();
 }
 
 // FilterParams::filter_counts + process_post_filter (filtering.rs:60-87, mod.rs:115-128) for a Mash sketch, without a copy
@@ -2079,7 +2091,7 @@ static int finish_mash_in_place(fh_sketcher *h, const std::string &name, const f
     std::vector<uint32_t> rows_part[8];
     uint32_t max_count = 0, lo_t = 0, hi_t = UINT32_MAX;
     const size_t want = (size_t)std::min<uint64_t>(n, sp.final_size);
-    host_team(n, [&](unsigned t, unsigned nt, const auto &barrier) {
+    const bool team_ok = host_team(n, [&](unsigned t, unsigned nt, const auto &barrier) {
         const size_t per = (n + nt - 1) / nt, lo = std::min<size_t>(n, t * per), hi = std::min<size_t>(n, lo + per);
         if (strand || errf) {
             uint32_t m = 0;
@@ -2099,18 +2111,18 @@ static int finish_mash_in_place(fh_sketcher *h, const std::string &name, const f
             maxes[t] = m;
         }
         if (errf) {
-            barrier();
+            if (!barrier()) return;
             if (t == 0) {
                 for (unsigned j = 0; j < nt; ++j) max_count = std::max(max_count, maxes[j]);
             }
-            barrier();
+            if (!barrier()) return;
             if (max_count <= (1u << 22)) {
                 std::vector<uint64_t> &p = hist_part[t];
                 p.assign(max_count, 0);
                 for (size_t i = lo; i < hi; ++i)
                     if (!(d && d[i]) && cnt[i]) p[cnt[i] - 1] += 1;
             }
-            barrier();
+            if (!barrier()) return;
             if (t == 0) {
                 std::vector<uint64_t> hist_data(max_count, 0);
                 if (max_count <= (1u << 22)) {
@@ -2129,17 +2141,18 @@ static int finish_mash_in_place(fh_sketcher *h, const std::string &name, const f
                 }
             }
         }
-        barrier();
+        if (!barrier()) return;
         if (t == 0) {
             const bool abun = filter_on && (fp.has_abun_lo || fp.has_abun_hi);
             lo_t = (abun && fp.has_abun_lo) ? fp.abun_lo : 0u;
             hi_t = (abun && fp.has_abun_hi) ? fp.abun_hi : UINT32_MAX;
         }
-        barrier();
+        if (!barrier()) return;
         std::vector<uint32_t> &p = rows_part[t];
         for (size_t i = lo; i < hi && p.size() < want; ++i)
             if (!(d && d[i]) && lo_t <= cnt[i] && cnt[i] <= hi_t) p.push_back((uint32_t)i);
     });
+    if (!team_ok) return hfail(FH_ERR_CAPACITY, "out of host memory");
     if (trace) tt1 = tt2 = now_ms();
     std::vector<uint32_t> rows;
     rows.reserve(want);
