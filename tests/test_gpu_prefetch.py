@@ -13,9 +13,9 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _fastq(seed, n_reads, rl=120):
+def _fastq(seed, n_reads, rl=120, genome=80_000):
     rng = np.random.default_rng(seed)
-    g = S.synth_genome_host(80_000, seed)
+    g = S.synth_genome_host(genome, seed)
     recs = []
     for i in range(n_reads):
         st = int(rng.integers(0, len(g) - rl))
@@ -71,3 +71,29 @@ def test_prefetch_changes_nothing_but_timing(mode):
     # bad arguments are refused, harmless ones ignored
     assert L.fh_text_prefetch(h, 2, 10) != 0 and L.fh_text_prefetch(h, -1, 10) != 0
     assert L.fh_text_prefetch(h, 0, 0) == 0 and L.fh_text_prefetch(h, 0, 1 << 40) == 0
+
+
+def test_to_arrays_refills_the_callers_buffers():
+    """HipSketcher.to_arrays(out=...): the arrays of an earlier call are filled again (views of them come back) when they have
+    room, fresh ones are made when they do not; large sketches come out of the lazy copy-out path the same"""
+    recs = _fastq(5, 8000, genome=600_000)  # ~500 k distinct 21-mers
+    text = b"".join(recs)
+    for n in (300, 200_000):  # the second leaves its wide columns on the device until asked (>= 128 k records)
+        o = O.OracleSketcher(O.MASH, n, 21, 0)
+        assert o.sketch_stream(text) == 2
+        okc, okm = o.to_vec()
+        sk = F.SketchParams.mash(n, n, True, 21, 0).create_sketcher()
+        for r in recs:
+            sk.process(r.split(b"\n")[1])
+        a = sk.to_arrays()
+        assert len(okc) == n and np.array_equal(a[0], okc) and np.array_equal(a[1], okm)
+        keep = (a[0].copy(), a[1].copy())
+        a[0]["hash"][:] = 0
+        a[1][:] = 0
+        b = sk.to_arrays(out=a)
+        assert b[0].base is a[0] or b[0] is a[0] or np.shares_memory(b[0], a[0])
+        assert np.array_equal(b[0], keep[0]) and np.array_equal(b[1], keep[1])
+        small = (np.empty(1, a[0].dtype), np.empty((1, 21), np.uint8), np.empty(1, np.uint64))
+        c = sk.to_arrays(out=small) if len(okc) > 1 else b
+        assert np.array_equal(c[0], keep[0])
+        sk.close()
