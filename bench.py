@@ -644,6 +644,9 @@ def measure_extras(F, S, dr, dg, n_reads, dev):
             res = H.sketch_from_sketcher(s, "c3", bases, 2, pp, filt)
             best = min(best, time.perf_counter() - t0)
             assert H.lib().finch_sketch_n_hashes(res._p, 0) == 10_000
+        sk0 = res.sketch(0)  # the filtered 10 000-hash sketch against the oracle's (sharded oracle -> its own filters)
+        if bases == 66666667 * READ_LEN:
+            r["sketch_check"] = check_golden(fingerprint(sk0.arrays[0], sk0.arrays[1], sk0.num_valid_kmers), "c3_k31_filtered")[0]
         s.close()
         r["ms_per_pass_with_host_filters"] = round(best * 1e3, 3)
         r["gbases_per_s_with_host_filters"] = round(bases / best / 1e9, 2)

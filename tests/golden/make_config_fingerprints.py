@@ -112,6 +112,28 @@ def main():
             out["c5_files_0_255"] = {"sample_files": 256, "hash_xor": fx, "count_sum": cs, "total_kmers": tk, "k": 21, "n": 1000}
             print("c5_files_0_255:", json.dumps(out["c5_files_0_255"]), flush=True)
             json.dump(out, open(args.out, "w"), indent=1, sort_keys=True)
+        if args.only is None or "c3_k31_filtered" in names:
+            # BASELINE configs[2]: 10 Gbase, k = 31, kmers_to_sketch = 2 000 000 (CLI oversketch x200 of 10 000), then the reference's
+            # filters -- strand 0.1, error 0.31 (guess_filter_threshold on what the strand filter left), abundance -- and the cut to
+            # final_size 10 000 (filtering.rs:60-87, mod.rs:115-128), all by the oracle
+            from oracle import oracle as O
+            gb, k, n, final = 10.0, 31, 2_000_000, 10_000
+            reads = int(np.ceil(gb * 1e9 / RL))
+            blocks = args.procs * 4
+            b = np.linspace(0, reads, blocks + 1).astype(np.int64)
+            t0 = time.time()
+            parts = pool.map(_shard, [(int(b[i]), int(b[i + 1] - b[i]), k, n) for i in range(blocks)], chunksize=1)
+            kc, km, tk = merge_numpy(parts, n)
+            a, ak = O.filter_strands(kc, km, 0.1)
+            cutoff = O.guess_filter_threshold(a, 0.31)
+            f, fk = O.filter_abundance(a, ak, cutoff, None)
+            f, fk = f[:final], fk[:final]
+            fp = fingerprint(f, fk, tk)
+            fp.update({"gbases": gb, "reads": reads, "k": k, "kmers_to_sketch": n, "final_size": final, "strand_filter": 0.1, "err_filter": 0.31,
+                       "abun_lo": int(cutoff), "oversketch_hash_xor": int(np.bitwise_xor.reduce(kc["hash"])), "read_blocks": blocks})
+            out["c3_k31_filtered"] = fp
+            print("c3_k31_filtered: %.0f s %s" % (time.time() - t0, json.dumps(fp)), flush=True)
+            json.dump(out, open(args.out, "w"), indent=1, sort_keys=True)
         for name in [n for n in names if n in CONFIGS]:
             gb, k, n = CONFIGS[name]
             reads = int(np.ceil(gb * 1e9 / RL))
