@@ -169,6 +169,12 @@ def _c3_oversketch_and_filtering(gbases):
     assert direct.filter_params.filter_on is True and direct.filter_params.abun_filter == (cutoff, None)  # FASTQ: filtering on by default
     assert np.array_equal(direct.arrays[0], b[:final]) and np.array_equal(direct.arrays[1], bk[:final])
     assert (direct.seq_length, direct.num_valid_kmers) == (n_reads * RL, tk)
+    if gbases == 10.0:  # ... and that is the sketch bench.py's self-check of configs[2] expects
+        import json
+        g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config_fingerprints.json")))["c3_k31_filtered"]
+        d0 = direct.arrays[0]
+        assert (g["hash_xor"], g["count_sum"], g["extra_sum"], g["total_kmers"], g["abun_lo"]) == (
+            int(np.bitwise_xor.reduce(d0["hash"])), int(d0["count"].astype(np.uint64).sum()), int(d0["extra_count"].astype(np.uint64).sum()), tk, cutoff)
 
 
 def test_c4_50gbase_sharded_read_blocks_and_host_merge_full():
