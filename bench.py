@@ -212,7 +212,7 @@ def main():
     ap.add_argument("--files", type=int, default=10000, help="c5: number of FASTA files")
     ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--n", type=int, default=1000)
-    ap.add_argument("--cpu-sample-mbases", type=float, default=450.0)
+    ap.add_argument("--cpu-sample-mbases", type=float, default=600.0)  # ~11 s of one host core
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the measurements reported under 'extras'")
     ap.add_argument("--cpu-allcores-mbases", type=float, default=100.0,
