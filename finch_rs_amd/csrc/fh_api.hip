@@ -904,10 +904,7 @@ int ensure_out(fh_sketcher *s, uint32_t n) {
     if (n <= s->out_cap) return FH_OK;
     HIP_TRY(hipStreamSynchronize(s->stream));
     (void)hipFree(s->o_block);
-    (void)hipFree(s->d_rows);
-    (void)hipFree(s->d_rows_out);
-    if (s->h_rows) (void)hipHostFree(s->h_rows);
-    if (s->h_rows_out) (void)hipHostFree(s->h_rows_out);
+    // (the row-gather buffers of fh_copy_out_rows do not depend on out_cap: they live until destroy_handle)
     s->o_block = nullptr;
     s->o_hash = s->o_kmer = s->o_pos = s->o_kmer_hi = nullptr; s->o_count = s->o_extra = nullptr;
     s->out_cap = 0;
@@ -949,9 +946,18 @@ void parallel_for(size_t n, F f) {
         return;
     }
     std::vector<std::thread> th;
+    th.reserve(nt - 1);
     const size_t per = (n + nt - 1) / nt;
-    for (size_t t = 1; t < nt; ++t) th.emplace_back([=] { f(std::min(n, t * per), std::min(n, (t + 1) * per)); });
+    size_t started = 1;
+    try {
+        for (; started < nt; ++started) {
+            const size_t t = started;
+            th.emplace_back([=] { f(std::min(n, t * per), std::min(n, (t + 1) * per)); });
+        }
+    } catch (...) { // no thread to be had (EAGAIN): the rest runs here -- joinable threads must never unwind
+    }
     f((size_t)0, std::min(n, per));
+    for (size_t t = started; t < nt; ++t) f(std::min(n, t * per), std::min(n, (t + 1) * per));
     for (auto &x : th) x.join();
 }
 
@@ -1316,6 +1322,10 @@ void destroy_handle(fh_sketcher *s) {
     (void)hipFree(s->ctl);
     (void)hipFree(s->clog);
     (void)hipFree(s->o_block);
+    (void)hipFree(s->d_rows);
+    (void)hipFree(s->d_rows_out);
+    if (s->h_rows) (void)hipHostFree(s->h_rows);
+    if (s->h_rows_out) (void)hipHostFree(s->h_rows_out);
     (void)hipFree(s->kmer_hi);
     (void)hipFree(s->smp_list);
     (void)hipFree(s->smp_hist);
@@ -1842,13 +1852,19 @@ static int ensure_wide(fh_sketcher *s) {
 }
 
 // the record form of a finished sketch (merges work on it); built from the arrays fh_finish left behind
-static void ensure_records(fh_sketcher *s) {
-    if (s->res_built) return;
-    (void)ensure_wide(s);
+static int ensure_records(fh_sketcher *s) {
+    if (s->res_built) return FH_OK;
+    // (a failed copy leaves wide_pending set: the arrays still hold an earlier sketch's columns and must not be merged)
+    int prev_dev = -1;
+    const bool restore = s->wide_pending && hipGetDevice(&prev_dev) == hipSuccess;
+    const int rc = ensure_wide(s);
+    if (restore && prev_dev != s->device) (void)hipSetDevice(prev_dev); // fh_merge(dst, src): the caller's device stays current
+    if (rc) return rc;
     s->res.resize(s->r_n);
     for (size_t i = 0; i < s->r_n; ++i)
         s->res[i] = ResultRec{s->r_hash[i], s->r_count[i], s->r_extra[i], s->r_kmer[i], s->r_pos[i], s->r_kmer_hi ? s->r_kmer_hi[i] : 0ull};
     s->res_built = true;
+    return FH_OK;
 }
 
 int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
@@ -2109,7 +2125,7 @@ int fh_merge_arrays(fh_sketcher *dst, uint64_t n, const uint64_t *hashes, const 
     std::vector<ResultRec> src(n), out;
     for (uint64_t j = 0; j < n; ++j)
         src[j] = make_rec(hashes[j], counts[j], extra_counts[j], kmers + j * (size_t)k, k, first_pos[j]);
-    ensure_records(dst);
+    if (int rc = ensure_records(dst)) return rc;
     if (int rc = merge_sorted(dst->res, src, out)) return rc;
     select_final(dst, out);
     dst->res.swap(out);
@@ -2221,7 +2237,7 @@ int fh_merge(fh_sketcher *dst, const fh_sketcher *src) {
     if (!src->finished) return fail(FH_ERR_STATE, "fh_merge: src not finished");
     if (dst->p.k != src->p.k || dst->p.kind != src->p.kind || dst->p.seed != src->p.seed || dst->p.size != src->p.size)
         return fail(FH_ERR_INVALID, "fh_merge: incompatible sketch parameters");
-    ensure_records(const_cast<fh_sketcher *>(src));
+    if (int rc = ensure_records(const_cast<fh_sketcher *>(src))) return rc;
     const size_t n = src->res.size();
     const int k = (int)src->p.k;
     std::vector<uint64_t> hh(n), pp(n);

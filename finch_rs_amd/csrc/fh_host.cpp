@@ -30,6 +30,23 @@
 #include "fh_inflate.h"
 #include "fh_pargz.h"
 
+// job(t) for t = 0 .. n - 1, one thread each (the caller's runs job(0)).  A thread that cannot be created (EAGAIN under a
+// thread limit) must not take the process down -- a vector of joinable threads that unwinds calls std::terminate -- so its
+// share runs on the calling thread instead.
+template <class J>
+static void fork_join(unsigned n, J job) {
+    std::vector<std::thread> th;
+    th.reserve(n ? n - 1 : 0); // (before the first thread exists: may throw freely)
+    unsigned started = 1;
+    try {
+        for (; started < n; ++started) th.emplace_back(job, started);
+    } catch (...) {
+    }
+    if (n) job(0u);
+    for (unsigned t = started; t < n; ++t) job(t);
+    for (auto &x : th) x.join();
+}
+
 namespace finch {
 
 thread_local std::string g_host_err;
@@ -238,10 +255,7 @@ struct MemSource : ByteSource {
                 const size_t lo = std::min(m, (size_t)t * per), hi = std::min(m, lo + per);
                 if (lo < hi) memcpy(dst + lo, src + lo, hi - lo);
             };
-            std::vector<std::thread> th;
-            for (unsigned t = 1; t < n_thr; ++t) th.emplace_back(job, t);
-            job(0);
-            for (auto &x : th) x.join();
+            fork_join(n_thr, job);
         }
         off += m;
         return m;
@@ -282,10 +296,7 @@ struct FileSource : ByteSource {
             }
             got[t] = done;
         };
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < n_thr; ++t) th.emplace_back(job, t);
-        job(0);
-        for (auto &x : th) x.join();
+        fork_join(n_thr, job);
         size_t total = 0; // contiguous prefix that was read
         for (unsigned t = 0; t < n_thr; ++t) {
             const size_t lo = std::min(want, (size_t)t * per), hi = std::min(want, lo + per);
@@ -942,10 +953,7 @@ struct BgzfSource : ByteSource {
             }
             inflateEnd(&zs);
         };
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(job, t);
-        job(0);
-        for (auto &x : th) x.join();
+        fork_join(nt, job);
         t_inflate += now_s() - tr2;
         if (!ok) { bad = true; return false; }
         c_lo += scan;
@@ -1281,10 +1289,7 @@ struct ParGzSource : ByteSource {
                 f(i);
             }
         };
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < std::min<size_t>(n_thr, n); ++t) th.emplace_back(work);
-        work();
-        for (auto &x : th) x.join();
+        fork_join((unsigned)std::min<size_t>(n_thr, n), [&](unsigned) { work(); }); // (a share that got no thread: the others take its items)
     }
 
     // The next batch, decoded.  Runs on a thread of its own while the batch before it is handed out: it owns the compressed
@@ -1926,10 +1931,7 @@ struct FastaCounter {
                 i = (size_t)(g - p) + 1;
             }
         };
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(job, t);
-        job(0);
-        for (auto &x : th) x.join();
+        fork_join(nt, job);
         for (auto &v : part) out.insert(out.end(), v.begin(), v.end());
     }
     // gts: the positions of every '>' in p[0, n) if the caller has them (find_gt), else they are searched for as the walk goes
@@ -2018,10 +2020,7 @@ static void host_parallel(size_t n, F f) {
         return;
     }
     const size_t per = (n + t_max - 1) / t_max;
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < t_max; ++t) th.emplace_back([=] { f(t, std::min(n, t * per), std::min(n, (t + 1) * per)); });
-    f(0, 0, std::min(n, per));
-    for (auto &x : th) x.join();
+    fork_join(t_max, [=](unsigned t) { f(t, std::min(n, (size_t)t * per), std::min(n, ((size_t)t + 1) * per)); });
 }
 
 // the same team of threads for several passes in a row: starting and joining a std::thread costs 50-100 us, which for three
@@ -2052,8 +2051,13 @@ static bool host_team(size_t n, F f) {
         }
     };
     std::vector<std::thread> th;
-    for (unsigned t = 1; t < t_max; ++t) th.emplace_back(run, t);
-    run(0u);
+    th.reserve(t_max - 1);
+    try {
+        for (unsigned t = 1; t < t_max; ++t) th.emplace_back(run, t);
+    } catch (...) { // a thread could not be created: the team is short of a member its barriers wait for -- everybody leaves
+        failed.store(true, std::memory_order_release);
+    }
+    if (!failed.load(std::memory_order_acquire)) run(0u);
     for (auto &x : th) x.join();
     return !failed.load();
 }
@@ -2845,8 +2849,24 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
             give_back(job.buf); // (the push is done with the host copy of its buffer when it returns)
         }
     };
-    for (auto &w : W) w->th = std::thread(worker_main, w.get());
-    auto send = [&](size_t d, const ShardWork &job) {
+    auto send_stop = [&](Worker *w) {
+        ShardWork stop;
+        stop.stop = true;
+        std::lock_guard<std::mutex> lk(w->q.mu);
+        w->q.q.push_back(stop);
+        w->q.cv.notify_all();
+    };
+    try {
+        for (auto &w : W) w->th = std::thread(worker_main, w.get());
+    } catch (...) { // a worker thread could not be created: stop the ones that run, nothing joinable may unwind
+        for (auto &w : W)
+            if (w->th.joinable()) {
+                send_stop(w.get());
+                w->th.join();
+            }
+        return hfail(FH_ERR_STATE, "could not start the worker threads of a sharded input");
+    }
+    auto send =[&](size_t d, const ShardWork &job) {
         Worker *w = W[d].get();
         std::unique_lock<std::mutex> lk(w->q.mu);
         w->q.cv.wait(lk, [&] { return w->q.q.size() < 2; });
@@ -3202,9 +3222,16 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
             }
         }
     };
-    std::vector<std::thread> th;
-    for (uint32_t w = 0; w < n_threads; ++w) th.emplace_back(worker, w);
-    for (auto &t : th) t.join();
+    {
+        std::vector<std::thread> th;
+        th.reserve(n_threads);
+        try {
+            for (uint32_t w = 0; w < n_threads; ++w) th.emplace_back(worker, w);
+        } catch (...) { // fewer workers than asked for: the files are pulled from one queue, those that started take them all
+        }
+        if (th.empty()) worker(0u);
+        for (auto &t : th) t.join();
+    }
     if (first_err_code != FH_OK) return hfail(first_err_code, "%s", first_err_msg.c_str());
     *out = res.release();
     return FH_OK;

@@ -137,25 +137,35 @@ struct StructR {
     uint64_t data = 0, ptrs = 0; // word offsets inside the segment
     uint32_t data_bits = 0;      // (a list element may be narrower than a word)
     uint16_t n_ptrs = 0;
+    uint8_t byte_shift = 0;      // a 1- / 2- / 4-byte list element read as a struct: where in its word it starts
     bool null() const { return m == nullptr; }
+    // the first word of the data section with the bits that are not the struct's cleared (a whole word when data_bits >= 64)
+    uint64_t first() const {
+        const uint64_t w = m->segs[seg].p[data] >> (8 * byte_shift);
+        return data_bits >= 64 ? w : (w & ((1ull << data_bits) - 1));
+    }
     uint64_t word(unsigned i) const { // 64-bit field i of the data section; fields beyond it read as 0 (schema evolution)
         if (!m || (uint64_t)(i + 1) * 64 > data_bits) return 0;
         return m->segs[seg].p[data + i];
     }
     uint32_t u32(unsigned i) const { // 32-bit field i
         if (!m || (uint64_t)(i + 1) * 32 > data_bits) return 0;
+        if (data_bits < 64) return (uint32_t)first();
         return (uint32_t)(m->segs[seg].p[data + i / 2] >> (32 * (i & 1)));
     }
     uint16_t u16(unsigned i) const {
         if (!m || (uint64_t)(i + 1) * 16 > data_bits) return 0;
+        if (data_bits < 64) return (uint16_t)(first() >> (16 * i));
         return (uint16_t)(m->segs[seg].p[data + i / 4] >> (16 * (i & 3)));
     }
     uint8_t u8(unsigned i) const {
         if (!m || (uint64_t)(i + 1) * 8 > data_bits) return 0;
+        if (data_bits < 64) return (uint8_t)(first() >> (8 * i));
         return (uint8_t)(m->segs[seg].p[data + i / 8] >> (8 * (i & 7)));
     }
     bool bit(unsigned i) const {
         if (!m || i >= data_bits) return false;
+        if (data_bits < 64) return (first() >> i) & 1u;
         return (m->segs[seg].p[data + i / 64] >> (i & 63)) & 1u;
     }
 };
@@ -306,15 +316,15 @@ struct Walker {
         out.assign(p, n);
         return true;
     }
-    // A list about to be read as List(struct): its encoding must be one a struct list can have (element size 64-bit,
-    // pointer, or composite -- void / bit / sub-word lists cannot be upgraded), and elements that occupy no words at all
-    // (composite with an empty struct) are charged one word each against a traversal budget, as the capnp runtime does: a
+    // A list about to be read as List(struct): every encoding but a bit list can be read that way (the capnp runtime upgrades
+    // void, byte, 2- / 4- / 8-byte, pointer and composite lists alike; fields beyond the element read as defaults), and elements
+    // that occupy no words at all (void, or composite with an empty struct) are charged one word each against a traversal budget, as the capnp runtime does: a
     // 24-byte message must not be able to claim 2^29 elements and have the reader allocate for them.
     static constexpr uint64_t TRAVERSAL_WORDS = 8ull << 20; // capnp's default ReaderOptions::traversal_limit_in_words
     bool struct_list(const ListR &l) {
         if (!l.m) return true;
-        if (l.elem < 5) return m.fail("list of structs stored with sub-word elements");
-        if (l.elem == 7 && (uint32_t)l.data_words + l.n_ptrs == 0) {
+        if (l.elem == 1) return m.fail("list of structs stored as a bit list"); // (the one upgrade the capnp runtime refuses)
+        if (l.elem == 0 || (l.elem == 7 && (uint32_t)l.data_words + l.n_ptrs == 0)) {
             amplified += l.count;
             if (amplified > TRAVERSAL_WORDS) return m.fail("read limit exceeded (zero-sized list elements)");
         }
@@ -337,8 +347,17 @@ struct Walker {
         } else if (l.elem == 5) {
             out.data = l.at + i;
             out.data_bits = 64;
+        } else if (l.elem == 0) { // void elements: every field reads as its default
+        } else if (l.elem >= 2 && l.elem <= 4) {
+            // byte / 2-byte / 4-byte elements upgraded to structs (the capnp runtime allows it): the element is the start of
+            // the data section, fields beyond it read as defaults
+            const uint32_t eb = 1u << (l.elem - 2);
+            const uint64_t off = (uint64_t)i * eb;
+            out.data = l.at + off / 8;
+            out.byte_shift = (uint8_t)(off & 7u);
+            out.data_bits = 8 * eb;
         } else {
-            return m.fail("list of structs stored with sub-word elements");
+            return m.fail("list of structs stored as a bit list");
         }
         return true;
     }

@@ -142,7 +142,11 @@ class HipSketcher:
         `out`: arrays of an earlier call to fill again (a caller that keeps its buffers: 2 M records are 110 MB, and first
         touching fresh pages costs several times what the copy does); used if they have room, views of them are returned."""
         n, _ = self.finish()
-        if out is not None and len(out[0]) >= n and out[1].shape[1] == self.kmer_length:
+        def fits(a, dtype, ndim):  # the library writes through raw pointers: only arrays laid out as it expects
+            return (isinstance(a, np.ndarray) and a.dtype == dtype and a.ndim == ndim and a.flags.c_contiguous and
+                    a.flags.writeable and len(a) >= n)
+        if (out is not None and len(out) == 3 and fits(out[0], KC_DTYPE, 1) and fits(out[1], np.uint8, 2) and
+                out[1].shape[1] == self.kmer_length and fits(out[2], np.uint64, 1)):
             kc, km, ps = out[0][:n], out[1][:n], out[2][:n]
         else:
             kc = np.empty(n, dtype=KC_DTYPE)  # = struct fh_kmer_count
