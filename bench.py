@@ -8,9 +8,8 @@ timed beside it and a self-check of the sketch against the oracle's golden finge
 
 How the N GPUs are driven.  Launched by torch.distributed.run (WORLD_SIZE in the environment): one process per GPU, rank r
 sketches read block r, rank 0 gathers the <= n-record partial sketches and merges them on the host.  Launched plainly with
---gpus N > 1: ONE process, one host thread and one sketcher handle per device (the reference's own shape -- finch is one
-process, lib.rs:34-36 -- and SURVEY section 7 step 5; ctypes releases the GIL inside every library call), the main thread
-merging the partial sketches.  Either way there is no
+--gpus N > 1: ONE process and one fh_sketch_device_blocks call per step -- the library runs one host thread and one sketcher
+handle per device (the reference's own shape: finch is one process, lib.rs:34-36) and merges the partial sketches.  Either way there is no
 data-path collective: read blocks are independent and the merge is O(N n).
 
 Workloads (synthetic 150 bp FASTQ-shaped read sets of SURVEY.md 8d M4, already resident in HBM as the packed sequence stream
@@ -289,42 +288,28 @@ def main():
     shards = [Shard(F, S, d, bounds[r][0], bounds[r][1] - bounds[r][0], params, args.max_launch, profiling=(r == 0))
               for r, d in zip(my_ranks, my_devices)]
 
-    # The merge of a step's partial sketches (<= n records per GPU, O(N n) on the host -- finch_rs_amd/sharding.py) runs behind
-    # the sketching.  Launched by torch.distributed.run: every rank ships its partial sketch to rank 0 as one small fixed-size
-    # tensor, on a thread of its own (MergePipe).  One process: every device has its own host thread that runs ITS K passes
-    # back to back (no per-step rendezvous of the devices; at most two partial sketches per device wait to be merged), and
-    # this thread merges step i as soon as all N partial sketches of step i are there.
+    # The merge of a step's partial sketches (<= n records per GPU, O(N n) on the host).  Launched by torch.distributed.run:
+    # every rank ships its partial sketch to rank 0 as one small fixed-size tensor, on a thread of its own (MergePipe), so
+    # the merge of step i runs behind the sketching of step i + 1.  One process: one fh_sketch_device_blocks call per step --
+    # the library's own team of threads (one per device) and its own merge.
     kernel_acc = [0.0, 0, 0]  # ms, launches, positions of device 0's sketch launches
 
     def run_steps(n_steps, timed):
         if threads_mode:
-            import queue
-            import threading
-            qs = [queue.Queue(maxsize=2) for _ in shards]
-            errs = []
-
-            def device_loop(i):
-                try:
-                    for _ in range(n_steps):
-                        part = shards[i].step()
-                        if timed and i == 0:
-                            ms, nl, npos = shards[0].sk.kernel_time()
-                            kernel_acc[0] += ms; kernel_acc[1] += nl; kernel_acc[2] += npos
-                        qs[i].put(part)
-                except BaseException as e:  # noqa: BLE001 -- re-raised below
-                    errs.append(e)
-                    qs[i].put(None)
-            ths = [threading.Thread(target=device_loop, args=(i,), daemon=True) for i in range(len(shards))]
-            for t in ths:
-                t.start()
+            # ONE library call per step (fh_sketch_device_blocks): every device's reset / push / finish runs on a library thread
+            # of its own and the partial sketches are merged on the calling thread inside the call -- no Python in the
+            # per-device loop, so the GIL cannot serialise eight 10 ms steps
             last = None
+            sks = [sh.sk for sh in shards]
+            ptrs, lens = [sh.dr.ptr for sh in shards], [sh.nbytes for sh in shards]
+            offs = [sh.first_read * REC for sh in shards]
             for _ in range(n_steps):
-                parts = [q.get() for q in qs]
-                if any(p is None for p in parts):
-                    raise errs[0]
-                last = SH.merge_wire(params, [SH.pack_partial(kc, km, pos, tk, args.n, args.k) for (kc, km, pos, tk) in parts], args.n)
-            for t in ths:
-                t.join()
+                SH.sketch_device_blocks(sks, ptrs, lens, offs)
+                if timed:
+                    ms, nl, npos = shards[0].sk.kernel_time()
+                    kernel_acc[0] += ms; kernel_acc[1] += nl; kernel_acc[2] += npos
+                kc, km, pos = shards[0].sk.to_arrays()
+                last = (kc, km, pos, shards[0].sk.finish()[1])
             return last
         last = None
         for _ in range(n_steps):
@@ -372,6 +357,7 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "kernel": "k2_sketch<%d>" % args.k, "launches": kernel_launches,
+                "kernel_ms_per_pass": round(kernel_ms / max(args.steps, 1), 4),
                 "avg_launch_ms": round(kernel_ms / max(kernel_launches, 1), 4),
                 "alg_bytes_per_launch": int(kernel_pos / max(kernel_launches, 1)),
                 "binding_resource": "VALU issue (integer hashing: murmur3's 64-bit multiplies and mixes per k-mer; DESIGN.md 3.1), "

@@ -63,10 +63,12 @@ SYMBOLS = {
                                     _U64P, _P, _P, _P, _P, _P]),
     "fh_merge_wire": (C.c_int, [C.c_uint32, C.c_uint64, C.c_double, C.c_uint32, C.c_uint64, C.c_uint32, _P, _U64P, _P, _P, _P, _P, _P,
                       _U64P]),
+    "fh_sketch_device_blocks": (C.c_int, [_P, _P, _U64P, _U64P, C.c_uint32]),
     "fh_set_profiling": (C.c_int, [_P, C.c_int]),
     "fh_kernel_time": (C.c_int, [_P, C.POINTER(C.c_double), _U64P, _U64P]),
     "fh_debug_counters": (C.c_int, [_P, _U64P, _U64P, _U64P]),
     "fh_debug_speculation": (C.c_int, [_P, _U64P, _U64P]),
+    "fh_debug_fast_path": (C.c_int, [_P, _U64P, _U64P, _U64P]),
     "fh_measure_read_bandwidth": (C.c_int, [C.c_int, _P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     "fh_device_alloc": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(_P)]),
     "fh_device_free": (C.c_int, [C.c_int, _P]),

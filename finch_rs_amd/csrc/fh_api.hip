@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -148,9 +149,25 @@ struct fh_sketcher {
         const uint8_t *seq = nullptr;
         uint64_t len = 0, base_pos = 0, p_begin = 0, p_end = 0;
         uint32_t tiles_total = 0, n_units = 0, n_left_in = 0;
+        uint32_t unit_tiles = UNIT_TILES; // queue granularity of this range (1 for inputs that would not fill the chip with 2)
         int left_cur = 0;
         double admit_at_start = 1.0; // admit rate the range started with (for the novelty estimate)
+        bool gated = false;   // queued behind an unverified speculation: its launches run only if Ctl::spec_ok
+        bool verdict = false; // the speculative range itself: its epilogue sets Ctl::spec_ok
     } pend;
+    // Small sketches (kmers_to_sketch <= 3000): the launches that follow a sketch launch are one fused kernel
+    // (k_small_epilogue), the threshold is refreshed inside the launch (Ctl::hist), and a speculative first range is NOT
+    // waited for -- its verdict is taken on the device, whatever is queued behind it is gated on that verdict, and the host
+    // looks at the outcome at its next synchronisation (the next push, or fh_finish): one round trip per file / per pass
+    // instead of five.  FH_NO_FAST=1 keeps the step-by-step path (A/B, tests); FH_NO_HIST=1 only the refresh off.
+    bool fast = false, hist = false;
+    struct Spec {
+        bool pending = false; // a speculative range whose verdict the host has not read yet
+        Pending range;        // that range (to finish it the slow way if the speculation failed)
+        uint64_t tau = 0;     // the guessed threshold
+        uint64_t n_pos = 0;   // positions it covered (counted into positions_done in advance)
+    } spec;
+    uint64_t n_fast_finish = 0, n_spec_deferred = 0, n_spec_recovered = 0;
     uint32_t *left_buf[2] = {nullptr, nullptr}; // leftover tile ranges of a stopped launch (pairs)
     uint64_t max_waves = 0;
     uint64_t max_range = 0; // test knob: cap on positions per range
@@ -278,8 +295,10 @@ static void bgzf_quiesce(fh_sketcher *s) {
     s->bz_acc_n = 0;
     s->bz_acc_bytes = s->bz_acc_text = 0;
 }
-int init_state(fh_sketcher *s) {
-    HIP_TRY(launch_init_ctl(s->ctl, initial_tau(s), s->stream));
+// (device_part = false: the caller has queued a kernel that re-initialises the control block itself)
+int init_state(fh_sketcher *s, bool device_part = true) {
+    if (device_part) HIP_TRY(launch_init_ctl(s->ctl, initial_tau(s), s->stream, false, s->p.size, 0ull, s->hist));
+    s->spec.pending = false;
     s->stream_off = 0;
     s->ins_seen = 0;
     s->novelty = 1.0;
@@ -382,6 +401,8 @@ uint64_t next_range_size(const fh_sketcher *s, uint64_t remaining) {
 }
 
 int check_ctl(fh_sketcher *s);
+int recover_spec(fh_sketcher *s);
+int sketch_positions(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos, uint64_t pos, uint64_t n_pos, uint64_t lo_end);
 int big_prune(fh_sketcher *s, bool sorted = true);
 int grow_table(fh_sketcher *s, uint64_t new_live_cap);
 
@@ -393,6 +414,22 @@ int collect_profile(fh_sketcher *s) {
     }
     s->prof_used = 0;
     return FH_OK;
+}
+
+EpiArgs epi_args(const fh_sketcher *s, uint32_t flags) {
+    EpiArgs e{};
+    e.table = s->table;
+    e.live = s->live;
+    e.dead = s->dead;
+    e.dead_cap = s->dead_cap;
+    e.ctl = s->ctl;
+    e.kind = s->p.kind;
+    e.size = s->p.size;
+    e.max_hash = s->max_hash;
+    e.trigger = s->trigger;
+    e.flags = flags;
+    e.wide = s->p.k > 32 ? 1u : 0u;
+    return e;
 }
 
 // one launch of the persistent sketch kernel over the pending range's queue (+ the in-stream prune)
@@ -411,6 +448,8 @@ int launch_pending(fh_sketcher *s) {
     a.tiles_total = r.tiles_total;
     a.n_units = r.n_units;
     a.n_left_in = r.n_left_in;
+    a.gate = r.gated ? 1u : 0u;
+    a.unit_tiles = r.unit_tiles;
     a.left_in = s->left_buf[r.left_cur];
     a.left_out = s->left_buf[r.left_cur ^ 1];
     const uint64_t work_units = (uint64_t)r.n_units + r.n_left_in;
@@ -446,10 +485,18 @@ int launch_pending(fh_sketcher *s) {
         HIP_TRY(hipEventRecord(e1, s->stream));
         s->prof_launches++;
     }
-    HIP_TRY(launch_live_flatten(s->ctl, s->stream)); // shard lists -> flat live list, n_live
-    if (!s->big_mode)
-        HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size, s->max_hash,
-                                   s->trigger, s->open_loop ? 0u : 1u, 0u, s->stream));
+    if (s->fast) {
+        // shard lists -> live list, the in-stream selection and (a speculative range) the verdict: one launch
+        EpiArgs e = epi_args(s, EPI_FLATTEN | (s->open_loop && !r.verdict ? EPI_PRUNE_TRIGGER : EPI_PRUNE_FORCE) |
+                                    (r.gated ? EPI_GATED : 0u) | (r.verdict ? EPI_VERDICT : 0u));
+        e.n_units = r.n_units;
+        HIP_TRY(launch_small_epilogue(e, s->stream));
+    } else {
+        HIP_TRY(launch_live_flatten(s->ctl, s->stream)); // shard lists -> flat live list, n_live
+        if (!s->big_mode)
+            HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size, s->max_hash,
+                                       s->trigger, s->open_loop ? 0u : 1u, 0u, s->stream));
+    }
     s->n_launches++;
     return FH_OK;
 }
@@ -457,8 +504,24 @@ int launch_pending(fh_sketcher *s) {
 // wait for the pending range; if its launch stopped early (table near its guarded size), prune and
 // relaunch until the queue is dry
 int drain(fh_sketcher *s) {
+    if (s->spec.pending && !s->pend.active) { // nothing but the verdict of a speculative range to wait for
+        if (int rc = check_ctl(s)) return rc;
+        if (!s->h_ctl->spec_ok) return recover_spec(s);
+        s->spec.pending = false;
+        s->last_tau = s->h_ctl->tau;
+        s->last_live = s->h_ctl->n_live;
+        return FH_OK;
+    }
     while (s->pend.active) {
         if (int rc = check_ctl(s)) return rc;
+        if (s->spec.pending) { // the range waited for was queued behind a speculation
+            if (!s->h_ctl->spec_ok) {
+                if (int rc = recover_spec(s)) return rc;
+                continue;
+            }
+            s->spec.pending = false;
+            s->pend.gated = false;
+        }
         const Ctl c = *s->h_ctl;
         s->last_tau = c.tau;
         s->last_live = c.n_live;
@@ -497,6 +560,7 @@ int drain(fh_sketcher *s) {
         }
         s->pend.n_left_in = c.n_left_out;
         s->pend.left_cur ^= 1;
+        s->pend.gated = s->pend.verdict = false; // (a relaunch is ordinary work: whatever it was queued behind has been looked at)
         HIP_TRY(launch_queue_reset(s->ctl, 0u, soft_limit_of(s), read_first_of(s), s->stream));
         s->n_relaunches++;
         if (int rc = launch_pending(s)) return rc;
@@ -505,7 +569,10 @@ int drain(fh_sketcher *s) {
 }
 
 // sketch [0,len) of a device-resident packed stream whose first byte has stream coordinate base_pos
-int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos, uint64_t pos, uint64_t end) {
+// (spec_tau != 0: a speculative range -- the threshold rides on the queue reset and the epilogue takes the verdict; gated:
+//  the range is queued behind a speculation nobody has looked at yet)
+int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos, uint64_t pos, uint64_t end,
+                uint64_t spec_tau = 0, bool gated = false) {
     fh_sketcher::Pending &r = s->pend;
     r.seq = d_seq;
     r.len = len;
@@ -515,11 +582,20 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
     const uint64_t tiles = (end - pos + TILE_POS - 1) / TILE_POS;
     if (tiles >= (1ull << 31)) return fail(FH_ERR_INVALID, "block too large for one range");
     r.tiles_total = (uint32_t)tiles;
-    r.n_units = (uint32_t)((tiles + UNIT_TILES - 1) / UNIT_TILES);
+    // an input of a few megabases does not fill the chip with units of two tiles (configs[4]: 4 Mb = 977 of them for 1024
+    // SIMDs): single tiles put twice as many waves to work, each for half as long
+    static const uint32_t unit_knob = [] {
+        const char *e = getenv("FH_UNIT_TILES"); // A/B knob: 0 = by size
+        return e ? (uint32_t)atoi(e) : 0u;
+    }();
+    r.unit_tiles = unit_knob ? unit_knob : (tiles < (uint64_t)UNIT_TILES * 2 * s->max_waves ? 1u : (uint32_t)UNIT_TILES);
+    r.n_units = (uint32_t)((tiles + r.unit_tiles - 1) / r.unit_tiles);
     r.n_left_in = 0;
     r.left_cur = 0;
+    r.gated = gated;
+    r.verdict = spec_tau != 0;
     r.admit_at_start = admit_rate(s->last_tau);
-    HIP_TRY(launch_queue_reset(s->ctl, 1u, soft_limit_of(s), read_first_of(s), s->stream));
+    HIP_TRY(launch_queue_reset(s->ctl, 1u, soft_limit_of(s), read_first_of(s), s->stream, spec_tau != 0, spec_tau, gated));
     if (int rc = launch_pending(s)) return rc;
     r.active = true;
     if (s->profiling) s->prof_positions += end - pos;
@@ -553,6 +629,28 @@ int speculative_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, 
     uint64_t tau_spec = (uint64_t)(want / (double)n_pos * 18446744073709551616.0);
     if (s->p.kind == FH_KIND_SCALED) tau_spec = std::max(tau_spec, s->max_hash);
     if (tau_spec == 0 || tau_spec >= EMPTY64 - 1) return FH_OK;
+    if (s->fast && !s->big_mode && s->p.kind == FH_KIND_MASH && s->p.size > 0) {
+        // Not waited for: the range's epilogue takes the verdict on the device (Ctl::spec_ok), what the caller queues behind
+        // it is gated on that, and the host reads the outcome at its next synchronisation (drain / fh_finish).  Until
+        // then the bookkeeping assumes success: at least `size` hashes at or below the guess.
+        s->n_spec++;
+        s->n_spec_deferred++;
+        const bool was_open = s->open_loop;
+        s->open_loop = true;
+        const int rc = start_range(s, d_seq, len, base_pos, 0, n_pos, tau_spec, false);
+        s->open_loop = was_open;
+        if (rc) return rc;
+        s->spec.pending = true;
+        s->spec.range = s->pend;
+        s->spec.tau = tau_spec;
+        s->spec.n_pos = n_pos;
+        s->pend.active = false;
+        s->last_tau = tau_spec;
+        s->last_live = (uint32_t)s->p.size;
+        s->positions_done += n_pos;
+        *done = true;
+        return FH_OK;
+    }
     if (int rc = set_tau(s, tau_spec)) return rc;
     s->n_spec++;
     const bool was_open = s->open_loop;
@@ -773,12 +871,20 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
             lo_end = spec_pos;
         }
     }
+    return sketch_positions(s, d_seq, len, base_pos, pos, n_pos, lo_end);
+}
+
+// positions [pos, n_pos) of a device-resident block through the range loop; with s->tau_lo set, [pos, lo_end) are re-read
+// for the hashes above it only (a speculation that found too few)
+int sketch_positions(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos, uint64_t pos, uint64_t n_pos, uint64_t lo_end) {
     struct LoGuard { // the lower bound only applies inside this call
         fh_sketcher *s;
         ~LoGuard() { s->tau_lo = 0; }
     } lo_guard{s};
     while (pos < n_pos) {
-        if (int rc = drain(s)) return rc;
+        // (a speculation whose verdict is still out does not hold the next range up: that one is queued gated)
+        if (s->pend.active)
+            if (int rc = drain(s)) return rc;
         if (s->tau_lo && pos >= lo_end) s->tau_lo = 0; // the re-read of the speculated prefix is complete (drained)
         if (!s->open_loop) {
             // status of everything before this range is known (drained): decide whether the threshold is
@@ -787,16 +893,60 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
             const double room = (double)s->live_target -
                                 (double)std::min<uint64_t>(std::max<uint64_t>(s->p.size, s->last_live), s->live_target);
             if (s->positions_done > 0 && inflight * fill_rate(s) <= 0.25 * room) s->open_loop = true;
+            // with the threshold refreshed inside the launch (Ctl::hist) what a launch inserts no longer grows with its
+            // length: ~size x ln(distinct after / distinct before), and the waves stop by themselves should that fill the
+            // live set after all
+            if (s->hist && s->positions_done > 0 && (s->spec.pending || (uint64_t)s->last_live >= s->p.size)) s->open_loop = true;
         }
         const uint64_t limit = s->tau_lo ? lo_end : n_pos;
         const uint64_t P = next_range_size(s, limit - pos);
         const uint64_t end = std::min<uint64_t>(limit, pos + P);
-        if (int rc = start_range(s, d_seq, len, base_pos, pos, end)) return rc;
+        if (int rc = start_range(s, d_seq, len, base_pos, pos, end, 0, s->spec.pending)) return rc;
         s->positions_done += end - pos;
         pos = end;
         if (!s->open_loop || s->tau_lo)
             if (int rc = drain(s)) return rc; // closed loop: the next range is sized from this one's outcome
     }
+    return FH_OK;
+}
+
+// The verdict of a deferred speculation came back negative (Ctl::spec_ok == 0 after its epilogue): the speculative range
+// stopped early or found fewer than `size` hashes below its guess, and nothing that was queued behind it has run.  Take
+// the bookkeeping back, finish the range the step-by-step way (relaunches, then the re-read for the hashes above the
+// guess if they are still too few) and sketch what was queued behind it through the ordinary loop.
+int recover_spec(fh_sketcher *s) {
+    const fh_sketcher::Pending queued = s->pend; // (gated; did nothing)
+    const fh_sketcher::Spec sp = s->spec;
+    s->spec.pending = false;
+    s->n_spec_recovered++;
+    s->positions_done -= sp.n_pos;
+    if (queued.active) {
+        s->positions_done -= queued.p_end - queued.p_begin;
+        if (s->profiling) s->prof_positions -= queued.p_end - queued.p_begin;
+    }
+    s->open_loop = false;
+    s->pend = sp.range;
+    s->pend.active = true;
+    s->pend.gated = s->pend.verdict = false;
+    if (int rc = drain(s)) return rc; // (relaunches a range that stopped early until its queue is dry)
+    HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size, s->max_hash, 0u, 1u, 0u, s->stream));
+    if (int rc = check_ctl(s)) return rc;
+    s->last_tau = s->h_ctl->tau;
+    s->last_live = s->h_ctl->n_live;
+    if (s->h_ctl->need_big)
+        if (int rc = big_prune(s, false)) return rc;
+    if ((uint64_t)s->last_live >= s->p.size) {
+        s->positions_done += sp.n_pos;
+    } else {
+        // too few: everything <= the guess is in the table with exact counts; re-read the range for the rest
+        s->n_spec_fallback++;
+        s->tau_lo = sp.tau;
+        if (int rc = set_tau(s, EMPTY64)) return rc;
+        if (int rc = sketch_positions(s, sp.range.seq, sp.range.len, sp.range.base_pos, sp.range.p_begin, sp.range.p_end, sp.range.p_end)) return rc;
+        if (int rc = drain(s)) return rc;
+    }
+    if (queued.active)
+        if (int rc = sketch_positions(s, queued.seq, queued.len, queued.base_pos, queued.p_begin, queued.p_end, 0)) return rc;
     return FH_OK;
 }
 
@@ -1056,7 +1206,7 @@ uint32_t sat_add(uint32_t a, uint32_t b) {
 
 extern "C" {
 
-int fh_abi_version(void) { return 3; } // 3: fh_text_prefetch
+int fh_abi_version(void) { return 4; } // 4: fh_debug_fast_path, fh_sketch_device_blocks
 
 const char *fh_last_error(void) { return g_err.c_str(); }
 
@@ -1130,6 +1280,19 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
                 s->profiling = false;
                 // the environment knobs a handle reads at creation are the new owner's to set
                 s->no_spec = getenv("FH_NO_SPEC") != nullptr;
+                s->n_fast_finish = s->n_spec_deferred = s->n_spec_recovered = 0;
+                {
+                    const bool fast = !s->big_mode && getenv("FH_NO_FAST") == nullptr;
+                    const bool hist = fast && s->p.size > 0 && getenv("FH_NO_HIST") == nullptr;
+                    if (fast != s->fast || hist != s->hist) { // (the control block was initialised for the previous owner's setting)
+                        s->fast = fast;
+                        s->hist = hist;
+                        if (hipSetDevice(s->device) != hipSuccess || init_state(s) != FH_OK) {
+                            destroy_handle(s);
+                            break; // (a fresh handle below)
+                        }
+                    }
+                }
                 {
                     const char *mr = getenv("FH_MAX_RANGE");
                     s->max_range = mr ? strtoull(mr, nullptr, 10) : 0;
@@ -1199,6 +1362,8 @@ static fh_sketcher *new_handle(const fh_params *params, int device) {
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     s->big_mode = params->kind == FH_KIND_SCALED || params->size > SMALL_N_MAX;
+    s->fast = !s->big_mode && getenv("FH_NO_FAST") == nullptr;
+    s->hist = s->fast && params->size > 0 && getenv("FH_NO_HIST") == nullptr;
     s->live_target = s->big_mode ? std::max<uint64_t>(4 * params->size, 1ull << 16) : (uint64_t)SMALL_MAX;
     // the table can never fill: waves stop pulling work at soft_limit (<= live_target) and each of the
     // max_waves resident waves can insert at most one tile's worth (2048) after that
@@ -1342,10 +1507,17 @@ void destroy_handle(fh_sketcher *s) {
 int fh_reset(fh_sketcher *s) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (int rc = set_device(s)) return rc;
+    if (s->spec.pending && !s->pend.active) s->spec.pending = false; // (nobody will ask for its outcome; the clear below is stream-ordered behind it)
     if (int rc = drain(s)) return rc;
     if (s->dirty) {
         // clear only the slots this run touched (live + dropped); fall back to a full refill if the
         // dropped-slot list overflowed
+        if (s->fast && s->finished && s->h_ctl->n_dead != 0xFFFFFFFFu && (uint64_t)s->h_ctl->n_live + s->h_ctl->n_dead <= 65536u) {
+            // (a finished sketch: the host has its final control block, and the two lists are short -- one
+            // single-workgroup launch clears them and re-initialises the control block)
+            HIP_TRY(launch_reset_small(s->table, s->live, s->dead, s->ctl, initial_tau(s), s->p.size, 0ull, s->hist ? 1u : 0u, s->stream));
+            return init_state(s, false);
+        }
         HIP_TRY(launch_clear_slots(s->table, s->cap, s->live, s->dead, s->ctl, s->stream));
     }
     return init_state(s);
@@ -1878,6 +2050,47 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
     const auto t0 = now();
     auto t1 = t0, t2 = t0, t3 = t0;
     if (!s->finished) {
+        const bool wide = s->p.k > 32;
+        auto ensure_h_out = [&](size_t need) -> int {
+            if (need <= s->h_out_bytes) return FH_OK;
+            if (s->h_out) (void)hipHostFree(s->h_out);
+            s->h_out = nullptr;
+            s->h_out_bytes = 0;
+            HIP_TRY(host_malloc(&s->h_out, need + need / 4));
+            s->h_out_bytes = need + need / 4;
+            return FH_OK;
+        };
+        // Small sketches: the final selection, the sort, to_vec and the control block's way to the host are ONE launch
+        // queued behind whatever is still running, and ONE synchronisation -- the sorted sketch lands in the pinned result
+        // buffer without a copy.  Afterwards the mirrored control block says whether everything queued did what it was
+        // queued for; if not (speculation failed, a launch stopped early, more live entries than the LDS holds) the
+        // step-by-step path below takes over from whatever state that left (a selection at any time is harmless).
+        bool fused = false;
+        if (s->fast) {
+            if (int rc = ensure_out(s, (uint32_t)std::min<uint64_t>(s->p.size + 1, SMALL_MAX))) return rc;
+            if (int rc = ensure_h_out(s->out_stride * (wide ? 40 : 32) + 64)) return rc;
+            EpiArgs e = epi_args(s, EPI_PRUNE_FORCE | EPI_SORT | EPI_GATHER);
+            e.out = (uint64_t *)s->h_out;
+            e.out_stride = (uint32_t)s->out_stride;
+            e.h_ctl = s->h_ctl;
+            HIP_TRY(launch_small_epilogue(e, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            const Ctl &c = *s->h_ctl;
+            if (c.overflow == 1) return fail(FH_ERR_CAPACITY, "device hash table capacity exceeded");
+            if (c.overflow == 2) return fail(FH_ERR_CAPACITY, "hash collision log capacity exceeded");
+            const bool spec_ok = !s->spec.pending || c.spec_ok;
+            const bool dry = !s->pend.active || (c.next_unit >= s->pend.n_units && c.n_left_out == 0);
+            fused = spec_ok && dry && !c.need_big && c.sorted && (uint64_t)c.n_live <= s->p.size;
+            if (fused) {
+                s->spec.pending = false;
+                s->pend.active = false;
+                s->last_tau = c.tau;
+                s->last_live = c.n_live;
+                s->ins_seen = c.inserted_total;
+                s->n_fast_finish++;
+            }
+        }
+        if (!fused) {
         if (int rc = drain(s)) return rc;
         if (int rc = check_ctl(s)) return rc;
         if (!s->big_mode && s->h_ctl->n_live <= (uint32_t)SMALL_MAX && !s->h_ctl->need_big) {
@@ -1887,10 +2100,13 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         } else {
             if (int rc = big_prune(s)) return rc;
         }
+        }
         t1 = now(); // drained + pruned
-        if (int rc = ensure_out(s, s->h_ctl->n_live)) return rc;
-        HIP_TRY(launch_gather(s->table, s->live, s->ctl, (int)s->p.k, s->o_hash, s->o_count, s->o_extra, s->o_kmer,
-                              s->o_kmer_hi, s->o_pos, s->out_cap, s->stream));
+        if (!fused) {
+            if (int rc = ensure_out(s, s->h_ctl->n_live)) return rc;
+            HIP_TRY(launch_gather(s->table, s->live, s->ctl, (int)s->p.k, s->o_hash, s->o_count, s->o_extra, s->o_kmer,
+                                  s->o_kmer_hi, s->o_pos, s->out_cap, s->stream));
+        }
         // (the control block read back after the prune is final: the gather only reads it)
         if (int rc = collect_profile(s)) return rc;
         const Ctl c = *s->h_ctl;
@@ -1898,17 +2114,9 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         // D2H through one pinned staging area (pageable destinations crawl at a few GB/s); one spare record for the
         // special hash.  A small sketch (the whole block of arrays under 1 MiB: n = 1000 is 32 KB) crosses in ONE copy, the
         // host arrays the device's stride apart; a large one array by array, n entries each.
-        const bool wide = s->p.k > 32;
         const bool one_copy = s->o_block_bytes <= ((size_t)1 << 20);
         const size_t cap = one_copy ? s->out_stride : (size_t)n + 1;
-        const size_t need = cap * (wide ? 40 : 32) + 64;
-        if (need > s->h_out_bytes) {
-            if (s->h_out) (void)hipHostFree(s->h_out);
-            s->h_out = nullptr;
-            s->h_out_bytes = 0;
-            HIP_TRY(host_malloc(&s->h_out, need + need / 4));
-            s->h_out_bytes = need + need / 4;
-        }
+        if (int rc = ensure_h_out(cap * (wide ? 40 : 32) + 64)) return rc;
         uint64_t *hh = (uint64_t *)s->h_out, *kk = hh + cap, *pp = kk + cap;
         uint64_t *kh = wide ? pp + cap : nullptr;
         uint32_t *cc = (uint32_t *)(pp + cap + (wide ? cap : 0)), *ee = cc + cap;
@@ -1916,7 +2124,9 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         //  the special hash: the final selection is "the first `size`")
         static const bool lazy_off = getenv("FH_NO_LAZY_COPYOUT") != nullptr; // A/B knob
         s->wide_pending = !lazy_off && !one_copy && n >= (1u << 17) && s->p.kind == FH_KIND_MASH && c.n_coll == 0 && c.sp_count == 0;
-        if (n && one_copy) {
+        if (fused) {
+            // (the columns are there already)
+        } else if (n && one_copy) {
             HIP_TRY(hipMemcpyAsync(hh, s->o_block, s->o_block_bytes, hipMemcpyDeviceToHost, s->stream));
         } else if (n) {
             if (!s->wide_pending) {
@@ -1931,7 +2141,7 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         std::vector<CollRec> coll(std::min<uint32_t>(c.n_coll, CLOG_CAP));
         if (!coll.empty())
             HIP_TRY(hipMemcpyAsync(coll.data(), s->clog, coll.size() * sizeof(CollRec), hipMemcpyDeviceToHost, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (!fused || !coll.empty()) HIP_TRY(hipStreamSynchronize(s->stream));
         t2 = now(); // gathered + copied to the host
         size_t m = n;
         // the hash value that cannot be a table key, if it occurred (it sorts last)
@@ -2253,6 +2463,151 @@ int fh_merge(fh_sketcher *dst, const fh_sketcher *src) {
     return fh_merge_arrays(dst, n, hh.data(), cc.data(), ee.data(), km.data(), pp.data(), src->total_kmers);
 }
 
+// ---- N resident read blocks on N devices -> one sketch ----
+// The fan-out of sketch_files (lib.rs:34-36: one rayon worker per file) applied to the read blocks of ONE input: a team of
+// library threads, one per handle, kept between calls (starting and joining a std::thread costs 50-100 us; a rank's share of
+// configs[3] on 8 GPUs is 10 ms).  The threads only ever wait on the condition variable between calls, so the team's
+// destructor at process exit finds them idle.
+} // extern "C"
+namespace {
+class BlockTeam {
+    struct Job {
+        fh_sketcher *h = nullptr;
+        const void *block = nullptr;
+        uint64_t len = 0, off = 0;
+        int rc = FH_OK;
+        std::string err;
+    };
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> th;
+    std::vector<Job> jobs;
+    uint64_t generation = 0;
+    size_t n_jobs = 0, n_done = 0;
+    bool quit = false;
+
+    static void run_one(Job &j) {
+        int rc = fh_reset(j.h);
+        if (rc == FH_OK) rc = fh_set_stream_offset(j.h, j.off);
+        if (rc == FH_OK) rc = fh_push_device(j.h, j.block, j.len);
+        if (rc == FH_OK) rc = fh_finish(j.h, nullptr, nullptr);
+        j.rc = rc;
+        if (rc != FH_OK) j.err = fh_last_error();
+    }
+    void worker(size_t me) {
+        uint64_t seen = 0;
+        for (;;) {
+            Job *j = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return quit || (generation != seen && me < n_jobs); });
+                if (quit) return;
+                seen = generation;
+                j = &jobs[me];
+            }
+            run_one(*j);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (++n_done == n_jobs) cv_done.notify_all();
+            }
+        }
+    }
+
+public:
+    std::mutex call_mu; // one call at a time uses the team
+    ~BlockTeam() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : th)
+            if (t.joinable()) t.join();
+    }
+    // block i on handle i, each on its own thread (the caller's runs block 0); -> first error
+    int run(fh_sketcher *const *handles, const void *const *blocks, const uint64_t *lens, const uint64_t *offs, uint32_t n, std::string &err) {
+        size_t have = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            jobs.assign(n, Job{});
+            for (uint32_t i = 0; i < n; ++i) jobs[i] = Job{handles[i], blocks[i], lens[i], offs[i], FH_OK, {}};
+            try { // threads for blocks 1 .. n-1 (worker w serves jobs[w + 1]); what cannot get a thread runs on the caller's
+                th.reserve(n);
+                while (th.size() + 1 < n) {
+                    const size_t me = th.size() + 1;
+                    th.emplace_back([this, me] { worker(me); });
+                }
+            } catch (...) {
+            }
+            have = std::min<size_t>(th.size() + 1, n);
+            n_jobs = have;
+            n_done = 1; // (job 0 is the caller's)
+            ++generation;
+        }
+        cv_work.notify_all();
+        run_one(jobs[0]);
+        for (size_t i = have; i < n; ++i) run_one(jobs[i]);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return n_done >= n_jobs; });
+            n_jobs = 0;
+        }
+        for (uint32_t i = 0; i < n; ++i)
+            if (jobs[i].rc != FH_OK) {
+                err = jobs[i].err;
+                return jobs[i].rc;
+            }
+        return FH_OK;
+    }
+};
+BlockTeam &block_team() {
+    static BlockTeam t;
+    return t;
+}
+} // namespace
+extern "C" {
+
+int fh_sketch_device_blocks(fh_sketcher *const *handles, const void *const *dev_blocks, const uint64_t *lens,
+                            const uint64_t *stream_offsets, uint32_t n) {
+    if (!handles || !dev_blocks || !lens || !stream_offsets || n == 0) return fail(FH_ERR_INVALID, "null argument");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!handles[i]) return fail(FH_ERR_INVALID, "null handle");
+        for (uint32_t j = 0; j < i; ++j)
+            if (handles[j] == handles[i]) return fail(FH_ERR_INVALID, "the same handle for two blocks");
+        const fh_params &a = handles[0]->p, &b = handles[i]->p;
+        if (a.k != b.k || a.kind != b.kind || a.seed != b.seed || a.size != b.size || memcmp(&a.scale, &b.scale, sizeof(double)) != 0)
+            return fail(FH_ERR_INVALID, "fh_sketch_device_blocks: incompatible sketch parameters");
+    }
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
+    std::string err;
+    int rc;
+    try {
+        BlockTeam &team = block_team();
+        std::lock_guard<std::mutex> call(team.call_mu);
+        rc = team.run(handles, dev_blocks, lens, stream_offsets, n, err);
+    } catch (const std::exception &e) {
+        return fail(FH_ERR_STATE, "fh_sketch_device_blocks: %s", e.what());
+    }
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
+    if (rc != FH_OK) return fail(rc, "%s", err.c_str());
+    if (n == 1) return FH_OK;
+    // the host-side merge: union of the ascending partial sketches, counts summed (saturating), k-mer of
+    // the smallest first position, re-selection -- on the records, without the detour through ASCII k-mers fh_merge takes
+    fh_sketcher *dst = handles[0];
+    if (int r = ensure_records(dst)) return r;
+    std::vector<ResultRec> out;
+    for (uint32_t i = 1; i < n; ++i) {
+        if (int r = ensure_records(handles[i])) return r;
+        if (int r = merge_sorted(dst->res, handles[i]->res, out)) return r;
+        select_final(dst, out);
+        dst->res.swap(out);
+        dst->total_kmers += handles[i]->total_kmers;
+    }
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
+    return FH_OK;
+}
+
 int fh_set_profiling(fh_sketcher *s, int enable) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     s->profiling = enable != 0;
@@ -2276,6 +2631,14 @@ int fh_debug_counters(fh_sketcher *s, uint64_t *launches, uint64_t *relaunches, 
     if (launches) *launches = s->n_launches;
     if (relaunches) *relaunches = s->n_relaunches;
     if (big_prunes) *big_prunes = s->n_big_prunes;
+    return FH_OK;
+}
+
+int fh_debug_fast_path(fh_sketcher *s, uint64_t *deferred, uint64_t *recovered, uint64_t *fused_finishes) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (deferred) *deferred = s->n_spec_deferred;
+    if (recovered) *recovered = s->n_spec_recovered;
+    if (fused_finishes) *fused_finishes = s->n_fast_finish;
     return FH_OK;
 }
 

@@ -36,15 +36,28 @@ struct Ctl {
     uint32_t n_coll;        // collision log entries
     uint32_t need_big;      // the single-workgroup prune met more live entries than it can sort
     uint32_t sorted;        // live list currently sorted ascending by hash
-    uint32_t pad_a;
+    uint32_t spec_ok;       // verdict of the last speculative range, taken on the device (k_small_epilogue): 1 = the range ran
+                            // dry and left at least `size` hashes at or below the guessed threshold.  Launches marked
+                            // `gate` (SketchArgs, k_queue_reset) do nothing unless it is 1, so the host can queue the
+                            // speculated range, the verdict and the rest of the input without a round trip in between.
     uint32_t n_dead;        // entries in the dropped-slot list (0xFFFFFFFF = list overflowed)
-    uint32_t pad0;
+    uint32_t hist_on;       // 1: every NEW hash is counted in hist[] and the admit path refreshes tau from it (below)
     uint32_t left_in_pos;   // next unread entry of the leftover list handed to this launch
     uint32_t n_left_out;    // leftover tile ranges recorded by waves that stopped mid-chunk
     uint32_t soft_limit;    // the inserter that takes n_live to this value raises `stopped`
     uint32_t read_first;    // admit path of this launch reads an entry before it issues atomics on it (fh_k2.hip, upsert)
     // the one hash value that cannot be a table key (== EMPTY64)
     uint64_t sp_count, sp_extra, sp_pos, sp_kmer;
+    // In-launch threshold refresh.  A persistent wave used to keep the threshold it read at its start, so a launch over
+    // 50 Gbases admitted at the rate of its first microsecond, filled the live set and had to be stopped, pruned and
+    // relaunched three times per pass.  Now every hash that is NEW to the table is counted by quarter-octave of its value
+    // (fh_core.h qoct_index; each distinct hash is inserted at most once between resets, tau being monotone), and the
+    // upper edge of the first bucket at which the running total reaches sel_size is a valid threshold whatever the table
+    // still holds: at least sel_size distinct hashes at or below it have been seen, so no final member lies above it
+    // (SURVEY.md 8e).  The wave whose insert is the 16th of its shard list recomputes it (refresh_tau, fh_k2_common.h) and
+    // lowers tau with an atomic min; waves re-read tau once per tile.  sel_size = 0: off.  tau_floor: a scaled sketch
+    // keeps everything <= max_hash.
+    uint64_t sel_size, tau_floor;
     // K > 32: a k-mer is two words.  The table entry keeps the low one (the last 32 bases); the first K - 32 bases of slot i
     // sit in kmer_hi[i], an array of its own so that the entry layout and the K <= 32 kernels do not change.  null otherwise.
     uint64_t *kmer_hi;
@@ -77,12 +90,15 @@ struct Ctl {
     uint32_t pad5[31];
     // -DFH_PROFILE_FLUSH builds only: wave-cycles spent inside flush_queue, number of flushes, entries flushed
     uint64_t dbg_flush_cycles, dbg_flush_calls, dbg_flush_entries, dbg_wave_cycles;
+    uint32_t hist[256];     // new hashes since the last reset per quarter-octave of hash value (hist_on)
 };
 
 constexpr int TILE_POS = 2048;   // k-mer start positions per wavefront tile (64 lanes x 32)
 constexpr int LANE_POS = 32;
 constexpr int WAVES_PER_BLOCK = 4;
-constexpr int SMALL_MAX = 8192;  // live entries the single-workgroup prune can sort in LDS
+constexpr int SMALL_MAX = 12288; // live entries the single-workgroup prune can select from in LDS (8 B of key each: 96 KB of the 160)
+constexpr int SMALL_SORT_MAX = 4096; // survivors it can sort there (12 B each)
+constexpr int HIST_REFRESH = 16; // a shard list's every HIST_REFRESH-th insert recomputes the threshold from Ctl::hist
 constexpr int MAX_PROBE = 4096;
 constexpr int N_SHARDS = 256;
 constexpr int SHARD_STRIDE = 32; // dwords between shard cursors (one 128-byte line each)
@@ -92,7 +108,7 @@ constexpr int SHARD_STRIDE = 32; // dwords between shard cursors (one 128-byte l
 #ifndef FH_MAX_UNITS
 #define FH_MAX_UNITS 8
 #endif
-constexpr int UNIT_TILES = FH_UNIT_TILES; // queue granularity; a pull takes 1..MAX_UNITS consecutive units
+constexpr int UNIT_TILES = FH_UNIT_TILES; // queue granularity (SketchArgs::unit_tiles); a pull takes 1..MAX_UNITS consecutive units
 constexpr int MAX_UNITS = FH_MAX_UNITS;   // (guided self-scheduling: big pulls first, single units at the end)
 constexpr int WAVE_BUDGET = 2048; // + at most TILE_POS-1 overshoot inside the tile that crosses it   // tiles a wave pulls from the queue at a time (contiguous: halo reuse)
 
@@ -111,6 +127,8 @@ struct SketchArgs {
     uint32_t n_waves;        // waves of this launch (guides the pull size)
     uint32_t wave_budget;    // new hashes one wave may insert per launch before it stops (hard capacity guard)
     uint32_t n_left_in;      // leftover tile ranges from the previous (stopped) launch of this range
+    uint32_t gate;           // 1: the launch does nothing unless ctl->spec_ok (the speculation before it succeeded)
+    uint32_t unit_tiles;     // tiles per queue unit (UNIT_TILES; 1 for inputs too small to fill the chip with units of 2)
     const uint32_t *left_in; // pairs (t0, t1)
     uint32_t *left_out;      // pairs (t0, t1), capacity >= number of waves
 };

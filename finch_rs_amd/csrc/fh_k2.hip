@@ -33,12 +33,13 @@ namespace fh {
 // ------------------------------------------------------------------------------------------------
 // K2
 // ------------------------------------------------------------------------------------------------
-// Register budget: four waves per SIMD (<= 128 VGPRs) for every K.  With everything wave-uniform kept scalar
-// (threshold, wave index, queue bookkeeping) K <= 24 fits with room to spare (k = 21: 120 VGPRs, no scratch); K >= 25
-// would take 150-190 registers, but those kernels do 6-8 table lookups per position and live off the LDS pipe, where a
-// fourth wave is worth more than the handful of registers it makes the compiler spill (measured k = 31: 373 Gbases/s
-// unbounded at 2 waves, 427 at 3, 443 at 4, 272 at 5).  What must never be spilled is anything the admit path reads:
-// a reload there stalls ~40 % of the wave-iterations of a launch that admits 1 %.
+// Register budget: four waves per SIMD (<= 128 VGPRs) for every K, with NO spilled register (tools/k2_regs.py checks the
+// shipped objects).  Everything wave-uniform is kept scalar (threshold, wave index, queue bookkeeping); K <= 22 run the
+// lane's 32 positions as one unrolled pass (k = 21: 128 VGPRs), K >= 23 -- K >= 25 would take 150-190 registers that way --
+// as two rounds of 16 (102-116 VGPRs; profiles/r03_ab_rounds.txt).  Those kernels do 6-8 table lookups per position and
+// live off the LDS pipe, where a fourth wave is worth more than a longer unrolled pass (measured k = 31: 373 Gbases/s at
+// 2 waves, 427 at 3, 443 at 4, 272 at 5).  What must never be spilled is anything the admit path reads: a reload there
+// stalls ~40 % of the wave-iterations of a launch that admits 1 %.
 #ifndef FH_MINW_BIG
 #define FH_MINW_BIG 4
 #endif
@@ -51,7 +52,7 @@ constexpr int k2_min_waves(int K) { return K <= 21 ? FH_MINW_SMALL : FH_MINW_BIG
 #define FH_ROUND_BIG 16
 #endif
 #ifndef FH_ROUND_FROM
-#define FH_ROUND_FROM 25
+#define FH_ROUND_FROM 23 // (k = 23, 24 as one pass of 32 spill 2-7 registers at the 128-VGPR limit; in two rounds they take 109)
 #endif
 constexpr int k2_round(int K) { return K >= FH_ROUND_FROM ? FH_ROUND_BIG : 32; }
 template <int K, bool MASKED, bool SEED0, bool HASLO>
@@ -71,6 +72,9 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
     // scalar registers instead of vector registers the hot loop would have to spill
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // a gated launch was queued behind a speculative range before anybody knew how that would end (fh_api.hip): it runs
+    // only if the verdict taken on the device says the speculation held
+    if (a.gate && __hip_atomic_load(&a.ctl->spec_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     {
         if (has_pair_word(K, false)) {
             sA1[tid] = lut_rec_A((u32)tid, false);
@@ -87,11 +91,17 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
 
     // (a loaded value lands in vector registers; the threshold is needed on the admit path only, and a 64-bit vector
     // value that lives across the whole unrolled loop gets spilled and reloaded from scratch there)
-    const u64 tau_v = __hip_atomic_load(&a.ctl->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u64 tau = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(tau_v >> 32)) << 32) |
-                    (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)tau_v);
+    // The threshold is read again after every tile: the admit path of ANY wave may have lowered it meanwhile (refresh_tau,
+    // fh_k2_common.h) -- a persistent wave that kept the value of its first microsecond would admit at that rate for the
+    // whole launch.
+    auto load_tau = [&]() -> u64 {
+        const u64 tau_v = __hip_atomic_load(&a.ctl->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(tau_v >> 32)) << 32) |
+               (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)tau_v);
+    };
+    u64 tau = load_tau();
     // readfirstlane keeps the bound an opaque scalar (otherwise the select inside is re-expanded per position)
-    const u32 tau_hi1 = (u32)__builtin_amdgcn_readfirstlane((int)tau_hi_bound(tau));
+    u32 tau_hi1 = (u32)__builtin_amdgcn_readfirstlane((int)tau_hi_bound(tau));
 
     const u32 gw = blockIdx.x * WAVES_PER_BLOCK + (u32)wave;
     u32 *codes_ring = sCodes[wave];
@@ -107,11 +117,13 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
 #ifdef FH_PROFILE_FLUSH
     u64 prof_cycles = 0, prof_calls = 0, prof_entries = 0;
     const u64 prof_t0 = __builtin_readcyclecounter();
-#define FLUSH(ctl_, q_, qn_, shard_) ([&] { const u64 t0_ = __builtin_readcyclecounter(); const u32 r_ = flush_queue(ctl_, q_, qn_, shard_); prof_cycles += __builtin_readcyclecounter() - t0_; prof_calls++; prof_entries += qn_; return r_; }())
+#define FLUSH(ctl_, q_, qn_, shard_) ([&] { const u64 t0_ = __builtin_readcyclecounter(); const u32 r_ = flush_queue(ctl_, q_, qn_, shard_); prof_cycles += __builtin_readcyclecounter() - t0_; prof_calls++; prof_entries += qn_; want_refresh |= r_ >> 31; return r_ & 0x7FFFFFFFu; }())
 #else
-// (the count returned is wave-uniform; saying so keeps wave_inserts, qn and the branches on them scalar)
-#define FLUSH(ctl_, q_, qn_, shard_) ((u32)__builtin_amdgcn_readfirstlane((int)flush_queue(ctl_, q_, qn_, shard_)))
+// (the count returned is wave-uniform; saying so keeps wave_inserts, qn and the branches on them scalar.  Bit 31: a refresh
+// of the threshold is due -- taken at the end of the tile)
+#define FLUSH(ctl_, q_, qn_, shard_) ([&] { const u32 r_ = (u32)__builtin_amdgcn_readfirstlane((int)flush_queue(ctl_, q_, qn_, shard_)); want_refresh |= r_ >> 31; return r_ & 0x7FFFFFFFu; }())
 #endif
+    u32 want_refresh = 0; // flush_queue asked for a refresh of the threshold (wave-uniform)
     u32 wave_inserts = 0; // new hashes this wave inserted in this launch (wave-uniform)
     u32 qn = 0;           // occupancy of the admit queue (wave-uniform)
     AdmitQueueT<false> *queue = &sQueue[wave];
@@ -139,8 +151,8 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
                 const u32 c = atomicAdd(&a.ctl->next_unit, k);
                 last_unit = c + k;
                 if (c < a.n_units) {
-                    rt0 = c * (u32)UNIT_TILES;
-                    const u32 e = (c + k) * (u32)UNIT_TILES;
+                    rt0 = c * a.unit_tiles;
+                    const u32 e = (c + k) * a.unit_tiles;
                     rt1 = e < a.tiles_total ? e : a.tiles_total;
                 }
             }
@@ -177,8 +189,8 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
         Windows<K> win;
         win.init(clo, chi);
 
-        // The lane's 32 positions in rounds of R (k2_round: 32 = one fully unrolled pass for K <= 24; 8 for the register-hungry
-        // K >= 25, with the two strings moved on between rounds so that every bit-field offset stays a compile-time constant).
+        // The lane's 32 positions in rounds of R (k2_round: 32 = one fully unrolled pass for K <= 22; 16 for the register-hungry
+        // K >= 23, with the two strings moved on between rounds so that every bit-field offset stays a compile-time constant).
         // software pipeline: the table lookups of position u+1 are issued before the dependent multiply chain of
         // position u runs, so their LDS latency is hidden inside the wave
         constexpr int R = k2_round(K);
@@ -246,6 +258,18 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
         if (qn >= (u32)(QCAP / 2) || (qn && t + 1 == rt1)) { // drain when half full or at the end of the pulled range
             wave_inserts += FLUSH(a.ctl, queue, qn, shard);
             qn = 0;
+        }
+        if (want_refresh) {
+            refresh_tau(a.ctl);
+            want_refresh = 0;
+        }
+        if (!MASKED) { // (the test hook's masked hashes are compared in full inside the loop: that build keeps its first threshold)
+            const u64 tau_now = load_tau();
+            if (tau_now != tau) { // wave-uniform
+                tau = tau_now;
+                tau_hi1 = (u32)__builtin_amdgcn_readfirstlane((int)tau_hi_bound(tau));
+                if (lane == 0) queue->tau = tau; // (the queue is empty or its entries passed a looser test: both fine)
+            }
         }
         if (t + 1 < rt1 && wave_inserts >= a.wave_budget) {
             if (qn) { // nothing may stay parked when the wave gives the rest of its range back

@@ -195,6 +195,50 @@ struct AdmitQueueT<false> {
     u32 pre, pad;               // pre_shift(K): the canonical word is parked as the loop carries it
 };
 
+// The threshold from the histogram of new hashes (Ctl::hist, fh_device.h): the upper edge of the first quarter-octave at
+// which the running count of distinct hashes seen reaches sel_size.  Called by a whole wave (64 lanes x 4 buckets); the
+// counts only grow and tau only drops (atomic min), so concurrent refreshes and inserts need no ordering.
+__device__ __noinline__ void refresh_tau(Ctl *ctl_v) {
+    Ctl *ctl = uniform_ptr(ctl_v);
+    const FH_GLOBAL Ctl *gctl = (const FH_GLOBAL Ctl *)ctl;
+    const u64 want = gctl->sel_size;
+    if (want == 0ull) return;
+    const u32 lane = threadIdx.x & 63u;
+    u32 c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = __hip_atomic_load(&ctl->hist[4u * lane + (u32)j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 mine = c[0] + c[1] + c[2] + c[3];
+    u64 inc = mine; // inclusive scan over the lanes (counts fit 32 bits, their sum need not)
+    for (int off = 1; off < 64; off <<= 1) {
+        const u64 t = __shfl_up(inc, off);
+        if (lane >= (u32)off) inc += t;
+    }
+    // lane 63 holds the number of hashes inserted since the reset: with what the live list held when the launch began
+    // (both fixed while it runs) that is the live set's size NOW, exactly -- the shard lists' own limit (shard_soft) is
+    // only the coarse guard
+    if (lane == 63u) {
+        const u64 n_now = (u64)gctl->n_live + (inc - gctl->inserted_total);
+        if (n_now >= (u64)gctl->soft_limit) atomicExch(&ctl->stopped, 1u);
+    }
+    const u64 reached = __ballot(inc >= want);
+    if (reached == 0ull) return; // fewer than sel_size distinct hashes so far: nothing to say yet
+    const u32 first = (u32)__builtin_ctzll(reached);
+    if (lane == first) {
+        u64 run = inc - mine;
+        u32 q = 4u * lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            run += c[j];
+            if (run >= want) break;
+            ++q;
+        }
+        u64 t = qoct_upper_edge(q);
+        const u64 floor_ = gctl->tau_floor;
+        if (t < floor_) t = floor_;
+        if (t < g_load((const ull *)&ctl->tau)) g_min((ull *)&ctl->tau, (ull)t);
+    }
+}
+
 template <bool WIDE = false>
 __device__ __noinline__ u32 flush_queue(Ctl *ctl, const AdmitQueueT<WIDE> *q_generic, u32 qn_v, u32 shard) {
     const u32 lane = threadIdx.x & 63u;
@@ -214,7 +258,23 @@ __device__ __noinline__ u32 flush_queue(Ctl *ctl, const AdmitQueueT<WIDE> *q_gen
                 ins = upsert(ctl, h, q->k[lane] >> q->pre, pp & 0x7FFFFFFFFFFFFFFFull, (u32)(pp >> 63), shard);
         }
     }
-    return (u32)__popcll(__ballot(ins != 0u));
+    // A NEW hash is counted by quarter-octave of its value (Ctl::hist); every HIST_REFRESH-th of a bucket asks the caller
+    // for a refresh of the threshold (bit 31 of the result; the kernels call refresh_tau at the end of the tile, where
+    // next to nothing is live across the call).  The hash is formed again from the queue rather than kept across the upsert
+    // call: every register this function holds there is one the hot loop cannot use across its call of this function
+    // (fh_k2.hip sits at 128 VGPRs), and the few lanes that get here can afford two multiplies.
+    u32 want = 0u;
+    {
+        const FH_GLOBAL Ctl *gctl = (const FH_GLOBAL Ctl *)uniform_ptr(ctl);
+        if (gctl->hist_on && ins != 0u) {
+            u64 h;
+            if constexpr (WIDE) h = q->h[lane];
+            else h = parts_hash(HashParts{q->ka[lane], q->kb[lane]}) & q->hash_mask;
+            const u32 old = atomicAdd(&uniform_ptr(ctl)->hist[qoct_index(h)], 1u);
+            want = ((old + 1u) & (u32)(HIST_REFRESH - 1)) == 0u ? 1u : 0u;
+        }
+    }
+    return (u32)__popcll(__ballot(ins != 0u)) | (__ballot(want != 0u) ? 0x80000000u : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------

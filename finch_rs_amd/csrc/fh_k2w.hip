@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256, 2) void k2_sketch_w(const SketchArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.gate && __hip_atomic_load(&a.ctl->spec_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return; // (fh_k2.hip)
     sA1[tid] = lut_rec_A((u32)tid, false);
     sB1[tid] = lut_rec_B((u32)tid, 4, false);
     sA2[tid] = lut_rec_A((u32)tid, true);
@@ -44,10 +45,13 @@ __global__ __launch_bounds__(256, 2) void k2_sketch_w(const SketchArgs a) {
     const LutTables LT{sA1, sA2, sB1, sB2, sP};
     __syncthreads();
 
-    const u64 tau_v = __hip_atomic_load(&a.ctl->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u64 tau = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(tau_v >> 32)) << 32) |
-                    (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)tau_v);
-    const u32 tau_hi1 = (u32)__builtin_amdgcn_readfirstlane((int)tau_hi_bound(tau));
+    auto load_tau = [&]() -> u64 { // re-read after every tile: refresh_tau (fh_k2_common.h) lowers it while the launch runs
+        const u64 tau_v = __hip_atomic_load(&a.ctl->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(tau_v >> 32)) << 32) |
+               (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)tau_v);
+    };
+    u64 tau = load_tau();
+    u32 tau_hi1 = (u32)__builtin_amdgcn_readfirstlane((int)tau_hi_bound(tau));
     const bool masked = a.hash_mask != ~0ull; // wave-uniform run-time switches
     const bool haslo = a.tau_lo != 0ull;
 
@@ -55,8 +59,8 @@ __global__ __launch_bounds__(256, 2) void k2_sketch_w(const SketchArgs a) {
     u32 *codes_ring = sCodes[wave];
     u32 *good_ring = sGood[wave];
     u32 nvalid = 0;
-#define FLUSHW(ctl_, q_, qn_, shard_) ((u32)__builtin_amdgcn_readfirstlane((int)flush_queue<true>(ctl_, q_, qn_, shard_)))
-    u32 wave_inserts = 0, qn = 0;
+#define FLUSHW(ctl_, q_, qn_, shard_) ([&] { const u32 r_ = (u32)__builtin_amdgcn_readfirstlane((int)flush_queue<true>(ctl_, q_, qn_, shard_)); want_refresh |= r_ >> 31; return r_ & 0x7FFFFFFFu; }())
+    u32 wave_inserts = 0, qn = 0, want_refresh = 0;
     AdmitQueueT<true> *queue = &sQueue[wave];
     const u32 shard = gw & (u32)(N_SHARDS - 1);
     u32 last_unit = 0;
@@ -76,8 +80,8 @@ __global__ __launch_bounds__(256, 2) void k2_sketch_w(const SketchArgs a) {
                 const u32 c = atomicAdd(&a.ctl->next_unit, k);
                 last_unit = c + k;
                 if (c < a.n_units) {
-                    rt0 = c * (u32)UNIT_TILES;
-                    const u32 e = (c + k) * (u32)UNIT_TILES;
+                    rt0 = c * a.unit_tiles;
+                    const u32 e = (c + k) * a.unit_tiles;
                     rt1 = e < a.tiles_total ? e : a.tiles_total;
                 }
             }
@@ -154,6 +158,14 @@ __global__ __launch_bounds__(256, 2) void k2_sketch_w(const SketchArgs a) {
             if (qn >= (u32)(QCAP / 2) || (qn && t + 1 == rt1)) {
                 wave_inserts += FLUSHW(a.ctl, queue, qn, shard);
                 qn = 0;
+            }
+            if (want_refresh) {
+                refresh_tau(a.ctl);
+                want_refresh = 0;
+            }
+            if (!masked) {
+                tau = load_tau();
+                tau_hi1 = (u32)__builtin_amdgcn_readfirstlane((int)tau_hi_bound(tau));
             }
             if (t + 1 < rt1 && wave_inserts >= a.wave_budget) {
                 if (qn) {

@@ -22,6 +22,30 @@ constexpr int FH_MAX_K = 64;
 hipError_t launch_prune_small(Entry *table, uint32_t *live, uint32_t *dead, uint32_t dead_cap, Ctl *ctl, uint32_t kind,
                               uint64_t size, uint64_t max_hash, uint32_t trigger, uint32_t force, uint32_t sort_out,
                               hipStream_t st);
+// the fused epilogue of small sketches (fh_kernels.hip, k_small_epilogue)
+constexpr uint32_t EPI_GATED = 1u;         // do nothing (but mirror the control block) unless ctl->spec_ok
+constexpr uint32_t EPI_FLATTEN = 2u;       // append the shard lists of new inserts to the live list
+constexpr uint32_t EPI_PRUNE_TRIGGER = 4u; // select if the live list is longer than `trigger`
+constexpr uint32_t EPI_PRUNE_FORCE = 8u;   // select whatever its length
+constexpr uint32_t EPI_SORT = 16u;         // ... and leave the survivors sorted (to_vec order)
+constexpr uint32_t EPI_VERDICT = 32u;      // set ctl->spec_ok for the speculative range of n_units units just run
+constexpr uint32_t EPI_GATHER = 64u;       // write the sorted sketch's columns to `out` (needs EPI_SORT)
+struct EpiArgs {
+    Entry *table;
+    uint32_t *live, *dead;
+    uint32_t dead_cap;
+    Ctl *ctl;
+    uint32_t kind;
+    uint64_t size, max_hash;
+    uint32_t trigger, flags, n_units;
+    uint64_t *out;       // EPI_GATHER: hash | k-mer | first position | [high k-mer word] | count | extra columns, out_stride
+    uint32_t out_stride; //   entries apart (device or pinned host memory)
+    uint32_t wide;       // K > 32
+    Ctl *h_ctl;          // pinned host mirror of the control block, written last (or null)
+};
+hipError_t launch_small_epilogue(const EpiArgs &a, hipStream_t st);
+hipError_t launch_reset_small(Entry *table, const uint32_t *live, const uint32_t *dead, Ctl *ctl, uint64_t tau0, uint64_t sel_size,
+                              uint64_t tau_floor, uint32_t hist_on, hipStream_t st);
 hipError_t launch_clear_slots(Entry *table, uint64_t cap, const uint32_t *live, const uint32_t *dead, const Ctl *ctl,
                               hipStream_t st);
 // (o_kmer_hi: K > 32 only, else null)
@@ -66,13 +90,16 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfMember *members, u
 hipError_t launch_fastq_cut(const uint8_t *text, uint32_t total, uint32_t last, uint32_t *out, hipStream_t st);
 hipError_t launch_fill_table(Entry *table, uint64_t cap, hipStream_t st);
 // (keep_text_bases: everything but the count of sequence bytes the text packers have emitted so far)
-hipError_t launch_init_ctl(Ctl *ctl, uint64_t tau0, hipStream_t st, bool keep_text_bases = false);
+// (sel_size / tau_floor / hist_on: the in-launch threshold refresh, Ctl in fh_device.h)
+hipError_t launch_init_ctl(Ctl *ctl, uint64_t tau0, hipStream_t st, bool keep_text_bases = false, uint64_t sel_size = 0,
+                           uint64_t tau_floor = 0, bool hist_on = false);
 hipError_t launch_set_tau(Ctl *ctl, uint64_t tau, hipStream_t st);
 hipError_t launch_set_table(Ctl *ctl, Entry *table, uint32_t *live, CollRec *clog, uint32_t cap, uint32_t live_cap,
                             uint32_t clog_cap, uint32_t *shard_cnt, uint32_t *shard_buf, uint32_t shard_cap, uint64_t *kmer_hi,
                             hipStream_t st);
 hipError_t launch_live_flatten(Ctl *ctl, hipStream_t st);
-hipError_t launch_queue_reset(Ctl *ctl, uint32_t new_range, uint32_t soft_limit, uint32_t read_first, hipStream_t st);
+hipError_t launch_queue_reset(Ctl *ctl, uint32_t new_range, uint32_t soft_limit, uint32_t read_first, hipStream_t st,
+                              bool set_tau = false, uint64_t tau = 0, bool gate = false);
 hipError_t launch_read_probe(const void *p, uint64_t bytes, uint32_t *sink, hipStream_t st);
 hipError_t launch_synth_genome(uint8_t *out, uint64_t len, uint64_t seed, hipStream_t st);
 hipError_t launch_synth_reads(uint8_t *out, const uint8_t *genome, uint64_t genome_len, uint64_t first_read,

@@ -93,190 +93,330 @@ __device__ u64 lds_select_kth(const u64 *keys, u32 M, u32 rank, u32 *hist /* 256
     return prefix;
 }
 
-// sort_out = 1: full sort (live list left ascending = to_vec order; used by fh_finish)
-// sort_out = 0: selection only (radix select of the new threshold + partition), ~5x cheaper
+// The selection itself, as a device function: the kernels below wrap it.
+//   sort_out = 0: radix select of the new threshold + partition of the live list (between launches)
+//   sort_out = 1: the same, then the survivors sorted ascending (live list = to_vec order; fh_finish) -- at most
+//                 SMALL_SORT_MAX of them, which is every case the host launches this for (kmers_to_sketch <= 3000)
+// LDS: keys[SMALL_MAX] (8 B each: what the select reads), then the survivors' (key, slot) pairs for the sort.  The slots of
+// the live list are held in registers between the read of the list and its rewrite (12 per thread).
+// Returns the number of live entries left (all threads), or 0xFFFFFFFF if it declined (need_big set / nothing to do);
+// after a sort skeys / sslots hold the sorted survivors.
+struct SmallLds {
+    u64 *keys;   // [SMALL_MAX]
+    u64 *skeys;  // [SMALL_SORT_MAX]
+    u32 *sslots; // [SMALL_SORT_MAX]
+    u32 *hist;   // [256]
+    u32 *wsum;   // [16]
+    u64 *bcast;  // [2]
+    u32 *cnt;    // [2]
+};
+constexpr size_t SMALL_LDS_BYTES = (size_t)SMALL_MAX * 8 + (size_t)SMALL_SORT_MAX * 12;
+constexpr u32 PRUNE_DECLINED = 0xFFFFFFFFu;
+
+__device__ u32 prune_small_dev(Entry *table, u32 *live, u32 *dead, u32 dead_cap, Ctl *ctl, u32 M, u32 kind, u64 size, u64 max_hash,
+                               u32 sort_out, const SmallLds L) {
+    const u32 tid = threadIdx.x, nthr = blockDim.x; // (1024)
+    u64 *keys = L.keys;
+    constexpr int PER = SMALL_MAX / 1024;
+    u32 my_slot[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const u32 i = tid + (u32)j * 1024u;
+        my_slot[j] = 0u;
+        if (i < M) {
+            const u32 sl = live[i];
+            my_slot[j] = sl;
+            keys[i] = table[sl].hash;
+        }
+    }
+    if (tid < 2) L.cnt[tid] = 0;
+    __syncthreads();
+    // the new threshold and how many entries stay (mash.rs:37-60 / scaled.rs:41-58 net effect)
+    u64 tau;
+    u32 keep;
+    if (kind == 0u) {
+        if ((u64)M >= size && size > 0) {
+            tau = lds_select_kth(keys, M, (u32)size, L.hist, L.wsum, L.bcast);
+            keep = (u32)size;
+        } else if (size == 0) {
+            tau = 0ull;
+            keep = 0;
+        } else {
+            tau = EMPTY64;
+            keep = M;
+        }
+    } else {
+        u32 c = 0;
+        for (u32 i = tid; i < M; i += nthr) c += keys[i] <= max_hash ? 1u : 0u;
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+        if ((tid & 63u) == 0 && c) atomicAdd(&L.cnt[1], c);
+        __syncthreads();
+        const u32 n_le = L.cnt[1];
+        __syncthreads();
+        if (tid == 0) L.cnt[1] = 0;
+        if ((u64)n_le >= size) {
+            tau = max_hash;
+            keep = n_le;
+        } else if ((u64)M >= size) {
+            tau = lds_select_kth(keys, M, (u32)size, L.hist, L.wsum, L.bcast);
+            keep = (u32)size;
+        } else {
+            tau = (size != 0) ? EMPTY64 : max_hash;
+            keep = M;
+        }
+        __syncthreads();
+    }
+    if (sort_out && keep > (u32)SMALL_SORT_MAX) { // (never launched that way: the device-wide sort takes such sketches)
+        if (tid == 0) ctl->need_big = 1u;
+        return PRUNE_DECLINED;
+    }
+    // partition: keys are distinct, so exactly `keep` of them are <= tau (or keep == M)
+    const u32 nd0 = ctl->n_dead;
+    const u32 ndrop = M - keep;
+    const bool dead_fits = nd0 != 0xFFFFFFFFu && nd0 <= dead_cap && ndrop <= dead_cap - nd0;
+    const bool none = size == 0 && kind == 0u;
+    if (keep < M || sort_out) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const u32 i = tid + (u32)j * 1024u;
+            if (i < M) {
+                const u64 key = keys[i];
+                const bool k = none ? false : (keep == M || key <= tau);
+                if (k) {
+                    const u32 pos = atomicAdd(&L.cnt[0], 1u);
+                    if (sort_out) {
+                        L.skeys[pos] = key;
+                        L.sslots[pos] = my_slot[j];
+                    } else {
+                        live[pos] = my_slot[j];
+                    }
+                } else if (dead_fits) {
+                    dead[nd0 + atomicAdd(&L.cnt[1], 1u)] = my_slot[j];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (sort_out) {
+        u32 N = 1;
+        while (N < keep) N <<= 1;
+        for (u32 i = keep + tid; i < N; i += nthr) {
+            L.skeys[i] = EMPTY64;
+            L.sslots[i] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        for (u32 kk = 2; kk <= N; kk <<= 1) {
+            for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+                for (u32 i = tid; i < N; i += nthr) {
+                    const u32 ixj = i ^ jj;
+                    if (ixj > i) {
+                        const bool up = (i & kk) == 0;
+                        const u64 a = L.skeys[i], b = L.skeys[ixj];
+                        if ((a > b) == up) {
+                            L.skeys[i] = b;
+                            L.skeys[ixj] = a;
+                            const u32 sa = L.sslots[i];
+                            L.sslots[i] = L.sslots[ixj];
+                            L.sslots[ixj] = sa;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (u32 i = tid; i < keep; i += nthr) live[i] = L.sslots[i];
+    }
+    if (tid == 0) {
+        ctl->n_live = keep;
+        ctl->tau = tau;
+        ctl->sorted = sort_out ? 1u : 0u;
+        ctl->n_dead = dead_fits ? nd0 + ndrop : 0xFFFFFFFFu; // (overflow marker: fh_reset sweeps the whole table)
+    }
+    return keep;
+}
+
+__device__ __forceinline__ SmallLds small_lds(unsigned char *smem, u32 *hist, u32 *wsum, u64 *bcast, u32 *cnt) {
+    SmallLds L;
+    L.keys = reinterpret_cast<u64 *>(smem);
+    L.skeys = reinterpret_cast<u64 *>(smem + (size_t)SMALL_MAX * 8);
+    L.sslots = reinterpret_cast<u32 *>(smem + (size_t)SMALL_MAX * 8 + (size_t)SMALL_SORT_MAX * 8);
+    L.hist = hist;
+    L.wsum = wsum;
+    L.bcast = bcast;
+    L.cnt = cnt;
+    return L;
+}
+
 __global__ __launch_bounds__(1024) void k3_prune_small(Entry *table, u32 *live, u32 *dead, u32 dead_cap, Ctl *ctl,
                                                        u32 kind, u64 size, u64 max_hash, u32 trigger, u32 force,
                                                        u32 sort_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u64 *keys = reinterpret_cast<u64 *>(smem);
-    u32 *slots = reinterpret_cast<u32 *>(smem + (size_t)SMALL_MAX * 8);
     __shared__ u32 s_hist[256];
     __shared__ u32 s_wsum[16];
     __shared__ u64 s_bcast[2];
     __shared__ u32 s_cnt[2];
-    const u32 tid = threadIdx.x, nthr = blockDim.x;
     const u32 M = ctl->n_live;
     if (ctl->need_big) return;
     if (!force && M <= trigger) return;
     if (M > (u32)SMALL_MAX) {
-        if (tid == 0) ctl->need_big = 1u;
+        if (threadIdx.x == 0) ctl->need_big = 1u;
         return;
     }
-    if (!sort_out) {
-        for (u32 i = tid; i < M; i += nthr) {
-            const u32 sl = live[i];
-            keys[i] = table[sl].hash;
-            slots[i] = sl;
+    (void)prune_small_dev(table, live, dead, dead_cap, ctl, M, kind, size, max_hash, sort_out, small_lds(smem, s_hist, s_wsum, s_bcast, s_cnt));
+}
+
+static hipError_t small_lds_attr(const void *fn) {
+    // function attributes belong to the current device: once per device and kernel, and harmless if two worker threads
+    // of the same device both get here first
+    static std::atomic<const void *> done[64][2];
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64)
+        for (auto &d : done[dev])
+            if (d.load(std::memory_order_acquire) == fn) return hipSuccess;
+    if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMALL_LDS_BYTES); e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64)
+        for (auto &d : done[dev]) {
+            const void *expect = nullptr;
+            if (d.compare_exchange_strong(expect, fn, std::memory_order_acq_rel)) break;
         }
-        if (tid < 2) s_cnt[tid] = 0;
-        __syncthreads();
-        // decide the new threshold (same rule as the sorted path below)
-        u64 tau;
-        u32 keep;
-        if (kind == 0u) {
-            if ((u64)M >= size && size > 0) {
-                tau = lds_select_kth(keys, M, (u32)size, s_hist, s_wsum, s_bcast);
-                keep = (u32)size;
-            } else if (size == 0) {
-                tau = 0ull;
-                keep = 0;
-            } else {
-                tau = EMPTY64;
-                keep = M;
-            }
-        } else {
-            u32 c = 0;
-            for (u32 i = tid; i < M; i += nthr) c += keys[i] <= max_hash ? 1u : 0u;
-            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-            if ((tid & 63u) == 0 && c) atomicAdd(&s_cnt[1], c);
-            __syncthreads();
-            const u32 n_le = s_cnt[1];
-            __syncthreads();
-            if ((u64)n_le >= size) {
-                tau = max_hash;
-                keep = n_le;
-            } else if ((u64)M >= size) {
-                tau = lds_select_kth(keys, M, (u32)size, s_hist, s_wsum, s_bcast);
-                keep = (u32)size;
-            } else {
-                tau = (size != 0) ? EMPTY64 : max_hash;
-                keep = M;
-            }
-        }
-        // partition: keys are distinct, so exactly `keep` of them are <= tau (or keep == M)
-        const u32 nd0 = ctl->n_dead;
-        const u32 ndrop = M - keep;
-        const bool dead_fits = nd0 != 0xFFFFFFFFu && nd0 <= dead_cap && ndrop <= dead_cap - nd0;
-        if (keep < M) {
-            for (u32 i = tid; i < M; i += nthr) {
-                const bool k = (size == 0 && kind == 0u) ? false : keys[i] <= tau;
-                if (k) live[atomicAdd(&s_cnt[0], 1u)] = slots[i];
-            }
-            __syncthreads();
-            if (dead_fits) { // dropped slots, compacted
-                if (tid == 0) s_cnt[1] = 0;
-                __syncthreads();
-                for (u32 i = tid; i < M; i += nthr) {
-                    const bool k = (size == 0 && kind == 0u) ? false : keys[i] <= tau;
-                    if (!k) dead[nd0 + atomicAdd(&s_cnt[1], 1u)] = slots[i];
-                }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            ctl->n_live = keep;
-            ctl->tau = tau;
-            ctl->sorted = 0u;
-            ctl->n_dead = dead_fits ? nd0 + ndrop : 0xFFFFFFFFu;
-        }
-        return;
-    }
-    u32 N = 1;
-    while (N < M) N <<= 1;
-    for (u32 i = tid; i < N; i += nthr) {
-        if (i < M) {
-            const u32 s = live[i];
-            keys[i] = table[s].hash;
-            slots[i] = s;
-        } else {
-            keys[i] = EMPTY64;
-            slots[i] = 0xFFFFFFFFu;
-        }
-    }
-    __syncthreads();
-    for (u32 kk = 2; kk <= N; kk <<= 1) {
-        for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
-            for (u32 i = tid; i < N; i += nthr) {
-                const u32 ixj = i ^ jj;
-                if (ixj > i) {
-                    const bool up = (i & kk) == 0;
-                    const u64 a = keys[i], b = keys[ixj];
-                    if ((a > b) == up) {
-                        keys[i] = b;
-                        keys[ixj] = a;
-                        const u32 sa = slots[i];
-                        slots[i] = slots[ixj];
-                        slots[ixj] = sa;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    // choose how many entries stay live and the new admit threshold
-    u32 keep;
-    u64 tau;
-    if (kind == 0u) { // mash.rs:37-60 : bottom-`size` distinct hashes
-        if ((u64)M >= size) {
-            keep = (u32)size;
-            tau = size ? keys[size - 1] : 0ull;
-        } else {
-            keep = M;
-            tau = EMPTY64;
-        }
-    } else { // scaled.rs:41-58 : everything <= max_hash, padded with the smallest others up to `size`
-        // count of keys <= max_hash by binary search (keys sorted, M real keys)
-        u32 lo = 0, hi = M;
-        while (lo < hi) {
-            const u32 mid = (lo + hi) >> 1;
-            if (keys[mid] <= max_hash) lo = mid + 1;
-            else hi = mid;
-        }
-        const u32 n_le = lo;
-        if ((u64)n_le >= size) {
-            keep = n_le;
-            tau = max_hash;
-        } else if ((u64)M >= size) {
-            keep = (u32)size;
-            tau = keys[size - 1];
-        } else {
-            keep = M;
-            tau = (size != 0) ? EMPTY64 : max_hash;
-        }
-    }
-    for (u32 i = tid; i < keep; i += nthr) live[i] = slots[i];
-    // remember the dropped slots so that fh_reset can clear them without sweeping the whole table
-    const u32 nd0 = ctl->n_dead;
-    const u32 ndrop = M - keep;
-    if (nd0 <= dead_cap && ndrop <= dead_cap - nd0) {
-        for (u32 i = tid; i < ndrop; i += nthr) dead[nd0 + i] = slots[keep + i];
-    }
-    __syncthreads();
-    if (tid == 0) {
-        ctl->n_live = keep;
-        ctl->tau = tau;
-        ctl->sorted = 1u;
-        ctl->n_dead = (nd0 <= dead_cap && ndrop <= dead_cap - nd0) ? nd0 + ndrop : 0xFFFFFFFFu; // overflow marker
-    }
+    return hipSuccess;
 }
 
 hipError_t launch_prune_small(Entry *table, u32 *live, u32 *dead, u32 dead_cap, Ctl *ctl, u32 kind, u64 size,
                               u64 max_hash, u32 trigger, u32 force, u32 sort_out, hipStream_t st) {
-    const size_t lds = (size_t)SMALL_MAX * 12;
-    // function attributes belong to the current device: once per device, and harmless if two worker threads of the
-    // same device both get here first
-    static std::atomic<bool> attr_set[64];
-    int dev = 0;
-    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k3_prune_small),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
-    }
-    hipLaunchKernelGGL(k3_prune_small, dim3(1), dim3(1024), lds, st, table, live, dead, dead_cap, ctl, kind, size,
+    if (hipError_t e = small_lds_attr(reinterpret_cast<const void *>(k3_prune_small)); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k3_prune_small, dim3(1), dim3(1024), SMALL_LDS_BYTES, st, table, live, dead, dead_cap, ctl, kind, size,
                        max_hash, trigger, force, sort_out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fused epilogue of small sketches (kmers_to_sketch <= 3000, Mash)
+// ------------------------------------------------------------------------------------------------
+// Everything that follows a sketch launch of a small sketch, in ONE single-workgroup kernel instead of up to seven launches
+// and three host round trips: append the shard lists of new inserts to the live list (k_live_flatten + k_live_commit),
+// select / sort (k3_prune_small), take the verdict on a speculative range (Ctl::spec_ok), write the finished sketch's
+// columns straight into the caller's pinned host buffer (k4_gather + the device-to-host copy) and mirror the control
+// block there (the check_ctl copy).  A file of a batch (configs[4]) is reset, sketched and finished with one
+// synchronisation; a pass over 50 Gbases queues its speculative prefix, the verdict, the gated main launch and the finish
+// back to back.  The host checks the mirrored control block afterwards and falls back to the step-by-step path whenever
+// something did not go as queued (speculation failed, launch stopped early, more live entries than the LDS holds).
+__global__ __launch_bounds__(1024) void k_small_epilogue(const EpiArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ u32 s_hist[256];
+    __shared__ u32 s_wsum[16];
+    __shared__ u64 s_bcast[2];
+    __shared__ u32 s_cnt[2];
+    __shared__ u32 s_off[N_SHARDS + 1];
+    __shared__ u32 s_live;
+    Ctl *ctl = a.ctl;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const bool skip = (a.flags & EPI_GATED) && ctl->spec_ok == 0u; // (the launch this follows did nothing: leave everything as it is)
+    if (!skip) {
+        u32 M = ctl->n_live;
+        if (a.flags & EPI_FLATTEN) {
+            // shard lists -> flat live list: an exclusive scan of the 256 cursors, then one wave per shard in turn
+            static_assert(N_SHARDS == 256, "the scan below is written for 256 shards");
+            u32 c = 0;
+            if (tid < (u32)N_SHARDS) {
+                c = ctl->shard_cnt[tid * SHARD_STRIDE];
+                if (c > ctl->shard_cap) c = ctl->shard_cap; // overflow already flagged by the inserter
+            }
+            u32 inc = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const u32 t = __shfl_up(inc, off);
+                if (lane >= (u32)off) inc += t;
+            }
+            if (tid < (u32)N_SHARDS && lane == 63u) s_wsum[wave] = inc;
+            __syncthreads();
+            if (tid < (u32)N_SHARDS) {
+                u32 base = 0;
+                for (u32 w = 0; w < wave; ++w) base += s_wsum[w];
+                s_off[tid] = base + inc - c;
+                if (tid == (u32)N_SHARDS - 1) s_off[N_SHARDS] = base + inc;
+            }
+            __syncthreads();
+            const u32 total = s_off[N_SHARDS];
+            u32 *live = ctl->live;
+            const u32 live_cap = ctl->live_cap, shard_cap = ctl->shard_cap;
+            const u32 *buf = ctl->shard_buf;
+            for (u32 sh = wave; sh < (u32)N_SHARDS; sh += 16u) {
+                const u32 b = M + s_off[sh], n = s_off[sh + 1] - s_off[sh];
+                const u32 *src = buf + (size_t)sh * shard_cap;
+                for (u32 i = lane; i < n; i += 64u) {
+                    if (b + i < live_cap) live[b + i] = src[i];
+                    else atomicExch(&ctl->overflow, 1u);
+                }
+            }
+            if (tid < (u32)N_SHARDS) ctl->shard_cnt[tid * SHARD_STRIDE] = 0;
+            if (tid == 0 && total) {
+                ctl->inserted_total += total;
+                u32 n = M + total;
+                if (n > live_cap) n = live_cap;
+                ctl->n_live = n;
+                ctl->sorted = 0;
+                s_live = n;
+            } else if (tid == 0) {
+                s_live = M;
+            }
+            __syncthreads(); // (also: the appended slots are visible to the whole workgroup)
+            M = s_live;
+        }
+        u32 kept = PRUNE_DECLINED;
+        const u32 force = a.flags & EPI_PRUNE_FORCE, sort_out = (a.flags & EPI_SORT) ? 1u : 0u;
+        if ((a.flags & (EPI_PRUNE_FORCE | EPI_PRUNE_TRIGGER)) && !ctl->need_big && (force || M > a.trigger)) {
+            if (M > (u32)SMALL_MAX) {
+                if (tid == 0) ctl->need_big = 1u;
+            } else {
+                kept = prune_small_dev(a.table, a.live, a.dead, a.dead_cap, ctl, M, a.kind, a.size, a.max_hash, sort_out,
+                                       small_lds(smem, s_hist, s_wsum, s_bcast, s_cnt));
+            }
+        }
+        __syncthreads();
+        if (a.flags & EPI_VERDICT) {
+            // the speculation held iff the range ran dry (nothing left in the queue, no leftover ranges), nothing overflowed
+            // and at least `size` distinct hashes at or below the guess were found
+            if (tid == 0) {
+                const bool dry = ctl->next_unit >= a.n_units && ctl->n_left_out == 0u;
+                const bool ok = dry && kept != PRUNE_DECLINED && (u64)kept >= a.size && !ctl->need_big && !ctl->overflow;
+                ctl->spec_ok = ok ? 1u : 0u;
+            }
+        }
+        if ((a.flags & EPI_GATHER) && kept != PRUNE_DECLINED) {
+            // to_vec (mash.rs:86-102) from the sorted survivors in LDS, straight into the host's columns
+            const SmallLds L = small_lds(smem, s_hist, s_wsum, s_bcast, s_cnt);
+            const size_t st = a.out_stride;
+            u64 *o_hash = a.out, *o_kmer = o_hash + st, *o_pos = o_kmer + st;
+            u64 *o_kmer_hi = a.wide ? o_pos + st : nullptr;
+            u32 *o_count = (u32 *)((a.wide ? o_kmer_hi : o_pos) + st), *o_extra = o_count + st;
+            for (u32 i = tid; i < kept; i += 1024u) {
+                const u32 sl = L.sslots[i];
+                const Entry e = a.table[sl];
+                o_hash[i] = L.skeys[i];
+                const u64 occ = e.count + e.extra; // the table counts the two strands separately (fh_device.h)
+                o_count[i] = occ > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)occ;
+                o_extra[i] = e.extra > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)e.extra;
+                o_kmer[i] = e.kmer;
+                if (o_kmer_hi) o_kmer_hi[i] = ctl->kmer_hi[sl];
+                o_pos[i] = e.pos;
+            }
+        }
+    }
+    if (a.h_ctl) {
+        // the control block as the host reads it (what the check_ctl copy used to fetch); every write above is visible to
+        // this workgroup after the barrier
+        __syncthreads();
+        const u32 *src = reinterpret_cast<const u32 *>(ctl);
+        u32 *dst = reinterpret_cast<u32 *>(a.h_ctl);
+        for (u32 i = tid; i < (u32)(sizeof(Ctl) / 4); i += 1024u) dst[i] = src[i];
+        __threadfence_system();
+    }
+}
+
+hipError_t launch_small_epilogue(const EpiArgs &a, hipStream_t st) {
+    if (hipError_t e = small_lds_attr(reinterpret_cast<const void *>(k_small_epilogue)); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_small_epilogue, dim3(1), dim3(1024), SMALL_LDS_BYTES, st, a);
     return hipGetLastError();
 }
 
@@ -507,8 +647,8 @@ hipError_t launch_live_flatten(Ctl *ctl, hipStream_t st) {
     return hipGetLastError();
 }
 
-__global__ void k_init_ctl(Ctl *ctl, u64 tau0, u32 keep_text_bases) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+__device__ __forceinline__ void init_ctl_dev(Ctl *ctl, u64 tau0, u32 keep_text_bases, u64 sel_size, u64 tau_floor, u32 hist_on) {
+    if (threadIdx.x == 0) {
         ctl->tau = tau0;
         ctl->inserted_total = 0;
         ctl->n_live = 0;
@@ -516,9 +656,11 @@ __global__ void k_init_ctl(Ctl *ctl, u64 tau0, u32 keep_text_bases) {
         ctl->n_coll = 0;
         ctl->need_big = 0;
         ctl->sorted = 1;
-        ctl->pad_a = 0;
+        ctl->spec_ok = 0;
         ctl->n_dead = 0;
-        ctl->pad0 = 0;
+        ctl->hist_on = hist_on;
+        ctl->sel_size = sel_size;
+        ctl->tau_floor = tau_floor;
         ctl->next_unit = 0;
         ctl->left_in_pos = 0;
         ctl->n_left_out = 0;
@@ -531,14 +673,50 @@ __global__ void k_init_ctl(Ctl *ctl, u64 tau0, u32 keep_text_bases) {
         ctl->sp_extra = 0;
         ctl->sp_pos = EMPTY64;
         ctl->sp_kmer = EMPTY64;
+        if (!keep_text_bases) ctl->text_bases = 0;
     }
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) ctl->kmer_counts[i] = 0;
-    if (threadIdx.x == 0 && !keep_text_bases) ctl->text_bases = 0;
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        ctl->kmer_counts[i] = 0;
+        ctl->hist[i] = 0;
+    }
+}
+
+__global__ void k_init_ctl(Ctl *ctl, u64 tau0, u32 keep_text_bases, u64 sel_size, u64 tau_floor, u32 hist_on) {
+    if (blockIdx.x == 0) init_ctl_dev(ctl, tau0, keep_text_bases, sel_size, tau_floor, hist_on);
+}
+
+// fh_reset of a sketch whose live and dropped-slot lists are short (the host knows: it has the control block of the
+// finished sketch): clear exactly those slots and re-initialise the control block in one single-workgroup launch
+__global__ __launch_bounds__(1024) void k_reset_small(Entry *table, const u32 *live, const u32 *dead, Ctl *ctl, u64 tau0, u64 sel_size,
+                                                      u64 tau_floor, u32 hist_on) {
+    const u32 nl = ctl->n_live, nd = ctl->n_dead;
+    u64 *khi = ctl->kmer_hi;
+    for (u32 i = threadIdx.x; i < nl; i += blockDim.x) {
+        clear_entry(&table[live[i]]);
+        if (khi) khi[live[i]] = EMPTY64;
+    }
+    if (nd != 0xFFFFFFFFu) // (the host does not choose this kernel when the dropped-slot list overflowed)
+        for (u32 i = threadIdx.x; i < nd; i += blockDim.x) {
+            clear_entry(&table[dead[i]]);
+            if (khi) khi[dead[i]] = EMPTY64;
+        }
+    __syncthreads(); // every thread has read the two counts
+    init_ctl_dev(ctl, tau0, 0u, sel_size, tau_floor, hist_on);
+}
+
+hipError_t launch_reset_small(Entry *table, const u32 *live, const u32 *dead, Ctl *ctl, u64 tau0, u64 sel_size, u64 tau_floor,
+                              u32 hist_on, hipStream_t st) {
+    hipLaunchKernelGGL(k_reset_small, dim3(1), dim3(1024), 0, st, table, live, dead, ctl, tau0, sel_size, tau_floor, hist_on);
+    return hipGetLastError();
 }
 
 // new range: empty queue; relaunch of a stopped range: keep next_chunk, swap leftover lists
-__global__ void k_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, u32 read_first) {
+// (set_tau: the threshold of a speculative range rides along instead of a k_set_tau launch of its own; gate: the range was
+//  queued behind a speculation and must leave the queue of that range alone unless it held -- Ctl::spec_ok)
+__global__ void k_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, u32 read_first, u32 set_tau, u64 tau, u32 gate) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (gate && ctl->spec_ok == 0u) return;
+        if (set_tau) ctl->tau = tau;
         if (new_range) ctl->next_unit = 0;
         ctl->left_in_pos = 0;
         ctl->n_left_out = 0;
@@ -548,14 +726,18 @@ __global__ void k_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, u32 read_
         const u32 nl = ctl->n_live;
         const u32 room = soft_limit > nl ? soft_limit - nl : 0u;
         u32 share = room / (u32)N_SHARDS;
+        // (with the histogram on, refresh_tau sees the exact total every few inserts and stops the launch on it: the
+        // per-list limit, which a lucky list reaches long before the total does, is then only a coarse guard)
+        if (ctl->hist_on) share *= 4u;
         ctl->shard_soft = share ? share : 1u;
         // the live set may already sit at/above the limit (nothing pruned since): stop at once
         ctl->stopped = nl >= soft_limit ? 1u : 0u;
     }
 }
 
-hipError_t launch_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, u32 read_first, hipStream_t st) {
-    hipLaunchKernelGGL(k_queue_reset, dim3(1), dim3(64), 0, st, ctl, new_range, soft_limit, read_first);
+hipError_t launch_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, u32 read_first, hipStream_t st, bool set_tau, u64 tau, bool gate) {
+    hipLaunchKernelGGL(k_queue_reset, dim3(1), dim3(64), 0, st, ctl, new_range, soft_limit, read_first, set_tau ? 1u : 0u, tau,
+                       gate ? 1u : 0u);
     return hipGetLastError();
 }
 
@@ -569,8 +751,8 @@ hipError_t launch_set_tau(Ctl *ctl, u64 tau, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_init_ctl(Ctl *ctl, u64 tau0, hipStream_t st, bool keep_text_bases) {
-    hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(256), 0, st, ctl, tau0, keep_text_bases ? 1u : 0u);
+hipError_t launch_init_ctl(Ctl *ctl, u64 tau0, hipStream_t st, bool keep_text_bases, u64 sel_size, u64 tau_floor, bool hist_on) {
+    hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(256), 0, st, ctl, tau0, keep_text_bases ? 1u : 0u, sel_size, tau_floor, hist_on ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -111,6 +111,21 @@ def merge_wire(params: SketchParams, bufs: List[np.ndarray], pad_n: int):
     return kc, ok[:n], op[:n], int(tk.value)
 
 
+def sketch_device_blocks(sketchers, blocks, lens, stream_offsets) -> None:
+    """fh_sketch_device_blocks: block i (a device pointer on sketcher i's device) through sketcher i, each on a library thread
+    of its own, partial sketches merged into sketchers[0] -- ONE call, no Python in the per-device loop.  Afterwards
+    sketchers[0].to_arrays() / .finish() deliver the merged sketch."""
+    L = _lib.load()
+    n = len(sketchers)
+    if not (n == len(blocks) == len(lens) == len(stream_offsets)) or n == 0:
+        raise ValueError("one block, length and stream offset per sketcher")
+    hs = (C.c_void_p * n)(*[s._h for s in sketchers])
+    bs = (C.c_void_p * n)(*[int(b) for b in blocks])
+    ls = (C.c_uint64 * n)(*[int(x) for x in lens])
+    os_ = (C.c_uint64 * n)(*[int(x) for x in stream_offsets])
+    check(L.fh_sketch_device_blocks(hs, bs, ls, os_, n))
+
+
 def gather_and_merge(dist, params: SketchParams, partial: tuple, pad_n: int, device=None):
     """rank 0 returns the merged sketch, the other ranks None.  `dist` = torch.distributed (any backend)."""
     import torch

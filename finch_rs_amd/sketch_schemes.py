@@ -186,8 +186,10 @@ class HipSketcher:
         check(self._L.fh_debug_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
         d, e = C.c_uint64(), C.c_uint64()
         check(self._L.fh_debug_speculation(self._h, C.byref(d), C.byref(e)))
+        f, g, h = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(self._L.fh_debug_fast_path(self._h, C.byref(f), C.byref(g), C.byref(h)))
         return {"launches": a.value, "relaunches": b.value, "big_prunes": c.value, "spec": d.value,
-                "spec_second_pass": e.value}
+                "spec_second_pass": e.value, "spec_deferred": f.value, "spec_recovered": g.value, "fused_finishes": h.value}
 
     # --- measurement ---
     def set_profiling(self, on: bool) -> None:

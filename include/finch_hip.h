@@ -222,6 +222,17 @@ int fh_merge_wire(uint32_t kind, uint64_t size, double scale, uint32_t k, uint64
                   const int64_t *const *bufs, uint64_t *n_out, uint64_t *out_hashes, uint32_t *out_counts,
                   uint32_t *out_extra, uint8_t *out_kmers, uint64_t *out_pos, uint64_t *total_kmers);
 
+/* ONE input resident as n read blocks in the HBM of n devices -> one sketch (north_star: read-block sharding with a
+ * host-side merge and no collective; the fan-out of sketch_files, lib.rs:34-36, applied to the blocks of a single file).
+ * Handle i -- a sketcher on the device that holds block i -- is reset and sketches dev_blocks[i] (as fh_push_device:
+ * 16-byte aligned, lens[i] bytes of packed stream whose first byte has stream coordinate stream_offsets[i]) on a thread
+ * of its own, kept by the library between calls; the calling thread runs block 0 and then merges the n partial sketches
+ * into handles[0] by fh_merge's rule.  On return every handle is finished: handles[0] holds the merged sketch (fh_finish
+ * reports its size and the k-mer total of all blocks, fh_copy_out* deliver it), the others their partial ones.  The
+ * handles must be distinct and have the same sketch parameters; several may share a device.  First error wins. */
+int fh_sketch_device_blocks(fh_sketcher *const *handles, const void *const *dev_blocks, const uint64_t *lens,
+                            const uint64_t *stream_offsets, uint32_t n);
+
 /* --- measurement support (bench.py) --- */
 /* when enabled, every sketch-kernel launch is bracketed by HIP events on the handle's stream */
 int fh_set_profiling(fh_sketcher *s, int enable);
@@ -234,6 +245,11 @@ int fh_debug_counters(fh_sketcher *s, uint64_t *launches, uint64_t *relaunches, 
 
 /* diagnostics: blocks sketched with a speculative threshold, and how many of them needed the second pass */
 int fh_debug_speculation(fh_sketcher *s, uint64_t *first_pass, uint64_t *second_pass);
+
+/* diagnostics of the single-synchronisation path of small sketches (kmers_to_sketch <= 3000): speculative ranges whose
+ * verdict was taken on the device and read later, how many of those had to be finished step by step after all, and
+ * fh_finish calls served by the one fused launch */
+int fh_debug_fast_path(fh_sketcher *s, uint64_t *deferred, uint64_t *recovered, uint64_t *fused_finishes);
 
 /* streaming-read bandwidth of this box's HBM over [dev_bytes, dev_bytes+bytes) (16 B/lane loads, best of `reps`):
  * the measured counterpart of the 8 TB/s spec peak that bench.py prints next to the roofline */

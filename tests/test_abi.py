@@ -39,7 +39,7 @@ def test_host_header_symbols_all_exported(built):
 
 
 def test_abi_version(built):
-    assert built.fh_abi_version() == 3  # 3: fh_text_prefetch
+    assert built.fh_abi_version() == 4  # 4: fh_sketch_device_blocks, fh_debug_fast_path
 
 
 def test_no_silent_cpu_fallback(built):

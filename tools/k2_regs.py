@@ -2,10 +2,12 @@
 """Register / scratch use of the sketch kernels, from the code objects hipcc makes for gfx950 (no GPU needed).
 
     python tools/k2_regs.py                 # every K = 1..64 as the library is built (table -> stdout)
+    python tools/k2_regs.py --objects       # the same from the objects the shipped library was linked from (csrc/obj/*.o)
     python tools/k2_regs.py --k 31 [--asm out.s] [--flags "..."] [-D NAME=V ...]   # one K, development build
 
 Prints per kernel: VGPRs, spilled VGPRs, scratch bytes per lane, SGPRs, LDS bytes (llvm-readelf --notes of the unbundled
-device object).  profiles/r03_k2_registers.txt is this script's output.
+device object).  profiles/r04_k2_registers.txt is this script's output on the shipped objects.  Exit code 1 if any sketch
+kernel spills a register or needs more than 128 VGPRs (four waves per SIMD: fh_k2.hip).
 """
 import argparse
 import os
@@ -32,6 +34,16 @@ def notes(elf):
         out.append({"name": g("name"), "vgpr": g("vgpr_count"), "spill": g("vgpr_spill_count"), "scratch": g("private_segment_fixed_size"),
                     "sgpr": g("sgpr_count"), "lds": g("group_segment_fixed_size")})
     return out
+
+
+def unbundle_object(obj):
+    """device notes of an object file of the library build (a host object with the code object bundled inside)"""
+    d = tempfile.mkdtemp(prefix="k2regs_")
+    fat, elf = os.path.join(d, "fat.bin"), os.path.join(d, "k.elf")
+    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, obj])
+    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o",
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat, "--output=" + elf])
+    return notes(elf)
 
 
 def compile_one(src, defs, flags, asm=None):
@@ -99,13 +111,21 @@ def main():
     ap.add_argument("--flags", default=None, help="replaces the build's extra flags for the sketch kernel")
     ap.add_argument("-D", action="append", default=[])
     ap.add_argument("--all-variants", action="store_true", help="list the masked / seeded / re-read variants too")
+    ap.add_argument("--objects", action="store_true", help="read finch_rs_amd/csrc/obj/fh_k2*.o (what libfinch_hip.so was linked from) instead of compiling")
     ap.add_argument("--mix", action="store_true", help="with --k: VALU instruction classes per position of the hot loop (static, from the ISA)")
     args = ap.parse_args()
     kflags = args.flags.split() if args.flags is not None else list(B.K2_FLAGS)
     rows = []
     if args.k is not None and args.mix and not args.asm:
         args.asm = os.path.join(tempfile.mkdtemp(prefix="k2mix_"), "k.s")
-    if args.k is not None:
+    if args.objects:
+        import glob
+        objs = sorted(glob.glob(os.path.join(CSRC, "obj", "fh_k2_*.o")) + glob.glob(os.path.join(CSRC, "obj", "fh_k2w_*.o")))
+        if len(objs) != 2 * B.NPARTS:
+            sys.exit("expected %d sketch-kernel objects under csrc/obj, found %d: build the library first" % (2 * B.NPARTS, len(objs)))
+        for o in objs:
+            rows += unbundle_object(o)
+    elif args.k is not None:
         if args.k <= 32:
             rows = compile_one("fh_k2.hip", ["FH_PART=0", "FH_ONLY_K=%d" % args.k] + args.D, kflags, args.asm)
         else:
@@ -129,9 +149,13 @@ def main():
         print("%-28s %5s %6s %8s %5s %6s" % (pretty(r["name"]), r["vgpr"], r["spill"], r["scratch"], r["sgpr"], r["lds"]))
 
 
+    bad = [r for r in rows if r["spill"] not in ("0", "?") or (r["vgpr"].isdigit() and int(r["vgpr"]) > 128)]
     if args.mix and args.k is not None:
         sub = "k2_sketchILi%dELb0ELb1ELb0E" % args.k if args.k <= 32 else "k2_sketch_wILi%dE" % args.k
         print("hot loop per position:", hot_mix(args.asm, sub))
+    if bad:
+        print("FAIL: spilled registers or more than 128 VGPRs:", ", ".join(pretty(r["name"]) for r in bad))
+        sys.exit(1)
 
 
 if __name__ == "__main__":
