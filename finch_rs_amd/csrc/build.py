@@ -25,7 +25,9 @@ FLAGS += os.environ.get("FH_EXTRA_FLAGS", "").split()
 K2_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 if "FH_K2_FLAGS" in os.environ:  # A/B builds of the sketch kernel only
     K2_FLAGS = os.environ["FH_K2_FLAGS"].split()
-OUT = os.environ.get("FH_OUT", OUT)
+if "FH_OUT" in os.environ:  # an A/B build: its objects must not replace those libfinch_hip.so was linked from (tools/k2_regs.py --objects)
+    OUT = os.environ["FH_OUT"]
+    OBJ = os.path.join(HERE, "obj", "ab_" + os.path.splitext(os.path.basename(OUT))[0])
 
 SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2_common.h", "fh_k2w.hip", "fh_k2.hip", "fh_kernels.hip", "fh_big.hip", "fh_text.hip", "fh_bgzf.hip", "fh_api.hip", "fh_host.cpp",
            "fh_host_model.h", "fh_inflate.h", "fh_pargz.h", "fh_serial.cpp", os.path.join("..", "..", "include", "finch_host.h"),

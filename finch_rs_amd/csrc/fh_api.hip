@@ -150,6 +150,7 @@ struct fh_sketcher {
         uint64_t len = 0, base_pos = 0, p_begin = 0, p_end = 0;
         uint32_t tiles_total = 0, n_units = 0, n_left_in = 0;
         uint32_t unit_tiles = UNIT_TILES; // queue granularity of this range (1 for inputs that would not fill the chip with 2)
+        uint32_t first_units = 0, grid_waves = 0; // the range's first launch: units every wave starts on unasked, and its waves
         int left_cur = 0;
         double admit_at_start = 1.0; // admit rate the range started with (for the novelty estimate)
         bool gated = false;   // queued behind an unverified speculation: its launches run only if Ctl::spec_ok
@@ -168,6 +169,9 @@ struct fh_sketcher {
         uint64_t n_pos = 0;   // positions it covered (counted into positions_done in advance)
     } spec;
     uint64_t n_fast_finish = 0, n_spec_deferred = 0, n_spec_recovered = 0;
+    // the epilogue of the last sketch launch, not launched yet: whatever touches the control block next launches it first
+    // (flush_epilogue) -- and fh_finish folds it into its own, so a file of a batch gets ONE epilogue launch, not two
+    uint32_t epi_pending = 0, epi_units = 0;
     uint32_t *left_buf[2] = {nullptr, nullptr}; // leftover tile ranges of a stopped launch (pairs)
     uint64_t max_waves = 0;
     uint64_t max_range = 0; // test knob: cap on positions per range
@@ -297,6 +301,7 @@ static void bgzf_quiesce(fh_sketcher *s) {
 }
 // (device_part = false: the caller has queued a kernel that re-initialises the control block itself)
 int init_state(fh_sketcher *s, bool device_part = true) {
+    s->epi_pending = 0; // (callers that could have one pending -- fh_reset -- have launched it: it rewinds the shard cursors)
     if (device_part) HIP_TRY(launch_init_ctl(s->ctl, initial_tau(s), s->stream, false, s->p.size, 0ull, s->hist));
     s->spec.pending = false;
     s->stream_off = 0;
@@ -401,6 +406,7 @@ uint64_t next_range_size(const fh_sketcher *s, uint64_t remaining) {
 }
 
 int check_ctl(fh_sketcher *s);
+int flush_epilogue(fh_sketcher *s);
 int recover_spec(fh_sketcher *s);
 int sketch_positions(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos, uint64_t pos, uint64_t n_pos, uint64_t lo_end);
 int big_prune(fh_sketcher *s, bool sorted = true);
@@ -432,6 +438,15 @@ EpiArgs epi_args(const fh_sketcher *s, uint32_t flags) {
     return e;
 }
 
+int flush_epilogue(fh_sketcher *s) {
+    if (!s->epi_pending) return FH_OK;
+    EpiArgs e = epi_args(s, s->epi_pending);
+    e.n_units = s->epi_units;
+    s->epi_pending = 0;
+    HIP_TRY(launch_small_epilogue(e, s->stream));
+    return FH_OK;
+}
+
 // one launch of the persistent sketch kernel over the pending range's queue (+ the in-stream prune)
 int launch_pending(fh_sketcher *s) {
     fh_sketcher::Pending &r = s->pend;
@@ -450,6 +465,9 @@ int launch_pending(fh_sketcher *s) {
     a.n_left_in = r.n_left_in;
     a.gate = r.gated ? 1u : 0u;
     a.unit_tiles = r.unit_tiles;
+    a.first_units = r.first_units; // (start_range's launch only: a relaunch takes what is left through the queue)
+    a.static_only = r.first_units && (uint64_t)r.first_units * r.grid_waves >= r.n_units ? 1u : 0u;
+    r.first_units = 0;
     a.left_in = s->left_buf[r.left_cur];
     a.left_out = s->left_buf[r.left_cur ^ 1];
     const uint64_t work_units = (uint64_t)r.n_units + r.n_left_in;
@@ -487,10 +505,10 @@ int launch_pending(fh_sketcher *s) {
     }
     if (s->fast) {
         // shard lists -> live list, the in-stream selection and (a speculative range) the verdict: one launch
-        EpiArgs e = epi_args(s, EPI_FLATTEN | (s->open_loop && !r.verdict ? EPI_PRUNE_TRIGGER : EPI_PRUNE_FORCE) |
-                                    (r.gated ? EPI_GATED : 0u) | (r.verdict ? EPI_VERDICT : 0u));
-        e.n_units = r.n_units;
-        HIP_TRY(launch_small_epilogue(e, s->stream));
+        // (not launched yet: flush_epilogue, or folded into fh_finish's)
+        s->epi_pending = EPI_FLATTEN | (s->open_loop && !r.verdict ? EPI_PRUNE_TRIGGER : EPI_PRUNE_FORCE) |
+                         (r.gated ? EPI_GATED : 0u) | (r.verdict ? EPI_VERDICT : 0u);
+        s->epi_units = r.n_units;
     } else {
         HIP_TRY(launch_live_flatten(s->ctl, s->stream)); // shard lists -> flat live list, n_live
         if (!s->big_mode)
@@ -595,7 +613,23 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
     r.gated = gated;
     r.verdict = spec_tau != 0;
     r.admit_at_start = admit_rate(s->last_tau);
-    HIP_TRY(launch_queue_reset(s->ctl, 1u, soft_limit_of(s), read_first_of(s), s->stream, spec_tau != 0, spec_tau, gated));
+    // The first launch's waves (launch_pending: min(units, max_waves), rounded up to whole workgroups) start on units of
+    // their own, no atomic: all of a short range's units (at most MAX_UNITS per wave: the work per tile is uniform, there is
+    // nothing to balance), the first guided pull's worth of a long one -- the queue, which begins behind them, hands out the
+    // rest.  (Handing a long range out statically is NOT faster, on the contrary: with 4096 waves each streaming through a
+    // 12 MB stretch of its own the launch ran at 505-525 Gbases/s against 619 through the queue, which keeps the chip's
+    // reads inside one moving window of a few hundred megabytes -- profiles/r04_ab_static_units.txt.)
+    static const bool no_static = getenv("FH_NO_STATIC_UNITS") != nullptr; // A/B knob
+    {
+        const uint64_t waves = std::max<uint64_t>(1, std::min<uint64_t>(r.n_units, s->max_waves));
+        const uint64_t grid = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
+        const uint64_t fu = std::min<uint64_t>((r.n_units + waves - 1) / waves, MAX_UNITS);
+        r.first_units = no_static ? 0u : (uint32_t)fu;
+        r.grid_waves = (uint32_t)grid;
+    }
+    const uint32_t first_total = (uint32_t)std::min<uint64_t>(r.n_units, (uint64_t)r.first_units * r.grid_waves);
+    if (int rc = flush_epilogue(s)) return rc;
+    HIP_TRY(launch_queue_reset(s->ctl, 1u, soft_limit_of(s), read_first_of(s), s->stream, spec_tau != 0, spec_tau, gated, first_total));
     if (int rc = launch_pending(s)) return rc;
     r.active = true;
     if (s->profiling) s->prof_positions += end - pos;
@@ -604,6 +638,7 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
 }
 
 int set_tau(fh_sketcher *s, uint64_t tau) {
+    if (int rc = flush_epilogue(s)) return rc;
     HIP_TRY(launch_set_tau(s->ctl, tau, s->stream));
     s->last_tau = tau;
     return FH_OK;
@@ -951,6 +986,7 @@ int recover_spec(fh_sketcher *s) {
 }
 
 int check_ctl(fh_sketcher *s) {
+    if (int rc = flush_epilogue(s)) return rc;
     HIP_TRY(hipMemcpyAsync(s->h_ctl, s->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->h_ctl->overflow == 1) return fail(FH_ERR_CAPACITY, "device hash table capacity exceeded");
@@ -1509,6 +1545,7 @@ int fh_reset(fh_sketcher *s) {
     if (int rc = set_device(s)) return rc;
     if (s->spec.pending && !s->pend.active) s->spec.pending = false; // (nobody will ask for its outcome; the clear below is stream-ordered behind it)
     if (int rc = drain(s)) return rc;
+    if (int rc = flush_epilogue(s)) return rc; // (it also rewinds the shard cursors of the last launch)
     if (s->dirty) {
         // clear only the slots this run touched (live + dropped); fall back to a full refill if the
         // dropped-slot list overflowed
@@ -2069,7 +2106,9 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         if (s->fast) {
             if (int rc = ensure_out(s, (uint32_t)std::min<uint64_t>(s->p.size + 1, SMALL_MAX))) return rc;
             if (int rc = ensure_h_out(s->out_stride * (wide ? 40 : 32) + 64)) return rc;
-            EpiArgs e = epi_args(s, EPI_PRUNE_FORCE | EPI_SORT | EPI_GATHER);
+            EpiArgs e = epi_args(s, s->epi_pending | EPI_PRUNE_FORCE | EPI_SORT | EPI_GATHER); // (the last launch's own epilogue folded in)
+            e.n_units = s->epi_units;
+            s->epi_pending = 0;
             e.out = (uint64_t *)s->h_out;
             e.out_stride = (uint32_t)s->out_stride;
             e.h_ctl = s->h_ctl;

@@ -129,6 +129,11 @@ struct SketchArgs {
     uint32_t n_left_in;      // leftover tile ranges from the previous (stopped) launch of this range
     uint32_t gate;           // 1: the launch does nothing unless ctl->spec_ok (the speculation before it succeeded)
     uint32_t unit_tiles;     // tiles per queue unit (UNIT_TILES; 1 for inputs too small to fill the chip with units of 2)
+    uint32_t first_units;    // > 0 (first launch of a range): wave w starts on units [w, w + 1) x first_units without asking the
+                             // queue, which the host has set to begin behind them.  Every pull is an atomic on ONE address
+                             // (~14 ns each, serialised in L2): the 2 x 1953 of a 4 Mb genome's waves were 55 us of a launch
+                             // that hashes for 10, the 12 000 of a 32 M-position prefix 100 us of 150.
+    uint32_t static_only;    // the first units cover the whole range: no wave pulls from the queue
     const uint32_t *left_in; // pairs (t0, t1)
     uint32_t *left_out;      // pairs (t0, t1), capacity >= number of waves
 };

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
     }
     const u32 shard = gw & (u32)(N_SHARDS - 1);
     u32 last_unit = 0; // guides the pull size
+    bool first_pull = true;
     for (;;) {
         u32 rt0 = 0xFFFFFFFFu, rt1 = 0u;
         if (lane == 0) {
@@ -143,6 +144,19 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
             if (li < a.n_left_in) {
                 rt0 = a.left_in[2u * li];
                 rt1 = a.left_in[2u * li + 1u];
+            } else if (first_pull && a.first_units) {
+                // this wave's own units, no atomic (the queue begins behind all of them).  They are its to process even if
+                // the launch has been stopped meanwhile -- nobody else will; the wave's insert budget still holds
+                const u32 c = gw * a.first_units;
+                if (c < a.n_units) {
+                    rt0 = c * a.unit_tiles;
+                    const u32 e = (c + a.first_units) * a.unit_tiles;
+                    rt1 = e < a.tiles_total ? e : a.tiles_total;
+                }
+                last_unit = gridDim.x * (u32)WAVES_PER_BLOCK * a.first_units; // where the queue begins: what is left is behind it
+            } else if (a.static_only) {
+                // (every unit of the range was somebody's first: nothing to ask the queue for -- 1953 waves finding that out
+                // with an atomic each on its one address kept the last of them waiting 20 us)
             } else if (__hip_atomic_load(&a.ctl->stopped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                 // guided self-scheduling: take 1/(4 x waves) of what seems to be left, 1..MAX_UNITS units
                 const u32 left = a.n_units > last_unit ? a.n_units - last_unit : 0u;
@@ -157,6 +171,7 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
                 }
             }
         }
+        first_pull = false;
         rt0 = (u32)__builtin_amdgcn_readfirstlane((int)rt0);
         rt1 = (u32)__builtin_amdgcn_readfirstlane((int)rt1);
         if (rt0 == 0xFFFFFFFFu) break;

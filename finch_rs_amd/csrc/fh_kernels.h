@@ -99,7 +99,7 @@ hipError_t launch_set_table(Ctl *ctl, Entry *table, uint32_t *live, CollRec *clo
                             hipStream_t st);
 hipError_t launch_live_flatten(Ctl *ctl, hipStream_t st);
 hipError_t launch_queue_reset(Ctl *ctl, uint32_t new_range, uint32_t soft_limit, uint32_t read_first, hipStream_t st,
-                              bool set_tau = false, uint64_t tau = 0, bool gate = false);
+                              bool set_tau = false, uint64_t tau = 0, bool gate = false, uint32_t first_total = 0);
 hipError_t launch_read_probe(const void *p, uint64_t bytes, uint32_t *sink, hipStream_t st);
 hipError_t launch_synth_genome(uint8_t *out, uint64_t len, uint64_t seed, hipStream_t st);
 hipError_t launch_synth_reads(uint8_t *out, const uint8_t *genome, uint64_t genome_len, uint64_t first_read,

@@ -93,6 +93,71 @@ __device__ u64 lds_select_kth(const u64 *keys, u32 M, u32 rank, u32 *hist /* 256
     return prefix;
 }
 
+// The same in two steps for keys that spread evenly over their range -- hashes do: ONE histogram over the top 11 bits any
+// key uses finds the bucket that holds the rank-th key, and the handful of keys in that bucket are ranked against each
+// other directly.  Two passes over the keys instead of up to eight (the rank-th of 4000 hashes below a speculative
+// threshold: 14 us -> 4).  A bucket with more than 1024 keys (keys that do not spread: the test hook's masked hashes) goes
+// through the byte-wise loop above.  scratch: 2048 u32 + 1024 u64 of LDS nobody else uses during the call.
+__device__ u64 lds_select_kth_fast(const u64 *keys, u32 M, u32 rank, u32 *hist256, u32 *wsum, u64 *bcast, unsigned char *scratch) {
+    const u32 tid = threadIdx.x, nthr = blockDim.x; // (1024)
+    u32 *hist = reinterpret_cast<u32 *>(scratch);          // [2048]
+    u64 *list = reinterpret_cast<u64 *>(scratch + 8192);   // [1024]
+    u64 kor = 0;
+    for (u32 i = tid; i < M; i += nthr) kor |= keys[i];
+    for (int off = 32; off > 0; off >>= 1) kor |= __shfl_xor(kor, off);
+    if (tid == 0) bcast[0] = 0;
+    for (u32 i = tid; i < 2048u; i += nthr) hist[i] = 0;
+    __syncthreads();
+    if ((tid & 63u) == 0 && kor) atomicOr((unsigned long long *)&bcast[0], (unsigned long long)kor);
+    __syncthreads();
+    kor = bcast[0];
+    const int msb = kor ? 63 - __builtin_clzll(kor) : 0;
+    const int shift = msb > 10 ? msb - 10 : 0;
+    for (u32 i = tid; i < M; i += nthr) atomicAdd(&hist[(u32)(keys[i] >> shift) & 2047u], 1u);
+    __syncthreads();
+    // inclusive scan of the 2048 bins, two per thread
+    const u32 c0 = hist[2u * tid], c1 = hist[2u * tid + 1u];
+    u32 inc = c0 + c1;
+    const u32 lane = tid & 63u, wave = tid >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 t = __shfl_up(inc, off);
+        if (lane >= (u32)off) inc += t;
+    }
+    if (lane == 63u) wsum[wave] = inc;
+    __syncthreads();
+    u32 base = 0;
+    for (u32 w = 0; w < wave; ++w) base += wsum[w];
+    inc += base;
+    const u32 exc = inc - c0 - c1;
+    __syncthreads(); // (wsum[0] becomes the cursor of the list below)
+    if (exc < rank && rank <= inc) { // this thread's pair of bins holds the rank-th key
+        const bool second = rank > exc + c0;
+        bcast[0] = (u64)(2u * tid + (second ? 1u : 0u));                    // the bin
+        bcast[1] = (u64)(second ? exc + c0 : exc) | ((u64)(second ? c1 : c0) << 32); // keys below it | keys in it
+    }
+    if (tid == 0) wsum[0] = 0;
+    __syncthreads();
+    const u32 bin = (u32)bcast[0], below = (u32)bcast[1], in_bin = (u32)(bcast[1] >> 32);
+    __syncthreads();
+    if (in_bin > 1024u) return lds_select_kth(keys, M, rank, hist256, wsum, bcast);
+    for (u32 i = tid; i < M; i += nthr) {
+        const u64 key = keys[i];
+        if (((u32)(key >> shift) & 2047u) == bin) list[atomicAdd(&wsum[0], 1u)] = key;
+    }
+    __syncthreads();
+    const u32 want = rank - below - 1u; // the key of the bin with exactly this many smaller ones (keys are distinct)
+    if (tid < in_bin) {
+        const u64 mine = list[tid];
+        u32 smaller = 0;
+        for (u32 j = 0; j < in_bin; ++j) smaller += list[j] < mine ? 1u : 0u;
+        if (smaller == want) bcast[0] = mine;
+    }
+    __syncthreads();
+    const u64 r = bcast[0];
+    __syncthreads();
+    return r;
+}
+
 // The selection itself, as a device function: the kernels below wrap it.
 //   sort_out = 0: radix select of the new threshold + partition of the live list (between launches)
 //   sort_out = 1: the same, then the survivors sorted ascending (live list = to_vec order; fh_finish) -- at most
@@ -136,7 +201,7 @@ __device__ u32 prune_small_dev(Entry *table, u32 *live, u32 *dead, u32 dead_cap,
     u32 keep;
     if (kind == 0u) {
         if ((u64)M >= size && size > 0) {
-            tau = lds_select_kth(keys, M, (u32)size, L.hist, L.wsum, L.bcast);
+            tau = lds_select_kth_fast(keys, M, (u32)size, L.hist, L.wsum, L.bcast, reinterpret_cast<unsigned char *>(L.skeys));
             keep = (u32)size;
         } else if (size == 0) {
             tau = 0ull;
@@ -158,7 +223,7 @@ __device__ u32 prune_small_dev(Entry *table, u32 *live, u32 *dead, u32 dead_cap,
             tau = max_hash;
             keep = n_le;
         } else if ((u64)M >= size) {
-            tau = lds_select_kth(keys, M, (u32)size, L.hist, L.wsum, L.bcast);
+            tau = lds_select_kth_fast(keys, M, (u32)size, L.hist, L.wsum, L.bcast, reinterpret_cast<unsigned char *>(L.skeys));
             keep = (u32)size;
         } else {
             tau = (size != 0) ? EMPTY64 : max_hash;
@@ -197,7 +262,40 @@ __device__ u32 prune_small_dev(Entry *table, u32 *live, u32 *dead, u32 dead_cap,
         }
     }
     __syncthreads();
-    if (sort_out) {
+    if (sort_out && keep <= 1024u) {
+        // at most one survivor per thread (every sketch of the default size): a bitonic network on registers -- partners up
+        // to 32 lanes away come by wave shuffle, only the ten exchanges across waves go through LDS and a barrier (the
+        // all-LDS network below costs 55 barriers for 1024 keys: 16 us against 5)
+        u64 key = tid < keep ? L.skeys[tid] : EMPTY64;
+        u32 slot = tid < keep ? L.sslots[tid] : 0xFFFFFFFFu;
+        for (u32 kk = 2; kk <= 1024u; kk <<= 1) {
+            for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+                u64 pk;
+                u32 ps;
+                if (jj >= 64u) {
+                    __syncthreads();
+                    L.skeys[tid] = key;
+                    L.sslots[tid] = slot;
+                    __syncthreads();
+                    pk = L.skeys[tid ^ jj];
+                    ps = L.sslots[tid ^ jj];
+                } else {
+                    pk = __shfl_xor(key, (int)jj);
+                    ps = __shfl_xor(slot, (int)jj);
+                }
+                const bool keep_min = ((tid & kk) == 0u) == ((tid & jj) == 0u);
+                if (keep_min ? (pk < key) : (pk > key)) {
+                    key = pk;
+                    slot = ps;
+                }
+            }
+        }
+        __syncthreads();
+        L.skeys[tid] = key;
+        L.sslots[tid] = slot;
+        __syncthreads();
+        if (tid < keep) live[tid] = slot;
+    } else if (sort_out) {
         u32 N = 1;
         while (N < keep) N <<= 1;
         for (u32 i = keep + tid; i < N; i += nthr) {
@@ -341,13 +439,18 @@ __global__ __launch_bounds__(1024) void k_small_epilogue(const EpiArgs a) {
             u32 *live = ctl->live;
             const u32 live_cap = ctl->live_cap, shard_cap = ctl->shard_cap;
             const u32 *buf = ctl->shard_buf;
-            for (u32 sh = wave; sh < (u32)N_SHARDS; sh += 16u) {
-                const u32 b = M + s_off[sh], n = s_off[sh + 1] - s_off[sh];
-                const u32 *src = buf + (size_t)sh * shard_cap;
-                for (u32 i = lane; i < n; i += 64u) {
-                    if (b + i < live_cap) live[b + i] = src[i];
-                    else atomicExch(&ctl->overflow, 1u);
+            // (one entry per thread and trip, its shard found by bisection of the offsets: every load of the copy is in
+            // flight at once -- a wave per shard in turn made sixteen dependent round trips to HBM, 30 us of a 45 us kernel)
+            for (u32 i = tid; i < total; i += 1024u) {
+                u32 lo = 0, hi = (u32)N_SHARDS;
+                while (hi - lo > 1u) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if (s_off[mid] <= i) lo = mid;
+                    else hi = mid;
                 }
+                const u32 v = buf[(size_t)lo * shard_cap + (i - s_off[lo])];
+                if (M + i < live_cap) live[M + i] = v;
+                else atomicExch(&ctl->overflow, 1u);
             }
             if (tid < (u32)N_SHARDS) ctl->shard_cnt[tid * SHARD_STRIDE] = 0;
             if (tid == 0 && total) {
@@ -712,12 +815,13 @@ hipError_t launch_reset_small(Entry *table, const u32 *live, const u32 *dead, Ct
 
 // new range: empty queue; relaunch of a stopped range: keep next_chunk, swap leftover lists
 // (set_tau: the threshold of a speculative range rides along instead of a k_set_tau launch of its own; gate: the range was
-//  queued behind a speculation and must leave the queue of that range alone unless it held -- Ctl::spec_ok)
-__global__ void k_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, u32 read_first, u32 set_tau, u64 tau, u32 gate) {
+//  queued behind a speculation and must leave the queue of that range alone unless it held -- Ctl::spec_ok;
+//  first_total: the units the first launch's waves start on without asking the queue -- it begins behind them)
+__global__ void k_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, u32 read_first, u32 set_tau, u64 tau, u32 gate, u32 first_total) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         if (gate && ctl->spec_ok == 0u) return;
         if (set_tau) ctl->tau = tau;
-        if (new_range) ctl->next_unit = 0;
+        if (new_range) ctl->next_unit = first_total;
         ctl->left_in_pos = 0;
         ctl->n_left_out = 0;
         ctl->soft_limit = soft_limit;
@@ -735,9 +839,10 @@ __global__ void k_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, u32 read_
     }
 }
 
-hipError_t launch_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, u32 read_first, hipStream_t st, bool set_tau, u64 tau, bool gate) {
+hipError_t launch_queue_reset(Ctl *ctl, u32 new_range, u32 soft_limit, u32 read_first, hipStream_t st, bool set_tau, u64 tau, bool gate,
+                              u32 first_total) {
     hipLaunchKernelGGL(k_queue_reset, dim3(1), dim3(64), 0, st, ctl, new_range, soft_limit, read_first, set_tau ? 1u : 0u, tau,
-                       gate ? 1u : 0u);
+                       gate ? 1u : 0u, first_total);
     return hipGetLastError();
 }
 

@@ -1,5 +1,6 @@
 """bench.py's N > 1 flows on a 1-GPU box (--share-gpu maps every rank / thread to device 0):
-  * launched plainly (`python bench.py --gpus N`): one process, one host thread + sketcher handle per device;
+  * launched plainly (`python bench.py --gpus N`): one process, one fh_sketch_device_blocks call per step (one library thread +
+    sketcher handle per device, merge inside the call);
   * launched by torch.distributed.run: one process per rank, rank 0 gathers and merges.
 Each rank sketches its own read block; the merged sketch of N ranks must be the sketch one rank computes on the union (same read
 indices): SURVEY 8e through the real launchers, timing protocol and JSON contract included -- and, at BASELINE configs[3]'s
@@ -88,6 +89,24 @@ def test_driver_shaped_launch_of_two_gpus_matches_the_oracle_golden_at_full_size
     assert out["n_gpus"] == 2 and out["scaling"] == "strong"
     assert "BASELINE configs[3]" in out["config"]["workload"] and out["config"]["reads_total"] == 333333334
     assert out["sketch_check"]["matches_golden"] is True and out["sketch_check"]["golden"]
+
+
+def test_eight_read_blocks_in_one_library_call_match_the_oracle_golden_at_full_size():
+    """`python bench.py --gpus 8`: BASELINE configs[3] as its north_star states it -- 50 Gbase in eight read blocks, one
+    fh_sketch_device_blocks call per step (eight library threads, eight handles; here all on this box's one GPU), host merge --
+    and the merged sketch is the oracle's"""
+    out = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], 8, launcher=False)
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and "8 contiguous read blocks" in out["config"]["workload"]
+    assert "BASELINE configs[3]" in out["config"]["workload"] and out["config"]["reads_total"] == 333333334
+    assert out["sketch_check"]["matches_golden"] is True
+
+
+def test_eight_ranks_under_the_launcher():
+    """torch.distributed.run with eight ranks (gloo gather of the partial sketches, merge on rank 0) on a cut-down read set"""
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--gbases", "0.4"]
+    multi = _bench(common, 8, True)
+    single = _bench(common, 1)
+    assert multi["n_gpus"] == 8 and _fp(multi) == _fp(single)
 
 
 def test_single_gpu_default_is_configs3_and_checks_itself():
