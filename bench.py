@@ -675,6 +675,47 @@ def measure_extras(F, S, dr, dg, n_reads, dev):
                 "text_GBps": round(data.size / best / 1e9, 2)}
     guarded("end_to_end_fastq_text", e2e)
 
+    # -- the drop-in path at the trait level: sketch_stream's record loop calling process() --
+    def trait_path():
+        ns = min(n_reads, 4_000_000)
+        reads = np.ascontiguousarray(dr.download(ns * REC))  # the records as a parser would hand them over: slices of one buffer
+        offs = (np.arange(ns, dtype=np.uint64) * REC)
+        lens = np.full(ns, READ_LEN, dtype=np.uint64)
+        p = F.SketchParams.mash(1000, 1000, True, 21, 0)
+        out = {"what": "sketch_stream's loop as the Rust binding runs it (INTEGRATION.md 2): one fh_process call per record of %d 150-base "
+                       "records in host memory (one copy, blanks dropped on the way, into pinned staging; commits, H2D and kernels "
+                       "behind it), then to_vec -- single thread, as the reference drives one file; block_*: the same bytes handed "
+                       "over as 32 MB blocks of records + breakers through fh_push_block (the strip of a block runs on up to 8 threads)" % ns}
+        s = p.create_sketcher(device=dev)
+        best = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            s.reset()
+            s.process_records(reads, offs, lens)
+            kc, km, _ = s.to_arrays()
+            tk = s.finish()[1]
+            best = min(best, time.perf_counter() - t0)
+        out["seconds"] = round(best, 4)
+        out["gbases_per_s"] = round(ns * READ_LEN / best / 1e9, 2)
+        out["sequence_GBps"] = round(ns * READ_LEN / best / 1e9, 2)
+        fp_rec = fingerprint(kc, km, tk)
+        best = 1e30
+        blk = 32 << 20
+        for _ in range(3):
+            t0 = time.perf_counter()
+            s.reset()
+            for o in range(0, reads.size, blk // REC * REC):
+                s.push_block(reads[o:o + blk // REC * REC])
+            kc, km, _ = s.to_arrays()
+            tk = s.finish()[1]
+            best = min(best, time.perf_counter() - t0)
+        out["block_seconds"] = round(best, 4)
+        out["block_sequence_GBps"] = round(ns * READ_LEN / best / 1e9, 2)
+        out["both_forms_agree"] = fingerprint(kc, km, tk) == fp_rec
+        s.close()
+        return out
+    guarded("trait_path", trait_path)
+
     # -- compressed input: the host inflates (fh_inflate.h), the device splits records and sketches --
     def gz():
         import shutil
@@ -743,13 +784,17 @@ def measure_extras(F, S, dr, dg, n_reads, dev):
             paths = [m[0] for m in made]
             tot = sum(m[1] for m in made)
             best = 1e30
+            # (the sketchers the earlier lines parked fill the handle cache -- FH_POOL_BYTES, 8 GiB: with them there, part of this
+            # batch's sixteen worker handles would be allocated and pinned anew in every call, which is not what a process that
+            # sketches batches does)
+            H._lib.load().fh_release_cached()
             for _ in range(3):
                 t0 = time.perf_counter()
                 res = H.sketch_files(paths, F.SketchParams.default(), H.FilterParams(None), devices=[dev])
                 best = min(best, time.perf_counter() - t0)
                 assert len(res) == nf
             return {"what": "ONE finch_sketch_files call over %d synthetic FASTA files (log-uniform 1-10 Mb, 70-column lines, "
-                            "%.2f Gbases, page cache / tmpfs), library defaults (k=21 n=1000, 12 worker threads per GPU)" % (nf, tot / 1e9),
+                            "%.2f Gbases, page cache / tmpfs), library defaults (k=21 n=1000, up to 16 worker threads per GPU)" % (nf, tot / 1e9),
                     "seconds": round(best, 4), "files_per_s": round(nf / best, 1), "gbases_per_s": round(tot / best / 1e9, 2)}
         finally:
             shutil.rmtree(d, ignore_errors=True)

@@ -21,6 +21,7 @@
 
 #include "../../include/finch_hip.h"
 #include "fh_core.h"
+#include "fh_strip.h"
 #include "fh_device.h"
 #include "fh_kernels.h"
 
@@ -172,6 +173,14 @@ struct fh_sketcher {
     // the epilogue of the last sketch launch, not launched yet: whatever touches the control block next launches it first
     // (flush_epilogue) -- and fh_finish folds it into its own, so a file of a batch gets ONE epilogue launch, not two
     uint32_t epi_pending = 0, epi_units = 0;
+    // fh_finish's fused epilogue left the device side as fh_reset would (EPI_RESET): the next fh_reset is host bookkeeping only
+    // fh_process: the staging buffer records are being written to (null: none taken yet), how much of it is filled, whether
+    // the block continues a record an earlier commit cut, whether a record is open, and mash.rs:72's total_bases
+    uint8_t *proc_buf = nullptr;
+    uint64_t proc_cap = 0, proc_fill = 0, proc_total_bases = 0;
+    bool proc_continuing = false, proc_in_record = false;
+    bool device_clean = false;
+    uint64_t final_text_bases = 0; // Ctl::text_bases as of fh_finish (fh_text_bases stays valid after it)
     uint32_t *left_buf[2] = {nullptr, nullptr}; // leftover tile ranges of a stopped launch (pairs)
     uint64_t max_waves = 0;
     uint64_t max_range = 0; // test knob: cap on positions per range
@@ -302,6 +311,9 @@ static void bgzf_quiesce(fh_sketcher *s) {
 // (device_part = false: the caller has queued a kernel that re-initialises the control block itself)
 int init_state(fh_sketcher *s, bool device_part = true) {
     s->epi_pending = 0; // (callers that could have one pending -- fh_reset -- have launched it: it rewinds the shard cursors)
+    s->proc_buf = nullptr;
+    s->proc_fill = s->proc_total_bases = 0;
+    s->proc_continuing = s->proc_in_record = false;
     if (device_part) HIP_TRY(launch_init_ctl(s->ctl, initial_tau(s), s->stream, false, s->p.size, 0ull, s->hist));
     s->spec.pending = false;
     s->stream_off = 0;
@@ -1242,7 +1254,7 @@ uint32_t sat_add(uint32_t a, uint32_t b) {
 
 extern "C" {
 
-int fh_abi_version(void) { return 4; } // 4: fh_debug_fast_path, fh_sketch_device_blocks
+int fh_abi_version(void) { return 4; } // 4: fh_sketch_device_blocks, fh_process, fh_debug_fast_path
 
 const char *fh_last_error(void) { return g_err.c_str(); }
 
@@ -1543,6 +1555,11 @@ void destroy_handle(fh_sketcher *s) {
 int fh_reset(fh_sketcher *s) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (int rc = set_device(s)) return rc;
+    if (s->device_clean && s->finished && !s->pend.active && !s->epi_pending) { // fh_finish's epilogue has done the device side
+        s->device_clean = false;
+        return init_state(s, false);
+    }
+    s->device_clean = false;
     if (s->spec.pending && !s->pend.active) s->spec.pending = false; // (nobody will ask for its outcome; the clear below is stream-ordered behind it)
     if (int rc = drain(s)) return rc;
     if (int rc = flush_epilogue(s)) return rc; // (it also rewinds the shard cursors of the last launch)
@@ -1566,9 +1583,76 @@ int fh_set_stream_offset(fh_sketcher *s, uint64_t offset) {
     return FH_OK;
 }
 
+// ---- SketchScheme::process itself (mash.rs:67-80), one record per call ----
+// The record's bytes go straight into the pinned staging buffer, blanks dropped on the way (the ONE host-side copy), one
+// breaker byte behind them; a full buffer is committed as fh_push_staged does.  A binding at the trait level is this call
+// and nothing else per record -- no block of its own to append to and hand over (a second copy of every base).
+static int text_buffer_impl(fh_sketcher *s, uint8_t **buf, uint64_t *cap);
+static int proc_acquire(fh_sketcher *s) {
+    if (s->proc_buf) return FH_OK;
+    uint8_t *buf = nullptr;
+    uint64_t cap = 0;
+    if (int rc = text_buffer_impl(s, &buf, &cap)) return rc;
+    s->proc_buf = buf;
+    s->proc_cap = cap;
+    s->proc_fill = 0;
+    return FH_OK;
+}
+static int proc_commit(fh_sketcher *s) {
+    uint8_t *const buf = s->proc_buf;
+    s->proc_buf = nullptr; // (fh_push_staged hands the slot on; whatever happens, this block is done with)
+    if (!buf || s->proc_fill == 0) return FH_OK;
+    const uint64_t n = s->proc_fill;
+    s->proc_fill = 0;
+    const int rc = fh_push_staged(s, n, s->proc_continuing ? FH_PUSH_CONTINUE : 0u);
+    s->proc_continuing = s->proc_in_record;
+    return rc;
+}
+// records written by fh_process that no push has committed yet: every other way of feeding the sketcher, and everything that
+// looks at the result, commits them first
+static int proc_flush(fh_sketcher *s) { return s->proc_buf ? proc_commit(s) : FH_OK; }
+
+int fh_process(fh_sketcher *s, const uint8_t *seq, uint64_t len) {
+    if (!s || (!seq && len)) return fail(FH_ERR_INVALID, "null argument");
+    if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    s->proc_total_bases += len; // mash.rs:72: the raw sequence() slice, blanks included
+    s->proc_in_record = true;
+    while (len) {
+        if (int rc = proc_acquire(s)) return rc;
+        const uint64_t room = s->proc_cap - s->proc_fill;
+        if (room <= 64) { // (the strip stores whole vectors: 32 bytes of slack behind what it keeps)
+            if (int rc = proc_commit(s)) return rc;
+            continue;
+        }
+        const uint64_t take = std::min<uint64_t>(len, room - 64);
+        s->proc_fill += fh_strip::strip(s->proc_buf + s->proc_fill, seq, take);
+        seq += take;
+        len -= take;
+    }
+    if (int rc = proc_acquire(s)) return rc;
+    s->proc_buf[s->proc_fill++] = 0; // the breaker: k-mers never span records
+    s->proc_in_record = false;
+    if (s->proc_cap - s->proc_fill <= 64) return proc_commit(s);
+    return FH_OK;
+}
+
+int fh_process_records(fh_sketcher *s, const uint8_t *base, const uint64_t *offsets, const uint64_t *lens, uint64_t n) {
+    if (!s || (n && (!base || !offsets || !lens))) return fail(FH_ERR_INVALID, "null argument");
+    for (uint64_t i = 0; i < n; ++i)
+        if (int rc = fh_process(s, base + offsets[i], lens[i])) return rc;
+    return FH_OK;
+}
+
+int fh_total_bases(fh_sketcher *s, uint64_t *total_bases) {
+    if (!s || !total_bases) return fail(FH_ERR_INVALID, "null argument");
+    *total_bases = s->proc_total_bases;
+    return FH_OK;
+}
+
 int fh_push_device(fh_sketcher *s, const void *dev_bytes, uint64_t len) {
     if (!s || (!dev_bytes && len)) return fail(FH_ERR_INVALID, "null argument");
     if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    if (int rc = proc_flush(s)) return rc;
     if (((uintptr_t)dev_bytes & 15u) != 0) return fail(FH_ERR_INVALID, "device block must be 16-byte aligned");
     if (int rc = set_device(s)) return rc;
     s->carry_len = 0;
@@ -1578,33 +1662,54 @@ int fh_push_device(fh_sketcher *s, const void *dev_bytes, uint64_t len) {
     return rc;
 }
 
-// copy `n` bytes dropping ' ', '\t', '\r', '\n' (what normalize(false) removes); 8 bytes at a time when clean
-static inline uint64_t strip_copy(uint8_t *dst, const uint8_t *src, uint64_t n, uint64_t dst_room, uint64_t *consumed) {
-    uint64_t i = 0, m = 0;
-    while (i + 8 <= n && m + 8 <= dst_room) {
-        uint64_t x;
-        memcpy(&x, src + i, 8);
-        // any byte < 0x21 ?
-        if (((x - 0x2121212121212121ull) & ~x & 0x8080808080808080ull) == 0) {
-            memcpy(dst + m, &x, 8);
-            m += 8;
-            i += 8;
-        } else {
-            for (int j = 0; j < 8; ++j) {
-                const uint8_t c = src[i + j];
-                if (c == ' ' || c == '\t' || c == '\r' || c == '\n') continue;
-                dst[m++] = c;
+// copy src[0, n) to dst dropping ' ', '\t', '\r', '\n' (what normalize(false) removes: fh_strip.h); dst has room for n + 32
+// bytes.  A block of megabytes is split over a few threads: a first pass counts what every share keeps, the second copies
+// every share to its place (one thread strips ~5 GB/s, a third of what the copy to the device behind it moves).
+static uint64_t strip_block(uint8_t *dst, const uint8_t *src, uint64_t n) {
+    static const unsigned cap = [] {
+        const char *e = getenv("FH_HOST_THREADS"); // 1 = always inline
+        const unsigned v = e ? (unsigned)atoi(e) : 8u;
+        return v ? v : 1u;
+    }();
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nt = std::min<size_t>(std::min<size_t>(hw, cap), n >> 21);
+    if (nt <= 1) return fh_strip::strip(dst, src, n);
+    const size_t per = (n + nt - 1) / nt;
+    std::vector<size_t> kept(nt + 1, 0);
+    auto lo_of = [&](size_t t) { return std::min<size_t>(n, t * per); };
+    {
+        std::vector<std::thread> th;
+        th.reserve(nt);
+        size_t started = 0;
+        try {
+            for (; started < nt - 1; ++started) {
+                const size_t t = started + 1;
+                th.emplace_back([&, t] { kept[t + 1] = fh_strip::count_kept(src + lo_of(t), lo_of(t + 1) - lo_of(t)); });
             }
-            i += 8;
+        } catch (...) {
         }
+        kept[1] = fh_strip::count_kept(src, lo_of(1));
+        for (size_t t = started + 1; t < nt; ++t) kept[t + 1] = fh_strip::count_kept(src + lo_of(t), lo_of(t + 1) - lo_of(t));
+        for (auto &x : th) x.join();
     }
-    while (i < n && m < dst_room) {
-        const uint8_t c = src[i++];
-        if (c == ' ' || c == '\t' || c == '\r' || c == '\n') continue;
-        dst[m++] = c;
+    for (size_t t = 0; t < nt; ++t) kept[t + 1] += kept[t]; // -> where share t's bytes begin
+    {
+        // (the exact scalar form: a share must not write a byte behind what it keeps -- the next share's bytes begin there)
+        std::vector<std::thread> th;
+        th.reserve(nt);
+        size_t started = 0;
+        try {
+            for (; started < nt - 1; ++started) {
+                const size_t t = started + 1;
+                th.emplace_back([&, t] { (void)fh_strip::strip_scalar(dst + kept[t], src + lo_of(t), lo_of(t + 1) - lo_of(t)); });
+            }
+        } catch (...) {
+        }
+        (void)fh_strip::strip_scalar(dst, src, lo_of(1));
+        for (size_t t = started + 1; t < nt; ++t) (void)fh_strip::strip_scalar(dst + kept[t], src + lo_of(t), lo_of(t + 1) - lo_of(t));
+        for (auto &x : th) x.join();
     }
-    *consumed = i;
-    return m;
+    return kept[nt];
 }
 
 static int ensure_stage(fh_sketcher *s);
@@ -1613,6 +1718,7 @@ static int ensure_slot(fh_sketcher *s, int i, uint64_t want);
 int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_t flags) {
     if (!s || (!bytes && len)) return fail(FH_ERR_INVALID, "null argument");
     if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    if (int rc = proc_flush(s)) return rc;
     if (int rc = set_device(s)) return rc;
     // normalize(false) drops whitespace (needletail; mash.rs:73): strip it while staging so that device
     // positions are contiguous.  k-mers may span staging slices of one block: carry K-1 bytes over.
@@ -1630,8 +1736,9 @@ int fh_push_block_ex(fh_sketcher *s, const uint8_t *bytes, uint64_t len, uint32_
         }
         uint8_t *dst = s->h_stage[b];
         memcpy(dst, s->carry, carry_len);
-        uint64_t consumed = 0;
-        const uint64_t fresh = strip_copy(dst + carry_len, bytes + in, len - in, s->stage_cap[b] - carry_len, &consumed);
+        // (the slot was allocated 128 bytes larger than its capacity: room for the vector stores of the strip)
+        const uint64_t consumed = std::min<uint64_t>(len - in, s->stage_cap[b] - carry_len);
+        const uint64_t fresh = strip_block(dst + carry_len, bytes + in, consumed);
         in += consumed;
         const uint64_t m = carry_len + fresh;
         const uint64_t base = s->stream_off - carry_len;
@@ -1681,8 +1788,13 @@ static int ensure_stage(fh_sketcher *s) {
     return FH_OK;
 }
 
+static int text_buffer_impl(fh_sketcher *s, uint8_t **buf, uint64_t *cap);
 int fh_text_buffer(fh_sketcher *s, uint8_t **buf, uint64_t *cap) {
     if (!s || !buf || !cap) return fail(FH_ERR_INVALID, "null argument");
+    if (int rc = proc_flush(s)) return rc; // (records of fh_process sit in the very buffer this hands out)
+    return text_buffer_impl(s, buf, cap);
+}
+static int text_buffer_impl(fh_sketcher *s, uint8_t **buf, uint64_t *cap) {
     if (int rc = set_device(s)) return rc;
     if (int rc = ensure_stage(s)) return rc;
     const int b = s->stage_next;
@@ -1698,6 +1810,7 @@ int fh_text_buffer(fh_sketcher *s, uint8_t **buf, uint64_t *cap) {
 
 int fh_text_buffers(fh_sketcher *s, uint8_t *bufs[2], uint64_t *cap, int *next) {
     if (!s || !bufs || !cap || !next) return fail(FH_ERR_INVALID, "null argument");
+    if (int rc = proc_flush(s)) return rc;
     if (int rc = set_device(s)) return rc;
     if (int rc = ensure_stage(s)) return rc;
     for (int i = 0; i < N_STAGE; ++i) {
@@ -1783,6 +1896,7 @@ static int fastq_text_on_device(fh_sketcher *s, const uint8_t *text, uint64_t le
 int fh_push_fastq_text(fh_sketcher *s, uint64_t len) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    if (s->proc_buf) return fail(FH_ERR_STATE, "records of fh_process are waiting in the staging buffer: fh_sync first");
     if (len > s->stage_bytes) return fail(FH_ERR_INVALID, "text longer than the staging buffer");
     if (int rc = set_device(s)) return rc;
     if (int rc = ensure_stage(s)) return rc;
@@ -1868,6 +1982,7 @@ int fh_bgzf_text_capacity(fh_sketcher *s, uint64_t *cap) {
 int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint32_t flags) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    if (s->proc_buf) return fail(FH_ERR_STATE, "records of fh_process are waiting in the staging buffer: fh_sync first");
     if (bytes > s->stage_bytes) return fail(FH_ERR_INVALID, "batch longer than the staging buffer");
     if ((uint64_t)n_members * sizeof(fh_bgzf_member) > bytes) return fail(FH_ERR_INVALID, "member table longer than the batch");
     if (int rc = set_device(s)) return rc;
@@ -1964,6 +2079,7 @@ int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint3
 int fh_push_fasta_text(fh_sketcher *s, uint64_t len, uint32_t start_state, uint32_t flags) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    if (s->proc_buf) return fail(FH_ERR_STATE, "records of fh_process are waiting in the staging buffer: fh_sync first");
     if (start_state > 2u) return fail(FH_ERR_INVALID, "bad start_state");
     if (len > s->stage_bytes || len >= (1ull << 30)) return fail(FH_ERR_INVALID, "text longer than the staging buffer");
     if (int rc = set_device(s)) return rc;
@@ -2027,6 +2143,10 @@ int fh_set_text_halo(fh_sketcher *s, const uint8_t *halo, uint32_t n) {
 
 int fh_text_bases(fh_sketcher *s, uint64_t *total_bases) {
     if (!s || !total_bases) return fail(FH_ERR_INVALID, "null argument");
+    if (s->finished) { // (the device side may have been reset already: fh_finish kept the count)
+        *total_bases = s->final_text_bases;
+        return FH_OK;
+    }
     if (int rc = set_device(s)) return rc;
     if (int rc = drain(s)) return rc;
     if (int rc = check_ctl(s)) return rc;
@@ -2039,6 +2159,7 @@ int fh_push_block(fh_sketcher *s, const uint8_t *bytes, uint64_t len) { return f
 int fh_sync(fh_sketcher *s) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (int rc = set_device(s)) return rc;
+    if (int rc = proc_flush(s)) return rc;
     if (int rc = drain(s)) return rc;
     if (int rc = check_ctl(s)) return rc;
     return collect_profile(s);
@@ -2086,6 +2207,8 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
     };
     const auto t0 = now();
     auto t1 = t0, t2 = t0, t3 = t0;
+    if (!s->finished)
+        if (int rc = proc_flush(s)) return rc;
     if (!s->finished) {
         const bool wide = s->p.k > 32;
         auto ensure_h_out = [&](size_t need) -> int {
@@ -2106,9 +2229,15 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         if (s->fast) {
             if (int rc = ensure_out(s, (uint32_t)std::min<uint64_t>(s->p.size + 1, SMALL_MAX))) return rc;
             if (int rc = ensure_h_out(s->out_stride * (wide ? 40 : 32) + 64)) return rc;
-            EpiArgs e = epi_args(s, s->epi_pending | EPI_PRUNE_FORCE | EPI_SORT | EPI_GATHER); // (the last launch's own epilogue folded in)
+            static const bool no_fold = getenv("FH_NO_RESET_FOLD") != nullptr; // A/B knob
+            // (the last launch's own epilogue folded in; EPI_RESET: if all went as queued the handle is left reset)
+            EpiArgs e = epi_args(s, s->epi_pending | EPI_PRUNE_FORCE | EPI_SORT | EPI_GATHER | (s->spec.pending ? EPI_NEED_SPEC : 0u) |
+                                        (no_fold ? 0u : EPI_RESET));
             e.n_units = s->epi_units;
             s->epi_pending = 0;
+            e.check_units = s->pend.active ? s->pend.n_units : 0u;
+            e.tau0 = initial_tau(s);
+            e.hist_on = s->hist ? 1u : 0u;
             e.out = (uint64_t *)s->h_out;
             e.out_stride = (uint32_t)s->out_stride;
             e.h_ctl = s->h_ctl;
@@ -2117,9 +2246,9 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
             const Ctl &c = *s->h_ctl;
             if (c.overflow == 1) return fail(FH_ERR_CAPACITY, "device hash table capacity exceeded");
             if (c.overflow == 2) return fail(FH_ERR_CAPACITY, "hash collision log capacity exceeded");
-            const bool spec_ok = !s->spec.pending || c.spec_ok;
-            const bool dry = !s->pend.active || (c.next_unit >= s->pend.n_units && c.n_left_out == 0);
-            fused = spec_ok && dry && !c.need_big && c.sorted && (uint64_t)c.n_live <= s->p.size;
+            // (the kernel asked the control block what the host would: speculation held, range ran dry, nothing too large)
+            fused = c.sorted == FIN_OK || c.sorted == FIN_OK_RESET;
+            s->device_clean = c.sorted == FIN_OK_RESET; // (the collision log, if any, stays readable: only its counter was reset)
             if (fused) {
                 s->spec.pending = false;
                 s->pend.active = false;
@@ -2216,6 +2345,7 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         s->res_built = false;
         s->total_kmers = 0;
         for (int i = 0; i < 256; ++i) s->total_kmers += c.kmer_counts[i];
+        s->final_text_bases = c.text_bases;
         s->finished = true;
         t3 = now();
         if (trace)

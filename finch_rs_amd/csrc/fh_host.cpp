@@ -4,6 +4,7 @@
 //
 // Reference items mirrored (relative to the finch-rs tree) are cited at each function.
 #include <dlfcn.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -29,6 +30,7 @@
 #include "fh_host_model.h"
 #include "fh_inflate.h"
 #include "fh_pargz.h"
+#include "fh_strip.h"
 
 // job(t) for t = 0 .. n - 1, one thread each (the caller's runs job(0)).  A thread that cannot be created (EAGAIN under a
 // thread limit) must not take the process down -- a vector of joinable threads that unwinds calls std::terminate -- so its
@@ -610,6 +612,32 @@ struct FastGzSource : ByteSource {
 
 // Threads one input may use for large reads and BGZF members: FINCH_READ_THREADS, else a sixteenth of the machine's
 // hardware threads (a GPU node has ~32 cores per GPU and other ranks beside this one), between 8 and 16.
+// hardware threads this process may really use: the affinity mask capped by the cgroup's CPU quota (a container that sees 256
+// processors and is granted 16 runs 24 busy workers slower than 16)
+static unsigned usable_cpus() {
+    static const unsigned v = [] {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota|max> <period>"
+            char q[64];
+            long long per = 0;
+            if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) n = std::min<unsigned>(n, (unsigned)std::max(1ll, atoll(q) / per));
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { // cgroup v1
+            long long quota = -1, per = 0;
+            const bool ok = fscanf(g, "%lld", &quota) == 1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (ok && fscanf(h, "%lld", &per) == 1 && quota > 0 && per > 0) n = std::min<unsigned>(n, (unsigned)std::max(1ll, quota / per));
+                fclose(h);
+            }
+        }
+        return n;
+    }();
+    return v;
+}
+
 static unsigned read_threads_total(const char *env) {
     if (env) return (unsigned)std::min(64, std::max(1, atoi(env)));
     const unsigned hw = std::thread::hardware_concurrency();
@@ -1634,30 +1662,8 @@ struct CountSink : RecordSink {
 };
 
 // copy n bytes dropping ' ', '\t', '\r', '\n' (what normalize(false) removes, mash.rs:73); 8 bytes at a time when clean
-static inline size_t strip_copy(uint8_t *dst, const uint8_t *src, size_t n) {
-    size_t i = 0, m = 0;
-    while (i + 8 <= n) {
-        uint64_t x;
-        memcpy(&x, src + i, 8);
-        if (((x - 0x2121212121212121ull) & ~x & 0x8080808080808080ull) == 0) { // no byte < 0x21
-            memcpy(dst + m, &x, 8);
-            m += 8;
-        } else {
-            for (int j = 0; j < 8; ++j) {
-                const uint8_t c = src[i + j];
-                if (c == ' ' || c == '\t' || c == '\r' || c == '\n') continue;
-                dst[m++] = c;
-            }
-        }
-        i += 8;
-    }
-    for (; i < n; ++i) {
-        const uint8_t c = src[i];
-        if (c == ' ' || c == '\t' || c == '\r' || c == '\n') continue;
-        dst[m++] = c;
-    }
-    return m;
-}
+// (normalize(false) drops blanks, mash.rs:73: fh_strip.h; the destination needs 32 bytes of slack behind what is kept)
+static inline size_t strip_copy(uint8_t *dst, const uint8_t *src, size_t n) { return fh_strip::strip_scalar(dst, src, n); }
 
 // SketchScheme::process (mash.rs:67-80) over the C ABI: record bytes + one breaker byte, written (whitespace
 // already dropped) straight into the sketcher's pinned staging buffer and committed in large blocks; a record
@@ -2229,6 +2235,82 @@ static int finish_sketch(fh_sketcher *h, const std::string &name, const finch_sk
     return FH_OK;
 }
 
+// A plain FASTA file that fits the staging buffer twice over (a genome of a batch: configs[4]) is packed on the HOST, in
+// one pass, while it is staged: the file is read into the upper part of the sketcher's pinned staging buffer and its
+// sequence regions are copied to the front without their blanks (fh_strip.h), one breaker byte per record -- the packed
+// stream fh_push_staged commits.  The device then runs THREE launches for the file (queue reset, sketch kernel, the fused
+// epilogue that also leaves the handle reset) behind one host-to-device copy, and the host waits once.  The device-side
+// splitter (fh_push_fasta_text: five more launches and a round trip for the packed length) stays what large inputs go through,
+// where the host could not strip at the rate the link moves text.  Same records, same total_bases as parse_fastx:
+// a record starts at a line that begins with '>', its sequence region runs to the next such line, internal newlines count
+// (mash.rs:72), one trailing line end is trimmed.
+// -> FH_OK, or FH_ERR_STATE ("does not apply": nothing consumed that a rewind does not give back), or an error.
+static int fasta_small_on_host(ByteSource &src, fh_sketcher *h, FastxStats &st) {
+    const uint64_t hint = src.remaining_hint();
+    if (hint == UINT64_MAX || !src.can_rewind()) return FH_ERR_STATE;
+    uint8_t *buf = nullptr;
+    uint64_t cap = 0;
+    if (int rc = fh_text_buffer(h, &buf, &cap)) return hfail(rc, "%s", fh_last_error());
+    if (hint + 4096 > cap) return FH_ERR_STATE;
+    // the raw text goes to the upper part of the staging buffer if the packed stream has room in front of it, else to a heap
+    // buffer this worker keeps
+    static thread_local std::vector<uint8_t> scratch;
+    uint8_t *raw;
+    size_t room;
+    if (2 * hint + 4096 <= cap) {
+        raw = buf + ((cap - hint - 64) & ~(uint64_t)63);
+        room = (size_t)(buf + cap - raw);
+    } else {
+        if (scratch.size() < hint + 64) scratch.resize((size_t)hint + 64 + (hint >> 2));
+        raw = scratch.data();
+        room = scratch.size();
+    }
+    size_t n = 0;
+    for (;;) {
+        const size_t g = src.read(raw + n, room - n);
+        if (g == 0) break;
+        n += g;
+        if (n == room) { // longer than it said: not for this path
+            if (!src.rewind()) return hfail(FH_ERR_INVALID, "input grew while it was read");
+            return FH_ERR_STATE;
+        }
+    }
+    if (src.failed()) return hfail(FH_ERR_INVALID, "corrupt compressed stream");
+    if (n == 0 || raw[0] != '>') {
+        if (!src.rewind()) return hfail(FH_ERR_INVALID, "not a FASTA file");
+        return FH_ERR_STATE;
+    }
+    st.format = 1;
+    size_t pos = 0, m = 0; // pos: at the '>' of a header line
+    while (pos < n) {
+        const uint8_t *nl = (const uint8_t *)memchr(raw + pos, '\n', n - pos);
+        const size_t start = nl ? (size_t)(nl - raw) + 1 : n; // the sequence region begins behind the header line
+        // the next header: a '>' at a line start
+        size_t next = n;
+        for (size_t q = start; q < n;) {
+            const uint8_t *g = (const uint8_t *)memchr(raw + q, '>', n - q);
+            if (!g) break;
+            const size_t at = (size_t)(g - raw);
+            if (at == start || raw[at - 1] == '\n') {
+                next = at;
+                break;
+            }
+            q = at + 1;
+        }
+        const size_t len = next - start;
+        uint64_t trim = 0;
+        if (len >= 1 && raw[next - 1] == '\n') trim = (len >= 2 && raw[next - 2] == '\r') ? 2 : 1;
+        else if (len >= 1 && raw[next - 1] == '\r') trim = 1;
+        st.total_bases += len - trim;
+        st.n_records++;
+        m += fh_strip::strip(buf + m, raw + start, len);
+        buf[m++] = 0; // the record's breaker
+        pos = next;
+    }
+    if (int rc = fh_push_staged(h, m, 0u)) return hfail(rc, "%s", fh_last_error());
+    return FH_OK;
+}
+
 static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &name, const finch_sketch_params &sp,
                          const finch_filter_params &filters, HandleSet &handles, Sketch &out) {
     std::unique_ptr<ByteSource> src;
@@ -2298,7 +2380,18 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     }
     if (device_parse && first == '>') {
         st.format = 1;
-        if (int rc = fasta_text_to_device(*src, h, st, sp.kmer_length)) return rc;
+        // FINCH_SMALL_FASTA_HOST: unset / 1 = a small plain file is packed while it is staged (fasta_small_on_host), 0 = never
+        static const bool small_host = [] {
+            const char *e = getenv("FINCH_SMALL_FASTA_HOST");
+            return !(e && e[0] == '0');
+        }();
+        int rc = (small_host && !dp_on && !is_gz) ? fasta_small_on_host(*src, h, st) : FH_ERR_STATE;
+        if (rc == FH_ERR_STATE) { // does not apply: split on the device
+            st = FastxStats{};
+            st.format = 1;
+            rc = fasta_text_to_device(*src, h, st, sp.kmer_length);
+        }
+        if (rc) return rc;
     } else if (!device_parse) {
         DeviceSink sink(h);
         if (int rc = parse_fastx(*src, sink, st)) return rc;
@@ -3163,7 +3256,10 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
     std::vector<int> devs;
     if (devices && n_devices) devs.assign(devices, devices + n_devices);
     else devs.push_back(0);
-    if (n_threads == 0) n_threads = 12 * (uint32_t)devs.size(); // measured sweet spot: 12 host workers per GPU (tools/batch_threads.py; a worker spends most of a small file copying it out of the page cache)
+    // host workers per GPU: a worker spends most of a small file staging it (page cache -> pinned memory, blanks dropped) and
+    // waits for the device once per file; 16 of them keep one GPU 85 % busy (9400 files/s against 8600 with 12 on a 16-core
+    // grant, profiles/r04_c5_threads.txt), more than the cores granted run slower than fewer (24: 5500)
+    if (n_threads == 0) n_threads = std::min<uint32_t>(16u, std::max<uint32_t>(4u, usable_cpus() / (uint32_t)devs.size())) * (uint32_t)devs.size();
     n_threads = std::max<uint32_t>(1, std::min<uint32_t>(n_threads, std::max<uint32_t>(n_files, 1)));
     auto res = std::make_unique<finch_sketches>();
     res->v.resize(n_files);

@@ -30,6 +30,12 @@ constexpr uint32_t EPI_PRUNE_FORCE = 8u;   // select whatever its length
 constexpr uint32_t EPI_SORT = 16u;         // ... and leave the survivors sorted (to_vec order)
 constexpr uint32_t EPI_VERDICT = 32u;      // set ctl->spec_ok for the speculative range of n_units units just run
 constexpr uint32_t EPI_GATHER = 64u;       // write the sorted sketch's columns to `out` (needs EPI_SORT)
+constexpr uint32_t EPI_NEED_SPEC = 128u;   // EPI_GATHER: a speculation is unverified -- the sketch only counts if ctl->spec_ok
+constexpr uint32_t EPI_RESET = 256u;       // EPI_GATHER: if the sketch counts, leave the handle as fh_reset would (slots cleared,
+                                           // control block re-initialised) behind the mirror of the final control block
+// what the gather epilogue reports in the mirrored control block's `sorted` word
+constexpr uint32_t FIN_OK_RESET = 2u;      // everything queued did what it was queued for, the sketch is in `out`, the handle is reset
+constexpr uint32_t FIN_OK = 3u;            // ... the handle is not reset (dropped-slot list overflowed: fh_reset sweeps the table)
 struct EpiArgs {
     Entry *table;
     uint32_t *live, *dead;
@@ -38,6 +44,9 @@ struct EpiArgs {
     uint32_t kind;
     uint64_t size, max_hash;
     uint32_t trigger, flags, n_units;
+    uint32_t check_units; // EPI_GATHER: units of the range still pending that must all have been pulled (0 = no range pending)
+    uint64_t tau0;        // EPI_RESET: what init_ctl gets
+    uint32_t hist_on;
     uint64_t *out;       // EPI_GATHER: hash | k-mer | first position | [high k-mer word] | count | extra columns, out_stride
     uint32_t out_stride; //   entries apart (device or pinned host memory)
     uint32_t wide;       // K > 32

@@ -400,6 +400,9 @@ hipError_t launch_prune_small(Entry *table, u32 *live, u32 *dead, u32 dead_cap, 
 // synchronisation; a pass over 50 Gbases queues its speculative prefix, the verdict, the gated main launch and the finish
 // back to back.  The host checks the mirrored control block afterwards and falls back to the step-by-step path whenever
 // something did not go as queued (speculation failed, launch stopped early, more live entries than the LDS holds).
+__device__ __forceinline__ void clear_entry(Entry *e);
+__device__ __forceinline__ void init_ctl_dev(Ctl *ctl, u64 tau0, u32 keep_text_bases, u64 sel_size, u64 tau_floor, u32 hist_on);
+
 __global__ __launch_bounds__(1024) void k_small_epilogue(const EpiArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ u32 s_hist[256];
@@ -506,6 +509,18 @@ __global__ __launch_bounds__(1024) void k_small_epilogue(const EpiArgs a) {
             }
         }
     }
+    // fh_finish's epilogue: did everything that was queued do what it was queued for?  (The host asks the mirrored control
+    // block the same questions; with EPI_RESET the answer is taken here, because the handle is to be left reset.)
+    u32 fin = 0u;
+    if ((a.flags & EPI_GATHER) && !skip) {
+        __syncthreads();
+        const bool spec_ok = !(a.flags & EPI_NEED_SPEC) || ctl->spec_ok != 0u;
+        const bool dry = a.check_units == 0u || (ctl->next_unit >= a.check_units && ctl->n_left_out == 0u);
+        const bool ok = spec_ok && dry && !ctl->need_big && !ctl->overflow && ctl->sorted == 1u && (u64)ctl->n_live <= a.size;
+        if (ok) fin = ((a.flags & EPI_RESET) && ctl->n_dead != 0xFFFFFFFFu) ? FIN_OK_RESET : FIN_OK;
+        __syncthreads();
+        if (fin && tid == 0) ctl->sorted = fin;
+    }
     if (a.h_ctl) {
         // the control block as the host reads it (what the check_ctl copy used to fetch); every write above is visible to
         // this workgroup after the barrier
@@ -514,6 +529,26 @@ __global__ __launch_bounds__(1024) void k_small_epilogue(const EpiArgs a) {
         u32 *dst = reinterpret_cast<u32 *>(a.h_ctl);
         for (u32 i = tid; i < (u32)(sizeof(Ctl) / 4); i += 1024u) dst[i] = src[i];
         __threadfence_system();
+    }
+    if (fin == FIN_OK_RESET) {
+        // the sketch is with the host: clear the slots this run touched (the survivors -- the sorted list in LDS -- and the
+        // dropped ones) and re-initialise the control block, so that the fh_reset in front of the next file launches nothing
+        __syncthreads();
+        const SmallLds L = small_lds(smem, s_hist, s_wsum, s_bcast, s_cnt);
+        const u32 nl = ctl->n_live, nd = ctl->n_dead;
+        u64 *khi = ctl->kmer_hi;
+        for (u32 i = tid; i < nl; i += 1024u) {
+            const u32 sl = L.sslots[i];
+            clear_entry(&a.table[sl]);
+            if (khi) khi[sl] = EMPTY64;
+        }
+        for (u32 i = tid; i < nd; i += 1024u) {
+            const u32 sl = a.dead[i];
+            clear_entry(&a.table[sl]);
+            if (khi) khi[sl] = EMPTY64;
+        }
+        __syncthreads(); // every thread has read the two counts
+        init_ctl_dev(ctl, a.tau0, 0u, a.size, 0ull, a.hist_on);
     }
 }
 

@@ -107,8 +107,18 @@ class HipSketcher:
         """process(&mut self, seq): one record's raw sequence() bytes (mash.rs:67-80)"""
         b = bytes(seq)
         self.total_bases += len(b)
-        block = b + b"\x00"
-        check(self._L.fh_push_block(self._h, C.cast(C.c_char_p(block), C.c_void_p), len(block)))
+        check(self._L.fh_process(self._h, C.cast(C.c_char_p(b), C.c_void_p), len(b)))
+
+    def process_records(self, base: np.ndarray, offsets: np.ndarray, lens: np.ndarray) -> None:
+        """fh_process for every record (base[offsets[i] : offsets[i] + lens[i]]) in one call: the loop a binding at the trait
+        level runs, without Python in it"""
+        base = np.ascontiguousarray(base, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint64)
+        if len(offsets) != len(lens) or (len(lens) and int((offsets + lens).max()) > base.size):
+            raise ValueError("records outside the buffer")
+        check(self._L.fh_process_records(self._h, base.ctypes.data, offsets.ctypes.data, lens.ctypes.data, len(lens)))
+        self.total_bases += int(lens.sum())
 
     def push_block(self, block) -> None:
         """several records at once: sequences separated/terminated by a breaker byte (0)"""

@@ -93,6 +93,16 @@ int fh_set_stream_offset(fh_sketcher *s, uint64_t offset);
  * bottom-n / scaled admission on the device.  k-mers never span two pushed blocks.
  * Asynchronous: returns once the bytes are staged; the caller may reuse `bytes` immediately. */
 int fh_push_block(fh_sketcher *s, const uint8_t *bytes, uint64_t len);
+/* process() as the trait has it (mash.rs:67-80), ONE record per call: `seq` = the record's raw sequence() bytes, no breaker.
+ * The library copies them -- blanks dropped on the way, as normalize(false) would -- straight into its pinned staging buffer,
+ * puts the breaker behind them and commits a full buffer by itself; fh_finish / fh_sync / any other push commit what is
+ * waiting.  This is the binding of choice at the trait level: one call and one copy per record,
+ * nothing to buffer on the caller's side.  fh_process_records does the same for n records of one buffer
+ * (base + offsets[i], lens[i]); fh_total_bases returns the sum of the lengths fh_process has seen since the last reset
+ * (total_bases, mash.rs:72 -- the host counter of SURVEY B2, kept here so that the binding need not). */
+int fh_process(fh_sketcher *s, const uint8_t *seq, uint64_t len);
+int fh_process_records(fh_sketcher *s, const uint8_t *base, const uint64_t *offsets, const uint64_t *lens, uint64_t n);
+int fh_total_bases(fh_sketcher *s, uint64_t *total_bases);
 /* Same with flags.  FH_PUSH_CONTINUE: this block continues the record the previous push ended in (a
  * record longer than the caller's buffer, e.g. a chromosome): k-mers span the boundary of the two pushes. */
 #define FH_PUSH_CONTINUE 1u

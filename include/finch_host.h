@@ -59,7 +59,7 @@ void finch_default_sketch_params(finch_sketch_params *out);
 void finch_default_filter_params(finch_filter_params *out);
 
 /* sketch_files: `devices` lists the HIP devices to use (NULL/0 = device 0); n_threads = worker threads
- * (0 = twelve per device).  "-" reads stdin.  Returns 0 or a negative FH_ERR_* code (message via
+ * (0 = one per hardware thread the process may use, at least 4 and at most 16 per device).  "-" reads stdin.  Returns 0 or a negative FH_ERR_* code (message via
  * finch_last_error; the first failing file wins, as in the reference's collect()). */
 int finch_sketch_files(const char *const *filenames, uint32_t n_files, const finch_sketch_params *sketch_params,
                        const finch_filter_params *filters, const int *devices, uint32_t n_devices, uint32_t n_threads,

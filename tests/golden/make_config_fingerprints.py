@@ -61,6 +61,32 @@ def _c5_file(i):
     return int(np.bitwise_xor.reduce(kc["hash"])), int(kc["count"].astype(np.uint64).sum()), int(o.total_bases_and_kmers()[1])
 
 
+def genome_numpy(length, seed):
+    """SURVEY 8d M4's genome G restated in numpy from the specification alone -- base i = "ACGT"[splitmix64(splitmix64(seed ^
+    "genome") + i) >> 62] -- so that configs[0]'s golden input does not come out of the product's generator"""
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def sm(x):
+        with np.errstate(over="ignore"):
+            x = (x + np.uint64(0x9E3779B97F4A7C15)) & M
+            x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & M
+            x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & M
+            return x ^ (x >> np.uint64(31))
+    base = sm(np.array([seed ^ 0x67656E6F6D65], dtype=np.uint64))[0]
+    with np.errstate(over="ignore"):
+        h = sm(base + np.arange(length, dtype=np.uint64))
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[(h >> np.uint64(62)).astype(np.int64)]
+
+
+def fasta_70(genome, name=b"G"):
+    """configs[0]'s input: the genome as ONE record of 70-column lines"""
+    n = len(genome)
+    full = n // 70 * 70
+    body = np.concatenate([genome[:full].reshape(-1, 70), np.full((full // 70, 1), 10, np.uint8)], axis=1).reshape(-1).tobytes()
+    tail = genome[full:].tobytes()
+    return b">" + name + b"\n" + body + (tail + b"\n" if tail else b"")
+
+
 def merge_numpy(parts, n):
     kc = np.concatenate([p[0] for p in parts])
     km = np.concatenate([p[1] for p in parts])
@@ -111,6 +137,20 @@ def main():
                 fx ^= a; cs += b; tk += c
             out["c5_files_0_255"] = {"sample_files": 256, "hash_xor": fx, "count_sum": cs, "total_kmers": tk, "k": 21, "n": 1000}
             print("c5_files_0_255:", json.dumps(out["c5_files_0_255"]), flush=True)
+            json.dump(out, open(args.out, "w"), indent=1, sort_keys=True)
+        if args.only is None or "c1_fasta_k21_n1000" in names:
+            # BASELINE configs[0]: genome G (5 Mb) as a 70-column FASTA file, library defaults (Mash 1000 / 1000, k = 21, seed 0,
+            # filters off for FASTA): the oracle's own FASTA reader and sketch_stream (lib.rs:51-94 restated)
+            from oracle import oracle as O
+            o = O.OracleSketcher(O.MASH, 1000, 21, 0)
+            text = fasta_70(genome_numpy(GL, SEED))
+            assert o.sketch_stream(text) == 1
+            kc, km = o.to_vec()
+            tb, tk = o.total_bases_and_kmers()
+            fp = fingerprint(kc, km, tk)
+            fp.update({"k": 21, "n": 1000, "genome": GL, "seq_length": int(tb), "file_bytes": len(text)})
+            out["c1_fasta_k21_n1000"] = fp
+            print("c1_fasta_k21_n1000:", json.dumps(fp), flush=True)
             json.dump(out, open(args.out, "w"), indent=1, sort_keys=True)
         if args.only is None or "c3_k31_filtered" in names:
             # BASELINE configs[2]: 10 Gbase, k = 31, kmers_to_sketch = 2 000 000 (CLI oversketch x200 of 10 000), then the reference's

@@ -314,3 +314,43 @@ def _c5_batch(n_files, scale, base):
             assert sk.filter_params.filter_on is False  # lib.rs:70-76: FASTA defaults to no filtering
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def test_c1_ecoli_sized_fasta_through_sketch_files(tmp_path, golden_dir):
+    """BASELINE.json configs[0] by name: genome G -- 5 Mb, here from the numpy restatement of the generator's
+    specification in tests/golden/make_config_fingerprints.py, not from the product's -- written as ONE record of 70-column
+    lines, through finch_sketch_files with the library defaults (Mash 1000 / 1000, k = 21, seed 0; FASTA: no filtering).
+    Bit-exact against the oracle's own sketch_stream on the same bytes, and against the committed golden fingerprint
+    c1_fasta_k21_n1000 -- through the host-packed small-file path and through the device-side FASTA splitter."""
+    import json
+    import sys
+    from finch_rs_amd import host as H
+    sys.path.insert(0, golden_dir)
+    import make_config_fingerprints as M
+    text = M.fasta_70(M.genome_numpy(M.GL, M.SEED))
+    path = str(tmp_path / "G.fa")
+    with open(path, "wb") as f:
+        f.write(text)
+    ora = O.OracleSketcher(O.MASH, 1000, 21, 0)
+    assert ora.sketch_stream(text) == 1
+    okc, okm = ora.to_vec()
+    golden = json.load(open(os.path.join(golden_dir, "config_fingerprints.json")))["c1_fasta_k21_n1000"]
+    for small_host in ("1", "0"):
+        os.environ["FINCH_SMALL_FASTA_HOST"] = small_host  # (read once per process: the second value only matters in a fresh one)
+        res = H.sketch_files([path], F.SketchParams.default(), H.FilterParams(None))
+        sk = res.sketch(0)
+        assert np.array_equal(sk.arrays[0], okc) and np.array_equal(sk.arrays[1], okm)
+        assert (sk.seq_length, sk.num_valid_kmers) == ora.total_bases_and_kmers() == (golden["seq_length"], golden["total_kmers"])
+        fp = M.fingerprint(sk.arrays[0], sk.arrays[1], sk.num_valid_kmers)
+        assert all(fp[key] == golden[key] for key in fp), (fp, golden)
+        assert sk.filter_params.filter_on is False
+    os.environ.pop("FINCH_SMALL_FASTA_HOST", None)
+    # the same file through the device-side splitter, whatever this process read from the environment first
+    import subprocess
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); import finch_rs_amd as F; from finch_rs_amd import host as H; "
+            "sk = H.sketch_files([%r], F.SketchParams.default(), H.FilterParams(None)).sketch(0); "
+            "print(json.dumps([int(np.bitwise_xor.reduce(sk.arrays[0]['hash'])), int(sk.seq_length), int(sk.num_valid_kmers)]))"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FINCH_SMALL_FASTA_HOST="0"), stdout=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == [golden["hash_xor"], golden["seq_length"], golden["total_kmers"]]

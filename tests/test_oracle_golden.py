@@ -133,3 +133,22 @@ def test_order_independence_and_merge_property():
             s2.process(reads[i])
         a, b = s1.to_vec(), s2.to_vec()
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_config0_fasta_fingerprint_is_what_the_oracle_gives(golden_dir):
+    """BASELINE configs[0]: the committed golden c1_fasta_k21_n1000 is the oracle's sketch_stream of genome G as 70-column FASTA
+    (the generator script re-run here: seconds on one core)"""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_config_fingerprints as M
+    text = M.fasta_70(M.genome_numpy(M.GL, M.SEED))
+    o = O.OracleSketcher(O.MASH, 1000, 21, 0)
+    assert o.sketch_stream(text) == 1
+    kc, km = o.to_vec()
+    tb, tk = o.total_bases_and_kmers()
+    golden = json.load(open(os.path.join(golden_dir, "config_fingerprints.json")))["c1_fasta_k21_n1000"]
+    fp = M.fingerprint(kc, km, tk)
+    assert all(fp[key] == golden[key] for key in fp) and tb == golden["seq_length"] and len(text) == golden["file_bytes"]
+    # the numpy restatement of the genome generator agrees with the product's (which the GPU tests use for the big configs)
+    from finch_rs_amd import sketch_schemes as S
+    assert np.array_equal(M.genome_numpy(200_000, M.SEED), S.synth_genome_host(200_000, M.SEED))
