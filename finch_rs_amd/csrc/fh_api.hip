@@ -634,7 +634,8 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
     static const bool no_static = getenv("FH_NO_STATIC_UNITS") != nullptr; // A/B knob
     {
         const uint64_t waves = std::max<uint64_t>(1, std::min<uint64_t>(r.n_units, s->max_waves));
-        const uint64_t grid = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
+        const uint64_t wpb = (uint64_t)k2_waves_per_block((int)s->p.k);
+        const uint64_t grid = (waves + wpb - 1) / wpb * wpb;
         const uint64_t fu = std::min<uint64_t>((r.n_units + waves - 1) / waves, MAX_UNITS);
         r.first_units = no_static ? 0u : (uint32_t)fu;
         r.grid_waves = (uint32_t)grid;

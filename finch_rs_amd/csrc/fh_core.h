@@ -501,6 +501,12 @@ struct LutTables {
     const Rec4 *A1, *A2; // 256 A records for k1 / k2 words
     const Rec2 *B1, *B2; // 256 B records for k1 / k2 words (full 4-base high group)
     const Rec2 *P;       // partial_entries(K) records for the key's last word
+    // A1 sixteen-fold replicated (murmur_lookup<K, 16>): entry q's replica r sits at byte (q << 8) + (r << 4), and a lane
+    // reads replica (lane & 15) -- a1_lane_off = (lane & 15) << 4.  The sixteen lanes of every lane group of a ds_read_b128
+    // ({0-3, 12-15, 20-27}, ...: MI355X_MICROARCH.md, LDS) differ in lane & 15, so they read sixteen different 16-byte slots
+    // of the 256-byte bank row whatever their indices: no bank conflicts (a random-index 16-byte lookup costs 9.6 LDS cycles
+    // per wave otherwise, 4 then).  64 KB instead of 4: affordable once one 1024-thread workgroup per CU shares the tables.
+    u32 a1_lane_off = 0;
 };
 
 // What the lookups of one position return, kept raw so that the kernel can issue the loads of the next position
@@ -523,6 +529,18 @@ FH_HD u32 byte_shl(u32 x, int b, int lg) {
     return r;
 #else
     return ((x >> (8 * b)) & 0xFFu) << lg;
+#endif
+}
+
+// ((byte `b` of x) << 8) | low: the offset of a sixteen-fold replicated 16-byte record, `low` = the lane's replica offset
+// (< 256) in byte 0 and, in byte 2, bits 16-23 of the table's address -- ONE instruction like byte_shl (v_perm_b32 picks the byte into bits 8-15 and the low byte from the second source)
+FH_HD u32 byte_shl8_or(u32 x, int b, u32 low) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_perm_b32 D, S0, S1, sel: bytes 0-3 of the pool are S1's, 4-7 S0's; selector byte 0x0C = constant 0
+    // (byte 2 of the result is byte 2 of `low`: the caller may park the table's 64 KB-aligned base there)
+    return __builtin_amdgcn_perm(x, low, 0x0C020000u | ((u32)(4 + b) << 8));
+#else
+    return (((x >> (8 * b)) & 0xFFu) << 8) | (low & 0x00FF00FFu);
 #endif
 }
 
@@ -549,8 +567,9 @@ FH_HD Rec4 load_rec4(const Rec4 *p) {
 #endif
 }
 
-template <int K>
+template <int K, int A1REP = 1>
 FH_HD void murmur_lookup(u64 cm, const LutTables &T, KeyWords<K> &w) { // cm = canonical word << pre_shift(K)
+    static_assert(A1REP == 1 || A1REP == 16, "A1 is plain or sixteen-fold replicated");
     constexpr int PRE = pre_shift(K);
     const u32 cml = (u32)cm, cmh = (u32)(cm >> 32);
 #if defined(__HIPCC__)
@@ -564,7 +583,14 @@ FH_HD void murmur_lookup(u64 cm, const LutTables &T, KeyWords<K> &w) { // cm = c
             w.a0[i] = r.x;
             w.a1[i] = r.y;
         } else if (g.kind == 2) {
-            const Rec4 ra = load_rec4((const Rec4 *)((const char *)(g.is_k2 ? T.A2 : T.A1) + field_off(cml, cmh, g.shiftA + PRE, 4, 4)));
+            u32 a_off;
+            if (A1REP == 16 && !g.is_k2) {
+                const int sh = g.shiftA + PRE; // (a full group of the pre-shifted word is a byte of a register)
+                a_off = byte_shl8_or(sh < 32 ? cml : cmh, (sh >> 3) & 3, T.a1_lane_off);
+            } else {
+                a_off = field_off(cml, cmh, g.shiftA + PRE, 4, 4);
+            }
+            const Rec4 ra = load_rec4((const Rec4 *)((const char *)(g.is_k2 ? T.A2 : T.A1) + a_off));
 #if defined(__HIP_DEVICE_COMPILE__)
             // A 16-byte LDS read costs 9.5 cycles per wave, the 12-byte read the compiler narrows this to costs 16
             // (tools/ubench_lds.hip), so the unused fourth dword is kept "live".  Measured: k = 14-16 +3 %, k = 21 +2.7 %,

@@ -55,10 +55,28 @@ constexpr int k2_min_waves(int K) { return K <= 21 ? FH_MINW_SMALL : FH_MINW_BIG
 #define FH_ROUND_FROM 23 // (k = 23, 24 as one pass of 32 spill 2-7 registers at the 128-VGPR limit; in two rounds they take 109)
 #endif
 constexpr int k2_round(int K) { return K >= FH_ROUND_FROM ? FH_ROUND_BIG : 32; }
-template <int K, bool MASKED, bool SEED0, bool HASLO>
-__global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchArgs a) {
-    // murmur3 lookup tables with the second stage folded in (fh_core.h): A / B records of two-group key words,
-    // P = the key's last (short) word; sized by what this K uses
+// K >= 25 live off the LDS pipe (8 random table lookups per position at k = 31: the CU's LDS array was busy 310 of the 325
+// cycles a wave-iteration took, two thirds of that bank conflicts -- profiles/r03b_k31_pmc_k2.json).  There ONE workgroup of
+// sixteen waves per CU shares the tables instead of four workgroups holding a set each, and the LDS that frees holds the k1
+// words' A table sixteen times over, laid out so that its 16-byte reads cannot conflict (fh_core.h, LutTables): two of
+// k = 31's four A lookups drop from 9.6 to 4 LDS cycles.
+#ifndef FH_SHARE_FROM
+#define FH_SHARE_FROM 25
+#endif
+constexpr int k2_wpb_of(int K) { return K >= FH_SHARE_FROM ? 16 : WAVES_PER_BLOCK; } // waves per workgroup (fh_kernels.h: k2_waves_per_block)
+constexpr int k2_a1_rep(int K) { return K >= FH_SHARE_FROM && has_pair_word(K, false) ? 16 : 1; }
+// where a workgroup's LDS lives: the lookup tables, and per wave the two-tile ring of classified bases and the admit queue
+struct K2Lds {
+    Rec4 *A1, *A2;
+    Rec2 *B1, *B2, *P;
+    u32 *codes, *good; // [WPB][256], [WPB][128]
+    AdmitQueueT<false> *queue_lo, *queue_hi; // waves [0, Q_SPLIT) and [Q_SPLIT, WPB)
+    const Rec4 *a1_lookup_base;              // what the hot loop adds its A1 offsets to (the hand-laid block's first byte)
+};
+constexpr int K2_Q_SPLIT = 11;
+// four workgroups of four waves per CU, a table set each: separate arrays, as the K <= 24 kernels were tuned with
+template <int K>
+__device__ __forceinline__ K2Lds k2_lds_plain() {
     __shared__ Rec4 sA1[has_pair_word(K, false) ? 256 : 1];
     __shared__ Rec4 sA2[has_pair_word(K, true) ? 256 : 1];
     __shared__ Rec2 sB1[has_pair_word(K, false) ? 256 : 1];
@@ -67,6 +85,37 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
     __shared__ __attribute__((aligned(16))) u32 sCodes[WAVES_PER_BLOCK][256];
     __shared__ __attribute__((aligned(16))) u32 sGood[WAVES_PER_BLOCK][128];
     __shared__ __attribute__((aligned(16))) AdmitQueueT<false> sQueue[WAVES_PER_BLOCK];
+    return K2Lds{sA1, sA2, sB1, sB2, sP, &sCodes[0][0], &sGood[0][0], sQueue, sQueue, sA1};
+}
+// One workgroup of sixteen waves per CU: ONE block of LDS laid out by hand.  Everything the hot loop reaches through an
+// instruction's 16-bit offset field -- the small tables -- sits in the first 64 KB; the replicated A1 table is the second
+// 64 KB exactly, so that its address (0x10000 | index byte << 8 | replica << 4) still comes out of the ONE v_perm_b32 that
+// forms the offset (fh_core.h, byte_shl8_or: the 0x01 of bits 16-23 rides in the lane constant); the admit queues of the
+// last five waves follow behind it.  (Left to the compiler's layout, tables beyond 64 KB cost an address add per lookup:
+// +5.6 VALU instructions per position at k = 31, which ate what the conflict-free reads gave.)
+constexpr u32 K2S_A2 = 0, K2S_B1 = 4096, K2S_B2 = 6144, K2S_P = 8192, K2S_CODES = 16384, K2S_GOOD = 32768, K2S_QLO = 40960,
+              K2S_A1 = 65536, K2S_QHI = 131072, K2S_BYTES = K2S_QHI + (16 - K2_Q_SPLIT) * (u32)sizeof(AdmitQueueT<false>);
+static_assert(K2S_QLO + K2_Q_SPLIT * sizeof(AdmitQueueT<false>) <= K2S_A1, "the low admit queues end below the replicated table");
+static_assert(K2S_BYTES <= 160 * 1024, "one workgroup's LDS");
+template <int K>
+__device__ __forceinline__ K2Lds k2_lds_shared() {
+    static_assert(partial_entries(K) * sizeof(Rec2) <= K2S_CODES - K2S_P, "the key's last-word table fits its slot");
+    __shared__ __attribute__((aligned(65536))) unsigned char blob[K2S_BYTES];
+    return K2Lds{(Rec4 *)(blob + K2S_A1), (Rec4 *)(blob + K2S_A2), (Rec2 *)(blob + K2S_B1), (Rec2 *)(blob + K2S_B2), (Rec2 *)(blob + K2S_P),
+                 (u32 *)(blob + K2S_CODES), (u32 *)(blob + K2S_GOOD), (AdmitQueueT<false> *)(blob + K2S_QLO),
+                 (AdmitQueueT<false> *)(blob + K2S_QHI) - K2_Q_SPLIT, (const Rec4 *)blob};
+}
+
+template <int K, bool MASKED, bool SEED0, bool HASLO>
+__global__ __launch_bounds__(64 * k2_wpb_of(K), k2_min_waves(K)) void k2_sketch(const SketchArgs a) {
+    constexpr int WPB = k2_wpb_of(K), NTHR = 64 * WPB, REP = k2_a1_rep(K);
+    // murmur3 lookup tables with the second stage folded in (fh_core.h): A / B records of two-group key words,
+    // P = the key's last (short) word; sized by what this K uses
+    K2Lds lds;
+    if constexpr (REP == 16) lds = k2_lds_shared<K>();
+    else lds = k2_lds_plain<K>();
+    Rec4 *const sA1 = lds.A1, *const sA2 = lds.A2;
+    Rec2 *const sB1 = lds.B1, *const sB2 = lds.B2, *const sP = lds.P;
 
     // the wave index is uniform, and saying so keeps everything derived from it (ring and queue addresses, shard) in
     // scalar registers instead of vector registers the hot loop would have to spill
@@ -77,16 +126,20 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
     if (a.gate && __hip_atomic_load(&a.ctl->spec_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
     {
         if (has_pair_word(K, false)) {
-            sA1[tid] = lut_rec_A((u32)tid, false);
-            sB1[tid] = lut_rec_B((u32)tid, 4, false);
+            // (replicated: entry q's copy r at record q * REP + r, i.e. byte (q << 8) + (r << 4) for REP = 16)
+            for (int i = tid; i < 256 * REP; i += NTHR) sA1[i] = lut_rec_A((u32)(i / REP), false);
+            for (int q = tid; q < 256; q += NTHR) sB1[q] = lut_rec_B((u32)q, 4, false);
         }
         if (has_pair_word(K, true)) {
-            sA2[tid] = lut_rec_A((u32)tid, true);
-            sB2[tid] = lut_rec_B((u32)tid, 4, true);
+            for (int q = tid; q < 256; q += NTHR) {
+                sA2[q] = lut_rec_A((u32)q, true);
+                sB2[q] = lut_rec_B((u32)q, 4, true);
+            }
         }
-        for (int q = tid; q < partial_entries(K); q += 256) sP[q] = lut_rec_P<K>((u32)q);
+        for (int q = tid; q < partial_entries(K); q += NTHR) sP[q] = lut_rec_P<K>((u32)q);
     }
-    const LutTables LT{sA1, sA2, sB1, sB2, sP};
+    // (REP == 16: the lane's replica offset with the table's 64 KB base in bits 16-23, fh_core.h byte_shl8_or)
+    const LutTables LT{lds.a1_lookup_base, sA2, sB1, sB2, sP, REP == 16 ? (((u32)lane & 15u) << 4) | K2S_A1 : 0u};
     __syncthreads();
 
     // (a loaded value lands in vector registers; the threshold is needed on the admit path only, and a 64-bit vector
@@ -103,9 +156,9 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
     // readfirstlane keeps the bound an opaque scalar (otherwise the select inside is re-expanded per position)
     u32 tau_hi1 = (u32)__builtin_amdgcn_readfirstlane((int)tau_hi_bound(tau));
 
-    const u32 gw = blockIdx.x * WAVES_PER_BLOCK + (u32)wave;
-    u32 *codes_ring = sCodes[wave];
-    u32 *good_ring = sGood[wave];
+    const u32 gw = blockIdx.x * (u32)WPB + (u32)wave;
+    u32 *codes_ring = lds.codes + 256 * wave;
+    u32 *good_ring = lds.good + 128 * wave;
     u32 nvalid = 0; // per lane
 
     // Persistent wave: pull ranges of tiles until the queue is dry, the live set reaches its soft limit
@@ -126,7 +179,7 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
     u32 want_refresh = 0; // flush_queue asked for a refresh of the threshold (wave-uniform)
     u32 wave_inserts = 0; // new hashes this wave inserted in this launch (wave-uniform)
     u32 qn = 0;           // occupancy of the admit queue (wave-uniform)
-    AdmitQueueT<false> *queue = &sQueue[wave];
+    AdmitQueueT<false> *queue = (wave < K2_Q_SPLIT ? lds.queue_lo : lds.queue_hi) + wave;
     if (lane == 0) { // what the drain needs to finish the admit test
         queue->tau = tau;
         queue->tau_lo = HASLO ? a.tau_lo : 0ull;
@@ -153,7 +206,7 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
                     const u32 e = (c + a.first_units) * a.unit_tiles;
                     rt1 = e < a.tiles_total ? e : a.tiles_total;
                 }
-                last_unit = gridDim.x * (u32)WAVES_PER_BLOCK * a.first_units; // where the queue begins: what is left is behind it
+                last_unit = gridDim.x * (u32)WPB * a.first_units; // where the queue begins: what is left is behind it
             } else if (a.static_only) {
                 // (every unit of the range was somebody's first: nothing to ask the queue for -- 1953 waves finding that out
                 // with an atomic each on its one address kept the last of them waiting 20 us)
@@ -217,7 +270,7 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
         bool rc_cur;
         KeyWords<K> kw_cur;
         window(0, cm_cur, rc_cur);
-        murmur_lookup<K>(cm_cur, LT, kw_cur);
+        murmur_lookup<K, REP>(cm_cur, LT, kw_cur);
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             u64 cm_nxt = 0;
@@ -225,7 +278,7 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
             KeyWords<K> kw_nxt;
             if (j + 1 < R) {
                 window(j + 1, cm_nxt, rc_nxt);
-                murmur_lookup<K>(cm_nxt, LT, kw_nxt);
+                murmur_lookup<K, REP>(cm_nxt, LT, kw_nxt);
             }
             const u64 cm = cm_cur;
             const bool is_rc = rc_cur;
@@ -321,17 +374,19 @@ __global__ __launch_bounds__(256, k2_min_waves(K)) void k2_sketch(const SketchAr
 }
 
 template <int K>
-static hipError_t launch_k2_t(const SketchArgs &a, int blocks, hipStream_t st) {
+static hipError_t launch_k2_t(const SketchArgs &a, int, hipStream_t st) {
+    constexpr int WPB = k2_wpb_of(K);
+    const dim3 grid((a.n_waves + WPB - 1) / WPB), block(64 * WPB); // (the waves the host asked for, in workgroups of this K's size)
     const bool lo = a.tau_lo != 0ull;
     if (a.hash_mask != ~0ull) {
-        if (lo) hipLaunchKernelGGL((k2_sketch<K, true, false, true>), dim3(blocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k2_sketch<K, true, false, false>), dim3(blocks), dim3(256), 0, st, a);
+        if (lo) hipLaunchKernelGGL((k2_sketch<K, true, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k2_sketch<K, true, false, false>), grid, block, 0, st, a);
     } else if (a.seed == 0) {
-        if (lo) hipLaunchKernelGGL((k2_sketch<K, false, true, true>), dim3(blocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k2_sketch<K, false, true, false>), dim3(blocks), dim3(256), 0, st, a);
+        if (lo) hipLaunchKernelGGL((k2_sketch<K, false, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k2_sketch<K, false, true, false>), grid, block, 0, st, a);
     } else {
-        if (lo) hipLaunchKernelGGL((k2_sketch<K, false, false, true>), dim3(blocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((k2_sketch<K, false, false, false>), dim3(blocks), dim3(256), 0, st, a);
+        if (lo) hipLaunchKernelGGL((k2_sketch<K, false, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k2_sketch<K, false, false, false>), grid, block, 0, st, a);
     }
     return hipGetLastError();
 }

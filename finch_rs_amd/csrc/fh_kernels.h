@@ -8,7 +8,14 @@
 
 namespace fh {
 
+// (`blocks` is not used any more: every kernel launches ceil(a.n_waves / k2_waves_per_block(k)) workgroups)
 hipError_t launch_k2(int k, const SketchArgs &a, int blocks, hipStream_t st);
+// waves per workgroup of the sketch kernel for k-mer length k: 16 where one workgroup per CU shares the lookup tables
+// (fh_k2.hip: K = 25..32), 4 otherwise.  The host needs it to know how many waves a launch really has.
+#ifndef FH_SHARE_FROM
+#define FH_SHARE_FROM 25
+#endif
+constexpr int k2_waves_per_block(int k) { return (k >= FH_SHARE_FROM && k <= 32) ? 16 : WAVES_PER_BLOCK; }
 hipError_t launch_k2_part0(int k, const SketchArgs &a, int blocks, hipStream_t st);
 hipError_t launch_k2_part1(int k, const SketchArgs &a, int blocks, hipStream_t st);
 hipError_t launch_k2_part2(int k, const SketchArgs &a, int blocks, hipStream_t st);
