@@ -12,6 +12,7 @@ timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${T}_bench_defa
 timeout 600 python bench.py --gpus 8 --share-gpu --steps 5 --warmup 1 --no-extras --no-cpu-baseline > $O/${T}_bench_gpus8_share.json 2> $O/${T}_bench_gpus8_share.err; echo "bench8 rc=$?"
 bash tools/gpu_bench_full.sh ${T}_c4 c4_k21_n1000 > $O/${T}_c4_full.log 2>&1; tail -3 $O/${T}_c4_full.log
 bash tools/gpu_bench_full.sh ${T}_k31 c2_k31_n1000 --workload c2 --k 31 > $O/${T}_k31_full.log 2>&1; tail -3 $O/${T}_k31_full.log
+timeout 900 python bench.py --workload c5 --steps 2 --warmup 1 > $O/${T}_bench_c5.json 2> $O/${T}_bench_c5.err; echo "c5 rc=$?"; tail -c 600 $O/${T}_bench_c5.json
 rm -rf $O/${T}_*_stats $O/${T}_*_pmc_fetch $O/${T}_*_pmc_write $O/${T}_*_pmc_sq
 python - <<PY
 import json
