@@ -2381,10 +2381,8 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     if (device_parse && first == '>') {
         st.format = 1;
         // FINCH_SMALL_FASTA_HOST: unset / 1 = a small plain file is packed while it is staged (fasta_small_on_host), 0 = never
-        static const bool small_host = [] {
-            const char *e = getenv("FINCH_SMALL_FASTA_HOST");
-            return !(e && e[0] == '0');
-        }();
+        const char *sh_env = getenv("FINCH_SMALL_FASTA_HOST");
+        const bool small_host = !(sh_env && sh_env[0] == '0');
         int rc = (small_host && !dp_on && !is_gz) ? fasta_small_on_host(*src, h, st) : FH_ERR_STATE;
         if (rc == FH_ERR_STATE) { // does not apply: split on the device
             st = FastxStats{};

@@ -336,7 +336,7 @@ def test_c1_ecoli_sized_fasta_through_sketch_files(tmp_path, golden_dir):
     okc, okm = ora.to_vec()
     golden = json.load(open(os.path.join(golden_dir, "config_fingerprints.json")))["c1_fasta_k21_n1000"]
     for small_host in ("1", "0"):
-        os.environ["FINCH_SMALL_FASTA_HOST"] = small_host  # (read once per process: the second value only matters in a fresh one)
+        os.environ["FINCH_SMALL_FASTA_HOST"] = small_host
         res = H.sketch_files([path], F.SketchParams.default(), H.FilterParams(None))
         sk = res.sketch(0)
         assert np.array_equal(sk.arrays[0], okc) and np.array_equal(sk.arrays[1], okm)

@@ -62,7 +62,15 @@ for case in range(n_cases):
     os.environ["FINCH_DEVICE_PARSE"] = "0"
     ref = result(lambda: H.sketch_stream(data, "x", p, f))
     os.environ.pop("FINCH_DEVICE_PARSE")
-    routes = {"device split": lambda: H.sketch_stream(data, "x", p, f)}
+    routes = {"device split": lambda: H.sketch_stream(data, "x", p, f)}  # (a small FASTA text: packed on the host while staged)
+
+    def forced_splitter():
+        os.environ["FINCH_SMALL_FASTA_HOST"] = "0"
+        try:
+            return H.sketch_stream(data, "x", p, f)
+        finally:
+            os.environ.pop("FINCH_SMALL_FASTA_HOST")
+    routes["device splitter, small-file packing off"] = forced_splitter
     routes["sharded x3"] = lambda: H.sketch_stream_sharded(data, "x", p, f, [0, 0, 0], int(rng.integers(20000, 200000)))
     for name, fn in routes.items():
         r = result(fn)
@@ -90,4 +98,4 @@ for case in range(n_cases):
         assert (ref[3], ref[4]) == o.total_bases_and_kmers(), (case, "oracle totals")
         n_oracle += 1
     n_err += ref[0] == "err"
-print("fuzz_params: %d parameter sets x 6 routes agree (%d of them refusals), %d also equal to the oracle's sketch" % (n_cases, n_err, n_oracle))
+print("fuzz_params: %d parameter sets x 7 routes agree (%d of them refusals), %d also equal to the oracle's sketch" % (n_cases, n_err, n_oracle))
