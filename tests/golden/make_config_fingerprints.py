@@ -78,6 +78,61 @@ def genome_numpy(length, seed):
     return np.frombuffer(b"ACGT", dtype=np.uint8)[(h >> np.uint64(62)).astype(np.int64)]
 
 
+def _sm64(x):
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def _mulhi64(a, b):
+    """high 64 bits of a * b (b a Python int < 2^32 or a uint64 array), by 32-bit halves"""
+    a = a.astype(np.uint64)
+    b = np.uint64(b) if np.isscalar(b) else b.astype(np.uint64)
+    m = np.uint64(0xFFFFFFFF)
+    s32 = np.uint64(32)
+    with np.errstate(over="ignore"):
+        al, ah, bl, bh = a & m, a >> s32, b & m, b >> s32
+        t = al * bl
+        u = ah * bl + (t >> s32)
+        v = al * bh + (u & m)
+        return ah * bh + (u >> s32) + (v >> s32)
+
+
+def reads_numpy(genome, first_read, n_reads, read_len, seed, sub_ppm, n_ppm):
+    """SURVEY 8d M4's read generator restated in numpy from its specification (the counter-based rules of fh_core.h's
+    synth_read_byte, written down independently): read r starts at mulhi(splitmix(h0), |G| - L + 1) with h0 =
+    splitmix(splitmix(seed ^ "reads") + r), strand = top bit of h0, per base j a substitution (to one of the three other
+    bases) with probability sub_ppm and an 'N' with probability n_ppm from hj = splitmix(h0 + c (j + 1)); one 0 byte behind
+    each read.  The goldens of configs[1..3] were generated through the product's host generator; tests/test_oracle_golden.py
+    holds the two generators against each other."""
+    g = np.asarray(genome, dtype=np.uint8)
+    L = read_len
+    with np.errstate(over="ignore"):
+        base = _sm64(np.array([seed ^ 0x7265616473], dtype=np.uint64))[0]
+        h0 = _sm64(base + (np.uint64(first_read) + np.arange(n_reads, dtype=np.uint64)))
+        start = _mulhi64(_sm64(h0), len(g) - L + 1).astype(np.int64)
+        rev = (h0 >> np.uint64(63)) != 0
+        j = np.arange(L, dtype=np.int64)
+        idx = np.where(rev[:, None], start[:, None] + (L - 1 - j)[None, :], start[:, None] + j[None, :])
+        b = g[idx]
+        comp = np.arange(256, dtype=np.uint8)
+        comp[ord("A")], comp[ord("C")], comp[ord("G")], comp[ord("T")] = ord("T"), ord("G"), ord("C"), ord("A")
+        b = np.where(rev[:, None], comp[b], b)
+        hj = _sm64(h0[:, None] + np.uint64(0x632BE59BD9B4E019) * (j[None, :] + 1).astype(np.uint64))
+        u_sub = _mulhi64(hj.reshape(-1), 1000000).reshape(hj.shape)
+        u_n = _mulhi64(_sm64(hj).reshape(-1), 1000000).reshape(hj.shape)
+        code = np.select([b == ord("A"), b == ord("C"), b == ord("G")], [0, 1, 2], 3).astype(np.uint64)
+        add = np.uint64(1) + ((((hj >> np.uint64(20)) & np.uint64(0xFFFFF)) * np.uint64(3)) >> np.uint64(20))
+        sub = np.frombuffer(b"ACGT", dtype=np.uint8)[((code + add) & np.uint64(3)).astype(np.int64)]
+    b = np.where(u_sub < sub_ppm, sub, b)
+    b = np.where(u_n < n_ppm, np.uint8(ord("N")), b)
+    out = np.zeros((n_reads, L + 1), dtype=np.uint8)
+    out[:, :L] = b
+    return out.reshape(-1)
+
+
 def fasta_70(genome, name=b"G"):
     """configs[0]'s input: the genome as ONE record of 70-column lines"""
     n = len(genome)

@@ -152,3 +152,19 @@ def test_config0_fasta_fingerprint_is_what_the_oracle_gives(golden_dir):
     # the numpy restatement of the genome generator agrees with the product's (which the GPU tests use for the big configs)
     from finch_rs_amd import sketch_schemes as S
     assert np.array_equal(M.genome_numpy(200_000, M.SEED), S.synth_genome_host(200_000, M.SEED))
+
+
+def test_read_generator_restated_in_numpy_equals_the_products(golden_dir):
+    """the golden fingerprints of configs[1..3] come from reads made by the product's host generator; here that generator is
+    held against a numpy restatement of SURVEY 8d M4's rules written for the golden script (tests/golden/make_config_fingerprints.py)
+    -- read blocks from the start, the middle and the end of configs[3]'s 333 M reads, and other lengths / rates"""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_config_fingerprints as M
+    from finch_rs_amd import sketch_schemes as S
+    g = M.genome_numpy(M.GL, M.SEED)
+    for first, n, rl, sub, nn in ((0, 3000, 150, 10_000, 500), (166_000_000, 2000, 150, 10_000, 500), (333_333_000, 334, 150, 10_000, 500),
+                                  (12345, 500, 61, 300_000, 20_000), (7, 200, 250, 0, 0)):
+        a = M.reads_numpy(g, first, n, rl, M.SEED, sub, nn)
+        b = S.synth_reads_host(g, first, n, rl, M.SEED, sub, nn)
+        assert np.array_equal(a, b), (first, n, rl)
