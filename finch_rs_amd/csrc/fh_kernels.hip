@@ -326,7 +326,12 @@ __device__ u32 prune_small_dev(Entry *table, u32 *live, u32 *dead, u32 dead_cap,
     }
     if (tid == 0) {
         ctl->n_live = keep;
-        ctl->tau = tau;
+        // The selection only ever LOWERS the threshold.  With fewer than `size` entries it has nothing to say ("no threshold"),
+        // and must not undo one the host put there: a speculative range that stopped early with few hashes is relaunched for its
+        // remaining tiles, and were the threshold lifted in between, those tiles would admit what the first ones turned away
+        // -- a sketch that misses hashes (tools/fuzz_case_debug.py 41414 247: four waves, 27 000 distinct k-mers).
+        const u64 cur = ctl->tau;
+        ctl->tau = tau < cur ? tau : cur;
         ctl->sorted = sort_out ? 1u : 0u;
         ctl->n_dead = dead_fits ? nd0 + ndrop : 0xFFFFFFFFu; // (overflow marker: fh_reset sweeps the whole table)
     }

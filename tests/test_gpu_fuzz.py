@@ -39,7 +39,19 @@ SEED0 = int(os.environ.get("FH_FUZZ_SEED", "9000"))
 
 @pytest.mark.parametrize("case", range(N_CASES))
 def test_random_configuration(case):
-    rng = np.random.default_rng(SEED0 + case)
+    _configuration(SEED0, case)
+
+
+# cases of earlier campaigns that found something (seed, case): kept as regression tests
+#   (41414, 247)  round 4: four waves, 27 000 distinct 48-mers, n = 2999 -- a speculative range that stopped early with fewer
+#                 than n hashes was relaunched with the threshold lifted by the selection in between (hashes missing)
+@pytest.mark.parametrize("seed0,case", [(41414, 247)])
+def test_cases_that_once_failed(seed0, case):
+    _configuration(seed0, case)
+
+
+def _configuration(seed0, case):
+    rng = np.random.default_rng(seed0 + case)
     k = int(rng.choice([1, 2, 3, 5, 8, 11, 15, 16, 17, 21, 21, 21, 24, 27, 31, 31, 32, 33, 40, 48, 55, 63, 64]))
     kind = "mash" if rng.random() < 0.6 else "scaled"
     size = int(rng.choice([0, 1, 7, 100, 1000, 1000, 2999, 3001, 12000]))
