@@ -483,7 +483,9 @@ int launch_pending(fh_sketcher *s) {
     a.left_in = s->left_buf[r.left_cur];
     a.left_out = s->left_buf[r.left_cur ^ 1];
     const uint64_t work_units = (uint64_t)r.n_units + r.n_left_in;
-    const uint64_t waves = std::max<uint64_t>(1, std::min<uint64_t>(work_units, s->max_waves));
+    const uint64_t wpb = (uint64_t)k2_waves_per_block((int)s->p.k);
+    // (whole workgroups run: that many waves pull, insert and may leave a leftover entry; max_waves is a multiple of wpb)
+    const uint64_t waves = (std::max<uint64_t>(1, std::min<uint64_t>(work_units, s->max_waves)) + wpb - 1) / wpb * wpb;
     a.n_waves = (uint32_t)waves;
     // per-wave insert budget: the table and the shard lists are sized for max_waves waves inserting
     // WAVE_BUDGET + TILE_POS new hashes each, so a launch with fewer waves may let each of them insert
@@ -798,7 +800,8 @@ int sampled_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
         a.n_left_in = (uint32_t)n_runs;
         a.left_in = s->smp_list;
         a.left_out = s->left_buf[0];
-        const uint64_t waves = std::max<uint64_t>(1, std::min<uint64_t>(n_runs, s->max_waves));
+        const uint64_t wpb = (uint64_t)k2_waves_per_block((int)s->p.k);
+        const uint64_t waves = (std::max<uint64_t>(1, std::min<uint64_t>(n_runs, s->max_waves)) + wpb - 1) / wpb * wpb;
         a.n_waves = (uint32_t)waves;
         a.wave_budget = WAVE_BUDGET;
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1422,6 +1425,11 @@ static fh_sketcher *new_handle(const fh_params *params, int device) {
             return e ? (uint64_t)atoi(e) : 16ull; // what is resident at 4 waves per SIMD; 32 measured 1.4 % slower
         }();
         s->max_waves = std::max<uint64_t>(1, std::min<uint64_t>(256ull * waves_per_cu, s->max_launch / TILE_POS));
+        // whole workgroups: a launch is rounded up to them (16 waves for K = 25..32, fh_k2.hip), and everything sized by
+        // max_waves -- table, shard lists, the leftover lists a stopped launch writes one entry per wave into -- has to hold
+        // what really runs
+        const uint64_t wpb = (uint64_t)k2_waves_per_block((int)params->k);
+        s->max_waves = std::max<uint64_t>(wpb, s->max_waves / wpb * wpb);
         const char *mr = getenv("FH_MAX_RANGE"); // test knob: force many ranges per push
         s->max_range = mr ? strtoull(mr, nullptr, 10) : 0;
     }
