@@ -743,10 +743,12 @@ def measure_extras(F, S, dr, dg, n_reads, dev):
             # pin its buffers anew, which is not what a process that reads compressed files does)
             H._lib.load().fh_release_cached()
             out = {"what": "finch_sketch_files on one %.0f MB FASTQ (%d reads) compressed with zlib level 1: as a single gzip stream "
-                           "(decoded by the call's read threads together, fh_pargz.h) and as BGZF (members inflated on the device, one wavefront "
+                           "(cut into chunks and inflated on the device, a wavefront per chunk; gzip_host_inflate: decoded by the call's read threads "
+                           "together, fh_pargz.h) and as BGZF (members inflated on the device, one wavefront "
                            "each; bgzf_host_inflate: by the read threads instead); k=21 n=1000"
                            % (len(raw) / 1e6, ns)}
-            for key, path, env in (("gzip", gzp, None), ("bgzf", bgp, None), ("bgzf_host_inflate", bgp, "0")):
+            gz_before = H.debug_device_gzip()
+            for key, path, env in (("gzip", gzp, None), ("gzip_host_inflate", gzp, "0"), ("bgzf", bgp, None), ("bgzf_host_inflate", bgp, "0")):
                 if env is not None:
                     os.environ["FINCH_DEVICE_INFLATE"] = env
                 try:
@@ -761,6 +763,8 @@ def measure_extras(F, S, dr, dg, n_reads, dev):
                 out[key + "_gbases_per_s"] = round(ns * READ_LEN / best / 1e9, 3)
                 out[key + "_text_GBps"] = round(len(raw) / best / 1e9, 3)
             out["bgzf_inflated_on_device"] = H.debug_device_inflate()[0] > 0
+            gz_after = H.debug_device_gzip()
+            out["gzip_inflated_on_device"] = gz_after[0] - gz_before[0] >= 3 and gz_after[1] == gz_before[1]
             return out
         finally:
             shutil.rmtree(d, ignore_errors=True)

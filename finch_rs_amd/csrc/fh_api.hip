@@ -231,6 +231,19 @@ struct fh_sketcher {
     int bz_next = 0;
     const uint8_t *bgzf_left_ptr = nullptr; // text behind the last whole record of the previous batch (in the other bz_text)
     uint64_t bgzf_left_len = 0;
+    // fh_push_gzip_fastq (plain gzip: one DEFLATE stream cut into chunks, fh_bgzf.hip): symbol buffers and the pass over the
+    // chain of chunks; the text, packed bytes and scan scratch are the BGZF path's
+    uint16_t *gz_sym = nullptr;
+    uint64_t gz_sym_elems = 0;
+    GzChunk *gz_recs = nullptr;
+    uint8_t *gz_win_in = nullptr, *gz_window = nullptr;
+    uint32_t *gz_live = nullptr, *gz_tile_map = nullptr, *gz_crc_tmp = nullptr, *gz_summary = nullptr, *h_gz_summary = nullptr;
+    uint32_t gz_chunks_cap = 0, gz_slots = 0;
+    uint64_t gz_base = 0;     // where a push's bytes land in d_comp: what the previous push left undecoded sits in front of them
+    uint64_t gz_tail_len = 0; // ... that many bytes, decoding resumes at bit gz_bit of the first
+    uint32_t gz_bit = 0, gz_valid = 0, gz_crc = 0;
+    uint64_t gz_total = 0;
+    bool gz_open = false;
     uint8_t *d_packed[N_STAGE] = {nullptr, nullptr};
     uint32_t *d_blk_a[N_STAGE] = {nullptr, nullptr}, *d_blk_b[N_STAGE] = {nullptr, nullptr};
     uint32_t *d_lines = nullptr; // fh_push_fastq_text: where every text line of the chunk ends (one u32 per line)
@@ -328,6 +341,7 @@ int init_state(fh_sketcher *s, bool device_part = true) {
     s->carry_len = 0;
     s->dprev_len = 0;
     s->bgzf_left_len = 0;
+    s->gz_open = false;
     bgzf_quiesce(s);
     for (int i = 0; i < N_STAGE; ++i) // a copy fh_text_prefetch started for a stream that was then abandoned
         if (s->stage_prefetched[i]) {
@@ -1299,6 +1313,7 @@ uint64_t handle_bytes(const fh_sketcher *s) {
     uint64_t b = (uint64_t)s->cap * (sizeof(Entry) + (s->kmer_hi ? 8 : 0)) + (uint64_t)s->live_cap * 8 + (uint64_t)s->shard_cap * N_SHARDS * 4;
     for (int i = 0; i < N_STAGE; ++i) b += 2 * s->stage_cap[i];
     if (s->bz_text_cap) b += s->bz_comp_cap + 4 * s->bz_text_cap + s->bz_text_cap / 2;
+    b += 2 * s->gz_sym_elems + (uint64_t)s->gz_chunks_cap * (GZ_WINDOW + 48);
     return b + (uint64_t)s->out_cap * 32 + (uint64_t)s->big_cap * 24;
 }
 bool same_params(const fh_params &a, const fh_params &b) {
@@ -1518,6 +1533,15 @@ void destroy_handle(fh_sketcher *s) {
     (void)hipFree(s->d_bz_members);
     (void)hipFree(s->d_bz_status);
     (void)hipFree(s->bz_lines);
+    (void)hipFree(s->gz_sym);
+    (void)hipFree(s->gz_recs);
+    (void)hipFree(s->gz_win_in);
+    (void)hipFree(s->gz_window);
+    (void)hipFree(s->gz_live);
+    (void)hipFree(s->gz_tile_map);
+    (void)hipFree(s->gz_crc_tmp);
+    (void)hipFree(s->gz_summary);
+    if (s->h_gz_summary) (void)hipHostFree(s->h_gz_summary);
     for (int i = 0; i < 2; ++i) {
         (void)hipFree(s->bz_text[i]);
         (void)hipFree(s->bz_packed[i]);
@@ -2077,6 +2101,180 @@ int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint3
     const uint64_t cut = s->h_bz_status[1];
     s->bgzf_left_ptr = s->bz_text[t] + cut;
     s->bgzf_left_len = total - cut;
+    if (cut == 0) return FH_OK; // one record longer than the text so far: keep collecting (it moves on to the other buffer)
+    return fastq_text_on_device(s, s->bz_text[t], cut, s->bz_packed[t], s->bz_blk_a[t], s->bz_blk_b[t], s->bz_lines, s->bz_line_cap);
+}
+
+// Plain gzip of FASTQ text -- one DEFLATE stream, no index -- inflated on the device (fh_bgzf.hip: k_gz_find / k_gz_inflate /
+// k_gz_chain / k_gz_text).  A push is one batch: its bytes are cut into at most one chunk per resident wavefront, every
+// chunk is decoded from the first block start found in it, and the chain of chunks that really follow each other gives the
+// text; the bytes behind the last block boundary reached stay on the device and lead the next push, as do the 32 KiB of text a
+// match may reach back into and the partial FASTQ record the text ended with.
+constexpr uint64_t GZ_MIN_CHUNK = 32768;   // compressed bytes per chunk, at least (a level-6 block of reads is about that)
+constexpr uint64_t GZ_SYM_PER_BYTE = 24;   // symbol slots per compressed byte: text 12 x its DEFLATE bytes, chunks of uneven yield
+static int ensure_gzip_buffers(fh_sketcher *s, uint64_t n_bytes, uint32_t n_chunks) {
+    if (int rc = ensure_bgzf_buffers(s)) return rc;
+    if (!s->gz_summary) {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
+        s->gz_slots = (uint32_t)std::max(1, cus) * 5u; // (k_gz_inflate: five wavefronts per SIMD's worth of LDS)
+        s->gz_base = std::min<uint64_t>((uint64_t)16 << 20, s->bz_text_cap / 4) & ~(uint64_t)255;
+        HIP_TRY(dev_malloc((void **)&s->gz_window, GZ_WINDOW));
+        HIP_TRY(dev_malloc((void **)&s->gz_tile_map, (size_t)(s->bz_text_cap / 4096 + 2) * sizeof(uint32_t)));
+        HIP_TRY(dev_malloc((void **)&s->gz_crc_tmp, (size_t)(s->bz_text_cap / 65536 + 2) * sizeof(uint32_t)));
+        HIP_TRY(host_malloc((void **)&s->h_gz_summary, GZS_WORDS * sizeof(uint32_t)));
+        HIP_TRY(dev_malloc((void **)&s->gz_summary, GZS_WORDS * sizeof(uint32_t)));
+    }
+    if (n_chunks > s->gz_chunks_cap) {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        (void)hipFree(s->gz_recs);
+        (void)hipFree(s->gz_win_in);
+        (void)hipFree(s->gz_live);
+        s->gz_recs = nullptr, s->gz_win_in = nullptr, s->gz_live = nullptr;
+        const uint32_t want = std::min<uint32_t>(std::max<uint32_t>(n_chunks, 2 * s->gz_chunks_cap), std::max(n_chunks, s->gz_slots));
+        s->gz_chunks_cap = 0;
+        HIP_TRY(dev_malloc((void **)&s->gz_recs, (size_t)want * sizeof(GzChunk)));
+        HIP_TRY(dev_malloc((void **)&s->gz_win_in, (size_t)want * GZ_WINDOW));
+        HIP_TRY(dev_malloc((void **)&s->gz_live, (size_t)want * 4 * sizeof(uint32_t)));
+        s->gz_chunks_cap = want;
+    }
+    const uint64_t want_sym = GZ_SYM_PER_BYTE * n_bytes + (uint64_t)n_chunks * (GZ_WINDOW + 65536) + 64;
+    if (want_sym > s->gz_sym_elems) {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        (void)hipFree(s->gz_sym);
+        s->gz_sym = nullptr;
+        const uint64_t grown = std::max(want_sym, std::min<uint64_t>(2 * s->gz_sym_elems, GZ_SYM_PER_BYTE * (s->stage_bytes + s->gz_base)));
+        s->gz_sym_elems = 0;
+        HIP_TRY(dev_malloc((void **)&s->gz_sym, grown * sizeof(uint16_t)));
+        s->gz_sym_elems = grown;
+    }
+    return FH_OK;
+}
+
+int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t *member_done, uint64_t *trailing) {
+    if (!s || !member_done || !trailing) return fail(FH_ERR_INVALID, "null argument");
+    *member_done = 0;
+    *trailing = 0;
+    if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    if (s->proc_buf) return fail(FH_ERR_STATE, "records of fh_process are waiting in the staging buffer: fh_sync first");
+    if (bytes > s->stage_bytes) return fail(FH_ERR_INVALID, "batch longer than the staging buffer");
+    if (int rc = set_device(s)) return rc;
+    if (int rc = ensure_stage(s)) return rc;
+    if (int rc = ensure_bgzf_buffers(s)) return rc;
+    if (flags & FH_GZ_FIRST) {
+        s->gz_tail_len = 0;
+        s->gz_bit = s->gz_valid = s->gz_crc = 0;
+        s->gz_total = 0;
+        s->gz_open = true;
+        s->bgzf_left_len = 0;
+    } else if (!s->gz_open) {
+        return fail(FH_ERR_STATE, "no gzip member is open: the first push of one carries FH_GZ_FIRST");
+    }
+    const uint64_t n_bytes = s->gz_tail_len + bytes;
+    if (n_bytes == 0) {
+        if (flags & FH_GZ_LAST) return fail(FH_ERR_INVALID, "gzip: the stream ends before its final block");
+        return FH_OK;
+    }
+    // one chunk per wavefront the device holds at once, none smaller than a typical block
+    uint64_t chunk_bytes = 0;
+    uint32_t n_chunks = 0;
+    {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
+        const uint64_t slots = (uint64_t)std::max(1, cus) * 5u;
+        chunk_bytes = std::max<uint64_t>(GZ_MIN_CHUNK, ((n_bytes + slots - 1) / slots + 4095) & ~(uint64_t)4095);
+        if (const char *e = getenv("FH_GZ_CHUNK")) chunk_bytes = std::max<uint64_t>(1024, strtoull(e, nullptr, 10)); // (tests: many chunks in a small input)
+        n_chunks = (uint32_t)((n_bytes + chunk_bytes - 1) / chunk_bytes);
+    }
+    if (int rc = ensure_gzip_buffers(s, n_bytes, n_chunks)) return rc;
+    if (s->gz_tail_len > s->gz_base) return fail(FH_ERR_INVALID, "gzip: more undecoded bytes carried over than there is room for");
+    const int b = s->stage_next, t = s->bz_next;
+    if (int rc = drain(s)) return rc; // the packed buffer of this slot may still feed a pending range
+    // (the carried bytes begin at a multiple of four, where fh_bgzf.hip's bit reader wants its words; the new ones follow them)
+    uint8_t *const comp = s->d_comp + s->gz_base - ((s->gz_tail_len + 3) & ~(uint64_t)3);
+    if (bytes) {
+        HIP_TRY(hipMemcpyAsync(comp + s->gz_tail_len, s->h_stage[b] + STAGE_HEADROOM, bytes, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+        s->stage_busy[b] = true;
+        s->stage_next = (b + 1) % N_STAGE;
+    }
+    HIP_TRY(hipMemsetAsync(comp + n_bytes, 0, 256, s->stream));
+    const uint64_t left = s->bgzf_left_len;
+    s->bgzf_left_len = 0;
+    if (left) HIP_TRY(hipMemcpyAsync(s->bz_text[t], s->bgzf_left_ptr, left, hipMemcpyDeviceToDevice, s->stream));
+    GzBatch B{};
+    B.comp = comp;
+    B.n_bytes = n_bytes;
+    B.first_bit = s->gz_bit;
+    B.chunk_bits = chunk_bytes * 8u;
+    B.n_chunks = n_chunks;
+    B.cap = (s->gz_sym_elems / n_chunks) & ~(uint64_t)7;
+    if (B.cap > 0x7FFFFFFFull) B.cap = 0x7FFFFFF8ull;
+    B.recs = s->gz_recs;
+    B.sym = s->gz_sym;
+    B.win_in = s->gz_win_in;
+    B.window = s->gz_window;
+    B.valid = s->gz_valid;
+    B.live = s->gz_live;
+    B.tile_map = s->gz_tile_map;
+    B.crc_tmp = s->gz_crc_tmp;
+    B.text = s->bz_text[t];
+    B.left = (uint32_t)left;
+    B.text_cap = std::min<uint64_t>(s->bz_text_cap - left, (1ull << 31) - 1 - left);
+    B.summary = s->gz_summary;
+    HIP_TRY(launch_gzip_batch(B, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_gz_summary, s->gz_summary, GZS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->stage_busy[b] = false;
+    const uint32_t *S = s->h_gz_summary;
+    if (const uint32_t st = S[GZS_STATUS]) {
+        static const char *const why[] = {"", "bad block header, or no block where one has to begin", "invalid code", "distance reaches before the start of the stream",
+                                          "more text than the buffers hold", "stream longer or shorter than its bytes", "CRC-32 differs"};
+        s->gz_open = false;
+        return fail(FH_ERR_INVALID, "gzip: chunk %u of the batch: %s", st >> 8, (st & 255u) < 7u ? why[st & 255u] : "corrupt");
+    }
+    const uint64_t total = S[GZS_TOTAL];
+    const uint64_t end_bit = S[GZS_END_BIT_LO] | ((uint64_t)S[GZS_END_BIT_HI] << 32);
+    const uint32_t end_state = S[GZS_END_STATE];
+    static const bool trace = getenv("FH_TRACE") != nullptr;
+    if (trace)
+        fprintf(stderr, "[fh] gzip batch: %llu bytes (%llu carried) in %u chunks of %llu: %u on the chain, %llu bytes of text, stopped at bit %llu (%s)\n",
+                (unsigned long long)n_bytes, (unsigned long long)s->gz_tail_len, n_chunks, (unsigned long long)chunk_bytes, S[GZS_N_LIVE],
+                (unsigned long long)total, (unsigned long long)end_bit, end_state == GZ_MEMBER_END ? "end of the member" : "out of input");
+    s->gz_crc = crc32_join(s->gz_crc, S[GZS_CRC], total);
+    s->gz_total += total;
+    s->gz_valid = S[GZS_VALID];
+    if (end_state == GZ_MEMBER_END) {
+        s->gz_open = false;
+        if (!S[GZS_HAVE_TRAILER]) return fail(FH_ERR_INVALID, "gzip: the member's trailer is cut short");
+        if (S[GZS_CRC_WANT] != s->gz_crc || S[GZS_ISIZE_WANT] != (uint32_t)s->gz_total)
+            return fail(FH_ERR_INVALID, "gzip: CRC-32 or size differ from the member's trailer");
+        *member_done = 1;
+        *trailing = S[GZS_TRAILING];
+        s->gz_tail_len = 0;
+    } else {
+        if (flags & FH_GZ_LAST) {
+            s->gz_open = false;
+            return fail(FH_ERR_INVALID, "gzip: the stream ends inside a block");
+        }
+        const uint64_t from = (end_bit >> 3) & ~(uint64_t)3;
+        const uint64_t rest = n_bytes - from;
+        // (no block boundary beyond the carried bytes: a block longer than a push, or bytes that are no DEFLATE stream)
+        if (from < s->gz_tail_len || (from == 0 && total == 0) || rest + 4 > s->gz_base) {
+            s->gz_open = false;
+            return fail(FH_ERR_INVALID, "gzip: no block boundary within a batch");
+        }
+        if (rest) HIP_TRY(hipMemcpyAsync(s->d_comp + s->gz_base - ((rest + 3) & ~(uint64_t)3), comp + from, rest, hipMemcpyDeviceToDevice, s->stream));
+        s->gz_tail_len = rest;
+        s->gz_bit = (uint32_t)(end_bit - from * 8u);
+    }
+    const uint64_t text_total = left + total;
+    if (text_total == 0) return FH_OK;
+    s->bz_next = t ^ 1;
+    if (S[GZS_CUT_BAD]) return fail(FH_ERR_INVALID, "no FASTQ record boundary at the end of a batch of gzip text");
+    const uint64_t cut = S[GZS_CUT];
+    s->bgzf_left_ptr = s->bz_text[t] + cut;
+    s->bgzf_left_len = text_total - cut;
     if (cut == 0) return FH_OK; // one record longer than the text so far: keep collecting (it moves on to the other buffer)
     return fastq_text_on_device(s, s->bz_text[t], cut, s->bz_packed[t], s->bz_blk_a[t], s->bz_blk_b[t], s->bz_lines, s->bz_line_cap);
 }

@@ -43,7 +43,7 @@ constexpr u32 KIND_LIT = 0, KIND_BASE = 1, KIND_EOB = 2, KIND_LONG = 3;
 // loop's common cases (literal, match) need no validity test of their own
 constexpr u32 LIT_STOP = KIND_EOB << 8;
 // (reasons of failure, see BgzfFail)
-constexpr u32 BZ_BAD_CODE_ = 2, BZ_BAD_MATCH_ = 3, BZ_BAD_SIZE_ = 4, BZ_OVERRUN_ = 5;
+constexpr u32 BZ_BAD_BLOCK_ = 1, BZ_BAD_CODE_ = 2, BZ_BAD_MATCH_ = 3, BZ_BAD_SIZE_ = 4, BZ_OVERRUN_ = 5;
 
 // table entry: bits 0-3 code length (0 = no such code), 4-7 extra bits, 8-9 kind, 16-31 literal / base value / symbol
 __device__ __forceinline__ u32 make_entry(u32 nbits, u32 extra, u32 kind, u32 value) {
@@ -73,15 +73,18 @@ struct CodeSet { // the canonical code itself, for the codes longer than the tab
     u32 count[16], first[16], offs[16];
     uint16_t sorted[288];
 };
-struct Lds {
+template <class QP>
+struct LdsT {
     u32 lit[1 << LIT_BITS];
     u32 dist[1 << DIST_BITS]; // (its first 128 entries hold the code-length code while a dynamic header is read)
     CodeSet cs[2];
     uint8_t lens[320];
     uint8_t cl_lens[32];
     u32 qinfo[128];   // (the lane-parallel symbol loop) tokens waiting for a full group of 64 ...
-    uint16_t qpos[128]; // ... and where they go (a member's text is at most 65536 bytes, a token starts below that)
+    QP qpos[128];     // ... and where they go
 };
+using Lds = LdsT<uint16_t>; // BGZF: a member's text is at most 65536 bytes, a token starts below that
+using LdsGz = LdsT<u32>;    // plain gzip: a chunk's symbols, the 32768 window slots in front included
 
 __device__ __forceinline__ u32 rfl(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
 // v_writelane_b32 (clang has no builtin of that name; the LLVM intrinsic takes care of M0 for the lane select)
@@ -90,7 +93,8 @@ __device__ __forceinline__ u32 writelane(u32 value, u32 lane_idx, u32 vec) { ret
 
 // Huffman table of the n code lengths at `lens`: root table of 2^R entries (codes longer than R bits: KIND_LONG, decoded
 // from `cs`).  false: over-subscribed lengths.
-__device__ bool build_table(const uint8_t *lens, u32 n, int R, u32 *table, CodeSet &cs, int which, u32 lane) {
+// *unused: code space left over, in units of 2^-15 (0 = complete code, 16384 = one code of length 1, 32768 = no code).
+__device__ bool build_table(const uint8_t *lens, u32 n, int R, u32 *table, CodeSet &cs, int which, u32 lane, int *unused = nullptr) {
     if (lane < 16u) cs.count[lane] = 0u;
     for (u32 i = lane; i < (1u << R); i += 64u) table[i] = which == 0 ? LIT_STOP : 0u;
     __syncthreads();
@@ -114,6 +118,7 @@ __device__ bool build_table(const uint8_t *lens, u32 n, int R, u32 *table, CodeS
             left = left * 2 - (int)c;
             if (left < 0) ok = false;
         }
+        if (unused) *unused = left;
     }
     __syncthreads();
     if (!ok) return false;
@@ -225,6 +230,63 @@ __device__ __forceinline__ u32 rd_take(Reader &r, u32 n) {
 }
 __device__ __forceinline__ u64 rd_used_bits(const Reader &r) { return r.base_bits + (u64)r.widx * 32u - r.bc - r.skip0; }
 
+// The header of a dynamic-Huffman block behind its three type bits (>= 14 bits buffered): HLIT, HDIST, the code-length
+// code, and with it the hlit + hdist code lengths into L.lens.  Wave-uniform; 0 or the reason of failure.
+template <class LDS>
+__device__ __forceinline__ u32 read_dynamic_header(LDS &L, Reader &r, u32 lane, u32 &hlit, u32 &hdist) {
+    u32 fail = 0;
+    hlit = rd_take(r, 5) + 257u;
+    hdist = rd_take(r, 5) + 1u;
+    const u32 hclen = rd_take(r, 4) + 4u;
+    if (lane < 32u) L.cl_lens[lane] = 0;
+    __syncthreads();
+    // the order the code-length code's own lengths come in: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+    const u64 ord_lo = 16ull | (17ull << 5) | (18ull << 10) | (0ull << 15) | (8ull << 20) | (7ull << 25) | (9ull << 30) |
+                       (6ull << 35) | (10ull << 40) | (5ull << 45) | (11ull << 50) | (4ull << 55);
+    const u64 ord_hi = 12ull | (3ull << 5) | (13ull << 10) | (2ull << 15) | (14ull << 20) | (1ull << 25) | (15ull << 30);
+    for (u32 i = 0; i < hclen; ++i) {
+        rd_fill(r, lane);
+        const u32 v = rd_take(r, 3);
+        const u32 sym = (u32)((i < 12u ? ord_lo >> (5u * i) : ord_hi >> (5u * (i - 12u))) & 31ull);
+        if (lane == 0) L.cl_lens[sym] = (uint8_t)v;
+    }
+    __syncthreads();
+    if (!build_table(L.cl_lens, 19, CL_BITS, L.dist, L.cs[1], 2, lane)) return BZ_BAD_BLOCK_;
+    const u32 n = hlit + hdist;
+    u32 i = 0, prev = 0;
+    while (i < n && !fail) {
+        rd_fill(r, lane);
+        const u32 e = rfl(L.dist[(u32)r.bb & ((1u << CL_BITS) - 1u)]);
+        const u32 nb = e & 15u;
+        if (nb == 0u) return BZ_BAD_CODE_;
+        rd_take(r, nb);
+        const u32 sym = e >> 16;
+        if (sym < 16u) {
+            if (lane == 0) L.lens[i] = (uint8_t)sym;
+            prev = sym;
+            i++;
+        } else {
+            u32 rep, val = 0;
+            if (sym == 16u) {
+                if (i == 0u) return BZ_BAD_BLOCK_;
+                rep = 3u + rd_take(r, 2);
+                val = prev;
+            } else if (sym == 17u) {
+                rep = 3u + rd_take(r, 3);
+            } else {
+                rep = 11u + rd_take(r, 7);
+            }
+            if (i + rep > n) return BZ_BAD_BLOCK_;
+            for (u32 j = lane; j < rep; j += 64u) L.lens[i + j] = (uint8_t)val;
+            prev = val;
+            i += rep;
+        }
+    }
+    __syncthreads();
+    if (L.lens[256] == 0) return BZ_BAD_BLOCK_; // no end-of-block code
+    return fail;
+}
+
 // One match: `len` bytes from `dist` bytes back.  Nothing else writes either range while this runs.
 __device__ __forceinline__ void copy_match(uint8_t *d, const uint8_t *s, u32 len, u32 dist) {
     if (dist >= len) { // apart: up to 64 bytes are loaded before the first of them is stored (one wait, not one per word)
@@ -266,7 +328,9 @@ __device__ __forceinline__ void copy_match(uint8_t *d, const uint8_t *s, u32 len
 // The queued symbols of one group, one per lane, written out.  pos / info: the lane's token (info: low 9 bits match
 // length, 0 = literal; high half the distance, or the literal byte -- two of them if bit 9 is set).  A lane copies when everything its match reads
 // has been written: sources below `W`, the output position of the first token not yet written.
-__device__ void resolve_group(uint8_t *out, u32 tpos, u32 tinfo, u32 ntok, u32 lane) {
+// T: bytes (BGZF), or 16-bit symbols (plain gzip: a byte, or a marker for a byte of the unknown window, copied like any other).
+template <class T>
+__device__ void resolve_group(T *out, u32 tpos, u32 tinfo, u32 ntok, u32 lane) {
     const u32 len = tinfo & 0x1FFu, hi = tinfo >> 16;
     bool done = lane >= ntok;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, BZ_FENCE_SCOPE); // earlier groups' bytes
@@ -276,14 +340,14 @@ __device__ void resolve_group(uint8_t *out, u32 tpos, u32 tinfo, u32 ntok, u32 l
         const u32 W = (u32)__builtin_amdgcn_readlane((int)tpos, (int)__builtin_ctzll(pending));
         if (!done) {
             if (len == 0u) {
-                out[tpos] = (uint8_t)hi;
-                if (tinfo & 0x200u) out[tpos + 1u] = (uint8_t)(hi >> 8);
+                out[tpos] = (T)(hi & 0xFFu);
+                if (tinfo & 0x200u) out[tpos + 1u] = (T)((hi >> 8) & 0xFFu);
                 done = true;
             } else {
                 const u32 src = tpos - hi;
                 const u32 src_end = src + (len < hi ? len : hi); // (an overlapping match re-reads its own bytes)
                 if (src_end <= W) {
-                    copy_match(out + tpos, out + src, len, hi);
+                    copy_match((uint8_t *)(out + tpos), (const uint8_t *)(out + src), len * (u32)sizeof(T), hi * (u32)sizeof(T));
                     done = true;
                 }
             }
@@ -306,7 +370,8 @@ __device__ __forceinline__ u32 wave_scan_add(u32 v) {
 }
 
 // write out the queued tokens, 64 at a time (`all`: the rest too)
-__device__ void flush_queue(Lds &L, uint8_t *out, u32 &qn, u32 lane, bool all) {
+template <class LDS, class T>
+__device__ void flush_queue(LDS &L, T *out, u32 &qn, u32 lane, bool all) {
     while (qn >= 64u || (all && qn > 0u)) {
         const u32 n = qn < 64u ? qn : 64u;
         __syncthreads();
@@ -316,7 +381,7 @@ __device__ void flush_queue(Lds &L, uint8_t *out, u32 &qn, u32 lane, bool all) {
         const u32 p1 = L.qpos[64u + lane], i1 = L.qinfo[64u + lane];
         __syncthreads();
         if (lane < rest) {
-            L.qpos[lane] = (uint16_t)p1;
+            L.qpos[lane] = p1; // (narrowed to the queue's position type)
             L.qinfo[lane] = i1;
         }
         qn = rest;
@@ -329,7 +394,8 @@ __device__ void flush_queue(Lds &L, uint8_t *out, u32 &qn, u32 lane, bool all) {
 // following the lengths from the first one (a scalar chase of one v_readlane per symbol).  Output positions come from a
 // prefix sum over those lanes; their tokens join the queue.  mbits: bits of the member consumed (in: where the block's
 // symbols begin, out: behind its end-of-block code).  Returns 0 or the reason of failure.
-__device__ u32 block_symbols_parallel(Lds &L, const uint8_t *mbase, u64 in_bits, u32 isize, uint8_t *out, u64 &mbits_ref, u32 &pos_ref,
+template <class LDS, class T>
+__device__ u32 block_symbols_parallel(LDS &L, const uint8_t *mbase, u64 in_bits, u32 isize, T *out, u64 &mbits_ref, u32 &pos_ref,
                                       u32 &qn_ref, u32 lane) {
     u64 mbits = mbits_ref;
     u32 pos = pos_ref, qn = qn_ref, fail = 0;
@@ -397,7 +463,7 @@ __device__ u32 block_symbols_parallel(Lds &L, const uint8_t *mbase, u64 in_bits,
         }
         const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(marks >> 32), __builtin_amdgcn_mbcnt_lo((u32)marks, 0u));
         if (tok) {
-            L.qpos[qn + rank] = (uint16_t)mypos;
+            L.qpos[qn + rank] = mypos; // (narrowed to the queue's position type)
             L.qinfo[qn + rank] = info;
         }
         qn += (u32)__popcll(marks);
@@ -479,71 +545,8 @@ __global__ __launch_bounds__(64, 5) void k_bgzf_inflate(const uint8_t *comp, con
             for (u32 s = lane; s < 288u; s += 64u) L.lens[s] = s < 144u ? 8 : s < 256u ? 9 : s < 280u ? 7 : 8;
             if (lane < 32u) L.lens[288u + lane] = 5;
         } else {
-            hlit = rd_take(r, 5) + 257u;
-            hdist = rd_take(r, 5) + 1u;
-            const u32 hclen = rd_take(r, 4) + 4u;
-            if (lane < 32u) L.cl_lens[lane] = 0;
-            __syncthreads();
-            // the order the code-length code's own lengths come in: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
-            const u64 ord_lo = 16ull | (17ull << 5) | (18ull << 10) | (0ull << 15) | (8ull << 20) | (7ull << 25) | (9ull << 30) |
-                               (6ull << 35) | (10ull << 40) | (5ull << 45) | (11ull << 50) | (4ull << 55);
-            const u64 ord_hi = 12ull | (3ull << 5) | (13ull << 10) | (2ull << 15) | (14ull << 20) | (1ull << 25) | (15ull << 30);
-            for (u32 i = 0; i < hclen; ++i) {
-                rd_fill(r, lane);
-                const u32 v = rd_take(r, 3);
-                const u32 sym = (u32)((i < 12u ? ord_lo >> (5u * i) : ord_hi >> (5u * (i - 12u))) & 31ull);
-                if (lane == 0) L.cl_lens[sym] = (uint8_t)v;
-            }
-            __syncthreads();
-            if (!build_table(L.cl_lens, 19, CL_BITS, L.dist, L.cs[1], 2, lane)) {
-                fail = BZ_BAD_BLOCK;
-                break;
-            }
-            const u32 n = hlit + hdist;
-            u32 i = 0, prev = 0;
-            while (i < n && !fail) {
-                rd_fill(r, lane);
-                const u32 e = rfl(L.dist[(u32)r.bb & ((1u << CL_BITS) - 1u)]);
-                const u32 nb = e & 15u;
-                if (nb == 0u) {
-                    fail = BZ_BAD_CODE;
-                    break;
-                }
-                rd_take(r, nb);
-                const u32 sym = e >> 16;
-                if (sym < 16u) {
-                    if (lane == 0) L.lens[i] = (uint8_t)sym;
-                    prev = sym;
-                    i++;
-                } else {
-                    u32 rep, val = 0;
-                    if (sym == 16u) {
-                        if (i == 0u) {
-                            fail = BZ_BAD_BLOCK;
-                            break;
-                        }
-                        rep = 3u + rd_take(r, 2);
-                        val = prev;
-                    } else if (sym == 17u) {
-                        rep = 3u + rd_take(r, 3);
-                    } else {
-                        rep = 11u + rd_take(r, 7);
-                    }
-                    if (i + rep > n) {
-                        fail = BZ_BAD_BLOCK;
-                        break;
-                    }
-                    for (u32 j = lane; j < rep; j += 64u) L.lens[i + j] = (uint8_t)val;
-                    prev = val;
-                    i += rep;
-                }
-            }
+            fail = read_dynamic_header(L, r, lane, hlit, hdist);
             if (fail) break;
-            __syncthreads();
-            if (L.lens[256] == 0) { // no end-of-block code
-                fail = BZ_BAD_BLOCK;
-                break;
-            }
         }
         __syncthreads();
         if (!build_table(L.lens, hlit, LIT_BITS, L.lit, L.cs[0], 0, lane) ||
@@ -623,6 +626,245 @@ __global__ __launch_bounds__(64, 5) void k_bgzf_inflate(const uint8_t *comp, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// plain gzip: one DEFLATE stream, no index -- the two-pass scheme of pugz / rapidgzip (fh_pargz.h has it for host threads)
+// with a wavefront per chunk.
+//   k_gz_find     chunk c > 0: the first bit offset of its range that reads as the header of a non-final dynamic block --
+//                 64 offsets at a time through the cheap tests (type bits, HLIT / HDIST, a complete code-length code), the
+//                 survivors one by one through the real header parser, complete literal and distance codes, and first
+//                 symbols that are text.
+//   k_gz_inflate  every chunk with a start decodes from it into 16-bit symbols behind 32768 marker slots (what lies in front
+//                 of a chunk is unknown: a match that reaches there copies markers), block by block, until a block ends
+//                 exactly where a later chunk was found to begin (GZ_NEXT), the stream ends, or the bytes do.
+//   k_gz_chain    one workgroup walks the chunks that really follow each other: text offsets, the 32 KiB in front of each
+//                 (the previous one's tail, its markers looked up in the window before that), which text tile is whose.
+//   k_gz_text     symbols narrowed to bytes, markers looked up; then CRC-32 of the batch's text (k_gz_crc_*).
+// A "start" that is none costs its wavefront's work and nothing else: no chain passes through it.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ bool gz_text_byte(u32 c) { return c == '\n' || c == '\r' || c == '\t' || (c >= 32u && c < 127u); }
+
+// Does a non-final dynamic block with complete codes, whose first symbols are text, begin at bit `pos`?  Wave-uniform.
+__device__ bool gz_block_check(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 pos, u32 lane) {
+    Reader r;
+    rd_init(r, comp, pos >> 3, n_bytes, (pos >> 3) * 8u, lane);
+    rd_fill(r, lane);
+    rd_take(r, (u32)(pos & 7u));
+    rd_fill(r, lane);
+    rd_take(r, 3); // BFINAL = 0, BTYPE = 2: the caller has looked
+    u32 hlit, hdist;
+    if (read_dynamic_header(L, r, lane, hlit, hdist)) return false;
+    __syncthreads();
+    int free_lit = 0, free_dist = 0;
+    if (!build_table(L.lens, hlit, LIT_BITS, L.lit, L.cs[0], 0, lane, &free_lit) || free_lit != 0) return false;
+    if (!build_table(L.lens + hlit, hdist, DIST_BITS, L.dist, L.cs[1], 1, lane, &free_dist)) return false;
+    if (free_dist != 0 && free_dist != 16384 && free_dist != 32768) return false; // complete, one code, or none
+    const u64 in_bits = n_bytes * 8u;
+    for (u32 sym = 0; sym < 512u; ++sym) {
+        if (rd_used_bits(r) > in_bits) return false;
+        rd_fill(r, lane);
+        u32 e = rfl(L.lit[(u32)r.bb & ((1u << LIT_BITS) - 1u)]);
+        u32 kind = (e >> 8) & 3u;
+        if (kind == KIND_LONG) {
+            e = rfl(decode_long(L.cs[0], LIT_BITS, 0, (u32)r.bb));
+            kind = (e >> 8) & 3u;
+        }
+        if (kind == KIND_LIT) {
+            if (!gz_text_byte(e >> 16)) return false;
+            rd_take(r, e & 15u);
+            continue;
+        }
+        if (kind != KIND_BASE) return (e & 15u) != 0u && sym > 0u; // end of block (an empty one tells nothing), or no such code
+        rd_take(r, e & 15u);
+        rd_take(r, (e >> 4) & 15u);
+        rd_fill(r, lane);
+        u32 d = rfl(L.dist[(u32)r.bb & ((1u << DIST_BITS) - 1u)]);
+        if (((d >> 8) & 3u) == KIND_LONG) d = rfl(decode_long(L.cs[1], DIST_BITS, 1, (u32)r.bb));
+        if ((d & 15u) == 0u) return false;
+        rd_take(r, d & 15u);
+        rd_take(r, (d >> 4) & 15u);
+    }
+    return true;
+}
+} // namespace
+
+__global__ __launch_bounds__(64) void k_gz_find(const uint8_t *comp, u64 n_bytes, u64 chunk_bits, u32 n_chunks, u64 first_bit,
+                                                GzChunk *recs) {
+    __shared__ LdsGz L;
+    const u32 ci = blockIdx.x, lane = threadIdx.x;
+    if (ci >= n_chunks) return;
+    u64 found = GZ_NONE;
+    if (ci == 0u) {
+        found = first_bit;
+    } else {
+        u64 from = (u64)ci * chunk_bits;
+        if (from <= first_bit) from = first_bit + 1u;
+        // (a header and a few symbols have to fit behind a start: nothing is looked for in the last 64 bytes)
+        const u64 all = n_bytes > 64u ? (n_bytes - 64u) * 8u : 0u;
+        u64 to = (u64)(ci + 1u) * chunk_bits;
+        if (to > all) to = all;
+        for (u64 p0 = from; p0 < to && found == GZ_NONE; p0 += 64u) {
+            const u64 pos = p0 + lane;
+            bool cand = false;
+            if (pos < to) {
+                u64 a;
+                __builtin_memcpy(&a, comp + (pos >> 3), 8);
+                const u64 v = a >> (u32)(pos & 7u);
+                const u32 hl = (u32)(v >> 3) & 31u, hd = (u32)(v >> 8) & 31u, hclen = ((u32)(v >> 13) & 15u) + 4u;
+                if ((v & 7u) == 4u && hl <= 29u && hd <= 29u) {
+                    const u64 p2 = pos + 17u;
+                    u64 b;
+                    __builtin_memcpy(&b, comp + (p2 >> 3), 8);
+                    const u64 w = b >> (u32)(p2 & 7u); // 57 bits: 19 lengths of 3
+                    u32 kraft = 0;
+#pragma unroll
+                    for (u32 i = 0; i < 19u; ++i) {
+                        const u32 l = (u32)(w >> (3u * i)) & 7u;
+                        if (i < hclen && l) kraft += 128u >> l;
+                    }
+                    cand = kraft == 128u; // every encoder's code-length code is complete
+                }
+            }
+            unsigned long long mask = __ballot(cand);
+            while (mask) {
+                const u32 b = (u32)__builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                if (gz_block_check(L, comp, n_bytes, p0 + b, lane)) {
+                    found = p0 + b;
+                    break;
+                }
+            }
+        }
+    }
+    if (lane == 0) recs[ci] = GzChunk{found, found, 0u, (u32)GZ_IDLE};
+}
+
+__global__ __launch_bounds__(64, 5) void k_gz_inflate(const uint8_t *comp, u64 n_bytes, u64 chunk_bits, u32 n_chunks, GzChunk *recs,
+                                                      uint16_t *sym, u64 cap) {
+    __shared__ LdsGz L;
+    const u32 ci = blockIdx.x, lane = threadIdx.x;
+    if (ci >= n_chunks) return;
+    const u64 start = recs[ci].start_bit;
+    if (start == GZ_NONE) return;
+    uint16_t *out = sym + (u64)ci * cap;
+    for (u32 j = lane; j < GZ_WINDOW / 2u; j += 64u) ((u32 *)out)[j] = (0x8000u | (2u * j)) | ((0x8001u | (2u * j)) << 16);
+    __syncthreads();
+    const u64 in_bits = n_bytes * 8u;
+    // room: this chunk's share of the symbol buffer and those of the chunks behind it in which no start was found (a chunk
+    // that decodes through their ranges produces their text as well)
+    u32 limit;
+    {
+        u32 j = ci + 1u;
+        while (j < n_chunks && recs[j].start_bit == GZ_NONE) j++;
+        const u64 room = (u64)(j - ci) * cap;
+        limit = room > 0x7FFFFFF0ull ? 0x7FFFFFF0u : (u32)room;
+    }
+    Reader r;
+    rd_init(r, comp, start >> 3, n_bytes, (start >> 3) * 8u, lane);
+    rd_fill(r, lane);
+    rd_take(r, (u32)(start & 7u));
+    u32 fail = 0, state = GZ_FAILED, pos = GZ_WINDOW, qn = 0;
+    u64 end_bit = start, fail_at = 0;
+    u32 end_pos = pos;
+    for (;;) {
+        // a block boundary: what has been decoded up to here stands whatever becomes of the next block
+        end_bit = rd_used_bits(r);
+        end_pos = pos;
+        if (end_bit + 3u > in_bits) {
+            state = GZ_OUT_OF_INPUT;
+            break;
+        }
+        rd_fill(r, lane);
+        const bool final_block = rd_take(r, 1) != 0u;
+        const u32 type = rd_take(r, 2);
+        if (type == 3u) {
+            fail = BZ_BAD_BLOCK;
+            fail_at = end_bit;
+            break;
+        }
+        if (type == 0u) { // stored: LEN, ~LEN, then the bytes themselves
+            rd_take(r, r.bc & 7u);
+            rd_fill(r, lane);
+            const u32 len = rd_take(r, 16), nlen = rd_take(r, 16);
+            const u64 used = rd_used_bits(r) >> 3;
+            if (used + len > n_bytes) {
+                state = GZ_OUT_OF_INPUT;
+                break;
+            }
+            if ((len ^ 0xFFFFu) != nlen) {
+                fail = BZ_BAD_BLOCK;
+                fail_at = used * 8u;
+                break;
+            }
+            if ((u64)pos + len > limit) {
+                fail = BZ_BAD_SIZE;
+                break;
+            }
+            flush_queue(L, out, qn, lane, true);
+            const uint8_t *src = comp + used;
+            for (u32 j = lane; j < len; j += 64u) out[pos + j] = src[j];
+            pos += len;
+            rd_init(r, comp, used + len, n_bytes, (used + len) * 8u, lane);
+        } else {
+            u32 hlit = 288, hdist = 32;
+            if (type == 1u) { // the fixed code
+                for (u32 s = lane; s < 288u; s += 64u) L.lens[s] = s < 144u ? 8 : s < 256u ? 9 : s < 280u ? 7 : 8;
+                if (lane < 32u) L.lens[288u + lane] = 5;
+            } else {
+                fail = read_dynamic_header(L, r, lane, hlit, hdist);
+                if (fail) {
+                    fail_at = rd_used_bits(r);
+                    break;
+                }
+            }
+            __syncthreads();
+            if (!build_table(L.lens, hlit, LIT_BITS, L.lit, L.cs[0], 0, lane) ||
+                !build_table(L.lens + hlit, hdist, DIST_BITS, L.dist, L.cs[1], 1, lane)) {
+                fail = BZ_BAD_BLOCK;
+                fail_at = rd_used_bits(r);
+                break;
+            }
+            pair_literals(L.lit, lane);
+            u64 mb = rd_used_bits(r);
+            fail = block_symbols_parallel(L, comp, in_bits, limit, out, mb, pos, qn, lane);
+            if (fail) {
+                fail_at = mb;
+                break;
+            }
+            rd_init(r, comp, mb >> 3, n_bytes, (mb >> 3) * 8u, lane);
+            rd_fill(r, lane);
+            rd_take(r, (u32)(mb & 7u));
+        }
+        const u64 b = rd_used_bits(r);
+        if (b > in_bits) { // the block "ended" in the padding behind the bytes
+            state = GZ_OUT_OF_INPUT;
+            break;
+        }
+        end_bit = b;
+        end_pos = pos;
+        if (final_block) {
+            state = GZ_MEMBER_END;
+            break;
+        }
+        const u64 j = b / chunk_bits;
+        if (j > ci && j < n_chunks && recs[j].start_bit == b) {
+            state = GZ_NEXT;
+            break;
+        }
+    }
+    if (fail) {
+        // (what was decoded from the padding behind the last byte proves nothing: the block is cut short by the batch's end)
+        if (fail != BZ_BAD_SIZE && fail_at + 512u > in_bits) state = GZ_OUT_OF_INPUT;
+        else state = (u32)GZ_FAILED | (fail << 8);
+    }
+    flush_queue(L, out, qn, lane, true);
+    if (lane == 0) {
+        recs[ci].end_bit = end_bit;
+        recs[ci].out_len = end_pos - GZ_WINDOW;
+        recs[ci].state = state;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // CRC-32 (IEEE 802.3, reflected) of each member's text
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
@@ -692,7 +934,7 @@ __global__ __launch_bounds__(256) void k_bgzf_crc(const BgzfMember *members, u32
 
 // out[0] = offset of the last header line whose line two below is a '+' line (what fh_host.cpp's reader cuts a FASTQ
 // chunk at), or `total` for the last text of a file; out[1] = 1 when no such line is in the last 16.
-__global__ __launch_bounds__(64) void k_fastq_cut(const uint8_t *text, u32 total, u32 last, u32 *out) {
+__device__ void fastq_cut_body(const uint8_t *text, u32 total, u32 last, u32 *out) {
     const u32 lane = threadIdx.x;
     if (last || total == 0u) {
         if (lane == 0) {
@@ -737,9 +979,242 @@ __global__ __launch_bounds__(64) void k_fastq_cut(const uint8_t *text, u32 total
     }
 }
 
-hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfMember *members, uint32_t n_members, uint8_t *text,
-                               uint32_t *status, hipStream_t st) {
-    if (n_members == 0) return hipSuccess;
+__global__ __launch_bounds__(64) void k_fastq_cut(const uint8_t *text, u32 total, u32 last, u32 *out) { fastq_cut_body(text, total, last, out); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// plain gzip, second half: the chain of chunks, markers looked up, the text's CRC-32
+// ---------------------------------------------------------------------------------------------------------------------
+// live[4 * i ..]: chunk index, symbols, text offset, bytes of real text in front of it (<= GZ_WINDOW)
+__global__ __launch_bounds__(1024) void k_gz_chain(GzBatch B) {
+    __shared__ uint8_t W[GZ_WINDOW];
+    __shared__ u32 s_stop;
+    const u32 tid = threadIdx.x;
+    {
+        const uint4 *src = (const uint4 *)B.window;
+        uint4 *dst = (uint4 *)W;
+        dst[tid] = src[tid];
+        dst[tid + 1024u] = src[tid + 1024u];
+    }
+    __syncthreads();
+    u32 ci = 0, n = 0, status = 0, valid = B.valid, kind = GZ_IDLE;
+    u64 off = 0, end_bit = 0;
+    for (;;) {
+        const GzChunk c = B.recs[ci];
+        kind = c.state & 255u;
+        end_bit = c.end_bit;
+        if (kind == GZ_IDLE || kind == GZ_FAILED) {
+            status = (ci << 8) | (kind == GZ_FAILED ? ((c.state >> 8) & 255u) : (u32)BZ_BAD_BLOCK);
+            break;
+        }
+        if (off + c.out_len > B.text_cap) {
+            status = (ci << 8) | (u32)BZ_BAD_SIZE;
+            break;
+        }
+        { // the window in front of this chunk
+            uint4 *dst = (uint4 *)(B.win_in + (u64)ci * GZ_WINDOW);
+            const uint4 *src = (const uint4 *)W;
+            dst[tid] = src[tid];
+            dst[tid + 1024u] = src[tid + 1024u];
+        }
+        if (tid == 0) {
+            B.live[4u * n] = ci;
+            B.live[4u * n + 1u] = c.out_len;
+            B.live[4u * n + 2u] = (u32)off;
+            B.live[4u * n + 3u] = valid;
+        }
+        for (u64 t = (off + 4095u) / 4096u + tid; t < (off + c.out_len + 4095u) / 4096u; t += 1024u) B.tile_map[t] = n;
+        // the window behind it: the last GZ_WINDOW of [marker slots | symbols], markers looked up
+        const uint16_t *tail = B.sym + (u64)ci * B.cap + c.out_len;
+        u32 packed[8];
+        {
+            uint4 raw[4];
+#pragma unroll
+            for (u32 q = 0; q < 4u; ++q) __builtin_memcpy(&raw[q], tail + tid * 32u + q * 8u, 16);
+            const uint16_t *e = (const uint16_t *)raw;
+#pragma unroll
+            for (u32 q = 0; q < 8u; ++q) {
+                u32 w = 0;
+#pragma unroll
+                for (u32 z = 0; z < 4u; ++z) {
+                    const u32 v = e[q * 4u + z];
+                    w |= (v < 256u ? v : (u32)W[v & 0x7FFFu]) << (8u * z);
+                }
+                packed[q] = w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 q = 0; q < 8u; ++q) ((u32 *)W)[tid * 8u + q] = packed[q];
+        __syncthreads();
+        off += c.out_len;
+        valid = (u64)valid + c.out_len > GZ_WINDOW ? GZ_WINDOW : valid + c.out_len;
+        n++;
+        if (kind != GZ_NEXT) break;
+        const u64 nx = c.end_bit / B.chunk_bits;
+        if (nx <= ci || nx >= B.n_chunks) { // (k_gz_inflate stops with GZ_NEXT only at a later chunk's start)
+            status = (ci << 8) | (u32)BZ_BAD_BLOCK;
+            break;
+        }
+        ci = (u32)nx;
+    }
+    (void)s_stop;
+    {
+        uint4 *dst = (uint4 *)B.window;
+        const uint4 *src = (const uint4 *)W;
+        dst[tid] = src[tid];
+        dst[tid + 1024u] = src[tid + 1024u];
+    }
+    if (tid == 0) {
+        u32 *S = B.summary;
+        S[GZS_STATUS] = status;
+        S[GZS_N_LIVE] = n;
+        S[GZS_TOTAL] = (u32)off;
+        S[GZS_END_STATE] = kind;
+        S[GZS_END_BIT_LO] = (u32)end_bit;
+        S[GZS_END_BIT_HI] = (u32)(end_bit >> 32);
+        S[GZS_VALID] = valid;
+        u32 have = 0, crc = 0, isize = 0, trailing = 0;
+        if (kind == GZ_MEMBER_END) {
+            const u64 t = (end_bit + 7u) >> 3;
+            if (t + 8u <= B.n_bytes) {
+                const uint8_t *p = B.comp + t;
+                have = 1;
+                crc = p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24);
+                isize = p[4] | ((u32)p[5] << 8) | ((u32)p[6] << 16) | ((u32)p[7] << 24);
+                trailing = (u32)(B.n_bytes - t - 8u);
+            }
+        }
+        S[GZS_HAVE_TRAILER] = have;
+        S[GZS_CRC_WANT] = crc;
+        S[GZS_ISIZE_WANT] = isize;
+        S[GZS_TRAILING] = trailing;
+    }
+}
+
+// one workgroup per 4096 bytes of text, 16 bytes a thread
+__global__ __launch_bounds__(256) void k_gz_text(GzBatch B) {
+    const u32 *S = B.summary;
+    if (S[GZS_STATUS]) return;
+    const u32 total = S[GZS_TOTAL];
+    const u32 o = blockIdx.x * 4096u + threadIdx.x * 16u;
+    if (o >= total) return;
+    u32 li = B.tile_map[blockIdx.x];
+    u32 ci = B.live[4u * li], len = B.live[4u * li + 1u], off = B.live[4u * li + 2u], valid = B.live[4u * li + 3u];
+    while (o >= off + len) { // (the tile began in an earlier chunk than this thread's bytes do)
+        li++;
+        ci = B.live[4u * li], len = B.live[4u * li + 1u], off = B.live[4u * li + 2u], valid = B.live[4u * li + 3u];
+    }
+    uint8_t res[16];
+    u32 e = 0, bad = 0;
+    const u32 want = total - o < 16u ? total - o : 16u;
+    while (e < want) {
+        const u32 x = o + e - off;
+        const u32 run = want - e < len - x ? want - e : len - x;
+        const uint16_t *p = B.sym + (u64)ci * B.cap + GZ_WINDOW + x;
+        const uint8_t *Wn = B.win_in + (u64)ci * GZ_WINDOW;
+        uint16_t v16[16];
+        if (run == 16u) {
+            __builtin_memcpy(v16, p, 32);
+        } else {
+            for (u32 q = 0; q < run; ++q) v16[q] = p[q];
+        }
+        for (u32 q = 0; q < 16u; ++q) {
+            if (q >= run) break;
+            u32 v = v16[q];
+            if (v >= 256u) {
+                const u32 idx = v & 0x7FFFu;
+                if (idx < GZ_WINDOW - valid) bad = 1; // before the first byte of the member
+                v = Wn[idx];
+            }
+            res[e + q] = (uint8_t)v;
+        }
+        e += run;
+        if (e < want) {
+            do {
+                li++;
+                ci = B.live[4u * li], len = B.live[4u * li + 1u], off = B.live[4u * li + 2u], valid = B.live[4u * li + 3u];
+            } while (len == 0u);
+        }
+    }
+    uint8_t *dst = B.text + B.left + o;
+    if (want == 16u) {
+        __builtin_memcpy(dst, res, 16);
+    } else {
+        for (u32 q = 0; q < want; ++q) dst[q] = res[q];
+    }
+    if (bad) atomicMax(&B.summary[GZS_STATUS], (ci << 8) | (u32)BZ_BAD_MATCH);
+}
+
+// CRC-32 of text[left, left + total): a wavefront per 64 KiB slice, then one wavefront joins the slices
+__global__ __launch_bounds__(256) void k_gz_crc_slices(GzBatch B, X2N x2n) {
+    __shared__ u32 T[4][256];
+    {
+        u32 c = threadIdx.x;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
+        T[0][threadIdx.x] = c;
+    }
+    __syncthreads();
+    for (int t = 1; t < 4; ++t) {
+        const u32 prev = T[t - 1][threadIdx.x];
+        T[t][threadIdx.x] = (prev >> 8) ^ T[0][prev & 0xFFu];
+        __syncthreads();
+    }
+    if (B.summary[GZS_STATUS]) return;
+    const u32 total = B.summary[GZS_TOTAL];
+    const u32 lane = threadIdx.x & 63u;
+    const u32 si = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if ((u64)si * 65536u >= total) return;
+    const u32 size = total - si * 65536u < 65536u ? total - si * 65536u : 65536u;
+    const u32 slice = (((size + 63u) >> 6) + 3u) & ~3u;
+    const u32 lo = lane * slice < size ? lane * slice : size;
+    const u32 hi = lo + slice < size ? lo + slice : size;
+    const uint8_t *p = B.text + B.left + (u64)si * 65536u;
+    u32 c = 0xFFFFFFFFu, i = lo;
+    for (; i < hi && ((uintptr_t)(p + i) & 3u); ++i) c = (c >> 8) ^ T[0][(c ^ p[i]) & 0xFFu];
+    for (; i + 4u <= hi; i += 4u) {
+        c ^= *(const u32 *)(p + i);
+        c = T[3][c & 0xFFu] ^ T[2][(c >> 8) & 0xFFu] ^ T[1][(c >> 16) & 0xFFu] ^ T[0][c >> 24];
+    }
+    for (; i < hi; ++i) c = (c >> 8) ^ T[0][(c ^ p[i]) & 0xFFu];
+    c ^= 0xFFFFFFFFu;
+    u32 part = hi > lo ? crc_multmodp(crc_x2nmodp(x2n, size - hi, 3), c) : 0u;
+    for (int off = 32; off > 0; off >>= 1) part ^= __shfl_xor(part, off);
+    if (lane == 0) B.crc_tmp[si] = part;
+}
+__global__ __launch_bounds__(64) void k_gz_crc_join(GzBatch B, X2N x2n) {
+    if (B.summary[GZS_STATUS]) return;
+    const u32 total = B.summary[GZS_TOTAL];
+    const u32 lane = threadIdx.x;
+    const u32 n = (u32)(((u64)total + 65535u) >> 16);
+    const u32 per = (n + 63u) / 64u;
+    const u32 lo = lane * per < n ? lane * per : n, hi = lo + per < n ? lo + per : n;
+    const u32 shift64k = crc_x2nmodp(x2n, 65536u, 3);
+    u32 acc = 0;
+    u64 bytes = 0;
+    for (u32 s = lo; s < hi; ++s) {
+        const u32 size = total - s * 65536u < 65536u ? total - s * 65536u : 65536u;
+        const u32 op = size == 65536u ? shift64k : crc_x2nmodp(x2n, size, 3);
+        acc = crc_multmodp(op, acc) ^ B.crc_tmp[s];
+        bytes += size;
+    }
+    // the lanes' stretches, in order
+    const u32 my_op = crc_x2nmodp(x2n, (u32)bytes, 3); // (a lane holds < 2^32 bytes: the whole text does)
+    u32 crc = 0;
+    for (u32 l = 0; l < 64u; ++l) {
+        const u32 a = (u32)__builtin_amdgcn_readlane((int)acc, (int)l), op = (u32)__builtin_amdgcn_readlane((int)my_op, (int)l);
+        const u32 nb = (u32)__builtin_amdgcn_readlane((int)(u32)bytes, (int)l);
+        if (nb) crc = crc_multmodp(op, crc) ^ a;
+    }
+    if (lane == 0) B.summary[GZS_CRC] = crc;
+}
+// (launch_fastq_cut for a total only the device knows)
+__global__ __launch_bounds__(64) void k_gz_cut(GzBatch B) {
+    const u32 *S = B.summary;
+    if (S[GZS_STATUS]) return;
+    fastq_cut_body(B.text, B.left + S[GZS_TOTAL], S[GZS_END_STATE] == (u32)GZ_MEMBER_END ? 1u : 0u, B.summary + GZS_CUT);
+}
+
+static const X2N &x2n_table() {
     static const X2N x2n = [] {
         X2N x;
         u32 p = 1u << 30; // x^1
@@ -747,6 +1222,36 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfMember *members, u
         for (int k = 1; k < 32; ++k) x.t[k] = p = crc_multmodp(p, p);
         return x;
     }();
+    return x2n;
+}
+
+uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+    const X2N &x = x2n_table();
+    u32 p = 1u << 31; // x^0
+    u32 k = 3;        // bits -> bytes
+    for (uint64_t n = len_b; n; n >>= 1, ++k)
+        if (n & 1u) p = crc_multmodp(x.t[k & 31u], p);
+    return crc_multmodp(p, crc_a) ^ crc_b;
+}
+
+hipError_t launch_gzip_batch(const GzBatch &b, hipStream_t st) {
+    if (b.n_chunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gz_find, dim3(b.n_chunks), dim3(64), 0, st, b.comp, b.n_bytes, b.chunk_bits, b.n_chunks, b.first_bit, b.recs);
+    hipLaunchKernelGGL(k_gz_inflate, dim3(b.n_chunks), dim3(64), 0, st, b.comp, b.n_bytes, b.chunk_bits, b.n_chunks, b.recs, b.sym, b.cap);
+    hipLaunchKernelGGL(k_gz_chain, dim3(1), dim3(1024), 0, st, b);
+    const u32 n_tiles = (u32)((b.text_cap + 4095u) / 4096u);
+    hipLaunchKernelGGL(k_gz_text, dim3(n_tiles), dim3(256), 0, st, b);
+    const u32 n_slices = (u32)((b.text_cap + 65535u) / 65536u);
+    hipLaunchKernelGGL(k_gz_crc_slices, dim3((n_slices + 3u) / 4u), dim3(256), 0, st, b, x2n_table());
+    hipLaunchKernelGGL(k_gz_crc_join, dim3(1), dim3(64), 0, st, b, x2n_table());
+    hipLaunchKernelGGL(k_gz_cut, dim3(1), dim3(64), 0, st, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfMember *members, uint32_t n_members, uint8_t *text,
+                               uint32_t *status, hipStream_t st) {
+    if (n_members == 0) return hipSuccess;
+    const X2N &x2n = x2n_table();
     static const bool serial = getenv("FH_BGZF_SERIAL") != nullptr; // A/B: one symbol at a time
     if (serial) hipLaunchKernelGGL(k_bgzf_inflate<false>, dim3(n_members), dim3(64), 0, st, comp, members, n_members, text, status);
     else hipLaunchKernelGGL(k_bgzf_inflate<true>, dim3(n_members), dim3(64), 0, st, comp, members, n_members, text, status);

@@ -780,6 +780,60 @@ struct BgzfSource : ByteSource {
         if (!inf::inflate_exact(*dec, p + hdr, tot - hdr - 8, text.data(), isize)) return -1;
         return text[0];
     }
+    // ---- plain gzip on the device (fh_push_gzip_fastq) takes the DEFLATE bytes as they are ----
+    // The file starts with a gzip member that is not BGZF: the length of its header (*hdr_len) and the first byte of its
+    // text, nothing consumed.  -1: it does not, or nothing can be decoded from its first 64 KiB.
+    int peek_plain_gzip(size_t *hdr_len) {
+        join_prefetch();
+        if (tail || c_lo) return -1; // (only for a reader that has handed out nothing yet)
+        fill_compressed(std::min<size_t>(cbuf.size(), 65536));
+        const uint8_t *p = cbuf.data();
+        const size_t n = c_hi;
+        if (n < 18 + 16) return -1;
+        uint32_t bh = 0;
+        if (member_size(p, &bh)) return -1; // BGZF: the other path
+        if (p[0] != 0x1F || p[1] != 0x8B || p[2] != 8 || (p[3] & 0xE0)) return -1;
+        const uint8_t flg = p[3];
+        size_t off = 10;
+        if (flg & 4) {
+            off += 2 + (p[off] | ((size_t)p[off + 1] << 8));
+            if (off >= n) return -1;
+        }
+        for (int bit : {8, 16})
+            if (flg & bit) {
+                const void *z = memchr(p + off, 0, n - off);
+                if (!z) return -1;
+                off = (size_t)((const uint8_t *)z - p) + 1;
+            }
+        if (flg & 2) off += 2;
+        if (off + 16 >= n) return -1;
+        std::unique_ptr<inf::Decoder> dec(new inf::Decoder());
+        dec->reset();
+        uint8_t out[2048];
+        const uint8_t *ip = p + off;
+        uint8_t *op = out;
+        const inf::Status st = dec->run(ip, p + n - 8, op, out + sizeof(out), out); // (8 readable bytes behind the end given)
+        if (st == inf::BAD || op == out) return -1;
+        *hdr_len = off;
+        return out[0];
+    }
+    // the file's bytes as they are, from where the reader stands (what the probes above buffered first)
+    size_t raw_read(uint8_t *dst, size_t cap) {
+        join_prefetch();
+        size_t n = 0;
+        if (c_hi > c_lo) {
+            n = std::min(cap, c_hi - c_lo);
+            memcpy(dst, cbuf.data() + c_lo, n);
+            c_lo += n;
+            if (c_lo == c_hi) c_lo = c_hi = 0;
+        }
+        while (n < cap && !in_eof) {
+            const size_t got = inner->read(dst + n, cap - n);
+            if (got == 0) in_eof = true;
+            n += got;
+        }
+        return n;
+    }
     // Whole members into dst: a table of n records at the front (room for max_members), the members behind it exactly as
     // they lie in the file -- the file is read straight into dst, large reads split over the source's threads, and the
     // table points at the DEFLATE bytes between each member's header and trailer.  Members are taken while the table, dst
@@ -1890,6 +1944,8 @@ static fh_params to_fh(const finch_sketch_params &sp, uint64_t max_launch, uint6
 static int pump_text_to_device(ByteSource &src, fh_sketcher *h, bool fastq, uint32_t k, struct FastxStats &st);
 static int bgzf_fastq_to_device(struct BgzfSource &bz, fh_sketcher *h);
 static std::atomic<uint64_t> g_bgzf_on_device{0}, g_bgzf_reread{0};
+static int gzip_fastq_to_device(struct BgzfSource &bz, size_t hdr_len, fh_sketcher *h);
+static std::atomic<uint64_t> g_gzip_on_device{0}, g_gzip_reread{0};
 static int fastq_text_to_device(ByteSource &src, fh_sketcher *h, uint32_t k);
 
 // Device-side FASTA (fh_push_fasta_text): the host reads raw file bytes into the pinned staging buffer, cuts chunks
@@ -2331,7 +2387,15 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
         BgzfSource *bz = dynamic_cast<BgzfSource *>(src.get());
         if (bz && !(di && di[0] == '0') && src->can_rewind() && bz->peek_first_text_byte() == '@') bgzf_dev = bz;
     }
-    if (bgzf_dev) {
+    // ... and so is plain gzip (FINCH_DEVICE_GZIP=0: on the host, by the call's read threads together, fh_pargz.h)
+    bool gzip_dev = false;
+    size_t gzip_hdr = 0;
+    if (is_gz && !dp_off && !bgzf_dev) {
+        const char *di = getenv("FINCH_DEVICE_INFLATE"), *dg = getenv("FINCH_DEVICE_GZIP");
+        BgzfSource *bz = dynamic_cast<BgzfSource *>(src.get());
+        if (bz && !(di && di[0] == '0') && !(dg && dg[0] == '0') && src->can_rewind() && bz->peek_plain_gzip(&gzip_hdr) == '@') gzip_dev = true;
+    }
+    if (bgzf_dev || gzip_dev) {
         first = '@';
     } else if (is_gz) {
         // compressed: the format shows in the first inflated byte; what follows it reaches the staging buffer straight
@@ -2363,6 +2427,18 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
         g_bgzf_reread++;
         if (int r2 = fh_reset(h)) return hfail(r2, "%s", fh_last_error());
         // (the text now comes through the host-side inflate; its first byte is known)
+    }
+    if (gzip_dev) {
+        st.format = 2;
+        const int rc = gzip_fastq_to_device(*static_cast<BgzfSource *>(src.get()), gzip_hdr, h);
+        if (rc == FH_OK) {
+            g_gzip_on_device++;
+            if (int r2 = fh_text_bases(h, &st.total_bases)) return hfail(r2, "%s", fh_last_error());
+            return finish_sketch(h, name, sp, filters, st, out);
+        }
+        if (rc != FH_ERR_INVALID || !src->rewind()) return rc;
+        g_gzip_reread++;
+        if (int r2 = fh_reset(h)) return hfail(r2, "%s", fh_last_error());
     }
     bool device_parse = !dp_off && (first == '>' || first == '@');
     if (device_parse && first == '@' && !dp_on && !src->can_rewind()) device_parse = false; // no second chance: host parser
@@ -2827,6 +2903,116 @@ static int bgzf_fastq_to_device(BgzfSource &bz, fh_sketcher *h) {
     return FH_OK;
 }
 
+// gzip-compressed FASTQ -- one DEFLATE stream -- with the inflate on the device (fh_push_gzip_fastq): the reader thread
+// moves the file's bytes into the sketcher's pinned buffers, a buffer's worth per push, while the calling thread has the
+// previous push decoded, checked, split and sketched.  Anything but one sound member of plain 4-line FASTQ whose blocks
+// fit a push (several members, trailing bytes, damage, text more than about 12 x its DEFLATE bytes) is FH_ERR_INVALID: the
+// caller reads the file again through the host-side inflate, whose verdict is the one reported.
+static int gzip_fastq_to_device(BgzfSource &bz, size_t hdr_len, fh_sketcher *h) {
+    uint8_t *raw[2] = {nullptr, nullptr};
+    uint64_t cap = 0;
+    int next = 0;
+    if (int rc = fh_text_buffers(h, raw, &cap, &next)) return hfail(rc, "%s", fh_last_error());
+    if (cap < ((uint64_t)1 << 20)) return hfail(FH_ERR_INVALID, "staging buffers too small for batches of gzip blocks");
+    { // a push's text has to fit the device-side text buffer: reads with constant quality strings compress sixfold, allow twelve
+        uint64_t text_cap = 0;
+        if (int rc = fh_bgzf_text_capacity(h, &text_cap)) return hfail(rc, "%s", fh_last_error());
+        cap = std::min<uint64_t>(cap, std::max<uint64_t>((uint64_t)1 << 20, text_cap / 12));
+    }
+    { // the member's header is the host's to skip
+        std::vector<uint8_t> skip(hdr_len);
+        if (bz.raw_read(skip.data(), hdr_len) != hdr_len) return hfail(FH_ERR_INVALID, "gzip header cut short");
+    }
+    struct Job {
+        int slot;
+        uint64_t bytes;
+        bool last;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    bool is_free[2] = {true, true}, producer_done = false;
+    std::vector<Job> ready;
+    std::atomic<bool> abort{false};
+    static const bool trace = getenv("FH_TRACE") != nullptr;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now_s();
+    double t_read = 0, t_push = 0, t_wait = 0;
+    uint64_t n_bytes = 0;
+    unsigned n_pushes = 0;
+    // (the first push is a short one, so that the device has something to do while the bulk of the file is read)
+    std::thread producer([&] {
+        int slot = next;
+        bool first = true;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return is_free[slot] || abort.load(); });
+                if (abort) break;
+                is_free[slot] = false;
+            }
+            const double t0 = trace ? now_s() : 0;
+            const uint64_t want = first ? std::min<uint64_t>(cap, (uint64_t)16 << 20) : cap;
+            first = false;
+            const size_t got = bz.raw_read(raw[slot], (size_t)want);
+            if (trace) t_read += now_s() - t0;
+            Job job{slot, got, got < want};
+            std::lock_guard<std::mutex> g(mu);
+            n_bytes += got;
+            ready.push_back(job);
+            cv.notify_all();
+            if (job.last) break;
+            slot ^= 1;
+        }
+        std::lock_guard<std::mutex> g(mu);
+        producer_done = true;
+        cv.notify_all();
+    });
+    int rc = FH_OK;
+    std::string msg;
+    bool first = true, done = false;
+    for (;;) {
+        Job job;
+        const double tw0 = trace ? now_s() : 0;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !ready.empty() || producer_done; });
+            if (ready.empty()) break;
+            job = ready.front();
+            ready.erase(ready.begin());
+        }
+        const double tw1 = trace ? now_s() : 0;
+        t_wait += tw1 - tw0;
+        if (rc == FH_OK) {
+            if (done) { // bytes behind the member's end
+                if (job.bytes) rc = FH_ERR_INVALID, msg = "more than one gzip member";
+            } else {
+                uint32_t member_done = 0;
+                uint64_t trailing = 0;
+                n_pushes++;
+                rc = fh_push_gzip_fastq(h, job.bytes, (first ? FH_GZ_FIRST : 0u) | (job.last ? FH_GZ_LAST : 0u), &member_done, &trailing);
+                first = false;
+                if (rc != FH_OK) msg = fh_last_error();
+                else if (member_done) {
+                    done = true;
+                    if (trailing) rc = FH_ERR_INVALID, msg = "more than one gzip member";
+                }
+            }
+            if (trace) t_push += now_s() - tw1;
+            if (rc != FH_OK) abort = true;
+        }
+        std::lock_guard<std::mutex> g(mu);
+        is_free[job.slot] = true;
+        cv.notify_all();
+    }
+    producer.join();
+    if (trace)
+        fprintf(stderr, "[finch] gzip on the device: %u pushes, %.1f MB in %.1f ms: reads %.1f ms, pushes took %.1f ms and waited %.1f ms for bytes\n", n_pushes,
+                n_bytes / 1e6, (now_s() - t_begin) * 1e3, t_read * 1e3, t_push * 1e3, t_wait * 1e3);
+    if (rc != FH_OK) return hfail(rc, "%s", msg.c_str());
+    if (!done) return hfail(FH_ERR_INVALID, "gzip: the stream ends before its final block");
+    return FH_OK;
+}
+
 // *device_rejected: the input is FASTQ and the device-side splitter refused a chunk of it (not strictly 4-line, a record
 // longer than a chunk): the caller sends the file through the single-handle path, whose host parser is the judge of
 // what needletail accepts.
@@ -3204,6 +3390,11 @@ extern "C" {
 void finch_debug_device_inflate(uint64_t *files_on_device, uint64_t *files_reread) {
     if (files_on_device) *files_on_device = finch::g_bgzf_on_device.load();
     if (files_reread) *files_reread = finch::g_bgzf_reread.load();
+}
+
+void finch_debug_device_gzip(uint64_t *files_on_device, uint64_t *files_reread) {
+    if (files_on_device) *files_on_device = finch::g_gzip_on_device.load();
+    if (files_reread) *files_reread = finch::g_gzip_reread.load();
 }
 
 const char *finch_last_error(void) { return g_host_err.c_str(); }

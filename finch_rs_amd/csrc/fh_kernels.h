@@ -104,6 +104,60 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfMember *members, u
                                uint32_t *status, hipStream_t st);
 // out[0]: where the last whole FASTQ record of text[0, total) ends (`last`: total); out[1]: 1 if no boundary was found
 hipError_t launch_fastq_cut(const uint8_t *text, uint32_t total, uint32_t last, uint32_t *out, hipStream_t st);
+// fh_bgzf.hip: plain gzip -- ONE DEFLATE stream, cut into chunks of `chunk_bits`, a wavefront each.  comp[0, n_bytes) are the
+// stream's bytes from bit `first_bit` of comp[0] on (+ 4096 readable bytes behind them).  A chunk's record: where its
+// first block was found (GZ_NONE: nowhere in its range), the block boundary it stopped at, the symbols it produced and why
+// it stopped.  Symbols are 16-bit: a byte, or 0x8000 + i = "byte i of the 32 KiB in front of this chunk"; chunk c's go to
+// sym[c * cap + GZ_WINDOW ...) behind GZ_WINDOW marker slots.
+constexpr uint32_t GZ_WINDOW = 32768;
+constexpr uint64_t GZ_NONE = ~0ull;
+enum GzState : uint32_t { // low byte of GzChunk::state (the reason of a failure above it: BgzfFail in fh_bgzf.hip)
+    GZ_IDLE = 0,         // never decoded (no block start in its range)
+    GZ_NEXT = 1,         // stopped where a later chunk begins
+    GZ_MEMBER_END = 2,   // the final block ended at end_bit
+    GZ_OUT_OF_INPUT = 3, // the bytes ended inside the block that begins at end_bit
+    GZ_FAILED = 4,
+};
+struct GzChunk {
+    uint64_t start_bit, end_bit;
+    uint32_t out_len, state;
+};
+// what the pass over the chain of chunks that really follow each other leaves behind (u32 words)
+enum GzSummaryWord : uint32_t {
+    GZS_STATUS = 0,   // 0, or (chunk << 8 | reason)
+    GZS_N_LIVE = 1,   // chunks on the chain
+    GZS_TOTAL = 2,    // bytes of text they hold (< 2^32)
+    GZS_END_STATE = 3, // the last one's GzState
+    GZS_END_BIT_LO = 4, GZS_END_BIT_HI = 5,
+    GZS_HAVE_TRAILER = 6, GZS_CRC_WANT = 7, GZS_ISIZE_WANT = 8, // MEMBER_END: the eight bytes behind the stream, if they are there
+    GZS_TRAILING = 9, // bytes behind the trailer
+    GZS_VALID = 10,   // bytes of the member's text known in front of the next batch (<= GZ_WINDOW)
+    GZS_CRC = 11,     // CRC-32 of this batch's text
+    GZS_CUT = 12, GZS_CUT_BAD = 13, // (launch_fastq_cut's two words)
+    GZS_WORDS = 16,
+};
+// scratch (all device memory): recs[n_chunks], sym[n_chunks * cap], win_in[n_chunks * GZ_WINDOW], live[4 * n_chunks],
+// tile_map[text_cap / 4096 + 2], crc_tmp[text_cap / 65536 + 2].  window: the text in front of the batch (GZ_WINDOW bytes, the last `valid`
+// of them real) on entry, in front of the next batch on return.  The batch's text goes to text[left ...) (`left` bytes in
+// front of it are the partial record the previous batch ended with); GZS_CUT is launch_fastq_cut's answer for text[0, left + total).
+struct GzBatch {
+    const uint8_t *comp;
+    uint64_t n_bytes, first_bit, chunk_bits;
+    uint32_t n_chunks;
+    uint64_t cap;
+    GzChunk *recs;
+    uint16_t *sym;
+    uint8_t *win_in, *window;
+    uint32_t valid;
+    uint32_t *live, *tile_map, *crc_tmp;
+    uint8_t *text;
+    uint32_t left;
+    uint64_t text_cap; // room behind text + left
+    uint32_t *summary;
+};
+hipError_t launch_gzip_batch(const GzBatch &b, hipStream_t st);
+// crc(A || B) from crc(A), crc(B) and |B| (zlib's crc32_combine)
+uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 hipError_t launch_fill_table(Entry *table, uint64_t cap, hipStream_t st);
 // (keep_text_bases: everything but the count of sequence bytes the text packers have emitted so far)
 // (sel_size / tau_floor / hist_on: the in-launch threshold refresh, Ctl in fh_device.h)

@@ -107,6 +107,7 @@ _SYMS = {
     "finch_read_file_probe": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "finch_source_probe": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "finch_debug_device_inflate": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "finch_debug_device_gzip": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "finch_bgzf_batch_probe": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
 }
@@ -410,6 +411,13 @@ def debug_device_inflate():
     """(inputs sketched with the BGZF inflate on the device, inputs re-read through the host inflate) -- test hook"""
     a, b = C.c_uint64(), C.c_uint64()
     lib().finch_debug_device_inflate(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def debug_device_gzip():
+    """(inputs sketched with plain gzip inflated on the device, inputs re-read through the host inflate) -- test hook"""
+    a, b = C.c_uint64(), C.c_uint64()
+    lib().finch_debug_device_gzip(C.byref(a), C.byref(b))
     return a.value, b.value
 
 

@@ -192,6 +192,8 @@ int finch_bgzf_batch_probe(const uint8_t *data, uint64_t len, uint64_t buf_bytes
  * finch_sketch_buffer: bgzip'd FASTQ unless FINCH_DEVICE_INFLATE=0), and how many of them it had to read again through the
  * host-side inflate because the device pass refused them. */
 void finch_debug_device_inflate(uint64_t *files_on_device, uint64_t *files_reread);
+/* the same for plain gzip files (fh_push_gzip_fastq) */
+void finch_debug_device_gzip(uint64_t *files_on_device, uint64_t *files_reread);
 
 #ifdef __cplusplus
 }
