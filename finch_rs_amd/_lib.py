@@ -47,6 +47,7 @@ SYMBOLS = {
     "fh_push_fastq_text": (C.c_int, [_P, C.c_uint64]),
     "fh_push_bgzf_fastq": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32]),
     "fh_push_gzip_fastq": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), _U64P]),
+    "fh_gzip_batch_capacity": (C.c_int, [_P, _U64P]),
     "fh_bgzf_text_capacity": (C.c_int, [_P, _U64P]),
     "fh_push_fasta_text": (C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32]),
     "fh_push_staged": (C.c_int, [_P, C.c_uint64, C.c_uint32]),

@@ -186,7 +186,7 @@ struct fh_sketcher {
     uint64_t max_range = 0; // test knob: cap on positions per range
     uint64_t tau_lo = 0;    // != 0 while a block is re-read for the hashes above a speculative threshold
     bool no_spec = false;   // test knob: disable the speculative first pass
-    uint64_t n_spec = 0, n_spec_fallback = 0;
+    uint64_t n_spec = 0, n_spec_fallback = 0, n_spec_rescaled = 0;
     // sampling pre-pass of large sketches (fh_kernels.hip, k_sample_hashes): buffers allocated on first use
     uint32_t *smp_list = nullptr, *smp_hist = nullptr, *h_smp_hist = nullptr; // tile runs; histograms (h_: pinned)
     uint64_t smp_list_cap = 0;
@@ -238,7 +238,13 @@ struct fh_sketcher {
     GzChunk *gz_recs = nullptr;
     uint8_t *gz_win_in = nullptr, *gz_window = nullptr;
     uint32_t *gz_live = nullptr, *gz_tile_map = nullptr, *gz_crc_tmp = nullptr, *gz_summary = nullptr, *h_gz_summary = nullptr;
-    uint32_t gz_chunks_cap = 0, gz_slots = 0;
+    uint32_t gz_chunks_cap = 0, gz_launched = 0; // chunks there is room for; chunks of the batch being collected that have been launched
+    uint64_t gz_chunk_alloc = 0; // the chunk size the buffers were sized for
+    uint64_t gz_cap = 0, gz_acc = 0;              // symbol slots per chunk; bytes of the batch being collected (FH_GZ_MORE)
+    uint16_t *gz_group_map = nullptr;
+    uint32_t *gz_claims = nullptr;
+    uint8_t *gz_group_win = nullptr;
+    hipEvent_t gz_copied = nullptr;
     uint64_t gz_base = 0;     // where a push's bytes land in d_comp: what the previous push left undecoded sits in front of them
     uint64_t gz_tail_len = 0; // ... that many bytes, decoding resumes at bit gz_bit of the first
     uint32_t gz_bit = 0, gz_valid = 0, gz_crc = 0;
@@ -342,6 +348,7 @@ int init_state(fh_sketcher *s, bool device_part = true) {
     s->dprev_len = 0;
     s->bgzf_left_len = 0;
     s->gz_open = false;
+    s->gz_acc = 0;
     bgzf_quiesce(s);
     for (int i = 0; i < N_STAGE; ++i) // a copy fh_text_prefetch started for a stream that was then abandoned
         if (s->stage_prefetched[i]) {
@@ -434,6 +441,7 @@ uint64_t next_range_size(const fh_sketcher *s, uint64_t remaining) {
 int check_ctl(fh_sketcher *s);
 int flush_epilogue(fh_sketcher *s);
 int recover_spec(fh_sketcher *s);
+int reread_above(fh_sketcher *s, const uint8_t *seq, uint64_t len, uint64_t base_pos, uint64_t p_begin, uint64_t p_end, uint64_t lo);
 int sketch_positions(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos, uint64_t pos, uint64_t n_pos, uint64_t lo_end);
 int big_prune(fh_sketcher *s, bool sorted = true);
 int grow_table(fh_sketcher *s, uint64_t new_live_cap);
@@ -933,7 +941,9 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
             if (spec_pos == n_pos) return FH_OK;
             pos = spec_pos;
         } else if (s->tau_lo) {
-            lo_end = spec_pos;
+            if (int rc = reread_above(s, d_seq, len, base_pos, 0, spec_pos, s->tau_lo)) return rc;
+            if (spec_pos == n_pos) return FH_OK;
+            pos = spec_pos;
         }
     }
     return sketch_positions(s, d_seq, len, base_pos, pos, n_pos, lo_end);
@@ -975,6 +985,42 @@ int sketch_positions(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_
     return FH_OK;
 }
 
+// Positions [p_begin, p_end) hold fewer than `size` distinct hashes at or below `lo` (all of them in the table, counts exact):
+// a speculative threshold that assumed every k-mer distinct, on input that repeats itself -- reads at thirty-fold coverage
+// with few errors hold a thirtieth of the distinct k-mers their length suggests.  The range is read again for the hashes above
+// `lo`: not at once for all of them (that fills the table with every distinct k-mer of the range, selection after selection:
+// 12 ms for 40 M positions where the pass itself takes 0.1), but up to a threshold scaled by how far short the count fell
+// -- the density of distinct hashes is known now --, and only if that too comes up short for everything.
+int reread_above(fh_sketcher *s, const uint8_t *seq, uint64_t len, uint64_t base_pos, uint64_t p_begin, uint64_t p_end, uint64_t lo) {
+    static const bool no_scale = getenv("FH_NO_SPEC_RESCALE") != nullptr; // A/B
+    for (int attempt = 0;; ++attempt) {
+        uint64_t hi = EMPTY64;
+        const uint64_t have = s->last_live;
+        if (!no_scale && attempt < 2 && !s->big_mode && have >= 16 && have < s->p.size) {
+            const double t = (double)lo * 4.0 * (double)s->p.size / (double)have; // about 4 x size hashes at or below it
+            if (t < 1.7e19) hi = (uint64_t)t;
+        }
+        s->tau_lo = lo;
+        if (int rc = set_tau(s, hi)) return rc;
+        if (int rc = sketch_positions(s, seq, len, base_pos, p_begin, p_end, p_end)) return rc;
+        if (int rc = drain(s)) return rc;
+        if (hi == EMPTY64) return FH_OK;
+        s->n_spec_rescaled++;
+        static const bool trace = getenv("FH_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[fh] speculation fell short (%llu of %llu hashes at or below %.3e): range read again up to %.3e\n", (unsigned long long)have,
+                           (unsigned long long)s->p.size, (double)lo, (double)hi);
+        HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size, s->max_hash, 0u, 1u, 0u, s->stream));
+        if (int rc = check_ctl(s)) return rc;
+        s->last_tau = s->h_ctl->tau;
+        s->last_live = s->h_ctl->n_live;
+        if (s->h_ctl->need_big)
+            if (int rc = big_prune(s, false)) return rc;
+        if ((uint64_t)s->last_live >= s->p.size) return FH_OK;
+        s->positions_done -= p_end - p_begin; // (the next reading of the range counts it again)
+        lo = hi;
+    }
+}
+
 // The verdict of a deferred speculation came back negative (Ctl::spec_ok == 0 after its epilogue): the speculative range
 // stopped early or found fewer than `size` hashes below its guess, and nothing that was queued behind it has run.  Take
 // the bookkeeping back, finish the range the step-by-step way (relaunches, then the re-read for the hashes above the
@@ -1005,10 +1051,7 @@ int recover_spec(fh_sketcher *s) {
     } else {
         // too few: everything <= the guess is in the table with exact counts; re-read the range for the rest
         s->n_spec_fallback++;
-        s->tau_lo = sp.tau;
-        if (int rc = set_tau(s, EMPTY64)) return rc;
-        if (int rc = sketch_positions(s, sp.range.seq, sp.range.len, sp.range.base_pos, sp.range.p_begin, sp.range.p_end, sp.range.p_end)) return rc;
-        if (int rc = drain(s)) return rc;
+        if (int rc = reread_above(s, sp.range.seq, sp.range.len, sp.range.base_pos, sp.range.p_begin, sp.range.p_end, sp.tau)) return rc;
     }
     if (queued.active)
         if (int rc = sketch_positions(s, queued.seq, queued.len, queued.base_pos, queued.p_begin, queued.p_end, 0)) return rc;
@@ -1313,7 +1356,7 @@ uint64_t handle_bytes(const fh_sketcher *s) {
     uint64_t b = (uint64_t)s->cap * (sizeof(Entry) + (s->kmer_hi ? 8 : 0)) + (uint64_t)s->live_cap * 8 + (uint64_t)s->shard_cap * N_SHARDS * 4;
     for (int i = 0; i < N_STAGE; ++i) b += 2 * s->stage_cap[i];
     if (s->bz_text_cap) b += s->bz_comp_cap + 4 * s->bz_text_cap + s->bz_text_cap / 2;
-    b += 2 * s->gz_sym_elems + (uint64_t)s->gz_chunks_cap * (GZ_WINDOW + 48);
+    b += 2 * s->gz_sym_elems + (uint64_t)s->gz_chunks_cap * (GZ_WINDOW + 48) + (s->gz_summary ? (uint64_t)GZ_GROUPS * GZ_WINDOW * 3 : 0);
     return b + (uint64_t)s->out_cap * 32 + (uint64_t)s->big_cap * 24;
 }
 bool same_params(const fh_params &a, const fh_params &b) {
@@ -1322,6 +1365,7 @@ bool same_params(const fh_params &a, const fh_params &b) {
 }
 void destroy_handle(fh_sketcher *s);
 } // namespace
+static void free_gzip_buffers(fh_sketcher *s);
 
 void fh_release_cached(void) {
     std::vector<fh_sketcher *> victims;
@@ -1343,7 +1387,7 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
                 g_pool.erase(g_pool.begin() + (long)i);
                 // fh_free left it reset; only the per-handle statistics are still the previous owner's
                 s->n_launches = s->n_relaunches = s->n_big_prunes = 0;
-                s->n_spec = s->n_spec_fallback = s->n_sampled = 0;
+                s->n_spec = s->n_spec_fallback = s->n_sampled = s->n_spec_rescaled = 0;
                 s->profiling = false;
                 // the environment knobs a handle reads at creation are the new owner's to set
                 s->no_spec = getenv("FH_NO_SPEC") != nullptr;
@@ -1533,15 +1577,7 @@ void destroy_handle(fh_sketcher *s) {
     (void)hipFree(s->d_bz_members);
     (void)hipFree(s->d_bz_status);
     (void)hipFree(s->bz_lines);
-    (void)hipFree(s->gz_sym);
-    (void)hipFree(s->gz_recs);
-    (void)hipFree(s->gz_win_in);
-    (void)hipFree(s->gz_window);
-    (void)hipFree(s->gz_live);
-    (void)hipFree(s->gz_tile_map);
-    (void)hipFree(s->gz_crc_tmp);
-    (void)hipFree(s->gz_summary);
-    if (s->h_gz_summary) (void)hipHostFree(s->h_gz_summary);
+    free_gzip_buffers(s);
     for (int i = 0; i < 2; ++i) {
         (void)hipFree(s->bz_text[i]);
         (void)hipFree(s->bz_packed[i]);
@@ -2105,49 +2141,88 @@ int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint3
     return fastq_text_on_device(s, s->bz_text[t], cut, s->bz_packed[t], s->bz_blk_a[t], s->bz_blk_b[t], s->bz_lines, s->bz_line_cap);
 }
 
-// Plain gzip of FASTQ text -- one DEFLATE stream, no index -- inflated on the device (fh_bgzf.hip: k_gz_find / k_gz_inflate /
-// k_gz_chain / k_gz_text).  A push is one batch: its bytes are cut into at most one chunk per resident wavefront, every
-// chunk is decoded from the first block start found in it, and the chain of chunks that really follow each other gives the
-// text; the bytes behind the last block boundary reached stay on the device and lead the next push, as do the 32 KiB of text a
-// match may reach back into and the partial FASTQ record the text ended with.
-constexpr uint64_t GZ_MIN_CHUNK = 32768;   // compressed bytes per chunk, at least (a level-6 block of reads is about that)
-constexpr uint64_t GZ_SYM_PER_BYTE = 24;   // symbol slots per compressed byte: text 12 x its DEFLATE bytes, chunks of uneven yield
-static int ensure_gzip_buffers(fh_sketcher *s, uint64_t n_bytes, uint32_t n_chunks) {
+// Plain gzip of FASTQ text -- one DEFLATE stream, no index -- inflated on the device (fh_bgzf.hip: k_gz_chunks, k_gz_chain,
+// k_gz_win_*, k_gz_text).  A batch is the bytes of the pushes up to and including the first one without FH_GZ_MORE: they are
+// cut into chunks of ~a block's worth, a wavefront decodes each from the first block start found in it, and the chain of
+// chunks that really continue each other gives the text.  The chunks of a piece are launched as soon as the piece behind it
+// has been queued for copying, so the device decodes while the caller reads on.  The bytes behind the last block boundary
+// reached stay on the device and lead the next batch, as do the 32 KiB of text a match may reach back into and the partial
+// FASTQ record the text ended with.
+constexpr uint64_t GZ_CHUNK_BYTES = 16384;  // compressed bytes per chunk: about a block of level-1 output (a chunk without a block start idles)
+constexpr uint64_t GZ_SYM_PER_BYTE = 12;    // symbol slots per byte of a chunk (text up to twelve times its DEFLATE bytes: a chunk that decodes on
+                                            // through the ranges behind it takes over their slots, k_gz_chunks)
+constexpr uint64_t GZ_CARRY_MAX = 4ull << 20; // undecoded bytes a batch may leave for the next
+constexpr uint64_t GZ_LOOKAHEAD = 1ull << 20; // bytes that have to be there behind a chunk before it is decoded (FH_GZ_MORE)
+static void free_gzip_buffers(fh_sketcher *s) {
+    (void)hipFree(s->gz_sym);
+    (void)hipFree(s->gz_group_map);
+    (void)hipFree(s->gz_group_win);
+    (void)hipFree(s->gz_claims);
+    s->gz_claims = nullptr;
+    if (s->gz_copied) (void)hipEventDestroy(s->gz_copied);
+    (void)hipFree(s->gz_recs);
+    (void)hipFree(s->gz_win_in);
+    (void)hipFree(s->gz_window);
+    (void)hipFree(s->gz_live);
+    (void)hipFree(s->gz_tile_map);
+    (void)hipFree(s->gz_crc_tmp);
+    (void)hipFree(s->gz_summary);
+    if (s->h_gz_summary) (void)hipHostFree(s->h_gz_summary);
+    s->gz_sym = nullptr, s->gz_group_map = nullptr, s->gz_group_win = nullptr, s->gz_copied = nullptr, s->gz_recs = nullptr;
+    s->gz_win_in = s->gz_window = nullptr;
+    s->gz_live = s->gz_tile_map = s->gz_crc_tmp = s->gz_summary = s->h_gz_summary = nullptr;
+    s->gz_sym_elems = 0;
+    s->gz_chunks_cap = 0;
+}
+static uint64_t gz_chunk_bytes(const fh_sketcher *s) {
+    if (const char *e = getenv("FH_GZ_CHUNK")) return std::max<uint64_t>(1024, strtoull(e, nullptr, 10) & ~7ull); // (tests: many chunks in a small input)
+    const uint64_t most = s->gz_base + s->stage_bytes;
+    return std::max<uint64_t>(GZ_CHUNK_BYTES, ((most + GZ_MAX_CHUNKS - 1) / GZ_MAX_CHUNKS + 4095) & ~(uint64_t)4095);
+}
+// bytes one batch may hold: what a staging buffer does, and no more than the text buffer takes at twelve times the size
+static uint64_t gz_batch_capacity(const fh_sketcher *s) {
+    return std::min<uint64_t>(s->stage_bytes, std::max<uint64_t>((uint64_t)1 << 16, s->bz_text_cap / 12));
+}
+static int ensure_gzip_buffers(fh_sketcher *s) {
     if (int rc = ensure_bgzf_buffers(s)) return rc;
-    if (!s->gz_summary) {
-        int cus = 0;
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
-        s->gz_slots = (uint32_t)std::max(1, cus) * 5u; // (k_gz_inflate: five wavefronts per SIMD's worth of LDS)
-        s->gz_base = std::min<uint64_t>((uint64_t)16 << 20, s->bz_text_cap / 4) & ~(uint64_t)255;
-        HIP_TRY(dev_malloc((void **)&s->gz_window, GZ_WINDOW));
-        HIP_TRY(dev_malloc((void **)&s->gz_tile_map, (size_t)(s->bz_text_cap / 4096 + 2) * sizeof(uint32_t)));
-        HIP_TRY(dev_malloc((void **)&s->gz_crc_tmp, (size_t)(s->bz_text_cap / 65536 + 2) * sizeof(uint32_t)));
-        HIP_TRY(host_malloc((void **)&s->h_gz_summary, GZS_WORDS * sizeof(uint32_t)));
-        HIP_TRY(dev_malloc((void **)&s->gz_summary, GZS_WORDS * sizeof(uint32_t)));
-    }
-    if (n_chunks > s->gz_chunks_cap) {
+    s->gz_base = std::min<uint64_t>(GZ_CARRY_MAX, s->bz_text_cap / 4) & ~(uint64_t)255;
+    const uint64_t chunk = gz_chunk_bytes(s);
+    if (s->gz_summary && s->gz_chunk_alloc == chunk) return FH_OK;
+    if (s->gz_summary) { // (the FH_GZ_CHUNK test knob has changed under a pooled handle: its buffers are sized by the chunk)
+        if (s->gz_acc) return fail(FH_ERR_STATE, "FH_GZ_CHUNK changed in the middle of a batch");
         HIP_TRY(hipStreamSynchronize(s->stream));
-        (void)hipFree(s->gz_recs);
-        (void)hipFree(s->gz_win_in);
-        (void)hipFree(s->gz_live);
-        s->gz_recs = nullptr, s->gz_win_in = nullptr, s->gz_live = nullptr;
-        const uint32_t want = std::min<uint32_t>(std::max<uint32_t>(n_chunks, 2 * s->gz_chunks_cap), std::max(n_chunks, s->gz_slots));
-        s->gz_chunks_cap = 0;
-        HIP_TRY(dev_malloc((void **)&s->gz_recs, (size_t)want * sizeof(GzChunk)));
-        HIP_TRY(dev_malloc((void **)&s->gz_win_in, (size_t)want * GZ_WINDOW));
-        HIP_TRY(dev_malloc((void **)&s->gz_live, (size_t)want * 4 * sizeof(uint32_t)));
-        s->gz_chunks_cap = want;
+        HIP_TRY(hipStreamSynchronize(s->copy_stream));
+        free_gzip_buffers(s);
     }
-    const uint64_t want_sym = GZ_SYM_PER_BYTE * n_bytes + (uint64_t)n_chunks * (GZ_WINDOW + 65536) + 64;
-    if (want_sym > s->gz_sym_elems) {
-        HIP_TRY(hipStreamSynchronize(s->stream));
-        (void)hipFree(s->gz_sym);
-        s->gz_sym = nullptr;
-        const uint64_t grown = std::max(want_sym, std::min<uint64_t>(2 * s->gz_sym_elems, GZ_SYM_PER_BYTE * (s->stage_bytes + s->gz_base)));
-        s->gz_sym_elems = 0;
-        HIP_TRY(dev_malloc((void **)&s->gz_sym, grown * sizeof(uint16_t)));
-        s->gz_sym_elems = grown;
-    }
+    s->gz_chunk_alloc = chunk;
+    const uint32_t n = (uint32_t)std::min<uint64_t>(GZ_MAX_CHUNKS, (s->gz_base + gz_batch_capacity(s) + chunk - 1) / chunk + 1);
+    const uint64_t cap = (GZ_WINDOW + std::max<uint64_t>(GZ_SYM_PER_BYTE * chunk, 1u << 16) + 7) & ~(uint64_t)7;
+    HIP_TRY(dev_malloc((void **)&s->gz_sym, (size_t)n * cap * sizeof(uint16_t) + 64));
+    s->gz_sym_elems = (uint64_t)n * cap;
+    s->gz_cap = cap;
+    HIP_TRY(dev_malloc((void **)&s->gz_recs, (size_t)n * sizeof(GzChunk)));
+    HIP_TRY(dev_malloc((void **)&s->gz_win_in, (size_t)n * GZ_WINDOW));
+    HIP_TRY(dev_malloc((void **)&s->gz_live, (size_t)n * 4 * sizeof(uint32_t)));
+    HIP_TRY(dev_malloc((void **)&s->gz_claims, (size_t)n * sizeof(uint32_t)));
+    s->gz_chunks_cap = n;
+    HIP_TRY(dev_malloc((void **)&s->gz_group_map, (size_t)GZ_GROUPS * GZ_WINDOW * sizeof(uint16_t)));
+    HIP_TRY(dev_malloc((void **)&s->gz_group_win, (size_t)GZ_GROUPS * GZ_WINDOW));
+    HIP_TRY(dev_malloc((void **)&s->gz_window, GZ_WINDOW));
+    HIP_TRY(dev_malloc((void **)&s->gz_tile_map, (size_t)(s->bz_text_cap / 4096 + 2) * sizeof(uint32_t)));
+    HIP_TRY(dev_malloc((void **)&s->gz_crc_tmp, (size_t)(s->bz_text_cap / 65536 + 2) * sizeof(uint32_t)));
+    HIP_TRY(host_malloc((void **)&s->h_gz_summary, GZS_WORDS * sizeof(uint32_t)));
+    if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&s->gz_copied, hipEventDisableTiming));
+    HIP_TRY(dev_malloc((void **)&s->gz_summary, GZS_WORDS * sizeof(uint32_t)));
+    return FH_OK;
+}
+
+int fh_gzip_batch_capacity(fh_sketcher *s, uint64_t *cap) {
+    if (!s || !cap) return fail(FH_ERR_INVALID, "null argument");
+    if (int rc = set_device(s)) return rc;
+    if (int rc = ensure_stage(s)) return rc;
+    if (int rc = ensure_bgzf_buffers(s)) return rc;
+    *cap = gz_batch_capacity(s);
     return FH_OK;
 }
 
@@ -2157,11 +2232,12 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
     *trailing = 0;
     if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
     if (s->proc_buf) return fail(FH_ERR_STATE, "records of fh_process are waiting in the staging buffer: fh_sync first");
-    if (bytes > s->stage_bytes) return fail(FH_ERR_INVALID, "batch longer than the staging buffer");
+    if ((flags & FH_GZ_MORE) && (flags & FH_GZ_LAST)) return fail(FH_ERR_INVALID, "FH_GZ_MORE and FH_GZ_LAST exclude each other");
     if (int rc = set_device(s)) return rc;
     if (int rc = ensure_stage(s)) return rc;
-    if (int rc = ensure_bgzf_buffers(s)) return rc;
+    if (int rc = ensure_gzip_buffers(s)) return rc;
     if (flags & FH_GZ_FIRST) {
+        if (s->gz_acc) return fail(FH_ERR_STATE, "FH_GZ_FIRST in the middle of a batch");
         s->gz_tail_len = 0;
         s->gz_bit = s->gz_valid = s->gz_crc = 0;
         s->gz_total = 0;
@@ -2170,50 +2246,78 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
     } else if (!s->gz_open) {
         return fail(FH_ERR_STATE, "no gzip member is open: the first push of one carries FH_GZ_FIRST");
     }
-    const uint64_t n_bytes = s->gz_tail_len + bytes;
+    if (s->gz_acc + bytes > gz_batch_capacity(s)) return fail(FH_ERR_INVALID, "batch longer than fh_gzip_batch_capacity");
+    const int b = s->stage_next, t = s->bz_next;
+    const uint64_t chunk_bytes = gz_chunk_bytes(s);
+    // (the carried bytes begin at a multiple of four, where fh_bgzf.hip's bit reader wants its words; the new ones follow them)
+    uint8_t *const comp = s->d_comp + s->gz_base - ((s->gz_tail_len + 3) & ~(uint64_t)3);
+    GzBatch B{};
+    B.comp = comp;
+    B.first_bit = s->gz_bit;
+    B.chunk_bits = chunk_bytes * 8u;
+    B.cap = s->gz_cap;
+    B.recs = s->gz_recs;
+    B.sym = s->gz_sym;
+    B.claims = s->gz_claims;
+    B.n_regions = s->gz_chunks_cap;
+    const bool batch_start = s->gz_acc == 0;
+    if (batch_start) {
+        if (int rc = drain(s)) return rc; // the packed buffer of this slot may still feed a pending range
+        s->gz_launched = 0;
+        HIP_TRY(hipMemsetAsync(s->gz_claims, 0, (size_t)s->gz_chunks_cap * sizeof(uint32_t), s->copy_stream));
+    }
+    const uint64_t before = s->gz_tail_len + s->gz_acc; // bytes of the batch there before this push
+    if (bytes) {
+        HIP_TRY(hipMemcpyAsync(comp + before, s->h_stage[b] + STAGE_HEADROOM + s->gz_acc, bytes, hipMemcpyHostToDevice, s->copy_stream));
+        s->gz_acc += bytes;
+    }
+    const uint64_t n_bytes = s->gz_tail_len + s->gz_acc;
+    if (flags & FH_GZ_MORE) {
+        // the chunks with a megabyte of the stream behind them (no block is that long) can be decoded: off they go
+        HIP_TRY(hipEventRecord(s->gz_copied, s->copy_stream));
+        (void)before;
+        const uint32_t upto = n_bytes > GZ_LOOKAHEAD ? (uint32_t)((n_bytes - GZ_LOOKAHEAD) / chunk_bytes) : 0u;
+        if (upto > s->gz_launched) {
+            // (each piece's chunks on a side stream of their own: launches of one stream run one after the other, and a
+            // piece's few hundred wavefronts do not fill the device)
+            const int q = s->bz_q;
+            s->bz_q = (q + 1) % fh_sketcher::BZ_STREAMS;
+            HIP_TRY(hipStreamWaitEvent(s->bz_stream[q], s->gz_copied, 0));
+            HIP_TRY(launch_gzip_chunks(B, n_bytes, s->gz_launched, upto - s->gz_launched, false, s->bz_stream[q]));
+            HIP_TRY(hipEventRecord(s->bz_done[q], s->bz_stream[q]));
+            s->bz_used[q] = true;
+            s->gz_launched = upto;
+        }
+        return FH_OK;
+    }
+    // ---- the batch is complete ----
+    s->gz_acc = 0;
     if (n_bytes == 0) {
         if (flags & FH_GZ_LAST) return fail(FH_ERR_INVALID, "gzip: the stream ends before its final block");
         return FH_OK;
     }
-    // one chunk per wavefront the device holds at once, none smaller than a typical block
-    uint64_t chunk_bytes = 0;
-    uint32_t n_chunks = 0;
-    {
-        int cus = 0;
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
-        const uint64_t slots = (uint64_t)std::max(1, cus) * 5u;
-        chunk_bytes = std::max<uint64_t>(GZ_MIN_CHUNK, ((n_bytes + slots - 1) / slots + 4095) & ~(uint64_t)4095);
-        if (const char *e = getenv("FH_GZ_CHUNK")) chunk_bytes = std::max<uint64_t>(1024, strtoull(e, nullptr, 10)); // (tests: many chunks in a small input)
-        n_chunks = (uint32_t)((n_bytes + chunk_bytes - 1) / chunk_bytes);
-    }
-    if (int rc = ensure_gzip_buffers(s, n_bytes, n_chunks)) return rc;
-    if (s->gz_tail_len > s->gz_base) return fail(FH_ERR_INVALID, "gzip: more undecoded bytes carried over than there is room for");
-    const int b = s->stage_next, t = s->bz_next;
-    if (int rc = drain(s)) return rc; // the packed buffer of this slot may still feed a pending range
-    // (the carried bytes begin at a multiple of four, where fh_bgzf.hip's bit reader wants its words; the new ones follow them)
-    uint8_t *const comp = s->d_comp + s->gz_base - ((s->gz_tail_len + 3) & ~(uint64_t)3);
-    if (bytes) {
-        HIP_TRY(hipMemcpyAsync(comp + s->gz_tail_len, s->h_stage[b] + STAGE_HEADROOM, bytes, hipMemcpyHostToDevice, s->stream));
-        HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
-        s->stage_busy[b] = true;
-        s->stage_next = (b + 1) % N_STAGE;
-    }
-    HIP_TRY(hipMemsetAsync(comp + n_bytes, 0, 256, s->stream));
+    HIP_TRY(hipMemsetAsync(comp + n_bytes, 0, 256, s->copy_stream));
+    HIP_TRY(hipEventRecord(s->stage_done[b], s->copy_stream));
+    s->stage_busy[b] = true;
+    s->stage_next = (b + 1) % N_STAGE;
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->stage_done[b], 0));
+    const uint32_t n_chunks = (uint32_t)((n_bytes + chunk_bytes - 1) / chunk_bytes);
+    if (n_chunks > s->gz_chunks_cap) return fail(FH_ERR_INVALID, "gzip: more chunks in a batch than there is room for");
+    B.n_bytes = n_bytes;
+    B.n_chunks = n_chunks;
+    HIP_TRY(launch_gzip_chunks(B, n_bytes, s->gz_launched, n_chunks - s->gz_launched, (flags & FH_GZ_LAST) != 0, s->stream));
+    for (int q = 0; q < fh_sketcher::BZ_STREAMS; ++q)
+        if (s->bz_used[q]) {
+            HIP_TRY(hipStreamWaitEvent(s->stream, s->bz_done[q], 0));
+            s->bz_used[q] = false;
+        }
     const uint64_t left = s->bgzf_left_len;
     s->bgzf_left_len = 0;
     if (left) HIP_TRY(hipMemcpyAsync(s->bz_text[t], s->bgzf_left_ptr, left, hipMemcpyDeviceToDevice, s->stream));
-    GzBatch B{};
-    B.comp = comp;
-    B.n_bytes = n_bytes;
-    B.first_bit = s->gz_bit;
-    B.chunk_bits = chunk_bytes * 8u;
-    B.n_chunks = n_chunks;
-    B.cap = (s->gz_sym_elems / n_chunks) & ~(uint64_t)7;
-    if (B.cap > 0x7FFFFFFFull) B.cap = 0x7FFFFFF8ull;
-    B.recs = s->gz_recs;
-    B.sym = s->gz_sym;
     B.win_in = s->gz_win_in;
     B.window = s->gz_window;
+    B.group_map = s->gz_group_map;
+    B.group_win = s->gz_group_win;
     B.valid = s->gz_valid;
     B.live = s->gz_live;
     B.tile_map = s->gz_tile_map;
@@ -2228,8 +2332,9 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
     s->stage_busy[b] = false;
     const uint32_t *S = s->h_gz_summary;
     if (const uint32_t st = S[GZS_STATUS]) {
-        static const char *const why[] = {"", "bad block header, or no block where one has to begin", "invalid code", "distance reaches before the start of the stream",
-                                          "more text than the buffers hold", "stream longer or shorter than its bytes", "CRC-32 differs"};
+        static const char *const why[] = {"", "bad block header, or no chunk begins where the one before it stopped", "invalid code",
+                                          "distance reaches before the start of the stream", "more text than the buffers hold",
+                                          "stream longer or shorter than its bytes", "CRC-32 differs"};
         s->gz_open = false;
         return fail(FH_ERR_INVALID, "gzip: chunk %u of the batch: %s", st >> 8, (st & 255u) < 7u ? why[st & 255u] : "corrupt");
     }
@@ -2259,12 +2364,13 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
         }
         const uint64_t from = (end_bit >> 3) & ~(uint64_t)3;
         const uint64_t rest = n_bytes - from;
-        // (no block boundary beyond the carried bytes: a block longer than a push, or bytes that are no DEFLATE stream)
+        // (no block boundary beyond the carried bytes: a block longer than a batch, or bytes that are no DEFLATE stream)
         if (from < s->gz_tail_len || (from == 0 && total == 0) || rest + 4 > s->gz_base) {
             s->gz_open = false;
             return fail(FH_ERR_INVALID, "gzip: no block boundary within a batch");
         }
-        if (rest) HIP_TRY(hipMemcpyAsync(s->d_comp + s->gz_base - ((rest + 3) & ~(uint64_t)3), comp + from, rest, hipMemcpyDeviceToDevice, s->stream));
+        // (on the copy stream: the next batch's bytes, copied there too, land right behind these)
+        if (rest) HIP_TRY(hipMemcpyAsync(s->d_comp + s->gz_base - ((rest + 3) & ~(uint64_t)3), comp + from, rest, hipMemcpyDeviceToDevice, s->copy_stream));
         s->gz_tail_len = rest;
         s->gz_bit = (uint32_t)(end_bit - from * 8u);
     }

@@ -394,9 +394,13 @@ __device__ void flush_queue(LDS &L, T *out, u32 &qn, u32 lane, bool all) {
 // following the lengths from the first one (a scalar chase of one v_readlane per symbol).  Output positions come from a
 // prefix sum over those lanes; their tokens join the queue.  mbits: bits of the member consumed (in: where the block's
 // symbols begin, out: behind its end-of-block code).  Returns 0 or the reason of failure.
-template <class LDS, class T>
+// grow(need, limit, mbits): the output would reach `need` elements, beyond `limit`: may the limit be raised (it does so)?
+struct NoGrow {
+    __device__ __forceinline__ bool operator()(u32, u32 &, u64) const { return false; }
+};
+template <class LDS, class T, class GROW = NoGrow>
 __device__ u32 block_symbols_parallel(LDS &L, const uint8_t *mbase, u64 in_bits, u32 isize, T *out, u64 &mbits_ref, u32 &pos_ref,
-                                      u32 &qn_ref, u32 lane) {
+                                      u32 &qn_ref, u32 lane, GROW grow = GROW(), u32 *limit_out = nullptr) {
     u64 mbits = mbits_ref;
     u32 pos = pos_ref, qn = qn_ref, fail = 0;
     for (;;) {
@@ -457,7 +461,7 @@ __device__ u32 block_symbols_parallel(LDS &L, const uint8_t *mbase, u64 in_bits,
             fail = BZ_BAD_MATCH_;
             break;
         }
-        if (pos + total > isize) {
+        if (pos + total > isize && !grow(pos + total, isize, mbits)) {
             fail = BZ_BAD_SIZE_;
             break;
         }
@@ -482,6 +486,7 @@ __device__ u32 block_symbols_parallel(LDS &L, const uint8_t *mbase, u64 in_bits,
     mbits_ref = mbits;
     pos_ref = pos;
     qn_ref = qn;
+    if (limit_out) *limit_out = isize;
     return fail;
 }
 
@@ -627,23 +632,169 @@ __global__ __launch_bounds__(64, 5) void k_bgzf_inflate(const uint8_t *comp, con
 
 // ---------------------------------------------------------------------------------------------------------------------
 // plain gzip: one DEFLATE stream, no index -- the two-pass scheme of pugz / rapidgzip (fh_pargz.h has it for host threads)
-// with a wavefront per chunk.
-//   k_gz_find     chunk c > 0: the first bit offset of its range that reads as the header of a non-final dynamic block --
-//                 64 offsets at a time through the cheap tests (type bits, HLIT / HDIST, a complete code-length code), the
-//                 survivors one by one through the real header parser, complete literal and distance codes, and first
-//                 symbols that are text.
-//   k_gz_inflate  every chunk with a start decodes from it into 16-bit symbols behind 32768 marker slots (what lies in front
-//                 of a chunk is unknown: a match that reaches there copies markers), block by block, until a block ends
-//                 exactly where a later chunk was found to begin (GZ_NEXT), the stream ends, or the bytes do.
-//   k_gz_chain    one workgroup walks the chunks that really follow each other: text offsets, the 32 KiB in front of each
-//                 (the previous one's tail, its markers looked up in the window before that), which text tile is whose.
+// with a wavefront per chunk of ~a block's worth of compressed bytes.
+//   k_gz_chunks   a chunk's wavefront first looks for a block start in its range: 512 bit offsets a step through the cheap
+//                 tests (the three type bits of a non-final dynamic block, HLIT / HDIST in range, a complete code-length
+//                 code: one table lookup per nine bits), the survivors collected and taken 64 at a time, a lane each, through
+//                 an exact parse of the header that stops as soon as the literal or distance code is over-subscribed, and
+//                 what is left (complete codes) one by one through the real tables and 512 symbols that have to be text.
+//                 From the start it decodes into 16-bit symbols behind 32768 marker slots (what lies in front of a chunk is
+//                 unknown: a match that reaches there copies markers), block by block, until a block boundary beyond its
+//                 range passes the very same tests -- that is where the wavefront of that range began --, the stream ends,
+//                 or the bytes do.
+//   k_gz_chain    one workgroup follows the chunks that really continue each other (a start that was none is never reached)
+//                 and lays out their text; k_gz_windows gives every one of them the 32 KiB in front of it (the tail of the
+//                 one before, its markers looked up in the window before that -- composed over groups of chunks so that the
+//                 groups run side by side).
 //   k_gz_text     symbols narrowed to bytes, markers looked up; then CRC-32 of the batch's text (k_gz_crc_*).
-// A "start" that is none costs its wavefront's work and nothing else: no chain passes through it.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-__device__ __forceinline__ bool gz_text_byte(u32 c) { return c == '\n' || c == '\r' || c == '\t' || (c >= 32u && c < 127u); }
+constexpr u32 GZ_QCAP = 448;    // candidates waiting for the exact header parse
+constexpr u64 GZ_TAIL_GUARD = 4608; // no start is looked for in the last bytes of what is there: header (<= 563 bytes) and 512 symbols (<= 3 KiB) of one must lie inside
+struct GzFindLds { // (laid over the literal table while a start is being looked for)
+    uint8_t lut[512]; // Kraft sum, in 1/128, of three 3-bit code lengths
+    u32 n;
+    u32 queue[GZ_QCAP];
+};
+static_assert(sizeof(GzFindLds) <= sizeof(u32) << LIT_BITS, "the finder's scratch lies over the literal table");
 
-// Does a non-final dynamic block with complete codes, whose first symbols are text, begin at bit `pos`?  Wave-uniform.
+__device__ __forceinline__ bool gz_text_byte(u32 c) { return c == '\n' || c == '\r' || c == '\t' || (c >= 32u && c < 127u); }
+__device__ __forceinline__ u64 gz_peek(const uint8_t *comp, u64 bit) { // >= 57 bits of the stream from bit `bit`
+    u64 a;
+    __builtin_memcpy(&a, comp + (bit >> 3), 8);
+    return a >> (u32)(bit & 7u);
+}
+__device__ void gz_fill_lut(GzFindLds &F, u32 lane) {
+    for (u32 i = lane; i < 512u; i += 64u) {
+        u32 s = 0;
+        for (u32 f = 0; f < 3u; ++f) {
+            const u32 l = (i >> (3u * f)) & 7u;
+            if (l) s += 128u >> l;
+        }
+        F.lut[i] = (uint8_t)s;
+    }
+    if (lane == 0) F.n = 0;
+    __syncthreads();
+}
+// The cheap tests of a bit offset whose three type bits read "non-final, dynamic": v = the stream's bits from it on, vh =
+// those from its bit 64 on.  HLIT / HDIST in range, and the code-length code complete (every encoder's is).
+template <bool LUT>
+__device__ __forceinline__ bool gz_stage_a(const GzFindLds *F, u64 v, u64 vh) {
+    const u32 hl = (u32)(v >> 3) & 31u, hd = (u32)(v >> 8) & 31u, hclen = ((u32)(v >> 13) & 15u) + 4u;
+    if (hl > 29u || hd > 29u) return false;
+    u64 w = (v >> 17) | (vh << 47); // the 3-bit lengths
+    w &= (1ull << (3u * hclen)) - 1ull;
+    u32 k = 0;
+    if (LUT) {
+#pragma unroll
+        for (u32 f = 0; f < 7u; ++f) k += F->lut[(u32)(w >> (9u * f)) & 511u];
+    } else {
+        for (u32 f = 0; f < 19u; ++f) {
+            const u32 l = (u32)(w >> (3u * f)) & 7u;
+            if (l) k += 128u >> l;
+        }
+    }
+    return k == 128u;
+}
+
+// The exact parse of a dynamic block's header at bit `pos`, by one lane: true if the hlit + hdist code lengths can be read
+// and describe a complete literal/length code with an end-of-block symbol and a distance code that is complete, a single
+// code or empty.  Gives up as soon as either code is over-subscribed (random bits are after some thirty lengths).
+__device__ bool gz_stage_b(const uint8_t *comp, u64 pos, u64 in_bits) {
+    const u64 v = gz_peek(comp, pos);
+    const u32 hlit = ((u32)(v >> 3) & 31u) + 257u, hdist = ((u32)(v >> 8) & 31u) + 1u, hclen = ((u32)(v >> 13) & 15u) + 4u;
+    const u64 w = gz_peek(comp, pos + 17u) & ((1ull << (3u * hclen)) - 1ull);
+    // the code-length code: field i of w is the length of symbol ORD[i]
+    constexpr u32 ORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    u32 cl[19];
+#pragma unroll
+    for (u32 i = 0; i < 19u; ++i) cl[ORD[i]] = (u32)(w >> (3u * i)) & 7u;
+    u32 cnt[8], first[8], offs[8];
+#pragma unroll
+    for (u32 l = 1; l <= 7u; ++l) {
+        u32 c = 0;
+#pragma unroll
+        for (u32 s = 0; s < 19u; ++s) c += cl[s] == l;
+        cnt[l] = c;
+    }
+    {
+        u32 code = 0, off = 0;
+#pragma unroll
+        for (u32 l = 1; l <= 7u; ++l) {
+            first[l] = code;
+            offs[l] = off;
+            code = (code + cnt[l]) << 1;
+            off += cnt[l];
+        }
+    }
+    u64 srt_lo = 0, srt_hi = 0; // the symbols in canonical order, five bits each
+    {
+        u32 k = 0;
+#pragma unroll
+        for (u32 l = 1; l <= 7u; ++l)
+#pragma unroll
+            for (u32 s = 0; s < 19u; ++s)
+                if (cl[s] == l) {
+                    if (k < 12u) srt_lo |= (u64)s << (5u * k);
+                    else srt_hi |= (u64)s << (5u * (k - 12u));
+                    k++;
+                }
+    }
+    const u32 n = hlit + hdist;
+    u64 bp = pos + 17u + 3u * hclen;
+    u32 i = 0, prev = 0, kl = 0, kd = 0, nd = 0;
+    bool eob = false;
+    while (i < n) {
+        if (bp + 64u > in_bits) return false;
+        u64 b = gz_peek(comp, bp);
+        u32 code = 0, sym = 0, used = 0;
+#pragma unroll
+        for (u32 l = 1; l <= 7u; ++l) {
+            code = (code << 1) | ((u32)(b >> (l - 1u)) & 1u);
+            const u32 idx = code - first[l];
+            if (used == 0u && idx < cnt[l]) {
+                const u32 k = offs[l] + idx;
+                sym = k < 12u ? (u32)(srt_lo >> (5u * k)) & 31u : (u32)(srt_hi >> (5u * (k - 12u))) & 31u;
+                used = l;
+            }
+        }
+        if (used == 0u) return false;
+        b >>= used;
+        bp += used;
+        u32 rep = 1, val = sym;
+        if (sym == 16u) {
+            if (i == 0u) return false;
+            rep = 3u + ((u32)b & 3u);
+            bp += 2u;
+            val = prev;
+        } else if (sym == 17u) {
+            rep = 3u + ((u32)b & 7u);
+            bp += 3u;
+            val = 0;
+        } else if (sym == 18u) {
+            rep = 11u + ((u32)b & 127u);
+            bp += 7u;
+            val = 0;
+        }
+        if (i + rep > n) return false;
+        if (val) {
+            const u32 add = 32768u >> val;
+            for (u32 r = 0; r < rep; ++r) {
+                const u32 at = i + r;
+                if (at < hlit) kl += add;
+                else kd += add, nd++;
+                if (at == 256u) eob = true;
+            }
+            if (kl > 32768u || kd > 32768u) return false;
+        }
+        prev = val;
+        i += rep;
+    }
+    return kl == 32768u && eob && (kd == 32768u || kd == 0u || (kd == 16384u && nd == 1u));
+}
+
+// Does a non-final dynamic block with complete codes, whose first symbols are text, begin at bit `pos`?  The real tables,
+// wave-uniform; overwrites the block tables (and the finder's scratch over them).
 __device__ bool gz_block_check(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 pos, u32 lane) {
     Reader r;
     rd_init(r, comp, pos >> 3, n_bytes, (pos >> 3) * 8u, lane);
@@ -673,7 +824,10 @@ __device__ bool gz_block_check(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 p
             rd_take(r, e & 15u);
             continue;
         }
-        if (kind != KIND_BASE) return (e & 15u) != 0u && sym > 0u; // end of block (an empty one tells nothing), or no such code
+        // end of block, or no such code.  (A block of a few symbols tells nothing: one bit pattern in fifty reads as "a text
+        // byte, then the end" under a random complete code.  Encoders close a block that short only at a flush, and a real
+        // one that is turned down here is simply decoded by the chunk in front of it.)
+        if (kind != KIND_BASE) return (e & 15u) != 0u && sym >= 64u;
         rd_take(r, e & 15u);
         rd_take(r, (e >> 4) & 15u);
         rd_fill(r, lane);
@@ -685,79 +839,153 @@ __device__ bool gz_block_check(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 p
     }
     return true;
 }
-} // namespace
 
-__global__ __launch_bounds__(64) void k_gz_find(const uint8_t *comp, u64 n_bytes, u64 chunk_bits, u32 n_chunks, u64 first_bit,
-                                                GzChunk *recs) {
-    __shared__ LdsGz L;
-    const u32 ci = blockIdx.x, lane = threadIdx.x;
-    if (ci >= n_chunks) return;
+__device__ __forceinline__ u32 wave_min_u32(u32 v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const u32 o = (u32)__shfl_xor((int)v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// The candidates collected so far, through the exact parse (a lane each) and the real tables (in stream order): the first
+// bit offset that passes, or GZ_NONE.  `base`: what the queue's offsets count from.
+__device__ u64 gz_flush_candidates(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 base, u32 lane) {
+    GzFindLds &F = *(GzFindLds *)L.lit;
+    __syncthreads();
+    const u32 n = F.n < GZ_QCAP ? F.n : GZ_QCAP;
+    const u64 in_bits = n_bytes * 8u;
+    u32 mine = 0xFFFFFFFFu;
+    for (u32 g = 0; g < n; g += 64u)
+        if (g + lane < n) {
+            const u32 rel = F.queue[g + lane];
+            if (rel < mine && gz_stage_b(comp, base + rel, in_bits)) mine = rel;
+        }
+    __syncthreads();
+    u64 best = GZ_NONE;
+    bool clobbered = false;
+    for (;;) {
+        const u32 mn = wave_min_u32(mine);
+        if (mn == 0xFFFFFFFFu) break;
+        clobbered = true;
+        if (gz_block_check(L, comp, n_bytes, base + mn, lane)) {
+            best = base + mn;
+            break;
+        }
+        if (mine == mn) mine = 0xFFFFFFFFu;
+    }
+    if (best == GZ_NONE) {
+        __syncthreads();
+        if (clobbered) gz_fill_lut(F, lane);
+        else if (lane == 0) F.n = 0;
+        __syncthreads();
+    }
+    return best;
+}
+
+// first bit offset in [from, to) at which a plausible block begins; GZ_NONE: nowhere.  (to <= (n_bytes - GZ_TAIL_GUARD) * 8)
+__device__ u64 gz_find_start(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 from, u64 to, u32 lane) {
+    if (from >= to) return GZ_NONE;
+    GzFindLds &F = *(GzFindLds *)L.lit;
+    gz_fill_lut(F, lane);
+    const u64 base = from & ~7ull;
     u64 found = GZ_NONE;
-    if (ci == 0u) {
-        found = first_bit;
-    } else {
-        u64 from = (u64)ci * chunk_bits;
-        if (from <= first_bit) from = first_bit + 1u;
-        // (a header and a few symbols have to fit behind a start: nothing is looked for in the last 64 bytes)
-        const u64 all = n_bytes > 64u ? (n_bytes - 64u) * 8u : 0u;
-        u64 to = (u64)(ci + 1u) * chunk_bits;
-        if (to > all) to = all;
-        for (u64 p0 = from; p0 < to && found == GZ_NONE; p0 += 64u) {
-            const u64 pos = p0 + lane;
-            bool cand = false;
-            if (pos < to) {
-                u64 a;
-                __builtin_memcpy(&a, comp + (pos >> 3), 8);
-                const u64 v = a >> (u32)(pos & 7u);
-                const u32 hl = (u32)(v >> 3) & 31u, hd = (u32)(v >> 8) & 31u, hclen = ((u32)(v >> 13) & 15u) + 4u;
-                if ((v & 7u) == 4u && hl <= 29u && hd <= 29u) {
-                    const u64 p2 = pos + 17u;
-                    u64 b;
-                    __builtin_memcpy(&b, comp + (p2 >> 3), 8);
-                    const u64 w = b >> (u32)(p2 & 7u); // 57 bits: 19 lengths of 3
-                    u32 kraft = 0;
-#pragma unroll
-                    for (u32 i = 0; i < 19u; ++i) {
-                        const u32 l = (u32)(w >> (3u * i)) & 7u;
-                        if (i < hclen && l) kraft += 128u >> l;
-                    }
-                    cand = kraft == 128u; // every encoder's code-length code is complete
-                }
-            }
-            unsigned long long mask = __ballot(cand);
-            while (mask) {
-                const u32 b = (u32)__builtin_ctzll(mask);
-                mask &= mask - 1ull;
-                if (gz_block_check(L, comp, n_bytes, p0 + b, lane)) {
-                    found = p0 + b;
-                    break;
+    for (u64 b0 = from >> 3; b0 * 8u < to && found == GZ_NONE; b0 += 64u) {
+        const u64 byte = b0 + lane;
+        if (byte * 8u < to) {
+            u64 lo, hi;
+            __builtin_memcpy(&lo, comp + byte, 8);
+            __builtin_memcpy(&hi, comp + byte + 8u, 8);
+            u32 m = (u32)(~lo & ~(lo >> 1) & (lo >> 2)) & 0xFFu; // offsets whose three bits read 0, 0, 1: non-final, dynamic
+            while (m) {
+                const u32 o = (u32)__builtin_ctz(m);
+                m &= m - 1u;
+                const u64 pos = byte * 8u + o;
+                if (pos < from || pos >= to) continue;
+                const u64 v = o ? (lo >> o) | (hi << (64u - o)) : lo;
+                if (gz_stage_a<true>(&F, v, hi >> o)) {
+                    const u32 slot = atomicAdd(&F.n, 1u);
+                    if (slot < GZ_QCAP) F.queue[slot] = (u32)(pos - base);
                 }
             }
         }
+        __syncthreads();
+        if (F.n >= 64u) found = gz_flush_candidates(L, comp, n_bytes, base, lane);
     }
-    if (lane == 0) recs[ci] = GzChunk{found, found, 0u, (u32)GZ_IDLE};
+    if (found == GZ_NONE) found = gz_flush_candidates(L, comp, n_bytes, base, lane);
+    __syncthreads();
+    return found;
 }
 
-__global__ __launch_bounds__(64, 5) void k_gz_inflate(const uint8_t *comp, u64 n_bytes, u64 chunk_bits, u32 n_chunks, GzChunk *recs,
-                                                      uint16_t *sym, u64 cap) {
+// The same verdict for ONE bit offset (a block boundary the decoder stands at): would gz_find_start stop here?
+__device__ bool gz_is_start(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 pos, u32 lane) {
+    u64 lo, hi;
+    __builtin_memcpy(&lo, comp + (pos >> 3), 8);
+    __builtin_memcpy(&hi, comp + (pos >> 3) + 8u, 8);
+    const u32 o = (u32)(pos & 7u);
+    const u64 v = o ? (lo >> o) | (hi << (64u - o)) : lo;
+    if ((v & 7u) != 4u) return false;
+    if (!gz_stage_a<false>(nullptr, v, hi >> o)) return false;
+    if (!gz_stage_b(comp, pos, n_bytes * 8u)) return false;
+    return gz_block_check(L, comp, n_bytes, pos, lane);
+}
+} // namespace
+
+// chunks [c0, c0 + gridDim.x) of the batch; comp[0, n_bytes) is what has arrived of it (`final`: all there will ever be of the
+// stream), chunk c covers bits [c, c + 1) * chunk_bits
+// A chunk's symbols go to its own stretch of the symbol buffer (`cap` slots) and on into those of the chunks behind it
+// whose ranges it has decoded all the way through: nothing on the chain begins in such a range (a boundary in it that
+// read as a start would have stopped this chunk), so the stretch is free unless a wavefront that began at a start that is
+// none has taken it -- claims[c]: 0, or 1 + the chunk that writes stretch c.
+struct GzGrow {
+    u32 ci, n_regions, *claims, *owned;
+    u64 cap, chunk_bits;
+    __device__ __forceinline__ bool operator()(u32 need, u32 &limit, u64 mbits) const {
+        while (limit < need) {
+            const u32 j = ci + *owned;
+            if (j >= n_regions || mbits < (u64)(j + 1u) * chunk_bits || limit + cap > 0x7FFFFFF0ull) return false;
+            u32 old = 0;
+            if (threadIdx.x == 0) old = atomicCAS(&claims[j], 0u, ci + 1u);
+            if (rfl(old) != 0u) return false;
+            *owned += 1u;
+            limit += (u32)cap;
+        }
+        return true;
+    }
+};
+
+__global__ __launch_bounds__(64, 5) void k_gz_chunks(const uint8_t *comp, u64 n_bytes, u64 chunk_bits, u32 c0, u64 first_bit, u32 final,
+                                                     GzChunk *recs, uint16_t *sym, u64 cap, u32 *claims, u32 n_regions) {
     __shared__ LdsGz L;
-    const u32 ci = blockIdx.x, lane = threadIdx.x;
-    if (ci >= n_chunks) return;
-    const u64 start = recs[ci].start_bit;
-    if (start == GZ_NONE) return;
+    const u32 ci = c0 + blockIdx.x, lane = threadIdx.x;
+    const u64 in_bits = n_bytes * 8u;
+    const u64 search_end = n_bytes > GZ_TAIL_GUARD ? (n_bytes - GZ_TAIL_GUARD) * 8u : 0u; // no start is looked for beyond
+    const u64 range_end = (u64)(ci + 1u) * chunk_bits;
+    u64 start;
+    if (ci == 0u) {
+        start = first_bit;
+    } else {
+        u64 from = (u64)ci * chunk_bits;
+        if (from <= first_bit) from = first_bit + 1u;
+        start = gz_find_start(L, comp, n_bytes, from, range_end < search_end ? range_end : search_end, lane);
+    }
+    if (start == GZ_NONE) {
+        if (lane == 0) recs[ci] = GzChunk{GZ_NONE, GZ_NONE, 0u, (u32)GZ_IDLE};
+        return;
+    }
+    {
+        u32 old = 0;
+        if (lane == 0) old = atomicCAS(&claims[ci], 0u, ci + 1u);
+        if (rfl(old) != 0u) { // (its stretch of the symbol buffer holds the overflow of a chunk in front of it)
+            if (lane == 0) recs[ci] = GzChunk{start, start, 0u, (u32)GZ_FAILED | ((u32)BZ_BAD_SIZE << 8)};
+            return;
+        }
+    }
     uint16_t *out = sym + (u64)ci * cap;
     for (u32 j = lane; j < GZ_WINDOW / 2u; j += 64u) ((u32 *)out)[j] = (0x8000u | (2u * j)) | ((0x8001u | (2u * j)) << 16);
     __syncthreads();
-    const u64 in_bits = n_bytes * 8u;
-    // room: this chunk's share of the symbol buffer and those of the chunks behind it in which no start was found (a chunk
-    // that decodes through their ranges produces their text as well)
-    u32 limit;
-    {
-        u32 j = ci + 1u;
-        while (j < n_chunks && recs[j].start_bit == GZ_NONE) j++;
-        const u64 room = (u64)(j - ci) * cap;
-        limit = room > 0x7FFFFFF0ull ? 0x7FFFFFF0u : (u32)room;
-    }
+    u32 limit = cap > 0x7FFFFFF0ull ? 0x7FFFFFF0u : (u32)cap, owned = 1;
+    const GzGrow grow{ci, n_regions, claims, &owned, cap, chunk_bits};
     Reader r;
     rd_init(r, comp, start >> 3, n_bytes, (start >> 3) * 8u, lane);
     rd_fill(r, lane);
@@ -765,6 +993,7 @@ __global__ __launch_bounds__(64, 5) void k_gz_inflate(const uint8_t *comp, u64 n
     u32 fail = 0, state = GZ_FAILED, pos = GZ_WINDOW, qn = 0;
     u64 end_bit = start, fail_at = 0;
     u32 end_pos = pos;
+    bool first_block = true;
     for (;;) {
         // a block boundary: what has been decoded up to here stands whatever becomes of the next block
         end_bit = rd_used_bits(r);
@@ -773,6 +1002,22 @@ __global__ __launch_bounds__(64, 5) void k_gz_inflate(const uint8_t *comp, u64 n
             state = GZ_OUT_OF_INPUT;
             break;
         }
+        if (!first_block && end_bit >= range_end) {
+            // beyond this chunk's range: the wavefront of the range this boundary lies in began here if it reads as a start
+            if (end_bit >= search_end) {
+                if (!final) { // (nobody looks for starts this close to the end of what is there)
+                    state = GZ_OUT_OF_INPUT;
+                    break;
+                }
+            } else {
+                flush_queue(L, out, qn, lane, true); // (the tests overwrite the tables and the queue's LDS neighbours)
+                if (gz_is_start(L, comp, n_bytes, end_bit, lane)) {
+                    state = GZ_NEXT;
+                    break;
+                }
+            }
+        }
+        first_block = false;
         rd_fill(r, lane);
         const bool final_block = rd_take(r, 1) != 0u;
         const u32 type = rd_take(r, 2);
@@ -795,7 +1040,7 @@ __global__ __launch_bounds__(64, 5) void k_gz_inflate(const uint8_t *comp, u64 n
                 fail_at = used * 8u;
                 break;
             }
-            if ((u64)pos + len > limit) {
+            if ((u64)pos + len > limit && !grow(pos + len, limit, (used + len) * 8u)) {
                 fail = BZ_BAD_SIZE;
                 break;
             }
@@ -825,7 +1070,7 @@ __global__ __launch_bounds__(64, 5) void k_gz_inflate(const uint8_t *comp, u64 n
             }
             pair_literals(L.lit, lane);
             u64 mb = rd_used_bits(r);
-            fail = block_symbols_parallel(L, comp, in_bits, limit, out, mb, pos, qn, lane);
+            fail = block_symbols_parallel(L, comp, in_bits, limit, out, mb, pos, qn, lane, grow, &limit);
             if (fail) {
                 fail_at = mb;
                 break;
@@ -845,11 +1090,6 @@ __global__ __launch_bounds__(64, 5) void k_gz_inflate(const uint8_t *comp, u64 n
             state = GZ_MEMBER_END;
             break;
         }
-        const u64 j = b / chunk_bits;
-        if (j > ci && j < n_chunks && recs[j].start_bit == b) {
-            state = GZ_NEXT;
-            break;
-        }
     }
     if (fail) {
         // (what was decoded from the padding behind the last byte proves nothing: the block is cut short by the batch's end)
@@ -857,11 +1097,7 @@ __global__ __launch_bounds__(64, 5) void k_gz_inflate(const uint8_t *comp, u64 n
         else state = (u32)GZ_FAILED | (fail << 8);
     }
     flush_queue(L, out, qn, lane, true);
-    if (lane == 0) {
-        recs[ci].end_bit = end_bit;
-        recs[ci].out_len = end_pos - GZ_WINDOW;
-        recs[ci].state = state;
-    }
+    if (lane == 0) recs[ci] = GzChunk{start, end_bit, end_pos - GZ_WINDOW, state};
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -985,94 +1221,101 @@ __global__ __launch_bounds__(64) void k_fastq_cut(const uint8_t *text, u32 total
 // plain gzip, second half: the chain of chunks, markers looked up, the text's CRC-32
 // ---------------------------------------------------------------------------------------------------------------------
 // live[4 * i ..]: chunk index, symbols, text offset, bytes of real text in front of it (<= GZ_WINDOW)
+__device__ __forceinline__ void lds_barrier() { // (not __syncthreads: loads of the next tail stay in flight across it)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+constexpr u32 GZC_END_MEMBER = 0xFFFFFFF1u, GZC_END_INPUT = 0xFFFFFFF2u, GZC_BROKEN = 0xFFFFFFF3u, GZC_FAILED = 0xFFFFFFF4u;
+
 __global__ __launch_bounds__(1024) void k_gz_chain(GzBatch B) {
-    __shared__ uint8_t W[GZ_WINDOW];
-    __shared__ u32 s_stop;
+    __shared__ u32 nxt[GZ_MAX_CHUNKS]; // the chunk that continues chunk c, or why none does
+    __shared__ u32 part[1024];
+    __shared__ u32 s_n, s_status, s_kind, s_last;
     const u32 tid = threadIdx.x;
-    {
-        const uint4 *src = (const uint4 *)B.window;
-        uint4 *dst = (uint4 *)W;
-        dst[tid] = src[tid];
-        dst[tid + 1024u] = src[tid + 1024u];
+    for (u32 c = tid; c < B.n_chunks; c += 1024u) {
+        const GzChunk r = B.recs[c];
+        const u32 kind = r.state & 255u;
+        u32 v = GZC_BROKEN;
+        if (kind == GZ_NEXT) {
+            const u64 j = r.end_bit / B.chunk_bits;
+            if (j > c && j < B.n_chunks && B.recs[j].start_bit == r.end_bit) v = (u32)j;
+        } else if (kind == GZ_MEMBER_END) {
+            v = GZC_END_MEMBER;
+        } else if (kind == GZ_OUT_OF_INPUT) {
+            v = GZC_END_INPUT;
+        } else if (kind == GZ_FAILED) {
+            v = GZC_FAILED;
+        }
+        nxt[c] = v;
     }
     __syncthreads();
-    u32 ci = 0, n = 0, status = 0, valid = B.valid, kind = GZ_IDLE;
-    u64 off = 0, end_bit = 0;
-    for (;;) {
-        const GzChunk c = B.recs[ci];
-        kind = c.state & 255u;
-        end_bit = c.end_bit;
-        if (kind == GZ_IDLE || kind == GZ_FAILED) {
-            status = (ci << 8) | (kind == GZ_FAILED ? ((c.state >> 8) & 255u) : (u32)BZ_BAD_BLOCK);
-            break;
-        }
-        if (off + c.out_len > B.text_cap) {
-            status = (ci << 8) | (u32)BZ_BAD_SIZE;
-            break;
-        }
-        { // the window in front of this chunk
-            uint4 *dst = (uint4 *)(B.win_in + (u64)ci * GZ_WINDOW);
-            const uint4 *src = (const uint4 *)W;
-            dst[tid] = src[tid];
-            dst[tid + 1024u] = src[tid + 1024u];
-        }
-        if (tid == 0) {
-            B.live[4u * n] = ci;
-            B.live[4u * n + 1u] = c.out_len;
-            B.live[4u * n + 2u] = (u32)off;
-            B.live[4u * n + 3u] = valid;
-        }
-        for (u64 t = (off + 4095u) / 4096u + tid; t < (off + c.out_len + 4095u) / 4096u; t += 1024u) B.tile_map[t] = n;
-        // the window behind it: the last GZ_WINDOW of [marker slots | symbols], markers looked up
-        const uint16_t *tail = B.sym + (u64)ci * B.cap + c.out_len;
-        u32 packed[8];
-        {
-            uint4 raw[4];
-#pragma unroll
-            for (u32 q = 0; q < 4u; ++q) __builtin_memcpy(&raw[q], tail + tid * 32u + q * 8u, 16);
-            const uint16_t *e = (const uint16_t *)raw;
-#pragma unroll
-            for (u32 q = 0; q < 8u; ++q) {
-                u32 w = 0;
-#pragma unroll
-                for (u32 z = 0; z < 4u; ++z) {
-                    const u32 v = e[q * 4u + z];
-                    w |= (v < 256u ? v : (u32)W[v & 0x7FFFu]) << (8u * z);
-                }
-                packed[q] = w;
+    if (tid == 0) {
+        u32 c = 0, n = 0, status = 0, kind = GZ_IDLE;
+        for (;;) {
+            B.live[4u * n] = c;
+            n++;
+            const u32 v = nxt[c];
+            if (v < B.n_chunks) {
+                c = v;
+                continue;
             }
-        }
-        __syncthreads();
-#pragma unroll
-        for (u32 q = 0; q < 8u; ++q) ((u32 *)W)[tid * 8u + q] = packed[q];
-        __syncthreads();
-        off += c.out_len;
-        valid = (u64)valid + c.out_len > GZ_WINDOW ? GZ_WINDOW : valid + c.out_len;
-        n++;
-        if (kind != GZ_NEXT) break;
-        const u64 nx = c.end_bit / B.chunk_bits;
-        if (nx <= ci || nx >= B.n_chunks) { // (k_gz_inflate stops with GZ_NEXT only at a later chunk's start)
-            status = (ci << 8) | (u32)BZ_BAD_BLOCK;
+            if (v == GZC_END_MEMBER) kind = GZ_MEMBER_END;
+            else if (v == GZC_END_INPUT) kind = GZ_OUT_OF_INPUT;
+            else status = (c << 8) | (v == GZC_FAILED ? ((B.recs[c].state >> 8) & 255u) : (u32)BZ_BAD_BLOCK);
             break;
         }
-        ci = (u32)nx;
+        s_n = n;
+        s_status = status;
+        s_kind = kind;
+        s_last = c;
     }
-    (void)s_stop;
-    {
-        uint4 *dst = (uint4 *)B.window;
-        const uint4 *src = (const uint4 *)W;
-        dst[tid] = src[tid];
-        dst[tid + 1024u] = src[tid + 1024u];
+    __syncthreads();
+    const u32 n = s_n;
+    // text offsets: a prefix sum over the chain, eight chunks a thread
+    u32 len[8], sum = 0;
+#pragma unroll
+    for (u32 q = 0; q < 8u; ++q) {
+        const u32 i = tid * 8u + q;
+        len[q] = i < n ? B.recs[B.live[4u * i]].out_len : 0u;
+        sum += len[q];
+    }
+    part[tid] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 1024u; d <<= 1) {
+        const u32 v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    const u64 total = part[1023];
+    u32 status = s_status;
+    if (!status && total > B.text_cap) status = (s_last << 8) | (u32)BZ_BAD_SIZE;
+    if (!status) {
+        u32 off = part[tid] - sum;
+#pragma unroll
+        for (u32 q = 0; q < 8u; ++q) {
+            const u32 i = tid * 8u + q;
+            if (i < n) {
+                B.live[4u * i + 1u] = len[q];
+                B.live[4u * i + 2u] = off;
+                const u64 valid = (u64)B.valid + off;
+                B.live[4u * i + 3u] = valid > GZ_WINDOW ? GZ_WINDOW : (u32)valid;
+                for (u32 t = (off + 4095u) / 4096u; t < (u32)(((u64)off + len[q] + 4095u) / 4096u); ++t) B.tile_map[t] = i;
+            }
+            off += len[q];
+        }
     }
     if (tid == 0) {
         u32 *S = B.summary;
+        const u64 end_bit = B.recs[s_last].end_bit;
+        const u32 kind = s_kind;
         S[GZS_STATUS] = status;
         S[GZS_N_LIVE] = n;
-        S[GZS_TOTAL] = (u32)off;
+        S[GZS_TOTAL] = (u32)total;
         S[GZS_END_STATE] = kind;
         S[GZS_END_BIT_LO] = (u32)end_bit;
         S[GZS_END_BIT_HI] = (u32)(end_bit >> 32);
-        S[GZS_VALID] = valid;
+        const u64 valid = (u64)B.valid + total;
+        S[GZS_VALID] = valid > GZ_WINDOW ? GZ_WINDOW : (u32)valid;
         u32 have = 0, crc = 0, isize = 0, trailing = 0;
         if (kind == GZ_MEMBER_END) {
             const u64 t = (end_bit + 7u) >> 3;
@@ -1088,6 +1331,139 @@ __global__ __launch_bounds__(1024) void k_gz_chain(GzBatch B) {
         S[GZS_CRC_WANT] = crc;
         S[GZS_ISIZE_WANT] = isize;
         S[GZS_TRAILING] = trailing;
+    }
+}
+
+// The window in front of every chunk on the chain = the last GZ_WINDOW symbols of [marker slots | symbols] of the one before
+// it, markers looked up in THAT one's window: a chain of 32768-entry maps.  Composed in three passes so that GZ_GROUPS
+// stretches of the chain run side by side: (1) every group's chunks composed into one map from "window in front of the
+// group" to "window behind it" (16-bit entries: a byte, or a marker into the group's input), (2) one workgroup walks the
+// groups, (3) every group again, from its now known input window, leaving each chunk's window behind.
+__device__ __forceinline__ void gz_group_range(const GzBatch &B, u32 g, u32 &lo, u32 &hi) {
+    const u32 n = B.summary[GZS_N_LIVE];
+    const u32 per = (n + GZ_GROUPS - 1u) / GZ_GROUPS;
+    lo = g * per < n ? g * per : n;
+    hi = lo + per < n ? lo + per : n;
+}
+// 32 consecutive tail symbols of a chunk for this thread
+struct GzTail { uint4 raw[4]; };
+__device__ __forceinline__ GzTail gz_load_tail(const GzBatch &B, u32 li, u32 tid) {
+    const u32 ci = B.live[4u * li], len = B.live[4u * li + 1u];
+    const uint16_t *tail = B.sym + (u64)ci * B.cap + len;
+    GzTail t;
+#pragma unroll
+    for (u32 q = 0; q < 4u; ++q) __builtin_memcpy(&t.raw[q], tail + tid * 32u + q * 8u, 16);
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void k_gz_win_compose(GzBatch B) {
+    __shared__ uint16_t M[GZ_WINDOW];
+    if (B.summary[GZS_STATUS]) return;
+    const u32 tid = threadIdx.x, g = blockIdx.x;
+    u32 lo, hi;
+    gz_group_range(B, g, lo, hi);
+#pragma unroll
+    for (u32 q = 0; q < 32u; ++q) M[tid * 32u + q] = (uint16_t)(0x8000u | (tid * 32u + q));
+    lds_barrier();
+    GzTail nx{};
+    if (lo < hi) nx = gz_load_tail(B, lo, tid);
+    for (u32 li = lo; li < hi; ++li) {
+        const GzTail cur = nx;
+        if (li + 1u < hi) nx = gz_load_tail(B, li + 1u, tid);
+        const uint16_t *e = (const uint16_t *)cur.raw;
+        u32 packed[16];
+#pragma unroll
+        for (u32 q = 0; q < 16u; ++q) {
+            const u32 a = e[2u * q], b = e[2u * q + 1u];
+            const u32 ra = a < 256u ? a : (u32)M[a & 0x7FFFu], rb = b < 256u ? b : (u32)M[b & 0x7FFFu];
+            packed[q] = ra | (rb << 16);
+        }
+        lds_barrier();
+#pragma unroll
+        for (u32 q = 0; q < 16u; ++q) ((u32 *)M)[tid * 16u + q] = packed[q];
+        lds_barrier();
+    }
+    uint4 *dst = (uint4 *)(B.group_map + (u64)g * GZ_WINDOW);
+    const uint4 *src = (const uint4 *)M;
+#pragma unroll
+    for (u32 q = 0; q < 4u; ++q) dst[tid * 4u + q] = src[tid * 4u + q];
+}
+
+__global__ __launch_bounds__(1024) void k_gz_win_groups(GzBatch B) {
+    __shared__ uint8_t W[GZ_WINDOW];
+    if (B.summary[GZS_STATUS]) return;
+    const u32 tid = threadIdx.x;
+    ((uint4 *)W)[tid] = ((const uint4 *)B.window)[tid];
+    ((uint4 *)W)[tid + 1024u] = ((const uint4 *)B.window)[tid + 1024u];
+    lds_barrier();
+    for (u32 g = 0; g < GZ_GROUPS; ++g) {
+        uint4 *dst = (uint4 *)(B.group_win + (u64)g * GZ_WINDOW);
+        dst[tid] = ((const uint4 *)W)[tid];
+        dst[tid + 1024u] = ((const uint4 *)W)[tid + 1024u];
+        uint4 raw[4];
+        const uint16_t *m = B.group_map + (u64)g * GZ_WINDOW + tid * 32u;
+#pragma unroll
+        for (u32 q = 0; q < 4u; ++q) raw[q] = ((const uint4 *)m)[q];
+        const uint16_t *e = (const uint16_t *)raw;
+        u32 packed[8];
+#pragma unroll
+        for (u32 q = 0; q < 8u; ++q) {
+            u32 w = 0;
+#pragma unroll
+            for (u32 z = 0; z < 4u; ++z) {
+                const u32 v = e[q * 4u + z];
+                w |= (v < 256u ? v : (u32)W[v & 0x7FFFu]) << (8u * z);
+            }
+            packed[q] = w;
+        }
+        lds_barrier();
+#pragma unroll
+        for (u32 q = 0; q < 8u; ++q) ((u32 *)W)[tid * 8u + q] = packed[q];
+        lds_barrier();
+    }
+    ((uint4 *)B.window)[tid] = ((const uint4 *)W)[tid];
+    ((uint4 *)B.window)[tid + 1024u] = ((const uint4 *)W)[tid + 1024u];
+}
+
+__global__ __launch_bounds__(1024) void k_gz_win_chunks(GzBatch B) {
+    __shared__ uint8_t W[GZ_WINDOW];
+    if (B.summary[GZS_STATUS]) return;
+    const u32 tid = threadIdx.x, g = blockIdx.x;
+    u32 lo, hi;
+    gz_group_range(B, g, lo, hi);
+    if (lo >= hi) return;
+    {
+        const uint4 *src = (const uint4 *)(B.group_win + (u64)g * GZ_WINDOW);
+        ((uint4 *)W)[tid] = src[tid];
+        ((uint4 *)W)[tid + 1024u] = src[tid + 1024u];
+    }
+    lds_barrier();
+    GzTail nx = gz_load_tail(B, lo, tid);
+    for (u32 li = lo; li < hi; ++li) {
+        const GzTail cur = nx;
+        if (li + 1u < hi) nx = gz_load_tail(B, li + 1u, tid);
+        { // the window in front of this chunk
+            uint4 *dst = (uint4 *)(B.win_in + (u64)B.live[4u * li] * GZ_WINDOW);
+            dst[tid] = ((const uint4 *)W)[tid];
+            dst[tid + 1024u] = ((const uint4 *)W)[tid + 1024u];
+        }
+        if (li + 1u == hi) break; // (the window behind the group's last chunk is the next group's: pass 2 has it)
+        const uint16_t *e = (const uint16_t *)cur.raw;
+        u32 packed[8];
+#pragma unroll
+        for (u32 q = 0; q < 8u; ++q) {
+            u32 w = 0;
+#pragma unroll
+            for (u32 z = 0; z < 4u; ++z) {
+                const u32 v = e[q * 4u + z];
+                w |= (v < 256u ? v : (u32)W[v & 0x7FFFu]) << (8u * z);
+            }
+            packed[q] = w;
+        }
+        lds_barrier();
+#pragma unroll
+        for (u32 q = 0; q < 8u; ++q) ((u32 *)W)[tid * 8u + q] = packed[q];
+        lds_barrier();
     }
 }
 
@@ -1234,11 +1610,19 @@ uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
     return crc_multmodp(p, crc_a) ^ crc_b;
 }
 
+hipError_t launch_gzip_chunks(const GzBatch &b, uint64_t avail_bytes, uint32_t c0, uint32_t n, bool final, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gz_chunks, dim3(n), dim3(64), 0, st, b.comp, avail_bytes, b.chunk_bits, c0, b.first_bit, final ? 1u : 0u, b.recs, b.sym,
+                       b.cap, b.claims, b.n_regions);
+    return hipGetLastError();
+}
+
 hipError_t launch_gzip_batch(const GzBatch &b, hipStream_t st) {
-    if (b.n_chunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_gz_find, dim3(b.n_chunks), dim3(64), 0, st, b.comp, b.n_bytes, b.chunk_bits, b.n_chunks, b.first_bit, b.recs);
-    hipLaunchKernelGGL(k_gz_inflate, dim3(b.n_chunks), dim3(64), 0, st, b.comp, b.n_bytes, b.chunk_bits, b.n_chunks, b.recs, b.sym, b.cap);
+    if (b.n_chunks == 0 || b.n_chunks > GZ_MAX_CHUNKS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_gz_chain, dim3(1), dim3(1024), 0, st, b);
+    hipLaunchKernelGGL(k_gz_win_compose, dim3(GZ_GROUPS), dim3(1024), 0, st, b);
+    hipLaunchKernelGGL(k_gz_win_groups, dim3(1), dim3(1024), 0, st, b);
+    hipLaunchKernelGGL(k_gz_win_chunks, dim3(GZ_GROUPS), dim3(1024), 0, st, b);
     const u32 n_tiles = (u32)((b.text_cap + 4095u) / 4096u);
     hipLaunchKernelGGL(k_gz_text, dim3(n_tiles), dim3(256), 0, st, b);
     const u32 n_slices = (u32)((b.text_cap + 65535u) / 65536u);

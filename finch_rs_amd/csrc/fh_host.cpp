@@ -2436,6 +2436,10 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
             if (int r2 = fh_text_bases(h, &st.total_bases)) return hfail(r2, "%s", fh_last_error());
             return finish_sketch(h, name, sp, filters, st, out);
         }
+        { // FINCH_DEVICE_GZIP=1: the device pass or nothing (its refusals stay loud)
+            const char *dg = getenv("FINCH_DEVICE_GZIP");
+            if (dg && dg[0] == '1') return rc;
+        }
         if (rc != FH_ERR_INVALID || !src->rewind()) return rc;
         g_gzip_reread++;
         if (int r2 = fh_reset(h)) return hfail(r2, "%s", fh_last_error());
@@ -2910,23 +2914,26 @@ static int bgzf_fastq_to_device(BgzfSource &bz, fh_sketcher *h) {
 // caller reads the file again through the host-side inflate, whose verdict is the one reported.
 static int gzip_fastq_to_device(BgzfSource &bz, size_t hdr_len, fh_sketcher *h) {
     uint8_t *raw[2] = {nullptr, nullptr};
-    uint64_t cap = 0;
+    uint64_t buf_cap = 0, cap = 0;
     int next = 0;
-    if (int rc = fh_text_buffers(h, raw, &cap, &next)) return hfail(rc, "%s", fh_last_error());
-    if (cap < ((uint64_t)1 << 20)) return hfail(FH_ERR_INVALID, "staging buffers too small for batches of gzip blocks");
-    { // a push's text has to fit the device-side text buffer: reads with constant quality strings compress sixfold, allow twelve
-        uint64_t text_cap = 0;
-        if (int rc = fh_bgzf_text_capacity(h, &text_cap)) return hfail(rc, "%s", fh_last_error());
-        cap = std::min<uint64_t>(cap, std::max<uint64_t>((uint64_t)1 << 20, text_cap / 12));
-    }
+    if (int rc = fh_text_buffers(h, raw, &buf_cap, &next)) return hfail(rc, "%s", fh_last_error());
+    if (int rc = fh_gzip_batch_capacity(h, &cap)) return hfail(rc, "%s", fh_last_error());
+    cap = std::min(cap, buf_cap);
+    if (cap < ((uint64_t)1 << 16)) return hfail(FH_ERR_INVALID, "staging buffers too small for batches of gzip blocks");
     { // the member's header is the host's to skip
         std::vector<uint8_t> skip(hdr_len);
         if (bz.raw_read(skip.data(), hdr_len) != hdr_len) return hfail(FH_ERR_INVALID, "gzip header cut short");
     }
+    // A batch fills one buffer, in pieces: every piece is handed over as soon as it has been read (FH_GZ_MORE), so that the
+    // device decodes the front of the batch while the rest of it is still coming in.
+    static const uint64_t PIECE = [] {
+        const char *e = getenv("FINCH_GZIP_PIECE"); // (A/B)
+        return e ? std::max<uint64_t>(65536, strtoull(e, nullptr, 10)) : ((uint64_t)8 << 20);
+    }();
     struct Job {
         int slot;
         uint64_t bytes;
-        bool last;
+        bool more, last;
     };
     std::mutex mu;
     std::condition_variable cv;
@@ -2938,30 +2945,37 @@ static int gzip_fastq_to_device(BgzfSource &bz, size_t hdr_len, fh_sketcher *h) 
     const double t_begin = now_s();
     double t_read = 0, t_push = 0, t_wait = 0;
     uint64_t n_bytes = 0;
-    unsigned n_pushes = 0;
-    // (the first push is a short one, so that the device has something to do while the bulk of the file is read)
+    unsigned n_pushes = 0, n_batches = 0;
     std::thread producer([&] {
         int slot = next;
-        bool first = true;
+        uint64_t acc = 0;
         for (;;) {
-            {
+            if (acc == 0) {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return is_free[slot] || abort.load(); });
                 if (abort) break;
                 is_free[slot] = false;
+            } else if (abort) {
+                break;
             }
             const double t0 = trace ? now_s() : 0;
-            const uint64_t want = first ? std::min<uint64_t>(cap, (uint64_t)16 << 20) : cap;
-            first = false;
-            const size_t got = bz.raw_read(raw[slot], (size_t)want);
+            const uint64_t want = std::min<uint64_t>(PIECE, cap - acc);
+            const size_t got = bz.raw_read(raw[slot] + acc, (size_t)want);
             if (trace) t_read += now_s() - t0;
-            Job job{slot, got, got < want};
-            std::lock_guard<std::mutex> g(mu);
-            n_bytes += got;
-            ready.push_back(job);
-            cv.notify_all();
-            if (job.last) break;
-            slot ^= 1;
+            acc += got;
+            const bool eof = got < want;
+            Job job{slot, got, !eof && cap - acc >= ((uint64_t)1 << 16), eof};
+            {
+                std::lock_guard<std::mutex> g(mu);
+                n_bytes += got;
+                ready.push_back(job);
+                cv.notify_all();
+            }
+            if (eof) break;
+            if (!job.more) {
+                slot ^= 1;
+                acc = 0;
+            }
         }
         std::lock_guard<std::mutex> g(mu);
         producer_done = true;
@@ -2989,7 +3003,9 @@ static int gzip_fastq_to_device(BgzfSource &bz, size_t hdr_len, fh_sketcher *h) 
                 uint32_t member_done = 0;
                 uint64_t trailing = 0;
                 n_pushes++;
-                rc = fh_push_gzip_fastq(h, job.bytes, (first ? FH_GZ_FIRST : 0u) | (job.last ? FH_GZ_LAST : 0u), &member_done, &trailing);
+                n_batches += !job.more;
+                rc = fh_push_gzip_fastq(h, job.bytes, (first ? FH_GZ_FIRST : 0u) | (job.more ? FH_GZ_MORE : 0u) | (job.last ? FH_GZ_LAST : 0u), &member_done,
+                                        &trailing);
                 first = false;
                 if (rc != FH_OK) msg = fh_last_error();
                 else if (member_done) {
@@ -3000,14 +3016,19 @@ static int gzip_fastq_to_device(BgzfSource &bz, size_t hdr_len, fh_sketcher *h) 
             if (trace) t_push += now_s() - tw1;
             if (rc != FH_OK) abort = true;
         }
-        std::lock_guard<std::mutex> g(mu);
-        is_free[job.slot] = true;
-        cv.notify_all();
+        if (!job.more) {
+            std::lock_guard<std::mutex> g(mu);
+            is_free[job.slot] = true;
+            cv.notify_all();
+        } else if (rc != FH_OK) {
+            std::lock_guard<std::mutex> g(mu);
+            cv.notify_all();
+        }
     }
     producer.join();
     if (trace)
-        fprintf(stderr, "[finch] gzip on the device: %u pushes, %.1f MB in %.1f ms: reads %.1f ms, pushes took %.1f ms and waited %.1f ms for bytes\n", n_pushes,
-                n_bytes / 1e6, (now_s() - t_begin) * 1e3, t_read * 1e3, t_push * 1e3, t_wait * 1e3);
+        fprintf(stderr, "[finch] gzip on the device: %u batches in %u pushes, %.1f MB in %.1f ms: reads %.1f ms, pushes took %.1f ms and waited %.1f ms for bytes\n",
+                n_batches, n_pushes, n_bytes / 1e6, (now_s() - t_begin) * 1e3, t_read * 1e3, t_push * 1e3, t_wait * 1e3);
     if (rc != FH_OK) return hfail(rc, "%s", msg.c_str());
     if (!done) return hfail(FH_ERR_INVALID, "gzip: the stream ends before its final block");
     return FH_OK;

@@ -110,6 +110,8 @@ hipError_t launch_fastq_cut(const uint8_t *text, uint32_t total, uint32_t last, 
 // it stopped.  Symbols are 16-bit: a byte, or 0x8000 + i = "byte i of the 32 KiB in front of this chunk"; chunk c's go to
 // sym[c * cap + GZ_WINDOW ...) behind GZ_WINDOW marker slots.
 constexpr uint32_t GZ_WINDOW = 32768;
+constexpr uint32_t GZ_MAX_CHUNKS = 8192; // chunks of one batch
+constexpr uint32_t GZ_GROUPS = 64;      // stretches of the chain of chunks whose windows are worked out side by side
 constexpr uint64_t GZ_NONE = ~0ull;
 enum GzState : uint32_t { // low byte of GzChunk::state (the reason of a failure above it: BgzfFail in fh_bgzf.hip)
     GZ_IDLE = 0,         // never decoded (no block start in its range)
@@ -136,7 +138,7 @@ enum GzSummaryWord : uint32_t {
     GZS_CUT = 12, GZS_CUT_BAD = 13, // (launch_fastq_cut's two words)
     GZS_WORDS = 16,
 };
-// scratch (all device memory): recs[n_chunks], sym[n_chunks * cap], win_in[n_chunks * GZ_WINDOW], live[4 * n_chunks],
+// scratch (all device memory): recs[n_chunks], sym[n_chunks * cap], win_in[n_chunks * GZ_WINDOW], live[4 * n_chunks], group_map, group_win,
 // tile_map[text_cap / 4096 + 2], crc_tmp[text_cap / 65536 + 2].  window: the text in front of the batch (GZ_WINDOW bytes, the last `valid`
 // of them real) on entry, in front of the next batch on return.  The batch's text goes to text[left ...) (`left` bytes in
 // front of it are the partial record the previous batch ended with); GZS_CUT is launch_fastq_cut's answer for text[0, left + total).
@@ -147,7 +149,11 @@ struct GzBatch {
     uint64_t cap;
     GzChunk *recs;
     uint16_t *sym;
+    uint32_t *claims;   // [n_regions]: who writes each chunk's stretch of `sym` (zero before a batch's first chunks are launched)
+    uint32_t n_regions; // stretches there are (>= n_chunks)
     uint8_t *win_in, *window;
+    uint16_t *group_map; // GZ_GROUPS x GZ_WINDOW
+    uint8_t *group_win;  // GZ_GROUPS x GZ_WINDOW
     uint32_t valid;
     uint32_t *live, *tile_map, *crc_tmp;
     uint8_t *text;
@@ -155,6 +161,9 @@ struct GzBatch {
     uint64_t text_cap; // room behind text + left
     uint32_t *summary;
 };
+// the chunks [c0, c0 + n) of the batch decoded (k_gz_chunks), with avail_bytes of the batch's bytes there (`final`: all the stream
+// will ever have); then, once every chunk has been: the chain, the windows, the text, its CRC-32 and where its last record ends
+hipError_t launch_gzip_chunks(const GzBatch &b, uint64_t avail_bytes, uint32_t c0, uint32_t n, bool final, hipStream_t st);
 hipError_t launch_gzip_batch(const GzBatch &b, hipStream_t st);
 // crc(A || B) from crc(A), crc(B) and |B| (zlib's crc32_combine)
 uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);

@@ -145,20 +145,26 @@ typedef struct fh_bgzf_member {
                          * fill the device); the table entries in the buffer are rewritten by the call */
 int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint32_t flags);
 /* Plain gzip (one DEFLATE stream, no index: what `gzip` and most sequencers' pipelines write) of FASTQ text, inflated on the
- * device.  The caller puts the next `bytes` of the member's DEFLATE stream -- what follows the RFC 1952 header -- into the
- * text buffer of fh_text_buffers; FH_GZ_FIRST: they are the stream's first, FH_GZ_LAST: the input ends with them.  A push is
- * decoded as one batch: cut into chunks, a wavefront each, every chunk from the first block start found in it into 16-bit
- * symbols (a byte, or "byte i of the 32 KiB in front of this chunk"), the chunks that really follow each other chained and
- * their markers looked up (the two-pass scheme of pugz / rapidgzip).  What lies behind the last block boundary reached
- * stays on the device for the next push, like the partial FASTQ record the text ended with.  *member_done: the final
- * block has been decoded and the text's CRC-32 and size are those of the trailer; *trailing: bytes of this push behind
- * the trailer (another member, or garbage: the caller's business).  Replaces the decompress-then-parse step of needletail's
- * reader (lib.rs:60) for gzip'd reads.  FH_ERR_INVALID: a damaged stream, a block longer than a push, text more than about 12 x
- * its DEFLATE bytes, or text that is not plain 4-line FASTQ; the sketcher has to be reset then (the host-side inflate is
- * the judge of such files). */
+ * device.  The caller puts the next bytes of the member's DEFLATE stream -- what follows the RFC 1952 header -- into the
+ * text buffer of fh_text_buffers; FH_GZ_FIRST: they are the stream's first, FH_GZ_LAST: the input ends with them.  A batch
+ * is what the pushes up to and including the first one without FH_GZ_MORE have put into ONE buffer, each push its `bytes`
+ * behind those of the push before (fh_gzip_batch_capacity in all, at most); with FH_GZ_MORE a push only has its piece
+ * copied over and the chunks in front of it decoded, so the device works while the caller reads on.  The batch is cut into
+ * chunks, a wavefront each: every chunk is decoded from the first block start found in it into 16-bit symbols (a byte, or
+ * "byte i of the 32 KiB in front of this chunk"), the chunks that really continue each other are chained and their markers
+ * looked up (the two-pass scheme of pugz / rapidgzip).  What lies behind the last block boundary reached stays on the device
+ * for the next batch, like the partial FASTQ record the text ended with.  *member_done: the final block has been decoded
+ * and the text's CRC-32 and size are those of the trailer; *trailing: bytes of this batch behind the trailer (another
+ * member, or garbage: the caller's business).  Replaces the decompress-then-parse step of needletail's reader (lib.rs:60)
+ * for gzip'd reads.  FH_ERR_INVALID: a damaged stream, a block longer than a batch, text more than about 12 x its DEFLATE
+ * bytes, or text that is not plain 4-line FASTQ; the sketcher has to be reset then (the host-side inflate is the judge of such
+ * files). */
 #define FH_GZ_FIRST 1u
 #define FH_GZ_LAST 2u
+#define FH_GZ_MORE 4u
 int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t *member_done, uint64_t *trailing);
+/* bytes one batch of fh_push_gzip_fastq may hold */
+int fh_gzip_batch_capacity(fh_sketcher *s, uint64_t *cap);
 /* Text one batch may inflate to, the carried-over partial record included (8 x stage_bytes, at most 1 GiB: a wavefront
  * per member only fills the device with thousands of members in flight). */
 int fh_bgzf_text_capacity(fh_sketcher *s, uint64_t *cap);

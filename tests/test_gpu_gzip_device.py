@@ -21,7 +21,7 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-FH_GZ_FIRST, FH_GZ_LAST = 1, 2
+FH_GZ_FIRST, FH_GZ_LAST, FH_GZ_MORE = 1, 2, 4
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -58,22 +58,30 @@ def fastq_text(n_reads, seed, rl_lo=30, rl_hi=300, noisy_quals=True):
     return b"".join(recs)
 
 
-def push_stream(sk, body: bytes, push_bytes=None):
-    """the DEFLATE bytes of one member (trailer included) through fh_push_gzip_fastq, push_bytes at a time"""
+def push_stream(sk, body: bytes, push_bytes=None, piece_bytes=None):
+    """the DEFLATE bytes of one member (trailer included) through fh_push_gzip_fastq: batches of push_bytes, each handed over
+    in pieces of piece_bytes (FH_GZ_MORE on all but the last piece of a batch)"""
     L, h = sk._L, sk._h
     bufs = (C.c_void_p * 2)()
-    cap, nxt = C.c_uint64(), C.c_int()
+    cap, nxt, bcap = C.c_uint64(), C.c_int(), C.c_uint64()
     S.check(L.fh_text_buffers(h, bufs, C.byref(cap), C.byref(nxt)))
+    S.check(L.fh_gzip_batch_capacity(h, C.byref(bcap)))
     slot = nxt.value
-    step = min(push_bytes or cap.value, cap.value)
+    step = min(push_bytes or bcap.value, bcap.value, cap.value)
     done, trailing = C.c_uint32(), C.c_uint64()
     n_push = 0
     for o in range(0, max(1, len(body)), step):
-        piece = body[o:o + step]
+        batch = body[o:o + step]
         last = o + step >= len(body)
-        C.memmove(bufs[slot], piece, len(piece))
-        S.check(L.fh_push_gzip_fastq(h, len(piece), (FH_GZ_FIRST if o == 0 else 0) | (FH_GZ_LAST if last else 0), C.byref(done), C.byref(trailing)))
-        n_push += 1
+        C.memmove(bufs[slot], batch, len(batch))
+        piece = piece_bytes or max(1, len(batch))
+        offs = list(range(0, max(1, len(batch)), piece))
+        for i, po in enumerate(offs):
+            n = min(piece, len(batch) - po)
+            more = i + 1 < len(offs)
+            flags = (FH_GZ_FIRST if o == 0 and i == 0 else 0) | (FH_GZ_MORE if more else (FH_GZ_LAST if last else 0))
+            S.check(L.fh_push_gzip_fastq(h, n, flags, C.byref(done), C.byref(trailing)))
+            n_push += 1
         slot ^= 1
         if done.value:
             break
@@ -142,7 +150,7 @@ def test_undecoded_bytes_window_and_partial_record_carry_over_between_pushes(lev
     body = deflate_raw(text, level=level) + zlib.crc32(text).to_bytes(4, "little") + len(text).to_bytes(4, "little")
     assert len(body) > 3 * push
     os.environ["FH_GZ_CHUNK"] = "65536"
-    sk = new_sketcher(size, k, stage_bytes=4 << 20)
+    sk = new_sketcher(size, k, stage_bytes=8 << 20)
     done, trailing, n_push = push_stream(sk, body, push)
     assert (done, trailing) == (1, 0) and n_push >= 3
     assert_is_oracle_sketch(sk, o)
@@ -152,6 +160,27 @@ def test_undecoded_bytes_window_and_partial_record_carry_over_between_pushes(lev
     assert (done, trailing) == (1, 0)
     assert_is_oracle_sketch(sk, o)
     sk.close()
+
+
+@pytest.mark.parametrize("level,piece", [(1, 1 << 20), (6, 1_300_000), (6, 3 << 20), (9, 200_000)])
+def test_a_batch_handed_over_in_pieces_is_decoded_while_it_comes_in(level, piece, chunk_env):
+    """FH_GZ_MORE: the chunks in front of the newest piece are launched with what is there; the verdicts of a chunk on where
+    it stops and of the chunk that begins there must agree whatever was there when either ran"""
+    text = b"".join(fastq_text(9000, 500 + i) for i in range(8))
+    k, size = 21, 1000
+    o = O.OracleSketcher(O.MASH, size, k, 0, 0.001)
+    assert o.sketch_stream(text) == 2
+    body = deflate_raw(text, level=level) + zlib.crc32(text).to_bytes(4, "little") + len(text).to_bytes(4, "little")
+    for chunk in ("8192", None):
+        if chunk:
+            os.environ["FH_GZ_CHUNK"] = chunk
+        else:
+            os.environ.pop("FH_GZ_CHUNK", None)
+        sk = new_sketcher(size, k)
+        done, trailing, n_push = push_stream(sk, body, None, piece)
+        assert (done, trailing) == (1, 0) and n_push >= 3
+        assert_is_oracle_sketch(sk, o)
+        sk.close()
 
 
 def test_trailing_bytes_are_reported_and_damage_is_loud(chunk_env):
