@@ -243,6 +243,8 @@ struct fh_sketcher {
     uint64_t gz_cap = 0, gz_acc = 0;              // symbol slots per chunk; bytes of the batch being collected (FH_GZ_MORE)
     uint16_t *gz_group_map = nullptr;
     uint32_t *gz_claims = nullptr;
+    GzFeed *h_gz_feed = nullptr; // (pinned) how much of the batch being collected has arrived: the decoding launch polls it
+    bool gz_feeding = false;     // such a launch is out
     uint8_t *gz_group_win = nullptr;
     hipEvent_t gz_copied = nullptr;
     uint64_t gz_base = 0;     // where a push's bytes land in d_comp: what the previous push left undecoded sits in front of them
@@ -318,6 +320,15 @@ int set_device(const fh_sketcher *s) {
 }
 
 // the inflate launches of an abandoned batch may still be running
+// a batch of gzip bytes abandoned half-way: its decoding launch is still waiting for the rest
+static void gzip_quiesce(fh_sketcher *s) {
+    if (s->gz_feeding && s->h_gz_feed) {
+        __atomic_store_n(&s->h_gz_feed->abort, 1u, __ATOMIC_RELEASE);
+        (void)hipStreamSynchronize(s->stream);
+    }
+    s->gz_feeding = false;
+    s->gz_acc = 0;
+}
 static void bgzf_quiesce(fh_sketcher *s) {
     for (int q = 0; q < fh_sketcher::BZ_STREAMS; ++q)
         if (s->bz_stream[q] && s->bz_used[q]) {
@@ -348,7 +359,7 @@ int init_state(fh_sketcher *s, bool device_part = true) {
     s->dprev_len = 0;
     s->bgzf_left_len = 0;
     s->gz_open = false;
-    s->gz_acc = 0;
+    gzip_quiesce(s);
     bgzf_quiesce(s);
     for (int i = 0; i < N_STAGE; ++i) // a copy fh_text_prefetch started for a stream that was then abandoned
         if (s->stage_prefetched[i]) {
@@ -1348,7 +1359,7 @@ size_t pool_max() {
 uint64_t pool_max_bytes() {
     static const uint64_t v = [] {
         const char *e = getenv("FH_POOL_BYTES");
-        return e ? (uint64_t)strtoull(e, nullptr, 10) : (8ull << 30);
+        return e ? (uint64_t)strtoull(e, nullptr, 10) : (24ull << 30);
     }();
     return v;
 }
@@ -1577,6 +1588,7 @@ void destroy_handle(fh_sketcher *s) {
     (void)hipFree(s->d_bz_members);
     (void)hipFree(s->d_bz_status);
     (void)hipFree(s->bz_lines);
+    gzip_quiesce(s);
     free_gzip_buffers(s);
     for (int i = 0; i < 2; ++i) {
         (void)hipFree(s->bz_text[i]);
@@ -2148,11 +2160,14 @@ int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint3
 // has been queued for copying, so the device decodes while the caller reads on.  The bytes behind the last block boundary
 // reached stay on the device and lead the next batch, as do the 32 KiB of text a match may reach back into and the partial
 // FASTQ record the text ended with.
-constexpr uint64_t GZ_CHUNK_BYTES = 16384;  // compressed bytes per chunk: about a block of level-1 output (a chunk without a block start idles)
-constexpr uint64_t GZ_SYM_PER_BYTE = 12;    // symbol slots per byte of a chunk (text up to twelve times its DEFLATE bytes: a chunk that decodes on
-                                            // through the ranges behind it takes over their slots, k_gz_chunks)
+constexpr uint64_t GZ_CHUNK_BYTES = 8192;   // compressed bytes per chunk, at least (12 KiB with the default buffers: GZ_MAX_CHUNKS chunks have to cover a
+                                            // batch): below a block of level-1 output, so that a wavefront seldom decodes more than one block and
+                                            // the last ones of a batch are done soon after its last byte has arrived (a chunk without a block
+                                            // start costs a scan of its range)
+constexpr uint64_t GZ_SYM_PER_BYTE = 16;    // symbol slots per byte of a chunk: text up to eight times its DEFLATE bytes, for the chunk's own range
+                                            // and the one behind it -- only once a chunk has decoded all the way THROUGH a range behind it may it
+                                            // take that range's slots over as well (k_gz_chunks)
 constexpr uint64_t GZ_CARRY_MAX = 4ull << 20; // undecoded bytes a batch may leave for the next
-constexpr uint64_t GZ_LOOKAHEAD = 1ull << 20; // bytes that have to be there behind a chunk before it is decoded (FH_GZ_MORE)
 static void free_gzip_buffers(fh_sketcher *s) {
     (void)hipFree(s->gz_sym);
     (void)hipFree(s->gz_group_map);
@@ -2168,6 +2183,8 @@ static void free_gzip_buffers(fh_sketcher *s) {
     (void)hipFree(s->gz_crc_tmp);
     (void)hipFree(s->gz_summary);
     if (s->h_gz_summary) (void)hipHostFree(s->h_gz_summary);
+    if (s->h_gz_feed) (void)hipHostFree(s->h_gz_feed);
+    s->h_gz_feed = nullptr;
     s->gz_sym = nullptr, s->gz_group_map = nullptr, s->gz_group_win = nullptr, s->gz_copied = nullptr, s->gz_recs = nullptr;
     s->gz_win_in = s->gz_window = nullptr;
     s->gz_live = s->gz_tile_map = s->gz_crc_tmp = s->gz_summary = s->h_gz_summary = nullptr;
@@ -2179,9 +2196,10 @@ static uint64_t gz_chunk_bytes(const fh_sketcher *s) {
     const uint64_t most = s->gz_base + s->stage_bytes;
     return std::max<uint64_t>(GZ_CHUNK_BYTES, ((most + GZ_MAX_CHUNKS - 1) / GZ_MAX_CHUNKS + 4095) & ~(uint64_t)4095);
 }
-// bytes one batch may hold: what a staging buffer does, and no more than the text buffer takes at twelve times the size
+// bytes one batch may hold: what a staging buffer does, and no more than the text buffer takes at eight times the size
+// (reads with real quality strings inflate three- to fourfold, with constant ones five- to sixfold)
 static uint64_t gz_batch_capacity(const fh_sketcher *s) {
-    return std::min<uint64_t>(s->stage_bytes, std::max<uint64_t>((uint64_t)1 << 16, s->bz_text_cap / 12));
+    return std::min<uint64_t>(s->stage_bytes, std::max<uint64_t>((uint64_t)1 << 16, s->bz_text_cap / 8));
 }
 static int ensure_gzip_buffers(fh_sketcher *s) {
     if (int rc = ensure_bgzf_buffers(s)) return rc;
@@ -2210,7 +2228,8 @@ static int ensure_gzip_buffers(fh_sketcher *s) {
     HIP_TRY(dev_malloc((void **)&s->gz_window, GZ_WINDOW));
     HIP_TRY(dev_malloc((void **)&s->gz_tile_map, (size_t)(s->bz_text_cap / 4096 + 2) * sizeof(uint32_t)));
     HIP_TRY(dev_malloc((void **)&s->gz_crc_tmp, (size_t)(s->bz_text_cap / 65536 + 2) * sizeof(uint32_t)));
-    HIP_TRY(host_malloc((void **)&s->h_gz_summary, GZS_WORDS * sizeof(uint32_t)));
+    HIP_TRY(host_malloc((void **)&s->h_gz_summary, (GZS_WORDS + 4) * sizeof(uint32_t)));
+    HIP_TRY(host_malloc((void **)&s->h_gz_feed, sizeof(GzFeed)));
     if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&s->gz_copied, hipEventDisableTiming));
     HIP_TRY(dev_malloc((void **)&s->gz_summary, GZS_WORDS * sizeof(uint32_t)));
@@ -2261,56 +2280,61 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
     B.claims = s->gz_claims;
     B.n_regions = s->gz_chunks_cap;
     const bool batch_start = s->gz_acc == 0;
+    // From here on a failure leaves a launch behind that waits for bytes: the caller has to reset the sketcher (which tells
+    // it to give up, gzip_quiesce).
     if (batch_start) {
         if (int rc = drain(s)) return rc; // the packed buffer of this slot may still feed a pending range
-        s->gz_launched = 0;
         HIP_TRY(hipMemsetAsync(s->gz_claims, 0, (size_t)s->gz_chunks_cap * sizeof(uint32_t), s->copy_stream));
+        if (flags & FH_GZ_MORE) {
+            // the batch comes in pieces: ONE launch for all the chunks it may have, there from the first piece on; its
+            // wavefronts wait for their bytes (GzFeed) -- launches of their own per piece would queue up behind each other
+            HIP_TRY(hipStreamSynchronize(s->copy_stream)); // (the claims are clear, the carried bytes in place)
+            GzFeed *f = s->h_gz_feed;
+            f->avail = 0;
+            f->state = 0;
+            f->abort = 0;
+            __atomic_thread_fence(__ATOMIC_SEQ_CST);
+            const uint32_t most = (uint32_t)std::min<uint64_t>(s->gz_chunks_cap, (s->gz_tail_len + gz_batch_capacity(s) + chunk_bytes - 1) / chunk_bytes);
+            HIP_TRY(launch_gzip_chunks(B, f, 0, 0, most, false, s->stream));
+            s->gz_feeding = true;
+        }
     }
-    const uint64_t before = s->gz_tail_len + s->gz_acc; // bytes of the batch there before this push
     if (bytes) {
-        HIP_TRY(hipMemcpyAsync(comp + before, s->h_stage[b] + STAGE_HEADROOM + s->gz_acc, bytes, hipMemcpyHostToDevice, s->copy_stream));
+        HIP_TRY(hipMemcpyAsync(comp + s->gz_tail_len + s->gz_acc, s->h_stage[b] + STAGE_HEADROOM + s->gz_acc, bytes, hipMemcpyHostToDevice, s->copy_stream));
         s->gz_acc += bytes;
     }
     const uint64_t n_bytes = s->gz_tail_len + s->gz_acc;
-    if (flags & FH_GZ_MORE) {
-        // the chunks with a megabyte of the stream behind them (no block is that long) can be decoded: off they go
-        HIP_TRY(hipEventRecord(s->gz_copied, s->copy_stream));
-        (void)before;
-        const uint32_t upto = n_bytes > GZ_LOOKAHEAD ? (uint32_t)((n_bytes - GZ_LOOKAHEAD) / chunk_bytes) : 0u;
-        if (upto > s->gz_launched) {
-            // (each piece's chunks on a side stream of their own: launches of one stream run one after the other, and a
-            // piece's few hundred wavefronts do not fill the device)
-            const int q = s->bz_q;
-            s->bz_q = (q + 1) % fh_sketcher::BZ_STREAMS;
-            HIP_TRY(hipStreamWaitEvent(s->bz_stream[q], s->gz_copied, 0));
-            HIP_TRY(launch_gzip_chunks(B, n_bytes, s->gz_launched, upto - s->gz_launched, false, s->bz_stream[q]));
-            HIP_TRY(hipEventRecord(s->bz_done[q], s->bz_stream[q]));
-            s->bz_used[q] = true;
-            s->gz_launched = upto;
-        }
-        return FH_OK;
+    const bool more = (flags & FH_GZ_MORE) != 0;
+    // (zeros behind the last byte, for tidiness: what is decoded from there is taken back in any case.  Not while a launch
+    // waits for bytes: a fill is a kernel, and might queue up behind that launch)
+    if (!more && !s->gz_feeding) HIP_TRY(hipMemsetAsync(comp + n_bytes, 0, 256, s->copy_stream));
+    if (s->gz_feeding) {
+        // the piece is on the device: say so
+        HIP_TRY(hipStreamSynchronize(s->copy_stream));
+        GzFeed *f = s->h_gz_feed;
+        __atomic_store_n(&f->avail, n_bytes, __ATOMIC_RELEASE);
+        if (!more) __atomic_store_n(&f->state, (flags & FH_GZ_LAST) ? 2u : 1u, __ATOMIC_RELEASE);
     }
+    if (more) return FH_OK;
     // ---- the batch is complete ----
     s->gz_acc = 0;
     if (n_bytes == 0) {
+        gzip_quiesce(s);
         if (flags & FH_GZ_LAST) return fail(FH_ERR_INVALID, "gzip: the stream ends before its final block");
         return FH_OK;
     }
-    HIP_TRY(hipMemsetAsync(comp + n_bytes, 0, 256, s->copy_stream));
-    HIP_TRY(hipEventRecord(s->stage_done[b], s->copy_stream));
-    s->stage_busy[b] = true;
-    s->stage_next = (b + 1) % N_STAGE;
-    HIP_TRY(hipStreamWaitEvent(s->stream, s->stage_done[b], 0));
     const uint32_t n_chunks = (uint32_t)((n_bytes + chunk_bytes - 1) / chunk_bytes);
     if (n_chunks > s->gz_chunks_cap) return fail(FH_ERR_INVALID, "gzip: more chunks in a batch than there is room for");
     B.n_bytes = n_bytes;
     B.n_chunks = n_chunks;
-    HIP_TRY(launch_gzip_chunks(B, n_bytes, s->gz_launched, n_chunks - s->gz_launched, (flags & FH_GZ_LAST) != 0, s->stream));
-    for (int q = 0; q < fh_sketcher::BZ_STREAMS; ++q)
-        if (s->bz_used[q]) {
-            HIP_TRY(hipStreamWaitEvent(s->stream, s->bz_done[q], 0));
-            s->bz_used[q] = false;
-        }
+    HIP_TRY(hipEventRecord(s->stage_done[b], s->copy_stream));
+    s->stage_busy[b] = true;
+    s->stage_next = (b + 1) % N_STAGE;
+    if (!s->gz_feeding) { // the whole batch in one push: an ordinary launch
+        HIP_TRY(hipStreamWaitEvent(s->stream, s->stage_done[b], 0));
+        HIP_TRY(launch_gzip_chunks(B, nullptr, n_bytes, 0, n_chunks, (flags & FH_GZ_LAST) != 0, s->stream));
+    }
+    s->gz_feeding = false; // (it runs to its end now: every chunk has its bytes)
     const uint64_t left = s->bgzf_left_len;
     s->bgzf_left_len = 0;
     if (left) HIP_TRY(hipMemcpyAsync(s->bz_text[t], s->bgzf_left_ptr, left, hipMemcpyDeviceToDevice, s->stream));
@@ -2326,8 +2350,18 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
     B.left = (uint32_t)left;
     B.text_cap = std::min<uint64_t>(s->bz_text_cap - left, (1ull << 31) - 1 - left);
     B.summary = s->gz_summary;
-    HIP_TRY(launch_gzip_batch(B, s->stream));
+    // (the text's CRC-32 on a side stream: it is only needed once the text has been split and queued for sketching)
+    hipStream_t crc_stream = s->bz_stream[0];
+    HIP_TRY(launch_gzip_batch(B, s->stream, crc_stream, s->bz_done[0]));
     HIP_TRY(hipMemcpyAsync(s->h_gz_summary, s->gz_summary, GZS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->h_gz_summary + GZS_WORDS, s->gz_summary + GZS_CRC, sizeof(uint32_t), hipMemcpyDeviceToHost, crc_stream));
+    struct CrcGuard { // (whatever way this call ends, the side stream is idle again)
+        hipStream_t st;
+        bool waited = false;
+        ~CrcGuard() {
+            if (!waited) (void)hipStreamSynchronize(st);
+        }
+    } crc_guard{crc_stream};
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->stage_busy[b] = false;
     const uint32_t *S = s->h_gz_summary;
@@ -2346,16 +2380,13 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
         fprintf(stderr, "[fh] gzip batch: %llu bytes (%llu carried) in %u chunks of %llu: %u on the chain, %llu bytes of text, stopped at bit %llu (%s)\n",
                 (unsigned long long)n_bytes, (unsigned long long)s->gz_tail_len, n_chunks, (unsigned long long)chunk_bytes, S[GZS_N_LIVE],
                 (unsigned long long)total, (unsigned long long)end_bit, end_state == GZ_MEMBER_END ? "end of the member" : "out of input");
-    s->gz_crc = crc32_join(s->gz_crc, S[GZS_CRC], total);
     s->gz_total += total;
     s->gz_valid = S[GZS_VALID];
-    if (end_state == GZ_MEMBER_END) {
+    const bool member_end = end_state == GZ_MEMBER_END;
+    if (member_end) {
         s->gz_open = false;
         if (!S[GZS_HAVE_TRAILER]) return fail(FH_ERR_INVALID, "gzip: the member's trailer is cut short");
-        if (S[GZS_CRC_WANT] != s->gz_crc || S[GZS_ISIZE_WANT] != (uint32_t)s->gz_total)
-            return fail(FH_ERR_INVALID, "gzip: CRC-32 or size differ from the member's trailer");
-        *member_done = 1;
-        *trailing = S[GZS_TRAILING];
+        if (S[GZS_ISIZE_WANT] != (uint32_t)s->gz_total) return fail(FH_ERR_INVALID, "gzip: size differs from the member's trailer");
         s->gz_tail_len = 0;
     } else {
         if (flags & FH_GZ_LAST) {
@@ -2375,14 +2406,26 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
         s->gz_bit = (uint32_t)(end_bit - from * 8u);
     }
     const uint64_t text_total = left + total;
-    if (text_total == 0) return FH_OK;
-    s->bz_next = t ^ 1;
-    if (S[GZS_CUT_BAD]) return fail(FH_ERR_INVALID, "no FASTQ record boundary at the end of a batch of gzip text");
-    const uint64_t cut = S[GZS_CUT];
-    s->bgzf_left_ptr = s->bz_text[t] + cut;
-    s->bgzf_left_len = text_total - cut;
-    if (cut == 0) return FH_OK; // one record longer than the text so far: keep collecting (it moves on to the other buffer)
-    return fastq_text_on_device(s, s->bz_text[t], cut, s->bz_packed[t], s->bz_blk_a[t], s->bz_blk_b[t], s->bz_lines, s->bz_line_cap);
+    if (text_total) {
+        s->bz_next = t ^ 1;
+        if (S[GZS_CUT_BAD]) return fail(FH_ERR_INVALID, "no FASTQ record boundary at the end of a batch of gzip text");
+        const uint64_t cut = S[GZS_CUT];
+        s->bgzf_left_ptr = s->bz_text[t] + cut;
+        s->bgzf_left_len = text_total - cut;
+        // (cut == 0: one record longer than the text so far: keep collecting, it moves on to the other buffer)
+        if (cut)
+            if (int rc = fastq_text_on_device(s, s->bz_text[t], cut, s->bz_packed[t], s->bz_blk_a[t], s->bz_blk_b[t], s->bz_lines, s->bz_line_cap)) return rc;
+    }
+    // the checksum: of this batch's text, joined to that of the member's text before it
+    HIP_TRY(hipStreamSynchronize(crc_stream));
+    crc_guard.waited = true;
+    s->gz_crc = crc32_join(s->gz_crc, s->h_gz_summary[GZS_WORDS], total);
+    if (member_end) {
+        if (S[GZS_CRC_WANT] != s->gz_crc) return fail(FH_ERR_INVALID, "gzip: CRC-32 differs from the member's trailer");
+        *member_done = 1;
+        *trailing = S[GZS_TRAILING];
+    }
+    return FH_OK;
 }
 
 // Device-side FASTA: the staged chunk is raw file text (header lines, wrapped sequence lines); which bytes are

@@ -700,7 +700,7 @@ __device__ __forceinline__ bool gz_stage_a(const GzFindLds *F, u64 v, u64 vh) {
 // The exact parse of a dynamic block's header at bit `pos`, by one lane: true if the hlit + hdist code lengths can be read
 // and describe a complete literal/length code with an end-of-block symbol and a distance code that is complete, a single
 // code or empty.  Gives up as soon as either code is over-subscribed (random bits are after some thirty lengths).
-__device__ bool gz_stage_b(const uint8_t *comp, u64 pos, u64 in_bits) {
+__device__ __noinline__ bool gz_stage_b(const uint8_t *comp, u64 pos, u64 in_bits) {
     const u64 v = gz_peek(comp, pos);
     const u32 hlit = ((u32)(v >> 3) & 31u) + 257u, hdist = ((u32)(v >> 8) & 31u) + 1u, hclen = ((u32)(v >> 13) & 15u) + 4u;
     const u64 w = gz_peek(comp, pos + 17u) & ((1ull << (3u * hclen)) - 1ull);
@@ -795,7 +795,7 @@ __device__ bool gz_stage_b(const uint8_t *comp, u64 pos, u64 in_bits) {
 
 // Does a non-final dynamic block with complete codes, whose first symbols are text, begin at bit `pos`?  The real tables,
 // wave-uniform; overwrites the block tables (and the finder's scratch over them).
-__device__ bool gz_block_check(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 pos, u32 lane) {
+__device__ __noinline__ bool gz_block_check(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 pos, u32 lane) {
     Reader r;
     rd_init(r, comp, pos >> 3, n_bytes, (pos >> 3) * 8u, lane);
     rd_fill(r, lane);
@@ -850,7 +850,7 @@ __device__ __forceinline__ u32 wave_min_u32(u32 v) {
 
 // The candidates collected so far, through the exact parse (a lane each) and the real tables (in stream order): the first
 // bit offset that passes, or GZ_NONE.  `base`: what the queue's offsets count from.
-__device__ u64 gz_flush_candidates(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 base, u32 lane) {
+__device__ __noinline__ u64 gz_flush_candidates(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 base, u32 lane) {
     GzFindLds &F = *(GzFindLds *)L.lit;
     __syncthreads();
     const u32 n = F.n < GZ_QCAP ? F.n : GZ_QCAP;
@@ -884,7 +884,7 @@ __device__ u64 gz_flush_candidates(LdsGz &L, const uint8_t *comp, u64 n_bytes, u
 }
 
 // first bit offset in [from, to) at which a plausible block begins; GZ_NONE: nowhere.  (to <= (n_bytes - GZ_TAIL_GUARD) * 8)
-__device__ u64 gz_find_start(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 from, u64 to, u32 lane) {
+__device__ __noinline__ u64 gz_find_start(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 from, u64 to, u32 lane) {
     if (from >= to) return GZ_NONE;
     GzFindLds &F = *(GzFindLds *)L.lit;
     gz_fill_lut(F, lane);
@@ -918,7 +918,7 @@ __device__ u64 gz_find_start(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 fro
 }
 
 // The same verdict for ONE bit offset (a block boundary the decoder stands at): would gz_find_start stop here?
-__device__ bool gz_is_start(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 pos, u32 lane) {
+__device__ __noinline__ bool gz_is_start(LdsGz &L, const uint8_t *comp, u64 n_bytes, u64 pos, u32 lane) {
     u64 lo, hi;
     __builtin_memcpy(&lo, comp + (pos >> 3), 8);
     __builtin_memcpy(&hi, comp + (pos >> 3) + 8u, 8);
@@ -954,12 +954,53 @@ struct GzGrow {
     }
 };
 
-__global__ __launch_bounds__(64, 5) void k_gz_chunks(const uint8_t *comp, u64 n_bytes, u64 chunk_bits, u32 c0, u64 first_bit, u32 final,
-                                                     GzChunk *recs, uint16_t *sym, u64 cap, u32 *claims, u32 n_regions) {
+constexpr u64 GZ_WAIT_TICKS = 100000000ull; // s_memrealtime ticks (100 MHz) a wavefront waits for its bytes before it gives up
+
+// Wait until `need` bytes of the batch are on the device, or all of it is: how many there are (n_bytes) and whether more will
+// come (state, GzFeed).  false: told to give up, or nothing moved for a second.
+__device__ __noinline__ bool gz_wait_bytes(const GzFeed *feed, u64 need, u64 &n_bytes, u32 &state, u32 lane) {
+    u32 ok = 1, st = 0, av_lo = 0, av_hi = 0;
+    if (lane == 0) {
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            if (__hip_atomic_load(&feed->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+                ok = 0;
+                break;
+            }
+            st = __hip_atomic_load(&feed->state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); // (before avail: the host writes it last)
+            const u64 av = __hip_atomic_load(&feed->avail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            av_lo = (u32)av, av_hi = (u32)(av >> 32);
+            if (st || av >= need) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > GZ_WAIT_TICKS) {
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(127);
+        }
+    }
+    ok = rfl(ok), st = rfl(st), av_lo = rfl(av_lo), av_hi = rfl(av_hi);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // what the copy engine wrote, not what the caches remember of the last batch
+    n_bytes = av_lo | ((u64)av_hi << 32);
+    state = st;
+    return ok != 0u;
+}
+
+__global__ __launch_bounds__(64, 4) void k_gz_chunks(const uint8_t *comp, const GzFeed *feed, u64 n_bytes, u64 chunk_bits, u32 c0, u64 first_bit,
+                                                     u32 final, GzChunk *recs, uint16_t *sym, u64 cap, u32 *claims, u32 n_regions) {
     __shared__ LdsGz L;
     const u32 ci = c0 + blockIdx.x, lane = threadIdx.x;
-    const u64 in_bits = n_bytes * 8u;
-    const u64 search_end = n_bytes > GZ_TAIL_GUARD ? (n_bytes - GZ_TAIL_GUARD) * 8u : 0u; // no start is looked for beyond
+    u32 feed_state = 1; // (all of the batch is there)
+    if (feed) {
+        // the batch is still coming in: wait until this chunk's bytes and a block's worth behind them are there
+        if (!gz_wait_bytes(feed, (u64)(ci + 1u) * (chunk_bits >> 3) + GZ_LOOKAHEAD, n_bytes, feed_state, lane)) {
+            if (lane == 0) recs[ci] = GzChunk{GZ_NONE, GZ_NONE, 0u, (u32)GZ_FAILED | ((u32)BZ_OVERRUN << 8)};
+            return;
+        }
+        final = feed_state == 2u;
+        if ((u64)ci * (chunk_bits >> 3) >= n_bytes) return; // (the batch ended in front of this chunk)
+    }
+    u64 in_bits = n_bytes * 8u;
+    u64 search_end = n_bytes > GZ_TAIL_GUARD ? (n_bytes - GZ_TAIL_GUARD) * 8u : 0u; // no start is looked for beyond
     const u64 range_end = (u64)(ci + 1u) * chunk_bits;
     u64 start;
     if (ci == 0u) {
@@ -998,6 +1039,21 @@ __global__ __launch_bounds__(64, 5) void k_gz_chunks(const uint8_t *comp, u64 n_
         // a block boundary: what has been decoded up to here stands whatever becomes of the next block
         end_bit = rd_used_bits(r);
         end_pos = pos;
+        if (feed_state == 0u && end_bit + GZ_LOOKAHEAD * 8u > in_bits) {
+            // this chunk has decoded on and on (stored blocks, boundaries that do not read as starts) to the end of what was
+            // there when it set out, and the batch is still coming in: wait for more of it
+            if (!gz_wait_bytes(feed, (end_bit >> 3) + GZ_LOOKAHEAD, n_bytes, feed_state, lane)) {
+                fail = BZ_OVERRUN;
+                fail_at = 0;
+                break;
+            }
+            final = feed_state == 2u;
+            in_bits = n_bytes * 8u;
+            search_end = n_bytes > GZ_TAIL_GUARD ? (n_bytes - GZ_TAIL_GUARD) * 8u : 0u;
+            rd_init(r, comp, end_bit >> 3, n_bytes, (end_bit >> 3) * 8u, lane);
+            rd_fill(r, lane);
+            rd_take(r, (u32)(end_bit & 7u));
+        }
         if (end_bit + 3u > in_bits) {
             state = GZ_OUT_OF_INPUT;
             break;
@@ -1610,14 +1666,14 @@ uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
     return crc_multmodp(p, crc_a) ^ crc_b;
 }
 
-hipError_t launch_gzip_chunks(const GzBatch &b, uint64_t avail_bytes, uint32_t c0, uint32_t n, bool final, hipStream_t st) {
+hipError_t launch_gzip_chunks(const GzBatch &b, const GzFeed *feed, uint64_t avail_bytes, uint32_t c0, uint32_t n, bool final, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_gz_chunks, dim3(n), dim3(64), 0, st, b.comp, avail_bytes, b.chunk_bits, c0, b.first_bit, final ? 1u : 0u, b.recs, b.sym,
-                       b.cap, b.claims, b.n_regions);
+    hipLaunchKernelGGL(k_gz_chunks, dim3(n), dim3(64), 0, st, b.comp, feed, avail_bytes, b.chunk_bits, c0, b.first_bit, final ? 1u : 0u, b.recs,
+                       b.sym, b.cap, b.claims, b.n_regions);
     return hipGetLastError();
 }
 
-hipError_t launch_gzip_batch(const GzBatch &b, hipStream_t st) {
+hipError_t launch_gzip_batch(const GzBatch &b, hipStream_t st, hipStream_t st_crc, hipEvent_t text_done) {
     if (b.n_chunks == 0 || b.n_chunks > GZ_MAX_CHUNKS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_gz_chain, dim3(1), dim3(1024), 0, st, b);
     hipLaunchKernelGGL(k_gz_win_compose, dim3(GZ_GROUPS), dim3(1024), 0, st, b);
@@ -1625,9 +1681,11 @@ hipError_t launch_gzip_batch(const GzBatch &b, hipStream_t st) {
     hipLaunchKernelGGL(k_gz_win_chunks, dim3(GZ_GROUPS), dim3(1024), 0, st, b);
     const u32 n_tiles = (u32)((b.text_cap + 4095u) / 4096u);
     hipLaunchKernelGGL(k_gz_text, dim3(n_tiles), dim3(256), 0, st, b);
+    if (hipError_t e = hipEventRecord(text_done, st); e != hipSuccess) return e;
+    if (hipError_t e = hipStreamWaitEvent(st_crc, text_done, 0); e != hipSuccess) return e;
     const u32 n_slices = (u32)((b.text_cap + 65535u) / 65536u);
-    hipLaunchKernelGGL(k_gz_crc_slices, dim3((n_slices + 3u) / 4u), dim3(256), 0, st, b, x2n_table());
-    hipLaunchKernelGGL(k_gz_crc_join, dim3(1), dim3(64), 0, st, b, x2n_table());
+    hipLaunchKernelGGL(k_gz_crc_slices, dim3((n_slices + 3u) / 4u), dim3(256), 0, st_crc, b, x2n_table());
+    hipLaunchKernelGGL(k_gz_crc_join, dim3(1), dim3(64), 0, st_crc, b, x2n_table());
     hipLaunchKernelGGL(k_gz_cut, dim3(1), dim3(64), 0, st, b);
     return hipGetLastError();
 }

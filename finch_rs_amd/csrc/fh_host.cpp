@@ -2910,7 +2910,7 @@ static int bgzf_fastq_to_device(BgzfSource &bz, fh_sketcher *h) {
 // gzip-compressed FASTQ -- one DEFLATE stream -- with the inflate on the device (fh_push_gzip_fastq): the reader thread
 // moves the file's bytes into the sketcher's pinned buffers, a buffer's worth per push, while the calling thread has the
 // previous push decoded, checked, split and sketched.  Anything but one sound member of plain 4-line FASTQ whose blocks
-// fit a push (several members, trailing bytes, damage, text more than about 12 x its DEFLATE bytes) is FH_ERR_INVALID: the
+// fit a push (several members, trailing bytes, damage, text more than about 8 x its DEFLATE bytes) is FH_ERR_INVALID: the
 // caller reads the file again through the host-side inflate, whose verdict is the one reported.
 static int gzip_fastq_to_device(BgzfSource &bz, size_t hdr_len, fh_sketcher *h) {
     uint8_t *raw[2] = {nullptr, nullptr};
@@ -2928,7 +2928,7 @@ static int gzip_fastq_to_device(BgzfSource &bz, size_t hdr_len, fh_sketcher *h) 
     // device decodes the front of the batch while the rest of it is still coming in.
     static const uint64_t PIECE = [] {
         const char *e = getenv("FINCH_GZIP_PIECE"); // (A/B)
-        return e ? std::max<uint64_t>(65536, strtoull(e, nullptr, 10)) : ((uint64_t)8 << 20);
+        return e ? std::max<uint64_t>(65536, strtoull(e, nullptr, 10)) : ((uint64_t)4 << 20);
     }();
     struct Job {
         int slot;

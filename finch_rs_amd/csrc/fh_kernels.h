@@ -161,10 +161,21 @@ struct GzBatch {
     uint64_t text_cap; // room behind text + left
     uint32_t *summary;
 };
-// the chunks [c0, c0 + n) of the batch decoded (k_gz_chunks), with avail_bytes of the batch's bytes there (`final`: all the stream
+// How much of a batch has arrived, in pinned host memory the chunks' wavefronts poll (a batch handed over in pieces is decoded
+// by ONE launch that is there from the first piece on: a wavefront waits until its chunk and GZ_LOOKAHEAD bytes behind it
+// are on the device).  The host writes `avail`, then `state`.
+constexpr uint64_t GZ_LOOKAHEAD = 1ull << 20; // (no block is that long)
+struct GzFeed {
+    uint64_t avail; // bytes of the batch on the device, the carried ones in front included
+    uint32_t state; // 0: more to come, 1: that is the whole batch, 2: ... and the stream ends with it
+    uint32_t abort; // give up (the batch is abandoned)
+};
+// the chunks [c0, c0 + n) of the batch decoded (k_gz_chunks; feed != nullptr: avail_bytes / final come from there, and chunks
+// that begin behind the batch's end drop out), with avail_bytes of the batch's bytes there (`final`: all the stream
 // will ever have); then, once every chunk has been: the chain, the windows, the text, its CRC-32 and where its last record ends
-hipError_t launch_gzip_chunks(const GzBatch &b, uint64_t avail_bytes, uint32_t c0, uint32_t n, bool final, hipStream_t st);
-hipError_t launch_gzip_batch(const GzBatch &b, hipStream_t st);
+hipError_t launch_gzip_chunks(const GzBatch &b, const GzFeed *feed, uint64_t avail_bytes, uint32_t c0, uint32_t n, bool final, hipStream_t st);
+// (the CRC-32 kernels go to st_crc, behind `text_done` recorded on st once the text is there)
+hipError_t launch_gzip_batch(const GzBatch &b, hipStream_t st, hipStream_t st_crc, hipEvent_t text_done);
 // crc(A || B) from crc(A), crc(B) and |B| (zlib's crc32_combine)
 uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 hipError_t launch_fill_table(Entry *table, uint64_t cap, hipStream_t st);

@@ -156,7 +156,7 @@ int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint3
  * for the next batch, like the partial FASTQ record the text ended with.  *member_done: the final block has been decoded
  * and the text's CRC-32 and size are those of the trailer; *trailing: bytes of this batch behind the trailer (another
  * member, or garbage: the caller's business).  Replaces the decompress-then-parse step of needletail's reader (lib.rs:60)
- * for gzip'd reads.  FH_ERR_INVALID: a damaged stream, a block longer than a batch, text more than about 12 x its DEFLATE
+ * for gzip'd reads.  FH_ERR_INVALID: a damaged stream, a block longer than a batch, text more than about 8 x its DEFLATE
  * bytes, or text that is not plain 4-line FASTQ; the sketcher has to be reset then (the host-side inflate is the judge of such
  * files). */
 #define FH_GZ_FIRST 1u
