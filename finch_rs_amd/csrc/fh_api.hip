@@ -1003,7 +1003,7 @@ int sketch_positions(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_
 // 12 ms for 40 M positions where the pass itself takes 0.1), but up to a threshold scaled by how far short the count fell
 // -- the density of distinct hashes is known now --, and only if that too comes up short for everything.
 int reread_above(fh_sketcher *s, const uint8_t *seq, uint64_t len, uint64_t base_pos, uint64_t p_begin, uint64_t p_end, uint64_t lo) {
-    static const bool no_scale = getenv("FH_NO_SPEC_RESCALE") != nullptr; // A/B
+    const bool no_scale = getenv("FH_NO_SPEC_RESCALE") != nullptr; // A/B (read per call: a rare path)
     for (int attempt = 0;; ++attempt) {
         uint64_t hi = EMPTY64;
         const uint64_t have = s->last_live;

@@ -119,6 +119,21 @@ def test_failed_speculation_is_finished_step_by_step():
         assert dbg["spec_recovered"] >= 1, dbg
 
 
+@pytest.mark.parametrize("genome_len,n_reads,env", [(500_000, 200_000, {}), (500_000, 470_000, {}), (120_000, 200_000, {}),
+                                                     (500_000, 200_000, {"FH_NO_FAST": 1}), (500_000, 200_000, {"FH_NO_SPEC_RESCALE": 1})],
+                         ids=["whole block", "prefix", "few hashes below the guess", "undeferred", "old way"])
+def test_speculation_that_falls_short_on_deep_coverage_is_reread_up_to_a_rescaled_threshold(genome_len, n_reads, env):
+    """reads without errors at 60- to 250-fold coverage: the guess (every k-mer distinct) leaves some tens of the 1000 hashes; the
+    range is read again up to a threshold scaled by how far short the count fell -- not, as until round 4, for every hash above
+    the guess -- and the sketch is the oracle's either way"""
+    g = S.synth_genome_host(genome_len, 21)
+    data = S.synth_reads_host(g, 0, n_reads, 150, 21, 0, 0)
+    ora = _oracle(data)
+    for kc, km, tk, dbg in _device_pass(data, **env):
+        _same(kc, km, tk, ora, str(dbg))
+        assert dbg["spec_second_pass"] >= 1, dbg
+
+
 def test_pushes_after_a_deferred_speculation_resolve_it_first():
     """the verdict of a speculation is read at the next call that needs it: a second push, fh_sync, fh_text_bases"""
     data = _reads(300_000, seed=3)

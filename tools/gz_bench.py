@@ -1,4 +1,7 @@
-"""plain gzip through finch_sketch_files, device-side inflate against the host's: python tools/gz_bench.py [reads [level]]  (on an MI355X)"""
+"""plain gzip through finch_sketch_files, device-side inflate against the host's:
+    python tools/gz_bench.py [reads [level [noisy|const [substitutions per million]]]]      (on an MI355X)
+1 M reads of 150 bases from a 5 Mb genome (30-fold coverage), 1 % substitutions unless told otherwise (0: every k-mer thirty
+times over -- the case in which a speculative first threshold falls short)."""
 import os, sys, time, zlib, tempfile, shutil
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +13,8 @@ level = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 noisy = len(sys.argv) > 3 and sys.argv[3] == "noisy"
 RL = 150
 g = S.synth_genome_host(5_000_000, 1)
-reads = S.synth_reads_host(g, 0, ns, RL, 7, 10_000, 500).reshape(ns, RL + 1)[:, :RL]
+sub_ppm = int(sys.argv[4]) if len(sys.argv) > 4 else 10_000
+reads = S.synth_reads_host(g, 0, ns, RL, 7, sub_ppm, 500).reshape(ns, RL + 1)[:, :RL]
 w = 12 + RL + 3 + RL + 1
 txt = np.empty((ns, w), np.uint8)
 txt[:, 0], txt[:, 1] = ord("@"), ord("r")
