@@ -238,7 +238,7 @@ struct fh_sketcher {
     GzChunk *gz_recs = nullptr;
     uint8_t *gz_win_in = nullptr, *gz_window = nullptr;
     uint32_t *gz_live = nullptr, *gz_tile_map = nullptr, *gz_crc_tmp = nullptr, *gz_summary = nullptr, *h_gz_summary = nullptr;
-    uint32_t gz_chunks_cap = 0, gz_launched = 0; // chunks there is room for; chunks of the batch being collected that have been launched
+    uint32_t gz_chunks_cap = 0; // chunks there is room for
     uint64_t gz_chunk_alloc = 0; // the chunk size the buffers were sized for
     uint64_t gz_cap = 0, gz_acc = 0;              // symbol slots per chunk; bytes of the batch being collected (FH_GZ_MORE)
     uint16_t *gz_group_map = nullptr;
@@ -246,7 +246,6 @@ struct fh_sketcher {
     GzFeed *h_gz_feed = nullptr; // (pinned) how much of the batch being collected has arrived: the decoding launch polls it
     bool gz_feeding = false;     // such a launch is out
     uint8_t *gz_group_win = nullptr;
-    hipEvent_t gz_copied = nullptr;
     uint64_t gz_base = 0;     // where a push's bytes land in d_comp: what the previous push left undecoded sits in front of them
     uint64_t gz_tail_len = 0; // ... that many bytes, decoding resumes at bit gz_bit of the first
     uint32_t gz_bit = 0, gz_valid = 0, gz_crc = 0;
@@ -2174,7 +2173,6 @@ static void free_gzip_buffers(fh_sketcher *s) {
     (void)hipFree(s->gz_group_win);
     (void)hipFree(s->gz_claims);
     s->gz_claims = nullptr;
-    if (s->gz_copied) (void)hipEventDestroy(s->gz_copied);
     (void)hipFree(s->gz_recs);
     (void)hipFree(s->gz_win_in);
     (void)hipFree(s->gz_window);
@@ -2185,7 +2183,7 @@ static void free_gzip_buffers(fh_sketcher *s) {
     if (s->h_gz_summary) (void)hipHostFree(s->h_gz_summary);
     if (s->h_gz_feed) (void)hipHostFree(s->h_gz_feed);
     s->h_gz_feed = nullptr;
-    s->gz_sym = nullptr, s->gz_group_map = nullptr, s->gz_group_win = nullptr, s->gz_copied = nullptr, s->gz_recs = nullptr;
+    s->gz_sym = nullptr, s->gz_group_map = nullptr, s->gz_group_win = nullptr, s->gz_recs = nullptr;
     s->gz_win_in = s->gz_window = nullptr;
     s->gz_live = s->gz_tile_map = s->gz_crc_tmp = s->gz_summary = s->h_gz_summary = nullptr;
     s->gz_sym_elems = 0;
@@ -2231,7 +2229,6 @@ static int ensure_gzip_buffers(fh_sketcher *s) {
     HIP_TRY(host_malloc((void **)&s->h_gz_summary, (GZS_WORDS + 4) * sizeof(uint32_t)));
     HIP_TRY(host_malloc((void **)&s->h_gz_feed, sizeof(GzFeed)));
     if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&s->gz_copied, hipEventDisableTiming));
     HIP_TRY(dev_malloc((void **)&s->gz_summary, GZS_WORDS * sizeof(uint32_t)));
     return FH_OK;
 }

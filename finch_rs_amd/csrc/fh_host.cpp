@@ -3408,6 +3408,27 @@ using namespace finch;
 
 extern "C" {
 
+int finch_gzip_probe(const uint8_t *data, uint64_t len, uint64_t piece_bytes, uint64_t *hdr_len, int *first_byte, uint64_t *deflate_bytes,
+                     uint32_t *crc_of_pieces) try {
+    if (!data || !hdr_len || !first_byte || !deflate_bytes || !crc_of_pieces) return finch::hfail(FH_ERR_INVALID, "null argument");
+    finch::BgzfSource bz(std::make_unique<finch::MemSource>(data, (size_t)len), 2);
+    size_t h = 0;
+    *first_byte = bz.peek_plain_gzip(&h);
+    *hdr_len = h;
+    *deflate_bytes = 0;
+    *crc_of_pieces = 0;
+    if (*first_byte < 0) return FH_OK;
+    std::vector<uint8_t> skip(h), piece((size_t)std::max<uint64_t>(1, piece_bytes));
+    if (bz.raw_read(skip.data(), h) != h) return finch::hfail(FH_ERR_INVALID, "gzip header cut short");
+    for (;;) {
+        const size_t got = bz.raw_read(piece.data(), piece.size());
+        *crc_of_pieces = finch::inf::crc32_fast(*crc_of_pieces, piece.data(), got);
+        *deflate_bytes += got;
+        if (got < piece.size()) break;
+    }
+    return FH_OK;
+} FINCH_CATCH
+
 void finch_debug_device_inflate(uint64_t *files_on_device, uint64_t *files_reread) {
     if (files_on_device) *files_on_device = finch::g_bgzf_on_device.load();
     if (files_reread) *files_reread = finch::g_bgzf_reread.load();

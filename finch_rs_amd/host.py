@@ -108,6 +108,8 @@ _SYMS = {
     "finch_source_probe": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "finch_debug_device_inflate": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "finch_debug_device_gzip": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "finch_gzip_probe": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_uint32)]),
     "finch_bgzf_batch_probe": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64),
                                          C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
 }
@@ -412,6 +414,14 @@ def debug_device_inflate():
     a, b = C.c_uint64(), C.c_uint64()
     lib().finch_debug_device_inflate(C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def gzip_probe(data: bytes, piece_bytes: int = 1 << 20):
+    """(header length, first text byte or -1, DEFLATE bytes the reader hands over, their CRC-32) of a gzip image -- test hook, no device"""
+    src = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)
+    h, fb, n, crc = C.c_uint64(), C.c_int(), C.c_uint64(), C.c_uint32()
+    _check(lib().finch_gzip_probe(src.ctypes.data, len(data), piece_bytes, C.byref(h), C.byref(fb), C.byref(n), C.byref(crc)))
+    return h.value, fb.value, n.value, crc.value
 
 
 def debug_device_gzip():

@@ -188,6 +188,13 @@ int finch_shard_probe(const uint8_t *data, uint64_t len, uint32_t k, uint64_t ch
 int finch_bgzf_batch_probe(const uint8_t *data, uint64_t len, uint64_t buf_bytes, uint32_t max_members, uint64_t text_budget,
                            uint8_t *text_out, uint64_t text_cap, uint64_t *text_len, uint64_t *n_batches, int *first_byte);
 
+/* Test hook (no device): what finch_sketch_files' reader hands to fh_push_gzip_fastq for a plain gzip image -- the probe of
+ * the file's first member (*first_byte: the first byte of its text, -1 if the member is BGZF, no gzip member, or nothing can
+ * be decoded from its first 64 KiB; *hdr_len: the length of its RFC 1952 header) and the bytes behind the header as the
+ * reader takes them, piece_bytes at a time (*deflate_bytes of them in all, *crc_of_pieces their running CRC-32). */
+int finch_gzip_probe(const uint8_t *data, uint64_t len, uint64_t piece_bytes, uint64_t *hdr_len, int *first_byte, uint64_t *deflate_bytes,
+                     uint32_t *crc_of_pieces);
+
 /* Test hook: inputs this process has sketched with the BGZF inflate on the device (finch_sketch_files /
  * finch_sketch_buffer: bgzip'd FASTQ unless FINCH_DEVICE_INFLATE=0), and how many of them it had to read again through the
  * host-side inflate because the device pass refused them. */

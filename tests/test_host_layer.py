@@ -540,6 +540,43 @@ def test_bgzf_reader_for_the_device_side_inflate():
         H.bgzf_batch_probe(bytes(dmg), 1 << 20, 4096, 1 << 30, len(text) + 65536)
 
 
+def test_the_reader_of_the_device_side_gzip_inflate_skips_the_header_and_hands_the_stream_over_in_pieces():
+    """finch_gzip_probe (no device): the probe that decides whether a file goes to fh_push_gzip_fastq -- first byte of the text,
+    length of the RFC 1952 header with any of its optional fields -- and the bytes behind the header exactly as the file has
+    them, whatever the piece size; BGZF, other formats and text that cannot be reached say -1"""
+    import struct
+    import zlib
+    rng = np.random.default_rng(5)
+    text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=100)), b"I" * 100) for i in range(3000))
+    body = zlib.compress(text, 6)[2:-4] + struct.pack("<II", zlib.crc32(text), len(text))
+
+    def image(flg, extra=b"\x07\x00extra!!"[:9], name=b"reads.fastq\0", comment=b"made by a test\0"):
+        h = b"\x1f\x8b\x08" + bytes([flg]) + b"\0\0\0\0\x00\x03"
+        if flg & 4:
+            h += struct.pack("<H", len(extra)) + extra
+        if flg & 8:
+            h += name
+        if flg & 16:
+            h += comment
+        if flg & 2:
+            h += struct.pack("<H", zlib.crc32(h) & 0xFFFF)
+        return h, h + body
+    for flg in (0, 2, 4, 8, 16, 8 | 16, 2 | 4 | 8 | 16):
+        h, img = image(flg)
+        for piece in (1, 4097, 1 << 20):
+            if piece == 1 and flg not in (0, 30):
+                continue
+            hdr_len, first, n, crc = H.gzip_probe(img, piece)
+            assert (hdr_len, first, n, crc) == (len(h), ord("@"), len(body), zlib.crc32(body)), (flg, piece)
+    assert H.gzip_probe(gzip.compress(b">g\nACGT\n" * 5000, 6))[1] == ord(">")
+    assert H.gzip_probe(_bgzf(text, 60000))[1] == -1                      # BGZF: the other path's
+    assert H.gzip_probe(b"@r\nACGT\n+\nIIII\n" * 100)[1] == -1        # not compressed at all
+    assert H.gzip_probe(image(0)[1][:30])[1] == -1                        # too short to tell
+    assert H.gzip_probe(image(8, name=b"x" * 70000)[1])[1] == -1          # a name that never ends within the probe's reach
+    assert H.gzip_probe(b"\x1f\x8b\x08\x00" + b"\0" * 6 + b"\xff" * 5000)[1] == -1  # no DEFLATE stream behind the header
+    assert H.gzip_probe(b"\x1f\x8b\x08\xe0" + b"\0" * 6 + body)[1] == -1  # reserved flag bits
+
+
 def test_one_gzip_member_decoded_by_several_threads(monkeypatch):
     """plain gzip with read threads to spare (fh_pargz.h): block starts found by search, chunks decoded with markers for the
     unknown window, stitched and checked against the member's CRC-32 -- the text must be zlib's for every chunk size,
