@@ -243,8 +243,10 @@ struct fh_sketcher {
     uint64_t gz_cap = 0, gz_acc = 0;              // symbol slots per chunk; bytes of the batch being collected (FH_GZ_MORE)
     uint16_t *gz_group_map = nullptr;
     uint32_t *gz_claims = nullptr;
+    uint64_t *gz_times = nullptr; // (FH_GZ_TIMES: per-chunk timestamps of the decoding launch)
     GzFeed *h_gz_feed = nullptr; // (pinned) how much of the batch being collected has arrived: the decoding launch polls it
     bool gz_feeding = false;     // such a launch is out
+    double gz_t0 = 0;            // (FH_TRACE)
     uint8_t *gz_group_win = nullptr;
     uint64_t gz_base = 0;     // where a push's bytes land in d_comp: what the previous push left undecoded sits in front of them
     uint64_t gz_tail_len = 0; // ... that many bytes, decoding resumes at bit gz_bit of the first
@@ -2172,7 +2174,9 @@ static void free_gzip_buffers(fh_sketcher *s) {
     (void)hipFree(s->gz_group_map);
     (void)hipFree(s->gz_group_win);
     (void)hipFree(s->gz_claims);
+    (void)hipFree(s->gz_times);
     s->gz_claims = nullptr;
+    s->gz_times = nullptr;
     (void)hipFree(s->gz_recs);
     (void)hipFree(s->gz_win_in);
     (void)hipFree(s->gz_window);
@@ -2220,6 +2224,7 @@ static int ensure_gzip_buffers(fh_sketcher *s) {
     HIP_TRY(dev_malloc((void **)&s->gz_win_in, (size_t)n * GZ_WINDOW));
     HIP_TRY(dev_malloc((void **)&s->gz_live, (size_t)n * 4 * sizeof(uint32_t)));
     HIP_TRY(dev_malloc((void **)&s->gz_claims, (size_t)n * sizeof(uint32_t)));
+    if (getenv("FH_GZ_TIMES")) HIP_TRY(dev_malloc((void **)&s->gz_times, (size_t)n * 3 * sizeof(uint64_t)));
     s->gz_chunks_cap = n;
     HIP_TRY(dev_malloc((void **)&s->gz_group_map, (size_t)GZ_GROUPS * GZ_WINDOW * sizeof(uint16_t)));
     HIP_TRY(dev_malloc((void **)&s->gz_group_win, (size_t)GZ_GROUPS * GZ_WINDOW));
@@ -2275,6 +2280,7 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
     B.recs = s->gz_recs;
     B.sym = s->gz_sym;
     B.claims = s->gz_claims;
+    B.times = s->gz_times;
     B.n_regions = s->gz_chunks_cap;
     const bool batch_start = s->gz_acc == 0;
     // From here on a failure leaves a launch behind that waits for bytes: the caller has to reset the sketcher (which tells
@@ -2311,6 +2317,13 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
         GzFeed *f = s->h_gz_feed;
         __atomic_store_n(&f->avail, n_bytes, __ATOMIC_RELEASE);
         if (!more) __atomic_store_n(&f->state, (flags & FH_GZ_LAST) ? 2u : 1u, __ATOMIC_RELEASE);
+        static const bool trace_pieces = getenv("FH_TRACE") != nullptr;
+        if (trace_pieces) {
+            const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            if (batch_start) s->gz_t0 = now;
+            fprintf(stderr, "[fh] gzip piece: %llu bytes of the batch on the device %.2f ms after its first push%s\n", (unsigned long long)n_bytes,
+                    (now - s->gz_t0) * 1e3, more ? "" : " (complete)");
+        }
     }
     if (more) return FH_OK;
     // ---- the batch is complete ----
@@ -2374,9 +2387,23 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
     const uint32_t end_state = S[GZS_END_STATE];
     static const bool trace = getenv("FH_TRACE") != nullptr;
     if (trace)
+        fprintf(stderr, "[fh] gzip batch: text there %.2f ms after the batch's first push\n",
+                (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - s->gz_t0) * 1e3);
+    if (trace)
         fprintf(stderr, "[fh] gzip batch: %llu bytes (%llu carried) in %u chunks of %llu: %u on the chain, %llu bytes of text, stopped at bit %llu (%s)\n",
                 (unsigned long long)n_bytes, (unsigned long long)s->gz_tail_len, n_chunks, (unsigned long long)chunk_bytes, S[GZS_N_LIVE],
                 (unsigned long long)total, (unsigned long long)end_bit, end_state == GZ_MEMBER_END ? "end of the member" : "out of input");
+    if (s->gz_times) { // when the chunks' wavefronts were dispatched, had their bytes, were done: deciles over the batch's chunks
+        std::vector<uint64_t> tm((size_t)n_chunks * 3);
+        HIP_TRY(hipMemcpy(tm.data(), s->gz_times, tm.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        uint64_t t0 = ~0ull;
+        for (uint32_t c = 0; c < n_chunks; ++c) t0 = std::min(t0, tm[3 * c]);
+        fprintf(stderr, "[fh] gzip chunk times (ms after the first dispatch): chunk index: dispatched, bytes there, done\n");
+        for (int q = 0; q <= 10; ++q) {
+            const uint32_t c = (uint32_t)std::min<uint64_t>(n_chunks - 1, (uint64_t)n_chunks * q / 10);
+            fprintf(stderr, "[fh]   %5u: %7.2f %7.2f %7.2f\n", c, (tm[3 * c] - t0) / 1e5, (tm[3 * c + 1] - t0) / 1e5, (tm[3 * c + 2] - t0) / 1e5);
+        }
+    }
     s->gz_total += total;
     s->gz_valid = S[GZS_VALID];
     const bool member_end = end_state == GZ_MEMBER_END;

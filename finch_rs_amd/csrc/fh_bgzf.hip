@@ -403,6 +403,22 @@ __device__ u32 block_symbols_parallel(LDS &L, const uint8_t *mbase, u64 in_bits,
                                       u32 &qn_ref, u32 lane, GROW grow = GROW(), u32 *limit_out = nullptr) {
     u64 mbits = mbits_ref;
     u32 pos = pos_ref, qn = qn_ref, fail = 0;
+    // WINDOW (the chunks of a plain gzip stream): the wavefronts spend seven eighths of their time waiting, and the load of the
+    // stream's bits -- its address hangs on the symbols of the round before -- is the longest wait of a round.  So every lane
+    // keeps 24 bytes of the stream from ITS offset on, loaded one round ahead: a round moves on by at most 111 bits (63 + the
+    // longest symbol), so the 64 bits a lane needs next lie inside what it loaded for this round, a shift away.
+#ifdef FH_GZ_NO_WINDOW // (A/B builds)
+    constexpr bool WINDOW = false;
+#else
+    constexpr bool WINDOW = !__is_same(GROW, NoGrow);
+#endif
+    u64 w0 = 0, w1 = 0, w2 = 0, wbase = mbits;
+    if (WINDOW) {
+        const uint8_t *p = mbase + ((mbits + lane) >> 3);
+        __builtin_memcpy(&w0, p, 8);
+        __builtin_memcpy(&w1, p + 8, 8);
+        __builtin_memcpy(&w2, p + 16, 8);
+    }
     for (;;) {
         if (mbits > in_bits + 64u) {
             fail = BZ_OVERRUN_;
@@ -410,8 +426,21 @@ __device__ u32 block_symbols_parallel(LDS &L, const uint8_t *mbase, u64 in_bits,
         }
         const u64 my = mbits + lane;
         u64 b;
-        __builtin_memcpy(&b, mbase + (my >> 3), 8); // (reads at most 24 bytes past the member: inside the buffer's padding)
-        b >>= (u32)(my & 7u);
+        if (WINDOW) {
+            const u32 off = (u32)(mbits - wbase) + (u32)((wbase + lane) & 7u); // of this round's first bit within the lane's 24 bytes
+            const u64 lo = off < 64u ? w0 : w1, hi = off < 64u ? w1 : w2;
+            const u32 sh = off & 63u;
+            b = sh ? (lo >> sh) | (hi << (64u - sh)) : lo;
+            // the next round's, from this round's offset on
+            const uint8_t *p = mbase + (my >> 3);
+            __builtin_memcpy(&w0, p, 8);
+            __builtin_memcpy(&w1, p + 8, 8);
+            __builtin_memcpy(&w2, p + 16, 8);
+            wbase = mbits;
+        } else {
+            __builtin_memcpy(&b, mbase + (my >> 3), 8); // (reads at most 24 bytes past the member: inside the buffer's padding)
+            b >>= (u32)(my & 7u);
+        }
         u32 e = L.lit[(u32)b & ((1u << LIT_BITS) - 1u)];
         u32 kind = (e >> 8) & 3u;
         if (kind == KIND_LONG) {
@@ -979,16 +1008,19 @@ __device__ __noinline__ bool gz_wait_bytes(const GzFeed *feed, u64 need, u64 &n_
         }
     }
     ok = rfl(ok), st = rfl(st), av_lo = rfl(av_lo), av_hi = rfl(av_hi);
+#ifndef FH_GZ_NO_FENCE // (A/B builds)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // what the copy engine wrote, not what the caches remember of the last batch
+#endif
     n_bytes = av_lo | ((u64)av_hi << 32);
     state = st;
     return ok != 0u;
 }
 
 __global__ __launch_bounds__(64, 4) void k_gz_chunks(const uint8_t *comp, const GzFeed *feed, u64 n_bytes, u64 chunk_bits, u32 c0, u64 first_bit,
-                                                     u32 final, GzChunk *recs, uint16_t *sym, u64 cap, u32 *claims, u32 n_regions) {
+                                                     u32 final, GzChunk *recs, uint16_t *sym, u64 cap, u32 *claims, u32 n_regions, u64 *times) {
     __shared__ LdsGz L;
     const u32 ci = c0 + blockIdx.x, lane = threadIdx.x;
+    if (times && lane == 0) times[3u * ci] = __builtin_amdgcn_s_memrealtime(); // (FH_GZ_TIMES: dispatched / bytes there / done)
     u32 feed_state = 1; // (all of the batch is there)
     if (feed) {
         // the batch is still coming in: wait until this chunk's bytes and a block's worth behind them are there
@@ -1002,6 +1034,7 @@ __global__ __launch_bounds__(64, 4) void k_gz_chunks(const uint8_t *comp, const 
     u64 in_bits = n_bytes * 8u;
     u64 search_end = n_bytes > GZ_TAIL_GUARD ? (n_bytes - GZ_TAIL_GUARD) * 8u : 0u; // no start is looked for beyond
     const u64 range_end = (u64)(ci + 1u) * chunk_bits;
+    if (times && lane == 0) times[3u * ci + 1u] = __builtin_amdgcn_s_memrealtime();
     u64 start;
     if (ci == 0u) {
         start = first_bit;
@@ -1154,6 +1187,7 @@ __global__ __launch_bounds__(64, 4) void k_gz_chunks(const uint8_t *comp, const 
     }
     flush_queue(L, out, qn, lane, true);
     if (lane == 0) recs[ci] = GzChunk{start, end_bit, end_pos - GZ_WINDOW, state};
+    if (times && lane == 0) times[3u * ci + 2u] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1669,7 +1703,7 @@ uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
 hipError_t launch_gzip_chunks(const GzBatch &b, const GzFeed *feed, uint64_t avail_bytes, uint32_t c0, uint32_t n, bool final, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_gz_chunks, dim3(n), dim3(64), 0, st, b.comp, feed, avail_bytes, b.chunk_bits, c0, b.first_bit, final ? 1u : 0u, b.recs,
-                       b.sym, b.cap, b.claims, b.n_regions);
+                       b.sym, b.cap, b.claims, b.n_regions, b.times);
     return hipGetLastError();
 }
 

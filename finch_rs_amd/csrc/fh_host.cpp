@@ -2925,10 +2925,12 @@ static int gzip_fastq_to_device(BgzfSource &bz, size_t hdr_len, fh_sketcher *h) 
         if (bz.raw_read(skip.data(), hdr_len) != hdr_len) return hfail(FH_ERR_INVALID, "gzip header cut short");
     }
     // A batch fills one buffer, in pieces: every piece is handed over as soon as it has been read (FH_GZ_MORE), so that the
-    // device decodes the front of the batch while the rest of it is still coming in.
+    // device decodes the front of the batch while the rest of it is still coming in.  (What counts is when the LAST byte is
+    // there -- every chunk of a batch is resident at once, and a live one takes ~10 ms whenever it starts --, so pieces are
+    // as large as it takes for the reads to be split over the call's read threads.)
     static const uint64_t PIECE = [] {
         const char *e = getenv("FINCH_GZIP_PIECE"); // (A/B)
-        return e ? std::max<uint64_t>(65536, strtoull(e, nullptr, 10)) : ((uint64_t)4 << 20);
+        return e ? std::max<uint64_t>(65536, strtoull(e, nullptr, 10)) : ((uint64_t)16 << 20); // (what FileSource splits over the call's read threads)
     }();
     struct Job {
         int slot;

@@ -151,6 +151,7 @@ struct GzBatch {
     uint16_t *sym;
     uint32_t *claims;   // [n_regions]: who writes each chunk's stretch of `sym` (zero before a batch's first chunks are launched)
     uint32_t n_regions; // stretches there are (>= n_chunks)
+    uint64_t *times;    // nullptr, or 3 x n_regions: when every chunk's wavefront was dispatched / had its bytes / was done (100 MHz ticks)
     uint8_t *win_in, *window;
     uint16_t *group_map; // GZ_GROUPS x GZ_WINDOW
     uint8_t *group_win;  // GZ_GROUPS x GZ_WINDOW

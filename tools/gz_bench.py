@@ -42,7 +42,7 @@ try:
         if env:
             os.environ["FINCH_DEVICE_GZIP"] = env
         best = 1e9
-        for _ in range(4):
+        for _ in range(int(os.environ.get("GZ_REPS", "4"))):
             t0 = time.perf_counter()
             sk = H.sketch_files([path], p, H.FilterParams(False))
             best = min(best, time.perf_counter() - t0)
