@@ -1637,6 +1637,7 @@ void destroy_handle(fh_sketcher *s) {
 int fh_reset(fh_sketcher *s) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (int rc = set_device(s)) return rc;
+    gzip_quiesce(s); // (a launch that waits for the rest of an abandoned batch holds the stream until it is told to give up)
     if (s->device_clean && s->finished && !s->pend.active && !s->epi_pending) { // fh_finish's epilogue has done the device side
         s->device_clean = false;
         return init_state(s, false);

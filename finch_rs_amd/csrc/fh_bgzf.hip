@@ -983,10 +983,10 @@ struct GzGrow {
     }
 };
 
-constexpr u64 GZ_WAIT_TICKS = 100000000ull; // s_memrealtime ticks (100 MHz) a wavefront waits for its bytes before it gives up
+constexpr u64 GZ_WAIT_TICKS = 300000000ull; // s_memrealtime ticks (100 MHz: three seconds) a wavefront waits for its bytes before it gives up
 
 // Wait until `need` bytes of the batch are on the device, or all of it is: how many there are (n_bytes) and whether more will
-// come (state, GzFeed).  false: told to give up, or nothing moved for a second.
+// come (state, GzFeed).  false: told to give up, or nothing moved for three seconds (a reader stalled that long: the host-side inflate takes the file).
 __device__ __noinline__ bool gz_wait_bytes(const GzFeed *feed, u64 need, u64 &n_bytes, u32 &state, u32 lane) {
     u32 ok = 1, st = 0, av_lo = 0, av_hi = 0;
     if (lane == 0) {

@@ -206,6 +206,41 @@ def test_trailing_bytes_are_reported_and_damage_is_loud(chunk_env):
     sk.close()
 
 
+def test_a_batch_abandoned_half_way_does_not_leave_the_device_waiting(chunk_env):
+    """FH_GZ_MORE launches the batch's decoding at once; if the rest never comes, fh_reset (and fh_free) tell the launch to give up
+    -- promptly, not after its three-second patience -- and the handle decodes the next stream as if nothing had happened"""
+    import time
+    text = b"".join(fastq_text(9000, 700 + i) for i in range(3))
+    body = deflate_raw(text, level=6) + zlib.crc32(text).to_bytes(4, "little") + len(text).to_bytes(4, "little")
+    o = O.OracleSketcher(O.MASH, 500, 21, 0, 0.001)
+    o.sketch_stream(text)
+    sk = new_sketcher(500, 21)
+    L, h = sk._L, sk._h
+    bufs = (C.c_void_p * 2)()
+    cap, nxt = C.c_uint64(), C.c_int()
+    S.check(L.fh_text_buffers(h, bufs, C.byref(cap), C.byref(nxt)))
+    done, trailing = C.c_uint32(), C.c_uint64()
+    for _ in range(2):
+        piece = body[:len(body) // 3]
+        C.memmove(bufs[nxt.value], piece, len(piece))
+        S.check(L.fh_push_gzip_fastq(h, len(piece), FH_GZ_FIRST | FH_GZ_MORE, C.byref(done), C.byref(trailing)))
+        t0 = time.perf_counter()
+        sk.reset()
+        assert time.perf_counter() - t0 < 1.0
+        S.check(L.fh_text_buffers(h, bufs, C.byref(cap), C.byref(nxt)))
+    assert push_stream(sk, body, None, 1 << 20)[:2] == (1, 0)
+    assert_is_oracle_sketch(sk, o)
+    # ... and a handle freed in that state
+    sk2 = new_sketcher(500, 21)
+    S.check(sk2._L.fh_text_buffers(sk2._h, bufs, C.byref(cap), C.byref(nxt)))
+    C.memmove(bufs[nxt.value], body[:100_000], 100_000)
+    S.check(sk2._L.fh_push_gzip_fastq(sk2._h, 100_000, FH_GZ_FIRST | FH_GZ_MORE, C.byref(done), C.byref(trailing)))
+    t0 = time.perf_counter()
+    sk2.close()
+    assert time.perf_counter() - t0 < 1.0
+    sk.close()
+
+
 def sketch_of(path, p, device_gzip=True, **kw):
     if not device_gzip:
         os.environ["FINCH_DEVICE_GZIP"] = "0"
