@@ -1687,7 +1687,13 @@ static int open_source(std::unique_ptr<ByteSource> raw, std::unique_ptr<ByteSour
     if (bz && !Bz2Source::api().ok) return hfail(FH_ERR_UNSUPPORTED, "bzip2-compressed input: libbz2.so.1 not found");
     if (xz && !XzSource::api().ok) return hfail(FH_ERR_UNSUPPORTED, "xz-compressed input: liblzma.so.5 not found");
     if (is_gz) *is_gz = gz || bz || xz; // "compressed": not eligible for device-side text parsing
-    if (gz && dec_threads > 1) out = std::make_unique<BgzfSource>(std::move(pre), dec_threads); // falls back member by member
+    // (FINCH_GZ_FRONT=1, A/B: the reader that knows BGZF and hands compressed bytes to the device stands in front of gzip
+    //  input even when the call has no read thread to spare for it -- the workers of a many-file call)
+    static const bool front_always = [] {
+        const char *e = getenv("FINCH_GZ_FRONT");
+        return e && e[0] == '1';
+    }();
+    if (gz && (dec_threads > 1 || (front_always && !use_zlib_inflate()))) out = std::make_unique<BgzfSource>(std::move(pre), dec_threads); // falls back member by member
     else if (gz && use_zlib_inflate()) out = std::make_unique<GzSource>(std::move(pre));
     else if (gz) out = std::make_unique<FastGzSource>(std::move(pre));
     else if (bz) out = std::make_unique<Bz2Source>(std::move(pre));

@@ -1,10 +1,10 @@
-"""GPU tests of the device-side inflate of PLAIN gzip (fh_bgzf.hip: k_gz_find / k_gz_inflate / k_gz_chain / k_gz_text,
+"""GPU tests of the device-side inflate of PLAIN gzip (fh_bgzf.hip: k_gz_chunks / k_gz_chain / k_gz_win_* / k_gz_text,
 fh_push_gzip_fastq): one DEFLATE stream cut into chunks, every chunk decoded from a block start found by search, the
 chain of chunks stitched and the markers of the unknown windows looked up.  The text must be the text zlib produces --
 checked through the sketch of it against the oracle and through the stream's own CRC-32 -- for every block type, for
-chunks far smaller than a block (most "starts" then are none, or there is none in a chunk), across pushes (undecoded
-bytes, window and partial record carried over), and anything the device pass cannot vouch for must end up with the
-host-side inflate's verdict.  Run with -m gpu."""
+chunks far smaller than a block (most then hold no start at all), across batches (undecoded bytes, window and partial
+record carried over), for batches handed over in pieces while the launch that decodes them is already waiting, and
+anything the device pass cannot vouch for must end up with the host-side inflate's verdict.  Run with -m gpu."""
 import ctypes as C
 import gzip
 import os
