@@ -1211,6 +1211,38 @@ __host__ __device__ inline u32 crc_multmodp(u32 a, u32 b) {
 struct X2N {
     u32 t[32]; // x^(2^k) mod P
 };
+// the same table where a kernel can index it with a register: as a kernel argument it lives in scalar registers, and an index
+// that is not a constant sends the whole of it through scratch memory -- k_gz_crc_join spent 0.4 ms on 5 000 multiplications
+constexpr u32 crc_multmodp_c(u32 a, u32 b) {
+    u32 m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1u)) == 0u) break;
+        }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+struct X2NTable {
+    u32 t[32];
+    constexpr X2NTable() : t() {
+        u32 p = 1u << 30; // x^1
+        t[0] = p;
+        for (int k = 1; k < 32; ++k) t[k] = p = crc_multmodp_c(p, p);
+    }
+};
+__device__ __constant__ X2NTable g_x2n = X2NTable();
+__device__ inline u32 crc_x2n(u32 n, u32 k) { // x^(n * 2^k) mod P
+    u32 p = 1u << 31;
+    while (n) {
+        if (n & 1u) p = crc_multmodp(g_x2n.t[k & 31u], p);
+        n >>= 1;
+        k++;
+    }
+    return p;
+}
 __device__ inline u32 crc_x2nmodp(const X2N &x, u32 n, u32 k) { // x^(n * 2^k) mod P
     u32 p = 1u << 31;
     while (n) {
@@ -1221,6 +1253,51 @@ __device__ inline u32 crc_x2nmodp(const X2N &x, u32 n, u32 k) { // x^(n * 2^k) m
     return p;
 }
 } // namespace
+
+// CRC-32 of p[0, size) by one wavefront, 4 KiB at a time: every lane checksums 64 consecutive bytes of the block (a load
+// instruction of the wavefront then covers whole cache lines, and the next three use the rest of them -- a lane walking
+// through a KiB of its own made every load fetch 64 lines for 256 bytes, sixteen times the text through the L1), the 64
+// checksums are shifted past what follows them in the block and folded, and the block's joins those of the blocks before it.
+// T: the four slicing tables (LDS); ops[lane]: x^(8 * 64 * (63 - lane)) mod P, op_block: x^(8 * 4096) mod P.
+struct CrcLaneOps {
+    u32 piece, block;
+};
+__device__ __forceinline__ CrcLaneOps crc_lane_ops(const X2N &x2n, u32 lane) {
+    return CrcLaneOps{crc_x2n(64u * (63u - lane), 3), crc_x2n(4096u, 3)};
+}
+__device__ __forceinline__ u32 wave_crc32(const uint8_t *p, u32 size, const u32 (*T)[256], const X2N &x2n, const CrcLaneOps &ops, u32 lane) {
+    u32 running = 0;
+    for (u32 b0 = 0; b0 < size; b0 += 4096u) {
+        const u32 blen = size - b0 < 4096u ? size - b0 : 4096u;
+        const u32 o = lane * 64u;
+        const u32 n = o < blen ? (blen - o < 64u ? blen - o : 64u) : 0u;
+        const uint8_t *q = p + b0 + o;
+        u32 c = 0xFFFFFFFFu;
+        if (n == 64u) {
+            uint4 w[4];
+#pragma unroll
+            for (u32 k = 0; k < 4u; ++k) __builtin_memcpy(&w[k], q + 16u * k, 16);
+            const u32 *v = (const u32 *)w;
+#pragma unroll
+            for (u32 k = 0; k < 16u; ++k) {
+                c ^= v[k];
+                c = T[3][c & 0xFFu] ^ T[2][(c >> 8) & 0xFFu] ^ T[1][(c >> 16) & 0xFFu] ^ T[0][c >> 24];
+            }
+        } else {
+            for (u32 i = 0; i < n; ++i) c = (c >> 8) ^ T[0][(c ^ q[i]) & 0xFFu];
+        }
+        c ^= 0xFFFFFFFFu;
+        u32 part = 0;
+        if (n) {
+            // (a full block: the lane's operator is ready; the last, shorter one: worked out from what follows the piece)
+            const u32 op = blen == 4096u ? ops.piece : crc_x2n(blen - o - n, 3);
+            part = crc_multmodp(op, c);
+        }
+        for (int off = 32; off > 0; off >>= 1) part ^= __shfl_xor(part, off);
+        running = crc_multmodp(blen == 4096u ? ops.block : crc_x2n(blen, 3), running) ^ part;
+    }
+    return running;
+}
 
 __global__ __launch_bounds__(256) void k_bgzf_crc(const BgzfMember *members, u32 n_members, const uint8_t *text, X2N x2n,
                                                   u32 *status) {
@@ -1240,6 +1317,8 @@ __global__ __launch_bounds__(256) void k_bgzf_crc(const BgzfMember *members, u32
     const u32 mi = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (mi >= n_members) return;
     const BgzfMember m = members[mi];
+    // (a lane per sixty-fourth of the member; wave_crc32's layout -- made for the long text of a gzip batch -- is no faster here:
+    // 167 against 159 us per launch of ~1500 members, profiles/r04_crc_ab.txt)
     const u32 slice = (((m.isize + 63u) >> 6) + 3u) & ~3u;
     const u32 lo = lane * slice < m.isize ? lane * slice : m.isize;
     const u32 hi = lo + slice < m.isize ? lo + slice : m.isize;
@@ -1399,6 +1478,7 @@ __global__ __launch_bounds__(1024) void k_gz_chain(GzBatch B) {
         const u64 end_bit = B.recs[s_last].end_bit;
         const u32 kind = s_kind;
         S[GZS_STATUS] = status;
+        S[GZS_CRC] = 0; // (k_gz_crc_join XORs the slices' shares into it)
         S[GZS_N_LIVE] = n;
         S[GZS_TOTAL] = (u32)total;
         S[GZS_END_STATE] = kind;
@@ -1631,47 +1711,36 @@ __global__ __launch_bounds__(256) void k_gz_crc_slices(GzBatch B, X2N x2n) {
     const u32 si = blockIdx.x * 4u + (threadIdx.x >> 6);
     if ((u64)si * 65536u >= total) return;
     const u32 size = total - si * 65536u < 65536u ? total - si * 65536u : 65536u;
-    const u32 slice = (((size + 63u) >> 6) + 3u) & ~3u;
-    const u32 lo = lane * slice < size ? lane * slice : size;
-    const u32 hi = lo + slice < size ? lo + slice : size;
-    const uint8_t *p = B.text + B.left + (u64)si * 65536u;
-    u32 c = 0xFFFFFFFFu, i = lo;
-    for (; i < hi && ((uintptr_t)(p + i) & 3u); ++i) c = (c >> 8) ^ T[0][(c ^ p[i]) & 0xFFu];
-    for (; i + 4u <= hi; i += 4u) {
-        c ^= *(const u32 *)(p + i);
-        c = T[3][c & 0xFFu] ^ T[2][(c >> 8) & 0xFFu] ^ T[1][(c >> 16) & 0xFFu] ^ T[0][c >> 24];
-    }
-    for (; i < hi; ++i) c = (c >> 8) ^ T[0][(c ^ p[i]) & 0xFFu];
-    c ^= 0xFFFFFFFFu;
-    u32 part = hi > lo ? crc_multmodp(crc_x2nmodp(x2n, size - hi, 3), c) : 0u;
-    for (int off = 32; off > 0; off >>= 1) part ^= __shfl_xor(part, off);
-    if (lane == 0) B.crc_tmp[si] = part;
+    const CrcLaneOps ops = crc_lane_ops(x2n, lane);
+    const u32 crc = wave_crc32(B.text + B.left + (u64)si * 65536u, size, T, x2n, ops, lane);
+    if (lane == 0) B.crc_tmp[si] = crc;
 }
+// crc(whole) = the XOR over the slices of crc(slice) shifted past everything behind the slice: all shifts independent.  A thread
+// takes a run of consecutive slices, works out the shift of its last one from the byte count (x^(8 n) mod P by the bits of n),
+// and gets from slice to slice before it with one multiplication by x^(8 * 65536).
+// (sixteen wavefronts on sixteen CUs: on one they take turns, and the byte count's thirty multiplications are most of the work)
 __global__ __launch_bounds__(64) void k_gz_crc_join(GzBatch B, X2N x2n) {
     if (B.summary[GZS_STATUS]) return;
     const u32 total = B.summary[GZS_TOTAL];
-    const u32 lane = threadIdx.x;
+    const u32 tid = blockIdx.x * 64u + threadIdx.x;
     const u32 n = (u32)(((u64)total + 65535u) >> 16);
-    const u32 per = (n + 63u) / 64u;
-    const u32 lo = lane * per < n ? lane * per : n, hi = lo + per < n ? lo + per : n;
-    const u32 shift64k = crc_x2nmodp(x2n, 65536u, 3);
+    const u32 per = (n + 1023u) / 1024u;
+    const u32 lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
     u32 acc = 0;
-    u64 bytes = 0;
-    for (u32 s = lo; s < hi; ++s) {
-        const u32 size = total - s * 65536u < 65536u ? total - s * 65536u : 65536u;
-        const u32 op = size == 65536u ? shift64k : crc_x2nmodp(x2n, size, 3);
-        acc = crc_multmodp(op, acc) ^ B.crc_tmp[s];
-        bytes += size;
+    if (lo < hi) {
+        const u64 e = (u64)hi * 65536u;
+        const u32 end_last = e < total ? (u32)e : total; // where the run's last slice ends
+        u32 op = crc_x2n(total - end_last, 3);
+        const u32 step = crc_x2n(65536u, 3);
+        for (u32 i = hi; i-- > lo;) {
+            acc ^= crc_multmodp(op, B.crc_tmp[i]);
+            // the slice in front of slice i has slice i's bytes behind it as well
+            const u32 len_i = total - i * 65536u < 65536u ? total - i * 65536u : 65536u;
+            op = crc_multmodp(op, len_i == 65536u ? step : crc_x2n(len_i, 3));
+        }
     }
-    // the lanes' stretches, in order
-    const u32 my_op = crc_x2nmodp(x2n, (u32)bytes, 3); // (a lane holds < 2^32 bytes: the whole text does)
-    u32 crc = 0;
-    for (u32 l = 0; l < 64u; ++l) {
-        const u32 a = (u32)__builtin_amdgcn_readlane((int)acc, (int)l), op = (u32)__builtin_amdgcn_readlane((int)my_op, (int)l);
-        const u32 nb = (u32)__builtin_amdgcn_readlane((int)(u32)bytes, (int)l);
-        if (nb) crc = crc_multmodp(op, crc) ^ a;
-    }
-    if (lane == 0) B.summary[GZS_CRC] = crc;
+    for (int off = 32; off > 0; off >>= 1) acc ^= (u32)__shfl_xor((int)acc, off);
+    if (threadIdx.x == 0 && acc) atomicXor(&B.summary[GZS_CRC], acc); // (k_gz_chain left it at zero)
 }
 // (launch_fastq_cut for a total only the device knows)
 __global__ __launch_bounds__(64) void k_gz_cut(GzBatch B) {
@@ -1719,7 +1788,7 @@ hipError_t launch_gzip_batch(const GzBatch &b, hipStream_t st, hipStream_t st_cr
     if (hipError_t e = hipStreamWaitEvent(st_crc, text_done, 0); e != hipSuccess) return e;
     const u32 n_slices = (u32)((b.text_cap + 65535u) / 65536u);
     hipLaunchKernelGGL(k_gz_crc_slices, dim3((n_slices + 3u) / 4u), dim3(256), 0, st_crc, b, x2n_table());
-    hipLaunchKernelGGL(k_gz_crc_join, dim3(1), dim3(64), 0, st_crc, b, x2n_table());
+    hipLaunchKernelGGL(k_gz_crc_join, dim3(16), dim3(64), 0, st_crc, b, x2n_table());
     hipLaunchKernelGGL(k_gz_cut, dim3(1), dim3(64), 0, st, b);
     return hipGetLastError();
 }
