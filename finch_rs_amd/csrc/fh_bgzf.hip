@@ -84,7 +84,23 @@ struct LdsT {
     QP qpos[128];     // ... and where they go
 };
 using Lds = LdsT<uint16_t>; // BGZF: a member's text is at most 65536 bytes, a token starts below that
-using LdsGz = LdsT<u32>;    // plain gzip: a chunk's symbols, the 32768 window slots in front included
+// plain gzip: a chunk's symbols, the 32768 window slots in front included -- and the last GZ_RING of them kept in LDS, where the
+// matches of a group of tokens that reach back into the group itself (a header copied from the record before, a run of one
+// quality value) find their source without a round trip through the L2 (resolve_group_ring)
+constexpr u32 GZ_RING = 1024;
+constexpr u32 GZ_COOP_LEN = 24; // matches longer than this are copied by the wavefront together (resolve_group_ring)
+struct LdsGz : LdsT<u32> {
+    uint16_t ring[GZ_RING]; // symbol at position p: ring[p % GZ_RING], for ring_from <= p < the end of the last group written
+    u32 ring_from;
+};
+template <class L>
+struct HasRing {
+    static constexpr bool value = false;
+};
+template <>
+struct HasRing<LdsGz> {
+    static constexpr bool value = true;
+};
 
 __device__ __forceinline__ u32 rfl(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
 // v_writelane_b32 (clang has no builtin of that name; the LLVM intrinsic takes care of M0 for the lane select)
@@ -369,6 +385,104 @@ __device__ __forceinline__ u32 wave_scan_add(u32 v) {
     return v;
 }
 
+// The same for the chunks of a plain gzip stream, through the ring: every symbol of the group is first written to LDS -- a
+// literal as it is, a match from the ring where its source is recent, from global memory where it lies further back (written
+// there by earlier groups: one wait at the start covers them) -- and a lane whose source lies inside the group waits for an
+// LDS round, not for stores to reach the L2 and come back; then the group goes out to global memory in one piece, 16 bytes a
+// lane.  (Writing straight to global memory and waiting for it between rounds was half of k_gz_chunks' time.)  A group longer
+// than the ring goes the long way and leaves the ring empty.
+__device__ __noinline__ void resolve_group_ring(LdsGz &L, uint16_t *out, u32 tpos, u32 tinfo, u32 ntok, u32 lane) {
+    constexpr u32 M = GZ_RING - 1u;
+    const u32 len = tinfo & 0x1FFu, hi = tinfo >> 16;
+    const u32 adv = len ? len : 1u + ((tinfo >> 9) & 1u);
+    const u32 G0 = (u32)__builtin_amdgcn_readlane((int)tpos, 0);
+    const u32 G1 = (u32)__builtin_amdgcn_readlane((int)(tpos + adv), (int)(ntok - 1u));
+    u32 R0 = rfl(L.ring_from);
+    if (G1 - G0 > GZ_RING || R0 > G0) {
+        resolve_group(out, tpos, tinfo, ntok, lane);
+        if (lane == 0) L.ring_from = G1;
+        return;
+    }
+    if (G1 > GZ_RING && R0 < G1 - GZ_RING) R0 = G1 - GZ_RING; // (what lies further back is overwritten by this group)
+    // (out of line, this function sees L through a generic pointer: the ring is addressed as what it is, LDS)
+    __attribute__((address_space(3))) uint16_t *const ring = (__attribute__((address_space(3))) uint16_t *)L.ring;
+    bool done = lane >= ntok;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, BZ_FENCE_SCOPE); // earlier groups' symbols are in global memory
+    for (;;) {
+        const unsigned long long pending = __ballot(!done);
+        if (pending == 0ull) break;
+        const u32 W = (u32)__builtin_amdgcn_readlane((int)tpos, (int)__builtin_ctzll(pending));
+        if (!done) {
+            if (len == 0u) {
+                ring[tpos & M] = (uint16_t)(hi & 0xFFu);
+                if (tinfo & 0x200u) ring[(tpos + 1u) & M] = (uint16_t)((hi >> 8) & 0xFFu);
+                done = true;
+            } else {
+                const u32 src = tpos - hi;
+                const u32 src_end = src + (len < hi ? len : hi); // (an overlapping match re-reads its own symbols)
+                if (src_end <= W && len <= GZ_COOP_LEN) {
+                    if (src_end <= R0 && hi >= len) { // all of it further back than the ring: four symbols a load
+                        const uint16_t *sp = out + src;
+                        for (u32 j = 0; j < len; j += 32u) {
+                            const u32 n = len - j < 32u ? len - j : 32u;
+                            u64 r[8];
+#pragma unroll
+                            for (u32 q = 0; q < 8u; ++q)
+                                if (4u * q < n) __builtin_memcpy(&r[q], sp + j + 4u * q, 8); // (may read up to 3 symbols past the match: not kept)
+#pragma unroll
+                            for (u32 q = 0; q < 8u; ++q) {
+                                u64 w = r[q];
+#pragma unroll
+                                for (u32 z = 0; z < 4u; ++z, w >>= 16)
+                                    if (4u * q + z < n) ring[(tpos + j + 4u * q + z) & M] = (uint16_t)w;
+                            }
+                        }
+                    } else {
+                        for (u32 j = 0; j < len; ++j) {
+                            const u32 p = src + j;
+                            ring[(tpos + j) & M] = p >= R0 ? ring[p & M] : out[p];
+                        }
+                    }
+                    done = true;
+                }
+            }
+        }
+        // A long match would hold the other 63 lanes up for as many steps as it has symbols (a run of one quality value: 150
+        // of them in every record): the wavefront copies those together, 64 symbols a step.  Its source is complete (that is
+        // what "ready" means), and where a match overlaps itself every symbol is its pattern's, src + j mod dist.
+        unsigned long long longs = __ballot(!done && len > GZ_COOP_LEN && (tpos - hi) + (len < hi ? len : hi) <= W);
+        while (longs) {
+            const int l = (int)__builtin_ctzll(longs);
+            longs &= longs - 1ull;
+            const u32 t_pos = (u32)__builtin_amdgcn_readlane((int)tpos, l), t_len = (u32)__builtin_amdgcn_readlane((int)len, l);
+            const u32 t_dist = (u32)__builtin_amdgcn_readlane((int)hi, l);
+            const u32 t_src = t_pos - t_dist;
+            for (u32 j = lane; j < t_len; j += 64u) {
+                const u32 p = t_src + (t_dist >= t_len ? j : j % t_dist);
+                uint16_t v;
+                if (p >= R0) v = ring[p & M];
+                else v = __builtin_nontemporal_load(out + p);
+                ring[(t_pos + j) & M] = v;
+            }
+            if ((int)lane == l) done = true;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // (the LDS serves a wavefront's accesses in order: nothing to wait for)
+    }
+    // the group's symbols, in one piece
+    const u32 span = G1 - G0;
+    for (u32 e = lane * 8u; e < span; e += 512u) {
+        uint16_t v[8];
+#pragma unroll
+        for (u32 q = 0; q < 8u; ++q) v[q] = ring[(G0 + e + q) & M];
+        if (e + 8u <= span) {
+            __builtin_memcpy(out + G0 + e, v, 16);
+        } else {
+            for (u32 q = 0; e + q < span; ++q) out[G0 + e + q] = v[q];
+        }
+    }
+    if (lane == 0) L.ring_from = R0;
+}
+
 // write out the queued tokens, 64 at a time (`all`: the rest too)
 template <class LDS, class T>
 __device__ void flush_queue(LDS &L, T *out, u32 &qn, u32 lane, bool all) {
@@ -376,7 +490,11 @@ __device__ void flush_queue(LDS &L, T *out, u32 &qn, u32 lane, bool all) {
         const u32 n = qn < 64u ? qn : 64u;
         __syncthreads();
         const u32 tpos = L.qpos[lane], tinfo = L.qinfo[lane];
-        resolve_group(out, tpos, tinfo, n, lane);
+#ifndef FH_GZ_NO_RING // (A/B builds)
+        if constexpr (HasRing<LDS>::value) resolve_group_ring(L, out, tpos, tinfo, n, lane);
+        else
+#endif
+            resolve_group(out, tpos, tinfo, n, lane);
         const u32 rest = qn - n;
         const u32 p1 = L.qpos[64u + lane], i1 = L.qinfo[64u + lane];
         __syncthreads();
@@ -1057,6 +1175,7 @@ __global__ __launch_bounds__(64, 4) void k_gz_chunks(const uint8_t *comp, const 
     }
     uint16_t *out = sym + (u64)ci * cap;
     for (u32 j = lane; j < GZ_WINDOW / 2u; j += 64u) ((u32 *)out)[j] = (0x8000u | (2u * j)) | ((0x8001u | (2u * j)) << 16);
+    if (lane == 0) L.ring_from = GZ_WINDOW; // (nothing in the ring yet)
     __syncthreads();
     u32 limit = cap > 0x7FFFFFF0ull ? 0x7FFFFFF0u : (u32)cap, owned = 1;
     const GzGrow grow{ci, n_regions, claims, &owned, cap, chunk_bits};
@@ -1137,6 +1256,7 @@ __global__ __launch_bounds__(64, 4) void k_gz_chunks(const uint8_t *comp, const 
             const uint8_t *src = comp + used;
             for (u32 j = lane; j < len; j += 64u) out[pos + j] = src[j];
             pos += len;
+            if (lane == 0) L.ring_from = pos; // (these went straight to global memory)
             rd_init(r, comp, used + len, n_bytes, (used + len) * 8u, lane);
         } else {
             u32 hlit = 288, hdist = 32;
