@@ -88,7 +88,10 @@ using Lds = LdsT<uint16_t>; // BGZF: a member's text is at most 65536 bytes, a t
 // matches of a group of tokens that reach back into the group itself (a header copied from the record before, a run of one
 // quality value) find their source without a round trip through the L2 (resolve_group_ring)
 constexpr u32 GZ_RING = 1024;
-constexpr u32 GZ_COOP_LEN = 24; // matches longer than this are copied by the wavefront together (resolve_group_ring)
+#ifndef FH_GZ_COOP_LEN
+#define FH_GZ_COOP_LEN 8
+#endif
+constexpr u32 GZ_COOP_LEN = FH_GZ_COOP_LEN; // matches longer than this are copied by the wavefront together (resolve_group_ring)
 struct LdsGz : LdsT<u32> {
     uint16_t ring[GZ_RING]; // symbol at position p: ring[p % GZ_RING], for ring_from <= p < the end of the last group written
     u32 ring_from;
