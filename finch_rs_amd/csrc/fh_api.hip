@@ -2158,14 +2158,15 @@ int fh_push_bgzf_fastq(fh_sketcher *s, uint64_t bytes, uint32_t n_members, uint3
 // Plain gzip of FASTQ text -- one DEFLATE stream, no index -- inflated on the device (fh_bgzf.hip: k_gz_chunks, k_gz_chain,
 // k_gz_win_*, k_gz_text).  A batch is the bytes of the pushes up to and including the first one without FH_GZ_MORE: they are
 // cut into chunks of ~a block's worth, a wavefront decodes each from the first block start found in it, and the chain of
-// chunks that really continue each other gives the text.  The chunks of a piece are launched as soon as the piece behind it
-// has been queued for copying, so the device decodes while the caller reads on.  The bytes behind the last block boundary
+// chunks that really continue each other gives the text.  A batch that comes in pieces is decoded by ONE launch that is there
+// from the first piece on: its wavefronts wait for their bytes on a word in pinned host memory that every push moves on
+// (GzFeed), so the device decodes while the caller reads on.  The bytes behind the last block boundary
 // reached stay on the device and lead the next batch, as do the 32 KiB of text a match may reach back into and the partial
 // FASTQ record the text ended with.
 constexpr uint64_t GZ_CHUNK_BYTES = 8192;   // compressed bytes per chunk, at least (12 KiB with the default buffers: GZ_MAX_CHUNKS chunks have to cover a
-                                            // batch): below a block of level-1 output, so that a wavefront seldom decodes more than one block and
-                                            // the last ones of a batch are done soon after its last byte has arrived (a chunk without a block
-                                            // start costs a scan of its range)
+                                            // batch): below a block of level-1 output, so that a wavefront seldom decodes more than one block --
+                                            // every chunk of a batch is resident at once, and the launch lasts as long as its longest chunk (a
+                                            // chunk without a block start costs a scan of its range)
 constexpr uint64_t GZ_SYM_PER_BYTE = 16;    // symbol slots per byte of a chunk: text up to eight times its DEFLATE bytes, for the chunk's own range
                                             // and the one behind it -- only once a chunk has decoded all the way THROUGH a range behind it may it
                                             // take that range's slots over as well (k_gz_chunks)
