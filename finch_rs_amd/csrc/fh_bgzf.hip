@@ -1125,7 +1125,12 @@ __device__ __noinline__ bool gz_wait_bytes(const GzFeed *feed, u64 need, u64 &n_
                 ok = 0;
                 break;
             }
-            __builtin_amdgcn_s_sleep(127);
+            // (every poll is a read across the PCIe link, and thousands of wavefronts may be waiting while the batch's own
+            // bytes come in over it: the further away a wavefront's bytes are, the longer it sleeps -- 3.4 us per 32 KiB
+            // still missing, what arrives in that time at 10 GB/s, half a millisecond at most)
+            const u64 missing = need - av;
+            const u32 naps = missing >> 15 > 128u ? 128u : (u32)(missing >> 15);
+            for (u32 i = 0; i <= naps; ++i) __builtin_amdgcn_s_sleep(127);
         }
     }
     ok = rfl(ok), st = rfl(st), av_lo = rfl(av_lo), av_hi = rfl(av_hi);
