@@ -578,6 +578,19 @@ FH_HD void murmur_lookup(u64 cm, const LutTables &T, KeyWords<K> &w) { // cm = c
     for (int i = 0; i < KeyWords<K>::N; ++i) {
         const WordGeom g = word_geom(K, i);
         w.a0[i] = w.a1[i] = w.a2[i] = w.b0[i] = w.b1[i] = 0;
+#ifdef FH_EXP_NO_LDS // measurement only -- WRONG hashes: the records are made of their offsets, no table is read (what the lookups cost the loop)
+        if (g.kind == 1) {
+            w.a0[i] = field_off(cml, cmh, g.shiftA + PRE, g.nbA, 3);
+            w.a1[i] = cmh;
+        } else if (g.kind == 2) {
+            w.a0[i] = field_off(cml, cmh, g.shiftA + PRE, 4, 4);
+            w.a1[i] = cml;
+            w.a2[i] = cmh;
+            w.b0[i] = field_off(cml, cmh, g.shiftB + PRE, g.nbB, 3);
+            w.b1[i] = cml;
+        }
+        continue;
+#endif
         if (g.kind == 1) {
             const Rec2 r = *(const Rec2 *)((const char *)T.P + field_off(cml, cmh, g.shiftA + PRE, g.nbA, 3));
             w.a0[i] = r.x;

@@ -232,6 +232,9 @@ __global__ __launch_bounds__(64 * k2_wpb_of(K), k2_min_waves(K)) void k2_sketch(
     bool stop = false;
     classify_tile(a, rt0, lane, codes_ring, good_ring);
     for (u64 t = rt0; t < rt1; ++t) {
+#ifdef FH_EXP_NO_PHASE_A // measurement only -- WRONG sketches: the tiles behind a range's second are never loaded (what phase A and the wait for its loads cost)
+        if (t == rt0)
+#endif
         classify_tile(a, t + 1, lane, codes_ring, good_ring); // also provides the halo of lane 63
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -286,7 +289,12 @@ __global__ __launch_bounds__(64 * k2_wpb_of(K), k2_min_waves(K)) void k2_sketch(
             // reject on the high words alone (fh_core.h, HashParts); the hash_mask test hook needs the full hash.
             // windows that carry no k-mer hash garbage; they are rejected on the (rare) admit path only
             const bool cand = MASKED ? ((parts_hash(hp) & a.hash_mask) <= tau) : (parts_hi_plus1(hp) <= tau_hi1);
+#ifdef FH_EXP_NO_ADMIT // measurement only -- EMPTY sketches: candidates are counted, never parked (what the admit branch costs the loop)
+            nvalid += (u32)cand;
+            if (false) {
+#else
             if (__builtin_expect(__any(cand), 0)) { // wave-uniform branch
+#endif
                 // the candidate is parked with its hash unfinished; flush_queue completes and tests it (fh_k2_common.h)
                 const bool take = cand && ((Wc >> j) & 1u);
                 const u64 mask = __ballot(take);

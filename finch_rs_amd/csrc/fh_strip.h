@@ -64,7 +64,22 @@ __attribute__((target("avx2"))) inline size_t strip_avx2(uint8_t *dst, const uin
         m += p;
         i += p + 1;
     }
-    return m + strip_scalar(dst + m, src + i, n - i); // (fewer than 32 bytes)
+    if (i == n) return m;
+    // Fewer than 32 bytes are left.  With a whole vector behind them in src, load the LAST 32 bytes of src once more: if there
+    // is no blank among them, the n - i new ones follow in dst exactly where the vector's older bytes already lie (nothing was
+    // dropped between them), so one store that overlaps those finishes the copy -- a read's 150 or 250 bases end in such a
+    // tail, and the byte loop it replaces took as long as the vectors in front of it
+    if (n >= 32 && m >= 32 - (n - i)) {
+        const __m256i v = _mm256_loadu_si256((const __m256i *)(src + n - 32));
+        const __m256i b = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, sp), _mm256_cmpeq_epi8(v, tb)),
+                                          _mm256_or_si256(_mm256_cmpeq_epi8(v, cr), _mm256_cmpeq_epi8(v, nl)));
+        if (_mm256_movemask_epi8(b) == 0) {
+            const size_t r = n - i;
+            _mm256_storeu_si256((__m256i *)(dst + m - (32 - r)), v);
+            return m + r;
+        }
+    }
+    return m + strip_scalar(dst + m, src + i, n - i);
 }
 #endif
 

@@ -94,7 +94,7 @@ def main():
         for k in ks:
             r = res[name].get(k)
             line += "  %9.1f (%7.1f)    " % (r["gbases_per_s"], r["kernel_GBps"] or 0) if r else "  %-24s" % "-"
-        print(line)
+        print(line + "  launches/pass " + " ".join("%.2f" % res[name][k]["launches"] for k in ks if k in res[name]))
     for k in ks:
         fps = {name: res[name][k]["fp"] for name, _ in libs if k in res[name]}
         ref = None
