@@ -234,7 +234,19 @@ FH_HD u32 bfe_u32(u32 x, u32 off, u32 width) {
 // The canonical word leaves here shifted left by pre_shift(K) bits (its low pre_shift bits are scrap): that puts every
 // 4-base group of the murmur3 key on a byte boundary of the word, and a byte of a register times the record size is ONE
 // instruction (v_lshlrev_b32_sdwa) where a bit field is a shift and a mask or a funnel shift and a mask.
-constexpr int pre_shift(int K) { return (8 - (2 * K) % 8) % 8; } // 2K + pre_shift <= 64 for every K <= 32
+// For K = 23..32 the shift is the whole room the word leaves, 64 - 2K (the same modulo 8): the window then fills its two
+// registers to the top, each half is ONE funnel shift of the string, and the mask of the upper half (a v_bfe_u32, or a
+// funnel shift and a v_and_b32, or the 64-bit shift the compiler makes of them) is gone: 1.7 VALU instructions per position
+// fewer at k = 21 in the ISA.  Measured (profiles/r04j_ab_pre_wide.txt): k = 25 +1.8 %, k = 23, 24, 28 +0.5...0.7 %.  K = 17..22
+// run their 32 positions as one unrolled pass, which spills 10-23 registers with the wide shift, and in two rounds of 16 the
+// gain is what the rounds cost: they keep the smallest shift, as do shorter k-mers (their strings would move by 32 bits and
+// more) and K = 33..64 (WindowsW).
+#ifndef FH_PRE_WIDE_FROM
+#define FH_PRE_WIDE_FROM 23
+#endif
+constexpr int pre_shift(int K) { // 2K + pre_shift <= 64 for every K <= 32
+    return (K >= FH_PRE_WIDE_FROM && K >= 17 && K <= 32) ? 64 - 2 * K : (8 - (2 * K) % 8) % 8;
+}
 
 template <int K>
 struct Windows {

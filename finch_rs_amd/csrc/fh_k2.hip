@@ -155,6 +155,11 @@ __global__ __launch_bounds__(64 * k2_wpb_of(K), k2_min_waves(K)) void k2_sketch(
     u64 tau = load_tau();
     // readfirstlane keeps the bound an opaque scalar (otherwise the select inside is re-expanded per position)
     u32 tau_hi1 = (u32)__builtin_amdgcn_readfirstlane((int)tau_hi_bound(tau));
+#ifdef FH_EXP_NO_ADMIT // measurement only -- EMPTY sketches: the same code with a bound no hash is under (a zero the compiler cannot
+    // see: tau_lo of a launch without one), so the admit branch is there and never taken (what taking it costs the loop).
+    // (Leaving the branch OUT is no measurement: without it the compiler interleaves the positions' chains and spills 44-56 registers.)
+    tau_hi1 = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(a.tau_lo >> 32));
+#endif
 
     const u32 gw = blockIdx.x * (u32)WPB + (u32)wave;
     u32 *codes_ring = lds.codes + 256 * wave;
@@ -289,12 +294,7 @@ __global__ __launch_bounds__(64 * k2_wpb_of(K), k2_min_waves(K)) void k2_sketch(
             // reject on the high words alone (fh_core.h, HashParts); the hash_mask test hook needs the full hash.
             // windows that carry no k-mer hash garbage; they are rejected on the (rare) admit path only
             const bool cand = MASKED ? ((parts_hash(hp) & a.hash_mask) <= tau) : (parts_hi_plus1(hp) <= tau_hi1);
-#ifdef FH_EXP_NO_ADMIT // measurement only -- EMPTY sketches: candidates are counted, never parked (what the admit branch costs the loop)
-            nvalid += (u32)cand;
-            if (false) {
-#else
             if (__builtin_expect(__any(cand), 0)) { // wave-uniform branch
-#endif
                 // the candidate is parked with its hash unfinished; flush_queue completes and tests it (fh_k2_common.h)
                 const bool take = cand && ((Wc >> j) & 1u);
                 const u64 mask = __ballot(take);
@@ -343,7 +343,9 @@ __global__ __launch_bounds__(64 * k2_wpb_of(K), k2_min_waves(K)) void k2_sketch(
             const u64 tau_now = load_tau();
             if (tau_now != tau) { // wave-uniform
                 tau = tau_now;
+#ifndef FH_EXP_NO_ADMIT
                 tau_hi1 = (u32)__builtin_amdgcn_readfirstlane((int)tau_hi_bound(tau));
+#endif
                 if (lane == 0) queue->tau = tau; // (the queue is empty or its entries passed a looser test: both fine)
             }
         }
