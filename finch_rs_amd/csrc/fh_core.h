@@ -274,6 +274,9 @@ struct Windows {
         D[2] = (u32)rh;
         D[3] = (u32)(rh >> 32);
         D[4] = 0;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FH_EXP_D_OPAQUE)
+        for (int i = 0; i < 4; ++i) asm("" : "+v"(D[i]));
+#endif
     }
     // bits [off, off + NB) of the string W (off, K compile-time after unrolling)
     static FH_HDM u64 field(const u32 *W, int off) {
