@@ -274,7 +274,10 @@ struct Windows {
         D[2] = (u32)rh;
         D[3] = (u32)(rh >> 32);
         D[4] = 0;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(FH_EXP_D_OPAQUE)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FH_D_FOLDABLE)
+        // The words are made opaque: knowing that D[2], D[3] are the halves of ONE 64-bit value, the compiler folds the upper-half
+        // bit field of a forward window into a 64-bit shift of the pair (v_lshrrev_b64 + v_and_b32 where one v_bfe_u32 does:
+        // k = 21 58.8 -> 58.0 VALU instructions per position; k = 17 +1.2 %, k = 21 +0.5 %, k = 22 +0.7 %, profiles/r04k_ab_d_opaque.txt)
         for (int i = 0; i < 4; ++i) asm("" : "+v"(D[i]));
 #endif
     }

@@ -35,7 +35,7 @@ namespace fh {
 // ------------------------------------------------------------------------------------------------
 // Register budget: four waves per SIMD (<= 128 VGPRs) for every K, with NO spilled register (tools/k2_regs.py checks the
 // shipped objects).  Everything wave-uniform is kept scalar (threshold, wave index, queue bookkeeping); K <= 22 run the
-// lane's 32 positions as one unrolled pass (k = 21: 128 VGPRs), K >= 23 -- K >= 25 would take 150-190 registers that way --
+// lane's 32 positions as one unrolled pass (k = 21: 127 VGPRs), K >= 23 -- K >= 25 would take 150-190 registers that way --
 // as two rounds of 16 (102-116 VGPRs; profiles/r03_ab_rounds.txt).  Those kernels do 6-8 table lookups per position and
 // live off the LDS pipe, where a fourth wave is worth more than a longer unrolled pass (measured k = 31: 373 Gbases/s at
 // 2 waves, 427 at 3, 443 at 4, 272 at 5).  What must never be spilled is anything the admit path reads: a reload there
