@@ -20,7 +20,10 @@ SO = os.path.join(HERE, "hostcore", "libfhcore_host.so")
 def core():
     hdr = os.path.join(HERE, "..", "finch_rs_amd", "csrc", "fh_core.h")
     if (not os.path.exists(SO)) or os.path.getmtime(SO) < max(os.path.getmtime(SRC), os.path.getmtime(hdr)):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC])
+        # (several pytest-xdist workers may get here at once: each builds its own file and renames it into place)
+        tmp = "%s.tmp.%d" % (SO, os.getpid())
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-o", tmp, SRC])
+        os.replace(tmp, SO)
     L = C.CDLL(SO)
     L.fhcore_positions.restype = C.c_int
     L.fhcore_positions.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64] + [C.c_void_p] * 4
