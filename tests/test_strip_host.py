@@ -34,6 +34,15 @@ int main() {
         const size_t m0 = ref(r.data(), src, n), m1 = fh_strip::strip(a.data(), src, n);
         if (m0 != m1 || memcmp(r.data(), a.data(), m0)) { printf("INPLACE MISMATCH\n"); return 1; }
     }
+    for (size_t n = 0; n < 200; ++n) // the overlapping last vector: clean records of every length, then one blank at every place of the tail
+        for (size_t blank = 0; blank <= n; ++blank) {
+            std::vector<uint8_t> a(n + 64), b(n + 64), c(n + 96, 0xEE);
+            for (size_t i = 0; i < n; ++i) a[i] = (uint8_t)"ACGT"[(i * 7 + n) & 3];
+            if (blank < n) a[blank] = '\n';
+            const size_t m0 = ref(b.data(), a.data(), n), m1 = fh_strip::strip(c.data(), a.data(), n);
+            if (m0 != m1 || memcmp(b.data(), c.data(), m0)) { printf("TAIL MISMATCH n=%zu blank=%zu\n", n, blank); return 1; }
+            for (size_t i = m0 + 32; i < n + 96; ++i) if (c[i] != 0xEE) { printf("TAIL WROTE BEYOND ITS SLACK n=%zu\n", n); return 1; }
+        }
     puts("strip ok");
     return 0;
 }
