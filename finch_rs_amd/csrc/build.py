@@ -22,7 +22,10 @@ FLAGS += os.environ.get("FH_EXTRA_FLAGS", "").split()
 # The sketch kernel's 32-position unrolled loop sits at the 128-VGPR limit of four waves per SIMD; LLVM's ILP-first
 # scheduling strategy fits it without spills where the default one spills 11-21 registers (k = 21: +1 %, k = 24-31:
 # +2.5 %, A/B on MI355X).
-K2_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+# The position loop is unrolled in full (`#pragma unroll`: every window offset a compile-time constant); LLVM honours the pragma
+# only below -pragma-unroll-threshold (16 K instructions of IR before clean-up), which K = 22 crossed with round 5's admit path
+# -- the loop came out rolled, its strings in scratch.
+K2_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-pragma-unroll-threshold=200000"]
 if "FH_K2_FLAGS" in os.environ:  # A/B builds of the sketch kernel only
     K2_FLAGS = os.environ["FH_K2_FLAGS"].split()
 if "FH_OUT" in os.environ:  # an A/B build: its objects must not replace those libfinch_hip.so was linked from (tools/k2_regs.py --objects)

@@ -241,11 +241,30 @@ FH_HD u32 bfe_u32(u32 x, u32 off, u32 width) {
 // run their 32 positions as one unrolled pass, which spills 10-23 registers with the wide shift, and in two rounds of 16 the
 // gain is what the rounds cost: they keep the smallest shift, as do shorter k-mers (their strings would move by 32 bits and
 // more) and K = 33..64 (WindowsW).
+// Round 5: where the pre-shifted word leaves the top two bits of its register pair clear (2K + PRE <= 62: every K <= 28 with
+// the SMALLEST shift), min(fwd, rc) is ONE v_min_f64 on the bit patterns -- sign 0, exponent never all ones, so the doubles
+// order exactly as the integers do (denormals are kept: the kernels run with the default f64 denormal mode; tools/ubench.hip
+// checks the instruction against the integer minimum bit for bit) -- instead of v_cmp_lt_u64 and two v_cndmask_b32.  The
+// strand flag is not needed to hash: the (rare) admit path works it out again (Windows::strand_of).  That is worth more than
+// the wide shift's missing masks, so K = 23..28 go back to the smallest shift (FH_MINF64=0: round 4's windows).
+#ifndef FH_MINF64
+#define FH_MINF64 1
+#endif
 #ifndef FH_PRE_WIDE_FROM
-#define FH_PRE_WIDE_FROM 23
+#define FH_PRE_WIDE_FROM (FH_MINF64 ? 29 : 23)
 #endif
 constexpr int pre_shift(int K) { // 2K + pre_shift <= 64 for every K <= 32
     return (K >= FH_PRE_WIDE_FROM && K >= 17 && K <= 32) ? 64 - 2 * K : (8 - (2 * K) % 8) % 8;
+}
+// min of two 64-bit words whose top two bits are clear
+FH_HD u64 min_u62(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a < b ? a : b;
+#endif
 }
 
 template <int K>
@@ -320,12 +339,41 @@ struct Windows {
             D[0] <<= 16;
         }
     }
+    // the canonical word is formed without the strand flag (canonical_word) and the flag recovered on the admit path (strand_of)
+    static constexpr bool MINF64 = FH_MINF64 && NB <= 62;
+    // the canonical m-form word << PRE alone
+    FH_HDM u64 canonical_word(int j) const {
+#ifdef FH_EXP_FWD_ONLY // measurement only -- WRONG sketches: the ceiling of any cheaper strand decision (DESIGN.md 5, profiles/r03_*)
+        return fwd(j);
+#endif
+        const u64 f = fwd(j), r = rc(j);
+        if (MINF64) return min_u62(f, r); // (even K: rc's scrap bits are cleared, so equal k-mers give rc's word -- either is the k-mer)
+        return (f < r) ? f : r;
+    }
+    // Was window j's canonical word the reverse complement's (ties -> yes)?  Worked out again from the strings, from copies the
+    // compiler cannot connect with the hot loop's own windows: what it could share it would keep alive from the loop into the
+    // branch, in registers the loop does not have.
+    FH_HDM bool strand_of(int j) const {
+        u32 d[5], c[5];
+        for (int i = 0; i < 5; ++i) d[i] = D[i], c[i] = nC[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(d[i]), "+v"(c[i]));
+#endif
+        const u64 f = field(d, 2 * (64 - K - j) - PRE);
+        u64 r = field(c, 2 * j);
+        if (K % 2 == 0) r &= ~((1ULL << PRE) - 1ULL);
+        return !(f < r);
+    }
     // the canonical m-form word << PRE
     FH_HDM u64 canonical(int j, bool &is_rc) const {
-#ifdef FH_EXP_FWD_ONLY // measurement only -- WRONG sketches: the ceiling of any cheaper strand decision (DESIGN.md 5, profiles/r03_*)
+#ifdef FH_EXP_FWD_ONLY
         is_rc = false;
         return fwd(j);
 #endif
+        if (MINF64) {
+            is_rc = strand_of(j);
+            return canonical_word(j);
+        }
         const u64 f = fwd(j), r = rc(j);
         is_rc = !(f < r);
         return is_rc ? r : f;

@@ -273,7 +273,12 @@ __global__ __launch_bounds__(64 * k2_wpb_of(K), k2_min_waves(K)) void k2_sketch(
         u32 Wc = W; // valid bits of the current round in its low R bits
 #pragma unroll 1
         for (int c = 0; c < LANE_POS / R; ++c) {
-        auto window = [&](int j, u64 &cm, bool &is_rc) { cm = win.canonical(j, is_rc); };
+        // (where the canonical word is a v_min_f64 -- fh_core.h, Windows::MINF64 -- the strand flag is not formed here at all: the
+        // admit path works it out for the one candidate)
+        auto window = [&](int j, u64 &cm, bool &is_rc) {
+            if constexpr (Windows<K>::MINF64) cm = win.canonical_word(j), is_rc = false;
+            else cm = win.canonical(j, is_rc);
+        };
         u64 cm_cur;
         bool rc_cur;
         KeyWords<K> kw_cur;
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(64 * k2_wpb_of(K), k2_min_waves(K)) void k2_sketch(
                 murmur_lookup<K, REP>(cm_nxt, LT, kw_nxt);
             }
             const u64 cm = cm_cur;
-            const bool is_rc = rc_cur;
+            const bool rc_loop = rc_cur;
             const HashParts hp = murmur_finish_parts<K, SEED0>(kw_cur, a.seed);
             // reject on the high words alone (fh_core.h, HashParts); the hash_mask test hook needs the full hash.
             // windows that carry no k-mer hash garbage; they are rejected on the (rare) admit path only
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(64 * k2_wpb_of(K), k2_min_waves(K)) void k2_sketch(
             if (__builtin_expect(__any(cand), 0)) { // wave-uniform branch
                 // the candidate is parked with its hash unfinished; flush_queue completes and tests it (fh_k2_common.h)
                 const bool take = cand && ((Wc >> j) & 1u);
-                const u64 mask = __ballot(take);
+                const u64 mask = __builtin_amdgcn_ballot_w64(take); // (__ballot goes through a v_cndmask and a second compare)
                 const u32 cnt = (u32)__popcll(mask);
                 if (cnt) {
                     if (qn + cnt > (u32)QCAP) {
@@ -314,6 +319,8 @@ __global__ __launch_bounds__(64 * k2_wpb_of(K), k2_min_waves(K)) void k2_sketch(
                         u32 lane_here; // (volatile: or the compiler hoists it out of the loop and spills it after all)
                         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_here));
                         const u64 pos = tile_stream_pos + (u64)(lane_here * (u32)LANE_POS + (u32)(c * R + j));
+                        bool is_rc = rc_loop;
+                        if constexpr (Windows<K>::MINF64) is_rc = win.strand_of(j);
                         queue->p[my] = pos | ((u64)(is_rc ? 1u : 0u) << 63);
                     }
                     qn += cnt;

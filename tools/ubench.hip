@@ -77,6 +77,40 @@ constexpr int REP = 8; // instructions per chain per iteration
 #define A_XOR_ADD(n) "v_xor_b32 %" #n ", %" #n ", %8\nv_add_u32 %" #n ", %" #n ", %9\n"
 #define A_SDWA(n) "v_add_u32_sdwa %" #n ", %" #n ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n"
 #define A_DPP(n) "v_mov_b32_dpp %" #n ", %" #n " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define A_MINF32(n) "v_min_f32 %" #n ", %" #n ", %8\n"
+#define A_MINF32ABS(n) "v_min_f32_e64 %" #n ", |%" #n "|, %8\n"
+#define A_CMPNGTF32(n) "v_cmp_ngt_f32 vcc, %" #n ", %8\n"
+#define A_CMPNGTF32ABS(n) "v_cmp_ngt_f32_e64 vcc, |%" #n "|, %8\n"
+#define A_CMPGEU32(n) "v_cmp_ge_u32 vcc, %" #n ", %8\n"
+#define A_LSHLADD32(n) "v_lshl_add_u32 %" #n ", %" #n ", 2, %8\n"
+#define A_DOT4(n) "v_dot4_u32_u8 %" #n ", %" #n ", %8, %9\n"
+#define A_PKMULLO16(n) "v_pk_mul_lo_u16 %" #n ", %" #n ", %8\n"
+#define A_PKADD16(n) "v_pk_add_u16 %" #n ", %" #n ", %8\n"
+#define A_MAXU32(n) "v_max_u32 %" #n ", %" #n ", %8\n"
+#define A_LSHRV(n) "v_lshrrev_b32 %" #n ", %8, %" #n "\n"
+#define A_ASHR(n) "v_ashrrev_i32 %" #n ", 5, %" #n "\n"
+#define A_MIN3U32(n) "v_min3_u32 %" #n ", %" #n ", %8, %9\n"
+#define A_SUBREV(n) "v_subrev_u32 %" #n ", %8, %" #n "\n"
+#define A_CVTF32U32(n) "v_cvt_f32_u32 %" #n ", %" #n "\n"
+#define A_BFI(n) "v_bfi_b32 %" #n ", %" #n ", %8, %9\n"
+#define A_ADDU32_X2(n) "v_add_u32 %" #n ", %" #n ", %" #n "\n"
+DEF_KERNEL32(k_minf32, A_MINF32)
+DEF_KERNEL32(k_minf32abs, A_MINF32ABS)
+DEF_KERNEL32(k_cmpngtf32, A_CMPNGTF32)
+DEF_KERNEL32(k_cmpngtf32abs, A_CMPNGTF32ABS)
+DEF_KERNEL32(k_cmpgeu32, A_CMPGEU32)
+DEF_KERNEL32(k_lshladd32, A_LSHLADD32)
+DEF_KERNEL32(k_dot4, A_DOT4)
+DEF_KERNEL32(k_pkmullo16, A_PKMULLO16)
+DEF_KERNEL32(k_pkadd16, A_PKADD16)
+DEF_KERNEL32(k_maxu32, A_MAXU32)
+DEF_KERNEL32(k_lshrv, A_LSHRV)
+DEF_KERNEL32(k_ashr, A_ASHR)
+DEF_KERNEL32(k_min3u32, A_MIN3U32)
+DEF_KERNEL32(k_subrev, A_SUBREV)
+DEF_KERNEL32(k_cvtf32u32, A_CVTF32U32)
+DEF_KERNEL32(k_bfi, A_BFI)
+DEF_KERNEL32(k_addx2, A_ADDU32_X2)
 DEF_KERNEL32(k_and, A_AND)
 DEF_KERNEL32(k_or, A_OR)
 DEF_KERNEL32(k_sub, A_SUB)
@@ -147,6 +181,14 @@ DEF_KERNEL32(k_addc, A_ADDC)
 #define A_MULF64(n) "v_mul_f64 %" #n ", %" #n ", %9\n"
 #define A_PKADD(n) "v_pk_add_u16 %" #n ", %" #n ", %9\n"
 
+#define A_MINF64(n) "v_min_f64 %" #n ", %" #n ", %9\n"
+#define A_MAXF64(n) "v_max_f64 %" #n ", %" #n ", %9\n"
+#define A_FMAF64(n) "v_fma_f64 %" #n ", %" #n ", %9, %9\n"
+#define A_ADDF64(n) "v_add_f64 %" #n ", %" #n ", %9\n"
+DEF_KERNEL64(k_minf64, A_MINF64)
+DEF_KERNEL64(k_maxf64, A_MAXF64)
+DEF_KERNEL64(k_fmaf64, A_FMAF64)
+DEF_KERNEL64(k_addf64, A_ADDF64)
 DEF_KERNEL64(k_mad64, A_MAD64)
 DEF_KERNEL64(k_lshl64, A_LSHL64)
 DEF_KERNEL64(k_lshr64, A_LSHR64)
@@ -199,6 +241,34 @@ __global__ void k_clock(unsigned long long *out, unsigned long long ticks) {
     unsigned long long t = t0;
     while (t - t0 < ticks) t = __builtin_readcyclecounter();
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t - t0;
+}
+
+// Do v_min_f64 / v_cmp_ngt_f32 order integer bit patterns the way the sketch kernel wants to use them?
+//   min64: for a, b < 2^62 (sign 0, exponent never all ones; denormals included) v_min_f64 must return min(a, b) bit for bit
+//   cmp32: "not (|X| > B)" on the bit patterns must be true whenever (X & 0x7fffffff) <= B  (NaN patterns of X count as true)
+__global__ void k_semantics(unsigned long long *bad, unsigned seed) {
+    unsigned long long x = (blockIdx.x * 256ull + threadIdx.x) * 0x9E3779B97F4A7C15ull + seed;
+    unsigned long long nb64 = 0, nb32 = 0, nfalsepos = 0;
+    for (int i = 0; i < 4096; ++i) {
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        unsigned long long a = x >> 2, b = (x * 0x94D049BB133111EBull) >> 2;
+        const int sh = (i & 63);
+        if (i & 64) { a >>= sh; b >>= (sh ^ 5) & 63; }          // small values: denormals and zero
+        if ((i & 255) == 7) b = a;                               // ties
+        if ((i & 255) == 9) b = a ^ 1ull;                        // differ in the last bit
+        unsigned long long m;
+        asm volatile("v_min_f64 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+        if (m != (a < b ? a : b)) ++nb64;
+        unsigned X = (unsigned)(x >> 17), B = (unsigned)((x >> 40) & 0xFFFFF) >> (i & 15);
+        if ((i & 3) == 1) X >>= (i >> 2) & 31;
+        unsigned long long vc;
+        asm volatile("v_cmp_ngt_f32_e64 %0, |%1|, %2" : "=s"(vc) : "v"(X), "v"(B));
+        const bool f = (vc >> (threadIdx.x & 63)) & 1ull;
+        const bool want = (X & 0x7FFFFFFFu) <= B;
+        if (want && !f) ++nb32;
+        if (f && !want && ((X & 0x7F800000u) != 0x7F800000u)) ++nfalsepos;
+    }
+    atomicAdd(&bad[0], nb64); atomicAdd(&bad[1], nb32); atomicAdd(&bad[2], nfalsepos);
 }
 
 typedef void (*kern_t)(unsigned *, unsigned);
@@ -254,6 +324,37 @@ int main(int argc, char **argv) {
         }
     }
     const double n32 = (double)ITER * REP * 8;
+    {
+        unsigned long long *d_bad, h_bad[3] = {0, 0, 0};
+        CHECK(hipMalloc(&d_bad, 24));
+        CHECK(hipMemset(d_bad, 0, 24));
+        hipLaunchKernelGGL(k_semantics, dim3(1024), dim3(256), 0, 0, d_bad, 12345u);
+        CHECK(hipMemcpy(h_bad, d_bad, 24, hipMemcpyDeviceToHost));
+        printf("semantics over %llu cases: v_min_f64 != integer min: %llu   v_cmp_ngt_f32(|X|, B) missed (X & 0x7fffffff) <= B: %llu   (extra non-NaN trues: %llu)\n",
+               1024ull * 256 * 4096, h_bad[0], h_bad[1], h_bad[2]);
+    }
+    run("v_min_f64", k_minf64, n32, d_out, blocks, clk);
+    run("v_max_f64", k_maxf64, n32, d_out, blocks, clk);
+    run("v_fma_f64", k_fmaf64, n32, d_out, blocks, clk);
+    run("v_add_f64", k_addf64, n32, d_out, blocks, clk);
+    run("v_min_f32", k_minf32, n32, d_out, blocks, clk);
+    run("v_min_f32 |x|", k_minf32abs, n32, d_out, blocks, clk);
+    run("v_cmp_ngt_f32", k_cmpngtf32, n32, d_out, blocks, clk);
+    run("v_cmp_ngt_f32 |x|", k_cmpngtf32abs, n32, d_out, blocks, clk);
+    run("v_cmp_ge_u32", k_cmpgeu32, n32, d_out, blocks, clk);
+    run("v_lshl_add_u32", k_lshladd32, n32, d_out, blocks, clk);
+    run("v_dot4_u32_u8", k_dot4, n32, d_out, blocks, clk);
+    run("v_pk_mul_lo_u16", k_pkmullo16, n32, d_out, blocks, clk);
+    run("v_pk_add_u16", k_pkadd16, n32, d_out, blocks, clk);
+    run("v_max_u32", k_maxu32, n32, d_out, blocks, clk);
+    run("v_lshrrev_b32 v", k_lshrv, n32, d_out, blocks, clk);
+    run("v_ashrrev_i32", k_ashr, n32, d_out, blocks, clk);
+    run("v_min3_u32", k_min3u32, n32, d_out, blocks, clk);
+    run("v_subrev_u32", k_subrev, n32, d_out, blocks, clk);
+    run("v_cvt_f32_u32", k_cvtf32u32, n32, d_out, blocks, clk);
+    run("v_bfi_b32", k_bfi, n32, d_out, blocks, clk);
+    run("v_add_u32 x,x", k_addx2, n32, d_out, blocks, clk);
+    if (argc > 2) return 0; // (a second argument: only the round-5 additions above)
     run("v_and_b32", k_and, n32, d_out, blocks, clk);
     run("v_or_b32", k_or, n32, d_out, blocks, clk);
     run("v_sub_u32", k_sub, n32, d_out, blocks, clk);
