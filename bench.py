@@ -95,6 +95,50 @@ def _write_fasta_job(job):
     return path, S.synth_fasta_length(i, SEED)
 
 
+def _oracle_file_job(path):
+    """one file through the oracle's sketch_stream (lib.rs:51-94), as one rayon task of sketch_files would (lib.rs:34-36)"""
+    from oracle import oracle as O
+    with open(path, "rb") as f:
+        data = f.read()
+    o = O.OracleSketcher(O.MASH, 1000, 21, 0)
+    o.sketch_stream(data)
+    return o.total_bases_and_kmers()[0]
+
+
+def c5_cpu_baseline(paths, lens, max_files=256):
+    """BASELINE configs[4]'s CPU side: the oracle's sketch_stream over the first files of the SAME batch, one
+    file per task on every core this process is granted -- for a batch of files that IS the reference's behaviour
+    (sketch_files is a rayon par_iter over the file names, lib.rs:34-36)"""
+    import multiprocessing as mp
+    from oracle import oracle as O
+    flags = O.use_native()
+    cores = max(1, min(_usable_cpus(), 256))
+    sample = list(range(min(len(paths), max(max_files, 2 * cores) if len(paths) >= 2 * cores else len(paths))))
+    with mp.get_context("fork").Pool(cores) as pool:
+        pool.map(_oracle_file_job, [paths[0]] * cores, chunksize=1)  # start the workers, page the files' directory in
+        c0 = time.perf_counter()
+        got = pool.map(_oracle_file_job, [paths[i] for i in sample], chunksize=1)
+        ct = time.perf_counter() - c0
+    bases = sum(lens[i] for i in sample)
+    return {"value": round(bases / ct, 1), "unit": "bases/s", "cores": cores, "kind": "port", "files_per_s": round(len(sample) / ct, 1),
+            "sample": "the first %d files of the same batch (%.0f Mbases) through the oracle's sketch_stream, one file per task on %d "
+                      "worker processes = the reference's behaviour for a batch (rayon par_iter over files, lib.rs:34-36); gcc %s"
+                      % (len(sample), bases / 1e6, cores, flags)}
+
+
+def c5_roofline(kernel_ms, launches, positions, wall_ms, n_gpus):
+    """the batch's roofline block: the sketch kernel over ALL files (sum of its launches' HIP-event times on the workers'
+    streams, finch_debug_kernel_times) against the HBM peak, and how much of the call the GPU spent in it"""
+    ach = positions / 1e9 / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+            "traffic": None, "kernel": "k2_sketch<21> (one launch per file, 1-10 M positions each)", "launches": int(launches),
+            "avg_launch_ms": round(kernel_ms / max(launches, 1), 4), "alg_bytes_per_launch": int(positions / max(launches, 1)),
+            "kernel_ms_total": round(kernel_ms, 3), "call_ms_total": round(wall_ms, 3),
+            "kernel_share_of_call": round(kernel_ms / max(wall_ms * n_gpus, 1e-9), 4),
+            "binding_resource": "the call, not the kernel: host-side reading / packing of the files and one PCIe link per GPU "
+                                "(DESIGN.md 5); the kernel itself is VALU-issue bound as in the resident workloads"}
+
+
 def _pmc_derived(key):
     """what the committed rocprofv3 PMC passes say about the kernel's binding resource (profiles/pmc_summary.json, written
     by tools/pmc_summary.py from the counter files named there); None if no set was collected for this workload"""
@@ -245,6 +289,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: libfinch_hip has no CPU path")
     if not args.share_gpu and not launched and F.device_count() < world:
         raise SystemExit("--gpus %d but only %d device(s) visible" % (world, F.device_count()))
+    if launched and not args.share_gpu and local_rank >= F.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d device(s) visible: two ranks would share a GPU (--share-gpu to allow it)"
+                         % (rank, local_rank, F.device_count()))
     if args.share_gpu:
         local_rank = 0
     # devices this PROCESS drives
@@ -285,7 +332,7 @@ def main():
     else:
         total_reads = int(np.ceil(gbases * 1e9 / READ_LEN))  # in total: contiguous read blocks, one per GPU
         bounds = {r: SH.shard_bounds(total_reads, r, world) for r in my_ranks}
-    shards = [Shard(F, S, d, bounds[r][0], bounds[r][1] - bounds[r][0], params, args.max_launch, profiling=(r == 0))
+    shards = [Shard(F, S, d, bounds[r][0], bounds[r][1] - bounds[r][0], params, args.max_launch, profiling=True)
               for r, d in zip(my_ranks, my_devices)]
 
     # The merge of a step's partial sketches (<= n records per GPU, O(N n) on the host).  Launched by torch.distributed.run:
@@ -293,6 +340,7 @@ def main():
     # the merge of step i runs behind the sketching of step i + 1.  One process: one fh_sketch_device_blocks call per step --
     # the library's own team of threads (one per device) and its own merge.
     kernel_acc = [0.0, 0, 0]  # ms, launches, positions of device 0's sketch launches
+    rank_ms = {r: 0.0 for r in my_ranks}  # every rank's own sketch-kernel time (a slow device shows in the first real curve)
 
     def run_steps(n_steps, timed):
         if threads_mode:
@@ -306,17 +354,22 @@ def main():
             for _ in range(n_steps):
                 SH.sketch_device_blocks(sks, ptrs, lens, offs)
                 if timed:
-                    ms, nl, npos = shards[0].sk.kernel_time()
-                    kernel_acc[0] += ms; kernel_acc[1] += nl; kernel_acc[2] += npos
+                    for r, sh in zip(my_ranks, shards):
+                        ms, nl, npos = sh.sk.kernel_time()
+                        rank_ms[r] += ms
+                        if r == 0:
+                            kernel_acc[0] += ms; kernel_acc[1] += nl; kernel_acc[2] += npos
                 kc, km, pos = shards[0].sk.to_arrays()
                 last = (kc, km, pos, shards[0].sk.finish()[1])
             return last
         last = None
         for _ in range(n_steps):
             part = shards[0].step()
-            if timed and rank == 0:
+            if timed:
                 ms, nl, npos = shards[0].sk.kernel_time()
-                kernel_acc[0] += ms; kernel_acc[1] += nl; kernel_acc[2] += npos
+                rank_ms[rank] += ms
+                if rank == 0:
+                    kernel_acc[0] += ms; kernel_acc[1] += nl; kernel_acc[2] += npos
             if merge is not None:
                 merge.put(part)
             else:
@@ -341,6 +394,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        parts = [None] * world
+        dist.all_gather_object(parts, rank_ms)
+        for d in parts:
+            rank_ms.update(d)
 
     if rank != 0:
         if dist is not None:
@@ -443,6 +500,9 @@ def main():
         "config": {"workload": wl, "reads_per_gpu": n_reads, "reads_total": total_reads,
                    "parallelism": "read-block sharding x%d, host merge; %s" % (world, drive)},
         "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all,
+        "per_rank": [{"rank": r, "reads": (total_reads // world if workload == "c2" else
+                                           SH.shard_bounds(total_reads, r, world)[1] - SH.shard_bounds(total_reads, r, world)[0]),
+                      "kernel_ms_per_pass": round(rank_ms[r] / max(args.steps, 1), 4)} for r in sorted(rank_ms)],
         "sketch_check": check,
     }
     if extras is not None:
@@ -491,11 +551,13 @@ def run_c5(args, F, S, dist, barrier, rank, world, my_devices, launched, gather_
         for _ in range(args.warmup):
             step()
         barrier()
+        H.debug_kernel_times(1)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         barrier()
         elapsed = time.perf_counter() - t0
+        k_ms, k_launches, k_pos = H.debug_kernel_times(0)
         # fingerprint of the sample: files 0..255 (each rank contributes the ones it sketched)
         fx, tk, cs = 0, 0, 0
         for j, i in enumerate(mine):
@@ -509,10 +571,10 @@ def run_c5(args, F, S, dist, barrier, rank, world, my_devices, launched, gather_
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
             parts = [None] * world
-            dist.all_gather_object(parts, (fx, tk, cs))
-            fx, tk, cs = 0, 0, 0
-            for a, b, c in parts:
-                fx ^= a; tk += b; cs += c
+            dist.all_gather_object(parts, (fx, tk, cs, k_ms, k_launches, k_pos))
+            fx, tk, cs, k_ms, k_launches, k_pos = 0, 0, 0, 0.0, 0, 0
+            for a, b, c, d1, d2, d3 in parts:
+                fx ^= a; tk += b; cs += c; k_ms += d1; k_launches += d2; k_pos += d3
         if rank != 0:
             return 0
         tot = sum(lens)
@@ -529,7 +591,8 @@ def run_c5(args, F, S, dist, barrier, rank, world, my_devices, launched, gather_
                                          "" if nf == args.files else "; %d asked for, cut to what %s holds" % (args.files, base)),
                           "files": nf, "files_per_s": round(nf * args.steps / elapsed, 1),
                           "parallelism": "file -> GPU mapping x%d (%s)" % (world, "one call per rank" if launched and world > 1 else "one call, devices=[0..%d]" % (world - 1))},
-               "roofline": None, "cpu_baseline": None, "sketch_check": fp}
+               "roofline": c5_roofline(k_ms, k_launches, k_pos, elapsed * 1e3, world),
+               "cpu_baseline": None if args.no_cpu_baseline else c5_cpu_baseline(paths, lens), "sketch_check": fp}
         print(json.dumps(out), flush=True)
         return 0 if fp["matches_golden"] is not False else 3
     finally:
@@ -788,18 +851,25 @@ def measure_extras(F, S, dr, dg, n_reads, dev):
             paths = [m[0] for m in made]
             tot = sum(m[1] for m in made)
             best = 1e30
-            # (the sketchers the earlier lines parked fill the handle cache -- FH_POOL_BYTES, 8 GiB: with them there, part of this
+            # (the sketchers the earlier lines parked fill the handle cache -- FH_POOL_BYTES, 24 GiB: with them there, part of this
             # batch's sixteen worker handles would be allocated and pinned anew in every call, which is not what a process that
             # sketches batches does)
             H._lib.load().fh_release_cached()
+            kt = (0.0, 0, 0)
             for _ in range(3):
+                H.debug_kernel_times(1)
                 t0 = time.perf_counter()
                 res = H.sketch_files(paths, F.SketchParams.default(), H.FilterParams(None), devices=[dev])
-                best = min(best, time.perf_counter() - t0)
+                dt = time.perf_counter() - t0
+                if dt < best:
+                    best, kt = dt, H.debug_kernel_times(0)
                 assert len(res) == nf
+            H.debug_kernel_times(0)
             return {"what": "ONE finch_sketch_files call over %d synthetic FASTA files (log-uniform 1-10 Mb, 70-column lines, "
                             "%.2f Gbases, page cache / tmpfs), library defaults (k=21 n=1000, up to 16 worker threads per GPU)" % (nf, tot / 1e9),
-                    "seconds": round(best, 4), "files_per_s": round(nf / best, 1), "gbases_per_s": round(tot / best / 1e9, 2)}
+                    "seconds": round(best, 4), "files_per_s": round(nf / best, 1), "gbases_per_s": round(tot / best / 1e9, 2),
+                    "roofline": c5_roofline(kt[0], kt[1], kt[2], best * 1e3, 1),
+                    "cpu_baseline": c5_cpu_baseline(paths, [m[1] for m in made])}
         finally:
             shutil.rmtree(d, ignore_errors=True)
     guarded("c5_batch_1gpu", c5)

@@ -54,6 +54,8 @@ SYMBOLS = {
     "fh_set_text_halo": (C.c_int, [_P, _P, C.c_uint32]),
     "fh_text_bases": (C.c_int, [_P, _U64P]),
     "fh_push_device": (C.c_int, [_P, _P, C.c_uint64]),
+    "fh_set_record_stride": (C.c_int, [_P, C.c_uint32]),
+    "fh_debug_segments": (C.c_int, [_P, _U64P, _U64P, C.POINTER(C.c_uint32)]),
     "fh_sync": (C.c_int, [_P]),
     "fh_finish": (C.c_int, [_P, _U64P, _U64P]),
     "fh_copy_out": (C.c_int, [_P, _P, _P, _P, _P, _P]),

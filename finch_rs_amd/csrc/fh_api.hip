@@ -5,6 +5,7 @@
 // per-base operation of the reference's process()/push() (mash.rs:34-80) runs in fh_kernels.hip.
 // There is deliberately no CPU implementation of the sketching path in this library.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <chrono>
@@ -152,6 +153,8 @@ struct fh_sketcher {
         uint32_t tiles_total = 0, n_units = 0, n_left_in = 0;
         uint32_t unit_tiles = UNIT_TILES; // queue granularity of this range (1 for inputs that would not fill the chip with 2)
         uint32_t first_units = 0, grid_waves = 0; // the range's first launch: units every wave starts on unasked, and its waves
+        uint32_t seg = 0; // != 0: the range runs through the segment kernel with this stride (tiles of 64 x seg positions)
+        uint32_t max_units = MAX_UNITS; // units a pull takes at most
         int left_cur = 0;
         double admit_at_start = 1.0; // admit rate the range started with (for the novelty estimate)
         bool gated = false;   // queued behind an unverified speculation: its launches run only if Ctl::spec_ok
@@ -181,7 +184,14 @@ struct fh_sketcher {
     bool proc_continuing = false, proc_in_record = false;
     bool device_clean = false;
     uint64_t final_text_bases = 0; // Ctl::text_bases as of fh_finish (fh_text_bases stays valid after it)
-    uint32_t *left_buf[2] = {nullptr, nullptr}; // leftover tile ranges of a stopped launch (pairs)
+    uint32_t *left_buf[2] = {nullptr, nullptr}; // leftover tile ranges of a stopped launch (pairs; two per wave: fh_k2s.hip)
+    // The segment kernel (fh_k2s.hip): seg_hint is what the caller said about the records (fh_set_record_stride: 0 = find out,
+    // 1 = do not use it, else the stride), blk_seg the stride of the block being sketched (0: k2_sketch), gran what the block's
+    // ranges are cut at (a tile of the kernel that runs it)
+    uint32_t seg_hint = 0, blk_seg = 0;
+    uint64_t gran = TILE_POS;
+    uint32_t *h_probe = nullptr; // pinned: launch_seg_probe's answer
+    uint64_t n_seg_launches = 0, n_seg_probes = 0;
     uint64_t max_waves = 0;
     uint64_t max_range = 0; // test knob: cap on positions per range
     uint64_t tau_lo = 0;    // != 0 while a block is re-read for the hashes above a speculative threshold
@@ -435,19 +445,20 @@ uint32_t soft_limit_of(const fh_sketcher *s) {
 // whole remaining input: waves stop by themselves if the table ever nears its guarded size.
 uint64_t next_range_size(const fh_sketcher *s, uint64_t remaining) {
     uint64_t P;
+    const uint64_t G = s->gran; // ranges are cut at whole tiles of the kernel that runs the block (TILE_POS, or 64 segments)
     if (s->open_loop) {
-        P = ((remaining + TILE_POS - 1) / TILE_POS) * TILE_POS; // everything, incl. the last partial tile
+        P = ((remaining + G - 1) / G) * G; // everything, incl. the last partial tile
     } else {
         const double room = (double)s->live_target - (double)std::min<uint64_t>(s->last_live, s->live_target);
         // small mode keeps half the room in reserve (the live set has to fit the in-LDS prune); in big mode the
         // soft-limit stop makes overshoot harmless, and halving the room every range cost 5-11 launches per prune
         const double fr = fill_rate(s);
         double p = fr > 0.0 ? (s->big_mode ? 1.0 : 0.5) * room / fr : 1e19;
-        P = p >= 1e18 ? remaining + TILE_POS : (uint64_t)p; // (rounded down below; capped at the rounded-up remainder)
+        P = p >= 1e18 ? remaining + G : (uint64_t)p; // (rounded down below; capped at the rounded-up remainder)
     }
     if (s->max_range) P = std::min<uint64_t>(P, s->max_range);
-    P = std::max<uint64_t>((P / TILE_POS) * TILE_POS, TILE_POS);
-    return std::min<uint64_t>(P, ((remaining + TILE_POS - 1) / TILE_POS) * TILE_POS);
+    P = std::max<uint64_t>((P / G) * G, G);
+    return std::min<uint64_t>(P, ((remaining + G - 1) / G) * G);
 }
 
 int check_ctl(fh_sketcher *s);
@@ -513,11 +524,14 @@ int launch_pending(fh_sketcher *s) {
     a.unit_tiles = r.unit_tiles;
     a.first_units = r.first_units; // (start_range's launch only: a relaunch takes what is left through the queue)
     a.static_only = r.first_units && (uint64_t)r.first_units * r.grid_waves >= r.n_units ? 1u : 0u;
+    a.seg_stride = r.seg;
+    a.max_units = r.max_units;
     r.first_units = 0;
     a.left_in = s->left_buf[r.left_cur];
     a.left_out = s->left_buf[r.left_cur ^ 1];
     const uint64_t work_units = (uint64_t)r.n_units + r.n_left_in;
-    const uint64_t wpb = (uint64_t)k2_waves_per_block((int)s->p.k);
+    const uint64_t wpb = r.seg ? (uint64_t)K2S_WAVES_PER_BLOCK : (uint64_t)k2_waves_per_block((int)s->p.k);
+    if (r.seg) s->n_seg_launches++;
     // (whole workgroups run: that many waves pull, insert and may leave a leftover entry; max_waves is a multiple of wpb)
     const uint64_t waves = (std::max<uint64_t>(1, std::min<uint64_t>(work_units, s->max_waves)) + wpb - 1) / wpb * wpb;
     a.n_waves = (uint32_t)waves;
@@ -645,7 +659,10 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
     r.base_pos = base_pos;
     r.p_begin = pos;
     r.p_end = end;
-    const uint64_t tiles = (end - pos + TILE_POS - 1) / TILE_POS;
+    // the segment kernel where the block has a stride and the launch is the plain one (seed 0, no test mask, no lower threshold)
+    r.seg = (s->blk_seg && s->p.k <= 32 && s->p.seed == 0 && !s->p.hash_mask && !s->tau_lo && pos % (64ull * s->blk_seg) == 0) ? s->blk_seg : 0u;
+    const uint64_t tile = r.seg ? 64ull * r.seg : (uint64_t)TILE_POS;
+    const uint64_t tiles = (end - pos + tile - 1) / tile;
     if (tiles >= (1ull << 31)) return fail(FH_ERR_INVALID, "block too large for one range");
     r.tiles_total = (uint32_t)tiles;
     // an input of a few megabases does not fill the chip with units of two tiles (configs[4]: 4 Mb = 977 of them for 1024
@@ -655,6 +672,17 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
         return e ? (uint32_t)atoi(e) : 0u;
     }();
     r.unit_tiles = unit_knob ? unit_knob : (tiles < (uint64_t)UNIT_TILES * 2 * s->max_waves ? 1u : (uint32_t)UNIT_TILES);
+    r.max_units = MAX_UNITS;
+    if (r.seg) {
+        // a segment tile is 64 x stride positions, about five of k2_sketch's: single tiles are the units, and a pull takes about
+        // what eight of k2_sketch's units are (the chip's reads stay inside one moving window of a few hundred megabytes)
+        static const uint32_t seg_pull = [] {
+            const char *e = getenv("FH_SEG_PULL_POS"); // A/B knob: positions a pull takes at most
+            return e ? (uint32_t)atoi(e) : (uint32_t)MAX_UNITS * UNIT_TILES * TILE_POS;
+        }();
+        if (!unit_knob) r.unit_tiles = 1u;
+        r.max_units = std::max<uint32_t>(1u, seg_pull / (uint32_t)(tile * r.unit_tiles));
+    }
     r.n_units = (uint32_t)((tiles + r.unit_tiles - 1) / r.unit_tiles);
     r.n_left_in = 0;
     r.left_cur = 0;
@@ -670,9 +698,9 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
     static const bool no_static = getenv("FH_NO_STATIC_UNITS") != nullptr; // A/B knob
     {
         const uint64_t waves = std::max<uint64_t>(1, std::min<uint64_t>(r.n_units, s->max_waves));
-        const uint64_t wpb = (uint64_t)k2_waves_per_block((int)s->p.k);
+        const uint64_t wpb = r.seg ? (uint64_t)K2S_WAVES_PER_BLOCK : (uint64_t)k2_waves_per_block((int)s->p.k);
         const uint64_t grid = (waves + wpb - 1) / wpb * wpb;
-        const uint64_t fu = std::min<uint64_t>((r.n_units + waves - 1) / waves, MAX_UNITS);
+        const uint64_t fu = std::min<uint64_t>((r.n_units + waves - 1) / waves, r.max_units);
         r.first_units = no_static ? 0u : (uint32_t)fu;
         r.grid_waves = (uint32_t)grid;
     }
@@ -934,6 +962,37 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
     if (int rc = drain(s)) return rc;
     if (len < s->p.k) return FH_OK;
     const uint64_t n_pos = len - s->p.k + 1; // windows that fit
+    // Records of one length?  Then the segment kernel skips what every record's last k positions cannot hold (fh_k2s.hip).  The
+    // caller may have said so (fh_set_record_stride); a large block is asked itself -- one wavefront, one round trip (~20 us:
+    // worth it from a few milliseconds of sketching on).  The stride only decides how fast, never what comes out.
+    s->blk_seg = 0;
+    s->gran = TILE_POS;
+    {
+        static const bool seg_off = getenv("FH_NO_SEG") != nullptr; // A/B knob
+        static const uint64_t probe_min = [] {
+            const char *e = getenv("FH_SEG_PROBE_MIN"); // test knob
+            return e ? strtoull(e, nullptr, 10) : (64ull << 20);
+        }();
+        static const uint32_t seg_env = [] {
+            const char *e = getenv("FH_SEG_STRIDE"); // test knob: every block through the segment kernel with this stride
+            return e ? (uint32_t)atoi(e) : 0u;
+        }();
+        uint32_t S = seg_env ? seg_env : s->seg_hint;
+        if (!seg_off && S != 1u && s->p.k <= 32 && s->p.seed == 0 && !s->p.hash_mask) {
+            if (S == 0 && len >= probe_min) {
+                if (!s->h_probe) HIP_TRY(host_malloc(&s->h_probe, 64));
+                if (int rc = flush_epilogue(s)) return rc;
+                HIP_TRY(launch_seg_probe(d_seq, len, s->h_probe, s->stream));
+                HIP_TRY(hipStreamSynchronize(s->stream));
+                S = s->h_probe[0];
+                s->n_seg_probes++;
+            }
+            if (S >= SEG_MIN_STRIDE && S <= SEG_MAX_STRIDE && S > s->p.k && n_pos >= 64ull * S) {
+                s->blk_seg = S;
+                s->gran = 64ull * S;
+            }
+        }
+    }
     uint64_t pos = 0;
     uint64_t lo_end = 0; // a failed speculation re-reads [0, lo_end) for the hashes above its guess only
     bool sampled = false;
@@ -946,7 +1005,7 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
     if (!sampled && s->positions_done == 0 && s->tau_lo == 0) {
         // a large first block speculates on its first 32 M positions only: a wrong guess then costs a second pass
         // over that prefix (0.1 ms), a right one replaces the ten closed-loop warm-up ranges and their round trips
-        const uint64_t spec_pos = n_pos <= SPEC_MAX_POS ? n_pos : SPEC_PREFIX_POS;
+        const uint64_t spec_pos = n_pos <= SPEC_MAX_POS ? n_pos : SPEC_PREFIX_POS / s->gran * s->gran;
         bool done = false;
         if (int rc = speculative_first_block(s, d_seq, len, base_pos, spec_pos, &done)) return rc;
         if (done) {
@@ -1342,7 +1401,7 @@ int fh_device_count(void) {
 // table plus pinned staging memory: creating and freeing one costs ~5 ms, a 5 Mb genome ~1 ms to sketch.  fh_free
 // therefore resets the handle and parks it; the next fh_new with the same parameters on the same device takes it
 // over.  At most pool_max() handles (FH_POOL, default 64; 0 = off) holding at most pool_max_bytes() (FH_POOL_BYTES,
-// default 8 GiB) together stay parked; fh_release_cached frees them, and so does any allocation of the library that
+// default 24 GiB) together stay parked; fh_release_cached frees them, and so does any allocation of the library that
 // would otherwise run out of memory.
 namespace {
 std::mutex g_pool_mu;
@@ -1354,7 +1413,7 @@ size_t pool_max() {
     }();
     return v;
 }
-// device memory the parked handles may hold together (FH_POOL_BYTES, default 8 GiB: room for the eight worker sketchers
+// device memory the parked handles may hold together (FH_POOL_BYTES, default 24 GiB: room for the sixteen worker sketchers
 // per GPU of a finch_sketch_files batch, small next to 288 GB, and given back the moment any allocation of the library
 // would otherwise fail -- dev_malloc above; an embedding process that wants it all back calls fh_release_cached)
 uint64_t pool_max_bytes() {
@@ -1404,6 +1463,8 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
                 // the environment knobs a handle reads at creation are the new owner's to set
                 s->no_spec = getenv("FH_NO_SPEC") != nullptr;
                 s->n_fast_finish = s->n_spec_deferred = s->n_spec_recovered = 0;
+                s->n_seg_launches = s->n_seg_probes = 0;
+                s->seg_hint = 0;
                 {
                     const bool fast = !s->big_mode && getenv("FH_NO_FAST") == nullptr;
                     const bool hist = fast && s->p.size > 0 && getenv("FH_NO_HIST") == nullptr;
@@ -1523,7 +1584,7 @@ static fh_sketcher *new_handle(const fh_params *params, int device) {
     if ((e = hipMalloc(&s->dead, (size_t)s->dead_cap * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc(dead)", e);
     if ((e = hipMalloc(&s->ctl, sizeof(Ctl))) != hipSuccess) return bail("hipMalloc(ctl)", e);
     for (int i = 0; i < 2; ++i)
-        if ((e = hipMalloc(&s->left_buf[i], (size_t)s->max_waves * 2 * sizeof(uint32_t) + 64)) != hipSuccess)
+        if ((e = hipMalloc(&s->left_buf[i], (size_t)s->max_waves * 4 * sizeof(uint32_t) + 64)) != hipSuccess)
             return bail("hipMalloc(left)", e);
     if ((e = hipMalloc(&s->clog, CLOG_CAP * sizeof(CollRec))) != hipSuccess) return bail("hipMalloc(clog)", e);
     if ((e = hipHostMalloc(&s->h_ctl, sizeof(Ctl), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
@@ -1625,6 +1686,7 @@ void destroy_handle(fh_sketcher *s) {
     (void)hipFree(s->smp_list);
     (void)hipFree(s->smp_hist);
     if (s->h_smp_hist) (void)hipHostFree(s->h_smp_hist);
+    if (s->h_probe) (void)hipHostFree(s->h_probe);
     if (s->copy_stream) {
         (void)hipStreamSynchronize(s->copy_stream);
         (void)hipStreamDestroy(s->copy_stream);
@@ -1729,6 +1791,21 @@ int fh_process_records(fh_sketcher *s, const uint8_t *base, const uint64_t *offs
 int fh_total_bases(fh_sketcher *s, uint64_t *total_bases) {
     if (!s || !total_bases) return fail(FH_ERR_INVALID, "null argument");
     *total_bases = s->proc_total_bases;
+    return FH_OK;
+}
+
+int fh_set_record_stride(fh_sketcher *s, uint32_t stride) {
+    if (!s) return fail(FH_ERR_INVALID, "null argument");
+    if (stride > 1u && (stride < SEG_MIN_STRIDE || stride > SEG_MAX_STRIDE)) stride = 1u; // (nothing the segment kernel takes)
+    s->seg_hint = stride;
+    return FH_OK;
+}
+
+int fh_debug_segments(fh_sketcher *s, uint64_t *launches, uint64_t *probes, uint32_t *stride) {
+    if (!s) return fail(FH_ERR_INVALID, "null argument");
+    if (launches) *launches = s->n_seg_launches;
+    if (probes) *probes = s->n_seg_probes;
+    if (stride) *stride = s->blk_seg;
     return FH_OK;
 }
 
@@ -2217,6 +2294,14 @@ static int ensure_gzip_buffers(fh_sketcher *s) {
         free_gzip_buffers(s);
     }
     s->gz_chunk_alloc = chunk;
+    // (gz_summary, allocated last, is what says "the buffers are there": an allocation that fails on the way frees what the
+    // ones before it got -- a second call would allocate over their pointers)
+    struct Undo {
+        fh_sketcher *s;
+        ~Undo() {
+            if (!s->gz_summary) free_gzip_buffers(s);
+        }
+    } undo{s};
     const uint32_t n = (uint32_t)std::min<uint64_t>(GZ_MAX_CHUNKS, (s->gz_base + gz_batch_capacity(s) + chunk - 1) / chunk + 1);
     const uint64_t cap = (GZ_WINDOW + std::max<uint64_t>(GZ_SYM_PER_BYTE * chunk, 1u << 16) + 7) & ~(uint64_t)7;
     HIP_TRY(dev_malloc((void **)&s->gz_sym, (size_t)n * cap * sizeof(uint16_t) + 64));
@@ -3037,6 +3122,50 @@ class BlockTeam {
     size_t n_jobs = 0, n_done = 0;
     bool quit = false;
 
+    // A worker thread moves next to its device: the CPUs of the NUMA node the GPU's PCIe slot hangs off (launch and
+    // completion paths of eight devices then do not all cross one socket), as far as the process is allowed on them; nothing
+    // changes if sysfs does not say (numa_node -1 or absent), and the caller's own thread is never touched.
+    static void sit_near(int device) {
+        static thread_local int sitting = -1;
+        if (sitting == device || getenv("FH_NO_NUMA_PIN")) return;
+        sitting = device;
+        char bdf[32] = {0};
+        if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) return;
+        for (char *c = bdf; *c; ++c) *c = (char)tolower(*c);
+        char path[160];
+        snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+        int node = -1;
+        if (FILE *f = fopen(path, "r")) {
+            if (fscanf(f, "%d", &node) != 1) node = -1;
+            fclose(f);
+        }
+        if (node < 0) return;
+        snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+        char list[4096] = {0};
+        if (FILE *f = fopen(path, "r")) {
+            if (!fgets(list, (int)sizeof(list), f)) list[0] = 0;
+            fclose(f);
+        }
+        cpu_set_t allowed, want;
+        CPU_ZERO(&want);
+        if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+        int n = 0;
+        for (char *p = list; *p;) { // "0-63,128-191"
+            char *e;
+            const long a = strtol(p, &e, 10);
+            if (e == p) break;
+            long b = a;
+            if (*e == '-') b = strtol(e + 1, &e, 10);
+            for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+                if (CPU_ISSET((int)c, &allowed)) {
+                    CPU_SET((int)c, &want);
+                    ++n;
+                }
+            p = (*e == ',') ? e + 1 : e;
+            if (*e != ',') break;
+        }
+        if (n > 0) (void)sched_setaffinity(0, sizeof(want), &want);
+    }
     static void run_one(Job &j) {
         int rc = fh_reset(j.h);
         if (rc == FH_OK) rc = fh_set_stream_offset(j.h, j.off);
@@ -3056,6 +3185,7 @@ class BlockTeam {
                 seen = generation;
                 j = &jobs[me];
             }
+            sit_near(j->h->device);
             run_one(*j);
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -3104,8 +3234,8 @@ public:
             n_jobs = 0;
         }
         for (uint32_t i = 0; i < n; ++i)
-            if (jobs[i].rc != FH_OK) {
-                err = jobs[i].err;
+            if (jobs[i].rc != FH_OK) { // (the first block that failed; the others' handles hold their partial sketches, finished)
+                err = "block " + std::to_string(i) + " (device " + std::to_string(jobs[i].h->device) + "): " + jobs[i].err;
                 return jobs[i].rc;
             }
         return FH_OK;
@@ -3129,8 +3259,14 @@ int fh_sketch_device_blocks(fh_sketcher *const *handles, const void *const *dev_
         if (a.k != b.k || a.kind != b.kind || a.seed != b.seed || a.size != b.size || memcmp(&a.scale, &b.scale, sizeof(double)) != 0)
             return fail(FH_ERR_INVALID, "fh_sketch_device_blocks: incompatible sketch parameters");
     }
-    int prev_dev = -1;
-    (void)hipGetDevice(&prev_dev);
+    // the caller's current device is the caller's again on EVERY way out (job 0 and the merge run on its thread and set others)
+    struct DeviceGuard {
+        int prev = -1;
+        DeviceGuard() { (void)hipGetDevice(&prev); }
+        ~DeviceGuard() {
+            if (prev >= 0) (void)hipSetDevice(prev);
+        }
+    } device_guard;
     std::string err;
     int rc;
     try {
@@ -3140,8 +3276,7 @@ int fh_sketch_device_blocks(fh_sketcher *const *handles, const void *const *dev_
     } catch (const std::exception &e) {
         return fail(FH_ERR_STATE, "fh_sketch_device_blocks: %s", e.what());
     }
-    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
-    if (rc != FH_OK) return fail(rc, "%s", err.c_str());
+    if (rc != FH_OK) return fail(rc, "fh_sketch_device_blocks: %s", err.c_str());
     if (n == 1) return FH_OK;
     // the host-side merge: union of the ascending partial sketches, counts summed (saturating), k-mer of
     // the smallest first position, re-selection -- on the records, without the detour through ASCII k-mers fh_merge takes
@@ -3155,7 +3290,6 @@ int fh_sketch_device_blocks(fh_sketcher *const *handles, const void *const *dev_
         dst->res.swap(out);
         dst->total_kmers += handles[i]->total_kmers;
     }
-    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
     return FH_OK;
 }
 

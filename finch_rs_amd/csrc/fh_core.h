@@ -106,6 +106,17 @@ FH_HD u64 pairrev64(u64 x) {
     return ((r >> 1) & 0x5555555555555555ULL) | ((r & 0x5555555555555555ULL) << 1);
 }
 
+// reverse the order of the 16 2-bit digits of a dword
+FH_HD u32 pairrev32(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 r = __builtin_bitreverse32(x);
+#else
+    u32 r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i);
+#endif
+    return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+}
+
 // ASCII bytes (little endian, first base in byte 0) of an nb-base group given in m-form
 FH_HD u32 ascii_group(u32 q, int nb) {
     u32 w = 0;
@@ -297,6 +308,17 @@ struct Windows {
         // The words are made opaque: knowing that D[2], D[3] are the halves of ONE 64-bit value, the compiler folds the upper-half
         // bit field of a forward window into a 64-bit shift of the pair (v_lshrrev_b64 + v_and_b32 where one v_bfe_u32 does:
         // k = 21 58.8 -> 58.0 VALU instructions per position; k = 17 +1.2 %, k = 21 +0.5 %, k = 22 +0.7 %, profiles/r04k_ab_d_opaque.txt)
+        for (int i = 0; i < 4; ++i) asm("" : "+v"(D[i]));
+#endif
+    }
+    // The two strings given as they are (fh_k2s.hip cuts them out of a tile's strings in LDS): nc = the lane's 64-base view
+    // complemented and shifted left by PRE bits (bit i of nc = bit i - PRE of ~codes; 5 words), d = the view digit-reversed
+    // (base b at digit 63 - b; 4 words).
+    FH_HDM void init_words(const u32 *nc, const u32 *d) {
+        for (int i = 0; i < 5; ++i) nC[i] = nc[i];
+        for (int i = 0; i < 4; ++i) D[i] = d[i];
+        D[4] = 0;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FH_D_FOLDABLE)
         for (int i = 0; i < 4; ++i) asm("" : "+v"(D[i]));
 #endif
     }

@@ -112,6 +112,13 @@ constexpr int UNIT_TILES = FH_UNIT_TILES; // queue granularity (SketchArgs::unit
 constexpr int MAX_UNITS = FH_MAX_UNITS;   // (guided self-scheduling: big pulls first, single units at the end)
 constexpr int WAVE_BUDGET = 2048; // + at most TILE_POS-1 overshoot inside the tile that crosses it   // tiles a wave pulls from the queue at a time (contiguous: halo reuse)
 
+// The segment kernel (fh_k2s.hip): a lane owns one SEGMENT of seg_stride consecutive k-mer start positions instead of 32, a
+// tile is 64 segments.  With the stride of fixed-length records (read length + 1) the windows that cross a record's breaker
+// sit at the end of every lane's segment and are skipped for the whole wave -- 21 of 151 positions at k = 21, 31 at k = 31;
+// the result does not depend on the stride (a round of positions is skipped only when no lane has a valid window in it).
+constexpr uint32_t SEG_MIN_STRIDE = 40, SEG_MAX_STRIDE = 168; // (what a wave's share of the 160 KB of LDS holds two strings of)
+constexpr uint32_t SEG_PART = 0x80000000u; // leftover pair (tile | SEG_PART, round): that tile from that round on (a wave stopped inside it)
+
 struct SketchArgs {
     const uint8_t *seq;   // packed stream (device), 16-byte aligned
     uint64_t len_total;   // readable bytes
@@ -134,6 +141,8 @@ struct SketchArgs {
                              // (~14 ns each, serialised in L2): the 2 x 1953 of a 4 Mb genome's waves were 55 us of a launch
                              // that hashes for 10, the 12 000 of a 32 M-position prefix 100 us of 150.
     uint32_t static_only;    // the first units cover the whole range: no wave pulls from the queue
+    uint32_t seg_stride;     // != 0: the segment kernel, tiles of 64 x seg_stride positions (p_begin a multiple of 16)
+    uint32_t max_units;      // segment kernel: units a pull takes at most (k2_sketch: MAX_UNITS; its tiles are a fifth the size)
     const uint32_t *left_in; // pairs (t0, t1)
     uint32_t *left_out;      // pairs (t0, t1), capacity >= number of waves
 };

@@ -1952,6 +1952,10 @@ static int bgzf_fastq_to_device(struct BgzfSource &bz, fh_sketcher *h);
 static std::atomic<uint64_t> g_bgzf_on_device{0}, g_bgzf_reread{0};
 static int gzip_fastq_to_device(struct BgzfSource &bz, size_t hdr_len, fh_sketcher *h);
 static std::atomic<uint64_t> g_gzip_on_device{0}, g_gzip_reread{0};
+// finch_debug_kernel_times: the sketch kernel's own time (HIP events on each worker's stream, fh_kernel_time) over the files
+// this process sketches while it is on -- what a batch's roofline line is made of (bench.py --workload c5)
+static std::atomic<int> g_ktimes_on{0};
+static std::atomic<uint64_t> g_ktimes_us{0}, g_ktimes_launches{0}, g_ktimes_positions{0};
 static int fastq_text_to_device(ByteSource &src, fh_sketcher *h, uint32_t k);
 
 // Device-side FASTA (fh_push_fasta_text): the host reads raw file bytes into the pinned staging buffer, cuts chunks
@@ -2069,6 +2073,7 @@ struct HandleSet {
             if (small) p.size = final_size;
             h = fh_new(&p, device);
         }
+        if (h && g_ktimes_on.load(std::memory_order_relaxed)) fh_set_profiling(h, 1);
         return h;
     }
     ~HandleSet() {
@@ -2262,6 +2267,15 @@ static int finish_sketch(fh_sketcher *h, const std::string &name, const finch_sk
     if (fp.filter_on < 0) fp.filter_on = st.format == 2 ? 1 : 0;
     uint64_t n = 0, total_kmers = 0;
     if (int rc = fh_finish(h, &n, &total_kmers)) return hfail(rc, "%s", fh_last_error());
+    if (g_ktimes_on.load(std::memory_order_relaxed)) { // (since the handle's reset: this input's launches)
+        double ms = 0;
+        uint64_t nl = 0, np = 0;
+        if (fh_kernel_time(h, &ms, &nl, &np) == FH_OK) {
+            g_ktimes_us += (uint64_t)(ms * 1000.0 + 0.5);
+            g_ktimes_launches += nl;
+            g_ktimes_positions += np;
+        }
+    }
     const uint32_t k = sp.kmer_length;
     if (n > UINT32_MAX) return hfail(FH_ERR_UNSUPPORTED, "sketch of %llu hashes", (unsigned long long)n);
     if (sp.kind == 0) { // a Mash sketch: cut to final_size right behind the filters
@@ -2327,6 +2341,11 @@ static int fasta_small_on_host(ByteSource &src, fh_sketcher *h, FastxStats &st) 
         raw = scratch.data();
         room = scratch.size();
     }
+    // (the source may deliver more than it said -- a file that grew since its size was asked for, FileSource::read asks
+    // again --, and everything below is sized by what it said: the packed stream, at most one byte per byte read plus
+    // fh_strip's 32 bytes of slack, fits the staging buffer because hint + 4096 <= cap.  One byte more than the hint is "longer
+    // than it said".)
+    room = std::min<size_t>(room, (size_t)hint + 1);
     size_t n = 0;
     for (;;) {
         const size_t g = src.read(raw + n, room - n);
@@ -2365,6 +2384,11 @@ static int fasta_small_on_host(ByteSource &src, fh_sketcher *h, FastxStats &st) 
         else if (len >= 1 && raw[next - 1] == '\r') trim = 1;
         st.total_bases += len - trim;
         st.n_records++;
+        if (m + len + 33 > cap) { // (cannot happen with n <= hint; a guard in front of the one place that writes)
+            if (!src.rewind()) return hfail(FH_ERR_INVALID, "input grew while it was read");
+            st = FastxStats();
+            return FH_ERR_STATE;
+        }
         m += fh_strip::strip(buf + m, raw + start, len);
         buf[m++] = 0; // the record's breaker
         pos = next;
@@ -3445,6 +3469,16 @@ void finch_debug_device_inflate(uint64_t *files_on_device, uint64_t *files_rerea
 void finch_debug_device_gzip(uint64_t *files_on_device, uint64_t *files_reread) {
     if (files_on_device) *files_on_device = finch::g_gzip_on_device.load();
     if (files_reread) *files_reread = finch::g_gzip_reread.load();
+}
+
+void finch_debug_kernel_times(int enable, double *kernel_ms, uint64_t *launches, uint64_t *positions) {
+    if (kernel_ms) *kernel_ms = (double)finch::g_ktimes_us.load() / 1000.0;
+    if (launches) *launches = finch::g_ktimes_launches.load();
+    if (positions) *positions = finch::g_ktimes_positions.load();
+    if (enable >= 0) {
+        finch::g_ktimes_on.store(enable ? 1 : 0);
+        if (enable) finch::g_ktimes_us = 0, finch::g_ktimes_launches = 0, finch::g_ktimes_positions = 0;
+    }
 }
 
 const char *finch_last_error(void) { return g_host_err.c_str(); }

@@ -1,0 +1,396 @@
+// fh_k2s.hip -- the SEGMENT form of the sketch kernel (K = 1..32), hand-written for gfx950 (CDNA4, wave64).
+//
+// What it replaces is what fh_k2.hip's k2_sketch<K> replaces (mash.rs:67-80, 34-42; hashing.rs:10-12), bit for bit; what it
+// adds is the reference's own shape of the work: needletail's canonical_kmers yields len - k + 1 windows per RECORD
+// (mash.rs:76), while k2_sketch hashes one window per stream POSITION and throws away, on the admit path, the k of every
+// record's len + 1 positions whose window crosses the record's breaker byte -- 21 of 151 at k = 21, 31 of 151 at k = 31.
+//
+// Here a lane owns one segment of S = SketchArgs::seg_stride consecutive start positions (S = read length + 1 when the host
+// knows or finds that the records are of one length), a wave a tile of 64 segments:
+//   * phase A: the wave loads the tile's 64 S + 96 bytes coalesced (16 bytes a lane a time, all loads in flight together),
+//     classifies them (fh_core.h classify_chunk) and leaves THREE tile-wide strings in its own LDS: the complemented 2-bit codes
+//     (a window's reverse complement is a bit field of it), the digit-reversed codes (the forward strand's windows) and the
+//     good bits;
+//   * a lane's 64-base view at segment offset R c (R = 32 or 16 positions per round, as in k2_sketch) is cut out of those
+//     strings with funnel shifts by a per-lane constant -- from there on the round is k2_sketch's: windows at compile-time
+//     offsets, table lookups, murmur3, the high-word reject, the admit queue;
+//   * a round none of whose windows is valid in ANY lane is skipped, and a round ends behind the last position that is valid
+//     in any lane (only rounds that reach a segment's last K bases ask: one wave-wide OR).  With S = record stride that is
+//     every record's tail; with any other S, or on a stream that is not made of equal records, nothing is skipped that
+//     k2_sketch would have admitted: the sketch never depends on S (tests/test_gpu_segments.py).
+// One workgroup of sixteen waves per CU (a wave's strings are 6.7 KB); a wave that uses up its insert budget stops at the
+// end of a ROUND and hands the rest of its tile back as a (tile | SEG_PART, round) leftover pair, so the table's guard is
+// k2_sketch's: budget + at most 2047 new hashes per wave and launch.
+//
+// Compiled FH_NPARTS times (-DFH_PART=i) like fh_k2.hip.
+#include <hip/hip_runtime.h>
+
+#include "fh_core.h"
+#include "fh_device.h"
+#include "fh_kernels.h"
+#include "fh_k2_common.h"
+
+#include <type_traits>
+
+#ifndef FH_PART
+#error "compile with -DFH_PART=<0..FH_NPARTS-1>"
+#endif
+
+namespace fh {
+
+constexpr int K2S_WPB = 16;
+constexpr int k2s_round(int K) { return K >= 23 ? 16 : 32; } // (fh_k2.hip, k2_round: the register budget is the same loop's)
+// LDS of the workgroup: lookup tables, admit queues, then a block per wave
+constexpr u32 K2S_A1 = 0, K2S_A2 = 4096, K2S_B1 = 8192, K2S_B2 = 10240, K2S_P = 12288, K2S_Q = 20480;
+constexpr u32 K2S_TILE = K2S_Q + K2S_WPB * (u32)sizeof(AdmitQueueT<false>);
+constexpr u32 K2S_NCH_MAX = 4 * SEG_MAX_STRIDE + 6; // 16-byte chunks of a tile with its 96-byte halo
+constexpr u32 K2S_FC_DW = K2S_NCH_MAX + 3, K2S_RV_DW = K2S_NCH_MAX + 2, K2S_G_DW = K2S_NCH_MAX / 2 + 3;
+constexpr u32 K2S_WAVE_DW = (K2S_FC_DW + K2S_RV_DW + K2S_G_DW + 3) / 4 * 4;
+constexpr u32 K2S_BYTES = K2S_TILE + K2S_WPB * 4 * K2S_WAVE_DW;
+static_assert(K2S_BYTES <= 160 * 1024, "one workgroup's LDS");
+constexpr int K2S_MAX_LOADS = (K2S_NCH_MAX + 63) / 64;
+
+// OR over the wave, in every lane's... lane 63's register, read out as a scalar (row-wise prefix OR, then the rows joined)
+__device__ __forceinline__ u32 wave_or(u32 x) {
+    x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true); // row_shr:1
+    x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true); // row_shr:2
+    x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true); // row_shr:4
+    x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true); // row_shr:8
+    x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    x |= (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return (u32)__builtin_amdgcn_readlane((int)x, 63);
+}
+
+__device__ __forceinline__ u32 lane_now() { // (recomputed where it is needed: a value kept across the position loop is a register the loop lacks)
+    u32 l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
+template <int K>
+__global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArgs a) {
+    constexpr int WPB = K2S_WPB, NTHR = 64 * WPB, R = k2s_round(K), PRE = pre_shift(K);
+    __shared__ __attribute__((aligned(16))) unsigned char blob[K2S_BYTES];
+    Rec4 *const sA1 = (Rec4 *)(blob + K2S_A1), *const sA2 = (Rec4 *)(blob + K2S_A2);
+    Rec2 *const sB1 = (Rec2 *)(blob + K2S_B1), *const sB2 = (Rec2 *)(blob + K2S_B2), *const sP = (Rec2 *)(blob + K2S_P);
+    static_assert(partial_entries(K) * sizeof(Rec2) <= K2S_Q - K2S_P, "the key's last-word table fits its slot");
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.gate && __hip_atomic_load(&a.ctl->spec_ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    {
+        if (has_pair_word(K, false))
+            for (int q = tid; q < 256; q += NTHR) {
+                sA1[q] = lut_rec_A((u32)q, false);
+                sB1[q] = lut_rec_B((u32)q, 4, false);
+            }
+        if (has_pair_word(K, true))
+            for (int q = tid; q < 256; q += NTHR) {
+                sA2[q] = lut_rec_A((u32)q, true);
+                sB2[q] = lut_rec_B((u32)q, 4, true);
+            }
+        for (int q = tid; q < partial_entries(K); q += NTHR) sP[q] = lut_rec_P<K>((u32)q);
+        // the waves' blocks start out zero: the words around the strings are read (never written) as "no good base there"
+        u32 *all = (u32 *)(blob + K2S_TILE);
+        for (u32 i = (u32)tid; i < (u32)WPB * K2S_WAVE_DW; i += (u32)NTHR) all[i] = 0u;
+    }
+    const LutTables LT{sA1, sA2, sB1, sB2, sP, 0u};
+    __syncthreads();
+
+    auto load_tau = [&]() -> u64 {
+        const u64 tau_v = __hip_atomic_load(&a.ctl->tau, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(tau_v >> 32)) << 32) |
+               (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)tau_v);
+    };
+    u64 tau = load_tau();
+    u32 tau_hi1 = (u32)__builtin_amdgcn_readfirstlane((int)tau_hi_bound(tau));
+
+    const u32 gw = blockIdx.x * (u32)WPB + (u32)wave;
+    u32 *const Fc = (u32 *)(blob + K2S_TILE) + (u32)wave * K2S_WAVE_DW; // ~codes: chunk i at word 1 + i
+    u32 *const Rv = Fc + K2S_FC_DW;                                      // digit-reversed codes: chunk i at word NCH - 1 - i
+    u32 *const Gd = Rv + K2S_RV_DW;                                      // good bits: chunk i at half-word i
+    const u32 S = (u32)__builtin_amdgcn_readfirstlane((int)a.seg_stride);
+    const u32 NCH = 4u * S + 6u, NR = (S + (u32)R - 1u) / (u32)R;
+    const u32 tile_pos = 64u * S;
+    u32 nvalid = 0;
+
+#define FLUSHS(ctl_, q_, qn_, shard_) ([&] { const u32 r_ = (u32)__builtin_amdgcn_readfirstlane((int)flush_queue(ctl_, q_, qn_, shard_)); want_refresh |= r_ >> 31; return r_ & 0x7FFFFFFFu; }())
+    u32 want_refresh = 0, wave_inserts = 0, qn = 0;
+    AdmitQueueT<false> *queue = (AdmitQueueT<false> *)(blob + K2S_Q) + wave;
+    if ((tid & 63) == 0) {
+        queue->tau = tau;
+        queue->tau_lo = 0ull;
+        queue->hash_mask = ~0ull;
+        queue->pre = (u32)PRE;
+    }
+    const u32 shard = gw & (u32)(N_SHARDS - 1);
+    u32 last_unit = 0;
+    bool first_pull = true;
+    for (;;) {
+        // work distribution as in k2_sketch: leftover ranges of a stopped launch first (here also single tiles from a round
+        // on), the wave's own first units, then guided pulls from the queue
+        u32 rt0 = 0xFFFFFFFFu, rt1 = 0u;
+        if ((tid & 63) == 0) {
+            u32 li = 0xFFFFFFFFu;
+            if (a.n_left_in) li = atomicAdd(&a.ctl->left_in_pos, 1u);
+            if (li < a.n_left_in) {
+                rt0 = a.left_in[2u * li];
+                rt1 = a.left_in[2u * li + 1u];
+            } else if (first_pull && a.first_units) {
+                const u32 c = gw * a.first_units;
+                if (c < a.n_units) {
+                    rt0 = c * a.unit_tiles;
+                    const u32 e = (c + a.first_units) * a.unit_tiles;
+                    rt1 = e < a.tiles_total ? e : a.tiles_total;
+                }
+                last_unit = gridDim.x * (u32)WPB * a.first_units;
+            } else if (a.static_only) {
+            } else if (__hip_atomic_load(&a.ctl->stopped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                const u32 left = a.n_units > last_unit ? a.n_units - last_unit : 0u;
+                u32 k = left / (4u * a.n_waves);
+                k = k < 1u ? 1u : (k > a.max_units ? a.max_units : k);
+                const u32 c = atomicAdd(&a.ctl->next_unit, k);
+                last_unit = c + k;
+                if (c < a.n_units) {
+                    rt0 = c * a.unit_tiles;
+                    const u32 e = (c + k) * a.unit_tiles;
+                    rt1 = e < a.tiles_total ? e : a.tiles_total;
+                }
+            }
+        }
+        first_pull = false;
+        rt0 = (u32)__builtin_amdgcn_readfirstlane((int)rt0);
+        rt1 = (u32)__builtin_amdgcn_readfirstlane((int)rt1);
+        if (rt0 == 0xFFFFFFFFu) break;
+        u32 c_first = 0u;
+        if (rt0 & SEG_PART) { // one tile, from round rt1 on
+            c_first = rt1;
+            rt0 &= ~SEG_PART;
+            rt1 = rt0 + 1u;
+        }
+
+        bool stop = false;
+#pragma unroll 1
+        for (u32 t = rt0; t < rt1; ++t) {
+            const u64 tile_pos0 = a.p_begin + (u64)t * tile_pos; // wave-uniform; a multiple of 16
+            // ---- phase A: the tile's bytes (and 96 behind them) -> the three strings ----
+            {
+                const u32 lane = (u32)tid & 63u;
+                uint4 buf[K2S_MAX_LOADS];
+#pragma unroll
+                for (int m = 0; m < K2S_MAX_LOADS; ++m) {
+                    const u32 i = lane + 64u * (u32)m;
+                    buf[m] = make_uint4(0u, 0u, 0u, 0u);
+                    if (i < NCH) buf[m] = load_chunk_guarded(a.seq, tile_pos0 + 16ull * i, a.len_total);
+                }
+                // (the strings of the tile before are still being read by nobody: the rounds below are this wave's own)
+#pragma unroll
+                for (int m = 0; m < K2S_MAX_LOADS; ++m) {
+                    const u32 i = lane + 64u * (u32)m;
+                    if (i < NCH) {
+                        u32 q, g;
+                        classify_chunk(buf[m].x, buf[m].y, buf[m].z, buf[m].w, q, g);
+                        Fc[1u + i] = ~q;
+                        Rv[NCH - 1u - i] = pairrev32(q);
+                        reinterpret_cast<unsigned short *>(Gd)[i] = (unsigned short)g;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            const u64 tile_stream_pos = a.base_pos + tile_pos0;
+#pragma unroll 1
+            for (u32 c = c_first; c < NR; ++c) {
+                const u32 rc0 = (u32)R * c; // the round's first segment offset (wave-uniform)
+                Windows<K> win;
+                u32 Wc;
+                u32 nmax = S - rc0 < (u32)R ? S - rc0 : (u32)R; // positions of the segment this round covers
+                {
+                    const u32 lane = lane_now();
+                    const u32 p0 = S * lane + rc0; // the lane's view begins at this tile position
+                    // which of its windows carry a k-mer: all K bases good, inside the segment, inside [p_begin, p_end)
+                    const u32 gi = p0 >> 5, gs = p0 & 31u;
+                    const u32 g0 = Gd[gi], g1 = Gd[gi + 1u], g2 = Gd[gi + 2u];
+                    const u64 g64 = (u64)alignbit_b32(g1, g0, gs) | ((u64)alignbit_b32(g2, g1, gs) << 32);
+                    const u64 lane_pos0 = tile_pos0 + p0;
+                    u32 limit = (a.p_end > lane_pos0) ? (u32)((a.p_end - lane_pos0) < 32 ? (a.p_end - lane_pos0) : 32) : 0u;
+                    limit = limit < nmax ? limit : nmax;
+                    Wc = window_valid_mask<K>(g64) & (limit >= 32u ? 0xFFFFFFFFu : ((1u << limit) - 1u));
+                    // a round whose windows reach the segment's last K bases may hold nothing, or nothing behind some position,
+                    // in every lane at once (the records' breakers): ask the wave
+                    // (asked in every round: seven instructions a round, and the compiler does not get to make two copies of
+                    // the positions' code, one of them with a spilled register per position)
+                    {
+                        const u32 any = wave_or(Wc);
+                        if (any == 0u) continue;
+                        nmax = 32u - (u32)__builtin_clz(any);
+                    }
+                    nvalid += (u32)__popc(Wc);
+                    // the lane's two strings for this round, cut out of the tile's (fh_core.h, Windows::init_words)
+                    const int gc = (int)(2u * p0) - PRE; // first bit of the complemented string's view, shifted left by PRE
+                    const u32 ic = (u32)((gc >> 5) + 1), sc = (u32)gc & 31u;
+                    u32 f[6], nc[5];
+#pragma unroll
+                    for (int w = 0; w < 6; ++w) f[w] = Fc[ic + (u32)w];
+#pragma unroll
+                    for (int w = 0; w < 5; ++w) nc[w] = alignbit_b32(f[w + 1], f[w], sc);
+                    const u32 gd = 2u * (16u * NCH - 64u - p0); // first bit of the digit-reversed string's view (base 63 of it)
+                    const u32 id = gd >> 5, sd = gd & 31u;
+                    u32 r[5], d[4];
+#pragma unroll
+                    for (int w = 0; w < 5; ++w) r[w] = Rv[id + (u32)w];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) d[w] = alignbit_b32(r[w + 1], r[w], sd);
+                    win.init_words(nc, d);
+                }
+
+                // ---- the round's positions: k2_sketch's loop (fh_k2.hip), ending behind the last valid one ----
+                auto window = [&](int j, u64 &cm, bool &is_rc) {
+                    if constexpr (Windows<K>::MINF64) cm = win.canonical_word(j), is_rc = false;
+                    else cm = win.canonical(j, is_rc);
+                };
+                u64 cm_cur;
+                bool rc_cur;
+                KeyWords<K> kw_cur;
+                window(0, cm_cur, rc_cur);
+                murmur_lookup<K, 1>(cm_cur, LT, kw_cur);
+                // The positions are a chain of nested ifs, not a loop: leaving a loop early (`break`) keeps LLVM from unrolling it
+                // -- its body holds convergent operations --, and skipping the bodies one by one (`continue`) merges control flow
+                // behind every position, with copies of everything the software pipeline carries (four moves per position).
+                auto step = [&](auto self, auto jc) __attribute__((always_inline)) -> void {
+                    constexpr int j = decltype(jc)::value;
+                    if ((u32)j >= nmax) return; // wave-uniform: behind the last position that is valid in any lane
+                    u64 cm_nxt = 0;
+                    bool rc_nxt = false;
+                    KeyWords<K> kw_nxt;
+                    if constexpr (j + 1 < R) {
+                        window(j + 1, cm_nxt, rc_nxt);
+                        murmur_lookup<K, 1>(cm_nxt, LT, kw_nxt);
+                    }
+                    const u64 cm = cm_cur;
+                    const bool rc_loop = rc_cur;
+                    const HashParts hp = murmur_finish_parts<K, true>(kw_cur, 0ull);
+                    const bool cand = parts_hi_plus1(hp) <= tau_hi1;
+                    if (__builtin_expect(__any(cand), 0)) { // wave-uniform branch
+                        const bool take = cand && ((Wc >> j) & 1u);
+                        const u64 mask = __builtin_amdgcn_ballot_w64(take);
+                        const u32 cnt = (u32)__popcll(mask);
+                        if (cnt) {
+                            if (qn + cnt > (u32)QCAP) {
+                                wave_inserts += FLUSHS(a.ctl, queue, qn, shard);
+                                qn = 0;
+                            }
+                            const u32 my = qn + __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+                            if (take) {
+                                queue->ka[my] = hp.ka;
+                                queue->kb[my] = hp.kb;
+                                queue->k[my] = cm;
+                                const u64 pos = tile_stream_pos + (u64)(lane_now() * S + rc0 + (u32)j);
+                                bool is_rc = rc_loop;
+                                if constexpr (Windows<K>::MINF64) is_rc = win.strand_of(j);
+                                queue->p[my] = pos | ((u64)(is_rc ? 1u : 0u) << 63);
+                            }
+                            qn += cnt;
+                        }
+                    }
+                    if constexpr (j + 1 < R) {
+                        cm_cur = cm_nxt;
+                        rc_cur = rc_nxt;
+                        kw_cur = kw_nxt;
+                        self(self, std::integral_constant<int, j + 1>{});
+                    }
+                };
+                step(step, std::integral_constant<int, 0>{});
+                __builtin_amdgcn_wave_barrier();
+                const bool last_round = c + 1u == NR;
+                if (qn >= (u32)(QCAP / 2)) { // drain when half full (and at the end of the pulled range, below)
+                    wave_inserts += FLUSHS(a.ctl, queue, qn, shard);
+                    qn = 0;
+                }
+                if (want_refresh) {
+                    refresh_tau(a.ctl);
+                    want_refresh = 0;
+                }
+                if (!(last_round && t + 1u == rt1) && wave_inserts >= a.wave_budget) {
+                    // the wave's insert budget is spent: the rest of the tile and of the pulled range goes back
+                    if (qn) {
+                        wave_inserts += FLUSHS(a.ctl, queue, qn, shard);
+                        qn = 0;
+                    }
+                    if ((tid & 63) == 0) {
+                        const u32 n = (last_round ? 0u : 1u) + (t + 1u < rt1 ? 1u : 0u);
+                        u32 idx = atomicAdd(&a.ctl->n_left_out, n);
+                        if (!last_round) {
+                            a.left_out[2u * idx] = t | SEG_PART;
+                            a.left_out[2u * idx + 1u] = c + 1u;
+                            ++idx;
+                        }
+                        if (t + 1u < rt1) {
+                            a.left_out[2u * idx] = t + 1u;
+                            a.left_out[2u * idx + 1u] = rt1;
+                        }
+                        atomicExch(&a.ctl->stopped, 1u);
+                    }
+                    stop = true;
+                    break;
+                }
+            }
+            if (stop) break;
+            c_first = 0u;
+            if (qn && t + 1u == rt1) { // nothing stays parked when the wave asks for more work (or finds none)
+                wave_inserts += FLUSHS(a.ctl, queue, qn, shard);
+                qn = 0;
+                if (want_refresh) {
+                    refresh_tau(a.ctl);
+                    want_refresh = 0;
+                }
+            }
+            // the threshold may have been lowered by any wave's admit path (fh_k2_common.h, refresh_tau)
+            const u64 tau_now = load_tau();
+            if (tau_now != tau) { // wave-uniform
+                tau = tau_now;
+                tau_hi1 = (u32)__builtin_amdgcn_readfirstlane((int)tau_hi_bound(tau));
+                if ((tid & 63) == 0) queue->tau = tau;
+            }
+        }
+        if (stop || wave_inserts >= a.wave_budget) {
+            if (!stop && (tid & 63) == 0) atomicExch(&a.ctl->stopped, 1u);
+            break;
+        }
+    }
+    // total_kmers (mash.rs:35): one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) nvalid += __shfl_xor(nvalid, off);
+    if ((tid & 63) == 0 && nvalid) atomicAdd((unsigned long long *)&a.ctl->kmer_counts[gw & 255u], (unsigned long long)nvalid);
+}
+
+template <int K>
+static hipError_t launch_k2s_t(const SketchArgs &a, hipStream_t st) {
+    const dim3 grid((a.n_waves + K2S_WPB - 1) / K2S_WPB), block(64 * K2S_WPB);
+    hipLaunchKernelGGL((k2_sketch_seg<K>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+
+#ifdef FH_ONLY_K
+constexpr int PART_LO = FH_ONLY_K, PART_HI = FH_ONLY_K;
+#else
+constexpr int PART_LO = FH_PART * (32 / FH_NPARTS) + 1;
+constexpr int PART_HI = (FH_PART + 1) * (32 / FH_NPARTS);
+#endif
+
+template <int K>
+static hipError_t launch_k2s_dispatch(int k, const SketchArgs &a, hipStream_t st) {
+    if (k == K) return launch_k2s_t<K>(a, st);
+    if constexpr (K > PART_LO) return launch_k2s_dispatch<K - 1>(k, a, st);
+    return hipErrorInvalidValue;
+}
+
+#define FH_CAT2(a, b) a##b
+#define FH_CAT(a, b) FH_CAT2(a, b)
+hipError_t FH_CAT(launch_k2s_part, FH_PART)(int k, const SketchArgs &a, hipStream_t st) {
+    if (k < PART_LO || k > PART_HI) return hipErrorInvalidValue;
+    return launch_k2s_dispatch<PART_HI>(k, a, st);
+}
+
+} // namespace fh

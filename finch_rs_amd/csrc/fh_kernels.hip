@@ -28,6 +28,15 @@ hipError_t launch_k2(int k, const SketchArgs &a, int blocks, hipStream_t st) {
         default: return launch_k2w_part3(k, a, blocks, st);
         }
     }
+    if (a.seg_stride) { // the segment form (fh_k2s.hip)
+        if (a.seg_stride < SEG_MIN_STRIDE || a.seg_stride > SEG_MAX_STRIDE || a.tau_lo || a.seed || a.hash_mask != ~0ull) return hipErrorInvalidValue;
+        switch ((k - 1) / (32 / FH_NPARTS)) {
+        case 0: return launch_k2s_part0(k, a, st);
+        case 1: return launch_k2s_part1(k, a, st);
+        case 2: return launch_k2s_part2(k, a, st);
+        default: return launch_k2s_part3(k, a, st);
+        }
+    }
     switch ((k - 1) / (32 / FH_NPARTS)) {
     case 0: return launch_k2_part0(k, a, blocks, st);
     case 1: return launch_k2_part1(k, a, blocks, st);
@@ -917,6 +926,58 @@ __global__ __launch_bounds__(256) void k_read_probe(const uint4 *p, u64 n16, u32
         acc ^= a.x ^ a.y ^ a.z ^ a.w;
     }
     if (acc == 0x9E3779B9u) *sink = acc; // practically never: keeps the loads alive
+}
+
+// ------------------------------------------------------------------------------------------------
+// records of one length?  (launch_seg_probe, fh_kernels.h)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool probe_is_base(uint8_t c) {
+    c &= 0xDFu;
+    return c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'U';
+}
+__global__ __launch_bounds__(64) void k_seg_probe(const uint8_t *seq, u64 len, u32 *out) {
+    const u32 lane = threadIdx.x;
+    __shared__ u32 cand[4];
+    {
+        // the first four bytes that are no bases, within the longest record the segment kernel takes: one of them ends record 0
+        // (the others are N's inside it).  Three bytes a lane, the lanes' verdicts as ballots.
+        u32 n = 0;
+        for (u32 base = 0; base < 192u && n < 4u; base += 64u) { // (wave-uniform loop)
+            const u32 i = base + lane;
+            const bool bad = i < SEG_MAX_STRIDE && (u64)i < len && !probe_is_base(seq[i]);
+            u64 m = __builtin_amdgcn_ballot_w64(bad);
+            while (m && n < 4u) {
+                const u32 b = (u32)__builtin_ctzll(m);
+                m &= m - 1ull;
+                if (lane == 0) cand[n] = base + b + 1u;
+                ++n;
+            }
+        }
+        if (lane == 0)
+            for (; n < 4u; ++n) cand[n] = 0u;
+    }
+    __syncthreads();
+    u32 found = 0u;
+    for (int ci = 0; ci < 4 && !found; ++ci) {
+        const u32 S = cand[ci];
+        if (S < SEG_MIN_STRIDE || S > SEG_MAX_STRIDE) continue;
+        const u64 nrec = len / S;
+        if (nrec < 128ull || nrec * S != len) continue; // (a block of whole records)
+        // the first 64 records, and 64 spread over the block: the byte where the breaker should be, and the one in front of
+        // the next record's breaker being a base more often than not (so that a stream of breakers does not pass)
+        const u64 r0 = lane, r1 = (nrec - 1ull) * lane / 63ull;
+        const bool ok = !probe_is_base(seq[r0 * S + S - 1u]) && !probe_is_base(seq[r1 * S + S - 1u]);
+        const bool inner = probe_is_base(seq[r0 * S]) || probe_is_base(seq[r1 * S + S / 2u]);
+        if (__builtin_amdgcn_ballot_w64(ok) == ~0ull && __popcll(__builtin_amdgcn_ballot_w64(inner)) >= 32) found = S;
+    }
+    if (lane == 0) {
+        out[0] = found;
+        __threadfence_system();
+    }
+}
+hipError_t launch_seg_probe(const uint8_t *seq, u64 len, u32 *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_seg_probe, dim3(1), dim3(64), 0, st, seq, len, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_read_probe(const void *p, u64 bytes, u32 *sink, hipStream_t st) {

@@ -108,6 +108,7 @@ _SYMS = {
     "finch_source_probe": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "finch_debug_device_inflate": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "finch_debug_device_gzip": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "finch_debug_kernel_times": (None, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "finch_gzip_probe": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_uint32)]),
     "finch_bgzf_batch_probe": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64),
@@ -429,6 +430,14 @@ def debug_device_gzip():
     a, b = C.c_uint64(), C.c_uint64()
     lib().finch_debug_device_gzip(C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def debug_kernel_times(enable: int = -1):
+    """(sketch-kernel ms, launches, positions) over the inputs sketched since the hook was switched on; then enable = 1 switches
+    it on and zeroes the sums, 0 off, -1 leaves it -- measurement hook"""
+    ms, nl, npos = C.c_double(), C.c_uint64(), C.c_uint64()
+    lib().finch_debug_kernel_times(enable, C.byref(ms), C.byref(nl), C.byref(npos))
+    return ms.value, nl.value, npos.value
 
 
 def source_probe(data: bytes, chunk: int, cap: int) -> bytes:

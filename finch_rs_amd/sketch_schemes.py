@@ -115,7 +115,9 @@ class HipSketcher:
         base = np.ascontiguousarray(base, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         lens = np.ascontiguousarray(lens, dtype=np.uint64)
-        if len(offsets) != len(lens) or (len(lens) and int((offsets + lens).max()) > base.size):
+        # (offsets + lens wraps in uint64: an offset near 2^64 would pass a check on the sum)
+        if len(offsets) != len(lens) or (len(lens) and (int(offsets.max()) > base.size or
+                                                        bool((lens > np.uint64(base.size) - offsets).any()))):
             raise ValueError("records outside the buffer")
         check(self._L.fh_process_records(self._h, base.ctypes.data, offsets.ctypes.data, lens.ctypes.data, len(lens)))
         self.total_bases += int(lens.sum())
@@ -127,6 +129,17 @@ class HipSketcher:
 
     def push_device(self, dev_ptr: int, nbytes: int) -> None:
         check(self._L.fh_push_device(self._h, C.c_void_p(dev_ptr), nbytes))
+
+    def set_record_stride(self, stride: int) -> None:
+        """records of the packed streams pushed from now on are `stride` - 1 bases long (0: not known, 1: not of one length);
+        a tuning hint, never part of the result (include/finch_hip.h)"""
+        check(self._L.fh_set_record_stride(self._h, stride))
+
+    def debug_segments(self):
+        """(launches of the segment kernel, blocks probed for a stride, stride of the last block)"""
+        a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
+        check(self._L.fh_debug_segments(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def set_stream_offset(self, off: int) -> None:
         check(self._L.fh_set_stream_offset(self._h, off))

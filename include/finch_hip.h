@@ -73,7 +73,7 @@ int fh_abi_version(void);
 fh_sketcher *fh_new(const fh_params *params, int device);
 /* Drop a sketcher.  finch creates one per file and drops it after to_vec (lib.rs:58-79); since a sketcher owns
  * gigabytes of device memory, fh_free resets it and keeps up to FH_POOL (environment, default 64, 0 = never) of them
- * parked -- FH_POOL_BYTES of device memory at most (environment, default 8 GiB) -- and fh_new hands a parked one back
+ * parked -- FH_POOL_BYTES of device memory at most (environment, default 24 GiB) -- and fh_new hands a parked one back
  * when the parameters and the device match (~0.1 ms instead of ~5 ms).  fh_release_cached frees what is parked; the
  * library does so itself before any of its own allocations fails for lack of memory. */
 void fh_free(fh_sketcher *s);
@@ -194,6 +194,17 @@ int fh_text_bases(fh_sketcher *s, uint64_t *total_bases);
  * The memory must stay valid until fh_finish/fh_sync returns. */
 int fh_push_device(fh_sketcher *s, const void *dev_bytes, uint64_t len);
 
+/* What the caller knows about the records of the packed streams it pushes (a property of its data: it survives fh_reset).
+ * stride = record length + 1 (the breaker): every record of every block pushed from now on has that length -- reads of one
+ * length, which is what sequencers write; 0 (the default) = not known: a block of 64 MiB or more is asked itself (one wavefront
+ * and one host round trip per block); 1 = records are not of one length, do not ask.  With a stride the library sketches the
+ * block with a kernel that does not hash the k positions of every record whose window crosses its breaker (fh_k2s.hip; the
+ * reference's canonical_kmers yields len - k + 1 windows per record, mash.rs:76).  A TUNING hint: the sketch is the same bit
+ * for bit whatever is said here, also when it is wrong (tests/test_gpu_segments.py).  Strides outside 40..168 are taken as 1. */
+int fh_set_record_stride(fh_sketcher *s, uint32_t stride);
+/* debug / tests: launches of the segment kernel, blocks probed for a stride, the stride of the last block (0: none) */
+int fh_debug_segments(fh_sketcher *s, uint64_t *launches, uint64_t *probes, uint32_t *stride);
+
 /* wait for all pushed work; surfaces deferred device errors */
 int fh_sync(fh_sketcher *s);
 
@@ -260,7 +271,12 @@ int fh_merge_wire(uint32_t kind, uint64_t size, double scale, uint32_t k, uint64
  * of its own, kept by the library between calls; the calling thread runs block 0 and then merges the n partial sketches
  * into handles[0] by fh_merge's rule.  On return every handle is finished: handles[0] holds the merged sketch (fh_finish
  * reports its size and the k-mer total of all blocks, fh_copy_out* deliver it), the others their partial ones.  The
- * handles must be distinct and have the same sketch parameters; several may share a device.  First error wins. */
+ * handles must be distinct and have the same sketch parameters; several may share a device.  EVERY handle is reset on entry
+ * (whatever the caller had pushed into it is discarded: the call sketches the blocks and nothing else).  The first block that
+ * fails decides the return code, and fh_last_error() names it ("block i (device d): ..."); the handles of the other blocks are
+ * left finished with their partial sketches, handles[0] then holds block 0's alone.  The caller's current HIP device is the
+ * same on return as on entry, whichever way the call ends.  The library's threads (not the caller's) run on the CPUs of the
+ * NUMA node their device is attached to where sysfs names one (FH_NO_NUMA_PIN=1: wherever the scheduler puts them). */
 int fh_sketch_device_blocks(fh_sketcher *const *handles, const void *const *dev_blocks, const uint64_t *lens,
                             const uint64_t *stream_offsets, uint32_t n);
 

@@ -201,6 +201,10 @@ int finch_gzip_probe(const uint8_t *data, uint64_t len, uint64_t piece_bytes, ui
 void finch_debug_device_inflate(uint64_t *files_on_device, uint64_t *files_reread);
 /* the same for plain gzip files (fh_push_gzip_fastq) */
 void finch_debug_device_gzip(uint64_t *files_on_device, uint64_t *files_reread);
+/* Measurement hook (bench.py --workload c5): reports the sketch kernel's own time (HIP events on every worker's stream), its
+ * launches and the k-mer start positions they covered over the inputs sketched since it was switched on, then: enable = 1
+ * switches it on and zeroes the sums, 0 switches it off, -1 leaves it as it is. */
+void finch_debug_kernel_times(int enable, double *kernel_ms, uint64_t *launches, uint64_t *positions);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,167 @@
+"""The segment form of the sketch kernel (fh_k2s.hip; fh_set_record_stride / the stride probe of large blocks): the sketch
+must be the oracle's bit for bit whatever the stride says -- right, wrong, or on a stream that has no records of one length
+at all.  canonical_kmers yields len - k + 1 windows per record (mash.rs:76): with the right stride the kernel hashes exactly
+those and skips the k positions per record whose window crosses the breaker."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import finch_rs_amd as F
+from finch_rs_amd import sketch_schemes as S
+from oracle import oracle as O
+from test_gpu_parity import assert_same, random_reads
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def packed(reads):
+    return np.frombuffer(b"".join(r + b"\0" for r in reads), dtype=np.uint8)
+
+
+def fixed_reads(rng, n, L, genome, p_n=0.004, p_lower=0.02):
+    return random_reads(rng, n, L, L, p_n=p_n, p_lower=p_lower, genome=genome)
+
+
+def sketch_on_device(params, stream, stride, pushes=1):
+    sk = params.create_sketcher()
+    sk.set_record_stride(stride)
+    bufs = []
+    # (blocks are sketched independently, as the records of one: cut between records, at 16-byte aligned places)
+    rec16 = 16 * (stride if stride > 1 else 151)
+    cut = [0] + [len(stream) * i // pushes // rec16 * rec16 for i in range(1, pushes)] + [len(stream)]
+    for a, b in zip(cut[:-1], cut[1:]):
+        d = F.DeviceBuffer(b - a + 256)
+        d.upload(stream[a:b])
+        bufs.append(d)
+        sk.push_device(d.ptr, b - a)
+    sk.sync()
+    return sk, bufs
+
+
+def oracle_of(kind, n, k, stream, scale=0.0):
+    ora = O.OracleSketcher(kind, n, k, 0, scale) if kind == O.SCALED else O.OracleSketcher(kind, n, k, 0)
+    ora.process_packed(stream, 0)
+    return ora
+
+
+@pytest.fixture(scope="module")
+def genome():
+    return S.synth_genome_host(300_000, 77)
+
+
+@pytest.mark.parametrize("k", [5, 12, 16, 17, 21, 22, 24, 27, 31, 32])
+def test_right_stride_every_kernel_shape(genome, k):
+    rng = np.random.default_rng(1000 + k)
+    stream = packed(fixed_reads(rng, 3000 + k, 150, genome))  # (not a multiple of 64 records: a partial last tile)
+    sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, k, 0), stream, 151)
+    assert sk.debug_segments()[0] > 0 and sk.debug_segments()[2] == 151
+    assert_same(sk, oracle_of(O.MASH, 1000, k, stream), "k=%d" % k)
+
+
+@pytest.mark.parametrize("stride", [40, 97, 100, 150, 152, 167, 168])
+@pytest.mark.parametrize("k", [21, 31])
+def test_wrong_stride_changes_nothing(genome, k, stride):
+    rng = np.random.default_rng(2000 + stride)
+    stream = packed(fixed_reads(rng, 2500, 150, genome))
+    sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, k, 0), stream, stride)
+    assert sk.debug_segments()[0] > 0
+    assert_same(sk, oracle_of(O.MASH, 1000, k, stream), "k=%d stride=%d" % (k, stride))
+
+
+@pytest.mark.parametrize("L", [39, 60, 100, 125, 167])
+def test_other_read_lengths(genome, L):
+    rng = np.random.default_rng(3000 + L)
+    stream = packed(fixed_reads(rng, 4000, L, genome))
+    for k in (21, 31):
+        sk, _ = sketch_on_device(F.SketchParams.mash(500, 500, True, k, 0), stream, L + 1)
+        assert sk.debug_segments()[0] > 0
+        assert_same(sk, oracle_of(O.MASH, 500, k, stream), "L=%d k=%d" % (L, k))
+
+
+def test_streams_that_are_not_records_of_one_length(genome):
+    rng = np.random.default_rng(4)
+    ragged = packed(random_reads(rng, 4000, 0, 220, p_n=0.01, genome=genome))     # every length, empty records too
+    one = np.concatenate([genome[:250_000], np.zeros(1, np.uint8)])               # one long record, no breaker inside
+    ns = packed([bytes(r) for r in np.full((2000, 150), ord("N"), np.uint8)])     # nothing valid at all
+    tail_n = packed([r[:140] + b"N" * 10 for r in fixed_reads(rng, 2000, 150, genome)])  # the last windows of every record invalid
+    for name, stream in (("ragged", ragged), ("one", one), ("all N", ns), ("tail N", tail_n)):
+        for k in (21, 31):
+            sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, k, 0), stream, 151)
+            assert_same(sk, oracle_of(O.MASH, 1000, k, stream), "%s k=%d" % (name, k))
+
+
+def test_breaker_positions_holding_bases(genome):
+    """the stride is right for most records, but some records are one base longer / shorter: the bytes where breakers
+    'should' be are bases there, and the rounds that would be skipped hold k-mers"""
+    rng = np.random.default_rng(5)
+    reads = fixed_reads(rng, 3000, 150, genome)
+    for i in range(100, 3000, 97):
+        reads[i] = reads[i] + b"A" if i & 1 else reads[i][:-1]
+    stream = packed(reads)
+    for k in (21, 31):
+        sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, k, 0), stream, 151)
+        assert_same(sk, oracle_of(O.MASH, 1000, k, stream), "k=%d" % k)
+
+
+def test_loose_thresholds_stop_waves_inside_a_tile(genome):
+    """a scaled sketch that keeps half of all k-mers, and an oversketch the input cannot fill: every wave runs into its insert
+    budget, stops at the end of a round and hands the rest of its tile back (SEG_PART leftover pairs)"""
+    rng = np.random.default_rng(6)
+    stream = packed(fixed_reads(rng, 6000, 150, genome, p_n=0.001))
+    sk, _ = sketch_on_device(F.SketchParams.scaled(1000, 21, 0.5, 0), stream, 151)
+    assert sk.debug_segments()[0] > 0
+    assert_same(sk, oracle_of(O.SCALED, 1000, 21, stream, 0.5), "scaled 0.5")
+    sk, _ = sketch_on_device(F.SketchParams.mash(400_000, 400_000, True, 31, 0), stream, 151)
+    assert_same(sk, oracle_of(O.MASH, 400_000, 31, stream), "oversketch")
+
+
+def test_low_complexity_fails_the_speculation(genome):
+    rng = np.random.default_rng(7)
+    few = fixed_reads(rng, 40, 150, genome, p_n=0.0)
+    stream = packed([few[i % 40] for i in range(6000)])  # 40 reads, 150 times each: far fewer distinct hashes than positions
+    for k in (21, 31):
+        sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, k, 0), stream, 151)
+        assert_same(sk, oracle_of(O.MASH, 1000, k, stream), "k=%d" % k)
+
+
+def test_blocks_pushed_one_after_the_other(genome):
+    rng = np.random.default_rng(8)
+    stream = packed(fixed_reads(rng, 6400, 150, genome))
+    sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, 21, 0), stream, 151, pushes=3)
+    assert_same(sk, oracle_of(O.MASH, 1000, 21, stream), "three pushes")
+
+
+def test_stride_found_by_the_probe():
+    """a block of whole records of one length is recognised without being told (FH_SEG_PROBE_MIN: from which size on a block
+    is asked; 64 MiB by default), N's inside the first record included; a ragged block is not"""
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import finch_rs_amd as F
+from finch_rs_amd import sketch_schemes as S
+from oracle import oracle as O
+from test_gpu_parity import assert_same, random_reads
+g = S.synth_genome_host(200000, 3)
+rng = np.random.default_rng(9)
+def run(reads, want_stride):
+    stream = np.frombuffer(b"".join(r + b"\0" for r in reads), dtype=np.uint8)
+    sk = F.SketchParams.mash(1000, 1000, True, 21, 0).create_sketcher()
+    d = F.DeviceBuffer(stream.size + 256); d.upload(stream)
+    sk.push_device(d.ptr, stream.size); sk.sync()
+    launches, probes, stride = sk.debug_segments()
+    assert probes == 1 and stride == want_stride and (launches > 0) == (want_stride != 0), (launches, probes, stride)
+    ora = O.OracleSketcher(O.MASH, 1000, 21, 0); ora.process_packed(stream, 0)
+    assert_same(sk, ora)
+reads = random_reads(rng, 3000, 150, 150, p_n=0.002, genome=g)
+reads[0] = reads[0][:30] + b"NN" + reads[0][32:]
+run(reads, 151)
+run(random_reads(rng, 3000, 100, 150, genome=g), 0)
+print("probe OK")
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FH_SEG_PROBE_MIN="0"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "probe OK" in r.stdout, r.stdout[-3000:]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of libfinch_hip builds on the resident synthetic stream (GPU box).
 
-    python tools/ab_k.py --libs name=path.so[,name=path.so...] --ks 21,31 [--n 1000] [--gbases 10] [--steps 3] [--env "K=V ..."]
+    python tools/ab_k.py --libs name=path.so[@K=V+K=V][,name=path.so...] --ks 21,31 [--n 1000] [--gbases 10] [--steps 3] [--env "K=V ..."]
 
 Every (build, k) runs in its own process (FH_LIB picks the library): `steps` passes over the same `gbases` Gbase of SURVEY 8d M4
 reads resident in HBM, best pass reported, with the kernel's own HIP-event time.  The fingerprints of the sketches are compared
@@ -80,6 +80,14 @@ def main():
         for kv in args.env.split():
             k, v = kv.split("=", 1)
             env[k] = v
+        if "@" in path:  # name=path@K=V+K2=V2 : environment of this build alone (A/B of a run-time knob of one library)
+            path, extra = path.split("@", 1)
+            for kv in extra.split("+"):
+                k, v = kv.split("=", 1)
+                env[k] = v
+            env.pop("FH_LIB", None)
+            if path:
+                env["FH_LIB"] = os.path.abspath(path)
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--ks", args.ks, "--n", str(args.n), "--gbases", str(args.gbases),
                               "--steps", str(args.steps)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         rows = [json.loads(l[3:]) for l in out.stdout.splitlines() if l.startswith("AB ")]
