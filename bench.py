@@ -413,7 +413,8 @@ def main():
     achieved = (kernel_pos / 1e9) / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                "kernel": "k2_sketch<%d>" % args.k, "launches": kernel_launches,
+                "kernel": ("k2_sketch_seg<%d> (segments of %d positions: the reads' stride)" % (args.k, shards[0].sk.debug_segments()[2])
+                           if shards[0].sk.debug_segments()[0] else "k2_sketch<%d>" % args.k), "launches": kernel_launches,
                 "kernel_ms_per_pass": round(kernel_ms / max(args.steps, 1), 4),
                 "avg_launch_ms": round(kernel_ms / max(kernel_launches, 1), 4),
                 "alg_bytes_per_launch": int(kernel_pos / max(kernel_launches, 1)),

@@ -191,6 +191,7 @@ struct fh_sketcher {
     uint32_t seg_hint = 0, blk_seg = 0;
     uint64_t gran = TILE_POS;
     uint32_t *h_probe = nullptr; // pinned: launch_seg_probe's answer
+    bool probe_seen = false;     // a block of this handle has been asked (h_probe[0] is its answer, or a later block's)
     uint64_t n_seg_launches = 0, n_seg_probes = 0;
     uint64_t max_waves = 0;
     uint64_t max_range = 0; // test knob: cap on positions per range
@@ -967,11 +968,21 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
     // worth it from a few milliseconds of sketching on).  The stride only decides how fast, never what comes out.
     s->blk_seg = 0;
     s->gran = TILE_POS;
+    bool probe_behind = false;
     {
         static const bool seg_off = getenv("FH_NO_SEG") != nullptr; // A/B knob
+        // A block is asked for its stride BEHIND its own launches, without a wait (the answer lands in pinned memory): what
+        // the last block this handle asked said is what the next one goes by -- the blocks of one input, or the passes over one
+        // buffer, share their read length, and a stale or wrong stride costs speed, never the result.  Only a handle that has
+        // not asked yet waits for the answer (one wavefront and a round trip, ~0.1-0.3 ms), and only for a block large enough
+        // not to notice.
         static const uint64_t probe_min = [] {
-            const char *e = getenv("FH_SEG_PROBE_MIN"); // test knob
-            return e ? strtoull(e, nullptr, 10) : (64ull << 20);
+            const char *e = getenv("FH_SEG_PROBE_MIN"); // test knob: blocks from this size on are asked (behind their launches)
+            return e ? strtoull(e, nullptr, 10) : (16ull << 20);
+        }();
+        static const uint64_t probe_wait_min = [] {
+            const char *e = getenv("FH_SEG_PROBE_WAIT_MIN"); // test knob: ... and waited for, if the handle has no answer yet
+            return e ? strtoull(e, nullptr, 10) : (256ull << 20);
         }();
         static const uint32_t seg_env = [] {
             const char *e = getenv("FH_SEG_STRIDE"); // test knob: every block through the segment kernel with this stride
@@ -980,12 +991,21 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
         uint32_t S = seg_env ? seg_env : s->seg_hint;
         if (!seg_off && S != 1u && s->p.k <= 32 && s->p.seed == 0 && !s->p.hash_mask) {
             if (S == 0 && len >= probe_min) {
-                if (!s->h_probe) HIP_TRY(host_malloc(&s->h_probe, 64));
-                if (int rc = flush_epilogue(s)) return rc;
-                HIP_TRY(launch_seg_probe(d_seq, len, s->h_probe, s->stream));
-                HIP_TRY(hipStreamSynchronize(s->stream));
-                S = s->h_probe[0];
-                s->n_seg_probes++;
+                if (!s->h_probe) {
+                    HIP_TRY(host_malloc(&s->h_probe, 64));
+                    s->h_probe[0] = 0;
+                }
+                if (s->probe_seen) {
+                    S = s->h_probe[0];
+                } else if (len >= probe_wait_min) {
+                    if (int rc = flush_epilogue(s)) return rc;
+                    HIP_TRY(launch_seg_probe(d_seq, len, s->h_probe, s->stream));
+                    HIP_TRY(hipStreamSynchronize(s->stream));
+                    S = s->h_probe[0];
+                    s->n_seg_probes++;
+                    s->probe_seen = true;
+                }
+                probe_behind = true;
             }
             if (S >= SEG_MIN_STRIDE && S <= SEG_MAX_STRIDE && S > s->p.k && n_pos >= 64ull * S) {
                 s->blk_seg = S;
@@ -993,6 +1013,19 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
             }
         }
     }
+    struct ProbeBehind { // (on every way out of this function that has launched the block's work)
+        fh_sketcher *s;
+        const uint8_t *seq;
+        uint64_t len;
+        bool on;
+        ~ProbeBehind() {
+            if (!on || !s->h_probe) return;
+            if (launch_seg_probe(seq, len, s->h_probe, s->stream) == hipSuccess) {
+                s->probe_seen = true;
+                s->n_seg_probes++;
+            }
+        }
+    } probe_guard{s, d_seq, len, probe_behind};
     uint64_t pos = 0;
     uint64_t lo_end = 0; // a failed speculation re-reads [0, lo_end) for the hashes above its guess only
     bool sampled = false;
@@ -1465,6 +1498,7 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
                 s->n_fast_finish = s->n_spec_deferred = s->n_spec_recovered = 0;
                 s->n_seg_launches = s->n_seg_probes = 0;
                 s->seg_hint = 0;
+                s->probe_seen = false; // (the previous owner's reads say nothing about the new one's)
                 {
                     const bool fast = !s->big_mode && getenv("FH_NO_FAST") == nullptr;
                     const bool hist = fast && s->p.size > 0 && getenv("FH_NO_HIST") == nullptr;
@@ -3308,6 +3342,18 @@ int fh_kernel_time(fh_sketcher *s, double *total_ms, uint64_t *launches, uint64_
     if (total_ms) *total_ms = s->prof_ms;
     if (launches) *launches = s->prof_launches;
     if (positions) *positions = s->prof_positions;
+    return FH_OK;
+}
+
+int fh_debug_add_counts(fh_sketcher *s, uint64_t add_count, uint64_t add_extra) {
+    if (!s) return fail(FH_ERR_INVALID, "null handle");
+    if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
+    if (int rc = proc_flush(s)) return rc;
+    if (int rc = set_device(s)) return rc;
+    if (int rc = drain(s)) return rc; // (everything pushed so far is in the table, its new entries on the live list)
+    if (int rc = flush_epilogue(s)) return rc;
+    if (!s->fast) HIP_TRY(launch_live_flatten(s->ctl, s->stream));
+    HIP_TRY(launch_debug_add_counts(s->table, s->live, s->ctl, add_count, add_extra, s->stream));
     return FH_OK;
 }
 

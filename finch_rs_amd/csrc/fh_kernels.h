@@ -196,6 +196,7 @@ hipError_t launch_fill_table(Entry *table, uint64_t cap, hipStream_t st);
 hipError_t launch_init_ctl(Ctl *ctl, uint64_t tau0, hipStream_t st, bool keep_text_bases = false, uint64_t sel_size = 0,
                            uint64_t tau_floor = 0, bool hist_on = false);
 hipError_t launch_set_tau(Ctl *ctl, uint64_t tau, hipStream_t st);
+hipError_t launch_debug_add_counts(Entry *table, const uint32_t *live, const Ctl *ctl, uint64_t add_count, uint64_t add_extra, hipStream_t st);
 hipError_t launch_set_table(Ctl *ctl, Entry *table, uint32_t *live, CollRec *clog, uint32_t cap, uint32_t live_cap,
                             uint32_t clog_cap, uint32_t *shard_cnt, uint32_t *shard_buf, uint32_t shard_cap, uint64_t *kmer_hi,
                             hipStream_t st);

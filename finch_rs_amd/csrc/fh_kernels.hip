@@ -899,6 +899,21 @@ __global__ void k_set_tau(Ctl *ctl, u64 tau) {
     if (threadIdx.x == 0 && blockIdx.x == 0) ctl->tau = tau;
 }
 
+// test hook (fh_debug_add_counts): every live entry's two counters moved up, so that a test reaches the saturation of the
+// reported u32 counts (mash.rs:45-50) without 2^32 occurrences
+__global__ void k_debug_add_counts(Entry *table, const u32 *live, const Ctl *ctl, u64 add_count, u64 add_extra) {
+    const u32 n = ctl->n_live;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        Entry &e = table[live[i]];
+        e.count += add_count;
+        e.extra += add_extra;
+    }
+}
+hipError_t launch_debug_add_counts(Entry *table, const u32 *live, const Ctl *ctl, u64 add_count, u64 add_extra, hipStream_t st) {
+    hipLaunchKernelGGL(k_debug_add_counts, dim3(256), dim3(256), 0, st, table, live, ctl, add_count, add_extra);
+    return hipGetLastError();
+}
+
 // the threshold as a kernel argument: no host buffer to keep alive, no synchronisation
 hipError_t launch_set_tau(Ctl *ctl, u64 tau, hipStream_t st) {
     hipLaunchKernelGGL(k_set_tau, dim3(1), dim3(64), 0, st, ctl, tau);

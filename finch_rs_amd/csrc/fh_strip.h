@@ -46,13 +46,22 @@ inline size_t strip_scalar(uint8_t *dst, const uint8_t *src, size_t n) {
 // are still to be loaded); closer than that the buffers must not overlap.
 __attribute__((target("avx2"))) inline size_t strip_avx2(uint8_t *dst, const uint8_t *src, size_t n) {
     const __m256i sp = _mm256_set1_epi8(' '), tb = _mm256_set1_epi8('\t'), cr = _mm256_set1_epi8('\r'), nl = _mm256_set1_epi8('\n');
+    // (the four blanks are all below 0x21: ONE signed compare says "no blank here" for a vector of sequence letters -- seven
+    // instructions fewer per vector than the four equalities, which only a vector that has such a byte, or a byte >= 0x80, goes
+    // through.  The per-record copy of fh_process is bound by instructions as much as by memory: 150-base records, one call each.)
+    const __m256i lim = _mm256_set1_epi8(0x21);
     size_t i = 0, m = 0;
     while (i + 32 <= n) {
         const __m256i v = _mm256_loadu_si256((const __m256i *)(src + i));
+        _mm256_storeu_si256((__m256i *)(dst + m), v);
+        if (__builtin_expect(_mm256_movemask_epi8(_mm256_cmpgt_epi8(lim, v)) == 0, 1)) {
+            m += 32;
+            i += 32;
+            continue;
+        }
         const __m256i b = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, sp), _mm256_cmpeq_epi8(v, tb)),
                                           _mm256_or_si256(_mm256_cmpeq_epi8(v, cr), _mm256_cmpeq_epi8(v, nl)));
         uint32_t mask = (uint32_t)_mm256_movemask_epi8(b);
-        _mm256_storeu_si256((__m256i *)(dst + m), v);
         if (mask == 0) {
             m += 32;
             i += 32;
@@ -71,9 +80,13 @@ __attribute__((target("avx2"))) inline size_t strip_avx2(uint8_t *dst, const uin
     // tail, and the byte loop it replaces took as long as the vectors in front of it
     if (n >= 32 && m >= 32 - (n - i)) {
         const __m256i v = _mm256_loadu_si256((const __m256i *)(src + n - 32));
-        const __m256i b = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, sp), _mm256_cmpeq_epi8(v, tb)),
-                                          _mm256_or_si256(_mm256_cmpeq_epi8(v, cr), _mm256_cmpeq_epi8(v, nl)));
-        if (_mm256_movemask_epi8(b) == 0) {
+        bool clean = _mm256_movemask_epi8(_mm256_cmpgt_epi8(lim, v)) == 0;
+        if (!clean) {
+            const __m256i b = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, sp), _mm256_cmpeq_epi8(v, tb)),
+                                              _mm256_or_si256(_mm256_cmpeq_epi8(v, cr), _mm256_cmpeq_epi8(v, nl)));
+            clean = _mm256_movemask_epi8(b) == 0;
+        }
+        if (clean) {
             const size_t r = n - i;
             _mm256_storeu_si256((__m256i *)(dst + m - (32 - r)), v);
             return m + r;

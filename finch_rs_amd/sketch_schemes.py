@@ -204,6 +204,10 @@ class HipSketcher:
                                       es.ctypes.data_as(C.c_void_p), km.ctypes.data_as(C.c_void_p),
                                       ps.ctypes.data_as(C.c_void_p), total_kmers))
 
+    def debug_add_counts(self, add_count: int, add_extra: int) -> None:
+        """test hook: move the two counters of every hash held so far up (include/finch_hip.h, fh_debug_add_counts)"""
+        check(self._L.fh_debug_add_counts(self._h, add_count, add_extra))
+
     def debug_counters(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(self._L.fh_debug_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))

@@ -289,6 +289,10 @@ int fh_kernel_time(fh_sketcher *s, double *total_ms, uint64_t *launches, uint64_
 
 /* diagnostics: sketch-kernel launches, relaunches after a capacity stop, device-wide selections */
 int fh_debug_counters(fh_sketcher *s, uint64_t *launches, uint64_t *relaunches, uint64_t *big_prunes);
+/* test hook: add_count / add_extra are added to the forward-strand / reverse-strand counters of every hash the sketcher holds
+ * at this moment (everything pushed so far is sketched first), so that a test can drive the reported u32 counts into their
+ * saturation (mash.rs:45-50: count.0 / count.1 are saturating adds) without 2^32 occurrences of a k-mer */
+int fh_debug_add_counts(fh_sketcher *s, uint64_t add_count, uint64_t add_extra);
 
 /* diagnostics: blocks sketched with a speculative threshold, and how many of them needed the second pass */
 int fh_debug_speculation(fh_sketcher *s, uint64_t *first_pass, uint64_t *second_pass);

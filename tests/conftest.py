@@ -15,3 +15,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """which BASELINE configurations ran at their full size (tests/test_gpu_full_size.py): a driver's tail shows it without -rs"""
+    mod = sys.modules.get("test_gpu_full_size")
+    if mod is None:
+        return
+    ran = getattr(mod, "FULL_RAN", [])
+    terminalreporter.write_line("BASELINE configurations sketched at their FULL size and held against the oracle: %s" %
+                                (", ".join(ran) if ran else "none (the _scaled twins ran; FH_REQUIRE_FULL=1 makes that a failure)"))

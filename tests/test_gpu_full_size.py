@@ -32,9 +32,20 @@ def _cores():
     return len(os.sched_getaffinity(0))
 
 
+FULL_RAN = []  # which BASELINE configurations ran at their full size in this session (conftest.py prints it)
+
+
+def _cannot_run_full(why):
+    """a box too small for a full-size check: skip with the reason -- unless FH_REQUIRE_FULL=1 says that the full sizes are the
+    point of the run (tools/gpu_evidence.sh suite), where a silent fall-back to the _scaled twin must be a FAILURE"""
+    if os.environ.get("FH_REQUIRE_FULL"):
+        pytest.fail("FH_REQUIRE_FULL=1: " + why)
+    pytest.skip(why)
+
+
 def _need_cores_for_full():
     if _cores() < FULL_MIN_CORES and not os.environ.get("FH_FORCE_FULL"):
-        pytest.skip("full BASELINE size needs >= %d cores for the oracle side, %d granted (FH_FORCE_FULL=1 to run anyway); the "
+        _cannot_run_full("full BASELINE size needs >= %d cores for the oracle side, %d granted (FH_FORCE_FULL=1 to run anyway); the "
                     "_scaled twin of this test ran" % (FULL_MIN_CORES, _cores()))
 
 
@@ -67,6 +78,7 @@ def test_c2_10gbase_stream_bit_exact_vs_sharded_oracle_full():
     """BASELINE.json configs[1] at its size: 10 Gbase"""
     _need_cores_for_full()
     _c2_stream(10.0)
+    FULL_RAN.append("configs[1] (10 Gbase)")
 
 
 def test_c2_stream_bit_exact_vs_sharded_oracle_scaled():
@@ -120,6 +132,7 @@ def test_c3_10gbase_oversketch_and_filtering_vs_sharded_oracle_full():
     """BASELINE.json configs[2] at its size: 10 Gbase, k=31, 2 M hashes, filters"""
     _need_cores_for_full()
     _c3_oversketch_and_filtering(10.0)
+    FULL_RAN.append("configs[2] (10 Gbase, k=31, 2 M hashes, filters)")
 
 
 def test_c3_oversketch_and_filtering_vs_sharded_oracle_scaled():
@@ -181,6 +194,7 @@ def test_c4_50gbase_sharded_read_blocks_and_host_merge_full():
     """BASELINE.json configs[3] at its size: 50 Gbase (and the result must also carry the committed golden fingerprint)"""
     _need_cores_for_full()
     _c4_sharded_read_blocks_and_host_merge(50.0)
+    FULL_RAN.append("configs[3] (50 Gbase, read blocks + merge)")
 
 
 def test_c4_sharded_read_blocks_and_host_merge_scaled():
@@ -273,8 +287,9 @@ def test_c5_batch_of_10k_fastas_through_sketch_files_full():
     base, free = _c5_room()
     need = 3.95e6 * 1.015 * 10000 / 0.8  # mean of the log-uniform lengths + newlines, with headroom
     if free < need and not os.environ.get("FH_FORCE_FULL"):
-        pytest.skip("full BASELINE size needs %.0f GB under %s, %.0f GB free; the _scaled twin of this test ran" % (need / 1e9, base, free / 1e9))
+        _cannot_run_full("full BASELINE size needs %.0f GB under %s, %.0f GB free; the _scaled twin of this test ran" % (need / 1e9, base, free / 1e9))
     _c5_batch(10000, 1.0, base)
+    FULL_RAN.append("configs[4] (10 000 FASTA files)")
 
 
 def test_c5_batch_of_fastas_through_sketch_files_scaled():

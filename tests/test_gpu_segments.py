@@ -136,10 +136,12 @@ def test_blocks_pushed_one_after_the_other(genome):
 
 
 def test_stride_found_by_the_probe():
-    """a block of whole records of one length is recognised without being told (FH_SEG_PROBE_MIN: from which size on a block
-    is asked; 64 MiB by default), N's inside the first record included; a ragged block is not"""
+    """a block of whole records of one length is recognised without being told, N's inside the first record included; a ragged
+    block is not.  A handle's first block waits for the answer if it is large (FH_SEG_PROBE_WAIT_MIN; 256 MiB by default);
+    otherwise it is asked behind its own launches and the NEXT block of the handle goes by the answer (FH_SEG_PROBE_MIN: from
+    which size on; 16 MiB by default)"""
     code = r'''
-import numpy as np, sys
+import numpy as np, os, sys
 sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
 import finch_rs_amd as F
 from finch_rs_amd import sketch_schemes as S
@@ -147,21 +149,29 @@ from oracle import oracle as O
 from test_gpu_parity import assert_same, random_reads
 g = S.synth_genome_host(200000, 3)
 rng = np.random.default_rng(9)
-def run(reads, want_stride):
+def run(sk, reads, want_stride):
     stream = np.frombuffer(b"".join(r + b"\0" for r in reads), dtype=np.uint8)
-    sk = F.SketchParams.mash(1000, 1000, True, 21, 0).create_sketcher()
     d = F.DeviceBuffer(stream.size + 256); d.upload(stream)
+    sk.reset(); l0 = sk.debug_segments()[0]
     sk.push_device(d.ptr, stream.size); sk.sync()
     launches, probes, stride = sk.debug_segments()
-    assert probes == 1 and stride == want_stride and (launches > 0) == (want_stride != 0), (launches, probes, stride)
+    assert probes >= 1 and stride == want_stride and (launches > l0) == (want_stride != 0), (launches, l0, probes, stride, want_stride)
     ora = O.OracleSketcher(O.MASH, 1000, 21, 0); ora.process_packed(stream, 0)
     assert_same(sk, ora)
 reads = random_reads(rng, 3000, 150, 150, p_n=0.002, genome=g)
 reads[0] = reads[0][:30] + b"NN" + reads[0][32:]
-run(reads, 151)
-run(random_reads(rng, 3000, 100, 150, genome=g), 0)
+ragged = random_reads(rng, 3000, 100, 150, genome=g)
+waits = os.environ["FH_SEG_PROBE_WAIT_MIN"] == "0"
+sk = F.SketchParams.mash(1000, 1000, True, 21, 0).create_sketcher()
+run(sk, reads, 151 if waits else 0)        # the handle's first block: by its own answer only if it waits for it
+run(sk, reads, 151)                        # the next one goes by what the first said
+run(sk, ragged, 151)                       # ... also when that is wrong for it (nothing but speed depends on it)
+run(sk, ragged, 0)                         # and the ragged block's own answer is "none"
+run(sk, random_reads(rng, 3000, 100, 100, genome=g), 0)
+run(sk, random_reads(rng, 3000, 100, 100, genome=g), 101)
 print("probe OK")
 ''' % (ROOT, ROOT)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FH_SEG_PROBE_MIN="0"), stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True, timeout=600)
-    assert r.returncode == 0 and "probe OK" in r.stdout, r.stdout[-3000:]
+    for wait_min in ("0", "1000000000000"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FH_SEG_PROBE_MIN="0", FH_SEG_PROBE_WAIT_MIN=wait_min),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0 and "probe OK" in r.stdout, (wait_min, r.stdout[-3000:])
