@@ -32,7 +32,7 @@ if "FH_OUT" in os.environ:  # an A/B build: its objects must not replace those l
     OUT = os.environ["FH_OUT"]
     OBJ = os.path.join(HERE, "obj", "ab_" + os.path.splitext(os.path.basename(OUT))[0])
 
-SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2_common.h", "fh_k2w.hip", "fh_k2.hip", "fh_k2s.hip", "fh_kernels.hip", "fh_big.hip", "fh_text.hip", "fh_bgzf.hip", "fh_api.hip", "fh_host.cpp",
+SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2_common.h", "fh_k2w.hip", "fh_k2.hip", "fh_k2s.hip", "fh_k2ws.hip", "fh_kernels.hip", "fh_big.hip", "fh_text.hip", "fh_bgzf.hip", "fh_api.hip", "fh_host.cpp",
            "fh_host_model.h", "fh_inflate.h", "fh_pargz.h", "fh_serial.cpp", os.path.join("..", "..", "include", "finch_host.h"),
            os.path.join("..", "..", "include", "finch_hip.h")]
 
@@ -68,6 +68,8 @@ def _build_locked(verbose):
         jobs.append([HIPCC] + FLAGS + K2_FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2.hip", "-o", os.path.join(OBJ, "fh_k2_%d.o" % part)])
     for part in range(NPARTS):  # the segment form of the sketch kernel
         jobs.append([HIPCC] + FLAGS + K2_FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2s.hip", "-o", os.path.join(OBJ, "fh_k2s_%d.o" % part)])
+    for part in range(NPARTS):  # ... and of the two-word kernel
+        jobs.append([HIPCC] + FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2ws.hip", "-o", os.path.join(OBJ, "fh_k2ws_%d.o" % part)])
     for part in range(NPARTS):  # K = 33..64
         jobs.append([HIPCC] + FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2w.hip", "-o", os.path.join(OBJ, "fh_k2w_%d.o" % part)])
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_kernels.hip", "-o", os.path.join(OBJ, "fh_kernels.o")])

@@ -181,7 +181,7 @@ struct fh_sketcher {
     // the block continues a record an earlier commit cut, whether a record is open, and mash.rs:72's total_bases
     uint8_t *proc_buf = nullptr;
     uint64_t proc_cap = 0, proc_fill = 0, proc_total_bases = 0;
-    bool proc_continuing = false, proc_in_record = false;
+    bool proc_continuing = false, proc_in_record = false, proc_in_cut = false;
     bool device_clean = false;
     uint64_t final_text_bases = 0; // Ctl::text_bases as of fh_finish (fh_text_bases stays valid after it)
     uint32_t *left_buf[2] = {nullptr, nullptr}; // leftover tile ranges of a stopped launch (pairs; two per wave: fh_k2s.hip)
@@ -355,7 +355,7 @@ int init_state(fh_sketcher *s, bool device_part = true) {
     s->epi_pending = 0; // (callers that could have one pending -- fh_reset -- have launched it: it rewinds the shard cursors)
     s->proc_buf = nullptr;
     s->proc_fill = s->proc_total_bases = 0;
-    s->proc_continuing = s->proc_in_record = false;
+    s->proc_continuing = s->proc_in_record = s->proc_in_cut = false;
     if (device_part) HIP_TRY(launch_init_ctl(s->ctl, initial_tau(s), s->stream, false, s->p.size, 0ull, s->hist));
     s->spec.pending = false;
     s->stream_off = 0;
@@ -531,7 +531,7 @@ int launch_pending(fh_sketcher *s) {
     a.left_in = s->left_buf[r.left_cur];
     a.left_out = s->left_buf[r.left_cur ^ 1];
     const uint64_t work_units = (uint64_t)r.n_units + r.n_left_in;
-    const uint64_t wpb = r.seg ? (uint64_t)K2S_WAVES_PER_BLOCK : (uint64_t)k2_waves_per_block((int)s->p.k);
+    const uint64_t wpb = r.seg ? (uint64_t)seg_waves_per_block((int)s->p.k) : (uint64_t)k2_waves_per_block((int)s->p.k);
     if (r.seg) s->n_seg_launches++;
     // (whole workgroups run: that many waves pull, insert and may leave a leftover entry; max_waves is a multiple of wpb)
     const uint64_t waves = (std::max<uint64_t>(1, std::min<uint64_t>(work_units, s->max_waves)) + wpb - 1) / wpb * wpb;
@@ -661,7 +661,8 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
     r.p_begin = pos;
     r.p_end = end;
     // the segment kernel where the block has a stride and the launch is the plain one (seed 0, no test mask, no lower threshold)
-    r.seg = (s->blk_seg && s->p.k <= 32 && s->p.seed == 0 && !s->p.hash_mask && !s->tau_lo && pos % (64ull * s->blk_seg) == 0) ? s->blk_seg : 0u;
+    // (K > 32: fh_k2ws.hip takes seed, mask and lower threshold at run time, as fh_k2w.hip does)
+    r.seg = (s->blk_seg && (s->p.k > 32 || (s->p.seed == 0 && !s->p.hash_mask && !s->tau_lo)) && pos % (64ull * s->blk_seg) == 0) ? s->blk_seg : 0u;
     const uint64_t tile = r.seg ? 64ull * r.seg : (uint64_t)TILE_POS;
     const uint64_t tiles = (end - pos + tile - 1) / tile;
     if (tiles >= (1ull << 31)) return fail(FH_ERR_INVALID, "block too large for one range");
@@ -699,7 +700,7 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
     static const bool no_static = getenv("FH_NO_STATIC_UNITS") != nullptr; // A/B knob
     {
         const uint64_t waves = std::max<uint64_t>(1, std::min<uint64_t>(r.n_units, s->max_waves));
-        const uint64_t wpb = r.seg ? (uint64_t)K2S_WAVES_PER_BLOCK : (uint64_t)k2_waves_per_block((int)s->p.k);
+        const uint64_t wpb = r.seg ? (uint64_t)seg_waves_per_block((int)s->p.k) : (uint64_t)k2_waves_per_block((int)s->p.k);
         const uint64_t grid = (waves + wpb - 1) / wpb * wpb;
         const uint64_t fu = std::min<uint64_t>((r.n_units + waves - 1) / waves, r.max_units);
         r.first_units = no_static ? 0u : (uint32_t)fu;
@@ -989,7 +990,7 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
             return e ? (uint32_t)atoi(e) : 0u;
         }();
         uint32_t S = seg_env ? seg_env : s->seg_hint;
-        if (!seg_off && S != 1u && s->p.k <= 32 && s->p.seed == 0 && !s->p.hash_mask) {
+        if (!seg_off && S != 1u && (s->p.k > 32 || (s->p.seed == 0 && !s->p.hash_mask))) {
             if (S == 0 && len >= probe_min) {
                 if (!s->h_probe) {
                     HIP_TRY(host_malloc(&s->h_probe, 64));
@@ -1594,7 +1595,8 @@ static fh_sketcher *new_handle(const fh_params *params, int device) {
         // whole workgroups: a launch is rounded up to them (16 waves for K = 25..32, fh_k2.hip), and everything sized by
         // max_waves -- table, shard lists, the leftover lists a stopped launch writes one entry per wave into -- has to hold
         // what really runs
-        const uint64_t wpb = (uint64_t)k2_waves_per_block((int)params->k);
+        // (... and the segment kernels' workgroups, which a block of equal reads brings in whatever K: sixteen waves for K <= 32)
+        const uint64_t wpb = std::max<uint64_t>((uint64_t)k2_waves_per_block((int)params->k), (uint64_t)seg_waves_per_block((int)params->k));
         s->max_waves = std::max<uint64_t>(wpb, s->max_waves / wpb * wpb);
         const char *mr = getenv("FH_MAX_RANGE"); // test knob: force many ranges per push
         s->max_range = mr ? strtoull(mr, nullptr, 10) : 0;
@@ -1791,18 +1793,45 @@ static int proc_commit(fh_sketcher *s) {
 // looks at the result, commits them first
 static int proc_flush(fh_sketcher *s) { return s->proc_buf ? proc_commit(s) : FH_OK; }
 
+// The common case of fh_process in one piece: a staging buffer is open and has room for the whole record, its breaker and the
+// copy's slack.  (A read is 100-250 bytes and the call is made once per read, on one thread: mash.rs:67-80 -- at 16 GB/s a
+// record has 9 ns, of which the calls, checks and the loop of the general path below were two.)
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static inline bool process_fast(fh_sketcher *s, const uint8_t *seq, uint64_t len) {
+    uint8_t *const b = s->proc_buf + s->proc_fill;
+    const size_t m = fh_strip::strip_avx2(b, seq, (size_t)len);
+    b[m] = 0; // the breaker: k-mers never span records
+    s->proc_fill += m + 1;
+    s->proc_total_bases += len; // mash.rs:72: the raw sequence() slice, blanks included
+    return true;
+}
+static const bool g_have_avx2 = __builtin_cpu_supports("avx2");
+#define FH_PROCESS_FAST(s, seq, len) \
+    (g_have_avx2 && (s)->proc_buf && !(s)->finished && (s)->proc_cap - (s)->proc_fill > (len) + 130 && process_fast((s), (seq), (len)))
+#else
+#define FH_PROCESS_FAST(s, seq, len) false
+#endif
+
 int fh_process(fh_sketcher *s, const uint8_t *seq, uint64_t len) {
     if (!s || (!seq && len)) return fail(FH_ERR_INVALID, "null argument");
+    if (FH_PROCESS_FAST(s, seq, len)) return FH_OK;
     if (s->finished) return fail(FH_ERR_STATE, "sketcher already finished; call fh_reset");
     s->proc_total_bases += len; // mash.rs:72: the raw sequence() slice, blanks included
     s->proc_in_record = true;
     while (len) {
         if (int rc = proc_acquire(s)) return rc;
         const uint64_t room = s->proc_cap - s->proc_fill;
-        if (room <= 64) { // (the strip stores whole vectors: 32 bytes of slack behind what it keeps)
-            if (int rc = proc_commit(s)) return rc;
+        // (the strip stores whole vectors: 32 bytes of slack behind what it keeps.)  A record that does not fit what is left
+        // of the block but would fit an empty one starts the next block: blocks then hold whole records -- no k-mer spans
+        // them, and a block of equal reads is one the stride probe recognises (fh_k2s.hip)
+        if (room <= 64 || (room < len + 130 && !s->proc_in_cut && s->proc_fill > 0 && len + 130 <= s->proc_cap)) {
+            s->proc_in_record = s->proc_in_cut; // (the block ends inside a record only if bytes of this one are in it)
+            const int rc = proc_commit(s);
+            s->proc_in_record = true;
+            if (rc) return rc;
             continue;
         }
+        s->proc_in_cut = true; // (bytes of this record are in the block: from here on it is cut where the block ends)
         const uint64_t take = std::min<uint64_t>(len, room - 64);
         s->proc_fill += fh_strip::strip(s->proc_buf + s->proc_fill, seq, take);
         seq += take;
@@ -1811,14 +1840,17 @@ int fh_process(fh_sketcher *s, const uint8_t *seq, uint64_t len) {
     if (int rc = proc_acquire(s)) return rc;
     s->proc_buf[s->proc_fill++] = 0; // the breaker: k-mers never span records
     s->proc_in_record = false;
+    s->proc_in_cut = false;
     if (s->proc_cap - s->proc_fill <= 64) return proc_commit(s);
     return FH_OK;
 }
 
 int fh_process_records(fh_sketcher *s, const uint8_t *base, const uint64_t *offsets, const uint64_t *lens, uint64_t n) {
     if (!s || (n && (!base || !offsets || !lens))) return fail(FH_ERR_INVALID, "null argument");
-    for (uint64_t i = 0; i < n; ++i)
+    for (uint64_t i = 0; i < n; ++i) {
+        if (FH_PROCESS_FAST(s, base + offsets[i], lens[i])) continue;
         if (int rc = fh_process(s, base + offsets[i], lens[i])) return rc;
+    }
     return FH_OK;
 }
 

@@ -27,6 +27,12 @@ hipError_t launch_k2s_part1(int k, const SketchArgs &a, hipStream_t st);
 hipError_t launch_k2s_part2(int k, const SketchArgs &a, hipStream_t st);
 hipError_t launch_k2s_part3(int k, const SketchArgs &a, hipStream_t st);
 constexpr int K2S_WAVES_PER_BLOCK = 16;
+// fh_k2ws.hip: the segment form for K = 33..64 (any seed / mask / lower threshold, like fh_k2w.hip), WAVES_PER_BLOCK waves per workgroup
+hipError_t launch_k2ws_part0(int k, const SketchArgs &a, hipStream_t st);
+hipError_t launch_k2ws_part1(int k, const SketchArgs &a, hipStream_t st);
+hipError_t launch_k2ws_part2(int k, const SketchArgs &a, hipStream_t st);
+hipError_t launch_k2ws_part3(int k, const SketchArgs &a, hipStream_t st);
+constexpr int seg_waves_per_block(int k) { return k > 32 ? WAVES_PER_BLOCK : K2S_WAVES_PER_BLOCK; }
 // Is the packed stream made of records of one length?  One wavefront looks at its first bytes and at records spread over
 // the block: out[0] = the records' stride (length + 1, within [SEG_MIN_STRIDE, SEG_MAX_STRIDE]) if every byte looked at where a
 // breaker should be is one, else 0.  (A tuning hint only: the segment kernel is exact for any stride.)  `out`: device or pinned host memory.

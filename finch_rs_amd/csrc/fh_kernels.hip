@@ -20,6 +20,15 @@ namespace fh {
 hipError_t launch_k2(int k, const SketchArgs &a, int blocks, hipStream_t st) {
     static_assert(FH_NPARTS == 4, "dispatcher below is written for 4 parts");
     if (k < 1 || k > FH_MAX_K) return hipErrorInvalidValue;
+    if (k > 32 && a.seg_stride) { // two-word k-mers, segment form (fh_k2ws.hip)
+        if (a.seg_stride < SEG_MIN_STRIDE || a.seg_stride > SEG_MAX_STRIDE) return hipErrorInvalidValue;
+        switch ((k - 33) / (32 / FH_NPARTS)) {
+        case 0: return launch_k2ws_part0(k, a, st);
+        case 1: return launch_k2ws_part1(k, a, st);
+        case 2: return launch_k2ws_part2(k, a, st);
+        default: return launch_k2ws_part3(k, a, st);
+        }
+    }
     if (k > 32) { // two-word k-mers (fh_k2w.hip)
         switch ((k - 33) / (32 / FH_NPARTS)) {
         case 0: return launch_k2w_part0(k, a, blocks, st);

@@ -62,6 +62,27 @@ def test_right_stride_every_kernel_shape(genome, k):
     assert_same(sk, oracle_of(O.MASH, 1000, k, stream), "k=%d" % k)
 
 
+@pytest.mark.parametrize("k", [33, 40, 47, 53, 64])
+def test_two_word_kmers(genome, k):
+    """fh_k2ws.hip: right stride, wrong stride, ragged records, a seed, a scaled sketch that stops waves inside tiles"""
+    rng = np.random.default_rng(5000 + k)
+    stream = packed(fixed_reads(rng, 3000 + k, 150, genome))
+    for stride in (151, 100, 168):
+        sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, k, 0), stream, stride)
+        assert sk.debug_segments()[0] > 0
+        assert_same(sk, oracle_of(O.MASH, 1000, k, stream), "k=%d stride=%d" % (k, stride))
+    ragged = packed(random_reads(rng, 3000, 0, 220, p_n=0.01, genome=genome))
+    sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, k, 0), ragged, 151)
+    assert_same(sk, oracle_of(O.MASH, 1000, k, ragged), "ragged k=%d" % k)
+    sk, _ = sketch_on_device(F.SketchParams.mash(500, 500, True, k, 42), stream, 151)
+    ora = O.OracleSketcher(O.MASH, 500, k, 42)
+    ora.process_packed(stream, 0)
+    assert sk.debug_segments()[0] > 0
+    assert_same(sk, ora, "seed 42 k=%d" % k)
+    sk, _ = sketch_on_device(F.SketchParams.scaled(1000, k, 0.5, 0), stream, 151)
+    assert_same(sk, oracle_of(O.SCALED, 1000, k, stream, 0.5), "scaled k=%d" % k)
+
+
 @pytest.mark.parametrize("stride", [40, 97, 100, 150, 152, 167, 168])
 @pytest.mark.parametrize("k", [21, 31])
 def test_wrong_stride_changes_nothing(genome, k, stride):
