@@ -113,7 +113,9 @@ def test_single_gpu_default_is_configs3_and_checks_itself():
     out = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], 1)
     assert "BASELINE configs[3]" in out["config"]["workload"] and out["n_gpus"] == 1 and out["scaling"] == "strong"
     assert out["sketch_check"]["matches_golden"] is True
-    assert out["roofline"]["frac"] > 0 and out["roofline"]["kernel"] == "k2_sketch<21>"
+    # (reads of one length: the segment form of the kernel, fh_k2s.hip -- found by the block's own probe)
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["kernel"].startswith("k2_sketch_seg<21>")
+    assert out["per_rank"] == [{"rank": 0, "reads": 333333334, "kernel_ms_per_pass": out["roofline"]["kernel_ms_per_pass"]}]
 
 
 def test_c5_workload_two_handles_one_call():
@@ -123,3 +125,43 @@ def test_c5_workload_two_handles_one_call():
     assert out["config"]["files"] == 300 and out["n_gpus"] == 2
     assert out["sketch_check"]["sample_files"] == 256 and out["sketch_check"]["matches_golden"] is True
     assert out["value"] > 0 and out["config"]["files_per_s"] > 0
+    # the batch's line carries the kernel's roofline block and the all-cores CPU baseline (one file per task)
+    r, c = out["roofline"], out["cpu_baseline"]
+    assert r["launches"] >= 300 and r["achieved"] > 0 and 0 < r["kernel_share_of_call"] <= 1.0
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "one file per task" in c["sample"]
+
+
+def test_multi_rank_line_names_every_ranks_kernel_time():
+    out = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--gbases", "0.8"], 4, launcher=False)
+    assert [p["rank"] for p in out["per_rank"]] == [0, 1, 2, 3] and all(p["kernel_ms_per_pass"] > 0 for p in out["per_rank"])
+    assert sum(p["reads"] for p in out["per_rank"]) == out["config"]["reads_total"]
+    out = _bench(["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--gbases", "0.8"], 2, launcher=True)
+    assert [p["rank"] for p in out["per_rank"]] == [0, 1] and all(p["kernel_ms_per_pass"] > 0 for p in out["per_rank"])
+
+
+def test_gather_on_rccl_with_device_tensors():
+    """`--backend nccl` puts the gather of the partial sketches on RCCL with device tensors (sharding.gather_and_merge(device=
+    "cuda")).  A box with one GPU cannot run two RCCL ranks; a world of one exercises the same code: group creation on the
+    device, the tensor's trip to the GPU, dist.gather, the merge of what came back."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+import finch_rs_amd as F
+from finch_rs_amd import sketch_schemes as S, sharding as SH
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+p = F.SketchParams.mash(1000, 1000, True, 21, 0)
+g = S.synth_genome_host(200000, 5)
+sk = p.create_sketcher()
+sk.push_block(S.synth_reads_host(g, 0, 5000, 150, 5, 10000, 500))
+kc, km, pos = sk.to_arrays(); tk = sk.finish()[1]
+mkc, mkm, mpos, mtk = SH.gather_and_merge(dist, p, (kc, km, pos, tk), 1000, device="cuda")
+assert np.array_equal(mkc, kc) and np.array_equal(mkm, km) and np.array_equal(mpos, pos) and mtk == tk
+t = torch.tensor([1.5], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t.item()) == 1.5
+dist.destroy_process_group()
+print("rccl gather OK")
+''' % (ROOT, str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl gather OK" in r.stdout, r.stdout[-3000:]
