@@ -117,7 +117,7 @@ constexpr int WAVE_BUDGET = 2048; // + at most TILE_POS-1 overshoot inside the t
 // sit at the end of every lane's segment and are skipped for the whole wave -- 21 of 151 positions at k = 21, 31 at k = 31;
 // the result does not depend on the stride (a round of positions is skipped only when no lane has a valid window in it).
 constexpr uint32_t SEG_MIN_STRIDE = 40, SEG_MAX_STRIDE = 168; // (what a wave's share of the 160 KB of LDS holds two strings of)
-constexpr uint32_t SEG_PART = 0x80000000u; // leftover pair (tile | SEG_PART, round): that tile from that round on (a wave stopped inside it)
+// (the segment kernels' leftover lists hold TRIPLES (t0, t1, c0): tiles [t0, t1), t0 from round c0 on -- a wave may stop inside a tile)
 
 struct SketchArgs {
     const uint8_t *seq;   // packed stream (device), 16-byte aligned
@@ -143,8 +143,8 @@ struct SketchArgs {
     uint32_t static_only;    // the first units cover the whole range: no wave pulls from the queue
     uint32_t seg_stride;     // != 0: the segment kernel, tiles of 64 x seg_stride positions (p_begin a multiple of 16)
     uint32_t max_units;      // segment kernel: units a pull takes at most (k2_sketch: MAX_UNITS; its tiles are a fifth the size)
-    const uint32_t *left_in; // pairs (t0, t1)
-    uint32_t *left_out;      // pairs (t0, t1), capacity >= number of waves
+    const uint32_t *left_in; // pairs (t0, t1); segment kernels: triples (t0, t1, c0)
+    uint32_t *left_out;      // the same, capacity >= number of waves
 };
 
 } // namespace fh

@@ -19,8 +19,8 @@
 //     every record's tail; with any other S, or on a stream that is not made of equal records, nothing is skipped that
 //     k2_sketch would have admitted: the sketch never depends on S (tests/test_gpu_segments.py).
 // One workgroup of sixteen waves per CU (a wave's strings are 6.7 KB); a wave that uses up its insert budget stops at the
-// end of a ROUND and hands the rest of its tile back as a (tile | SEG_PART, round) leftover pair, so the table's guard is
-// k2_sketch's: budget + at most 2047 new hashes per wave and launch.
+// end of a ROUND and hands the rest of its range back as ONE leftover entry (first tile, end of the range, round to resume the
+// first tile at), so the table's guard is k2_sketch's: budget + at most 2047 new hashes per wave and launch.
 //
 // Compiled FH_NPARTS times (-DFH_PART=i) like fh_k2.hip.
 #include <hip/hip_runtime.h>
@@ -127,15 +127,16 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
     u32 last_unit = 0;
     bool first_pull = true;
     for (;;) {
-        // work distribution as in k2_sketch: leftover ranges of a stopped launch first (here also single tiles from a round
-        // on), the wave's own first units, then guided pulls from the queue
-        u32 rt0 = 0xFFFFFFFFu, rt1 = 0u;
+        // work distribution as in k2_sketch: leftover ranges of a stopped launch first (here triples: the range's first tile may
+        // resume at a round), the wave's own first units, then guided pulls from the queue
+        u32 rt0 = 0xFFFFFFFFu, rt1 = 0u, c0 = 0u; // tiles [rt0, rt1), the first of them from round c0 on
         if ((tid & 63) == 0) {
             u32 li = 0xFFFFFFFFu;
             if (a.n_left_in) li = atomicAdd(&a.ctl->left_in_pos, 1u);
             if (li < a.n_left_in) {
-                rt0 = a.left_in[2u * li];
-                rt1 = a.left_in[2u * li + 1u];
+                rt0 = a.left_in[3u * li];
+                rt1 = a.left_in[3u * li + 1u];
+                c0 = a.left_in[3u * li + 2u];
             } else if (first_pull && a.first_units) {
                 const u32 c = gw * a.first_units;
                 if (c < a.n_units) {
@@ -162,12 +163,7 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
         rt0 = (u32)__builtin_amdgcn_readfirstlane((int)rt0);
         rt1 = (u32)__builtin_amdgcn_readfirstlane((int)rt1);
         if (rt0 == 0xFFFFFFFFu) break;
-        u32 c_first = 0u;
-        if (rt0 & SEG_PART) { // one tile, from round rt1 on
-            c_first = rt1;
-            rt0 &= ~SEG_PART;
-            rt1 = rt0 + 1u;
-        }
+        u32 c_first = (u32)__builtin_amdgcn_readfirstlane((int)c0);
 
         bool stop = false;
 #pragma unroll 1
@@ -320,17 +316,12 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
                         qn = 0;
                     }
                     if ((tid & 63) == 0) {
-                        const u32 n = (last_round ? 0u : 1u) + (t + 1u < rt1 ? 1u : 0u);
-                        u32 idx = atomicAdd(&a.ctl->n_left_out, n);
-                        if (!last_round) {
-                            a.left_out[2u * idx] = t | SEG_PART;
-                            a.left_out[2u * idx + 1u] = c + 1u;
-                            ++idx;
-                        }
-                        if (t + 1u < rt1) {
-                            a.left_out[2u * idx] = t + 1u;
-                            a.left_out[2u * idx + 1u] = rt1;
-                        }
+                        // ONE entry per stopping wave, as in k2_sketch (a relaunch has at least as many waves as the list has
+                        // entries, and every wave works its first entry off or hands its rest back: none is left unread)
+                        const u32 idx = atomicAdd(&a.ctl->n_left_out, 1u);
+                        a.left_out[3u * idx] = last_round ? t + 1u : t;
+                        a.left_out[3u * idx + 1u] = rt1;
+                        a.left_out[3u * idx + 2u] = last_round ? 0u : c + 1u;
                         atomicExch(&a.ctl->stopped, 1u);
                     }
                     stop = true;

@@ -87,13 +87,14 @@ __global__ __launch_bounds__(256, 2) void k2_sketch_ws(const SketchArgs a) {
     bool first_pull = true;
     for (;;) {
         // (work distribution exactly as in fh_k2s.hip)
-        u32 rt0 = 0xFFFFFFFFu, rt1 = 0u;
+        u32 rt0 = 0xFFFFFFFFu, rt1 = 0u, c0 = 0u; // tiles [rt0, rt1), the first of them from round c0 on
         if (lane == 0) {
             u32 li = 0xFFFFFFFFu;
             if (a.n_left_in) li = atomicAdd(&a.ctl->left_in_pos, 1u);
             if (li < a.n_left_in) {
-                rt0 = a.left_in[2u * li];
-                rt1 = a.left_in[2u * li + 1u];
+                rt0 = a.left_in[3u * li];
+                rt1 = a.left_in[3u * li + 1u];
+                c0 = a.left_in[3u * li + 2u];
             } else if (first_pull && a.first_units) {
                 const u32 c = gw * a.first_units;
                 if (c < a.n_units) {
@@ -120,12 +121,7 @@ __global__ __launch_bounds__(256, 2) void k2_sketch_ws(const SketchArgs a) {
         rt0 = (u32)__builtin_amdgcn_readfirstlane((int)rt0);
         rt1 = (u32)__builtin_amdgcn_readfirstlane((int)rt1);
         if (rt0 == 0xFFFFFFFFu) break;
-        u32 c_first = 0u;
-        if (rt0 & SEG_PART) { // one tile, from round rt1 on
-            c_first = rt1;
-            rt0 &= ~SEG_PART;
-            rt1 = rt0 + 1u;
-        }
+        u32 c_first = (u32)__builtin_amdgcn_readfirstlane((int)c0);
 
         bool stop = false;
 #pragma unroll 1
@@ -239,17 +235,12 @@ __global__ __launch_bounds__(256, 2) void k2_sketch_ws(const SketchArgs a) {
                         qn = 0;
                     }
                     if (lane == 0) {
-                        const u32 n = (last_round ? 0u : 1u) + (t + 1u < rt1 ? 1u : 0u);
-                        u32 idx = atomicAdd(&a.ctl->n_left_out, n);
-                        if (!last_round) {
-                            a.left_out[2u * idx] = t | SEG_PART;
-                            a.left_out[2u * idx + 1u] = c + 1u;
-                            ++idx;
-                        }
-                        if (t + 1u < rt1) {
-                            a.left_out[2u * idx] = t + 1u;
-                            a.left_out[2u * idx + 1u] = rt1;
-                        }
+                        // ONE entry per stopping wave, as in k2_sketch (a relaunch has at least as many waves as the list has
+                        // entries, and every wave works its first entry off or hands its rest back: none is left unread)
+                        const u32 idx = atomicAdd(&a.ctl->n_left_out, 1u);
+                        a.left_out[3u * idx] = last_round ? t + 1u : t;
+                        a.left_out[3u * idx + 1u] = rt1;
+                        a.left_out[3u * idx + 2u] = last_round ? 0u : c + 1u;
                         atomicExch(&a.ctl->stopped, 1u);
                     }
                     stop = true;

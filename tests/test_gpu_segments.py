@@ -26,8 +26,8 @@ def fixed_reads(rng, n, L, genome, p_n=0.004, p_lower=0.02):
     return random_reads(rng, n, L, L, p_n=p_n, p_lower=p_lower, genome=genome)
 
 
-def sketch_on_device(params, stream, stride, pushes=1):
-    sk = params.create_sketcher()
+def sketch_on_device(params, stream, stride, pushes=1, max_launch=0):
+    sk = params.create_sketcher(max_launch=max_launch)
     sk.set_record_stride(stride)
     bufs = []
     # (blocks are sketched independently, as the records of one: cut between records, at 16-byte aligned places)
@@ -128,14 +128,27 @@ def test_breaker_positions_holding_bases(genome):
         assert_same(sk, oracle_of(O.MASH, 1000, k, stream), "k=%d" % k)
 
 
-def test_loose_thresholds_stop_waves_inside_a_tile(genome):
-    """a scaled sketch that keeps half of all k-mers, and an oversketch the input cannot fill: every wave runs into its insert
-    budget, stops at the end of a round and hands the rest of its tile back (SEG_PART leftover pairs)"""
+@pytest.mark.parametrize("max_launch", [4096, 16384, 0])
+@pytest.mark.parametrize("k", [21, 31, 48])
+def test_loose_thresholds_stop_waves_inside_a_tile(genome, k, max_launch):
+    """a scaled sketch that keeps half of all k-mers, on few waves (max_launch: 16 or 4 of them): every wave runs into its insert
+    budget again and again, stops at the end of a round and hands the rest of its range back -- ONE leftover entry per wave
+    (first tile, end of range, round to resume at), so that a relaunch, which has as many waves as entries, leaves none unread.
+    (Round 5's first version wrote two entries per stopping wave; the second half of a list was never read: found by the fuzzer
+    under FH_SEG_STRIDE=151, seed 525252 case 340.)"""
+    rng = np.random.default_rng(6)
+    stream = packed(random_reads(rng, 150, 0, 5000, p_n=0.001, genome=genome))
+    for stride in (151, 100):
+        sk, _ = sketch_on_device(F.SketchParams.scaled(1000, k, 0.5, 0), stream, stride, max_launch=max_launch)
+        assert sk.debug_segments()[0] > 0
+        if max_launch:
+            assert sk.debug_counters()["relaunches"] > 0
+        assert_same(sk, oracle_of(O.SCALED, 1000, k, stream, 0.5), "scaled 0.5 k=%d stride=%d max_launch=%d" % (k, stride, max_launch))
+
+
+def test_oversketch_the_input_cannot_fill(genome):
     rng = np.random.default_rng(6)
     stream = packed(fixed_reads(rng, 6000, 150, genome, p_n=0.001))
-    sk, _ = sketch_on_device(F.SketchParams.scaled(1000, 21, 0.5, 0), stream, 151)
-    assert sk.debug_segments()[0] > 0
-    assert_same(sk, oracle_of(O.SCALED, 1000, 21, stream, 0.5), "scaled 0.5")
     sk, _ = sketch_on_device(F.SketchParams.mash(400_000, 400_000, True, 31, 0), stream, 151)
     assert_same(sk, oracle_of(O.MASH, 400_000, 31, stream), "oversketch")
 
