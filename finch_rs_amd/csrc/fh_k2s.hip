@@ -171,7 +171,10 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
             const u64 tile_pos0 = a.p_begin + (u64)t * tile_pos; // wave-uniform; a multiple of 16
             // ---- phase A: the tile's bytes (and 96 behind them) -> the three strings ----
             {
-                const u32 lane = (u32)tid & 63u;
+                // (the lane id is worked out anew for every tile: from a loop-invariant one the compiler derives a dozen
+                // addresses once per kernel, keeps them across the positions' code in registers that code needs -- 21-30 spilled at
+                // K = 29..32 -- and reloads them from scratch in front of every tile's loads)
+                const u32 lane = lane_now();
                 uint4 buf[K2S_MAX_LOADS];
 #pragma unroll
                 for (int m = 0; m < K2S_MAX_LOADS; ++m) {

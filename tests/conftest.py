@@ -20,7 +20,7 @@ def golden_dir():
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
     """which BASELINE configurations ran at their full size (tests/test_gpu_full_size.py): a driver's tail shows it without -rs"""
     mod = sys.modules.get("test_gpu_full_size")
-    if mod is None:
+    if mod is None or "not gpu" in (config.getoption("-m") or ""):
         return
     ran = getattr(mod, "FULL_RAN", [])
     terminalreporter.write_line("BASELINE configurations sketched at their FULL size and held against the oracle: %s" %
