@@ -428,7 +428,7 @@ def main():
     if pmc:
         # HBM bytes the counters saw per algorithmic byte, applied to this run's launch size
         roofline["traffic"] = int(pmc["hbm_bytes_per_position"] * roofline["alg_bytes_per_launch"])
-        roofline["pmc"] = {k: pmc.get(k) for k in ("valu_per_wave_iter", "cycles_per_wave_iter", "cycles_per_valu_inst", "valu_issue_model",
+        roofline["pmc"] = {k: pmc.get(k) for k in ("kernel", "valu_per_wave_iter", "cycles_per_wave_iter", "cycles_per_valu_inst", "valu_issue_model",
                                                    "lds_active_per_wave_iter", "lds_bank_conflict_per_wave_iter",
                                                    "hbm_bytes_per_position", "source")}
 
@@ -700,6 +700,7 @@ def measure_extras(F, S, dr, dg, n_reads, dev):
         s.close()
         r["ms_per_pass_with_host_filters"] = round(best * 1e3, 3)
         r["gbases_per_s_with_host_filters"] = round(bases / best / 1e9, 2)
+        r["pmc"] = _pmc_derived("c3_k31_n2000000")
         r["what"] = ("BASELINE configs[2]: 10 Gbase, k=31, final 10000 hashes from kmers_to_sketch=2000000; with_host_filters adds strand "
                      "filter 0.1 + err filter 0.31 + truncate on the host (filter_counts, process_post_filter)")
         return r
@@ -829,6 +830,7 @@ def measure_extras(F, S, dr, dg, n_reads, dev):
             out["bgzf_inflated_on_device"] = H.debug_device_inflate()[0] > 0
             gz_after = H.debug_device_gzip()
             out["gzip_inflated_on_device"] = gz_after[0] - gz_before[0] >= 3 and gz_after[1] == gz_before[1]
+            out["gzip_feed_timeouts"] = int(H._lib.load().fh_debug_gzip_feed_timeouts())  # (0, or the line above measured a fallback)
             return out
         finally:
             shutil.rmtree(d, ignore_errors=True)

@@ -75,6 +75,7 @@ SYMBOLS = {
     "fh_kernel_time": (C.c_int, [_P, C.POINTER(C.c_double), _U64P, _U64P]),
     "fh_debug_counters": (C.c_int, [_P, _U64P, _U64P, _U64P]),
     "fh_debug_add_counts": (C.c_int, [_P, C.c_uint64, C.c_uint64]),
+    "fh_debug_gzip_feed_timeouts": (C.c_uint64, []),
     "fh_debug_speculation": (C.c_int, [_P, _U64P, _U64P]),
     "fh_debug_fast_path": (C.c_int, [_P, _U64P, _U64P, _U64P]),
     "fh_measure_read_bandwidth": (C.c_int, [C.c_int, _P, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),

@@ -8,6 +8,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -257,7 +258,9 @@ struct fh_sketcher {
     uint64_t *gz_times = nullptr; // (FH_GZ_TIMES: per-chunk timestamps of the decoding launch)
     GzFeed *h_gz_feed = nullptr; // (pinned) how much of the batch being collected has arrived: the decoding launch polls it
     bool gz_feeding = false;     // such a launch is out
-    double gz_t0 = 0;            // (FH_TRACE)
+    double gz_t0 = 0;            // when the batch being collected saw its first push
+    bool gz_fed = false;         // the batch being collected is decoded by a launch that waits for its pieces
+    bool gz_no_feed = false;     // such a launch has timed out on this handle: batches are decoded once they are complete
     uint8_t *gz_group_win = nullptr;
     uint64_t gz_base = 0;     // where a push's bytes land in d_comp: what the previous push left undecoded sits in front of them
     uint64_t gz_tail_len = 0; // ... that many bytes, decoding resumes at bit gz_bit of the first
@@ -2314,6 +2317,7 @@ constexpr uint64_t GZ_SYM_PER_BYTE = 16;    // symbol slots per byte of a chunk:
                                             // and the one behind it -- only once a chunk has decoded all the way THROUGH a range behind it may it
                                             // take that range's slots over as well (k_gz_chunks)
 constexpr uint64_t GZ_CARRY_MAX = 4ull << 20; // undecoded bytes a batch may leave for the next
+static std::atomic<uint64_t> g_gz_feed_timeouts{0};
 static void free_gzip_buffers(fh_sketcher *s) {
     (void)hipFree(s->gz_sym);
     (void)hipFree(s->gz_group_map);
@@ -2391,6 +2395,8 @@ static int ensure_gzip_buffers(fh_sketcher *s) {
     return FH_OK;
 }
 
+uint64_t fh_debug_gzip_feed_timeouts(void) { return g_gz_feed_timeouts.load(); }
+
 int fh_gzip_batch_capacity(fh_sketcher *s, uint64_t *cap) {
     if (!s || !cap) return fail(FH_ERR_INVALID, "null argument");
     if (int rc = set_device(s)) return rc;
@@ -2441,7 +2447,9 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
     if (batch_start) {
         if (int rc = drain(s)) return rc; // the packed buffer of this slot may still feed a pending range
         HIP_TRY(hipMemsetAsync(s->gz_claims, 0, (size_t)s->gz_chunks_cap * sizeof(uint32_t), s->copy_stream));
-        if (flags & FH_GZ_MORE) {
+        s->gz_fed = false;
+        s->gz_t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        if ((flags & FH_GZ_MORE) && !s->gz_no_feed) {
             // the batch comes in pieces: ONE launch for all the chunks it may have, there from the first piece on; its
             // wavefronts wait for their bytes (GzFeed) -- launches of their own per piece would queue up behind each other
             HIP_TRY(hipStreamSynchronize(s->copy_stream)); // (the claims are clear, the carried bytes in place)
@@ -2453,6 +2461,7 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
             const uint32_t most = (uint32_t)std::min<uint64_t>(s->gz_chunks_cap, (s->gz_tail_len + gz_batch_capacity(s) + chunk_bytes - 1) / chunk_bytes);
             HIP_TRY(launch_gzip_chunks(B, f, 0, 0, most, false, s->stream));
             s->gz_feeding = true;
+            s->gz_fed = true;
         }
     }
     if (bytes) {
@@ -2473,7 +2482,6 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
         static const bool trace_pieces = getenv("FH_TRACE") != nullptr;
         if (trace_pieces) {
             const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-            if (batch_start) s->gz_t0 = now;
             fprintf(stderr, "[fh] gzip piece: %llu bytes of the batch on the device %.2f ms after its first push%s\n", (unsigned long long)n_bytes,
                     (now - s->gz_t0) * 1e3, more ? "" : " (complete)");
         }
@@ -2533,6 +2541,15 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
                                           "distance reaches before the start of the stream", "more text than the buffers hold",
                                           "stream longer or shorter than its bytes", "CRC-32 differs"};
         s->gz_open = false;
+        // A launch that waits for its pieces depends on the copies getting past it (they do: the copy engines; if a runtime ever
+        // ran them as kernels behind the waiting launch, every wavefront would give up after GZ_WAIT_TICKS, three seconds).  A
+        // batch that failed after that long is taken as that: this handle decodes its batches once they are complete from
+        // now on (the waiting launch never returns; the caller reads the file again through the host-side inflate as for any
+        // other refusal), and the process counts it (fh_debug_gzip_feed_timeouts).
+        if (s->gz_fed && std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - s->gz_t0 > 2.5) {
+            s->gz_no_feed = true;
+            g_gz_feed_timeouts++;
+        }
         return fail(FH_ERR_INVALID, "gzip: chunk %u of the batch: %s", st >> 8, (st & 255u) < 7u ? why[st & 255u] : "corrupt");
     }
     const uint64_t total = S[GZS_TOTAL];

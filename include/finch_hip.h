@@ -289,6 +289,10 @@ int fh_kernel_time(fh_sketcher *s, double *total_ms, uint64_t *launches, uint64_
 
 /* diagnostics: sketch-kernel launches, relaunches after a capacity stop, device-wide selections */
 int fh_debug_counters(fh_sketcher *s, uint64_t *launches, uint64_t *relaunches, uint64_t *big_prunes);
+/* gzip batches of this process whose piece-fed decoding launch gave up waiting for its bytes (fh_push_gzip_fastq with FH_GZ_MORE;
+ * the handle then decodes its batches only once they are complete).  0 on every system this was run on: a benchmark that sees
+ * anything else is measuring the fallback. */
+uint64_t fh_debug_gzip_feed_timeouts(void);
 /* test hook: add_count / add_extra are added to the forward-strand / reverse-strand counters of every hash the sketcher holds
  * at this moment (everything pushed so far is sketched first), so that a test can drive the reported u32 counts into their
  * saturation (mash.rs:45-50: count.0 / count.1 are saturating adds) without 2^32 occurrences of a k-mer */

@@ -24,6 +24,8 @@ for d in ["gpurun_out/%s_pmc_fetch"%tag,"gpurun_out/%s_pmc_write"%tag,"gpurun_ou
         acc=collections.defaultdict(float); n=collections.Counter()
         for r in csv.DictReader(open(f)):
             if "k2_sketch" in r["Kernel_Name"]:
+                out.setdefault("kernel_names", [])
+                if r["Kernel_Name"] not in out["kernel_names"]: out["kernel_names"].append(r["Kernel_Name"])
                 acc[r["Counter_Name"]]+=float(r["Counter_Value"]); n[r["Counter_Name"]]+=1
         for k in acc: out[k]={"sum":acc[k],"dispatches":n[k]}
     for f in glob.glob(d+"/**/*kernel_trace.csv", recursive=True):

@@ -7,6 +7,7 @@
 #   bench      python bench.py --steps 20 --warmup 5 as the driver runs it (with extras)
 #   bench8     --gpus 8 --share-gpu (one fh_sketch_device_blocks call per step, eight handles on the one GPU)
 #   c5         python bench.py --workload c5 (10 000 files)
+#   proxy      each rank's share of configs[3] alone on the GPU, predicted 1/2/4/8 efficiency, N handles on the one GPU
 #   pmc:<name>:<key>[:bench args separated by ','] rocprofv3 stats + PMC sets of one bench command (tools/gpu_bench_full.sh)
 #              e.g. pmc:c4:c4_k21_n1000   pmc:c3:c3_k31_n2000000:--workload,c2,--k,31,--n,2000000
 #   ab:<ks>:<name=lib.so,...>[:n[:env]]   tools/ab_k.py over the named builds (default first = shipped library)
@@ -39,6 +40,8 @@ for st in "$@"; do
     pmc)
       bash tools/gpu_bench_full.sh ${T}_$a $b ${c//,/ } > $O/${T}_${a}_full.log 2>&1; tail -4 $O/${T}_${a}_full.log
       rm -rf $O/${T}_${a}_stats $O/${T}_${a}_pmc_fetch $O/${T}_${a}_pmc_write $O/${T}_${a}_pmc_sq ;;
+    proxy)
+      python tools/scaling_proxy.py ${a:-20} 2>&1 | tee $O/${T}_scaling_proxy.txt ;;
     ab)
       libs="default="; [ -n "$b" ] && libs="$b"
       python tools/ab_k.py --libs "$libs" --ks "$a" --n ${c:-1000} --env "${d//,/ }" 2>&1 | tee $O/${T}_ab${i}.txt ;;

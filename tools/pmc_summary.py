@@ -63,8 +63,10 @@ def main():
             spec = importlib.util.spec_from_file_location("fh_build", os.path.join(k2_regs.CSRC, "build.py"))
             B = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(B)
-            k2_regs.compile_one("fh_k2.hip", ["FH_PART=0", "FH_ONLY_K=%d" % K], list(B.K2_FLAGS), asm)
-            mix = k2_regs.hot_mix(asm, "k2_sketchILi%dELb0ELb1ELb0E" % K)
+            seg = any("k2_sketch_seg" in n for n in (d.get("kernel_names") or []))  # which form of the kernel the counters are of
+            out["kernel"] = ("k2_sketch_seg<%d>" if seg else "k2_sketch<%d>") % K
+            k2_regs.compile_one("fh_k2s.hip" if seg else "fh_k2.hip", ["FH_PART=0", "FH_ONLY_K=%d" % K], list(B.K2_FLAGS), asm)
+            mix = k2_regs.hot_mix(asm, ("k2_sketch_segILi%dE" if seg else "k2_sketchILi%dELb0ELb1ELb0E") % K)
             if mix:
                 out["valu_issue_model"] = {"hot_loop_valu_fast_per_position": mix["valu_fast"], "hot_loop_valu_slow_per_position": mix["valu_slow"],
                                            "hot_loop_lds_per_position": mix["lds"], "issue_cycles_per_wave_iter": mix["issue_cycles"],
