@@ -96,6 +96,9 @@ def pretty(name):
     m = re.match(r"_ZN2fh13k2_sketch_segILi(\d+)EEE", name)
     if m:
         return "k2_sketch_seg<%s>" % m.group(1)
+    m = re.match(r"_ZN2fh12k2_sketch_wsILi(\d+)EEE", name)
+    if m:
+        return "k2_sketch_ws<%s>" % m.group(1)
     m = re.match(r"_ZN2fh11k2_sketch_wILi(\d+)EEE", name)
     if m:
         return "k2_sketch_w<%s>" % m.group(1)
@@ -125,9 +128,9 @@ def main():
     if args.objects:
         import glob
         objs = sorted(glob.glob(os.path.join(CSRC, "obj", "fh_k2_*.o")) + glob.glob(os.path.join(CSRC, "obj", "fh_k2w_*.o")) +
-                      glob.glob(os.path.join(CSRC, "obj", "fh_k2s_*.o")))
-        if len(objs) != 3 * B.NPARTS:
-            sys.exit("expected %d sketch-kernel objects under csrc/obj, found %d: build the library first" % (3 * B.NPARTS, len(objs)))
+                      glob.glob(os.path.join(CSRC, "obj", "fh_k2s_*.o")) + glob.glob(os.path.join(CSRC, "obj", "fh_k2ws_*.o")))
+        if len(objs) != 4 * B.NPARTS:
+            sys.exit("expected %d sketch-kernel objects under csrc/obj, found %d: build the library first" % (4 * B.NPARTS, len(objs)))
         for o in objs:
             rows += unbundle_object(o)
     elif args.k is not None:
