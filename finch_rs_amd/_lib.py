@@ -38,6 +38,7 @@ SYMBOLS = {
     "fh_set_stream_offset": (C.c_int, [_P, C.c_uint64]),
     "fh_process": (C.c_int, [_P, _P, C.c_uint64]),
     "fh_process_records": (C.c_int, [_P, _P, _P, _P, C.c_uint64]),
+    "fh_process_records_in": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint64, _P]),
     "fh_total_bases": (C.c_int, [_P, _U64P]),
     "fh_push_block": (C.c_int, [_P, _P, C.c_uint64]),
     "fh_push_block_ex": (C.c_int, [_P, _P, C.c_uint64, C.c_uint32]),

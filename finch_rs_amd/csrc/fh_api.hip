@@ -1857,6 +1857,26 @@ int fh_process_records(fh_sketcher *s, const uint8_t *base, const uint64_t *offs
     return FH_OK;
 }
 
+int fh_process_records_in(fh_sketcher *s, const uint8_t *base, uint64_t base_len, const uint64_t *offsets, const uint64_t *lens,
+                          uint64_t n, uint64_t *bases) {
+    if (!s || (n && (!base || !offsets || !lens))) return fail(FH_ERR_INVALID, "null argument");
+    uint64_t sum = 0;
+    int rc = FH_OK;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t o = offsets[i], l = lens[i];
+        if (o > base_len || l > base_len - o) { // (no sum of the two: it wraps)
+            char msg[96];
+            snprintf(msg, sizeof msg, "record %llu lies outside the buffer", (unsigned long long)i);
+            rc = fail(FH_ERR_INVALID, msg);
+            break;
+        }
+        if (!FH_PROCESS_FAST(s, base + o, l) && (rc = fh_process(s, base + o, l))) break;
+        sum += l;
+    }
+    if (bases) *bases = sum;
+    return rc;
+}
+
 int fh_total_bases(fh_sketcher *s, uint64_t *total_bases) {
     if (!s || !total_bases) return fail(FH_ERR_INVALID, "null argument");
     *total_bases = s->proc_total_bases;

@@ -115,12 +115,16 @@ class HipSketcher:
         base = np.ascontiguousarray(base, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         lens = np.ascontiguousarray(lens, dtype=np.uint64)
-        # (offsets + lens wraps in uint64: an offset near 2^64 would pass a check on the sum)
-        if len(offsets) != len(lens) or (len(lens) and (int(offsets.max()) > base.size or
-                                                        bool((lens > np.uint64(base.size) - offsets).any()))):
+        if len(offsets) != len(lens):
             raise ValueError("records outside the buffer")
-        check(self._L.fh_process_records(self._h, base.ctypes.data, offsets.ctypes.data, lens.ctypes.data, len(lens)))
-        self.total_bases += int(lens.sum())
+        # (the bounds of every record are checked where the loop is: two compares per record, not three passes of numpy)
+        taken = C.c_uint64(0)
+        rc = self._L.fh_process_records_in(self._h, base.ctypes.data, base.size, offsets.ctypes.data, lens.ctypes.data, len(lens),
+                                           C.byref(taken))
+        self.total_bases += taken.value
+        if rc == _lib.FH_ERR_INVALID and b"outside the buffer" in (self._L.fh_last_error() or b""):
+            raise ValueError("records outside the buffer")
+        check(rc)
 
     def push_block(self, block) -> None:
         """several records at once: sequences separated/terminated by a breaker byte (0)"""

@@ -102,6 +102,10 @@ int fh_push_block(fh_sketcher *s, const uint8_t *bytes, uint64_t len);
  * (total_bases, mash.rs:72 -- the host counter of SURVEY B2, kept here so that the binding need not). */
 int fh_process(fh_sketcher *s, const uint8_t *seq, uint64_t len);
 int fh_process_records(fh_sketcher *s, const uint8_t *base, const uint64_t *offsets, const uint64_t *lens, uint64_t n);
+/* fh_process_records for records the caller has not checked: a record that does not lie inside base[0, base_len) ends the call
+ * with FH_ERR_INVALID (the records in front of it have been taken); *bases (may be NULL) = the lengths taken, summed. */
+int fh_process_records_in(fh_sketcher *s, const uint8_t *base, uint64_t base_len, const uint64_t *offsets, const uint64_t *lens,
+                          uint64_t n, uint64_t *bases);
 int fh_total_bases(fh_sketcher *s, uint64_t *total_bases);
 /* Same with flags.  FH_PUSH_CONTINUE: this block continues the record the previous push ended in (a
  * record longer than the caller's buffer, e.g. a chromosome): k-mers span the boundary of the two pushes. */

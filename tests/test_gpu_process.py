@@ -67,6 +67,31 @@ def test_records_in_one_call_and_scaled():
     sk.close()
 
 
+def test_a_record_outside_the_buffer_is_refused_where_the_loop_is():
+    """bounds are checked per record in the library (no sum of offset and length: it wraps); the records in front of the
+    offending one have been taken, and the sketcher goes on working"""
+    rng = np.random.default_rng(10)
+    recs = _records(rng, 300, 80, 260)
+    base = np.frombuffer(b"#".join(recs), dtype=np.uint8)
+    lens = np.array([len(r) for r in recs], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens[:-1] + 1)]).astype(np.uint64)
+    for bad_off, bad_len in ((base.size - 10, 11), (base.size + 1, 0), (2**64 - 5, 10), (5, 2**64 - 3)):
+        sk = F.SketchParams.default().create_sketcher()
+        o2, l2 = offs.copy(), lens.copy()
+        o2[200], l2[200] = bad_off, bad_len
+        with pytest.raises(ValueError):
+            sk.process_records(base, o2, l2)
+        assert sk.total_bases == int(lens[:200].sum())
+        sk.process_records(base, offs[200:], lens[200:])
+        ora = O.OracleSketcher(O.MASH, 1000, 21, 0)
+        for r in recs:
+            ora.process(r)
+        _same(sk, ora)
+        sk.close()
+    with pytest.raises(ValueError):
+        F.SketchParams.default().create_sketcher().process_records(base, offs, lens[:-1])
+
+
 def test_records_longer_than_the_staging_buffer(monkeypatch):
     """a 300 kb record through 64 KiB staging buffers: the library cuts it and continues (k-mers span the cuts)"""
     monkeypatch.setenv("FH_STAGE_BYTES", "65536")

@@ -19,7 +19,7 @@ for name in ("records", "blocks"):
     for _ in range(5):
         t0 = time.perf_counter(); s.reset()
         if name == "records":
-            s.process_records(reads, offs, lens)
+            s.process_records(reads, offs, lens); t_calls = time.perf_counter() - t0
         else:
             blk = (32 << 20) // REC * REC
             for o in range(0, reads.size, blk):
@@ -28,3 +28,6 @@ for name in ("records", "blocks"):
         best = min(best, time.perf_counter() - t0)
     print("%-8s %.4f s  %.2f GB/s of sequence  (%.2f ns per record)  xor %x  segments %s" %
           (name, best, ns * RL / best / 1e9, best / ns * 1e9, int(np.bitwise_xor.reduce(kc["hash"])), s.debug_segments()), flush=True)
+    if name == "records":
+        print("         (last repeat: the calls alone %.4f s, reset + to_vec + finish behind them %.4f s)" %
+              (t_calls, time.perf_counter() - t0 - t_calls), flush=True)
