@@ -1,0 +1,19 @@
+#!/bin/bash
+# The round's closing fuzz campaign on the GPU box: the kernel fuzzer and the parity suites with every block forced through the
+# segment kernels at four strides (any stride must give the oracle's sketch) and unforced, then the parameter / text / gzip fuzzers.
+#   gpurun --timeout 3600 -- 'bash tools/fuzz_campaign.sh'   -> gpurun_out/r05_fuzz_final.txt
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+O=gpurun_out/r05_fuzz_final.txt; : > $O
+for cfg in "40 616161 1200" "100 626262 1200" "151 636363 2000" "168 646464 1200" "0 656565 1500"; do
+  set -- $cfg
+  if [ "$1" != "0" ]; then export FH_SEG_STRIDE=$1; else unset FH_SEG_STRIDE; fi
+  echo "== FH_SEG_STRIDE=${FH_SEG_STRIDE:-unset} seed $2 cases $3" >> $O
+  # (tests/test_gpu_segments.py asserts which stride a block went by: only where none is forced)
+  SEGT=""; [ "$1" = "0" ] && SEGT=tests/test_gpu_segments.py
+  FH_FUZZ_CASES=$3 FH_FUZZ_SEED=$2 timeout 900 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_parity.py tests/test_gpu_fast_path.py tests/test_gpu_process.py $SEGT -x -q 2>&1 | tail -3 >> $O
+done
+unset FH_SEG_STRIDE
+echo "== fuzz_params" >> $O; timeout 600 python tools/fuzz_params.py 2>&1 | tail -3 >> $O
+echo "== fuzz_device_text" >> $O; timeout 600 python tools/fuzz_device_text.py 2>&1 | tail -3 >> $O
+echo "== fuzz_gzip" >> $O; timeout 600 python tools/fuzz_gzip.py 2>&1 | tail -3 >> $O
+cat $O
