@@ -419,11 +419,11 @@ double fill_rate(const fh_sketcher *s) { return admit_rate(s->last_tau) * std::m
 // per position, so its size is chosen from the threshold read back after the previous launch such that
 // the live set stays inside what the in-LDS prune can sort.  tau only ever decreases, so once a
 // maximum-size launch is safe it stays safe and launches go open-loop (no host feedback).
-// each shard serves ceil(waves / N_SHARDS) waves, each of which inserts at most WAVE_BUDGET + TILE_POS new
+// each shard serves ceil(waves / N_SHARDS) waves, each of which inserts at most WAVE_BUDGET + WAVE_OVERSHOOT new
 // hashes per launch, plus its share of the room below the soft limit
 uint32_t shard_cap_for(const fh_sketcher *s, uint64_t live_target) {
     const uint64_t waves_per_shard = (s->max_waves + N_SHARDS - 1) / N_SHARDS;
-    return (uint32_t)(waves_per_shard * (WAVE_BUDGET + TILE_POS) + live_target / N_SHARDS + 1024);
+    return (uint32_t)(waves_per_shard * (WAVE_BUDGET + WAVE_OVERSHOOT) + live_target / N_SHARDS + 1024);
 }
 
 int alloc_shards(fh_sketcher *s, uint64_t live_target) {
@@ -540,14 +540,14 @@ int launch_pending(fh_sketcher *s) {
     const uint64_t waves = (std::max<uint64_t>(1, std::min<uint64_t>(work_units, s->max_waves)) + wpb - 1) / wpb * wpb;
     a.n_waves = (uint32_t)waves;
     // per-wave insert budget: the table and the shard lists are sized for max_waves waves inserting
-    // WAVE_BUDGET + TILE_POS new hashes each, so a launch with fewer waves may let each of them insert
+    // WAVE_BUDGET + WAVE_OVERSHOOT new hashes each, so a launch with fewer waves may let each of them insert
     // proportionally more (warm-up ranges at a loose threshold would otherwise stop after one tile per wave
     // and be relaunched for the rest)
     {
-        const uint64_t per_wave = (uint64_t)WAVE_BUDGET + TILE_POS;
+        const uint64_t per_wave = (uint64_t)WAVE_BUDGET + WAVE_OVERSHOOT;
         const uint64_t wps_max = (s->max_waves + N_SHARDS - 1) / N_SHARDS, wps = (waves + N_SHARDS - 1) / N_SHARDS;
         const uint64_t b_table = s->max_waves * per_wave / waves, b_shard = wps_max * per_wave / wps;
-        a.wave_budget = (uint32_t)std::min<uint64_t>(std::min(b_table, b_shard) - TILE_POS, 1u << 30);
+        a.wave_budget = (uint32_t)std::min<uint64_t>(std::min(b_table, b_shard) - WAVE_OVERSHOOT, 1u << 30);
     }
     const int blocks = (int)((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
 
@@ -1220,7 +1220,7 @@ int big_prune(fh_sketcher *s, bool sorted) {
     // scaled sketches keep everything <= max_hash: the live set itself grows with the input
     if (2 * (uint64_t)s->last_live > s->live_target) {
         s->live_target = 2 * (uint64_t)s->last_live;
-        const uint64_t need = s->live_target + s->max_waves * (uint64_t)(WAVE_BUDGET + TILE_POS) + 4096;
+        const uint64_t need = s->live_target + s->max_waves * (uint64_t)(WAVE_BUDGET + WAVE_OVERSHOOT) + 4096;
         if (need > s->live_cap) {
             if (int rc = grow_table(s, need + need / 2)) return rc;
         } else if (shard_cap_for(s, s->live_target) > s->shard_cap) {
@@ -1588,7 +1588,7 @@ static fh_sketcher *new_handle(const fh_params *params, int device) {
     s->hist = s->fast && params->size > 0 && getenv("FH_NO_HIST") == nullptr;
     s->live_target = s->big_mode ? std::max<uint64_t>(4 * params->size, 1ull << 16) : (uint64_t)SMALL_MAX;
     // the table can never fill: waves stop pulling work at soft_limit (<= live_target) and each of the
-    // max_waves resident waves can insert at most one tile's worth (2048) after that
+    // max_waves resident waves can insert at most WAVE_OVERSHOOT (a tile's or a long round's positions) after that
     {
         static const uint64_t waves_per_cu = [] {
             const char *e = getenv("FH_WAVES_PER_CU"); // tuning knob
@@ -1604,7 +1604,7 @@ static fh_sketcher *new_handle(const fh_params *params, int device) {
         const char *mr = getenv("FH_MAX_RANGE"); // test knob: force many ranges per push
         s->max_range = mr ? strtoull(mr, nullptr, 10) : 0;
     }
-    const uint64_t live_cap = s->live_target + s->max_waves * (uint64_t)(WAVE_BUDGET + TILE_POS) + 4096;
+    const uint64_t live_cap = s->live_target + s->max_waves * (uint64_t)(WAVE_BUDGET + WAVE_OVERSHOOT) + 4096;
     const uint64_t cap = 2 * live_cap;
     if (cap >= (1ull << 32)) {
         fail(FH_ERR_INVALID, "max_launch too large");

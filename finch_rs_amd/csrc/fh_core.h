@@ -278,9 +278,13 @@ FH_HD u64 min_u62(u64 a, u64 b) {
 #endif
 }
 
-template <int K>
+// DOFF (fh_k2s.hip's long rounds): the digit-reversed view reaches DOFF bases further (base b at digit 63 + DOFF - b, the
+// view's fifth word in use), so that the forward window's bit field -- whose low PRE bits are the bases behind the window --
+// stays inside the string for every window the 64-base view holds, j <= 64 - K, when DOFF = PRE / 2.
+template <int K, int DOFF = 0>
 struct Windows {
     static constexpr int PRE = pre_shift(K), NB = 2 * K + PRE;
+    static_assert(DOFF == 0 || (2 * DOFF == PRE && K <= 22), "the long view is for the smallest shift");
     u32 nC[5], D[5];
 
     FH_HDM void init(u64 clo, u64 chi) {
@@ -314,12 +318,13 @@ struct Windows {
     // The two strings given as they are (fh_k2s.hip cuts them out of a tile's strings in LDS): nc = the lane's 64-base view
     // complemented and shifted left by PRE bits (bit i of nc = bit i - PRE of ~codes; 5 words), d = the view digit-reversed
     // (base b at digit 63 - b; 4 words).
+    // With DOFF the view has a fifth word d[4] (its low 2 DOFF bits are looked at).
     FH_HDM void init_words(const u32 *nc, const u32 *d) {
         for (int i = 0; i < 5; ++i) nC[i] = nc[i];
         for (int i = 0; i < 4; ++i) D[i] = d[i];
-        D[4] = 0;
+        D[4] = DOFF ? d[4] : 0;
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(FH_D_FOLDABLE)
-        for (int i = 0; i < 4; ++i) asm("" : "+v"(D[i]));
+        for (int i = 0; i < (DOFF ? 5 : 4); ++i) asm("" : "+v"(D[i]));
 #endif
     }
     // bits [off, off + NB) of the string W (off, K compile-time after unrolling)
@@ -336,7 +341,7 @@ struct Windows {
         }
         return ((u64)hi << 32) | lo;
     }
-    FH_HDM u64 fwd(int j) const { return field(D, 2 * (64 - K - j) - PRE); } // low PRE bits: scrap (later bases)
+    FH_HDM u64 fwd(int j) const { return field(D, 2 * (64 + DOFF - K - j) - PRE); } // low PRE bits: scrap (later bases)
     // A k-mer can equal its reverse complement only for even K.  There the reverse complement's scrap bits are cleared
     // (the forward word's are not), so fwd' < rc' exactly when fwd < rc and equal words compare as "not less": the tie
     // goes to rc, as it must.  For odd K the words differ above the scrap bits and the scrap cannot matter.
@@ -381,7 +386,7 @@ struct Windows {
 #if defined(__HIP_DEVICE_COMPILE__)
         for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(d[i]), "+v"(c[i]));
 #endif
-        const u64 f = field(d, 2 * (64 - K - j) - PRE);
+        const u64 f = field(d, 2 * (64 + DOFF - K - j) - PRE);
         u64 r = field(c, 2 * j);
         if (K % 2 == 0) r &= ~((1ULL << PRE) - 1ULL);
         return !(f < r);
@@ -405,7 +410,7 @@ struct Windows {
 // bit j of the result: the K-base window starting at base j lies entirely in good bases (g64 bit b = base
 // b is one of ACGT).  Log-doubling AND of shifted masks; runs once per lane per tile.
 template <int K>
-FH_HD u32 window_valid_mask(u64 g64) {
+FH_HD u64 window_valid_mask64(u64 g64) {
     u64 A[6]; // A[p][j] = AND of 2^p consecutive good bits starting at j
     A[0] = g64;
 #if defined(__HIPCC__)
@@ -423,7 +428,55 @@ FH_HD u32 window_valid_mask(u64 g64) {
             off += (1 << p);
         }
     }
-    return (u32)W;
+    return W; // (bits j > 64 - K are clear: their windows reach behind the 64 bases)
+}
+template <int K>
+FH_HD u32 window_valid_mask(u64 g64) { return (u32)window_valid_mask64<K>(g64); }
+
+// ---- the segment kernel's views (fh_k2s.hip) ----
+// A wave's tile of NCH 16-byte chunks lies in LDS as three strings: Fc = the complemented codes (chunk i at word 1 + i, word 0
+// and the words behind the string zero), Rv = the digit-reversed codes (chunk i as pairrev32 at word NCH - 1 - i: the base at
+// tile position p is digit 16 NCH - 1 - p), Gd = the good bits (chunk i at half-word i).  A lane's round looks at the 64
+// bases from tile position p0 on (p0 + 63 + DOFF < 16 NCH): nc / d are what Windows<K, DOFF>::init_words takes, seg_good_bits
+// what window_valid_mask64 takes.  Positions per round: as many windows as the view holds for K <= 22 (65 - K, at most 48),
+// 16 for longer k-mers (their register budget: fh_k2.hip).
+#ifndef FH_SEG_LONG
+#define FH_SEG_LONG 1 // 0: rounds of 32 for K <= 22 (round 5's first form)
+#endif
+constexpr bool seg_long(int K) { return FH_SEG_LONG && K <= 22; }
+constexpr int seg_round(int K) { return K >= 23 ? 16 : (seg_long(K) ? (65 - K < 48 ? 65 - K : 48) : 32); }
+constexpr int seg_doff(int K) { return seg_long(K) ? pre_shift(K) / 2 : 0; }
+
+template <int K>
+FH_HD void seg_cut_views(const u32 *Fc, const u32 *Rv, u32 NCH, u32 p0, u32 *nc, u32 *d) {
+    constexpr int PRE = pre_shift(K), DOFF = seg_doff(K), ND = DOFF ? 5 : 4;
+    const int gc = (int)(2u * p0) - PRE; // first bit of the complemented string's view, shifted left by PRE
+    const u32 ic = (u32)((gc >> 5) + 1), sc = (u32)gc & 31u;
+    u32 f[6];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int w = 0; w < 6; ++w) f[w] = Fc[ic + (u32)w];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int w = 0; w < 5; ++w) nc[w] = alignbit_b32(f[w + 1], f[w], sc);
+    const u32 gd = 2u * (16u * NCH - 64u - (u32)DOFF - p0); // first bit of the digit-reversed string's view (its base 63 + DOFF)
+    const u32 id = gd >> 5, sd = gd & 31u;
+    u32 r[ND + 1];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int w = 0; w < ND + 1; ++w) r[w] = Rv[id + (u32)w];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int w = 0; w < ND; ++w) d[w] = alignbit_b32(r[w + 1], r[w], sd);
+}
+FH_HD u64 seg_good_bits(const u32 *Gd, u32 p0) {
+    const u32 gi = p0 >> 5, gs = p0 & 31u;
+    const u32 g0 = Gd[gi], g1 = Gd[gi + 1u], g2 = Gd[gi + 2u];
+    return (u64)alignbit_b32(g1, g0, gs) | ((u64)alignbit_b32(g2, g1, gs) << 32);
 }
 
 // ---- lookup tables with murmur3's second stage folded in ----

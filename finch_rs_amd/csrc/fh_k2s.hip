@@ -38,8 +38,18 @@
 
 namespace fh {
 
+#ifndef FH_SEG_WHOLE_TILES
+#define FH_SEG_WHOLE_TILES 1 // 0: every chunk through the guarded load (A/B)
+#endif
 constexpr int K2S_WPB = 16;
-constexpr int k2s_round(int K) { return K >= 23 ? 16 : 32; } // (fh_k2.hip, k2_round: the register budget is the same loop's)
+// Positions per round.  K >= 23: 16, as k2_sketch (fh_k2.hip, k2_round: the register budget is the same loop's).  K <= 22: as many
+// as the lane's 64-base view holds windows, 65 - K (at most 48): a round's set-up -- validity mask, the wave's question, the two
+// views, bounds: ~60 instructions, and a window and its lookups that run ahead of the last position -- is paid three times per
+// 150-base read at k = 21 (44 + 44 + 42 windows) instead of five times (32 + 32 + 32 + 32 + 2).  FH_SEG_LONG=0: rounds of 32.
+// (fh_core.h: seg_round, seg_long, seg_doff and the cut of the views, shared with the host logic test)
+constexpr bool k2s_long(int K) { return seg_long(K); }
+constexpr int k2s_round(int K) { return seg_round(K); }
+static_assert(64 * 48 <= WAVE_OVERSHOOT, "a round's positions are what a wave may overshoot its insert budget by (fh_device.h)");
 // LDS of the workgroup: lookup tables, admit queues, then a block per wave
 constexpr u32 K2S_A1 = 0, K2S_A2 = 4096, K2S_B1 = 8192, K2S_B2 = 10240, K2S_P = 12288, K2S_Q = 20480;
 constexpr u32 K2S_TILE = K2S_Q + K2S_WPB * (u32)sizeof(AdmitQueueT<false>);
@@ -61,6 +71,18 @@ __device__ __forceinline__ u32 wave_or(u32 x) {
     return (u32)__builtin_amdgcn_readlane((int)x, 63);
 }
 
+// max over the wave (same walk)
+__device__ __forceinline__ u32 wave_max(u32 x) {
+    auto mx = [](u32 a, u32 b) { return a > b ? a : b; };
+    x = mx(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true));
+    x = mx(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true));
+    x = mx(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true));
+    x = mx(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true));
+    x = mx(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));
+    x = mx(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));
+    return (u32)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 __device__ __forceinline__ u32 lane_now() { // (recomputed where it is needed: a value kept across the position loop is a register the loop lacks)
     u32 l;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
@@ -70,6 +92,10 @@ __device__ __forceinline__ u32 lane_now() { // (recomputed where it is needed: a
 template <int K>
 __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArgs a) {
     constexpr int WPB = K2S_WPB, NTHR = 64 * WPB, R = k2s_round(K), PRE = pre_shift(K);
+    constexpr bool LONG = k2s_long(K);
+    constexpr int DOFF = seg_doff(K); // (fh_core.h, Windows: the forward string's view reaches this many bases further)
+    using Win = Windows<K, DOFF>;
+    using Mask = std::conditional_t<LONG, u64, u32>; // a round's valid windows
     __shared__ __attribute__((aligned(16))) unsigned char blob[K2S_BYTES];
     Rec4 *const sA1 = (Rec4 *)(blob + K2S_A1), *const sA2 = (Rec4 *)(blob + K2S_A2);
     Rec2 *const sB1 = (Rec2 *)(blob + K2S_B1), *const sB2 = (Rec2 *)(blob + K2S_B2), *const sP = (Rec2 *)(blob + K2S_P);
@@ -176,11 +202,24 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
                 // K = 29..32 -- and reloads them from scratch in front of every tile's loads)
                 const u32 lane = lane_now();
                 uint4 buf[K2S_MAX_LOADS];
+                // A tile all of whose chunks lie inside the buffer (every tile but a block's last) needs no guard: one scalar base, the
+                // lane's 32-bit byte offset, one add per chunk; the guarded form costs a dozen VALU instructions a chunk (64-bit
+                // address, two 64-bit compares, the zeroes).  Both forms fill the same registers, chunk by chunk.
+                u32 nload = (NCH + 63u) >> 6;
+                asm volatile("" : "+s"(nload)); // (asked per tile: eleven conditions hoisted out of the loop are eleven SGPR pairs the kernel lacks)
+                const bool whole = FH_SEG_WHOLE_TILES && tile_pos0 + 1024ull * (u64)nload <= a.len_total; // wave-uniform
+                const uint8_t *const tb = a.seq + tile_pos0;
+                const u32 voff = 16u * lane;
 #pragma unroll
                 for (int m = 0; m < K2S_MAX_LOADS; ++m) {
-                    const u32 i = lane + 64u * (u32)m;
-                    buf[m] = make_uint4(0u, 0u, 0u, 0u);
-                    if (i < NCH) buf[m] = load_chunk_guarded(a.seq, tile_pos0 + 16ull * i, a.len_total);
+                    buf[m] = make_uint4(0u, 0u, 0u, 0u); // (every buffer defined on every path: left undefined past nload, k = 21 spills 109 registers)
+                    if ((u32)m >= nload) continue;      // (chunks >= NCH: nobody looks at them)
+                    if (__builtin_expect(whole, 1)) buf[m] = *reinterpret_cast<const uint4 *>(tb + (u64)(voff + 1024u * (u32)m));
+                    else {
+                        const u32 i = lane + 64u * (u32)m;
+                        buf[m] = make_uint4(0u, 0u, 0u, 0u);
+                        if (i < NCH) buf[m] = load_chunk_guarded(a.seq, tile_pos0 + 16ull * i, a.len_total);
+                    }
                 }
                 // (the strings of the tile before are still being read by nobody: the rounds below are this wave's own)
 #pragma unroll
@@ -203,51 +242,42 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
 #pragma unroll 1
             for (u32 c = c_first; c < NR; ++c) {
                 const u32 rc0 = (u32)R * c; // the round's first segment offset (wave-uniform)
-                Windows<K> win;
-                u32 Wc;
+                Win win;
+                Mask Wc;
                 u32 nmax = S - rc0 < (u32)R ? S - rc0 : (u32)R; // positions of the segment this round covers
                 {
                     const u32 lane = lane_now();
                     const u32 p0 = S * lane + rc0; // the lane's view begins at this tile position
                     // which of its windows carry a k-mer: all K bases good, inside the segment, inside [p_begin, p_end)
-                    const u32 gi = p0 >> 5, gs = p0 & 31u;
-                    const u32 g0 = Gd[gi], g1 = Gd[gi + 1u], g2 = Gd[gi + 2u];
-                    const u64 g64 = (u64)alignbit_b32(g1, g0, gs) | ((u64)alignbit_b32(g2, g1, gs) << 32);
+                    const u64 g64 = seg_good_bits(Gd, p0);
                     const u64 lane_pos0 = tile_pos0 + p0;
-                    u32 limit = (a.p_end > lane_pos0) ? (u32)((a.p_end - lane_pos0) < 32 ? (a.p_end - lane_pos0) : 32) : 0u;
+                    u32 limit = (a.p_end > lane_pos0) ? (u32)((a.p_end - lane_pos0) < 64 ? (a.p_end - lane_pos0) : 64) : 0u;
                     limit = limit < nmax ? limit : nmax;
-                    Wc = window_valid_mask<K>(g64) & (limit >= 32u ? 0xFFFFFFFFu : ((1u << limit) - 1u));
+                    if constexpr (LONG) Wc = window_valid_mask64<K>(g64) & (limit >= 64u ? ~0ull : ((1ull << limit) - 1ull));
+                    else Wc = window_valid_mask<K>(g64) & (limit >= 32u ? 0xFFFFFFFFu : ((1u << limit) - 1u));
                     // a round whose windows reach the segment's last K bases may hold nothing, or nothing behind some position,
                     // in every lane at once (the records' breakers): ask the wave
                     // (asked in every round: seven instructions a round, and the compiler does not get to make two copies of
                     // the positions' code, one of them with a spilled register per position)
-                    {
+                    if constexpr (LONG) {
+                        const u32 top = wave_max(Wc ? 64u - (u32)__builtin_clzll(Wc) : 0u);
+                        if (top == 0u) continue;
+                        nmax = top;
+                    } else {
                         const u32 any = wave_or(Wc);
                         if (any == 0u) continue;
                         nmax = 32u - (u32)__builtin_clz(any);
                     }
-                    nvalid += (u32)__popc(Wc);
+                    nvalid += (u32)__popcll((u64)Wc);
                     // the lane's two strings for this round, cut out of the tile's (fh_core.h, Windows::init_words)
-                    const int gc = (int)(2u * p0) - PRE; // first bit of the complemented string's view, shifted left by PRE
-                    const u32 ic = (u32)((gc >> 5) + 1), sc = (u32)gc & 31u;
-                    u32 f[6], nc[5];
-#pragma unroll
-                    for (int w = 0; w < 6; ++w) f[w] = Fc[ic + (u32)w];
-#pragma unroll
-                    for (int w = 0; w < 5; ++w) nc[w] = alignbit_b32(f[w + 1], f[w], sc);
-                    const u32 gd = 2u * (16u * NCH - 64u - p0); // first bit of the digit-reversed string's view (base 63 of it)
-                    const u32 id = gd >> 5, sd = gd & 31u;
-                    u32 r[5], d[4];
-#pragma unroll
-                    for (int w = 0; w < 5; ++w) r[w] = Rv[id + (u32)w];
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) d[w] = alignbit_b32(r[w + 1], r[w], sd);
+                    u32 nc[5], d[5];
+                    seg_cut_views<K>(Fc, Rv, NCH, p0, nc, d);
                     win.init_words(nc, d);
                 }
 
                 // ---- the round's positions: k2_sketch's loop (fh_k2.hip), ending behind the last valid one ----
                 auto window = [&](int j, u64 &cm, bool &is_rc) {
-                    if constexpr (Windows<K>::MINF64) cm = win.canonical_word(j), is_rc = false;
+                    if constexpr (Win::MINF64) cm = win.canonical_word(j), is_rc = false;
                     else cm = win.canonical(j, is_rc);
                 };
                 u64 cm_cur;
@@ -288,7 +318,7 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
                                 queue->k[my] = cm;
                                 const u64 pos = tile_stream_pos + (u64)(lane_now() * S + rc0 + (u32)j);
                                 bool is_rc = rc_loop;
-                                if constexpr (Windows<K>::MINF64) is_rc = win.strand_of(j);
+                                if constexpr (Win::MINF64) is_rc = win.strand_of(j);
                                 queue->p[my] = pos | ((u64)(is_rc ? 1u : 0u) << 63);
                             }
                             qn += cnt;

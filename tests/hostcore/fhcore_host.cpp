@@ -14,7 +14,7 @@ using namespace fh;
 template <int K>
 static int run(const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hashes, uint8_t *valid, uint8_t *isrc,
                uint64_t *canon) {
-    std::vector<uint8_t> buf(((len + 31) / 32) * 32 + 64, 0);
+    std::vector<uint8_t> buf(((len + 31) / 32) * 32 + 96, 0);
     memcpy(buf.data(), seq, len);
     std::vector<u64> T1(256), T2(256), TP(64, 0);
     for (u32 q = 0; q < 256; ++q) {
@@ -60,6 +60,40 @@ static int run(const uint8_t *seq, uint64_t len, uint64_t seed, uint64_t *hashes
             if (h_fast != h_ref) return -2;
             if (seed == 0 && murmur_h1_fast<K, true>(cm, 0, LT) != h_ref) return -3;
             hashes[p] = h_fast;
+        }
+    }
+    // The segment kernel's form (fh_k2s.hip): the buffer as ONE tile's three strings, a round's view cut at EVERY position p0
+    // (a lane's p0 = stride * lane + round * seg_round(K) is any number), Windows<K, seg_doff(K)> and the 64-bit validity mask:
+    // every window of the round against what the walk above found at that position.
+    {
+        const u32 NCH = (u32)(buf.size() / 16);
+        std::vector<u32> Fc(NCH + 3, 0u), Rv(NCH + 2, 0u), Gd(NCH / 2 + 3, 0u);
+        for (u32 i = 0; i < NCH; ++i) {
+            u32 d[4], q, g;
+            memcpy(d, buf.data() + 16 * (size_t)i, 16);
+            classify_chunk(d[0], d[1], d[2], d[3], q, g);
+            Fc[1 + i] = ~q;
+            Rv[NCH - 1 - i] = pairrev32(q);
+            reinterpret_cast<unsigned short *>(Gd.data())[i] = (unsigned short)g;
+        }
+        constexpr int R = seg_round(K), DOFF = seg_doff(K);
+        static_assert(R + K - 1 <= 64, "a round's windows lie inside the 64-base view");
+        for (uint64_t p0 = 0; p0 + 64 + DOFF <= 16ull * NCH && p0 < len; ++p0) {
+            u32 nc[5], d[5];
+            seg_cut_views<K>(Fc.data(), Rv.data(), NCH, (u32)p0, nc, d);
+            Windows<K, DOFF> win;
+            win.init_words(nc, d);
+            const u64 W = window_valid_mask64<K>(seg_good_bits(Gd.data(), (u32)p0));
+            for (int j = 0; j < R; ++j) {
+                const uint64_t p = p0 + j;
+                if (p >= len) break;
+                if (((W >> j) & 1u) != valid[p]) return -5;
+                if (!valid[p]) continue;
+                bool rc;
+                const u64 cm = win.canonical(j, rc);
+                if ((cm >> pre_shift(K)) != canon[p] || (rc ? 1 : 0) != isrc[p]) return -6;
+                if (win.canonical_word(j) != cm || win.strand_of(j) != rc) return -7;
+            }
         }
     }
     return 0;
