@@ -69,29 +69,36 @@ FH_HD u32 perm_b32(u32 s0, u32 s1, u32 sel) {
 // (A 001, C 011, T 100, U 101, G 111), so they index two 8-entry byte tables held in registers (v_perm_b32): the
 // letter the byte has to be, and its 2-bit code (A 0, C 1, G 2, T/U 3).
 //   qtop : the four codes gathered into the TOP byte (base i at bits [24+2i, 26+2i)); lower bytes are scrap
-//   btop : bit 28+i set iff byte i is NOT a base; lower bits are scrap
-FH_HD void classify4(u32 d, u32 &qtop, u32 &btop) {
+//   vf   : bit 8i+7 set iff byte i IS a base; all other bits clear
+// diff = the case-folded byte xor the letter it has to be: zero iff the byte is a base.  Its zero bytes are found with
+// (diff - 0x01010101) & ~diff & 0x80808080 -- two instructions where the carry-free form ((x & 0x7f..) + 0x7f.. | x) takes
+// three.  That test is wrong only for a byte 0x01 above a zero byte (the borrow), and a byte of diff is never 0x01: where
+// the table holds a letter the low three bits of diff are zero (the letter was picked by them), where it holds 0xFF bit 5
+// of diff is set (the fold cleared it in the byte).  tests/test_core_logic_host.py walks every pair of neighbouring bytes.
+FH_HD void classify4(u32 d, u32 &qtop, u32 &vf) {
     const u32 sel = d & 0x07070707u;
     const u32 expect = perm_b32(0x47FF5554u, 0x43FF41FFu, sel); // idx 0..7: -, A, -, C, T, U, -, G  (0xFF = none)
     const u32 code = perm_b32(0x02000303u, 0x01000000u, sel);   // idx 0..7: 0, 0, 0, 1, 3, 3, 0, 2
     const u32 diff = (d & 0xDFDFDFDFu) ^ expect;                // case folded; a byte is 0 iff it is a base
-    const u32 nz = (((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) & 0x80808080u; // bit 7 of byte i: byte != 0
-    // gather with one multiply each: the partial products land on disjoint bits, the wanted ones adjacent on top
+    vf = (diff - 0x01010101u) & ~diff & 0x80808080u;
+    // gather with one multiply: the partial products land on disjoint bits, the wanted ones adjacent on top
     qtop = code * 0x01041040u; // c0@24 c1@26 c2@28 c3@30
-    btop = nz * 0x00204081u;   // b0@28 b1@29 b2@30 b3@31
 }
 
 // 16 bytes (4 dwords, little endian) -> 16 codes (32 bits, l-form) + 16 good bits
 FH_HD void classify_chunk(u32 d0, u32 d1, u32 d2, u32 d3, u32 &codes, u32 &good) {
-    u32 q0, q1, q2, q3, b0, b1, b2, b3;
-    classify4(d0, q0, b0);
-    classify4(d1, q1, b1);
-    classify4(d2, q2, b2);
-    classify4(d3, q3, b3);
+    u32 q0, q1, q2, q3, v0, v1, v2, v3;
+    classify4(d0, q0, v0);
+    classify4(d1, q1, v1);
+    classify4(d2, q2, v2);
+    classify4(d3, q3, v3);
     // pack the four top bytes: selector 3 / 7 = top byte of the second / first operand, 0x0c = zero
     codes = perm_b32(q1, q0, 0x0c0c0703u) | perm_b32(q3, q2, 0x07030c0cu);
-    const u32 bad = (b0 >> 28) | ((b1 >> 28) << 4) | ((b2 >> 28) << 8) | ((b3 >> 28) << 12);
-    good = bad ^ 0xFFFFu;
+    // the flags of TWO dwords, interleaved four bits apart (byte j of the first at bit 8j+3, of the second at 8j+7), are
+    // gathered by ONE multiply: 2^21 + 2^14 + 2^7 + 1 brings them to bits 24+j and 28+j, and no two of the 32 partial
+    // products meet (8j' - 7j + {0, 4}, j != j', lies outside 0..7 and the two families differ by 4 mod 7 != 0)
+    const u32 w0 = (v0 >> 4) | v1, w1 = (v2 >> 4) | v3;
+    good = ((w0 * 0x00204081u) >> 24) | (((w1 * 0x00204081u) >> 16) & 0xFF00u);
 }
 
 // reverse the order of the 32 2-bit digits of a 64-bit word

@@ -210,3 +210,27 @@ def test_classification_every_byte_value_every_slot(core):
         assert np.array_equal(got[is_base], want[is_base]), s
     assert np.array_equal(good, exp_good)
     assert not np.any(good >> np.uint32(16))
+
+
+def test_classification_every_pair_of_neighbouring_bytes(core):
+    """the zero-byte test of classify4 borrows from a byte into the next one: all 65 536 pairs of neighbouring bytes, inside a
+    dword, across dwords and across the two halves of the chunk the flags are gathered by"""
+    core.fhcore_classify.restype = None
+    core.fhcore_classify.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    bases = np.frombuffer(b"ACGTacgtUuNn\x00\xff -", dtype=np.uint8)
+    a, b = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    is_base = np.zeros(256, dtype=bool)
+    is_base[list(b"ACGTacgtUu")] = True
+    for slot in (0, 1, 2, 3, 6, 7, 8, 11, 13, 14):
+        chunks = bases[rng.integers(0, len(bases), (65536, 16))]
+        chunks[:, slot] = a.ravel()
+        chunks[:, slot + 1] = b.ravel()
+        flat = np.ascontiguousarray(chunks)
+        codes = np.zeros(len(flat), dtype=np.uint32)
+        good = np.zeros(len(flat), dtype=np.uint32)
+        core.fhcore_classify(flat.ctypes.data, len(flat), codes.ctypes.data, good.ctypes.data)
+        exp = np.zeros(len(flat), dtype=np.uint32)
+        for s_ in range(16):
+            exp |= is_base[flat[:, s_]].astype(np.uint32) << np.uint32(s_)
+        assert np.array_equal(good, exp), slot
