@@ -239,6 +239,9 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             const u64 tile_stream_pos = a.base_pos + tile_pos0;
+            // start positions from the tile's first one to the end of the launch's range, as far as 32 bits count (scalar: a lane's
+            // share of it is one saturating subtraction per round instead of 64-bit arithmetic per lane)
+            const u32 tile_room = a.p_end > tile_pos0 ? (u32)(a.p_end - tile_pos0 < 0x7FFFFFFFull ? a.p_end - tile_pos0 : 0x7FFFFFFFull) : 0u;
 #pragma unroll 1
             for (u32 c = c_first; c < NR; ++c) {
                 const u32 rc0 = (u32)R * c; // the round's first segment offset (wave-uniform)
@@ -250,10 +253,9 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
                     const u32 p0 = S * lane + rc0; // the lane's view begins at this tile position
                     // which of its windows carry a k-mer: all K bases good, inside the segment, inside [p_begin, p_end)
                     const u64 g64 = seg_good_bits(Gd, p0);
-                    const u64 lane_pos0 = tile_pos0 + p0;
-                    u32 limit = (a.p_end > lane_pos0) ? (u32)((a.p_end - lane_pos0) < 64 ? (a.p_end - lane_pos0) : 64) : 0u;
-                    limit = limit < nmax ? limit : nmax;
-                    if constexpr (LONG) Wc = window_valid_mask64<K>(g64) & (limit >= 64u ? ~0ull : ((1ull << limit) - 1ull));
+                    u32 limit = __builtin_elementwise_sub_sat(tile_room, p0);
+                    limit = limit < nmax ? limit : nmax; // <= R
+                    if constexpr (LONG) Wc = window_valid_mask64<K>(g64) & ((1ull << limit) - 1ull); // (R <= 48)
                     else Wc = window_valid_mask<K>(g64) & (limit >= 32u ? 0xFFFFFFFFu : ((1u << limit) - 1u));
                     // a round whose windows reach the segment's last K bases may hold nothing, or nothing behind some position,
                     // in every lane at once (the records' breakers): ask the wave
