@@ -294,9 +294,20 @@ __device__ __forceinline__ uint4 load_chunk_guarded(const uint8_t *seq, u64 off,
 
 __device__ __forceinline__ void classify_tile(const SketchArgs &a, u64 tile, int lane, u32 *codes_ring,
                                               u32 *good_ring) {
-    const u64 off = a.p_begin + tile * (u64)TILE_POS + (u64)lane * LANE_POS;
-    const uint4 c0 = load_chunk_guarded(a.seq, off, a.len_total);
-    const uint4 c1 = load_chunk_guarded(a.seq, off + 16, a.len_total);
+    const u64 tile_off = a.p_begin + tile * (u64)TILE_POS; // wave-uniform
+    uint4 c0, c1;
+    if (__builtin_expect(tile_off + (u64)TILE_POS <= a.len_total, 1)) {
+        // the whole tile lies inside the buffer (every tile but a block's last): one scalar base and the lane's 32-bit offset; the
+        // guarded form is a dozen VALU instructions a chunk (64-bit address, two 64-bit compares, the zeroes)
+        const uint8_t *const tb = a.seq + tile_off;
+        const u32 vo = (u32)lane * (u32)LANE_POS;
+        c0 = *reinterpret_cast<const uint4 *>(tb + (u64)vo);
+        c1 = *reinterpret_cast<const uint4 *>(tb + (u64)(vo + 16u));
+    } else {
+        const u64 off = tile_off + (u64)lane * LANE_POS;
+        c0 = load_chunk_guarded(a.seq, off, a.len_total);
+        c1 = load_chunk_guarded(a.seq, off + 16, a.len_total);
+    }
     u32 q0, g0, q1, g1;
     classify_chunk(c0.x, c0.y, c0.z, c0.w, q0, g0);
     classify_chunk(c1.x, c1.y, c1.z, c1.w, q1, g1);
