@@ -291,7 +291,7 @@ FH_HD u64 min_u62(u64 a, u64 b) {
 template <int K, int DOFF = 0>
 struct Windows {
     static constexpr int PRE = pre_shift(K), NB = 2 * K + PRE;
-    static_assert(DOFF == 0 || (2 * DOFF == PRE && K <= 22), "the long view is for the smallest shift");
+    static_assert(DOFF == 0 || 2 * DOFF == PRE, "the long view reaches just as far as the window's scrap bits");
     u32 nC[5], D[5];
 
     FH_HDM void init(u64 clo, u64 chi) {
@@ -445,13 +445,17 @@ FH_HD u32 window_valid_mask(u64 g64) { return (u32)window_valid_mask64<K>(g64); 
 // and the words behind the string zero), Rv = the digit-reversed codes (chunk i as pairrev32 at word NCH - 1 - i: the base at
 // tile position p is digit 16 NCH - 1 - p), Gd = the good bits (chunk i at half-word i).  A lane's round looks at the 64
 // bases from tile position p0 on (p0 + 63 + DOFF < 16 NCH): nc / d are what Windows<K, DOFF>::init_words takes, seg_good_bits
-// what window_valid_mask64 takes.  Positions per round: as many windows as the view holds for K <= 22 (65 - K, at most 48),
+// what window_valid_mask64 takes.  Positions per round: as many windows as the view holds (65 - K, at most 48) for K <= 24 and 26,
 // 16 for longer k-mers (their register budget: fh_k2.hip).
 #ifndef FH_SEG_LONG
 #define FH_SEG_LONG 1 // 0: rounds of 32 for K <= 22 (round 5's first form)
 #endif
-constexpr bool seg_long(int K) { return FH_SEG_LONG && K <= 22; }
-constexpr int seg_round(int K) { return K >= 23 ? 16 : (seg_long(K) ? (65 - K < 48 ? 65 - K : 48) : 32); }
+// (long rounds wherever the unrolled pass keeps inside 128 VGPRs: K = 25, 27, 28 spill 18-30 registers with it, K = 29..32 32)
+#ifndef FH_SEG_LONG_MAXK
+#define FH_SEG_LONG_MAXK 24
+#endif
+constexpr bool seg_long(int K) { return FH_SEG_LONG && (K <= FH_SEG_LONG_MAXK || (K == 26 && FH_SEG_LONG_MAXK == 24)); }
+constexpr int seg_round(int K) { return seg_long(K) ? (65 - K < 48 ? 65 - K : 48) : (K >= 23 ? 16 : 32); }
 constexpr int seg_doff(int K) { return seg_long(K) ? pre_shift(K) / 2 : 0; }
 
 template <int K>

@@ -96,6 +96,14 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
     constexpr int DOFF = seg_doff(K); // (fh_core.h, Windows: the forward string's view reaches this many bases further)
     using Win = Windows<K, DOFF>;
     using Mask = std::conditional_t<LONG, u64, u32>; // a round's valid windows
+    // Rounds of 16 unrolled positions (the K whose registers allow no more: fh_core.h, seg_long) come in PAIRS: one set-up -- the
+    // validity mask, the wave's question, the two views -- serves 32 positions, the strings are moved on 32 bits in between as
+    // in k2_sketch (Windows::advance<16>).  RO = a round's positions as the tile's bookkeeping counts them.
+#ifndef FH_SEG_HALVES
+#define FH_SEG_HALVES 1
+#endif
+    constexpr int HALVES = (FH_SEG_HALVES && !LONG && R == 16) ? 2 : 1, RO = R * HALVES;
+    static_assert(RO + K - 1 <= 64, "a round's windows lie inside the lane's 64-base view");
     __shared__ __attribute__((aligned(16))) unsigned char blob[K2S_BYTES];
     Rec4 *const sA1 = (Rec4 *)(blob + K2S_A1), *const sA2 = (Rec4 *)(blob + K2S_A2);
     Rec2 *const sB1 = (Rec2 *)(blob + K2S_B1), *const sB2 = (Rec2 *)(blob + K2S_B2), *const sP = (Rec2 *)(blob + K2S_P);
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
     u32 *const Rv = Fc + K2S_FC_DW;                                      // digit-reversed codes: chunk i at word NCH - 1 - i
     u32 *const Gd = Rv + K2S_RV_DW;                                      // good bits: chunk i at half-word i
     const u32 S = (u32)__builtin_amdgcn_readfirstlane((int)a.seg_stride);
-    const u32 NCH = 4u * S + 6u, NR = (S + (u32)R - 1u) / (u32)R;
+    const u32 NCH = 4u * S + 6u, NR = (S + (u32)RO - 1u) / (u32)RO;
     const u32 tile_pos = 64u * S;
     u32 nvalid = 0;
 
@@ -244,17 +252,17 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
             const u32 tile_room = a.p_end > tile_pos0 ? (u32)(a.p_end - tile_pos0 < 0x7FFFFFFFull ? a.p_end - tile_pos0 : 0x7FFFFFFFull) : 0u;
 #pragma unroll 1
             for (u32 c = c_first; c < NR; ++c) {
-                const u32 rc0 = (u32)R * c; // the round's first segment offset (wave-uniform)
+                const u32 rc0 = (u32)RO * c; // the round's first segment offset (wave-uniform)
                 Win win;
                 Mask Wc;
-                u32 nmax = S - rc0 < (u32)R ? S - rc0 : (u32)R; // positions of the segment this round covers
+                u32 nmax = S - rc0 < (u32)RO ? S - rc0 : (u32)RO; // positions of the segment this round covers
                 {
                     const u32 lane = lane_now();
                     const u32 p0 = S * lane + rc0; // the lane's view begins at this tile position
                     // which of its windows carry a k-mer: all K bases good, inside the segment, inside [p_begin, p_end)
                     const u64 g64 = seg_good_bits(Gd, p0);
                     u32 limit = __builtin_elementwise_sub_sat(tile_room, p0);
-                    limit = limit < nmax ? limit : nmax; // <= R
+                    limit = limit < nmax ? limit : nmax; // <= RO
                     if constexpr (LONG) Wc = window_valid_mask64<K>(g64) & ((1ull << limit) - 1ull); // (R <= 48)
                     else Wc = window_valid_mask<K>(g64) & (limit >= 32u ? 0xFFFFFFFFu : ((1u << limit) - 1u));
                     // a round whose windows reach the segment's last K bases may hold nothing, or nothing behind some position,
@@ -278,6 +286,14 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
                 }
 
                 // ---- the round's positions: k2_sketch's loop (fh_k2.hip), ending behind the last valid one ----
+#pragma unroll 1
+                for (int h = 0; h < HALVES; ++h) {
+                if (HALVES > 1 && h) {
+                    if (nmax <= (u32)R) break; // (wave-uniform)
+                    nmax -= (u32)R;
+                    win.template advance<(HALVES > 1 ? R : 16)>();
+                    Wc >>= (HALVES > 1 ? R : 0);
+                }
                 auto window = [&](int j, u64 &cm, bool &is_rc) {
                     if constexpr (Win::MINF64) cm = win.canonical_word(j), is_rc = false;
                     else cm = win.canonical(j, is_rc);
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
                                 queue->ka[my] = hp.ka;
                                 queue->kb[my] = hp.kb;
                                 queue->k[my] = cm;
-                                const u64 pos = tile_stream_pos + (u64)(lane_now() * S + rc0 + (u32)j);
+                                const u64 pos = tile_stream_pos + (u64)(lane_now() * S + rc0 + (u32)(h * R + j));
                                 bool is_rc = rc_loop;
                                 if constexpr (Win::MINF64) is_rc = win.strand_of(j);
                                 queue->p[my] = pos | ((u64)(is_rc ? 1u : 0u) << 63);
@@ -334,6 +350,7 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
                     }
                 };
                 step(step, std::integral_constant<int, 0>{});
+                }
                 __builtin_amdgcn_wave_barrier();
                 const bool last_round = c + 1u == NR;
                 if (qn >= (u32)(QCAP / 2)) { // drain when half full (and at the end of the pulled range, below)
