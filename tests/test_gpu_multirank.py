@@ -165,3 +165,21 @@ print("rccl gather OK")
 ''' % (ROOT, str(_free_port()))
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "rccl gather OK" in r.stdout, r.stdout[-3000:]
+
+
+def test_the_bench_line_collects_its_own_counters():
+    """roofline.traffic of a standard-size run comes from PMC counters this very run collected (two profiled child runs), not
+    from the committed passes; the counters must see about one byte per position (the stream is read once) and the VALU
+    instruction count of the kernel that ran"""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("no rocprofv3 on this box")
+    d = _bench(["--workload", "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], 1)
+    r = d["roofline"]
+    assert r["traffic_source"].startswith("live"), r.get("traffic_source")
+    live = r["pmc_live"]
+    assert 0.95 < live["hbm_bytes_per_position"] < 1.6, live
+    assert 30.0 < live["valu_per_wave_iter"] < 80.0, live
+    assert r["traffic"] == int(live["hbm_bytes_per_position"] * r["alg_bytes_per_launch"])
+    committed = _bench(["--workload", "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-live-pmc"], 1)
+    assert committed["roofline"]["traffic_source"].startswith("committed")

@@ -7,9 +7,9 @@ TAG=${1:-r03}; KEY=${2:-c4_k21_n1000}; shift; shift
 ARGS="$@"
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-python bench.py --steps 5 --warmup 1 --no-extras --no-cpu-baseline $ARGS 2>&1 | tail -1 | tee gpurun_out/${TAG}_bench.json
+python bench.py --steps 5 --warmup 1 --no-extras --no-cpu-baseline --no-live-pmc $ARGS 2>&1 | tail -1 | tee gpurun_out/${TAG}_bench.json
 cd /tmp
-B="python $R/bench.py --no-cpu-baseline --no-extras $ARGS"
+B="python $R/bench.py --no-cpu-baseline --no-extras --no-live-pmc $ARGS"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_stats -o stats --output-format csv -- $B --steps 5 --warmup 1 > $R/gpurun_out/${TAG}_stats.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --kernel-trace -d $R/gpurun_out/${TAG}_pmc_fetch -o p --output-format csv -- $B --steps 1 --warmup 0 > $R/gpurun_out/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --kernel-trace -d $R/gpurun_out/${TAG}_pmc_write -o p --output-format csv -- $B --steps 1 --warmup 0 > $R/gpurun_out/${TAG}_pmc_write.log 2>&1

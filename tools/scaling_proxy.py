@@ -18,7 +18,7 @@ def run(args):
 
 t = {}
 for n in (1, 2, 4, 8):
-    d = run(["--gbases", str(50.0 / n), "--steps", steps, "--warmup", "5", "--no-extras", "--no-cpu-baseline"])
+    d = run(["--gbases", str(50.0 / n), "--steps", steps, "--warmup", "5", "--no-extras", "--no-cpu-baseline", "--no-live-pmc"])
     if d:
         t[n] = d["ms_per_step"]
         print("share 50/%d = %6.3f Gbase: %8.3f ms per pass  %6.1f Gbases/s  kernel %.3f ms  (%s)" %
