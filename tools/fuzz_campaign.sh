@@ -1,11 +1,13 @@
 #!/bin/bash
 # The round's closing fuzz campaign on the GPU box: the kernel fuzzer and the parity suites with every block forced through the
 # segment kernels at four strides (any stride must give the oracle's sketch) and unforced, then the parameter / text / gzip fuzzers.
-#   gpurun --timeout 3600 -- 'bash tools/fuzz_campaign.sh'   -> gpurun_out/r05_fuzz_final.txt
+#   gpurun --timeout 3600 -- 'bash tools/fuzz_campaign.sh [<out name> [<seed offset>]]'   -> gpurun_out/<out name>.txt (r05_fuzz_final)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-O=gpurun_out/r05_fuzz_final.txt; : > $O
-for cfg in "40 616161 1200" "100 626262 1200" "151 636363 2000" "168 646464 1200" "0 656565 1500"; do
+O=gpurun_out/${1:-r05_fuzz_final}.txt; : > $O
+SO=${2:-0}
+for cfg in "40 616161 1200" "100 626262 1200" "151 636363 2000" "168 646464 1200" "61 666666 800" "0 656565 1500"; do
   set -- $cfg
+  set -- $1 $(($2 + SO)) $3
   if [ "$1" != "0" ]; then export FH_SEG_STRIDE=$1; else unset FH_SEG_STRIDE; fi
   echo "== FH_SEG_STRIDE=${FH_SEG_STRIDE:-unset} seed $2 cases $3" >> $O
   # (tests/test_gpu_segments.py asserts which stride a block went by: only where none is forced)
