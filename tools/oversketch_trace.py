@@ -23,7 +23,7 @@ S.synth_genome_device(dg, GL, SEED)
 S.synth_reads_device(dr, dg, GL, 0, n_reads, RL, SEED, 10000, 500)
 s = F.SketchParams.mash(n, n, True, k, 0).create_sketcher()
 s.set_profiling(True)
-for it in range(3):
+for it in range(int(os.environ.get("PASSES", "3"))):
     sys.stderr.write("== pass %d\n" % it)
     t0 = time.perf_counter()
     s.reset()
