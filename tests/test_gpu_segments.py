@@ -53,7 +53,8 @@ def genome():
     return S.synth_genome_host(300_000, 77)
 
 
-@pytest.mark.parametrize("k", [5, 12, 16, 17, 21, 22, 24, 27, 31, 32])
+# (long rounds: K <= 24 and 26; rounds of 16 in pairs: 25, 27..32 -- fh_core.h seg_long; 1 and 16: the 48-position cap, no pre-shift)
+@pytest.mark.parametrize("k", [1, 5, 12, 16, 17, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32])
 def test_right_stride_every_kernel_shape(genome, k):
     rng = np.random.default_rng(1000 + k)
     stream = packed(fixed_reads(rng, 3000 + k, 150, genome))  # (not a multiple of 64 records: a partial last tile)
@@ -209,3 +210,18 @@ print("probe OK")
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FH_SEG_PROBE_MIN="0", FH_SEG_PROBE_WAIT_MIN=wait_min),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert r.returncode == 0 and "probe OK" in r.stdout, (wait_min, r.stdout[-3000:])
+
+
+@pytest.mark.parametrize("stride", [41, 44, 45, 46, 64, 65, 88, 89, 129, 133])
+@pytest.mark.parametrize("k", [21, 24, 26, 27, 30])
+def test_strides_around_the_round_lengths(genome, k, stride):
+    """a round is 65 - K positions (K <= 24, 26) or a pair of 16: strides one short of, equal to and one past a whole number of
+    rounds, with reads of exactly that length (the last round holds one window, none, or a full set) and a loose threshold that
+    stops waves between rounds"""
+    rng = np.random.default_rng(7000 + 100 * k + stride)
+    stream = packed(fixed_reads(rng, 1500 + stride, stride - 1, genome))
+    sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, k, 0), stream, stride)
+    assert sk.debug_segments()[0] > 0 and sk.debug_segments()[2] == stride
+    assert_same(sk, oracle_of(O.MASH, 1000, k, stream), "k=%d stride=%d" % (k, stride))
+    sk, _ = sketch_on_device(F.SketchParams.scaled(100, k, 0.5, 0), stream, stride, max_launch=4096)
+    assert_same(sk, oracle_of(O.SCALED, 100, k, stream, 0.5), "scaled k=%d stride=%d" % (k, stride))
