@@ -28,6 +28,14 @@ FLAGS += os.environ.get("FH_EXTRA_FLAGS", "").split()
 K2_FLAGS = ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-pragma-unroll-threshold=200000"]
 if "FH_K2_FLAGS" in os.environ:  # A/B builds of the sketch kernel only
     K2_FLAGS = os.environ["FH_K2_FLAGS"].split()
+# The segment kernels of K = 25..32 (the last part; LDS-pipe bound: configs[2]'s k = 31) under LLVM's iterative ILP scheduler:
+# the same instructions in another order, k = 29..31 +0.6-1.8 %, configs[2]'s launches +1.9 % (profiles/r05U_ab_iterative_ilp.txt);
+# K <= 24 and the tile kernels gain nothing from it (k = 12, 20 lose half a per cent) and keep max-ilp.
+K2S_FLAGS_LAST = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-mllvm", "-pragma-unroll-threshold=200000"]
+if "FH_K2S_FLAGS_LAST" in os.environ:
+    K2S_FLAGS_LAST = os.environ["FH_K2S_FLAGS_LAST"].split()
+elif "FH_K2_FLAGS" in os.environ:
+    K2S_FLAGS_LAST = K2_FLAGS
 if "FH_OUT" in os.environ:  # an A/B build: its objects must not replace those libfinch_hip.so was linked from (tools/k2_regs.py --objects)
     OUT = os.environ["FH_OUT"]
     OBJ = os.path.join(HERE, "obj", "ab_" + os.path.splitext(os.path.basename(OUT))[0])
@@ -67,7 +75,8 @@ def _build_locked(verbose):
     for part in range(NPARTS):
         jobs.append([HIPCC] + FLAGS + K2_FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2.hip", "-o", os.path.join(OBJ, "fh_k2_%d.o" % part)])
     for part in range(NPARTS):  # the segment form of the sketch kernel
-        jobs.append([HIPCC] + FLAGS + K2_FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2s.hip", "-o", os.path.join(OBJ, "fh_k2s_%d.o" % part)])
+        jobs.append([HIPCC] + FLAGS + (K2S_FLAGS_LAST if part == NPARTS - 1 else K2_FLAGS) +
+                    ["-DFH_PART=%d" % part, "-c", "fh_k2s.hip", "-o", os.path.join(OBJ, "fh_k2s_%d.o" % part)])
     for part in range(NPARTS):  # ... and of the two-word kernel
         jobs.append([HIPCC] + FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2ws.hip", "-o", os.path.join(OBJ, "fh_k2ws_%d.o" % part)])
     for part in range(NPARTS):  # K = 33..64
