@@ -43,6 +43,8 @@ if "FH_OUT" in os.environ:  # an A/B build: its objects must not replace those l
 # the two-word segment kernels (K = 33..64) under max-ilp too: k = 33..64 +0.8-2.6 % over the default scheduler, no spills
 # (profiles/r05W_ab_k2ws_sched.txt; iterative-ilp: +0-2.3 %)
 K2WS_FLAGS = os.environ["FH_K2WS_FLAGS"].split() if "FH_K2WS_FLAGS" in os.environ else ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+# ... and the two-word tile kernels: k = 33 / 48 / 64 +3.2 / 2.9 / 3.7 % (FH_NO_SEG=1, profiles/r05W_ab_k2ws_sched.txt), no spills
+K2W_FLAGS = os.environ["FH_K2W_FLAGS"].split() if "FH_K2W_FLAGS" in os.environ else ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2_common.h", "fh_k2w.hip", "fh_k2.hip", "fh_k2s.hip", "fh_k2ws.hip", "fh_kernels.hip", "fh_big.hip", "fh_text.hip", "fh_bgzf.hip", "fh_api.hip", "fh_host.cpp",
            "fh_host_model.h", "fh_inflate.h", "fh_pargz.h", "fh_serial.cpp", os.path.join("..", "..", "include", "finch_host.h"),
            os.path.join("..", "..", "include", "finch_hip.h")]
@@ -83,7 +85,7 @@ def _build_locked(verbose):
     for part in range(NPARTS):  # ... and of the two-word kernel
         jobs.append([HIPCC] + FLAGS + K2WS_FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2ws.hip", "-o", os.path.join(OBJ, "fh_k2ws_%d.o" % part)])
     for part in range(NPARTS):  # K = 33..64
-        jobs.append([HIPCC] + FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2w.hip", "-o", os.path.join(OBJ, "fh_k2w_%d.o" % part)])
+        jobs.append([HIPCC] + FLAGS + K2W_FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2w.hip", "-o", os.path.join(OBJ, "fh_k2w_%d.o" % part)])
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_kernels.hip", "-o", os.path.join(OBJ, "fh_kernels.o")])
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_big.hip", "-o", os.path.join(OBJ, "fh_big.o")])
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_text.hip", "-o", os.path.join(OBJ, "fh_text.o")])
