@@ -805,7 +805,12 @@ int speculative_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, 
 // sketched in ONE launch at a threshold a little above its final one.  If the estimate was too tight -- fewer than `size`
 // hashes live at the end -- everything at or below it is in the table with exact counts and the block is re-read for the
 // hashes above it, exactly like a failed speculation.
-constexpr uint32_t SAMPLE_RUN_TILES = 8, SAMPLE_ONE_IN = 64;
+constexpr uint32_t SAMPLE_RUN_TILES_DEFAULT = 8, SAMPLE_ONE_IN_DEFAULT = 64;
+static uint32_t sample_knob(const char *name, uint32_t dflt) { // measurement knobs (FH_SAMPLE_RUN_TILES, FH_SAMPLE_ONE_IN)
+    const char *e = getenv(name);
+    const long v = e ? atol(e) : 0;
+    return v > 0 && v < 65536 ? (uint32_t)v : dflt;
+}
 int sampled_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos, uint64_t n_pos, bool *attempted,
                         bool *done) {
     *attempted = *done = false;
@@ -821,7 +826,19 @@ int sampled_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
     if (off || s->no_spec || s->max_range || s->p.hash_mask || !s->big_mode || s->p.kind != FH_KIND_MASH || s->p.size < 16384 ||
         n_pos < min_pos || (double)n_pos < 64.0 * (double)s->p.size)
         return FH_OK;
+    static const uint32_t run_tiles_knob = sample_knob("FH_SAMPLE_RUN_TILES", 0);
+    static const uint32_t SAMPLE_ONE_IN = sample_knob("FH_SAMPLE_ONE_IN", SAMPLE_ONE_IN_DEFAULT);
+    static const double cap_knob = [] {
+        const char *e = getenv("FH_SAMPLE_CAP_SCALE"); // measurement knob: scales the sample pass's cap threshold
+        return e ? atof(e) : 1.0;
+    }();
     const uint64_t tiles = (n_pos + TILE_POS - 1) / TILE_POS;
+    // One run per resident wave where the block is large enough: the runs are dealt out one at a time, and 9 600 runs of 8 tiles
+    // on 4 096 waves are three rounds of which the last is a third full (0.78 ms for a 10 Gbase block; 4 100 runs of 19 tiles:
+    // 0.51 ms, profiles/r05_sample_runs.txt).  Between 8 and 128 tiles a run; the sampled share stays one tile in SAMPLE_ONE_IN.
+    const uint32_t SAMPLE_RUN_TILES = run_tiles_knob ? run_tiles_knob
+        : (uint32_t)std::min<uint64_t>(128, std::max<uint64_t>(SAMPLE_RUN_TILES_DEFAULT, (tiles + (uint64_t)SAMPLE_ONE_IN * s->max_waves - 1) /
+                                                                                             ((uint64_t)SAMPLE_ONE_IN * s->max_waves)));
     const uint32_t stride = SAMPLE_RUN_TILES * SAMPLE_ONE_IN;
     const uint64_t n_runs = tiles / stride;
     if (n_runs < 64 || tiles >= (1ull << 31)) return FH_OK;
@@ -845,7 +862,7 @@ int sampled_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
     uint64_t tau_guess = 0, tau_cap = 0;
     double S = 0, c1 = 0, c2 = 0;
     for (const double cap_occ : {0.5, 2.0}) {
-    const double cap_frac = std::min(0.25, cap_occ * (double)s->p.size / n_samples);
+    const double cap_frac = std::min(0.25, cap_knob * cap_occ * (double)s->p.size / n_samples);
     tau_cap = (uint64_t)(cap_frac * 18446744073709551616.0);
     // ---- the sample pass: the sketch kernel over the tile runs, handed over as a "leftover" list ----
     if (int rc = set_tau(s, tau_cap)) return rc;
