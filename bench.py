@@ -126,17 +126,47 @@ def c5_cpu_baseline(paths, lens, max_files=256):
                       % (len(sample), bases / 1e6, cores, flags)}
 
 
-def c5_roofline(kernel_ms, launches, positions, wall_ms, n_gpus):
+def _h2d_peak_gbs(dev=0, mib=32, reps=24):
+    """this box's pinned host-to-device copy rate (GB/s) on one stream, copies of `mib` MiB: what a batch of files is held against"""
+    try:
+        import torch
+        h = torch.empty(mib << 20, dtype=torch.uint8, pin_memory=True)
+        d = torch.empty(mib << 20, dtype=torch.uint8, device="cuda:%d" % dev)
+        for it in range(2):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                d.copy_(h, non_blocking=True)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+        return round(reps * (mib << 20) / dt / 1e9, 2)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def c5_roofline(kernel_ms, launches, positions, wall_ms, n_gpus, batch=None, live=None, h2d=None):
     """the batch's roofline block: the sketch kernel over ALL files (sum of its launches' HIP-event times on the workers'
-    streams, finch_debug_kernel_times) against the HBM peak, and how much of the call the GPU spent in it"""
+    streams, finch_debug_kernel_times) against the HBM peak, how much of the call the GPU spent in it, and what binds the call:
+    the packed sequence bytes that cross the PCIe link (1 per k-mer start position) against the link's measured rate"""
     ach = positions / 1e9 / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
-    return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-            "traffic": None, "kernel": "k2_sketch<21> (one launch per file, 1-10 M positions each)", "launches": int(launches),
-            "avg_launch_ms": round(kernel_ms / max(launches, 1), 4), "alg_bytes_per_launch": int(positions / max(launches, 1)),
-            "kernel_ms_total": round(kernel_ms, 3), "call_ms_total": round(wall_ms, 3),
-            "kernel_share_of_call": round(kernel_ms / max(wall_ms * n_gpus, 1e-9), 4),
-            "binding_resource": "the call, not the kernel: host-side reading / packing of the files and one PCIe link per GPU "
-                                "(DESIGN.md 5); the kernel itself is VALU-issue bound as in the resident workloads"}
+    link = positions / 1e9 / (wall_ms / 1e3) / max(n_gpus, 1) if wall_ms > 0 else 0.0
+    out = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+           "traffic": None if not live else round(live["hbm_bytes_per_position"] * positions / max(launches, 1), 1),
+           "kernel": "k2_batch<21> (fh_k2b.hip: the files a worker has staged, sketched by ONE launch; finished by one k_batch_epilogue "
+                     "launch, a workgroup per file)", "launches": int(launches),
+           "avg_launch_ms": round(kernel_ms / max(launches, 1), 4), "alg_bytes_per_launch": int(positions / max(launches, 1)),
+           "kernel_ms_total": round(kernel_ms, 3), "call_ms_total": round(wall_ms, 3),
+           "kernel_share_of_call": round(kernel_ms / max(wall_ms * n_gpus, 1e-9), 4),
+           "pcie": {"h2d_peak_gbs": h2d, "achieved_gbs": round(link, 2), "frac": round(link / h2d, 3) if h2d else None,
+                    "bytes": "the files' packed streams, 1 byte per k-mer start position, in copies of up to 32 MiB per worker"},
+           "binding_resource": "one PCIe link per GPU: the packed streams of the files cross it at pcie.achieved_gbs of the pcie.h2d_peak_gbs "
+                               "this box's link copies (measured in this run); the sketch kernels take kernel_share_of_call of the call"}
+    if batch is not None:
+        out["files_taken_many_per_launch"], out["files_through_own_sketcher"] = batch
+    if live:
+        out["traffic_source"] = live["source"]
+        out["pmc_live"] = live
+    return out
 
 
 def _pmc_derived(key):
@@ -148,7 +178,7 @@ def _pmc_derived(key):
         return None
 
 
-def _live_pmc(child_args, timeout_s=150):
+def _live_pmc(child_args, timeout_s=150, kernels=("k2_sketch",)):
     """HBM bytes of the sketch kernel's launches from rocprofv3 PMC counters collected NOW, by this run: two child runs of this
     very command (--steps 1 --warmup 0, nothing else measured), one `--pmc` pass per counter group with --kernel-trace only
     (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass), FETCH_SIZE doubled per that guide's gfx950 correction for
@@ -188,7 +218,7 @@ def _live_pmc(child_args, timeout_s=150):
                     positions = r["alg_bytes_per_launch"] * r["launches"]
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "k2_sketch" in row["Kernel_Name"]:
+                    if any(kn in row["Kernel_Name"] for kn in kernels):
                         sums[row["Counter_Name"]] = sums.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
                         disp[row["Counter_Name"]] = disp.get(row["Counter_Name"], 0) + 1
         if not positions or "FETCH_SIZE" not in sums or "WRITE_SIZE" not in sums:
@@ -199,7 +229,7 @@ def _live_pmc(child_args, timeout_s=150):
                 "cycles_per_wave_iter": round(sums["GRBM_GUI_ACTIVE"] / 8 * 1024 / (positions / 64.0), 1) if "GRBM_GUI_ACTIVE" in sums else None,
                 "positions": int(positions), "dispatches": disp.get("FETCH_SIZE"), "seconds": round(time.perf_counter() - t0, 1),
                 "source": "live: rocprofv3 --pmc {GRBM_GUI_ACTIVE FETCH_SIZE | WRITE_SIZE SQ_INSTS_VALU} --kernel-trace over two child runs "
-                          "of this command (--steps 1), summed over the k2_sketch* dispatches; HBM bytes = 2 x FETCH_SIZE (gfx950 "
+                          "of this command (--steps 1), summed over the %s* dispatches; HBM bytes = 2 x FETCH_SIZE (gfx950 " % "* / ".join(kernels) +
                           "correction for 16 B/lane streaming reads) + WRITE_SIZE"}
     except Exception:  # noqa: BLE001 -- a profiler hiccup must not take the bench line with it
         return None
@@ -547,6 +577,8 @@ def main():
 
     extras = None
     if world == 1 and not args.no_extras and is_default:
+        global LIVE_PMC_EXTRAS
+        LIVE_PMC_EXTRAS = not args.no_live_pmc
         extras = measure_extras(F, S, dr, dg, min(n_reads, int(np.ceil(10e9 / READ_LEN))), my_devices[0])
 
     drive = ("one process per GPU (torch.distributed.run, %s)" % args.backend if launched and world > 1 else
@@ -626,12 +658,14 @@ def run_c5(args, F, S, dist, barrier, rank, world, my_devices, launched, gather_
             step()
         barrier()
         H.debug_kernel_times(1)
+        fb0 = H.debug_file_batch()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         barrier()
         elapsed = time.perf_counter() - t0
         k_ms, k_launches, k_pos = H.debug_kernel_times(0)
+        fb1 = H.debug_file_batch()
         # fingerprint of the sample: files 0..255 (each rank contributes the ones it sketched)
         fx, tk, cs = 0, 0, 0
         for j, i in enumerate(mine):
@@ -665,7 +699,10 @@ def run_c5(args, F, S, dist, barrier, rank, world, my_devices, launched, gather_
                                          "" if nf == args.files else "; %d asked for, cut to what %s holds" % (args.files, base)),
                           "files": nf, "files_per_s": round(nf * args.steps / elapsed, 1),
                           "parallelism": "file -> GPU mapping x%d (%s)" % (world, "one call per rank" if launched and world > 1 else "one call, devices=[0..%d]" % (world - 1))},
-               "roofline": c5_roofline(k_ms, k_launches, k_pos, elapsed * 1e3, world),
+               "roofline": c5_roofline(k_ms, k_launches, k_pos, elapsed * 1e3, world, batch=(fb1[0] - fb0[0], fb1[1] - fb0[1]),
+                                       live=None if (args.no_live_pmc or world != 1) else
+                                       _live_pmc(["--workload", "c5", "--files", str(min(nf, 256))], kernels=("k2_batch", "k2_sketch")),
+                                       h2d=_h2d_peak_gbs(my_devices[0])),
                "cpu_baseline": None if args.no_cpu_baseline else c5_cpu_baseline(paths, lens), "sketch_check": fp}
         print(json.dumps(out), flush=True)
         return 0 if fp["matches_golden"] is not False else 3
@@ -677,6 +714,9 @@ def run_c5(args, F, S, dist, barrier, rank, world, my_devices, launched, gather_
             shutil.rmtree(d, ignore_errors=True)
         if dist is not None:
             dist.destroy_process_group()
+
+
+LIVE_PMC_EXTRAS = True  # main() clears it under --no-live-pmc
 
 
 def measure_extras(F, S, dr, dg, n_reads, dev):
@@ -932,19 +972,24 @@ def measure_extras(F, S, dr, dg, n_reads, dev):
             # sketches batches does)
             H._lib.load().fh_release_cached()
             kt = (0.0, 0, 0)
-            for _ in range(3):
+            fb = (0, 0)
+            for _ in range(4):
                 H.debug_kernel_times(1)
+                fb0 = H.debug_file_batch()
                 t0 = time.perf_counter()
                 res = H.sketch_files(paths, F.SketchParams.default(), H.FilterParams(None), devices=[dev])
                 dt = time.perf_counter() - t0
+                fb1 = H.debug_file_batch()
                 if dt < best:
-                    best, kt = dt, H.debug_kernel_times(0)
+                    best, kt, fb = dt, H.debug_kernel_times(0), (fb1[0] - fb0[0], fb1[1] - fb0[1])
                 assert len(res) == nf
             H.debug_kernel_times(0)
             return {"what": "ONE finch_sketch_files call over %d synthetic FASTA files (log-uniform 1-10 Mb, 70-column lines, "
                             "%.2f Gbases, page cache / tmpfs), library defaults (k=21 n=1000, up to 16 worker threads per GPU)" % (nf, tot / 1e9),
                     "seconds": round(best, 4), "files_per_s": round(nf / best, 1), "gbases_per_s": round(tot / best / 1e9, 2),
-                    "roofline": c5_roofline(kt[0], kt[1], kt[2], best * 1e3, 1),
+                    "roofline": c5_roofline(kt[0], kt[1], kt[2], best * 1e3, 1, batch=fb, h2d=_h2d_peak_gbs(dev),
+                                            live=_live_pmc(["--workload", "c5", "--files", "256"], kernels=("k2_batch", "k2_sketch"))
+                                            if LIVE_PMC_EXTRAS else None),
                     "cpu_baseline": c5_cpu_baseline(paths, [m[1] for m in made])}
         finally:
             shutil.rmtree(d, ignore_errors=True)

@@ -5,5 +5,5 @@ the C ABI (csrc/, include/finch_hip.h) and the host-side mirror of the reference
 that path.  Importing this package never falls back to a CPU implementation.
 """
 from ._lib import FinchHipError, SO_PATH, load  # noqa: F401
-from .sketch_schemes import (DeviceBuffer, FinchError, HipSketcher, KmerCount, SketchParams,  # noqa: F401
+from .sketch_schemes import (BatchSketcher, DeviceBuffer, FinchError, HipSketcher, KmerCount, SketchParams,  # noqa: F401
                              device_count)

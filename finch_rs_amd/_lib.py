@@ -72,6 +72,17 @@ SYMBOLS = {
     "fh_merge_wire": (C.c_int, [C.c_uint32, C.c_uint64, C.c_double, C.c_uint32, C.c_uint64, C.c_uint32, _P, _U64P, _P, _P, _P, _P, _P,
                       _U64P]),
     "fh_sketch_device_blocks": (C.c_int, [_P, _P, _U64P, _U64P, C.c_uint32]),
+    "fh_batch_new": (_P, [C.POINTER(FhParams), C.c_int, C.c_uint32, C.c_uint64]),
+    "fh_batch_free": (None, [_P]),
+    "fh_batch_stage": (C.c_int, [_P, C.c_int, C.POINTER(_P), _U64P]),
+    "fh_batch_submit": (C.c_int, [_P, C.c_int, _P, _P, C.c_uint32]),
+    "fh_batch_wait": (C.c_int, [_P, C.c_int, _P]),
+    "fh_batch_result": (C.c_int, [_P, C.c_int, C.c_uint32, _U64P, _U64P]),
+    "fh_batch_copy_out": (C.c_int, [_P, C.c_int, C.c_uint32, _P, _P, _P, _P, _P]),
+    "fh_batch_copy_out_records": (C.c_int, [_P, C.c_int, C.c_uint32, _P, _P]),
+    "fh_batch_set_profiling": (C.c_int, [_P, C.c_int]),
+    "fh_batch_kernel_time": (C.c_int, [_P, C.POINTER(C.c_double), _U64P, _U64P]),
+    "fh_batch_counters": (C.c_int, [_P, _U64P, _U64P]),
     "fh_set_profiling": (C.c_int, [_P, C.c_int]),
     "fh_kernel_time": (C.c_int, [_P, C.POINTER(C.c_double), _U64P, _U64P]),
     "fh_debug_counters": (C.c_int, [_P, _U64P, _U64P, _U64P]),

@@ -45,7 +45,7 @@ if "FH_OUT" in os.environ:  # an A/B build: its objects must not replace those l
 K2WS_FLAGS = os.environ["FH_K2WS_FLAGS"].split() if "FH_K2WS_FLAGS" in os.environ else ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 # ... and the two-word tile kernels: k = 33 / 48 / 64 +3.2 / 2.9 / 3.7 % (FH_NO_SEG=1, profiles/r05W_ab_k2ws_sched.txt), no spills
 K2W_FLAGS = os.environ["FH_K2W_FLAGS"].split() if "FH_K2W_FLAGS" in os.environ else ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
-SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2_common.h", "fh_k2w.hip", "fh_k2.hip", "fh_k2s.hip", "fh_k2ws.hip", "fh_kernels.hip", "fh_big.hip", "fh_text.hip", "fh_bgzf.hip", "fh_api.hip", "fh_host.cpp",
+SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2_common.h", "fh_k2_lds.h", "fh_internal.h", "fh_k2b.hip", "fh_batch.hip", "fh_k2w.hip", "fh_k2.hip", "fh_k2s.hip", "fh_k2ws.hip", "fh_kernels.hip", "fh_big.hip", "fh_text.hip", "fh_bgzf.hip", "fh_api.hip", "fh_host.cpp",
            "fh_host_model.h", "fh_inflate.h", "fh_pargz.h", "fh_serial.cpp", os.path.join("..", "..", "include", "finch_host.h"),
            os.path.join("..", "..", "include", "finch_hip.h")]
 
@@ -61,7 +61,33 @@ def _run(cmd):
     return r.stdout
 
 
+def _headers_mtime():
+    hs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
+    inc = os.path.join(HERE, "..", "..", "include")
+    hs += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+    return max(os.path.getmtime(h) for h in hs)
+
+
+_FORCE = False
+
+
+def _compile(cmd):
+    """One object: rebuilt only if it is older than its source or any header, or was made by another command line."""
+    obj, src = cmd[-1], os.path.join(HERE, cmd[cmd.index("-c") + 1])
+    stamp = obj + ".cmd"
+    line = " ".join(cmd)
+    if not _FORCE and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == line and \
+            os.path.getmtime(obj) >= max(os.path.getmtime(src), _headers_mtime()):
+        return ""
+    out = _run(cmd)
+    with open(stamp, "w") as f:
+        f.write(line)
+    return out
+
+
 def build(force=False, verbose=False):
+    global _FORCE
+    _FORCE = force
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= _newest_src():
         return OUT
     # several processes may get here at once (the ranks of a torch.distributed.run launch on a fresh checkout): one
@@ -79,6 +105,8 @@ def _build_locked(verbose):
     jobs = []
     for part in range(NPARTS):
         jobs.append([HIPCC] + FLAGS + K2_FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2.hip", "-o", os.path.join(OBJ, "fh_k2_%d.o" % part)])
+    for part in range(NPARTS):  # the batch form (many files per launch): the same per-tile code, the same flags
+        jobs.append([HIPCC] + FLAGS + K2_FLAGS + ["-DFH_PART=%d" % part, "-c", "fh_k2b.hip", "-o", os.path.join(OBJ, "fh_k2b_%d.o" % part)])
     for part in range(NPARTS):  # the segment form of the sketch kernel
         jobs.append([HIPCC] + FLAGS + (K2S_FLAGS_LAST if part == NPARTS - 1 else K2_FLAGS) +
                     ["-DFH_PART=%d" % part, "-c", "fh_k2s.hip", "-o", os.path.join(OBJ, "fh_k2s_%d.o" % part)])
@@ -91,10 +119,11 @@ def _build_locked(verbose):
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_text.hip", "-o", os.path.join(OBJ, "fh_text.o")])
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_bgzf.hip", "-o", os.path.join(OBJ, "fh_bgzf.o")])
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_api.hip", "-o", os.path.join(OBJ, "fh_api.o")])
+    jobs.append([HIPCC] + FLAGS + ["-c", "fh_batch.hip", "-o", os.path.join(OBJ, "fh_batch.o")])
     jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-c", "fh_host.cpp", "-o", os.path.join(OBJ, "fh_host.o")])
     jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-c", "fh_serial.cpp", "-o", os.path.join(OBJ, "fh_serial.o")])
     with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-        outs = list(ex.map(_run, jobs))
+        outs = list(ex.map(_compile, jobs))
     if verbose:
         for o in outs:
             if o.strip():

@@ -26,6 +26,7 @@
 #include "fh_strip.h"
 #include "fh_device.h"
 #include "fh_kernels.h"
+#include "fh_internal.h"
 
 using namespace fh;
 
@@ -1438,9 +1439,24 @@ uint32_t sat_add(uint32_t a, uint32_t b) {
 
 } // namespace
 
+namespace fh { // fh_internal.h
+int api_fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+hipError_t api_dev_malloc(void **p, size_t bytes) { return dev_malloc(p, bytes); }
+hipError_t api_host_malloc(void **p, size_t bytes) { return host_malloc(p, bytes); }
+void api_kmer_ascii(uint64_t m, uint64_t mhi, int k, uint8_t *out) { kmer_ascii(m, mhi, k, out); }
+} // namespace fh
+
 extern "C" {
 
-int fh_abi_version(void) { return 4; } // 4: fh_sketch_device_blocks, fh_process, fh_debug_fast_path
+int fh_abi_version(void) { return FH_ABI_VERSION; } // (include/finch_hip.h says what each version added)
 
 const char *fh_last_error(void) { return g_err.c_str(); }
 
@@ -1499,6 +1515,7 @@ void fh_release_cached(void) {
         victims.swap(g_pool);
     }
     for (fh_sketcher *s : victims) destroy_handle(s);
+    fh::batch_release_cached(); // (parked batch handles, fh_batch.hip)
 }
 
 static fh_sketcher *new_handle(const fh_params *params, int device);

@@ -150,4 +150,21 @@ struct SketchArgs {
     uint32_t *left_out;      // the same, capacity >= number of waves
 };
 
+// Many files per launch (fh_k2b.hip, fh_batch.hip): one descriptor per file of a batch.  Every file has a control block,
+// table partition and shard lists of its own; the batch's tiles form one tile space that the launch's waves cut into equal
+// contiguous stretches.
+struct BatchFile {
+    const uint8_t *seq;  // the file's packed stream (device), 16-byte aligned; bytes behind `len` are never read as sequence
+    uint64_t len;        // bytes = k-mer start positions
+    Ctl *ctl;            // the file's control block
+    uint64_t tau;        // the one threshold the file is sketched at (EMPTY64: everything is admitted)
+    uint32_t tile0;      // first tile of the file in the batch's tile space
+    uint32_t n_tiles;    // ceil(len / TILE_POS)
+};
+struct BatchArgs {
+    const BatchFile *files;
+    uint32_t n_files, tiles_total, tiles_per_wave, pad;
+    uint64_t seed;
+};
+
 } // namespace fh

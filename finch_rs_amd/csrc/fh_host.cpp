@@ -4,6 +4,7 @@
 //
 // Reference items mirrored (relative to the finch-rs tree) are cited at each function.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -1955,6 +1956,13 @@ static std::atomic<uint64_t> g_gzip_on_device{0}, g_gzip_reread{0};
 // finch_debug_kernel_times: the sketch kernel's own time (HIP events on each worker's stream, fh_kernel_time) over the files
 // this process sketches while it is on -- what a batch's roofline line is made of (bench.py --workload c5)
 static std::atomic<int> g_ktimes_on{0};
+// files of finch_sketch_files calls that the batch path (fh_batch_*) took / handed to a sketcher of their own
+static std::atomic<uint64_t> g_batch_taken{0}, g_batch_not_taken{0};
+// FINCH_FILE_BATCH=0: every file of a batch through a sketcher of its own (A/B, tests)
+static bool file_batch_enabled() {
+    const char *e = getenv("FINCH_FILE_BATCH");
+    return !(e && e[0] == '0');
+}
 static std::atomic<uint64_t> g_ktimes_us{0}, g_ktimes_launches{0}, g_ktimes_positions{0};
 static int fastq_text_to_device(ByteSource &src, fh_sketcher *h, uint32_t k);
 
@@ -2311,6 +2319,42 @@ static int finish_sketch(fh_sketcher *h, const std::string &name, const finch_sk
     return FH_OK;
 }
 
+// FASTA text raw[0, n) (raw[0] == '>') -> its packed stream at dst: the records' sequence regions without their blanks
+// (fh_strip.h), one breaker byte behind every record; st gets the records and total_bases as parse_fastx counts them (a record
+// starts at a line that begins with '>', its sequence region runs to the next such line, internal newlines count --
+// mash.rs:72 --, one trailing line end is trimmed).  false: dst[0, cap) does not hold it (nothing useful written).
+static bool pack_fasta_text(const uint8_t *raw, size_t n, uint8_t *dst, size_t cap, FastxStats &st, size_t &m_out) {
+    size_t pos = 0, m = 0; // pos: at the '>' of a header line
+    while (pos < n) {
+        const uint8_t *nl = (const uint8_t *)memchr(raw + pos, '\n', n - pos);
+        const size_t start = nl ? (size_t)(nl - raw) + 1 : n; // the sequence region begins behind the header line
+        // the next header: a '>' at a line start
+        size_t next = n;
+        for (size_t q = start; q < n;) {
+            const uint8_t *g = (const uint8_t *)memchr(raw + q, '>', n - q);
+            if (!g) break;
+            const size_t at = (size_t)(g - raw);
+            if (at == start || raw[at - 1] == '\n') {
+                next = at;
+                break;
+            }
+            q = at + 1;
+        }
+        const size_t len = next - start;
+        uint64_t trim = 0;
+        if (len >= 1 && raw[next - 1] == '\n') trim = (len >= 2 && raw[next - 2] == '\r') ? 2 : 1;
+        else if (len >= 1 && raw[next - 1] == '\r') trim = 1;
+        st.total_bases += len - trim;
+        st.n_records++;
+        if (m + len + 33 > cap) return false;
+        m += fh_strip::strip(dst + m, raw + start, len);
+        dst[m++] = 0; // the record's breaker
+        pos = next;
+    }
+    m_out = m;
+    return true;
+}
+
 // A plain FASTA file that fits the staging buffer twice over (a genome of a batch: configs[4]) is packed on the HOST, in
 // one pass, while it is staged: the file is read into the upper part of the sketcher's pinned staging buffer and its
 // sequence regions are copied to the front without their blanks (fh_strip.h), one breaker byte per record -- the packed
@@ -2362,36 +2406,11 @@ static int fasta_small_on_host(ByteSource &src, fh_sketcher *h, FastxStats &st) 
         return FH_ERR_STATE;
     }
     st.format = 1;
-    size_t pos = 0, m = 0; // pos: at the '>' of a header line
-    while (pos < n) {
-        const uint8_t *nl = (const uint8_t *)memchr(raw + pos, '\n', n - pos);
-        const size_t start = nl ? (size_t)(nl - raw) + 1 : n; // the sequence region begins behind the header line
-        // the next header: a '>' at a line start
-        size_t next = n;
-        for (size_t q = start; q < n;) {
-            const uint8_t *g = (const uint8_t *)memchr(raw + q, '>', n - q);
-            if (!g) break;
-            const size_t at = (size_t)(g - raw);
-            if (at == start || raw[at - 1] == '\n') {
-                next = at;
-                break;
-            }
-            q = at + 1;
-        }
-        const size_t len = next - start;
-        uint64_t trim = 0;
-        if (len >= 1 && raw[next - 1] == '\n') trim = (len >= 2 && raw[next - 2] == '\r') ? 2 : 1;
-        else if (len >= 1 && raw[next - 1] == '\r') trim = 1;
-        st.total_bases += len - trim;
-        st.n_records++;
-        if (m + len + 33 > cap) { // (cannot happen with n <= hint; a guard in front of the one place that writes)
-            if (!src.rewind()) return hfail(FH_ERR_INVALID, "input grew while it was read");
-            st = FastxStats();
-            return FH_ERR_STATE;
-        }
-        m += fh_strip::strip(buf + m, raw + start, len);
-        buf[m++] = 0; // the record's breaker
-        pos = next;
+    size_t m = 0;
+    if (!pack_fasta_text(raw, n, buf, cap, st, m)) { // (cannot happen with n <= hint; a guard in front of the one place that writes)
+        if (!src.rewind()) return hfail(FH_ERR_INVALID, "input grew while it was read");
+        st = FastxStats();
+        return FH_ERR_STATE;
     }
     if (int rc = fh_push_staged(h, m, 0u)) return hfail(rc, "%s", fh_last_error());
     return FH_OK;
@@ -3481,6 +3500,11 @@ void finch_debug_kernel_times(int enable, double *kernel_ms, uint64_t *launches,
     }
 }
 
+void finch_debug_file_batch(uint64_t *taken, uint64_t *not_taken) {
+    if (taken) *taken = finch::g_batch_taken.load();
+    if (not_taken) *not_taken = finch::g_batch_not_taken.load();
+}
+
 const char *finch_last_error(void) { return g_host_err.c_str(); }
 
 void finch_default_sketch_params(finch_sketch_params *out) {
@@ -3560,35 +3584,193 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
     const char *rt_env = getenv("FINCH_READ_THREADS");
     const unsigned read_total = read_threads_total(rt_env);
     const unsigned read_threads = std::max(1u, read_total / n_threads);
+    // Many files per launch (fh_batch_*, fh_k2b.hip): a worker stages the packed streams of plain FASTA files side by side in
+    // a slot of its batch handle and has them sketched by ONE launch, finished by ONE epilogue launch (a workgroup per file),
+    // behind one copy and in front of one synchronisation -- while it stages the next group in the other slot.  Applies to
+    // what a batch of genomes is: Mash sketches of <= 3000 hashes (after the cut to final_size the small sketcher makes),
+    // k <= 32, no filtering (the default for FASTA, lib.rs:70-76), regular uncompressed files that begin with '>'.
+    // Anything else, and every file the batch path reports as not taken, goes through sketch_stream as before.
+    const uint64_t group_n = (sp->final_size >= 1 && sp->final_size < sp->kmers_to_sketch) ? sp->final_size : sp->kmers_to_sketch;
+    const bool group_ok = batch && sp->kind == 0 && sp->kmer_length >= 1 && sp->kmer_length <= 32 && group_n >= 1 && group_n <= 3000 &&
+                          filters->filter_on <= 0 && file_batch_enabled();
+    constexpr uint64_t GROUP_STAGE = 32ull << 20;
+    constexpr uint32_t GROUP_FILES = 64;
     auto worker = [&](uint32_t w) {
         HandleSet handles;
         handles.full = to_fh(*sp, batch ? ml : single_ml, batch ? (16ull << 20) : single_stage);
         handles.final_size = sp->final_size;
         handles.device = devs[w % devs.size()];
+        auto record_error = [&](uint32_t i, int rc, const std::string &msg) {
+            std::lock_guard<std::mutex> g(err_mu);
+            if (i < first_err_idx) {
+                first_err_idx = i;
+                first_err_code = rc;
+                first_err_msg = msg;
+            }
+        };
+        auto through_sketcher = [&](uint32_t i) { // one file through its own sketcher (sketch_stream, lib.rs:51-94)
+            int rc = FH_OK;
+            std::string msg;
+            const std::string fn = filenames[i];
+            FILE *f = fn == "-" ? stdin : fopen(fn.c_str(), "rb");
+            if (!f) {
+                rc = FH_ERR_INVALID;
+                msg = fn + ": " + strerror(errno) + " (os error " + std::to_string(errno) + ")";
+            } else {
+                rc = sketch_stream(std::make_unique<FileSource>(f, f != stdin, read_threads), fn, *sp, *filters, handles, res->v[i]);
+                if (rc != FH_OK) msg = g_host_err;
+            }
+            if (rc != FH_OK) record_error(i, rc, msg);
+        };
+        // --- the worker's groups ---
+        struct Group {
+            std::vector<uint32_t> idx;
+            std::vector<uint64_t> off, len;
+            std::vector<FastxStats> st;
+            uint64_t fill = 0;
+            bool in_flight = false;
+        } grp[2];
+        fh_batch *bt = nullptr;
+        bool bt_failed = false;
+        int cur = 0;
+        uint8_t *stage[2] = {nullptr, nullptr};
+        uint64_t stage_cap = 0;
+        std::vector<uint8_t> raw; // a file's text as read
+        std::vector<uint8_t> status;
+        auto collect = [&](int slot) { // wait for the group in `slot`, turn its results into Sketches
+            Group &g = grp[slot];
+            if (!g.in_flight) return;
+            g.in_flight = false;
+            status.assign(g.idx.size() + 1, 1);
+            int rc = fh_batch_wait(bt, slot, status.data());
+            for (size_t j = 0; j < g.idx.size(); ++j) {
+                const uint32_t i = g.idx[j];
+                if (rc != FH_OK || status[j] != 0) { // not taken (or the batch failed as a whole): the long way, which is exact for anything
+                    through_sketcher(i);
+                    continue;
+                }
+                uint64_t n = 0, tk = 0;
+                int r2 = fh_batch_result(bt, slot, (uint32_t)j, &n, &tk);
+                const size_t keep = (size_t)std::min<uint64_t>(n, sp->final_size); // process_post_filter (mod.rs:115-128)
+                const uint32_t k = sp->kmer_length;
+                std::unique_ptr<fh_kmer_count[]> recs(new fh_kmer_count[n + 1]);
+                std::unique_ptr<uint8_t[]> km(new uint8_t[n * (size_t)k + 1]);
+                if (r2 == FH_OK) r2 = fh_batch_copy_out_records(bt, slot, (uint32_t)j, recs.get(), km.get());
+                if (r2 != FH_OK) {
+                    record_error(i, r2, fh_last_error());
+                    continue;
+                }
+                const std::string name = filenames[i];
+                if (!sp->no_strict && keep < sp->final_size) {
+                    char buf[512];
+                    snprintf(buf, sizeof buf, "%s had too few kmers (%zu) to sketch", name.c_str(), keep);
+                    record_error(i, FH_ERR_INVALID, buf);
+                    continue;
+                }
+                Sketch &out = res->v[i];
+                out.name = name;
+                out.seq_length = g.st[j].total_bases;
+                out.num_valid_kmers = tk;
+                out.comment = "";
+                out.hashes.resize(keep);
+                for (size_t q = 0; q < keep; ++q)
+                    out.hashes[q] = KmerCount{recs[q].hash, std::string((const char *)km.get() + q * (size_t)k, k), recs[q].count, recs[q].extra_count};
+                out.filter_params = *filters;
+                out.filter_params.filter_on = 0; // lib.rs:70-76: FASTA defaults to no filtering (group_ok: not asked for either)
+                out.sketch_params = *sp;
+            }
+            g.idx.clear();
+            g.off.clear();
+            g.len.clear();
+            g.st.clear();
+            g.fill = 0;
+        };
+        auto submit_cur = [&]() { // hand the current group to the device, go on in the other slot (its previous group collected)
+            Group &g = grp[cur];
+            if (g.idx.empty()) return;
+            if (fh_batch_submit(bt, cur, g.off.data(), g.len.data(), (uint32_t)g.idx.size()) != FH_OK) {
+                for (uint32_t i : g.idx) through_sketcher(i);
+                g.idx.clear(), g.off.clear(), g.len.clear(), g.st.clear();
+                g.fill = 0;
+                return;
+            }
+            g.in_flight = true;
+            cur ^= 1;
+            collect(cur);
+        };
+        auto try_stage = [&](uint32_t i) -> bool { // true: file i is part of the current group
+            if (!group_ok || bt_failed) return false;
+            const char *fn = filenames[i];
+            if (strcmp(fn, "-") == 0) return false;
+            const int fd = open(fn, O_RDONLY | O_CLOEXEC);
+            if (fd < 0) return false; // (sketch_stream reports it)
+            struct stat sb;
+            if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 1 || (uint64_t)sb.st_size + 4096 > GROUP_STAGE) {
+                close(fd);
+                return false;
+            }
+            const size_t size = (size_t)sb.st_size;
+            if (!bt) {
+                fh_params bp = to_fh(*sp, 0);
+                bp.size = group_n;
+                bt = fh_batch_new(&bp, handles.device, GROUP_FILES, GROUP_STAGE);
+                if (bt && (fh_batch_stage(bt, 0, &stage[0], &stage_cap) != FH_OK || fh_batch_stage(bt, 1, &stage[1], &stage_cap) != FH_OK)) {
+                    fh_batch_free(bt);
+                    bt = nullptr;
+                }
+                if (!bt) {
+                    bt_failed = true; // (no memory for it, say: every file the long way)
+                    close(fd);
+                    return false;
+                }
+                if (g_ktimes_on.load(std::memory_order_relaxed)) fh_batch_set_profiling(bt, 1);
+            }
+            if (grp[cur].idx.size() >= GROUP_FILES || grp[cur].fill + size + 64 > stage_cap) submit_cur();
+            if (raw.size() < size + 64) raw.resize(size + 64 + (size >> 2));
+            size_t got = 0;
+            while (got < size) {
+                const ssize_t r = pread(fd, raw.data() + got, size - got, (off_t)got);
+                if (r <= 0) break;
+                got += (size_t)r;
+            }
+            // one byte more than fstat said = the file grew: not for this path
+            uint8_t extra;
+            const bool grew = got == size && pread(fd, &extra, 1, (off_t)size) > 0;
+            close(fd);
+            if (got != size || grew || raw[0] != '>') return false;
+            Group &g = grp[cur];
+            FastxStats st;
+            st.format = 1;
+            size_t m = 0;
+            if (!pack_fasta_text(raw.data(), size, stage[cur] + g.fill, (size_t)(stage_cap - g.fill), st, m)) return false;
+            g.idx.push_back(i);
+            g.off.push_back(g.fill);
+            g.len.push_back(m);
+            g.st.push_back(st);
+            g.fill = (g.fill + m + 15) & ~15ull;
+            return true;
+        };
         for (;;) {
             const uint32_t i = next.fetch_add(1);
             if (i >= n_files) break;
-            int rc = FH_OK;
-            std::string msg;
-            {
-                const std::string fn = filenames[i];
-                FILE *f = fn == "-" ? stdin : fopen(fn.c_str(), "rb");
-                if (!f) {
-                    rc = FH_ERR_INVALID;
-                    msg = fn + ": " + strerror(errno) + " (os error " + std::to_string(errno) + ")";
-                } else {
-                    rc = sketch_stream(std::make_unique<FileSource>(f, f != stdin, read_threads), fn, *sp, *filters, handles, res->v[i]);
-                    if (rc != FH_OK) msg = g_host_err;
+            if (!try_stage(i)) through_sketcher(i);
+        }
+        if (bt) {
+            submit_cur();
+            collect(0);
+            collect(1);
+            if (g_ktimes_on.load(std::memory_order_relaxed)) {
+                double ms = 0;
+                uint64_t nl = 0, np = 0;
+                if (fh_batch_kernel_time(bt, &ms, &nl, &np) == FH_OK) {
+                    g_ktimes_us += (uint64_t)(ms * 1000.0 + 0.5);
+                    g_ktimes_launches += nl;
+                    g_ktimes_positions += np;
                 }
             }
-            if (rc != FH_OK) {
-                std::lock_guard<std::mutex> g(err_mu);
-                if (i < first_err_idx) {
-                    first_err_idx = i;
-                    first_err_code = rc;
-                    first_err_msg = msg;
-                }
-            }
+            uint64_t tk = 0, nt = 0;
+            if (fh_batch_counters(bt, &tk, &nt) == FH_OK) g_batch_taken += tk, g_batch_not_taken += nt;
+            fh_batch_free(bt);
         }
     };
     {

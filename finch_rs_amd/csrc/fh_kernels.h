@@ -42,6 +42,13 @@ hipError_t launch_k2w_part0(int k, const SketchArgs &a, int blocks, hipStream_t 
 hipError_t launch_k2w_part1(int k, const SketchArgs &a, int blocks, hipStream_t st);
 hipError_t launch_k2w_part2(int k, const SketchArgs &a, int blocks, hipStream_t st);
 hipError_t launch_k2w_part3(int k, const SketchArgs &a, int blocks, hipStream_t st);
+// fh_k2b.hip: the batch form of the tile kernel (K = 1..32, any seed): every file of a.files sketched at its own threshold
+// into its own control block, n_waves waves of tiles_per_wave tiles each
+hipError_t launch_k2b_part0(int k, const BatchArgs &a, uint32_t n_waves, hipStream_t st);
+hipError_t launch_k2b_part1(int k, const BatchArgs &a, uint32_t n_waves, hipStream_t st);
+hipError_t launch_k2b_part2(int k, const BatchArgs &a, uint32_t n_waves, hipStream_t st);
+hipError_t launch_k2b_part3(int k, const BatchArgs &a, uint32_t n_waves, hipStream_t st);
+hipError_t launch_k2b(int k, const BatchArgs &a, uint32_t n_waves, hipStream_t st);
 constexpr int FH_MAX_K = 64;
 hipError_t launch_prune_small(Entry *table, uint32_t *live, uint32_t *dead, uint32_t dead_cap, Ctl *ctl, uint32_t kind,
                               uint64_t size, uint64_t max_hash, uint32_t trigger, uint32_t force, uint32_t sort_out,
@@ -77,6 +84,20 @@ struct EpiArgs {
     Ctl *h_ctl;          // pinned host mirror of the control block, written last (or null)
 };
 hipError_t launch_small_epilogue(const EpiArgs &a, hipStream_t st);
+// the epilogue of a batch (fh_batch.hip): workgroup f runs the fused epilogue with args[f] -- flatten, select, sort, the
+// sketch's columns and the mirrored control block to the host, the partition left reset -- and, should that not end in
+// FIN_OK_RESET (an overflow somewhere), sweeps file f's whole partition so that the next batch finds it clean all the same.
+// read_first: what the reset control block's admit path is told (Ctl::read_first).
+hipError_t launch_batch_epilogue(const EpiArgs *args, uint32_t n_files, uint32_t read_first, hipStream_t st);
+// one workgroup per file: table partition filled with empty entries, control block initialised and pointed at the partition
+struct BatchPartition {
+    Ctl *ctl;
+    Entry *table;
+    uint32_t *live, *shard_cnt, *shard_buf;
+    CollRec *clog;
+    uint32_t cap, live_cap, clog_cap, shard_cap;
+};
+hipError_t launch_batch_init(const BatchPartition *parts, uint32_t n_files, uint64_t size, uint32_t read_first, hipStream_t st);
 hipError_t launch_reset_small(Entry *table, const uint32_t *live, const uint32_t *dead, Ctl *ctl, uint64_t tau0, uint64_t sel_size,
                               uint64_t tau_floor, uint32_t hist_on, hipStream_t st);
 hipError_t launch_clear_slots(Entry *table, uint64_t cap, const uint32_t *live, const uint32_t *dead, const Ctl *ctl,

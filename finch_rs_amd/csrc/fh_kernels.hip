@@ -54,6 +54,16 @@ hipError_t launch_k2(int k, const SketchArgs &a, int blocks, hipStream_t st) {
     }
 }
 
+hipError_t launch_k2b(int k, const BatchArgs &a, uint32_t n_waves, hipStream_t st) {
+    if (k < 1 || k > 32) return hipErrorInvalidValue;
+    switch ((k - 1) / (32 / FH_NPARTS)) {
+    case 0: return launch_k2b_part0(k, a, n_waves, st);
+    case 1: return launch_k2b_part1(k, a, n_waves, st);
+    case 2: return launch_k2b_part2(k, a, n_waves, st);
+    default: return launch_k2b_part3(k, a, n_waves, st);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3 (small): single workgroup, bitonic sort of the live hashes in LDS
 // ------------------------------------------------------------------------------------------------
@@ -389,7 +399,7 @@ __global__ __launch_bounds__(1024) void k3_prune_small(Entry *table, u32 *live, 
 static hipError_t small_lds_attr(const void *fn) {
     // function attributes belong to the current device: once per device and kernel, and harmless if two worker threads
     // of the same device both get here first
-    static std::atomic<const void *> done[64][2];
+    static std::atomic<const void *> done[64][4];
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
     if (dev >= 0 && dev < 64)
@@ -426,14 +436,9 @@ hipError_t launch_prune_small(Entry *table, u32 *live, u32 *dead, u32 dead_cap, 
 __device__ __forceinline__ void clear_entry(Entry *e);
 __device__ __forceinline__ void init_ctl_dev(Ctl *ctl, u64 tau0, u32 keep_text_bases, u64 sel_size, u64 tau_floor, u32 hist_on);
 
-__global__ __launch_bounds__(1024) void k_small_epilogue(const EpiArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ u32 s_hist[256];
-    __shared__ u32 s_wsum[16];
-    __shared__ u64 s_bcast[2];
-    __shared__ u32 s_cnt[2];
-    __shared__ u32 s_off[N_SHARDS + 1];
-    __shared__ u32 s_live;
+// (the body of k_small_epilogue and of k_batch_epilogue's workgroups; returns what the gather reported: 0, FIN_OK or FIN_OK_RESET)
+__device__ __forceinline__ u32 small_epilogue_body(const EpiArgs &a, unsigned char *smem, u32 *s_hist, u32 *s_wsum, u64 *s_bcast,
+                                                   u32 *s_cnt, u32 *s_off, u32 &s_live) {
     Ctl *ctl = a.ctl;
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const bool skip = (a.flags & EPI_GATED) && ctl->spec_ok == 0u; // (the launch this follows did nothing: leave everything as it is)
@@ -573,6 +578,83 @@ __global__ __launch_bounds__(1024) void k_small_epilogue(const EpiArgs a) {
         __syncthreads(); // every thread has read the two counts
         init_ctl_dev(ctl, a.tau0, 0u, a.size, 0ull, a.hist_on);
     }
+    return fin;
+}
+
+__global__ __launch_bounds__(1024) void k_small_epilogue(const EpiArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ u32 s_hist[256];
+    __shared__ u32 s_wsum[16];
+    __shared__ u64 s_bcast[2];
+    __shared__ u32 s_cnt[2];
+    __shared__ u32 s_off[N_SHARDS + 1];
+    __shared__ u32 s_live;
+    (void)small_epilogue_body(a, smem, s_hist, s_wsum, s_bcast, s_cnt, s_off, s_live);
+}
+
+// Many sketches per launch (fh_k2b.hip, fh_batch.hip): workgroup f finishes file f of the batch -- the same fused epilogue, F
+// of them side by side on F compute units.  A file whose epilogue did not end in FIN_OK_RESET (more hashes than the LDS
+// selection holds, a full shard list or table partition: the host is told through the mirrored control block and sketches
+// the file the long way) has its whole partition swept here, so that the next batch finds every partition clean.
+__global__ __launch_bounds__(1024) void k_batch_epilogue(const EpiArgs *args, u32 read_first) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ u32 s_hist[256];
+    __shared__ u32 s_wsum[16];
+    __shared__ u64 s_bcast[2];
+    __shared__ u32 s_cnt[2];
+    __shared__ u32 s_off[N_SHARDS + 1];
+    __shared__ u32 s_live;
+    const EpiArgs a = args[blockIdx.x];
+    const u32 fin = small_epilogue_body(a, smem, s_hist, s_wsum, s_bcast, s_cnt, s_off, s_live);
+    Ctl *ctl = a.ctl;
+    if (fin != FIN_OK_RESET) {
+        __syncthreads();
+        const u32 cap = ctl->cap;
+        for (u32 i = threadIdx.x; i < cap; i += 1024u) clear_entry(&a.table[i]);
+        if (threadIdx.x < (u32)N_SHARDS) ctl->shard_cnt[threadIdx.x * SHARD_STRIDE] = 0;
+        __syncthreads();
+        init_ctl_dev(ctl, a.tau0, 0u, a.size, 0ull, a.hist_on);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ctl->read_first = read_first; // (init_ctl_dev leaves it 0; the batch kernel has no queue reset that would set it)
+}
+
+hipError_t launch_batch_epilogue(const EpiArgs *args, uint32_t n_files, uint32_t read_first, hipStream_t st) {
+    if (n_files == 0) return hipSuccess;
+    if (hipError_t e = small_lds_attr(reinterpret_cast<const void *>(k_batch_epilogue)); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_batch_epilogue, dim3(n_files), dim3(1024), SMALL_LDS_BYTES, st, args, read_first);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(1024) void k_batch_init(const BatchPartition *parts, u64 size, u32 read_first) {
+    const BatchPartition p = parts[blockIdx.x];
+    for (u32 i = threadIdx.x; i < p.cap; i += 1024u) clear_entry(&p.table[i]);
+    if (threadIdx.x < (u32)N_SHARDS) p.shard_cnt[threadIdx.x * SHARD_STRIDE] = 0;
+    if (threadIdx.x == 0) {
+        Ctl *ctl = p.ctl;
+        ctl->kmer_hi = nullptr;
+        ctl->table = p.table;
+        ctl->live = p.live;
+        ctl->clog = p.clog;
+        ctl->cap = p.cap;
+        ctl->live_cap = p.live_cap;
+        ctl->clog_cap = p.clog_cap;
+        ctl->shard_cnt = p.shard_cnt;
+        ctl->shard_buf = p.shard_buf;
+        ctl->shard_cap = p.shard_cap;
+        ctl->pad1 = 0;
+        ctl->text_bases = 0;
+    }
+    __syncthreads();
+    init_ctl_dev(p.ctl, EMPTY64, 0u, size, 0ull, 0u);
+    __syncthreads();
+    if (threadIdx.x == 0) p.ctl->read_first = read_first;
+}
+
+hipError_t launch_batch_init(const BatchPartition *parts, uint32_t n_files, uint64_t size, uint32_t read_first, hipStream_t st) {
+    if (n_files == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_batch_init, dim3(n_files), dim3(1024), 0, st, parts, size, read_first);
+    return hipGetLastError();
 }
 
 hipError_t launch_small_epilogue(const EpiArgs &a, hipStream_t st) {

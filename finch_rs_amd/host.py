@@ -109,6 +109,7 @@ _SYMS = {
     "finch_debug_device_inflate": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "finch_debug_device_gzip": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "finch_debug_kernel_times": (None, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "finch_debug_file_batch": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "finch_gzip_probe": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_uint32)]),
     "finch_bgzf_batch_probe": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64),
@@ -429,6 +430,13 @@ def debug_device_gzip():
     """(inputs sketched with plain gzip inflated on the device, inputs re-read through the host inflate) -- test hook"""
     a, b = C.c_uint64(), C.c_uint64()
     lib().finch_debug_device_gzip(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def debug_file_batch():
+    """(files sketched many-per-launch, files the batch path handed to a sketcher of their own) by this process so far"""
+    a, b = C.c_uint64(), C.c_uint64()
+    lib().finch_debug_file_batch(C.byref(a), C.byref(b))
     return a.value, b.value
 
 

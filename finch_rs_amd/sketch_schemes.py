@@ -232,6 +232,95 @@ class HipSketcher:
         return ms.value, n.value, pos.value
 
 
+class BatchSketcher:
+    """Many sketches per launch (include/finch_hip.h, fh_batch_*): the packed streams of a batch of files sketched by one
+    launch, finished by one epilogue launch, one synchronisation -- what a worker of sketch_files (lib.rs:29-49) does with
+    the files it has staged.  Mash, 1..3000 hashes, k <= 32.  `sketch_many(blocks)` -> per block either
+    (records, kmers, first_pos, total_kmers) or None ("not taken": sketch that block through a HipSketcher)."""
+
+    def __init__(self, size: int, kmer_length: int, seed: int = 0, device: int = 0, max_files: int = 64,
+                 stage_bytes: int = 64 << 20):
+        self._L = _lib.load()
+        self.size, self.kmer_length, self.seed, self.device = size, kmer_length, seed, device
+        self.max_files = max_files
+        p = FhParams(KIND_MASH, kmer_length, size, seed, 0.0, 0, 0, 0)
+        self._h = self._L.fh_batch_new(C.byref(p), device, max_files, stage_bytes)
+        if not self._h:
+            raise FinchHipError(-1, (self._L.fh_last_error() or b"").decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fh_batch_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def stage(self, slot: int) -> np.ndarray:
+        """the pinned staging buffer of `slot` as a writable uint8 array"""
+        buf, cap = C.c_void_p(), C.c_uint64()
+        check(self._L.fh_batch_stage(self._h, slot, C.byref(buf), C.byref(cap)))
+        return np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(cap.value,))
+
+    def submit(self, slot: int, offsets, lens) -> None:
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = np.ascontiguousarray(lens, dtype=np.uint64)
+        check(self._L.fh_batch_submit(self._h, slot, o.ctypes.data, n.ctypes.data, len(o)))
+
+    def wait(self, slot: int, n_files: int) -> np.ndarray:
+        st = np.zeros(max(n_files, 1), dtype=np.uint8)
+        check(self._L.fh_batch_wait(self._h, slot, st.ctypes.data))
+        return st[:n_files]
+
+    def result(self, slot: int, i: int):
+        n, tk = C.c_uint64(), C.c_uint64()
+        check(self._L.fh_batch_result(self._h, slot, i, C.byref(n), C.byref(tk)))
+        kc = np.empty(n.value, dtype=KC_DTYPE)
+        km = np.empty((n.value, self.kmer_length), dtype=np.uint8)
+        check(self._L.fh_batch_copy_out_records(self._h, slot, i, kc.ctypes.data, km.ctypes.data))
+        hs = np.empty(n.value, dtype=np.uint64)
+        cs = np.empty(n.value, dtype=np.uint32)
+        es = np.empty(n.value, dtype=np.uint32)
+        km2 = np.empty((n.value, self.kmer_length), dtype=np.uint8)
+        ps = np.empty(n.value, dtype=np.uint64)
+        check(self._L.fh_batch_copy_out(self._h, slot, i, hs.ctypes.data, cs.ctypes.data, es.ctypes.data, km2.ctypes.data, ps.ctypes.data))
+        assert np.array_equal(hs, kc["hash"]) and np.array_equal(cs, kc["count"]) and np.array_equal(es, kc["extra_count"]) and np.array_equal(km, km2)
+        return kc, km, ps, tk.value
+
+    def sketch_many(self, blocks, slot: int = 0):
+        """blocks: packed streams (bytes / uint8 arrays) -> list of result tuples / None, in order; as many batches as it takes"""
+        out = []
+        buf = self.stage(slot)
+        i = 0
+        blocks = [np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b for b in blocks]
+        while i < len(blocks):
+            offs, lens, pos = [], [], 0
+            while i < len(blocks) and len(offs) < self.max_files and pos + len(blocks[i]) <= len(buf):
+                buf[pos:pos + len(blocks[i])] = blocks[i]
+                offs.append(pos)
+                lens.append(len(blocks[i]))
+                pos = (pos + len(blocks[i]) + 15) & ~15
+                i += 1
+            if not offs:
+                raise ValueError("block %d does not fit the staging buffer" % i)
+            self.submit(slot, offs, lens)
+            st = self.wait(slot, len(offs))
+            out += [self.result(slot, j) if st[j] == 0 else None for j in range(len(offs))]
+        return out
+
+    def counters(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(self._L.fh_batch_counters(self._h, C.byref(a), C.byref(b)))
+        return {"taken": a.value, "not_taken": b.value}
+
+    def set_profiling(self, on: bool) -> None:
+        check(self._L.fh_batch_set_profiling(self._h, 1 if on else 0))
+
+    def kernel_time(self):
+        ms, n, pos = C.c_double(), C.c_uint64(), C.c_uint64()
+        check(self._L.fh_batch_kernel_time(self._h, C.byref(ms), C.byref(n), C.byref(pos)))
+        return ms.value, n.value, pos.value
+
+
 class DeviceBuffer:
     """device memory through the C ABI (no torch needed)"""
 

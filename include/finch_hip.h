@@ -66,7 +66,9 @@ typedef struct fh_sketcher fh_sketcher;
 /* number of visible HIP devices (0 if none / runtime unusable) */
 int fh_device_count(void);
 const char *fh_last_error(void);
-/* library/ABI version, bumped on any signature change */
+/* library/ABI version, bumped on any change of this header's functions (5: the batch sketcher, fh_set_option; the round-5
+ * additions fh_set_record_stride, fh_debug_segments, fh_process_records_in, fh_debug_add_counts, fh_debug_gzip_feed_timeouts) */
+#define FH_ABI_VERSION 5
 int fh_abi_version(void);
 
 /* create_sketcher: allocate the device-resident sketch state on `device`. NULL on error. */
@@ -283,6 +285,48 @@ int fh_merge_wire(uint32_t kind, uint64_t size, double scale, uint32_t k, uint64
  * NUMA node their device is attached to where sysfs names one (FH_NO_NUMA_PIN=1: wherever the scheduler puts them). */
 int fh_sketch_device_blocks(fh_sketcher *const *handles, const void *const *dev_blocks, const uint64_t *lens,
                             const uint64_t *stream_offsets, uint32_t n);
+
+/* --- many sketches per launch: a BATCH of files (finch::sketch_files, lib/src/lib.rs:29-49, whose par_iter over the files
+ * -- lib.rs:34-36 -- is the one place the reference is parallel) ---
+ * Through an fh_sketcher a file costs a host-to-device copy, three kernel launches and a synchronisation of its own:
+ * ~150 us of latency-bound device time for the ~6 us a 4 Mb genome takes to hash.  A batch handle sketches ALL the files its
+ * caller has staged with one copy, one launch of the sketch kernel over the files' tiles (fh_k2b.hip), one launch of the
+ * epilogue (a workgroup per file: select, sort, to_vec straight into pinned host memory, state left reset) and one
+ * synchronisation.  Mash sketches of 1..3000 hashes, k = 1..32, any seed; everything else -- and every file the batch path
+ * cannot vouch for -- goes through an fh_sketcher.
+ *
+ *   fh_batch_new(params, device, max_files, stage_bytes)   two slots, each a pinned staging buffer of stage_bytes
+ *   fh_batch_stage(b, slot, &buf, &cap)                    where the caller writes the PACKED streams of its files (the
+ *                                                          format of fh_push_block: sequence bytes, one breaker byte
+ *                                                          behind every record), each at a 16-byte aligned offset
+ *   fh_batch_submit(b, slot, offsets, lens, n)             asynchronous; file i = buf[offsets[i], +lens[i]), offsets ascending
+ *   fh_batch_wait(b, slot, status)                         status[i] = 0: sketch i is ready (fh_batch_result /
+ *                                                          fh_batch_copy_out*); 1: NOT TAKEN -- the file holds fewer than
+ *                                                          `size` distinct k-mers below the threshold it was sketched at
+ *                                                          (low-complexity or tiny input), or two of its k-mers share a
+ *                                                          64-bit hash, or a capacity was exceeded: sketch it through an
+ *                                                          fh_sketcher, which handles all of that.  Never an approximate
+ *                                                          sketch: a taken file's hashes, counts and k-mer bytes are the
+ *                                                          reference's (mash.rs:34-63, 86-102), bit for bit.
+ * The two slots alternate: fill slot 1 while slot 0 is in flight.  A batch handle is single-threaded like an fh_sketcher;
+ * different handles are independent (one per worker thread). */
+typedef struct fh_batch fh_batch;
+fh_batch *fh_batch_new(const fh_params *params, int device, uint32_t max_files, uint64_t stage_bytes);
+void fh_batch_free(fh_batch *b);
+int fh_batch_stage(fh_batch *b, int slot, uint8_t **buf, uint64_t *cap);
+int fh_batch_submit(fh_batch *b, int slot, const uint64_t *offsets, const uint64_t *lens, uint32_t n_files);
+int fh_batch_wait(fh_batch *b, int slot, uint8_t *status);
+/* file i of the batch last waited for in `slot`: hashes retained and valid k-mers seen (mash.rs:35); then the sketch,
+ * ascending by hash, as fh_copy_out / fh_copy_out_records deliver it (any pointer may be NULL) */
+int fh_batch_result(fh_batch *b, int slot, uint32_t i, uint64_t *n_out, uint64_t *total_kmers);
+int fh_batch_copy_out(fh_batch *b, int slot, uint32_t i, uint64_t *hashes, uint32_t *counts, uint32_t *extra_counts, uint8_t *kmers,
+                      uint64_t *first_pos);
+int fh_batch_copy_out_records(fh_batch *b, int slot, uint32_t i, fh_kmer_count *records, uint8_t *kmers);
+/* measurement: HIP events around every batch's sketch launch; their sum, the launches and the positions they covered since
+ * the last call; files taken / not taken since fh_batch_new */
+int fh_batch_set_profiling(fh_batch *b, int enable);
+int fh_batch_kernel_time(fh_batch *b, double *total_ms, uint64_t *launches, uint64_t *positions);
+int fh_batch_counters(fh_batch *b, uint64_t *taken, uint64_t *not_taken);
 
 /* --- measurement support (bench.py) --- */
 /* when enabled, every sketch-kernel launch is bracketed by HIP events on the handle's stream */

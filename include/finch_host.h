@@ -205,6 +205,10 @@ void finch_debug_device_gzip(uint64_t *files_on_device, uint64_t *files_reread);
  * launches and the k-mer start positions they covered over the inputs sketched since it was switched on, then: enable = 1
  * switches it on and zeroes the sums, 0 switches it off, -1 leaves it as it is. */
 void finch_debug_kernel_times(int enable, double *kernel_ms, uint64_t *launches, uint64_t *positions);
+/* files of this process's finch_sketch_files calls that were sketched many-per-launch (fh_batch_*, include/finch_hip.h) and
+ * files the batch path handed to a sketcher of their own instead (not taken: too few distinct k-mers below the batch's
+ * threshold, ...; files that never qualified -- FASTQ, compressed, stdin, huge -- count in neither) */
+void finch_debug_file_batch(uint64_t *taken, uint64_t *not_taken);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ def built():
 def test_header_symbols_all_exported(built):
     hdr = open(os.path.join(ROOT, "include", "finch_hip.h")).read()
     declared = set(re.findall(r"\b(fh_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"fh_sketcher", "fh_params"}
+    declared -= {"fh_sketcher", "fh_params", "fh_batch"}
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     for name in declared:
@@ -39,7 +39,11 @@ def test_host_header_symbols_all_exported(built):
 
 
 def test_abi_version(built):
-    assert built.fh_abi_version() == 4  # 4: fh_sketch_device_blocks, fh_debug_fast_path
+    # the library reports the version its header declares (bumped on any change of the header's functions)
+    hdr = open(os.path.join(ROOT, "include", "finch_hip.h")).read()
+    want = int(re.search(r"#define\s+FH_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert want >= 5
+    assert built.fh_abi_version() == want
 
 
 def test_no_silent_cpu_fallback(built):
