@@ -928,7 +928,7 @@ def measure_extras(F, S, dr, dg, n_reads, dev):
             gz_before = H.debug_device_gzip()
             for key, path, env in (("gzip", gzp, None), ("gzip_host_inflate", gzp, "0"), ("bgzf", bgp, None), ("bgzf_host_inflate", bgp, "0")):
                 if env is not None:
-                    os.environ["FINCH_DEVICE_INFLATE"] = env
+                    F.debug_set(device_inflate=env)
                 try:
                     best = 1e30
                     for _ in range(3):
@@ -937,7 +937,7 @@ def measure_extras(F, S, dr, dg, n_reads, dev):
                         best = min(best, time.perf_counter() - t0)
                         assert H.lib().finch_sketch_seq_length(res._p, 0) == ns * READ_LEN
                 finally:
-                    os.environ.pop("FINCH_DEVICE_INFLATE", None)
+                    F.debug_set(device_inflate=None)
                 out[key + "_gbases_per_s"] = round(ns * READ_LEN / best / 1e9, 3)
                 out[key + "_text_GBps"] = round(len(raw) / best / 1e9, 3)
             out["bgzf_inflated_on_device"] = H.debug_device_inflate()[0] > 0
@@ -967,7 +967,7 @@ def measure_extras(F, S, dr, dg, n_reads, dev):
             paths = [m[0] for m in made]
             tot = sum(m[1] for m in made)
             best = 1e30
-            # (the sketchers the earlier lines parked fill the handle cache -- FH_POOL_BYTES, 24 GiB: with them there, part of this
+            # (the sketchers the earlier lines parked fill the handle cache -- option pool_bytes: with them there, part of this
             # batch's sixteen worker handles would be allocated and pinned anew in every call, which is not what a process that
             # sketches batches does)
             H._lib.load().fh_release_cached()

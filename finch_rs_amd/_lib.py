@@ -31,6 +31,9 @@ SYMBOLS = {
     "fh_device_count": (C.c_int, []),
     "fh_last_error": (C.c_char_p, []),
     "fh_abi_version": (C.c_int, []),
+    "fh_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "fh_get_option": (C.c_char_p, [C.c_char_p]),
+    "fh_option_list": (C.c_char_p, []),
     "fh_new": (_P, [C.POINTER(FhParams), C.c_int]),
     "fh_free": (None, [_P]),
     "fh_release_cached": (None, []),
@@ -133,3 +136,55 @@ def load():
 def check(rc):
     if rc != FH_OK:
         raise FinchHipError(rc, (load().fh_last_error() or b"").decode(errors="replace"))
+
+
+# --- the library's one configuration surface (include/finch_hip.h: fh_set_option, FH_DEBUG; csrc/fh_options.cpp) ---
+def set_option(name: str, value=None) -> None:
+    """process-wide option `name` = value (None: back to "not set"); FinchHipError for a name the library does not know"""
+    check(load().fh_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(name: str):
+    v = load().fh_get_option(name.encode())
+    return None if v is None else v.decode()
+
+
+def option_list():
+    """[(name, what it does)] for every option"""
+    return [tuple(line.split("\t", 1)) for line in load().fh_option_list().decode().splitlines() if line]
+
+
+def _debug_parse(s: str) -> dict:
+    d = {}
+    for item in (s or "").replace(";", ",").replace(" ", ",").split(","):
+        if item:
+            k, _, v = item.partition("=")
+            d[k] = v if _ else "1"
+    return d
+
+
+def debug_env(env=None, **opts) -> dict:
+    """a copy of `env` (default: this process's environment) whose FH_DEBUG -- the ONE environment variable the library reads --
+    carries `opts` on top of what it held (value None removes an option): for child processes of tests and tools"""
+    e = dict(os.environ if env is None else env)
+    d = _debug_parse(e.get("FH_DEBUG", ""))
+    for k, v in opts.items():
+        if v is None:
+            d.pop(k, None)
+        else:
+            d[k] = str(v)
+    if d:
+        e["FH_DEBUG"] = ",".join("%s=%s" % kv for kv in d.items())
+    else:
+        e.pop("FH_DEBUG", None)
+    return e
+
+
+def debug_set(**opts) -> None:
+    """the same on this process's own environment: the library looks at FH_DEBUG whenever it asks for an option, so options
+    that are read per call follow at once (those read once per process / per handle do not: use a child process)"""
+    e = debug_env(**opts)
+    if "FH_DEBUG" in e:
+        os.environ["FH_DEBUG"] = e["FH_DEBUG"]
+    else:
+        os.environ.pop("FH_DEBUG", None)

@@ -45,7 +45,7 @@ if "FH_OUT" in os.environ:  # an A/B build: its objects must not replace those l
 K2WS_FLAGS = os.environ["FH_K2WS_FLAGS"].split() if "FH_K2WS_FLAGS" in os.environ else ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 # ... and the two-word tile kernels: k = 33 / 48 / 64 +3.2 / 2.9 / 3.7 % (FH_NO_SEG=1, profiles/r05W_ab_k2ws_sched.txt), no spills
 K2W_FLAGS = os.environ["FH_K2W_FLAGS"].split() if "FH_K2W_FLAGS" in os.environ else ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
-SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2_common.h", "fh_k2_lds.h", "fh_internal.h", "fh_k2b.hip", "fh_batch.hip", "fh_k2w.hip", "fh_k2.hip", "fh_k2s.hip", "fh_k2ws.hip", "fh_kernels.hip", "fh_big.hip", "fh_text.hip", "fh_bgzf.hip", "fh_api.hip", "fh_host.cpp",
+SOURCES = ["fh_core.h", "fh_device.h", "fh_kernels.h", "fh_k2_common.h", "fh_k2_lds.h", "fh_internal.h", "fh_options.h", "fh_options.cpp", "fh_k2b.hip", "fh_batch.hip", "fh_k2w.hip", "fh_k2.hip", "fh_k2s.hip", "fh_k2ws.hip", "fh_kernels.hip", "fh_big.hip", "fh_text.hip", "fh_bgzf.hip", "fh_api.hip", "fh_host.cpp",
            "fh_host_model.h", "fh_inflate.h", "fh_pargz.h", "fh_serial.cpp", os.path.join("..", "..", "include", "finch_host.h"),
            os.path.join("..", "..", "include", "finch_hip.h")]
 
@@ -122,6 +122,7 @@ def _build_locked(verbose):
     jobs.append([HIPCC] + FLAGS + ["-c", "fh_batch.hip", "-o", os.path.join(OBJ, "fh_batch.o")])
     jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-c", "fh_host.cpp", "-o", os.path.join(OBJ, "fh_host.o")])
     jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-c", "fh_serial.cpp", "-o", os.path.join(OBJ, "fh_serial.o")])
+    jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-c", "fh_options.cpp", "-o", os.path.join(OBJ, "fh_options.o")])
     with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
         outs = list(ex.map(_compile, jobs))
     if verbose:

@@ -27,6 +27,7 @@
 #include "fh_device.h"
 #include "fh_kernels.h"
 #include "fh_internal.h"
+#include "fh_options.h"
 
 using namespace fh;
 
@@ -85,7 +86,7 @@ constexpr uint64_t FIRST_LAUNCH = 4096;
 constexpr uint64_t SMALL_N_MAX = 3000; // largest kmers_to_sketch served by the in-LDS selection alone
 constexpr uint32_t CLOG_CAP = 65536;
 const uint64_t STAGE_BYTES_ENV = [] {
-    const char *e = getenv("FH_STAGE_BYTES"); // test knob: force blocks to span staging slices
+    const char *e = cfg("stage_bytes"); // test knob: force blocks to span staging slices
     const uint64_t v = e ? strtoull(e, nullptr, 10) : 0;
     return v >= 4096 ? v : 0ull;
 }();
@@ -410,7 +411,7 @@ double admit_rate(uint64_t tau) { return tau == EMPTY64 ? 1.0 : ((double)tau + 1
 // all land on a handful of hot entries (k = 8: 1000 entries take 3 % of all positions): there the loads queue behind
 // the atomics on the same lines (103 -> 112 ms) and the launch keeps the plain form; the observed novelty tells.
 uint32_t read_first_of(const fh_sketcher *s) {
-    if (const char *e = getenv("FH_READ_FIRST")) return atoi(e) ? 1u : 0u; // A/B and tests: 0 = never, 1 = always
+    if (const char *e = cfg("read_first")) return atoi(e) ? 1u : 0u; // A/B and tests: 0 = never, 1 = always
     return s->novelty >= 0.02 ? 1u : 0u;
 }
 
@@ -611,7 +612,7 @@ int drain(fh_sketcher *s) {
         s->last_tau = c.tau;
         s->last_live = c.n_live;
         const bool remaining = c.next_unit < s->pend.n_units || c.n_left_out > 0;
-        static const bool trace = getenv("FH_TRACE") != nullptr; // per-launch outcome on stderr (debug aid)
+        static const bool trace = cfg("trace") != nullptr; // per-launch outcome on stderr (debug aid)
         if (trace)
             fprintf(stderr, "[fh] launch %llu: units %u/%u left_in %u left_out %u n_live %u stopped %u tau %.3e soft %u\n",
                     (unsigned long long)s->n_launches, c.next_unit, s->pend.n_units, s->pend.n_left_in, c.n_left_out,
@@ -674,7 +675,7 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
     // an input of a few megabases does not fill the chip with units of two tiles (configs[4]: 4 Mb = 977 of them for 1024
     // SIMDs): single tiles put twice as many waves to work, each for half as long
     static const uint32_t unit_knob = [] {
-        const char *e = getenv("FH_UNIT_TILES"); // A/B knob: 0 = by size
+        const char *e = cfg("unit_tiles"); // A/B knob: 0 = by size
         return e ? (uint32_t)atoi(e) : 0u;
     }();
     r.unit_tiles = unit_knob ? unit_knob : (tiles < (uint64_t)UNIT_TILES * 2 * s->max_waves ? 1u : (uint32_t)UNIT_TILES);
@@ -683,7 +684,7 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
         // a segment tile is 64 x stride positions, about five of k2_sketch's: single tiles are the units, and a pull takes about
         // what eight of k2_sketch's units are (the chip's reads stay inside one moving window of a few hundred megabytes)
         static const uint32_t seg_pull = [] {
-            const char *e = getenv("FH_SEG_PULL_POS"); // A/B knob: positions a pull takes at most
+            const char *e = cfg("seg_pull_pos"); // A/B knob: positions a pull takes at most
             return e ? (uint32_t)atoi(e) : (uint32_t)MAX_UNITS * UNIT_TILES * TILE_POS;
         }();
         if (!unit_knob) r.unit_tiles = 1u;
@@ -701,7 +702,7 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
     // rest.  (Handing a long range out statically is NOT faster, on the contrary: with 4096 waves each streaming through a
     // 12 MB stretch of its own the launch ran at 505-525 Gbases/s against 619 through the queue, which keeps the chip's
     // reads inside one moving window of a few hundred megabytes -- profiles/r04_ab_static_units.txt.)
-    static const bool no_static = getenv("FH_NO_STATIC_UNITS") != nullptr; // A/B knob
+    static const bool no_static = cfg("no_static_units") != nullptr; // A/B knob
     {
         const uint64_t waves = std::max<uint64_t>(1, std::min<uint64_t>(r.n_units, s->max_waves));
         const uint64_t wpb = r.seg ? (uint64_t)seg_waves_per_block((int)s->p.k) : (uint64_t)k2_waves_per_block((int)s->p.k);
@@ -807,30 +808,30 @@ int speculative_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, 
 // hashes live at the end -- everything at or below it is in the table with exact counts and the block is re-read for the
 // hashes above it, exactly like a failed speculation.
 constexpr uint32_t SAMPLE_RUN_TILES_DEFAULT = 8, SAMPLE_ONE_IN_DEFAULT = 64;
-static uint32_t sample_knob(const char *name, uint32_t dflt) { // measurement knobs (FH_SAMPLE_RUN_TILES, FH_SAMPLE_ONE_IN)
-    const char *e = getenv(name);
+static uint32_t sample_knob(const char *name, uint32_t dflt) { // measurement knobs (options sample_run_tiles, sample_one_in)
+    const char *e = cfg(name);
     const long v = e ? atol(e) : 0;
     return v > 0 && v < 65536 ? (uint32_t)v : dflt;
 }
 int sampled_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t base_pos, uint64_t n_pos, bool *attempted,
                         bool *done) {
     *attempted = *done = false;
-    static const bool off = getenv("FH_NO_SAMPLE") != nullptr;
+    static const bool off = cfg("no_sample") != nullptr;
     static const uint64_t min_pos = [] {
-        const char *e = getenv("FH_SAMPLE_MIN_POS"); // test knob
+        const char *e = cfg("sample_min_pos"); // test knob
         return e ? strtoull(e, nullptr, 10) : (256ull << 20);
     }();
     static const double scale_knob = [] {
-        const char *e = getenv("FH_SAMPLE_SCALE"); // test knob: multiply the estimated threshold (< 1 forces the repair pass)
+        const char *e = cfg("sample_scale"); // test knob: multiply the estimated threshold (< 1 forces the repair pass)
         return e ? atof(e) : 1.0;
     }();
     if (off || s->no_spec || s->max_range || s->p.hash_mask || !s->big_mode || s->p.kind != FH_KIND_MASH || s->p.size < 16384 ||
         n_pos < min_pos || (double)n_pos < 64.0 * (double)s->p.size)
         return FH_OK;
-    static const uint32_t run_tiles_knob = sample_knob("FH_SAMPLE_RUN_TILES", 0);
-    static const uint32_t SAMPLE_ONE_IN = sample_knob("FH_SAMPLE_ONE_IN", SAMPLE_ONE_IN_DEFAULT);
+    static const uint32_t run_tiles_knob = sample_knob("sample_run_tiles", 0);
+    static const uint32_t SAMPLE_ONE_IN = sample_knob("sample_one_in", SAMPLE_ONE_IN_DEFAULT);
     static const double cap_knob = [] {
-        const char *e = getenv("FH_SAMPLE_CAP_SCALE"); // measurement knob: scales the sample pass's cap threshold
+        const char *e = cfg("sample_cap_scale"); // measurement knob: scales the sample pass's cap threshold
         return e ? atof(e) : 1.0;
     }();
     const uint64_t tiles = (n_pos + TILE_POS - 1) / TILE_POS;
@@ -927,7 +928,7 @@ int sampled_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
     // lower one, left up to 1.49 x size entries live where 1.25 x was asked for: round 2's configs[2].)  The estimator
     // (Chao1: seen + singletons^2 / 2 doubletons) errs low, i.e. towards a threshold that is too high, never too tight.
     static const double want_factor = [] {
-        const char *e = getenv("FH_SAMPLE_WANT"); // A/B knob
+        const char *e = cfg("sample_want"); // A/B knob
         return e ? std::max(1.0, atof(e)) : 1.15;
     }();
     const uint32_t *H = s->h_smp_hist;
@@ -954,7 +955,7 @@ int sampled_first_block(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
     }
     if (tau_guess || cap_frac >= 0.25) break;
     }
-    static const bool trace = getenv("FH_TRACE") != nullptr;
+    static const bool trace = cfg("trace") != nullptr;
     if (trace)
         fprintf(stderr, "[fh] sample: %llu runs of %u tiles, cap %.3e: S %.0f c1 %.0f c2 %.0f -> tau %.3e (%s)\n",
                 (unsigned long long)n_runs, SAMPLE_RUN_TILES, (double)tau_cap, S, c1, c2, (double)tau_guess, tau_guess ? "guess" : "none");
@@ -992,22 +993,22 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
     s->gran = TILE_POS;
     bool probe_behind = false;
     {
-        static const bool seg_off = getenv("FH_NO_SEG") != nullptr; // A/B knob
+        static const bool seg_off = cfg("no_seg") != nullptr; // A/B knob
         // A block is asked for its stride BEHIND its own launches, without a wait (the answer lands in pinned memory): what
         // the last block this handle asked said is what the next one goes by -- the blocks of one input, or the passes over one
         // buffer, share their read length, and a stale or wrong stride costs speed, never the result.  Only a handle that has
         // not asked yet waits for the answer (one wavefront and a round trip, ~0.1-0.3 ms), and only for a block large enough
         // not to notice.
         static const uint64_t probe_min = [] {
-            const char *e = getenv("FH_SEG_PROBE_MIN"); // test knob: blocks from this size on are asked (behind their launches)
+            const char *e = cfg("seg_probe_min"); // test knob: blocks from this size on are asked (behind their launches)
             return e ? strtoull(e, nullptr, 10) : (16ull << 20);
         }();
         static const uint64_t probe_wait_min = [] {
-            const char *e = getenv("FH_SEG_PROBE_WAIT_MIN"); // test knob: ... and waited for, if the handle has no answer yet
+            const char *e = cfg("seg_probe_wait_min"); // test knob: ... and waited for, if the handle has no answer yet
             return e ? strtoull(e, nullptr, 10) : (256ull << 20);
         }();
         static const uint32_t seg_env = [] {
-            const char *e = getenv("FH_SEG_STRIDE"); // test knob: every block through the segment kernel with this stride
+            const char *e = cfg("seg_stride"); // test knob: every block through the segment kernel with this stride
             return e ? (uint32_t)atoi(e) : 0u;
         }();
         uint32_t S = seg_env ? seg_env : s->seg_hint;
@@ -1118,7 +1119,7 @@ int sketch_positions(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_
 // 12 ms for 40 M positions where the pass itself takes 0.1), but up to a threshold scaled by how far short the count fell
 // -- the density of distinct hashes is known now --, and only if that too comes up short for everything.
 int reread_above(fh_sketcher *s, const uint8_t *seq, uint64_t len, uint64_t base_pos, uint64_t p_begin, uint64_t p_end, uint64_t lo) {
-    const bool no_scale = getenv("FH_NO_SPEC_RESCALE") != nullptr; // A/B (read per call: a rare path)
+    const bool no_scale = cfg("no_spec_rescale") != nullptr; // A/B (read per call: a rare path)
     for (int attempt = 0;; ++attempt) {
         uint64_t hi = EMPTY64;
         const uint64_t have = s->last_live;
@@ -1132,7 +1133,7 @@ int reread_above(fh_sketcher *s, const uint8_t *seq, uint64_t len, uint64_t base
         if (int rc = drain(s)) return rc;
         if (hi == EMPTY64) return FH_OK;
         s->n_spec_rescaled++;
-        static const bool trace = getenv("FH_TRACE") != nullptr;
+        static const bool trace = cfg("trace") != nullptr;
         if (trace) fprintf(stderr, "[fh] speculation fell short (%llu of %llu hashes at or below %.3e): range read again up to %.3e\n", (unsigned long long)have,
                            (unsigned long long)s->p.size, (double)lo, (double)hi);
         HIP_TRY(launch_prune_small(s->table, s->live, s->dead, s->dead_cap, s->ctl, s->p.kind, s->p.size, s->max_hash, 0u, 1u, 0u, s->stream));
@@ -1217,7 +1218,7 @@ int big_prune(fh_sketcher *s, bool sorted) {
     if (int rc = check_ctl(s)) return rc;
     const uint32_t M = s->h_ctl->n_live;
     if (int rc = ensure_big_buffers(s, M)) return rc;
-    static const bool no_select = getenv("FH_NO_SELECT") != nullptr; // A/B and debugging: always sort
+    static const bool no_select = cfg("no_select") != nullptr; // A/B and debugging: always sort
     if (!sorted && !no_select && s->p.size >= 1)
         HIP_TRY(launch_big_prune_select(s->table, s->live, s->dead, s->dead_cap, s->ctl, M, s->h_ctl->n_dead, s->p.kind,
                                         s->p.size, s->max_hash, s->keys_a, s->slots_a, (char *)s->keep_dev + 64,
@@ -1320,7 +1321,7 @@ template <class F>
 void parallel_for(size_t n, F f) {
     const size_t MIN_PER_THREAD = 1u << 16;
     static const unsigned cap = [] {
-        const char *e = getenv("FH_HOST_THREADS"); // 1 = always inline
+        const char *e = cfg("host_threads"); // 1 = always inline
         const unsigned v = e ? (unsigned)atoi(e) : 8u;
         return v ? v : 1u;
     }();
@@ -1456,6 +1457,14 @@ void api_kmer_ascii(uint64_t m, uint64_t mhi, int k, uint8_t *out) { kmer_ascii(
 
 extern "C" {
 
+int fh_set_option(const char *name, const char *value) {
+    if (!name) return fail(FH_ERR_INVALID, "null option name");
+    if (cfg_assign(name, value) != 0) return fail(FH_ERR_INVALID, "no such option: %s (fh_option_list names them)", name);
+    return FH_OK;
+}
+const char *fh_get_option(const char *name) { return name && cfg_known(name) ? cfg(name) : nullptr; }
+const char *fh_option_list(void) { return cfg_list(); }
+
 int fh_abi_version(void) { return FH_ABI_VERSION; } // (include/finch_hip.h says what each version added)
 
 const char *fh_last_error(void) { return g_err.c_str(); }
@@ -1478,18 +1487,25 @@ std::mutex g_pool_mu;
 std::vector<fh_sketcher *> g_pool;
 size_t pool_max() {
     static const size_t v = [] {
-        const char *e = getenv("FH_POOL");
+        const char *e = cfg("pool");
         return e ? (size_t)strtoul(e, nullptr, 10) : (size_t)64;
     }();
     return v;
 }
-// device memory the parked handles may hold together (FH_POOL_BYTES, default 24 GiB: room for the sixteen worker sketchers
+// device memory the parked handles may hold together (option pool_bytes; default 24 GiB or a tenth of the device, whichever is
+// less: room for the sixteen worker sketchers
 // per GPU of a finch_sketch_files batch, small next to 288 GB, and given back the moment any allocation of the library
 // would otherwise fail -- dev_malloc above; an embedding process that wants it all back calls fh_release_cached)
 uint64_t pool_max_bytes() {
     static const uint64_t v = [] {
-        const char *e = getenv("FH_POOL_BYTES");
-        return e ? (uint64_t)strtoull(e, nullptr, 10) : (24ull << 30);
+        if (const char *e = cfg("pool_bytes")) return (uint64_t)strtoull(e, nullptr, 10);
+        // (a tenth of the current device at most: an embedding process -- PyTorch, RCCL in bench.py -- shares the device with
+        // an allocator that cannot ask this library to let go)
+        size_t free_b = 0, total_b = 0;
+        uint64_t cap = 24ull << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) cap = std::min<uint64_t>(cap, (uint64_t)total_b / 10);
+        else (void)hipGetLastError();
+        return cap;
     }();
     return v;
 }
@@ -1532,14 +1548,14 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
                 s->n_spec = s->n_spec_fallback = s->n_sampled = s->n_spec_rescaled = 0;
                 s->profiling = false;
                 // the environment knobs a handle reads at creation are the new owner's to set
-                s->no_spec = getenv("FH_NO_SPEC") != nullptr;
+                s->no_spec = cfg("no_spec") != nullptr;
                 s->n_fast_finish = s->n_spec_deferred = s->n_spec_recovered = 0;
                 s->n_seg_launches = s->n_seg_probes = 0;
                 s->seg_hint = 0;
                 s->probe_seen = false; // (the previous owner's reads say nothing about the new one's)
                 {
-                    const bool fast = !s->big_mode && getenv("FH_NO_FAST") == nullptr;
-                    const bool hist = fast && s->p.size > 0 && getenv("FH_NO_HIST") == nullptr;
+                    const bool fast = !s->big_mode && cfg("no_fast") == nullptr;
+                    const bool hist = fast && s->p.size > 0 && cfg("no_hist") == nullptr;
                     if (fast != s->fast || hist != s->hist) { // (the control block was initialised for the previous owner's setting)
                         s->fast = fast;
                         s->hist = hist;
@@ -1550,7 +1566,7 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
                     }
                 }
                 {
-                    const char *mr = getenv("FH_MAX_RANGE");
+                    const char *mr = cfg("max_range");
                     s->max_range = mr ? strtoull(mr, nullptr, 10) : 0;
                 }
                 return s;
@@ -1618,14 +1634,14 @@ static fh_sketcher *new_handle(const fh_params *params, int device) {
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     s->big_mode = params->kind == FH_KIND_SCALED || params->size > SMALL_N_MAX;
-    s->fast = !s->big_mode && getenv("FH_NO_FAST") == nullptr;
-    s->hist = s->fast && params->size > 0 && getenv("FH_NO_HIST") == nullptr;
+    s->fast = !s->big_mode && cfg("no_fast") == nullptr;
+    s->hist = s->fast && params->size > 0 && cfg("no_hist") == nullptr;
     s->live_target = s->big_mode ? std::max<uint64_t>(4 * params->size, 1ull << 16) : (uint64_t)SMALL_MAX;
     // the table can never fill: waves stop pulling work at soft_limit (<= live_target) and each of the
     // max_waves resident waves can insert at most WAVE_OVERSHOOT (a tile's or a long round's positions) after that
     {
         static const uint64_t waves_per_cu = [] {
-            const char *e = getenv("FH_WAVES_PER_CU"); // tuning knob
+            const char *e = cfg("waves_per_cu"); // tuning knob
             return e ? (uint64_t)atoi(e) : 16ull; // what is resident at 4 waves per SIMD; 32 measured 1.4 % slower
         }();
         s->max_waves = std::max<uint64_t>(1, std::min<uint64_t>(256ull * waves_per_cu, s->max_launch / TILE_POS));
@@ -1635,7 +1651,7 @@ static fh_sketcher *new_handle(const fh_params *params, int device) {
         // (... and the segment kernels' workgroups, which a block of equal reads brings in whatever K: sixteen waves for K <= 32)
         const uint64_t wpb = std::max<uint64_t>((uint64_t)k2_waves_per_block((int)params->k), (uint64_t)seg_waves_per_block((int)params->k));
         s->max_waves = std::max<uint64_t>(wpb, s->max_waves / wpb * wpb);
-        const char *mr = getenv("FH_MAX_RANGE"); // test knob: force many ranges per push
+        const char *mr = cfg("max_range"); // test knob: force many ranges per push
         s->max_range = mr ? strtoull(mr, nullptr, 10) : 0;
     }
     const uint64_t live_cap = s->live_target + s->max_waves * (uint64_t)(WAVE_BUDGET + WAVE_OVERSHOOT) + 4096;
@@ -1661,7 +1677,7 @@ static fh_sketcher *new_handle(const fh_params *params, int device) {
             return bail("hipMalloc(left)", e);
     if ((e = hipMalloc(&s->clog, CLOG_CAP * sizeof(CollRec))) != hipSuccess) return bail("hipMalloc(clog)", e);
     if ((e = hipHostMalloc(&s->h_ctl, sizeof(Ctl), hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
-    s->no_spec = getenv("FH_NO_SPEC") != nullptr;
+    s->no_spec = cfg("no_spec") != nullptr;
 
     if ((e = launch_fill_table(s->table, cap, s->stream)) != hipSuccess) return bail("fill_table", e);
     if (alloc_shards(s, s->live_target) != FH_OK) {
@@ -1950,7 +1966,7 @@ int fh_push_device(fh_sketcher *s, const void *dev_bytes, uint64_t len) {
 // every share to its place (one thread strips ~5 GB/s, a third of what the copy to the device behind it moves).
 static uint64_t strip_block(uint8_t *dst, const uint8_t *src, uint64_t n) {
     static const unsigned cap = [] {
-        const char *e = getenv("FH_HOST_THREADS"); // 1 = always inline
+        const char *e = cfg("host_threads"); // 1 = always inline
         const unsigned v = e ? (unsigned)atoi(e) : 8u;
         return v ? v : 1u;
     }();
@@ -2397,7 +2413,7 @@ static void free_gzip_buffers(fh_sketcher *s) {
     s->gz_chunks_cap = 0;
 }
 static uint64_t gz_chunk_bytes(const fh_sketcher *s) {
-    if (const char *e = getenv("FH_GZ_CHUNK")) return std::max<uint64_t>(1024, strtoull(e, nullptr, 10) & ~7ull); // (tests: many chunks in a small input)
+    if (const char *e = cfg("gz_chunk")) return std::max<uint64_t>(1024, strtoull(e, nullptr, 10) & ~7ull); // (tests: many chunks in a small input)
     const uint64_t most = s->gz_base + s->stage_bytes;
     return std::max<uint64_t>(GZ_CHUNK_BYTES, ((most + GZ_MAX_CHUNKS - 1) / GZ_MAX_CHUNKS + 4095) & ~(uint64_t)4095);
 }
@@ -2435,7 +2451,7 @@ static int ensure_gzip_buffers(fh_sketcher *s) {
     HIP_TRY(dev_malloc((void **)&s->gz_win_in, (size_t)n * GZ_WINDOW));
     HIP_TRY(dev_malloc((void **)&s->gz_live, (size_t)n * 4 * sizeof(uint32_t)));
     HIP_TRY(dev_malloc((void **)&s->gz_claims, (size_t)n * sizeof(uint32_t)));
-    if (getenv("FH_GZ_TIMES")) HIP_TRY(dev_malloc((void **)&s->gz_times, (size_t)n * 3 * sizeof(uint64_t)));
+    if (cfg("gz_times")) HIP_TRY(dev_malloc((void **)&s->gz_times, (size_t)n * 3 * sizeof(uint64_t)));
     s->gz_chunks_cap = n;
     HIP_TRY(dev_malloc((void **)&s->gz_group_map, (size_t)GZ_GROUPS * GZ_WINDOW * sizeof(uint16_t)));
     HIP_TRY(dev_malloc((void **)&s->gz_group_win, (size_t)GZ_GROUPS * GZ_WINDOW));
@@ -2533,7 +2549,7 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
         GzFeed *f = s->h_gz_feed;
         __atomic_store_n(&f->avail, n_bytes, __ATOMIC_RELEASE);
         if (!more) __atomic_store_n(&f->state, (flags & FH_GZ_LAST) ? 2u : 1u, __ATOMIC_RELEASE);
-        static const bool trace_pieces = getenv("FH_TRACE") != nullptr;
+        static const bool trace_pieces = cfg("trace") != nullptr;
         if (trace_pieces) {
             const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
             fprintf(stderr, "[fh] gzip piece: %llu bytes of the batch on the device %.2f ms after its first push%s\n", (unsigned long long)n_bytes,
@@ -2609,7 +2625,7 @@ int fh_push_gzip_fastq(fh_sketcher *s, uint64_t bytes, uint32_t flags, uint32_t 
     const uint64_t total = S[GZS_TOTAL];
     const uint64_t end_bit = S[GZS_END_BIT_LO] | ((uint64_t)S[GZS_END_BIT_HI] << 32);
     const uint32_t end_state = S[GZS_END_STATE];
-    static const bool trace = getenv("FH_TRACE") != nullptr;
+    static const bool trace = cfg("trace") != nullptr;
     if (trace)
         fprintf(stderr, "[fh] gzip batch: text there %.2f ms after the batch's first push\n",
                 (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - s->gz_t0) * 1e3);
@@ -2804,7 +2820,7 @@ static int ensure_records(fh_sketcher *s) {
 int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
     if (!s) return fail(FH_ERR_INVALID, "null handle");
     if (int rc = set_device(s)) return rc;
-    static const bool trace = getenv("FH_TRACE") != nullptr;
+    static const bool trace = cfg("trace") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
@@ -2833,7 +2849,7 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         if (s->fast) {
             if (int rc = ensure_out(s, (uint32_t)std::min<uint64_t>(s->p.size + 1, SMALL_MAX))) return rc;
             if (int rc = ensure_h_out(s->out_stride * (wide ? 40 : 32) + 64)) return rc;
-            static const bool no_fold = getenv("FH_NO_RESET_FOLD") != nullptr; // A/B knob
+            static const bool no_fold = cfg("no_reset_fold") != nullptr; // A/B knob
             // (the last launch's own epilogue folded in; EPI_RESET: if all went as queued the handle is left reset)
             EpiArgs e = epi_args(s, s->epi_pending | EPI_PRUNE_FORCE | EPI_SORT | EPI_GATHER | (s->spec.pending ? EPI_NEED_SPEC : 0u) |
                                         (no_fold ? 0u : EPI_RESET));
@@ -2894,7 +2910,7 @@ int fh_finish(fh_sketcher *s, uint64_t *n_out, uint64_t *total_kmers) {
         uint32_t *cc = (uint32_t *)(pp + cap + (wide ? cap : 0)), *ee = cc + cap;
         // (nothing on the host side of this function needs the wide columns of a Mash sketch without collisions and without
         //  the special hash: the final selection is "the first `size`")
-        static const bool lazy_off = getenv("FH_NO_LAZY_COPYOUT") != nullptr; // A/B knob
+        static const bool lazy_off = cfg("no_lazy_copyout") != nullptr; // A/B knob
         s->wide_pending = !lazy_off && !one_copy && n >= (1u << 17) && s->p.kind == FH_KIND_MASH && c.n_coll == 0 && c.sp_count == 0;
         if (fused) {
             // (the columns are there already)
@@ -3264,7 +3280,7 @@ class BlockTeam {
     // changes if sysfs does not say (numa_node -1 or absent), and the caller's own thread is never touched.
     static void sit_near(int device) {
         static thread_local int sitting = -1;
-        if (sitting == device || getenv("FH_NO_NUMA_PIN")) return;
+        if (sitting == device || cfg("no_numa_pin")) return;
         sitting = device;
         char bdf[32] = {0};
         if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) return;

@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "fh_core.h"
+#include "fh_options.h"
 #include "fh_kernels.h"
 
 namespace fh {
@@ -1925,7 +1926,7 @@ hipError_t launch_bgzf_inflate(const uint8_t *comp, const BgzfMember *members, u
                                uint32_t *status, hipStream_t st) {
     if (n_members == 0) return hipSuccess;
     const X2N &x2n = x2n_table();
-    static const bool serial = getenv("FH_BGZF_SERIAL") != nullptr; // A/B: one symbol at a time
+    static const bool serial = cfg("bgzf_serial") != nullptr; // A/B: one symbol at a time
     if (serial) hipLaunchKernelGGL(k_bgzf_inflate<false>, dim3(n_members), dim3(64), 0, st, comp, members, n_members, text, status);
     else hipLaunchKernelGGL(k_bgzf_inflate<true>, dim3(n_members), dim3(64), 0, st, comp, members, n_members, text, status);
     hipLaunchKernelGGL(k_bgzf_crc, dim3((n_members + 3u) / 4u), dim3(256), 0, st, members, n_members, (const uint8_t *)text,

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "fh_host_model.h"
+#include "fh_options.h"
 #include "fh_inflate.h"
 #include "fh_pargz.h"
 #include "fh_strip.h"
@@ -51,6 +52,7 @@ static void fork_join(unsigned n, J job) {
 }
 
 namespace finch {
+using fh::cfg;
 
 thread_local std::string g_host_err;
 
@@ -646,7 +648,7 @@ static unsigned read_threads_total(const char *env) {
 }
 static bool use_zlib_inflate() {
     static const bool v = [] {
-        const char *e = getenv("FINCH_ZLIB_INFLATE");
+        const char *e = cfg("zlib_inflate");
         return e && e[0] == '1';
     }();
     return v;
@@ -932,7 +934,7 @@ struct BgzfSource : ByteSource {
     static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     ~BgzfSource() override {
         if (pending.valid()) pending.wait();
-        static const bool trace = getenv("FH_TRACE") != nullptr;
+        static const bool trace = cfg("trace") != nullptr;
         if (trace && n_batches)
             fprintf(stderr, "[finch] bgzf: %llu batches, %llu members, %u threads: read %.1f ms, scan %.1f ms, inflate %.1f ms\n",
                     (unsigned long long)n_batches, (unsigned long long)n_members, n_thr, t_read * 1e3, t_scan * 1e3, t_inflate * 1e3);
@@ -1263,13 +1265,13 @@ struct ParGzSource : ByteSource {
 
     ParGzSource(std::unique_ptr<ByteSource> in, unsigned threads) : inner(std::move(in)), n_thr(std::max(2u, threads)) {
         rewindable = inner && inner->can_rewind();
-        const char *e = getenv("FINCH_PARGZ_CHUNK");
+        const char *e = cfg("pargz_chunk");
         chunk_bytes = e ? (size_t)std::max(4096ll, atoll(e)) : ((size_t)1 << 20);
     }
     ~ParGzSource() override {
         drop_prefetch();
         for (auto &c : ready) recycle(c);
-        static const bool trace = getenv("FH_TRACE") != nullptr;
+        static const bool trace = cfg("trace") != nullptr;
         if (trace && n_batches)
             fprintf(stderr, "[finch] parallel gzip: %llu batches, %llu chunks (%llu false starts), %.1f %% of the text decoded with markers, %u threads%s\n",
                     (unsigned long long)n_batches, (unsigned long long)n_chunks, (unsigned long long)n_false_starts,
@@ -1455,7 +1457,7 @@ struct ParGzSource : ByteSource {
             i = j;
         }
         n_chunks += live.size();
-        if (getenv("FH_TRACE_PARGZ"))
+        if (cfg("trace_pargz"))
             for (size_t li : live)
                 fprintf(stderr, "[pargz] batch %llu chunk %zu: bits %llu..%llu text %zu (+%zu sym) ok %d end %d ooi %d\n", (unsigned long long)n_batches, li,
                         (unsigned long long)ch[li].start_bit, (unsigned long long)ch[li].end_bit, ch[li].n_bytes, ch[li].n_sym, ch[li].ok,
@@ -1658,7 +1660,7 @@ struct ParGzSource : ByteSource {
 
 static std::unique_ptr<ByteSource> make_gzip_reader(std::unique_ptr<ByteSource> in, unsigned threads) {
     if (use_zlib_inflate()) return std::make_unique<GzSource>(std::move(in));
-    const char *e = getenv("FINCH_PARGZ");
+    const char *e = cfg("pargz");
     if (threads > 1 && !(e && e[0] == '0')) return std::make_unique<ParGzSource>(std::move(in), threads);
     return std::make_unique<FastGzSource>(std::move(in));
 }
@@ -1681,7 +1683,7 @@ static int open_source(std::unique_ptr<ByteSource> raw, std::unique_ptr<ByteSour
     // threads the decompressor may use: what the source was given (finch_sketch_files shares FINCH_READ_THREADS
     // among its workers); FINCH_BGZF_THREADS overrides it (tests, in-memory inputs)
     unsigned dec_threads = raw->threads_hint();
-    if (const char *e = getenv("FINCH_BGZF_THREADS")) dec_threads = (unsigned)std::max(1, atoi(e));
+    if (const char *e = cfg("bgzf_threads")) dec_threads = (unsigned)std::max(1, atoi(e));
     pre->inner = std::move(raw);
     if (is_gz) *is_gz = gz;
     if (first_byte) *first_byte = got ? pre->prefix[0] : -1;
@@ -1691,7 +1693,7 @@ static int open_source(std::unique_ptr<ByteSource> raw, std::unique_ptr<ByteSour
     // (FINCH_GZ_FRONT=1, A/B: the reader that knows BGZF and hands compressed bytes to the device stands in front of gzip
     //  input even when the call has no read thread to spare for it -- the workers of a many-file call)
     static const bool front_always = [] {
-        const char *e = getenv("FINCH_GZ_FRONT");
+        const char *e = cfg("gz_front");
         return e && e[0] == '1';
     }();
     if (gz && (dec_threads > 1 || (front_always && !use_zlib_inflate()))) out = std::make_unique<BgzfSource>(std::move(pre), dec_threads); // falls back member by member
@@ -1737,7 +1739,7 @@ struct DeviceSink : RecordSink {
     bool continuing = false; // the block starts inside a record that an earlier commit cut
     bool in_record = false;
     explicit DeviceSink(fh_sketcher *h_) : h(h_) {
-        const char *e = getenv("FINCH_BLOCK_BYTES"); // test knob: force records to span blocks
+        const char *e = cfg("block_bytes"); // test knob: force records to span blocks
         limit = e ? strtoull(e, nullptr, 10) : 0;
     }
     int acquire() {
@@ -1927,7 +1929,7 @@ static int parse_fastx(ByteSource &src, RecordSink &sink, FastxStats &st) {
 // sketch_stream (lib.rs:51-94)
 // ---------------------------------------------------------------------------------------------
 static uint64_t env_max_launch_value() {
-    const char *e = getenv("FINCH_MAX_LAUNCH");
+    const char *e = cfg("max_launch");
     return e ? strtoull(e, nullptr, 10) : 0;
 }
 
@@ -1960,7 +1962,7 @@ static std::atomic<int> g_ktimes_on{0};
 static std::atomic<uint64_t> g_batch_taken{0}, g_batch_not_taken{0};
 // FINCH_FILE_BATCH=0: every file of a batch through a sketcher of its own (A/B, tests)
 static bool file_batch_enabled() {
-    const char *e = getenv("FINCH_FILE_BATCH");
+    const char *e = cfg("file_batch");
     return !(e && e[0] == '0');
 }
 static std::atomic<uint64_t> g_ktimes_us{0}, g_ktimes_launches{0}, g_ktimes_positions{0};
@@ -2154,7 +2156,7 @@ static int finish_mash_in_place(fh_sketcher *h, const std::string &name, const f
     uint64_t n_view = 0;
     if (fh_result_counts(h, &cnt, &ext, &n_view) != FH_OK || n_view != n) return FH_ERR_STATE;
     const bool filter_on = fp.filter_on == 1;
-    static const bool trace = getenv("FH_TRACE") != nullptr;
+    static const bool trace = cfg("trace") != nullptr;
     auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tt0 = trace ? now_ms() : 0;
     double tt1 = 0, tt2 = 0, tt3 = 0;
@@ -2423,7 +2425,7 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     int first = -1;
     if (int rc = open_source(std::move(raw), src, &is_gz, &first)) return rc;
     FastxStats st;
-    const char *dp = getenv("FINCH_DEVICE_PARSE");
+    const char *dp = cfg("device_parse");
     // FINCH_DEVICE_PARSE: unset = plain FASTA and FASTQ text is split on the device (FASTQ with the host parser as the
     // fallback, see below); 1 = on the device, no fallback; 0 = on the host.  Compressed input is inflated on the host
     // and its text treated the same way.
@@ -2432,7 +2434,7 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     // fallback whenever the device pass refuses the file); 0 = always on the host
     BgzfSource *bgzf_dev = nullptr;
     if (is_gz && !dp_off) {
-        const char *di = getenv("FINCH_DEVICE_INFLATE");
+        const char *di = cfg("device_inflate");
         BgzfSource *bz = dynamic_cast<BgzfSource *>(src.get());
         if (bz && !(di && di[0] == '0') && src->can_rewind() && bz->peek_first_text_byte() == '@') bgzf_dev = bz;
     }
@@ -2440,7 +2442,7 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     bool gzip_dev = false;
     size_t gzip_hdr = 0;
     if (is_gz && !dp_off && !bgzf_dev) {
-        const char *di = getenv("FINCH_DEVICE_INFLATE"), *dg = getenv("FINCH_DEVICE_GZIP");
+        const char *di = cfg("device_inflate"), *dg = cfg("device_gzip");
         BgzfSource *bz = dynamic_cast<BgzfSource *>(src.get());
         if (bz && !(di && di[0] == '0') && !(dg && dg[0] == '0') && src->can_rewind() && bz->peek_plain_gzip(&gzip_hdr) == '@') gzip_dev = true;
     }
@@ -2460,7 +2462,7 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     // which sketcher: needletail takes the format from the first byte, and the format decides the filtering default
     const int filter_on_eff = filters.filter_on < 0 ? (first == '@' ? 1 : 0) : filters.filter_on;
     const bool small = (first == '>' || first == '@') && sp.kind == 0 && filter_on_eff == 0 && sp.final_size >= 1 &&
-                       sp.final_size < sp.kmers_to_sketch && getenv("FINCH_NO_SMALL_SKETCHER") == nullptr;
+                       sp.final_size < sp.kmers_to_sketch && cfg("no_small_sketcher") == nullptr;
     fh_sketcher *h = handles.get(small);
     if (!h) return hfail(FH_ERR_NO_DEVICE, "%s", fh_last_error());
     if (int rc = fh_reset(h)) return hfail(rc, "%s", fh_last_error());
@@ -2486,7 +2488,7 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
             return finish_sketch(h, name, sp, filters, st, out);
         }
         { // FINCH_DEVICE_GZIP=1: the device pass or nothing (its refusals stay loud)
-            const char *dg = getenv("FINCH_DEVICE_GZIP");
+            const char *dg = cfg("device_gzip");
             if (dg && dg[0] == '1') return rc;
         }
         if (rc != FH_ERR_INVALID || !src->rewind()) return rc;
@@ -2510,7 +2512,7 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
     if (device_parse && first == '>') {
         st.format = 1;
         // FINCH_SMALL_FASTA_HOST: unset / 1 = a small plain file is packed while it is staged (fasta_small_on_host), 0 = never
-        const char *sh_env = getenv("FINCH_SMALL_FASTA_HOST");
+        const char *sh_env = cfg("small_fasta_host");
         const bool small_host = !(sh_env && sh_env[0] == '0');
         int rc = (small_host && !dp_on && !is_gz) ? fasta_small_on_host(*src, h, st) : FH_ERR_STATE;
         if (rc == FH_ERR_STATE) { // does not apply: split on the device
@@ -2733,7 +2735,7 @@ static int pump_text_to_device(ByteSource &src, fh_sketcher *h, bool fastq, uint
     std::string pmsg;
     FastxStats pst;
     // FH_TRACE: how long each side waited for the other, and what the pushes took
-    static const bool trace = getenv("FH_TRACE") != nullptr;
+    static const bool trace = cfg("trace") != nullptr;
     auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now_s();
     double t_reader_waits = 0, t_pusher_waits = 0, t_push = 0;
@@ -2869,7 +2871,7 @@ static int bgzf_fastq_to_device(BgzfSource &bz, fh_sketcher *h) {
     constexpr uint64_t PUSH_TEXT = (uint64_t)96 << 20;
     std::vector<Job> ready;
     std::atomic<bool> abort{false};
-    static const bool trace = getenv("FH_TRACE") != nullptr;
+    static const bool trace = cfg("trace") != nullptr;
     auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now_s();
     double t_reader_waits = 0, t_pusher_waits = 0, t_push = 0, t_read = 0;
@@ -2978,7 +2980,7 @@ static int gzip_fastq_to_device(BgzfSource &bz, size_t hdr_len, fh_sketcher *h) 
     // there -- every chunk of a batch is resident at once, and a live one takes ~10 ms whenever it starts --, so pieces are
     // as large as it takes for the reads to be split over the call's read threads.)
     static const uint64_t PIECE = [] {
-        const char *e = getenv("FINCH_GZIP_PIECE"); // (A/B)
+        const char *e = cfg("gzip_piece"); // (A/B)
         return e ? std::max<uint64_t>(65536, strtoull(e, nullptr, 10)) : ((uint64_t)16 << 20); // (what FileSource splits over the call's read threads)
     }();
     struct Job {
@@ -2991,7 +2993,7 @@ static int gzip_fastq_to_device(BgzfSource &bz, size_t hdr_len, fh_sketcher *h) 
     bool is_free[2] = {true, true}, producer_done = false;
     std::vector<Job> ready;
     std::atomic<bool> abort{false};
-    static const bool trace = getenv("FH_TRACE") != nullptr;
+    static const bool trace = cfg("trace") != nullptr;
     auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now_s();
     double t_read = 0, t_push = 0, t_wait = 0;
@@ -3116,7 +3118,7 @@ static int sketch_stream_sharded(std::unique_ptr<ByteSource> raw, const std::str
     st.format = fastq ? 2 : 1;
     const int filter_on_eff = filters.filter_on < 0 ? (fastq ? 1 : 0) : filters.filter_on;
     const bool small = sp.kind == 0 && filter_on_eff == 0 && sp.final_size >= 1 && sp.final_size < sp.kmers_to_sketch &&
-                       getenv("FINCH_NO_SMALL_SKETCHER") == nullptr;
+                       cfg("no_small_sketcher") == nullptr;
     finch_sketch_params sp_dev = sp;
     if (small) sp_dev.kmers_to_sketch = sp.final_size; // (see HandleSet)
     uint64_t stage = chunk_bytes ? std::max<uint64_t>(chunk_bytes, 4096) : (32ull << 20);
@@ -3526,7 +3528,7 @@ void finch_default_filter_params(finch_filter_params *out) {
 }
 
 static uint64_t env_max_launch() {
-    const char *e = getenv("FINCH_MAX_LAUNCH");
+    const char *e = cfg("max_launch");
     return e ? strtoull(e, nullptr, 10) : 0;
 }
 
@@ -3539,7 +3541,7 @@ int finch_sketch_buffer(const uint8_t *data, uint64_t len, const char *name, con
     handles.device = device;
     auto res = std::make_unique<finch_sketches>();
     res->v.resize(1);
-    const int rc = sketch_stream(std::make_unique<MemSource>(data, (size_t)len, read_threads_total(getenv("FINCH_READ_THREADS"))),
+    const int rc = sketch_stream(std::make_unique<MemSource>(data, (size_t)len, read_threads_total(cfg("read_threads"))),
                                  name ? name : "", *sp, *filters, handles, res->v[0]);
     if (rc != FH_OK) return rc;
     *out = res.release();
@@ -3581,7 +3583,7 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
         }
     }
     // threads for the large reads of plain files, shared among the workers (a batch of genomes reads with one each)
-    const char *rt_env = getenv("FINCH_READ_THREADS");
+    const char *rt_env = cfg("read_threads");
     const unsigned read_total = read_threads_total(rt_env);
     const unsigned read_threads = std::max(1u, read_total / n_threads);
     // Many files per launch (fh_batch_*, fh_k2b.hip): a worker stages the packed streams of plain FASTA files side by side in
@@ -3803,7 +3805,7 @@ int finch_sketch_file_sharded(const char *filename, const finch_sketch_params *s
     const std::string fn = filename;
     FILE *f = fn == "-" ? stdin : fopen(fn.c_str(), "rb");
     if (!f) return hfail(FH_ERR_INVALID, "%s: %s (os error %d)", fn.c_str(), strerror(errno), errno);
-    const char *rt_env = getenv("FINCH_READ_THREADS");
+    const char *rt_env = cfg("read_threads");
     const unsigned read_threads = read_threads_total(rt_env);
     auto res = std::make_unique<finch_sketches>();
     res->v.resize(1);
@@ -3835,7 +3837,7 @@ int finch_sketch_buffer_sharded(const uint8_t *data, uint64_t len, const char *n
     auto res = std::make_unique<finch_sketches>();
     res->v.resize(1);
     bool rejected = false;
-    const unsigned mem_threads = read_threads_total(getenv("FINCH_READ_THREADS"));
+    const unsigned mem_threads = read_threads_total(cfg("read_threads"));
     int rc = sketch_stream_sharded(std::make_unique<MemSource>(data, (size_t)len, mem_threads), name ? name : "", *sp, *filters, devs, chunk_bytes,
                                    res->v[0], &rejected);
     if (rc != FH_OK && rejected) { // (see finch_sketch_file_sharded)
@@ -4102,7 +4104,7 @@ int finch_bgzf_batch_probe(const uint8_t *data, uint64_t len, uint64_t buf_bytes
                            uint8_t *text_out, uint64_t text_cap, uint64_t *text_len, uint64_t *n_batches, int *first_byte) try {
     if ((!data && len) || !text_out || !text_len || !n_batches || !first_byte) return hfail(FH_ERR_INVALID, "bad argument");
     std::unique_ptr<ByteSource> src;
-    setenv("FINCH_BGZF_THREADS", "2", 0); // (a BgzfSource only stands in front of gzip input when it may use threads)
+    if (!cfg("bgzf_threads")) fh::cfg_assign("bgzf_threads", "2"); // (a BgzfSource only stands in front of gzip input when it may use threads)
     if (int rc = open_source(std::make_unique<MemSource>(data, (size_t)len), src)) return rc;
     finch::BgzfSource *bz = dynamic_cast<finch::BgzfSource *>(src.get());
     if (!bz) return hfail(FH_ERR_INVALID, "not gzip input");

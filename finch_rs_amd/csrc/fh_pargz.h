@@ -20,6 +20,7 @@
 //
 // The member's CRC-32 and ISIZE are checked at its end as always, so a chunk stitched wrongly cannot go unnoticed.
 #pragma once
+#include "fh_options.h"
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
@@ -34,6 +35,7 @@
 
 namespace finch {
 namespace pargz {
+using fh::cfg;
 
 constexpr uint32_t WINDOW = 32768;
 constexpr uint16_t MARK = 0x8000;
@@ -190,7 +192,7 @@ struct BufPool {
     std::vector<GrowBuf<uint8_t>> free_list;
     size_t held = 0, limit;
     BufPool() {
-        const char *e = getenv("FINCH_PARGZ_POOL_MB");
+        const char *e = cfg("pargz_pool_mb");
         limit = (size_t)(e ? std::max(0ll, atoll(e)) : 2048ll) << 20;
     }
     static BufPool &global() {

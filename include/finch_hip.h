@@ -71,11 +71,24 @@ const char *fh_last_error(void);
 #define FH_ABI_VERSION 5
 int fh_abi_version(void);
 
+/* --- configuration: ONE surface ---
+ * Everything that selects between the library's (all exact) code paths, sizes a buffer for a test, sizes thread teams and
+ * pools or switches a trace on is a named option: set here, process-wide, or listed in the ONE environment variable the
+ * library reads, FH_DEBUG="name=value,name=value" (a name alone means "1"; an explicit fh_set_option wins).  No option
+ * changes a sketch.  value == NULL: back to "not set".  An option is looked at when the thing it configures is created or
+ * first used (a sketcher's options at fh_new; most A/B switches once per process), so set options before the first
+ * fh_new.  fh_option_list(): "name<TAB>what it does<NEWLINE>" for every option -- the authoritative list (README.md prints
+ * it); fh_get_option: the value in force, NULL if not set (or no such option).  FH_ERR_INVALID: no such option. */
+int fh_set_option(const char *name, const char *value);
+const char *fh_get_option(const char *name);
+const char *fh_option_list(void);
+
 /* create_sketcher: allocate the device-resident sketch state on `device`. NULL on error. */
 fh_sketcher *fh_new(const fh_params *params, int device);
 /* Drop a sketcher.  finch creates one per file and drops it after to_vec (lib.rs:58-79); since a sketcher owns
- * gigabytes of device memory, fh_free resets it and keeps up to FH_POOL (environment, default 64, 0 = never) of them
- * parked -- FH_POOL_BYTES of device memory at most (environment, default 24 GiB) -- and fh_new hands a parked one back
+ * gigabytes of device memory, fh_free resets it and keeps up to `pool` (option, default 64, 0 = never) of them
+ * parked -- `pool_bytes` of device memory at most (option; default 24 GiB or a tenth of the device, whichever is less; an
+ * embedding process that shares the device with another allocator calls fh_release_cached) -- and fh_new hands a parked one back
  * when the parameters and the device match (~0.1 ms instead of ~5 ms).  fh_release_cached frees what is parked; the
  * library does so itself before any of its own allocations fails for lack of memory. */
 void fh_free(fh_sketcher *s);
@@ -282,7 +295,7 @@ int fh_merge_wire(uint32_t kind, uint64_t size, double scale, uint32_t k, uint64
  * fails decides the return code, and fh_last_error() names it ("block i (device d): ..."); the handles of the other blocks are
  * left finished with their partial sketches, handles[0] then holds block 0's alone.  The caller's current HIP device is the
  * same on return as on entry, whichever way the call ends.  The library's threads (not the caller's) run on the CPUs of the
- * NUMA node their device is attached to where sysfs names one (FH_NO_NUMA_PIN=1: wherever the scheduler puts them). */
+ * NUMA node their device is attached to where sysfs names one (option no_numa_pin: wherever the scheduler puts them). */
 int fh_sketch_device_blocks(fh_sketcher *const *handles, const void *const *dev_blocks, const uint64_t *lens,
                             const uint64_t *stream_offsets, uint32_t n);
 

@@ -196,7 +196,7 @@ int finch_gzip_probe(const uint8_t *data, uint64_t len, uint64_t piece_bytes, ui
                      uint32_t *crc_of_pieces);
 
 /* Test hook: inputs this process has sketched with the BGZF inflate on the device (finch_sketch_files /
- * finch_sketch_buffer: bgzip'd FASTQ unless FINCH_DEVICE_INFLATE=0), and how many of them it had to read again through the
+ * finch_sketch_buffer: bgzip'd FASTQ unless option device_inflate is 0), and how many of them it had to read again through the
  * host-side inflate because the device pass refused them. */
 void finch_debug_device_inflate(uint64_t *files_on_device, uint64_t *files_reread);
 /* the same for plain gzip files (fh_push_gzip_fastq) */

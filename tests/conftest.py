@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _library_options_restored():
+    """the library's options travel in ONE environment variable (FH_DEBUG, include/finch_hip.h); a test that sets some
+    (finch_rs_amd.debug_set) leaves the variable as it found it"""
+    old = os.environ.get("FH_DEBUG")
+    yield
+    if old is None:
+        os.environ.pop("FH_DEBUG", None)
+    else:
+        os.environ["FH_DEBUG"] = old
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

@@ -71,3 +71,41 @@ def test_product_does_not_import_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, fn), errors="replace").read()
                 assert "finch_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, fn
+
+
+def test_one_configuration_surface(built):
+    """the library reads ONE environment variable, in ONE place (csrc/fh_options.cpp: FH_DEBUG); everything else is an option
+    of fh_set_option's table"""
+    csrc = os.path.join(ROOT, "finch_rs_amd", "csrc")
+    sites = []
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            for i, line in enumerate(open(os.path.join(csrc, fn), errors="replace"), 1):
+                if re.search(r"\bgetenv\s*\(", line) and not line.lstrip().startswith("//"):
+                    sites.append("%s:%d" % (fn, i))
+    assert len(sites) == 1 and sites[0].startswith("fh_options.cpp:"), sites
+    names = [n for n, _ in F.option_list()]
+    assert len(names) == len(set(names)) >= 40 and "trace" in names and "file_batch" in names
+    # set / get / unset, and the one environment variable
+    assert F.get_option("no_seg") is None
+    F.set_option("no_seg", 1)
+    assert F.get_option("no_seg") == "1"
+    F.set_option("no_seg", None)
+    assert F.get_option("no_seg") is None
+    with pytest.raises(F.FinchHipError):
+        F.set_option("no_such_option", 1)
+    old = os.environ.get("FH_DEBUG")
+    try:
+        F.debug_set(seg_stride=151, trace=None, no_fast=1)
+        assert F.get_option("seg_stride") == "151" and F.get_option("no_fast") == "1" and F.get_option("trace") is None
+        F.set_option("seg_stride", 77)  # an explicit fh_set_option wins over FH_DEBUG
+        assert F.get_option("seg_stride") == "77"
+        F.set_option("seg_stride", None)
+        assert F.get_option("seg_stride") == "151"
+        os.environ["FH_DEBUG"] = "trace gz_chunk=4096;unknown_thing=3"
+        assert F.get_option("trace") == "1" and F.get_option("gz_chunk") == "4096" and F.get_option("seg_stride") is None
+    finally:
+        if old is None:
+            os.environ.pop("FH_DEBUG", None)
+        else:
+            os.environ["FH_DEBUG"] = old

@@ -190,7 +190,7 @@ def _same_as_oracle(sk, data, n, k, seed=0, keep=None):
 def test_sketch_files_groups_match_the_oracle_and_the_one_by_one_path(tmp_path, monkeypatch):
     """a mixed batch: plain genomes (grouped), CRLF and unterminated files, several contigs, a repeat (not taken), a file
     with too few k-mers for the sketch only in no_strict mode, FASTQ and gzip'd FASTA (never grouped) -- one sketch per file,
-    input order (lib.rs:29-49), each equal to the oracle's sketch_stream and to what FINCH_FILE_BATCH=0 gives"""
+    input order (lib.rs:29-49), each equal to the oracle's sketch_stream and to what option file_batch=0 gives"""
     rng = np.random.default_rng(21)
     datas = []
     for i in range(20):
@@ -216,7 +216,7 @@ def test_sketch_files_groups_match_the_oracle_and_the_one_by_one_path(tmp_path, 
     t1, n1 = H.debug_file_batch()
     assert len(res) == len(paths)
     assert t1 - t0 >= 22 and n1 - n0 >= 1, (t1 - t0, n1 - n0)   # the genomes went many-per-launch, the repeat did not
-    monkeypatch.setenv("FINCH_FILE_BATCH", "0")
+    F.debug_set(file_batch="0")
     ref = H.sketch_files(paths, params, H.FilterParams(None), n_threads=3)
     assert H.debug_file_batch() == (t1, n1)
     for i, d in enumerate(datas):
@@ -228,7 +228,7 @@ def test_sketch_files_groups_match_the_oracle_and_the_one_by_one_path(tmp_path, 
         if i < len(datas) - 2:
             _same_as_oracle(a, d, 1000, 21)
     # strict mode: the file with 680 k-mers is the reference's error (mod.rs:123-125), whichever path took it
-    monkeypatch.delenv("FINCH_FILE_BATCH")
+    F.debug_set(file_batch=None)
     with pytest.raises(FinchError, match="had too few kmers \\(680\\) to sketch"):
         H.sketch_files(paths[:23] + [paths[24]], SketchParams.mash(1000, 1000, False, 21, 0), H.FilterParams(None), n_threads=2)
 

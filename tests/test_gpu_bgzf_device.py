@@ -9,6 +9,8 @@ import zlib
 import numpy as np
 import pytest
 
+import finch_rs_amd as F
+
 from finch_rs_amd import _lib
 from finch_rs_amd import host as H
 from finch_rs_amd import sketch_schemes as S
@@ -190,7 +192,7 @@ def test_damage_is_reported_not_sketched():
 def test_bgzipped_fastq_files_take_the_device_inflate(tmp_path, monkeypatch):
     """finch_sketch_files on bgzip'd reads: same sketch as the plain file and as the oracle, and the device did the inflating;
     a file the device pass refuses (here: records with blank lines between them) is read again on the host"""
-    monkeypatch.setenv("FINCH_READ_THREADS", "4")
+    F.debug_set(read_threads="4")
     text = fastq_text(40000, 11, rl_lo=100, rl_hi=151)
     params = SketchParams.mash(2000, 2000, True, 21, 0)
     filt = H.FilterParams(False)
@@ -212,11 +214,11 @@ def test_bgzipped_fastq_files_take_the_device_inflate(tmp_path, monkeypatch):
         sk = res.sketch(i)
         assert np.array_equal(sk.arrays[0], ref.arrays[0]) and np.array_equal(sk.arrays[1], ref.arrays[1])
         assert (sk.seq_length, sk.num_valid_kmers) == (ref.seq_length, ref.num_valid_kmers) == o.total_bases_and_kmers()
-    monkeypatch.setenv("FINCH_DEVICE_INFLATE", "0")
+    F.debug_set(device_inflate="0")
     res0 = H.sketch_files(paths[1:2], params, filt)
     assert H.debug_device_inflate() == after
     assert np.array_equal(res0.sketch(0).arrays[0], ref.arrays[0])
-    monkeypatch.delenv("FINCH_DEVICE_INFLATE")
+    F.debug_set(device_inflate=None)
     # blank lines between records: needletail accepts them, the device splitter does not -> host parser, same answer as the oracle
     loose = text.replace(b"\n@read7/", b"\n\n@read7/")
     assert loose != text
@@ -258,8 +260,8 @@ def test_plain_gzip_with_read_threads_goes_through_the_device_splitter_and_can_f
     """plain gzip decoded by several threads (fh_pargz.h) feeds the device-side FASTQ splitter like any text; a file the
     splitter refuses is rewound -- through the parallel reader -- and parsed on the host"""
     import gzip
-    monkeypatch.setenv("FINCH_READ_THREADS", "4")
-    monkeypatch.setenv("FINCH_PARGZ_CHUNK", "200000")
+    F.debug_set(read_threads="4")
+    F.debug_set(pargz_chunk="200000")
     text = fastq_text(30000, 5, rl_lo=100, rl_hi=151)
     params = SketchParams.mash(2000, 2000, True, 21, 0)
     filt = H.FilterParams(False)
@@ -283,13 +285,13 @@ def test_plain_gzip_with_read_threads_goes_through_the_device_splitter_and_can_f
 
 
 def test_the_one_symbol_at_a_time_loop_still_decodes():
-    """FH_BGZF_SERIAL=1 (read once per process, hence the child): the A/B variant of the inflate kernel's symbol loop"""
+    """option bgzf_serial (read once per process, hence the child): the A/B variant of the inflate kernel's symbol loop"""
     import subprocess
     import sys
-    if os.environ.get("FH_BGZF_SERIAL"):
+    if "bgzf_serial" in os.environ.get("FH_DEBUG", ""):
         pytest.skip("this is the child")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_bgzf_device.py"), "-q", "-x", "-m", "gpu", "-k",
-                        "every_block_type or long_codes or damage"], env=dict(os.environ, FH_BGZF_SERIAL="1"), cwd=root,
+                        "every_block_type or long_codes or damage"], env=F.debug_env(bgzf_serial="1"), cwd=root,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]

@@ -51,8 +51,8 @@ def big_block():
 
 
 def _device_pass(data, n=1000, k=21, **env):
-    old = {key: os.environ.get(key) for key in env}
-    os.environ.update({key: str(v) for key, v in env.items()})
+    old = os.environ.get("FH_DEBUG")
+    F.debug_set(**env)  # (options of the library: FH_DEBUG, include/finch_hip.h)
     try:
         F.load().fh_release_cached()  # (a parked handle would keep the previous setting of the creation-time knobs)
         buf = F.DeviceBuffer(len(data) + 64)
@@ -67,11 +67,10 @@ def _device_pass(data, n=1000, k=21, **env):
         sk.close()
         return out
     finally:
-        for key, v in old.items():
-            if v is None:
-                os.environ.pop(key, None)
-            else:
-                os.environ[key] = v
+        if old is None:
+            os.environ.pop("FH_DEBUG", None)
+        else:
+            os.environ["FH_DEBUG"] = old
         F.load().fh_release_cached()
 
 
@@ -85,13 +84,13 @@ def test_prefix_verdict_and_gated_main_launch_in_one_synchronisation(big_block):
         assert dbg["relaunches"] == 0 and dbg["launches"] == 2 * (i + 1), dbg
 
 
-@pytest.mark.parametrize("env", [{"FH_NO_FAST": 1}, {"FH_NO_HIST": 1}, {"FH_NO_SPEC": 1}, {"FH_UNIT_TILES": 2}, {"FH_MAX_RANGE": 3_000_000}],
+@pytest.mark.parametrize("env", [{"no_fast": 1}, {"no_hist": 1}, {"no_spec": 1}, {"unit_tiles": 2}, {"max_range": 3_000_000}],
                          ids=lambda e: "+".join(e))
 def test_knobs_that_switch_pieces_off_give_the_same_sketch(big_block, env):
     data, ora = big_block
     for kc, km, tk, dbg in _device_pass(data, **env):
         _same(kc, km, tk, ora, str(env))
-        if "FH_NO_FAST" in env:
+        if "no_fast" in env:
             assert dbg["spec_deferred"] == 0 and dbg["fused_finishes"] == 0
 
 
@@ -120,7 +119,7 @@ def test_failed_speculation_is_finished_step_by_step():
 
 
 @pytest.mark.parametrize("genome_len,n_reads,env", [(500_000, 200_000, {}), (500_000, 470_000, {}), (120_000, 200_000, {}),
-                                                     (500_000, 200_000, {"FH_NO_FAST": 1}), (500_000, 200_000, {"FH_NO_SPEC_RESCALE": 1})],
+                                                     (500_000, 200_000, {"no_fast": 1}), (500_000, 200_000, {"no_spec_rescale": 1})],
                          ids=["whole block", "prefix", "few hashes below the guess", "undeferred", "old way"])
 def test_speculation_that_falls_short_on_deep_coverage_is_reread_up_to_a_rescaled_threshold(genome_len, n_reads, env):
     """reads without errors at 60- to 250-fold coverage: the guess (every k-mer distinct) leaves some tens of the 1000 hashes; the

@@ -351,7 +351,7 @@ def test_c1_ecoli_sized_fasta_through_sketch_files(tmp_path, golden_dir):
     okc, okm = ora.to_vec()
     golden = json.load(open(os.path.join(golden_dir, "config_fingerprints.json")))["c1_fasta_k21_n1000"]
     for small_host in ("1", "0"):
-        os.environ["FINCH_SMALL_FASTA_HOST"] = small_host
+        F.debug_set(small_fasta_host=small_host)
         res = H.sketch_files([path], F.SketchParams.default(), H.FilterParams(None))
         sk = res.sketch(0)
         assert np.array_equal(sk.arrays[0], okc) and np.array_equal(sk.arrays[1], okm)
@@ -359,13 +359,13 @@ def test_c1_ecoli_sized_fasta_through_sketch_files(tmp_path, golden_dir):
         fp = M.fingerprint(sk.arrays[0], sk.arrays[1], sk.num_valid_kmers)
         assert all(fp[key] == golden[key] for key in fp), (fp, golden)
         assert sk.filter_params.filter_on is False
-    os.environ.pop("FINCH_SMALL_FASTA_HOST", None)
+    F.debug_set(small_fasta_host=None)
     # the same file through the device-side splitter, whatever this process read from the environment first
     import subprocess
     code = ("import sys, json, numpy as np; sys.path.insert(0, %r); import finch_rs_amd as F; from finch_rs_amd import host as H; "
             "sk = H.sketch_files([%r], F.SketchParams.default(), H.FilterParams(None)).sketch(0); "
             "print(json.dumps([int(np.bitwise_xor.reduce(sk.arrays[0]['hash'])), int(sk.seq_length), int(sk.num_valid_kmers)]))"
             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FINCH_SMALL_FASTA_HOST="0"), stdout=subprocess.PIPE, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], env=F.debug_env(small_fasta_host="0"), stdout=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0
     assert json.loads(r.stdout.strip().splitlines()[-1]) == [golden["hash_xor"], golden["seq_length"], golden["total_kmers"]]

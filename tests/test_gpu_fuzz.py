@@ -74,13 +74,13 @@ def _configuration(seed0, case):
     L = _lib.load()
     # admit path: chosen per launch by the library (None), or forced to read entries first / to plain atomics
     form = [None, "1", "0"][case % 3]
-    os.environ.pop("FH_READ_FIRST", None)
+    F.debug_set(read_first=None)
     if form is not None:
-        os.environ["FH_READ_FIRST"] = form
+        F.debug_set(read_first=form)
     try:
         _run_case(rng, sk, L, recs, kind, size, k, seed, scale, case, inflight, n_rec)
     finally:
-        os.environ.pop("FH_READ_FIRST", None)
+        F.debug_set(read_first=None)
 
 
 def _run_case(rng, sk, L, recs, kind, size, k, seed, scale, case, inflight, n_rec):

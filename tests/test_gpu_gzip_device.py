@@ -13,6 +13,8 @@ import zlib
 import numpy as np
 import pytest
 
+import finch_rs_amd as F
+
 from finch_rs_amd import _lib
 from finch_rs_amd import host as H
 from finch_rs_amd import sketch_schemes as S
@@ -118,7 +120,7 @@ MODES = [
 @pytest.fixture
 def chunk_env():
     yield
-    os.environ.pop("FH_GZ_CHUNK", None)
+    F.debug_set(gz_chunk=None)
 
 
 @pytest.mark.parametrize("mode", range(len(MODES)))
@@ -131,9 +133,9 @@ def test_chunked_inflate_reproduces_the_text_for_every_block_type(mode, chunk_en
     body = deflate_raw(text, **kw) + zlib.crc32(text).to_bytes(4, "little") + len(text).to_bytes(4, "little")
     for chunk in (None, 1024, 4096, 20000, 100_000):  # None: the library's choice (one chunk for an input this small)
         if chunk is None:
-            os.environ.pop("FH_GZ_CHUNK", None)
+            F.debug_set(gz_chunk=None)
         else:
-            os.environ["FH_GZ_CHUNK"] = str(chunk)
+            F.debug_set(gz_chunk=str(chunk))
         sk = new_sketcher(size, k)
         done, trailing, _ = push_stream(sk, body)
         assert (done, trailing) == (1, 0), (kw, chunk)
@@ -149,7 +151,7 @@ def test_undecoded_bytes_window_and_partial_record_carry_over_between_pushes(lev
     assert o.sketch_stream(text) == 2
     body = deflate_raw(text, level=level) + zlib.crc32(text).to_bytes(4, "little") + len(text).to_bytes(4, "little")
     assert len(body) > 3 * push
-    os.environ["FH_GZ_CHUNK"] = "65536"
+    F.debug_set(gz_chunk="65536")
     sk = new_sketcher(size, k, stage_bytes=8 << 20)
     done, trailing, n_push = push_stream(sk, body, push)
     assert (done, trailing) == (1, 0) and n_push >= 3
@@ -173,9 +175,9 @@ def test_a_batch_handed_over_in_pieces_is_decoded_while_it_comes_in(level, piece
     body = deflate_raw(text, level=level) + zlib.crc32(text).to_bytes(4, "little") + len(text).to_bytes(4, "little")
     for chunk in ("8192", None):
         if chunk:
-            os.environ["FH_GZ_CHUNK"] = chunk
+            F.debug_set(gz_chunk=chunk)
         else:
-            os.environ.pop("FH_GZ_CHUNK", None)
+            F.debug_set(gz_chunk=None)
         sk = new_sketcher(size, k)
         done, trailing, n_push = push_stream(sk, body, None, piece)
         assert (done, trailing) == (1, 0) and n_push >= 3
@@ -186,7 +188,7 @@ def test_a_batch_handed_over_in_pieces_is_decoded_while_it_comes_in(level, piece
 def test_trailing_bytes_are_reported_and_damage_is_loud(chunk_env):
     text = fastq_text(5000, 77)
     body = deflate_raw(text, level=6) + zlib.crc32(text).to_bytes(4, "little") + len(text).to_bytes(4, "little")
-    os.environ["FH_GZ_CHUNK"] = "16384"
+    F.debug_set(gz_chunk="16384")
     sk = new_sketcher(500, 21)
     assert push_stream(sk, body + b"x" * 37)[:2] == (1, 37)
     sk.reset()
@@ -243,12 +245,12 @@ def test_a_batch_abandoned_half_way_does_not_leave_the_device_waiting(chunk_env)
 
 def sketch_of(path, p, device_gzip=True, **kw):
     if not device_gzip:
-        os.environ["FINCH_DEVICE_GZIP"] = "0"
+        F.debug_set(device_gzip="0")
     try:
         sk = H.sketch_files([path], p, H.FilterParams(False), **kw).sketch(0)
         return sk.arrays[0].tobytes(), sk.arrays[1].tobytes(), sk.seq_length, sk.num_valid_kmers
     finally:
-        os.environ.pop("FINCH_DEVICE_GZIP", None)
+        F.debug_set(device_gzip=None)
 
 
 def test_sketch_files_takes_gzip_through_the_device_and_falls_back_when_it_must(tmp_path, chunk_env):
@@ -258,7 +260,7 @@ def test_sketch_files_takes_gzip_through_the_device_and_falls_back_when_it_must(
     o.sketch_stream(text)
     okc, okm = o.to_vec()
     want = (okc.tobytes(), okm.tobytes()) + o.total_bases_and_kmers()
-    os.environ["FH_GZ_CHUNK"] = "32768"
+    F.debug_set(gz_chunk="32768")
     cases = {
         "plain.fastq.gz": (gzip.compress(text, 6), 1, 0),
         "named.fastq.gz": (gzip_file(text, name=b"reads.fastq", level=1), 1, 0),

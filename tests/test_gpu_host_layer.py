@@ -9,6 +9,8 @@ import sys
 import numpy as np
 import pytest
 
+import finch_rs_amd as F
+
 from finch_rs_amd import host as H
 from finch_rs_amd import sketch_schemes as S
 from finch_rs_amd.sketch_schemes import FinchError, SketchParams
@@ -108,8 +110,9 @@ def test_batch_of_fastas_one_sketch_per_file_in_order(tmp_path):
 
 
 def _run_child(code, env):
-    e = dict(os.environ)
-    e.update(env)
+    """env: options of the library (lower-case names: they travel in FH_DEBUG) and plain environment variables (upper-case)"""
+    e = F.debug_env(**{k: v for k, v in env.items() if k.islower()})
+    e.update({k: v for k, v in env.items() if not k.islower()})
     r = subprocess.run([sys.executable, "-c", code], env=e, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
@@ -132,7 +135,7 @@ assert np.array_equal(sk.arrays[0], okc) and np.array_equal(sk.arrays[1], okm)
 assert (sk.seq_length, sk.num_valid_kmers) == o.total_bases_and_kmers()
 print("child ok")
 '''
-    for env in [{"FINCH_BLOCK_BYTES": "1000"}, {"FH_STAGE_BYTES": "4096"}, {"FINCH_BLOCK_BYTES": "7777", "FH_STAGE_BYTES": "5000"}]:
+    for env in [{"block_bytes": "1000"}, {"stage_bytes": "4096"}, {"block_bytes": "7777", "stage_bytes": "5000"}]:
         assert "child ok" in _run_child(code, env)
 
 
@@ -143,6 +146,7 @@ def test_wide_kmers_span_staging_slices_on_every_path():
     bytes: k >= 34 wrote before the allocation.)"""
     code = r'''
 import os, numpy as np
+import finch_rs_amd as F
 from finch_rs_amd import host as H, sketch_schemes as S
 from oracle import oracle as O
 seq = bytes(S.synth_genome_host(60000, 21))
@@ -157,9 +161,9 @@ for k in (33, 34, 48, 63, 64):
         okc, okm = o.to_vec()
         for mode in ("0", "1", None):
             if mode is None:
-                os.environ.pop("FINCH_DEVICE_PARSE", None)
+                F.debug_set(device_parse=None)
             else:
-                os.environ["FINCH_DEVICE_PARSE"] = mode
+                F.debug_set(device_parse=mode)
             if mode == "1" and data is fq:
                 continue  # (device only: a 3000-base record does not fit a 4 KiB slice -- an error by design)
             sk = H.sketch_stream(data, "x", p, H.FilterParams(False)).sketch(0)
@@ -167,8 +171,8 @@ for k in (33, 34, 48, 63, 64):
             assert (sk.seq_length, sk.num_valid_kmers) == o.total_bases_and_kmers(), (k, mode)
 print("child ok")
 '''
-    assert "child ok" in _run_child(code, {"FH_STAGE_BYTES": "4096"})
-    assert "child ok" in _run_child(code, {"FH_STAGE_BYTES": "5001"})
+    assert "child ok" in _run_child(code, {"stage_bytes": "4096"})
+    assert "child ok" in _run_child(code, {"stage_bytes": "5001"})
 
 
 def test_fastq_cut_off_inside_a_record_is_the_reference_error_on_every_path():
@@ -181,30 +185,30 @@ def test_fastq_cut_off_inside_a_record_is_the_reference_error_on_every_path():
     for tail in (b"@last\n", b"@last", b"@last\nACGTACGTACGTACGTACGTACGT\n", b"@last\nACGTACGTACGTACGTACGTACGT", b"@last\nACGT\n+"):
         for mode in ("0", None, "1"):
             if mode is None:
-                os.environ.pop("FINCH_DEVICE_PARSE", None)
+                F.debug_set(device_parse=None)
             else:
-                os.environ["FINCH_DEVICE_PARSE"] = mode
+                F.debug_set(device_parse=mode)
             try:
                 with pytest.raises(FinchError):
                     H.sketch_stream(whole + tail, "x", p, H.FilterParams(False))
             finally:
-                os.environ.pop("FINCH_DEVICE_PARSE", None)
+                F.debug_set(device_parse=None)
     # the last record without its quality line's newline, and with an empty quality line for an empty sequence, are fine
     for tail in (b"@last\nACGTACGTACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIIIIIIIIIII", b"@last\n\n+\n"):
         for mode in ("0", None):
             if mode is None:
-                os.environ.pop("FINCH_DEVICE_PARSE", None)
+                F.debug_set(device_parse=None)
             else:
-                os.environ["FINCH_DEVICE_PARSE"] = mode
+                F.debug_set(device_parse=mode)
             try:
                 sk = H.sketch_stream(whole + tail, "x", p, H.FilterParams(False)).sketch(0)
             finally:
-                os.environ.pop("FINCH_DEVICE_PARSE", None)
+                F.debug_set(device_parse=None)
             assert sk.seq_length == good.seq_length + (24 if b"ACGT" in tail else 0)
 
 
 def test_device_side_fastq_parsing_matches_host_parser(tmp_path):
-    """with FINCH_DEVICE_PARSE=1 the sequence lines of plain FASTQ are found on the device
+    """with option device_parse=1 the sequence lines of plain FASTQ are found on the device
     (fh_text.hip); same sketch, seq_length and numValidKmers as the host parser, incl. CRLF, a last line
     without newline, quality lines starting with '@', and chunks much smaller than the file."""
     code = r'''
@@ -237,9 +241,9 @@ f = H.FilterParams(False)
 for name, data in [("lf", fq(b"\n")), ("crlf", fq(b"\r\n")), ("nolast", fq(b"\n", False)), ("varlen", fq(b"\n", True, True))]:
     path = os.path.join(sys.argv[1], name + ".fastq")
     open(path, "wb").write(data)
-    os.environ["FINCH_DEVICE_PARSE"] = "0"
+    F.debug_set(device_parse="0")
     a = H.sketch_files([path], p, f).sketch(0)
-    os.environ["FINCH_DEVICE_PARSE"] = "1"
+    F.debug_set(device_parse="1")
     b = H.sketch_files([path], p, f).sketch(0)
     assert np.array_equal(a.arrays[0], b.arrays[0]) and np.array_equal(a.arrays[1], b.arrays[1]), name
     assert (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers), (name, a.seq_length, b.seq_length)
@@ -252,23 +256,23 @@ try:
     raise SystemExit("expected an error")
 except S.FinchError as e:
     assert "FASTQ" in str(e)
-# default mode (no FINCH_DEVICE_PARSE): the device pass is tried first and the same file falls back to the host parser
+# default mode (option device_parse not set): the device pass is tried first and the same file falls back to the host parser
 blank = os.path.join(sys.argv[1], "blank.fastq")   # real reads, a blank line after every 7th record
 recs = fq(b"\n").split(b"\n@r")
 open(blank, "wb").write(b"\n@r".join(r + (b"\n" if i % 7 == 3 else b"") for i, r in enumerate(recs)))
-os.environ["FINCH_DEVICE_PARSE"] = "0"
+F.debug_set(device_parse="0")
 a = H.sketch_files([blank], p, f).sketch(0)
-os.environ.pop("FINCH_DEVICE_PARSE")
+F.debug_set(device_parse=None)
 b = H.sketch_files([blank], p, f).sketch(0)
 assert np.array_equal(a.arrays[0], b.arrays[0]) and (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers)
 assert vs_oracle(b, open(blank, "rb").read(), p, "blank lines between records")
-os.environ["FINCH_DEVICE_PARSE"] = "1"
+F.debug_set(device_parse="1")
 try:
     H.sketch_files([blank], p, f)
     raise SystemExit("expected an error")
 except S.FinchError as e:
     assert "FASTQ" in str(e)
-os.environ.pop("FINCH_DEVICE_PARSE")
+F.debug_set(device_parse=None)
 # what needletail checks per record, the device pass checks too: blanks / tabs / an interior CR inside a sequence line
 # (normalize(false) drops them, k-mers span them) and unequal sequence / quality lengths send the file to the host
 # parser -- same sketch as the oracle, or the reference's error
@@ -289,37 +293,37 @@ data = b"\n@r".join(damage(i, r) for i, r in enumerate(recs))
 open(ws, "wb").write(data)
 b = H.sketch_files([ws], p, f).sketch(0)   # default mode: device pass refuses, host parser reads
 assert vs_oracle(b, data, p, "blanks inside sequence lines")
-os.environ["FINCH_DEVICE_PARSE"] = "1"
+F.debug_set(device_parse="1")
 try:
     H.sketch_files([ws], p, f)
     raise SystemExit("expected an error")
 except S.FinchError as e:
     assert "FASTQ" in str(e)
-os.environ.pop("FINCH_DEVICE_PARSE")
+F.debug_set(device_parse=None)
 mm = os.path.join(sys.argv[1], "mismatch.fastq")
 lines = fq(b"\n").split(b"\n")
 lines[4 * 777 + 3] = lines[4 * 777 + 3][:-1]          # one quality line a byte short
 open(mm, "wb").write(b"\n".join(lines))
 for mode in (None, "1", "0"):
     if mode is None:
-        os.environ.pop("FINCH_DEVICE_PARSE", None)
+        F.debug_set(device_parse=None)
     else:
-        os.environ["FINCH_DEVICE_PARSE"] = mode
+        F.debug_set(device_parse=mode)
     try:
         H.sketch_files([mm], p, f)
         raise SystemExit("expected an error (mode %r)" % mode)
     except S.FinchError as e:
         assert ("lengths differ" in str(e)) if mode != "1" else ("FASTQ" in str(e)), (mode, str(e))
-os.environ.pop("FINCH_DEVICE_PARSE", None)
+F.debug_set(device_parse=None)
 # ... and a well-formed file takes the device path by default with the host parser's result
 good = os.path.join(sys.argv[1], "lf.fastq")
 b = H.sketch_files([good], p, f).sketch(0)
-os.environ["FINCH_DEVICE_PARSE"] = "0"
+F.debug_set(device_parse="0")
 a = H.sketch_files([good], p, f).sketch(0)
 assert np.array_equal(a.arrays[0], b.arrays[0]) and (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers)
 print("child ok")
 '''
-    for env in [{}, {"FH_STAGE_BYTES": "65536"}]:
+    for env in [{}, {"stage_bytes": "65536"}]:
         e = dict(os.environ)
         e.update(env)
         r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=e,
@@ -329,7 +333,7 @@ print("child ok")
 
 
 def test_device_side_fasta_parsing_matches_host_parser(tmp_path):
-    """with FINCH_DEVICE_PARSE=1 the sequence bytes of multi-line FASTA are found on the device
+    """with option device_parse=1 the sequence bytes of multi-line FASTA are found on the device
     (fh_text.hip, latest-event max-scan); same sketch, seq_length and numValidKmers as the host parser: LF / CRLF,
     ragged line lengths, '>' inside lines, blank lines, spaces and tabs, empty records, a last line without newline,
     many short records, 0xFF bytes, header and sequence lines longer than the staging chunk, chunks of 4 KiB"""
@@ -370,13 +374,13 @@ f = H.FilterParams(False)
 for name, data in cases.items():
     path = os.path.join(sys.argv[1], name + ".fa")
     open(path, "wb").write(data)
-    os.environ["FINCH_DEVICE_PARSE"] = "0"
+    F.debug_set(device_parse="0")
     a = H.sketch_files([path], p, f).sketch(0)
     for mode in ("1", None):  # explicit, and the default (FASTA is split on the device unless told otherwise)
         if mode is None:
-            os.environ.pop("FINCH_DEVICE_PARSE", None)
+            F.debug_set(device_parse=None)
         else:
-            os.environ["FINCH_DEVICE_PARSE"] = mode
+            F.debug_set(device_parse=mode)
         b = H.sketch_files([path], p, f).sketch(0)
         assert np.array_equal(a.arrays[0], b.arrays[0]) and np.array_equal(a.arrays[1], b.arrays[1]), name
         assert (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers), (name, a.seq_length, b.seq_length, a.num_valid_kmers, b.num_valid_kmers)
@@ -385,7 +389,7 @@ for name, data in cases.items():
         assert vs_oracle(b, data, p, name), name
 print("child ok")
 '''
-    for env in [{}, {"FH_STAGE_BYTES": "65536"}, {"FH_STAGE_BYTES": "4096"}]:
+    for env in [{}, {"stage_bytes": "65536"}, {"stage_bytes": "4096"}]:
         e = dict(os.environ)
         e.update(env)
         r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=e,
@@ -429,23 +433,23 @@ for case in range(30):
     k = int(rng.choice([3, 16, 21, 31]))
     p = S.SketchParams.mash(50, 50, True, k, 0)
     f = H.FilterParams(False)
-    os.environ["FINCH_DEVICE_PARSE"] = "0"
+    F.debug_set(device_parse="0")
     a = H.sketch_stream(data, "x", p, f).sketch(0)
-    os.environ["FINCH_DEVICE_PARSE"] = "1"
+    F.debug_set(device_parse="1")
     b = H.sketch_stream(data, "x", p, f).sketch(0)
     assert np.array_equal(a.arrays[0], b.arrays[0]) and np.array_equal(a.arrays[1], b.arrays[1]), case
     assert (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers), (case, a.seq_length, b.seq_length)
     n_oracle += vs_oracle(b, data, p, case)
     # the default: a text that fits the staging buffer is packed on the host while it is staged (fasta_small_on_host);
     # with the tiny staging buffers of the repeats it does not fit and goes to the device-side splitter
-    os.environ.pop("FINCH_DEVICE_PARSE")
+    F.debug_set(device_parse=None)
     c = H.sketch_stream(data, "x", p, f).sketch(0)
     assert np.array_equal(a.arrays[0], c.arrays[0]) and np.array_equal(a.arrays[1], c.arrays[1]), case
     assert (a.seq_length, a.num_valid_kmers) == (c.seq_length, c.num_valid_kmers), (case, a.seq_length, c.seq_length)
 assert n_oracle == 30, n_oracle  # the text always begins with '>': the oracle's parser takes every case
 print("child ok")
 '''
-    for env in [{}, {"FH_STAGE_BYTES": "4096"}, {"FH_STAGE_BYTES": "5001"}]:
+    for env in [{}, {"stage_bytes": "4096"}, {"stage_bytes": "5001"}]:
         assert "child ok" in _run_child(code, env)
 
 
@@ -501,9 +505,9 @@ def test_compressed_text_goes_through_the_device_side_splitters(tmp_path, monkey
         (tmp_path / name).write_bytes(data)
     paths = [str(tmp_path / n) for n in files]
     p = SketchParams.mash(500, 500, False, 21, 0)
-    monkeypatch.setenv("FINCH_DEVICE_PARSE", "0")
+    F.debug_set(device_parse="0")
     want = H.sketch_files(paths, p, H.FilterParams(None))
-    monkeypatch.delenv("FINCH_DEVICE_PARSE")
+    F.debug_set(device_parse=None)
     got = H.sketch_files(paths, p, H.FilterParams(None))
     for i in range(len(paths)):
         a, b = want.sketch(i), got.sketch(i)
@@ -511,7 +515,7 @@ def test_compressed_text_goes_through_the_device_side_splitters(tmp_path, monkey
         assert (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers), paths[i]
     assert np.array_equal(got.sketch(1).arrays[0], got.sketch(2).arrays[0])  # the blank line changes nothing
     # device only: the loose file is an error, the strict ones are not
-    monkeypatch.setenv("FINCH_DEVICE_PARSE", "1")
+    F.debug_set(device_parse="1")
     H.sketch_files(paths[:2], p, H.FilterParams(None))
     with pytest.raises(FinchError):
         H.sketch_files(paths[2:], p, H.FilterParams(None))
@@ -519,9 +523,9 @@ def test_compressed_text_goes_through_the_device_side_splitters(tmp_path, monkey
     (tmp_path / "t.fq.gz").write_bytes(files["s.fq.gz"][:len(files["s.fq.gz"]) // 2])
     for mode in ("0", "1", None):
         if mode is None:
-            monkeypatch.delenv("FINCH_DEVICE_PARSE")
+            F.debug_set(device_parse=None)
         else:
-            monkeypatch.setenv("FINCH_DEVICE_PARSE", mode)
+            F.debug_set(device_parse=mode)
         with pytest.raises(FinchError):
             H.sketch_files([str(tmp_path / "t.fq.gz")], p, H.FilterParams(None))
 
@@ -537,9 +541,9 @@ def test_oversketch_without_filtering_uses_the_small_sketcher_and_changes_nothin
     fq.write_bytes(b"".join(b"@r%d\n" % i + reads[i].tobytes() + b"\n+\n" + b"I" * 150 + b"\n" for i in range(len(reads))))
     p = SketchParams.mash(50_000, 700, True, 21, 0)  # no_strict: the abundance filter empties the genome's sketch
     for filt in (H.FilterParams(None), H.FilterParams(False), H.FilterParams(True, (2, None), 0.0, 0.0)):
-        monkeypatch.setenv("FINCH_NO_SMALL_SKETCHER", "1")
+        F.debug_set(no_small_sketcher="1")
         want = H.sketch_files([str(fa), str(fq)], p, filt)
-        monkeypatch.delenv("FINCH_NO_SMALL_SKETCHER")
+        F.debug_set(no_small_sketcher=None)
         got = H.sketch_files([str(fa), str(fq)], p, filt)
         assert got.to_json() == want.to_json()
         for i in range(2):

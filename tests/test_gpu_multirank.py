@@ -127,7 +127,10 @@ def test_c5_workload_two_handles_one_call():
     assert out["value"] > 0 and out["config"]["files_per_s"] > 0
     # the batch's line carries the kernel's roofline block and the all-cores CPU baseline (one file per task)
     r, c = out["roofline"], out["cpu_baseline"]
-    assert r["launches"] >= 300 and r["achieved"] > 0 and 0 < r["kernel_share_of_call"] <= 1.0
+    # (the files go many per launch -- fh_batch_*: far fewer sketch launches than files, every file accounted for)
+    assert 1 <= r["launches"] < 300 and r["achieved"] > 0 and 0 < r["kernel_share_of_call"] <= 1.0
+    assert r["files_taken_many_per_launch"] + r["files_through_own_sketcher"] == 300 and r["files_taken_many_per_launch"] >= 290
+    assert r["pcie"]["achieved_gbs"] > 0
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "one file per task" in c["sample"]
 
 

@@ -223,7 +223,7 @@ def test_capacity_stop_and_relaunch(n, inflight, monkeypatch):
     tile queue: nothing lost, nothing counted twice"""
     # (the speculative threshold falls short on these reads; re-reading the block for EVERYTHING above it, as until round 4, is
     # what fills the table here -- the rescaled re-read of round 4 does not get that far)
-    monkeypatch.setenv("FH_NO_SPEC_RESCALE", "1")
+    F.debug_set(no_spec_rescale="1")
     gl, nr, rl, seed = 500000, 200000, 150, 21
     dg = F.DeviceBuffer(gl)
     nbytes = nr * (rl + 1)
@@ -361,7 +361,7 @@ def test_copy_out_forms_agree():
 
 
 def test_select_prune_equals_sort_prune():
-    """between launches large live sets are pruned by a radix select; FH_NO_SELECT=1 makes every prune the full
+    """between launches large live sets are pruned by a radix select; option no_select makes every prune the full
     sort that fh_finish uses.  Both must give the same sketch (run in a subprocess: the switch is read once)."""
     import subprocess
     import sys
@@ -378,8 +378,8 @@ def test_select_prune_equals_sort_prune():
         "print(repr(out))\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    for extra in ({}, {"FH_NO_SELECT": "1"}):
-        env = dict(os.environ, **extra)
+    for extra in ({}, {"no_select": "1"}):
+        env = F.debug_env(**extra)
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res.append(eval(r.stdout.strip().splitlines()[-1], {"np": np}))
@@ -548,9 +548,10 @@ assert np.array_equal(kc, okc) and np.array_equal(km, okm)
 print("child ok")
 '''
     import subprocess, sys
-    for env in ({"EXPECT": "hit"}, {"EXPECT": "repair", "FH_SAMPLE_SCALE": "0.02"}, {"EXPECT": "loose", "FH_SAMPLE_SCALE": "30"},
-                {"EXPECT": "off", "FH_NO_SAMPLE": "1"}):
-        e = dict(os.environ, FH_SAMPLE_MIN_POS="1000000", **env)
+    for env in ({"EXPECT": "hit"}, {"EXPECT": "repair", "sample_scale": "0.02"}, {"EXPECT": "loose", "sample_scale": "30"},
+                {"EXPECT": "off", "no_sample": "1"}):
+        e = F.debug_env(sample_min_pos="1000000", **{k: v for k, v in env.items() if k.islower()})
+        e["EXPECT"] = env["EXPECT"]
         r = subprocess.run([sys.executable, "-c", code], env=e, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode == 0 and "child ok" in r.stdout, (env, r.stdout[-3000:])

@@ -94,7 +94,7 @@ def test_a_record_outside_the_buffer_is_refused_where_the_loop_is():
 
 def test_records_longer_than_the_staging_buffer(monkeypatch):
     """a 300 kb record through 64 KiB staging buffers: the library cuts it and continues (k-mers span the cuts)"""
-    monkeypatch.setenv("FH_STAGE_BYTES", "65536")
+    F.debug_set(stage_bytes="65536")
     F.load().fh_release_cached()
     rng = np.random.default_rng(4)
     recs = _records(rng, 5, 250_000, 300_000, p_blank=0.015) + _records(rng, 300, 10, 500)

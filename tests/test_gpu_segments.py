@@ -136,7 +136,7 @@ def test_loose_thresholds_stop_waves_inside_a_tile(genome, k, max_launch):
     budget again and again, stops at the end of a round and hands the rest of its range back -- ONE leftover entry per wave
     (first tile, end of range, round to resume at), so that a relaunch, which has as many waves as entries, leaves none unread.
     (Round 5's first version wrote two entries per stopping wave; the second half of a list was never read: found by the fuzzer
-    under FH_SEG_STRIDE=151, seed 525252 case 340.)"""
+    under option seg_stride=151, seed 525252 case 340.)"""
     rng = np.random.default_rng(6)
     stream = packed(random_reads(rng, 150, 0, 5000, p_n=0.001, genome=genome))
     for stride in (151, 100):
@@ -172,8 +172,8 @@ def test_blocks_pushed_one_after_the_other(genome):
 
 def test_stride_found_by_the_probe():
     """a block of whole records of one length is recognised without being told, N's inside the first record included; a ragged
-    block is not.  A handle's first block waits for the answer if it is large (FH_SEG_PROBE_WAIT_MIN; 256 MiB by default);
-    otherwise it is asked behind its own launches and the NEXT block of the handle goes by the answer (FH_SEG_PROBE_MIN: from
+    block is not.  A handle's first block waits for the answer if it is large (option seg_probe_wait_min; 256 MiB by default);
+    otherwise it is asked behind its own launches and the NEXT block of the handle goes by the answer (option seg_probe_min: from
     which size on; 16 MiB by default)"""
     code = r'''
 import numpy as np, os, sys
@@ -196,7 +196,7 @@ def run(sk, reads, want_stride):
 reads = random_reads(rng, 3000, 150, 150, p_n=0.002, genome=g)
 reads[0] = reads[0][:30] + b"NN" + reads[0][32:]
 ragged = random_reads(rng, 3000, 100, 150, genome=g)
-waits = os.environ["FH_SEG_PROBE_WAIT_MIN"] == "0"
+waits = F.get_option("seg_probe_wait_min") == "0"
 sk = F.SketchParams.mash(1000, 1000, True, 21, 0).create_sketcher()
 run(sk, reads, 151 if waits else 0)        # the handle's first block: by its own answer only if it waits for it
 run(sk, reads, 151)                        # the next one goes by what the first said
@@ -207,7 +207,7 @@ run(sk, random_reads(rng, 3000, 100, 100, genome=g), 101)
 print("probe OK")
 ''' % (ROOT, ROOT)
     for wait_min in ("0", "1000000000000"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FH_SEG_PROBE_MIN="0", FH_SEG_PROBE_WAIT_MIN=wait_min),
+        r = subprocess.run([sys.executable, "-c", code], env=F.debug_env(seg_probe_min="0", seg_probe_wait_min=wait_min),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert r.returncode == 0 and "probe OK" in r.stdout, (wait_min, r.stdout[-3000:])
 

@@ -6,6 +6,8 @@ import json
 import numpy as np
 import pytest
 
+import finch_rs_amd as F
+
 from finch_rs_amd import host as H
 from finch_rs_amd.sketch_schemes import FinchError, KC_DTYPE, SketchParams
 from oracle import oracle as O
@@ -290,7 +292,7 @@ def test_bgzf_members_are_inflated_in_parallel_and_checked(monkeypatch):
     assert want[0] == len(reads) and want[2] == 2
     z = _bgzf(fq)
     for thr in ("1", "2", "5"):
-        monkeypatch.setenv("FINCH_BGZF_THREADS", thr)
+        F.debug_set(bgzf_threads=thr)
         assert H.fastx_scan(z) == want, thr
         assert H.fastx_scan(_bgzf(fq, 65536)) == want                      # full-size members
         assert H.fastx_scan(_bgzf(fq, 777, eof_marker=False)) == want      # thousands of tiny members, no EOF marker
@@ -300,7 +302,7 @@ def test_bgzf_members_are_inflated_in_parallel_and_checked(monkeypatch):
         assert H.fastx_scan(gzip.compress(fq[:half], 1) + _bgzf(fq[half:])) == want
         with pytest.raises(FinchError, match="empty input"):                 # only the EOF marker: empty, as for plain text
             H.fastx_scan(_bgzf(b""))
-    monkeypatch.setenv("FINCH_BGZF_THREADS", "4")
+    F.debug_set(bgzf_threads="4")
     bad = bytearray(z)
     bad[len(z) // 2] ^= 0x55  # flips a bit inside some member's deflate data or trailer
     with pytest.raises(Exception):
@@ -348,7 +350,7 @@ def test_decompressed_stream_is_the_text_whatever_the_request_size(monkeypatch):
     images = {"plain": text, "gzip": gzip.compress(text, 1), "bgzf": _bgzf(text), "bgzf x3 batches": _bgzf(text, 9000), "bgzf+gzip": _bgzf(text[:5_000_000], eof_marker=False) + gzip.compress(text[5_000_000:], 1),
               "bz2": bz2.compress(text[:3_000_000]), "xz": lzma.compress(text[:3_000_000], preset=1)}
     for thr in ("1", "4"):
-        monkeypatch.setenv("FINCH_BGZF_THREADS", thr)
+        F.debug_set(bgzf_threads=thr)
         for name, img in images.items():
             want = text if name in ("plain", "gzip", "bgzf", "bgzf x3 batches", "bgzf+gzip") else text[:3_000_000]
             for chunk in (4096, 1 << 20, (5 << 20) + 13, 64 << 20):
@@ -449,7 +451,7 @@ def test_the_library_s_own_inflate_decodes_what_zlib_writes(monkeypatch):
     1 byte to 16 MiB -- the delivered stream is the text.  Damaged input is an error: truncation at any point, flipped
     bits (caught by the decoder or by the member's CRC-32 / ISIZE), garbage after a member."""
     import zlib
-    monkeypatch.setenv("FINCH_BGZF_THREADS", "1")  # the sequential reader (the parallel BGZF reader has its own test above)
+    F.debug_set(bgzf_threads="1")  # the sequential reader (the parallel BGZF reader has its own test above)
     rng = np.random.default_rng(31)
     kinds = {
         "random": lambda n: rng.integers(0, 256, n, dtype=np.uint8).tobytes(),
@@ -501,7 +503,7 @@ def test_the_library_s_own_inflate_decodes_what_zlib_writes(monkeypatch):
             H.source_probe(gz + tail, 1 << 20, 40000)
     with pytest.raises(FinchError, match="corrupt"):
         H.source_probe(gz[:3] + b"\xe0" + gz[4:], 1 << 20, 40000)  # reserved FLG bits
-    # and the zlib-based reader (FINCH_ZLIB_INFLATE=1) is still there for A/B runs: same bytes (checked in a child process:
+    # and the zlib-based reader (option zlib_inflate=1) is still there for A/B runs: same bytes (checked in a child process:
     # the switch is read once per process)
     import subprocess, sys, os
     code = ("import sys; sys.path.insert(0, %r); from finch_rs_amd import host as H; d = open(sys.argv[1], 'rb').read(); "
@@ -510,7 +512,7 @@ def test_the_library_s_own_inflate_decodes_what_zlib_writes(monkeypatch):
     with tempfile.NamedTemporaryFile(suffix=".gz") as f:
         f.write(multi)
         f.flush()
-        env = dict(os.environ, FINCH_ZLIB_INFLATE="1", FINCH_BGZF_THREADS="1")
+        env = F.debug_env(zlib_inflate="1", bgzf_threads="1")
         assert subprocess.run([sys.executable, "-c", code, f.name], env=env, stdout=subprocess.PIPE, check=True).stdout == text
 
 
@@ -592,9 +594,9 @@ def test_one_gzip_member_decoded_by_several_threads(monkeypatch):
     text = b"".join(recs)  # ~9.5 MB
     unique = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=3_000_000))  # markers fade quickly in this one
     fasta = b">chr1 test\n" + b"\n".join(unique[i:i + 70] for i in range(0, len(unique), 70)) + b"\n"
-    monkeypatch.setenv("FINCH_BGZF_THREADS", "4")
+    F.debug_set(bgzf_threads="4")
     for chunk in ("40000", "250000", "4194304"):
-        monkeypatch.setenv("FINCH_PARGZ_CHUNK", chunk)
+        F.debug_set(pargz_chunk=chunk)
         for level in (1, 6, 9):
             z = gzip.compress(text, level)
             for req in (4096, (5 << 20) + 13, 64 << 20):
@@ -633,7 +635,7 @@ def test_one_gzip_member_decoded_by_several_threads(monkeypatch):
     for t in (b"", b"@r\nA\n+\nI\n", text[:70000]):
         assert H.source_probe(gzip.compress(t), 4096, len(t) + 64) == t
     # the records are what the host parser makes of the plain text
-    monkeypatch.setenv("FINCH_PARGZ_CHUNK", "100000")
+    F.debug_set(pargz_chunk="100000")
     assert H.fastx_scan(gzip.compress(text, 6)) == H.fastx_scan(text)
 
 
@@ -642,8 +644,8 @@ def test_gzip_header_fields_in_front_of_a_member_decoded_in_parallel(monkeypatch
     member the parallel reader takes"""
     import struct
     import zlib
-    monkeypatch.setenv("FINCH_BGZF_THREADS", "4")
-    monkeypatch.setenv("FINCH_PARGZ_CHUNK", "60000")
+    F.debug_set(bgzf_threads="4")
+    F.debug_set(pargz_chunk="60000")
     rng = np.random.default_rng(1)
     text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=100)),
                                               bytes(rng.integers(35, 74, size=100, dtype=np.uint8))) for i in range(20000))
@@ -706,7 +708,7 @@ def test_dynamic_block_that_ends_within_bits_of_its_header(monkeypatch):
     looking at the code -- and rejected members zlib accepts: a BGZF member's input ends exactly where its DEFLATE stream does"""
     import struct
     import zlib
-    monkeypatch.setenv("FINCH_BGZF_THREADS", "4")
+    F.debug_set(bgzf_threads="4")
     for extra in (0, 1):
         raw = _tiny_dynamic_block(extra)
         d = zlib.decompressobj(-15)
@@ -741,7 +743,7 @@ def test_parallel_gzip_keeps_going_through_a_very_compressible_member(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prog = ("import sys, hashlib; sys.path.insert(0, %r)\nfrom finch_rs_amd import host as H\n"
             "d = H.source_probe(open(%r, 'rb').read(), 1 << 22, %d)\nprint(len(d), hashlib.md5(d).hexdigest())" % (root, str(p), len(text) + 64))
-    r = subprocess.run([sys.executable, "-c", prog], env=dict(os.environ, FH_TRACE="1", FINCH_BGZF_THREADS="4"), stdout=subprocess.PIPE,
+    r = subprocess.run([sys.executable, "-c", prog], env=F.debug_env(trace="1", bgzf_threads="4"), stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True)
     import hashlib
     assert r.returncode == 0, r.stderr[-2000:]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE configs[2] on the resident 10 Gbase stream (what bench.py reports as extras.c3): k = 31, kmers_to_sketch = 2 000 000,
 then strand filter 0.1 + error filter 0.31 + cut to 10 000 on the host (finch_sketch_from_sketcher).  Best of --reps passes, with
-the phases of one pass.   FH_NO_LAZY_COPYOUT=1 / FH_SAMPLE_WANT=1.25 / FH_NO_SAMPLE=1 for A/B.   (GPU box)"""
+the phases of one pass.   FH_DEBUG=no_lazy_copyout / sample_want=1.25 / no_sample for A/B.   (GPU box)"""
 import argparse
 import os
 import sys
@@ -45,4 +45,4 @@ for rep in range(a.reps + 1):
     print("rep %d: sketch %.2f ms  finish %.2f ms  filters+records %.2f ms  total %.2f ms  fingerprint %s" %
           (rep, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t3 - t0) * 1e3, fp), flush=True)
 print("configs[2] with host filters: %.2f ms per pass, %.1f Gbases/s  (lazy copy-out %s)" %
-      (best * 1e3, n_reads * RL / best / 1e9, "off" if os.environ.get("FH_NO_LAZY_COPYOUT") else "on"))
+      (best * 1e3, n_reads * RL / best / 1e9, "off" if "no_lazy_copyout" in os.environ.get("FH_DEBUG", "") else "on"))

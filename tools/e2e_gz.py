@@ -4,6 +4,7 @@ import gzip, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from finch_rs_amd import host as H, sketch_schemes as S
+import finch_rs_amd as F  # noqa: E402
 g = S.synth_genome_host(5_000_000, 7)
 n_reads, rl = 1_500_000, 150
 reads = S.synth_reads_host(g, 0, n_reads, rl, 7, 10000, 500).reshape(n_reads, rl + 1)[:, :rl]
@@ -41,7 +42,7 @@ with open(bpath, "wb") as f: f.write(bgzf(raw))
 print("wrote the same text as %.0f MB BGZF in %.1f s" % (os.path.getsize(bpath) / 1e6, time.time() - t))
 ref = res.sketch(0).arrays[0]
 for thr in ("1", "2", "4", "8", "16"):
-    os.environ["FINCH_READ_THREADS"] = thr
+    F.debug_set(read_threads=thr)
     best = 1e9
     for rep in range(2):
         t = time.time(); rb = H.sketch_files([bpath], p, H.FilterParams(False)); best = min(best, time.time() - t)

@@ -1,5 +1,5 @@
 """End-to-end rate of one large FASTQ / FASTA file (page cache -> pinned staging -> device-side record splitting ->
-sketch) by FINCH_READ_THREADS.  Each setting runs in a child process (the knob is read once).
+sketch) by the option read_threads.  Each setting runs in a child process (the knob is read once).
 usage (GPU box): python tools/e2e_read_threads.py"""
 import os, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,5 +32,5 @@ if not os.path.exists("/tmp/e2e.fastq"):
             blk = seq[i:i + 70 * 100000]
             f.write(b"\n".join(blk[j:j + 70] for j in range(0, len(blk), 70))); f.write(b"\n")
 for nt in (1, 2, 4, 8):
-    print("FINCH_READ_THREADS=%d" % nt, flush=True)
-    subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, FINCH_READ_THREADS=str(nt)), check=True)
+    print("read_threads=%d" % nt, flush=True)
+    subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, FH_DEBUG="read_threads=%d" % nt), check=True)

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""Where an end-to-end call spends its time (GPU box): finch_sketch_buffer on a FASTQ text image in host memory with FH_TRACE=1,
+"""Where an end-to-end call spends its time (GPU box): finch_sketch_buffer on a FASTQ text image in host memory with option trace,
 by number of read threads.   python tools/e2e_trace.py [reads]"""
 import os
 import sys
 import time
 
-os.environ["FH_TRACE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import finch_rs_amd as F
+F.debug_set(trace="1")
 from finch_rs_amd import host as H, sketch_schemes as S
 
 ns = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
@@ -32,7 +32,7 @@ txt[:, w - 1] = 10
 data = txt.reshape(-1)
 p = F.SketchParams.mash(1000, 1000, True, 21, 0)
 for thr in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["1", "4", "8", "16"]):
-    os.environ["FINCH_READ_THREADS"] = thr
+    F.debug_set(read_threads=thr)
     best = 1e30
     for it in range(3):
         print("---- read threads %s, pass %d" % (thr, it), file=sys.stderr, flush=True)

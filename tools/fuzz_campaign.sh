@@ -8,13 +8,13 @@ SO=${2:-0}
 for cfg in "40 616161 1200" "100 626262 1200" "151 636363 2000" "168 646464 1200" "61 666666 800" "0 656565 1500"; do
   set -- $cfg
   set -- $1 $(($2 + SO)) $3
-  if [ "$1" != "0" ]; then export FH_SEG_STRIDE=$1; else unset FH_SEG_STRIDE; fi
-  echo "== FH_SEG_STRIDE=${FH_SEG_STRIDE:-unset} seed $2 cases $3" >> $O
+  if [ "$1" != "0" ]; then export FH_DEBUG=seg_stride=$1; else unset FH_DEBUG; fi
+  echo "== FH_DEBUG=${FH_DEBUG:-unset} seed $2 cases $3" >> $O
   # (tests/test_gpu_segments.py asserts which stride a block went by: only where none is forced)
   SEGT=""; [ "$1" = "0" ] && SEGT=tests/test_gpu_segments.py
   FH_FUZZ_CASES=$3 FH_FUZZ_SEED=$2 timeout 900 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_parity.py tests/test_gpu_fast_path.py tests/test_gpu_process.py $SEGT -x -q 2>&1 | tail -3 >> $O
 done
-unset FH_SEG_STRIDE
+unset FH_DEBUG
 echo "== fuzz_params" >> $O; timeout 600 python tools/fuzz_params.py 2>&1 | tail -3 >> $O
 echo "== fuzz_device_text" >> $O; timeout 600 python tools/fuzz_device_text.py 2>&1 | tail -3 >> $O
 echo "== fuzz_gzip" >> $O; timeout 600 python tools/fuzz_gzip.py 2>&1 | tail -3 >> $O

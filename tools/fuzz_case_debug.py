@@ -30,7 +30,7 @@ stage = int(rng.choice([0, 8192, 70000]))
 sk = params.create_sketcher(max_launch=inflight, stage_bytes=stage)
 form = [None, "1", "0"][case % 3]
 if form is not None:
-    os.environ["FH_READ_FIRST"] = form
+    F.debug_set(read_first=form)
 print(dict(k=k, kind=kind, size=size, seed=seed, inflight=inflight, n_rec=n_rec, maxlen=maxlen, stage=stage, form=form, total_bytes=sum(map(len, recs))))
 forced = os.environ.get("MODE")
 for rep in range(2):

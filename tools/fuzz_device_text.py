@@ -14,6 +14,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from finch_rs_amd import host as H, sketch_schemes as S
+import finch_rs_amd as F  # noqa: E402
 from oracle import oracle as O
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
@@ -22,9 +23,9 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 77000
 
 def run(data, p, mode):
     if mode is None:
-        os.environ.pop("FINCH_DEVICE_PARSE", None)
+        F.debug_set(device_parse=None)
     else:
-        os.environ["FINCH_DEVICE_PARSE"] = mode
+        F.debug_set(device_parse=mode)
     try:
         return H.sketch_stream(data, "x", p, H.FilterParams(False)).sketch(0), None
     except Exception as e:  # noqa
@@ -67,7 +68,7 @@ n_sharded = 0
 
 def check_sharded(ref, data, p, case, rng):
     global n_sharded
-    os.environ.pop("FINCH_DEVICE_PARSE", None)
+    F.debug_set(device_parse=None)
     for chunk in (int(rng.integers(16000, 40000)), 0):  # (a FASTQ record -- up to 6 KB here -- has to fit a chunk)
         try:
             r = H.sketch_stream_sharded(data, "x", p, H.FilterParams(False), [0, 0, 0], chunk).sketch(0)
@@ -83,7 +84,7 @@ def check_sharded(ref, data, p, case, rng):
 def check_files(ref, data, p, case):
     """ref: the sketch of the text through sketch_stream (None: it was refused)"""
     global n_files
-    os.environ.pop("FINCH_DEVICE_PARSE", None)
+    F.debug_set(device_parse=None)
     for ext, img in ((".txt", data), (".gz", gzip.compress(data, 1)), (".bgzf.gz", bgzf(data))):
         path = "/dev/shm/fuzz_text_%d%s" % (os.getpid(), ext)
         with open(path, "wb") as f:

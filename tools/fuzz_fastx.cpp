@@ -149,7 +149,8 @@ int main(int argc, char **argv) {
     const uint64_t iters = argc > 1 ? strtoull(argv[1], nullptr, 10) : 20000;
     const uint64_t seed = argc > 2 ? strtoull(argv[2], nullptr, 10) : 1;
     std::mt19937_64 rng(seed);
-    setenv("FINCH_PARGZ_CHUNK", "65536", 1); // several chunks per gzip member even in these small files
+    // (the library's options travel in FH_DEBUG: several chunks per gzip member even in these small files, 1 or 4 inflate threads)
+    auto options = [](const char *threads) { setenv("FH_DEBUG", (std::string("pargz_chunk=65536,bgzf_threads=") + threads).c_str(), 1); };
     std::vector<Case> cases;
     for (int rep = 0; rep < 3; ++rep) {
         uint64_t b = 0;
@@ -166,12 +167,12 @@ int main(int argc, char **argv) {
     }
     const char *threads[] = {"1", "4"};
     for (const char *t : threads) {
-        setenv("FINCH_BGZF_THREADS", t, 1);
+        options(t);
         for (const Case &c : cases) scan(c.image, &c);
     }
     fprintf(stderr, "%zu undamaged inputs scanned right with 1 and 4 inflate threads\n", cases.size());
     for (uint64_t it = 0; it < iters; ++it) {
-        setenv("FINCH_BGZF_THREADS", threads[rng() & 1], 1);
+        options(threads[rng() & 1]);
         const Case &c = cases[rng() % cases.size()];
         std::vector<uint8_t> d = c.image;
         mutate(rng, d);

@@ -54,16 +54,14 @@ def gz_image(rng, data):
 
 
 def run(path, p, device):
-    os.environ["FINCH_DEVICE_GZIP"] = "" if device else "0"
-    if device:
-        os.environ.pop("FINCH_DEVICE_GZIP")
+    F.debug_set(device_gzip=None if device else "0")
     try:
         sk = H.sketch_files([path], p, H.FilterParams(False), n_threads=4).sketch(0)
         return ("ok", sk.arrays[0].tobytes(), sk.arrays[1].tobytes(), sk.seq_length, sk.num_valid_kmers)
     except S.FinchError as e:
         return ("err",)
     finally:
-        os.environ.pop("FINCH_DEVICE_GZIP", None)
+        F.debug_set(device_gzip=None)
 
 
 d = tempfile.mkdtemp(prefix="fuzz_gz_", dir="/dev/shm")
@@ -90,14 +88,13 @@ try:
             n_damaged += 1
         path = os.path.join(d, "c%d.fastq.gz" % case)
         open(path, "wb").write(img)
-        for k in ("FH_GZ_CHUNK", "FINCH_GZIP_PIECE"):
-            os.environ.pop(k, None)
+        F.debug_set(gz_chunk=None, gzip_piece=None)
         ck = rng.choice([0, 0, 1024, 4096, 20000, 65536])
         if ck:
-            os.environ["FH_GZ_CHUNK"] = str(int(ck))
+            F.debug_set(gz_chunk=str(int(ck)))
         pc = rng.choice([0, 0, 65536, 300_000, 1 << 20])
         if pc:
-            os.environ["FINCH_GZIP_PIECE"] = str(int(pc))
+            F.debug_set(gzip_piece=str(int(pc)))
         kk = int(rng.choice([11, 21, 31]))
         p = F.SketchParams.mash(1000, 1000, True, kk, 0)
         before = H.debug_device_gzip()
@@ -120,5 +117,4 @@ try:
           % (n_cases, n_damaged, n_dev, n_refused))
 finally:
     shutil.rmtree(d, ignore_errors=True)
-    for k in ("FH_GZ_CHUNK", "FINCH_GZIP_PIECE"):
-        os.environ.pop(k, None)
+    F.debug_set(gz_chunk=None, gzip_piece=None)

@@ -10,6 +10,7 @@ import gzip, os, struct, sys, zlib
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from finch_rs_amd import host as H, sketch_schemes as S
+import finch_rs_amd as F  # noqa: E402
 from oracle import oracle as O
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
@@ -58,26 +59,26 @@ for case in range(n_cases):
     fo = [None, True, False][int(rng.integers(0, 3))]
     f = H.FilterParams(fo, (int(rng.integers(1, 4)) if rng.random() < 0.4 else None, int(rng.integers(20, 200)) if rng.random() < 0.3 else None),
                        float(rng.choice([0.0, 0.05, 0.2, 1.0])), float(rng.choice([0.0, 0.1, 0.4])))
-    os.environ.pop("FINCH_NO_SMALL_SKETCHER", None)
-    os.environ["FINCH_DEVICE_PARSE"] = "0"
+    F.debug_set(no_small_sketcher=None)
+    F.debug_set(device_parse="0")
     ref = result(lambda: H.sketch_stream(data, "x", p, f))
-    os.environ.pop("FINCH_DEVICE_PARSE")
+    F.debug_set(device_parse=None)
     routes = {"device split": lambda: H.sketch_stream(data, "x", p, f)}  # (a small FASTA text: packed on the host while staged)
 
     def forced_splitter():
-        os.environ["FINCH_SMALL_FASTA_HOST"] = "0"
+        F.debug_set(small_fasta_host="0")
         try:
             return H.sketch_stream(data, "x", p, f)
         finally:
-            os.environ.pop("FINCH_SMALL_FASTA_HOST")
+            F.debug_set(small_fasta_host=None)
     routes["device splitter, small-file packing off"] = forced_splitter
     routes["sharded x3"] = lambda: H.sketch_stream_sharded(data, "x", p, f, [0, 0, 0], int(rng.integers(20000, 200000)))
     for name, fn in routes.items():
         r = result(fn)
         assert r == ref, (case, name, r[0], ref[0], r[1:] if r[0] == "err" else "", ref[1:] if ref[0] == "err" else "")
-    os.environ["FINCH_NO_SMALL_SKETCHER"] = "1"
+    F.debug_set(no_small_sketcher="1")
     r = result(lambda: H.sketch_stream(data, "x", p, f))
-    os.environ.pop("FINCH_NO_SMALL_SKETCHER")
+    F.debug_set(no_small_sketcher=None)
     assert r == ref, (case, "full-size sketcher", r[0], ref[0])
     for ext, img in ((".gz", gzip.compress(data, 1)), (".bgzf.gz", bgzf(data))):
         path = "/dev/shm/fuzz_params_%d%s" % (os.getpid(), ext)

@@ -31,7 +31,7 @@ e2e)         # where the end-to-end paths spend their time
   python tools/batch_threads.py > gpurun_out/r03_batch_threads.txt 2>&1
   ;;
 c3prof)      # configs[2] (k=31, 2 M hashes): phases, kernel timeline, counters of the sketch launches
-  FH_TRACE=1 python tools/phase_times.py --k 31 --n 2000000 --reps 3 > gpurun_out/r03_c3_phases.txt 2>&1
+  FH_DEBUG=trace python tools/phase_times.py --k 31 --n 2000000 --reps 3 > gpurun_out/r03_c3_phases.txt 2>&1
   cd /tmp; rocprofv3 --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/r03_c3_trace -o t --output-format csv -- python $GRAFT_REPO_ROOT/tools/phase_times.py --k 31 --n 2000000 --reps 2 > /dev/null 2>&1; cd $GRAFT_REPO_ROOT
   python tools/kernel_timeline.py gpurun_out/r03_c3_trace --min-ms 0.05 > gpurun_out/r03_c3_kernel_timeline.txt 2>&1
   bash tools/pmc_k2.sh r03_c3 python $GRAFT_REPO_ROOT/tools/phase_times.py --k 31 --n 2000000 --reps 1 > gpurun_out/r03_c3_pmc.txt 2>&1
@@ -39,8 +39,8 @@ c3prof)      # configs[2] (k=31, 2 M hashes): phases, kernel timeline, counters 
 round2)      # after: interpolated sample threshold, H2D prefetch, wide LDS reads -- parity first, then the numbers
   timeout 1800 python -m pytest tests/test_gpu_parity.py tests/test_gpu_host_layer.py tests/test_gpu_fuzz.py tests/test_gpu_errors.py -x -q -m gpu 2>&1 | tail -4 | tee gpurun_out/r03_round2_pytest.txt
   python tools/e2e_trace.py 4000000 1,8 > gpurun_out/r03b_e2e_trace.txt 2> gpurun_out/r03b_e2e_trace.err
-  FH_TRACE=1 python tools/phase_times.py --k 31 --n 2000000 --reps 3 2>&1 | grep -v "launch " > gpurun_out/r03b_c3_phases.txt
-  FH_SAMPLE_WANT=1.25 FH_TRACE=1 python tools/phase_times.py --k 31 --n 2000000 --reps 3 2>&1 | grep -v "launch " > gpurun_out/r03b_c3_phases_want125.txt
+  FH_DEBUG=trace python tools/phase_times.py --k 31 --n 2000000 --reps 3 2>&1 | grep -v "launch " > gpurun_out/r03b_c3_phases.txt
+  FH_DEBUG=sample_want=1.25,trace python tools/phase_times.py --k 31 --n 2000000 --reps 3 2>&1 | grep -v "launch " > gpurun_out/r03b_c3_phases_want125.txt
   bash tools/pmc_k2.sh r03b_c3 python $GRAFT_REPO_ROOT/tools/phase_times.py --k 31 --n 2000000 --reps 1 > gpurun_out/r03b_c3_pmc.txt 2>&1
   ;;
 c5prof)      # what the GPU does per file of a batch (configs[4]'s shape)
@@ -70,7 +70,7 @@ round3)      # after: inline single-chunk pump, one-block copy-out, two-stage sa
   timeout 1800 python -m pytest tests/test_gpu_parity.py tests/test_gpu_host_layer.py tests/test_gpu_fuzz.py tests/test_gpu_errors.py tests/test_gpu_bgzf_device.py -x -q -m gpu 2>&1 | tail -4 | tee gpurun_out/r03_round3_pytest.txt
   for nt in 8 12 16; do python tools/batch_trace.py 512 $nt; done > gpurun_out/r03c_c5_threads.txt 2>&1
   python tools/one_worker_trace.py 2>&1 | tail -4 > gpurun_out/r03c_one_worker.txt
-  FH_TRACE=1 python tools/phase_times.py --k 31 --n 2000000 --reps 3 2>&1 | grep -v "launch " > gpurun_out/r03c_c3_phases.txt
+  FH_DEBUG=trace python tools/phase_times.py --k 31 --n 2000000 --reps 3 2>&1 | grep -v "launch " > gpurun_out/r03c_c3_phases.txt
   ;;
 c5bench)     # configs[4] at its size through bench.py (one GPU; and two handles on the one GPU), multirank tests
   timeout 1500 python bench.py --workload c5 --steps 2 --warmup 1 > gpurun_out/r03_bench_c5.json 2> gpurun_out/r03_bench_c5.err; echo "c5 rc=$?"
@@ -80,7 +80,7 @@ c5bench)     # configs[4] at its size through bench.py (one GPU; and two handles
 round4)      # after: lazy wide-column copy-out (+ device-side row gather)
   timeout 1800 python -m pytest tests/test_gpu_parity.py tests/test_gpu_host_layer.py tests/test_gpu_full_size.py -x -q -m gpu -k "not c4 and not c5 and not c2" 2>&1 | tail -4 | tee gpurun_out/r03_round4_pytest.txt
   python tools/c3_resident.py > gpurun_out/r03d_c3_resident.txt 2>&1
-  FH_NO_LAZY_COPYOUT=1 python tools/c3_resident.py > gpurun_out/r03d_c3_resident_nolazy.txt 2>&1
+  FH_DEBUG=no_lazy_copyout python tools/c3_resident.py > gpurun_out/r03d_c3_resident_nolazy.txt 2>&1
   ;;
 final)       # the state the round ends in
   timeout 2400 python -m pytest tests -x -q -m gpu -rs --durations=8 2>&1 | tail -24 | tee gpurun_out/r03z_pytest_gpu_tail.txt
@@ -93,7 +93,7 @@ final)       # the state the round ends in
 ab_waves)    # k <= 24 in rounds of 16 / 8 at four and five waves per SIMD (LDS 32 KB per workgroup makes five fit)
   L=cur=finch_rs_amd/libfinch_hip.so,r16=build/ab/k21r16.so,r16w5=build/ab/k21r16w5.so,r8w5=build/ab/k21r8w5.so
   timeout 900 python tools/ab_k.py --libs $L --ks 17,20,21,24,31 2>&1 | tee gpurun_out/r03_ab_waves.txt
-  timeout 900 python tools/ab_k.py --libs $L --ks 17,20,21,24,31 --env "FH_WAVES_PER_CU=20" 2>&1 | tee gpurun_out/r03_ab_waves_20percu.txt
+  timeout 900 python tools/ab_k.py --libs $L --ks 17,20,21,24,31 --env "FH_DEBUG=waves_per_cu=20" 2>&1 | tee gpurun_out/r03_ab_waves_20percu.txt
   ;;
 round5)      # after: fused filter passes (finish_mash_in_place)
   timeout 1800 python -m pytest tests/test_gpu_host_layer.py tests/test_gpu_full_size.py tests/test_gpu_fuzz.py -x -q -m gpu -k "not c4 and not c5 and not c2" 2>&1 | tail -4 | tee gpurun_out/r03_round5_pytest.txt

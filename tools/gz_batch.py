@@ -39,13 +39,13 @@ try:
     res = {}
     for name, env in (("device", None), ("host", "0")):
         if env:
-            os.environ["FINCH_DEVICE_GZIP"] = env
+            F.debug_set(device_gzip=env)
         best = 1e9
         for _ in range(3):
             t0 = time.perf_counter()
             r = H.sketch_files(paths, prm, H.FilterParams(False))
             best = min(best, time.perf_counter() - t0)
-        os.environ.pop("FINCH_DEVICE_GZIP", None)
+        F.debug_set(device_gzip=None)
         res[name] = [r.sketch(i).arrays[0].tobytes() for i in range(nf)]
         print("%-6s %.1f ms  %.0f files/s  %.2f Gbases/s   on device / reread: %s" % (name, best * 1e3, nf / best, nf * ns * RL / best / 1e9, H.debug_device_gzip()))
     assert res["device"] == res["host"]

@@ -40,19 +40,19 @@ try:
         modes = tuple(m for m in modes if m[0] == os.environ["GZ_ONLY"])
     for name, env in modes:
         if env:
-            os.environ["FINCH_DEVICE_GZIP"] = env
+            F.debug_set(device_gzip=env)
         best = 1e9
         for _ in range(int(os.environ.get("GZ_REPS", "4"))):
             t0 = time.perf_counter()
             sk = H.sketch_files([path], p, H.FilterParams(False))
             best = min(best, time.perf_counter() - t0)
-        os.environ.pop("FINCH_DEVICE_GZIP", None)
+        F.debug_set(device_gzip=None)
         s0 = sk.sketch(0)
         res[name] = (s0.arrays[0].tobytes(), s0.seq_length)
         print("%-6s %.1f ms  %.2f Gbases/s  %.2f GB/s of text   on device / reread: %s" % (name, best * 1e3, ns * RL / best / 1e9, len(raw) / best / 1e9, H.debug_device_gzip()))
     assert len(res) < 2 or res["device"] == res["host"]
     if os.environ.get("GZ_TRACE"):
-        os.environ["FH_TRACE"] = "1"
+        F.debug_set(trace="1")
         H.sketch_files([path], p, H.FilterParams(False))
 finally:
     shutil.rmtree(d, ignore_errors=True)

@@ -4,6 +4,7 @@ import gzip, os, sys, time, zlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from finch_rs_amd import host as H, sketch_schemes as S
+import finch_rs_amd as F  # noqa: E402
 noisy = "--noisy" in sys.argv
 level = int(sys.argv[sys.argv.index("--level") + 1]) if "--level" in sys.argv else 1
 g = S.synth_genome_host(5_000_000, 7)
@@ -18,7 +19,7 @@ with open(path, "wb") as f:
 p = S.SketchParams.mash(1000, 1000, True, 21, 0)
 print("%.0f MB text as %.0f MB gzip (level %d, %s quality)" % (len(raw) / 1e6, os.path.getsize(path) / 1e6, level, "random" if noisy else "constant"), flush=True)
 for thr in (1, 4, 8, 16, 32):
-    os.environ["FINCH_READ_THREADS"] = str(thr)
+    F.debug_set(read_threads=str(thr))
     best = 1e9
     for rep in range(3):
         t = time.time()

@@ -1,4 +1,4 @@
-"""one 5 Mb FASTA, CLI-default oversketch, a few times on one worker thread (for rocprofv3 / FH_TRACE)"""
+"""one 5 Mb FASTA, CLI-default oversketch, a few times on one worker thread (for rocprofv3 / FH_DEBUG=trace)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from finch_rs_amd import host as H, sketch_schemes as S

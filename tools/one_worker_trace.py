@@ -1,7 +1,8 @@
 import os, sys, time
-os.environ["FH_TRACE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from finch_rs_amd import host as H, sketch_schemes as S
+import finch_rs_amd as F  # noqa: E402
+F.debug_set(trace="1")
 seq = S.synth_genome_host(20_000_000, 7).tobytes()
 paths = []
 for i in range(24):

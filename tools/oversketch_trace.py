@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""What one pass over configs[1]'s resident stream is made of at a given (k, n): the launches FH_TRACE logs, the sketch kernel's own
-time, the pass's wall time.   FH_TRACE=1 python tools/oversketch_trace.py [k [n [gbases]]]      (on an MI355X; under
+"""What one pass over configs[1]'s resident stream is made of at a given (k, n): the launches the option trace logs, the sketch kernel's own
+time, the pass's wall time.   FH_DEBUG=trace python tools/oversketch_trace.py [k [n [gbases]]]      (on an MI355X; under
 `rocprofv3 --kernel-trace --stats` it also gives the per-kernel totals)"""
 import os
 import sys
