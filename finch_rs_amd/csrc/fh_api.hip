@@ -156,7 +156,8 @@ struct fh_sketcher {
         uint32_t tiles_total = 0, n_units = 0, n_left_in = 0;
         uint32_t unit_tiles = UNIT_TILES; // queue granularity of this range (1 for inputs that would not fill the chip with 2)
         uint32_t first_units = 0, grid_waves = 0; // the range's first launch: units every wave starts on unasked, and its waves
-        uint32_t seg = 0; // != 0: the range runs through the segment kernel with this stride (tiles of 64 x seg positions)
+        uint32_t seg = 0; // != 0: the range runs through the segment kernel with this stride (tiles of 64 / seg_sub x seg positions)
+        uint32_t seg_sub = 1; // lanes per record there (fh_device.h, seg_sub_for)
         uint32_t max_units = MAX_UNITS; // units a pull takes at most
         int left_cur = 0;
         double admit_at_start = 1.0; // admit rate the range started with (for the novelty estimate)
@@ -194,7 +195,9 @@ struct fh_sketcher {
     uint32_t seg_hint = 0, blk_seg = 0;
     uint64_t gran = TILE_POS;
     uint32_t *h_probe = nullptr; // pinned: launch_seg_probe's answer
-    bool probe_seen = false;     // a block of this handle has been asked (h_probe[0] is its answer, or a later block's)
+    bool probe_seen = false;     // a block of this handle has been asked (probe_answer is its answer, or a later block's)
+    hipEvent_t probe_ev = nullptr; // recorded behind the newest probe: h_probe[0] is read only once it has completed
+    uint32_t probe_answer = 0;     // the newest answer read that way
     uint64_t n_seg_launches = 0, n_seg_probes = 0;
     uint64_t max_waves = 0;
     uint64_t max_range = 0; // test knob: cap on positions per range
@@ -531,6 +534,7 @@ int launch_pending(fh_sketcher *s) {
     a.first_units = r.first_units; // (start_range's launch only: a relaunch takes what is left through the queue)
     a.static_only = r.first_units && (uint64_t)r.first_units * r.grid_waves >= r.n_units ? 1u : 0u;
     a.seg_stride = r.seg;
+    a.seg_sub = r.seg_sub;
     a.max_units = r.max_units;
     r.first_units = 0;
     a.left_in = s->left_buf[r.left_cur];
@@ -665,10 +669,11 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
     r.base_pos = base_pos;
     r.p_begin = pos;
     r.p_end = end;
-    // the segment kernel where the block has a stride and the launch is the plain one (seed 0, no test mask, no lower threshold)
+    // the segment kernel where the block has a stride and the launch is the plain one (any seed; no test mask, no lower threshold)
     // (K > 32: fh_k2ws.hip takes seed, mask and lower threshold at run time, as fh_k2w.hip does)
-    r.seg = (s->blk_seg && (s->p.k > 32 || (s->p.seed == 0 && !s->p.hash_mask && !s->tau_lo)) && pos % (64ull * s->blk_seg) == 0) ? s->blk_seg : 0u;
-    const uint64_t tile = r.seg ? 64ull * r.seg : (uint64_t)TILE_POS;
+    r.seg = (s->blk_seg && (s->p.k > 32 || (!s->p.hash_mask && !s->tau_lo)) && pos % s->gran == 0) ? s->blk_seg : 0u;
+    r.seg_sub = r.seg ? seg_sub_for(r.seg) : 1u;
+    const uint64_t tile = r.seg ? (uint64_t)seg_tile_pos(r.seg, r.seg_sub) : (uint64_t)TILE_POS;
     const uint64_t tiles = (end - pos + tile - 1) / tile;
     if (tiles >= (1ull << 31)) return fail(FH_ERR_INVALID, "block too large for one range");
     r.tiles_total = (uint32_t)tiles;
@@ -1012,27 +1017,34 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
             return e ? (uint32_t)atoi(e) : 0u;
         }();
         uint32_t S = seg_env ? seg_env : s->seg_hint;
-        if (!seg_off && S != 1u && (s->p.k > 32 || (s->p.seed == 0 && !s->p.hash_mask))) {
+        if (!seg_off && S != 1u && (s->p.k > 32 || !s->p.hash_mask)) {
             if (S == 0 && len >= probe_min) {
                 if (!s->h_probe) {
                     HIP_TRY(host_malloc(&s->h_probe, 64));
                     s->h_probe[0] = 0;
                 }
                 if (s->probe_seen) {
-                    S = s->h_probe[0];
+                    // (the newest probe may still be running -- it sits behind its block's launches: its answer is taken once
+                    // its event has completed, until then the one before it stands)
+                    if (s->probe_ev && hipEventQuery(s->probe_ev) == hipSuccess) s->probe_answer = s->h_probe[0];
+                    else (void)hipGetLastError();
+                    S = s->probe_answer;
                 } else if (len >= probe_wait_min) {
                     if (int rc = flush_epilogue(s)) return rc;
                     HIP_TRY(launch_seg_probe(d_seq, len, s->h_probe, s->stream));
                     HIP_TRY(hipStreamSynchronize(s->stream));
-                    S = s->h_probe[0];
+                    S = s->probe_answer = s->h_probe[0];
                     s->n_seg_probes++;
                     s->probe_seen = true;
                 }
                 probe_behind = true;
             }
-            if (S >= SEG_MIN_STRIDE && S <= SEG_MAX_STRIDE && S > s->p.k && n_pos >= 64ull * S) {
+            // (records of up to SEG_MAX_RECORD - 1 bases, two or four lanes to a record beyond SEG_MAX_STRIDE; the two-word kernels
+            // take a lane per record only)
+            const uint32_t s_max = s->p.k > 32 ? SEG_MAX_STRIDE : SEG_MAX_RECORD;
+            if (S >= SEG_MIN_STRIDE && S <= s_max && S > s->p.k && n_pos >= 64ull * S) {
                 s->blk_seg = S;
-                s->gran = 64ull * S;
+                s->gran = seg_tile_pos(S, seg_sub_for(S));
             }
         }
     }
@@ -1044,6 +1056,8 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
         ~ProbeBehind() {
             if (!on || !s->h_probe) return;
             if (launch_seg_probe(seq, len, s->h_probe, s->stream) == hipSuccess) {
+                if (!s->probe_ev && hipEventCreateWithFlags(&s->probe_ev, hipEventDisableTiming) != hipSuccess) s->probe_ev = nullptr;
+                if (s->probe_ev) (void)hipEventRecord(s->probe_ev, s->stream);
                 s->probe_seen = true;
                 s->n_seg_probes++;
             }
@@ -1553,6 +1567,8 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
                 s->n_seg_launches = s->n_seg_probes = 0;
                 s->seg_hint = 0;
                 s->probe_seen = false; // (the previous owner's reads say nothing about the new one's)
+                s->probe_answer = 0;
+                s->gz_no_feed = false; // (nor does a feed that timed out on its files)
                 {
                     const bool fast = !s->big_mode && cfg("no_fast") == nullptr;
                     const bool hist = fast && s->p.size > 0 && cfg("no_hist") == nullptr;
@@ -1776,6 +1792,7 @@ void destroy_handle(fh_sketcher *s) {
     (void)hipFree(s->smp_hist);
     if (s->h_smp_hist) (void)hipHostFree(s->h_smp_hist);
     if (s->h_probe) (void)hipHostFree(s->h_probe);
+    if (s->probe_ev) (void)hipEventDestroy(s->probe_ev);
     if (s->copy_stream) {
         (void)hipStreamSynchronize(s->copy_stream);
         (void)hipStreamDestroy(s->copy_stream);
@@ -1935,7 +1952,7 @@ int fh_total_bases(fh_sketcher *s, uint64_t *total_bases) {
 
 int fh_set_record_stride(fh_sketcher *s, uint32_t stride) {
     if (!s) return fail(FH_ERR_INVALID, "null argument");
-    if (stride > 1u && (stride < SEG_MIN_STRIDE || stride > SEG_MAX_STRIDE)) stride = 1u; // (nothing the segment kernel takes)
+    if (stride > 1u && (stride < SEG_MIN_STRIDE || stride > (s->p.k > 32 ? SEG_MAX_STRIDE : SEG_MAX_RECORD))) stride = 1u; // (nothing the segment kernel takes)
     s->seg_hint = stride;
     return FH_OK;
 }

@@ -120,6 +120,13 @@ constexpr int WAVE_BUDGET = 2048; // + at most TILE_POS-1 overshoot inside the t
 // sit at the end of every lane's segment and are skipped for the whole wave -- 21 of 151 positions at k = 21, 31 at k = 31;
 // the result does not depend on the stride (a round of positions is skipped only when no lane has a valid window in it).
 constexpr uint32_t SEG_MIN_STRIDE = 40, SEG_MAX_STRIDE = 168; // (what a wave's share of the 160 KB of LDS holds two strings of)
+// Records longer than a lane's segment may be (2 x 250 / 2 x 300 reads: strides 251, 301) are shared by TWO or FOUR lanes
+// (SketchArgs::seg_sub): a tile is then 32 or 16 records, its strings the same 10.7 KB at most, and the record's valid windows
+// are dealt out evenly -- the first lanes take ceil((stride - K) / sub) start positions each, the last lane the rest with the K
+// positions behind the last window -- so that every lane of the wave runs out of valid windows in the same round.
+constexpr uint32_t SEG_MAX_RECORD = 4 * SEG_MAX_STRIDE;
+constexpr uint32_t seg_sub_for(uint32_t stride) { return stride <= SEG_MAX_STRIDE ? 1u : stride <= 2 * SEG_MAX_STRIDE ? 2u : stride <= SEG_MAX_RECORD ? 4u : 0u; }
+constexpr uint32_t seg_tile_pos(uint32_t stride, uint32_t sub) { return (64u / sub) * stride; } // start positions of a tile (a multiple of 16)
 // (the segment kernels' leftover lists hold TRIPLES (t0, t1, c0): tiles [t0, t1), t0 from round c0 on -- a wave may stop inside a tile)
 
 struct SketchArgs {
@@ -144,7 +151,8 @@ struct SketchArgs {
                              // (~14 ns each, serialised in L2): the 2 x 1953 of a 4 Mb genome's waves were 55 us of a launch
                              // that hashes for 10, the 12 000 of a 32 M-position prefix 100 us of 150.
     uint32_t static_only;    // the first units cover the whole range: no wave pulls from the queue
-    uint32_t seg_stride;     // != 0: the segment kernel, tiles of 64 x seg_stride positions (p_begin a multiple of 16)
+    uint32_t seg_stride;     // != 0: the segment kernel, tiles of 64 / seg_sub x seg_stride positions (p_begin a multiple of 16)
+    uint32_t seg_sub;        // lanes per record of the segment kernel: 1 (strides <= 168), 2 (<= 336) or 4 (<= 672); K > 32: 1
     uint32_t max_units;      // segment kernel: units a pull takes at most (k2_sketch: MAX_UNITS; its tiles are a fifth the size)
     const uint32_t *left_in; // pairs (t0, t1); segment kernels: triples (t0, t1, c0)
     uint32_t *left_out;      // the same, capacity >= number of waves

@@ -6,7 +6,9 @@
 // record's len + 1 positions whose window crosses the record's breaker byte -- 21 of 151 at k = 21, 31 of 151 at k = 31.
 //
 // Here a lane owns one segment of S = SketchArgs::seg_stride consecutive start positions (S = read length + 1 when the host
-// knows or finds that the records are of one length), a wave a tile of 64 segments:
+// knows or finds that the records are of one length), a wave a tile of 64 segments -- or, for records longer than a lane's
+// share of the LDS holds (strides 169..672: 2 x 250 and 2 x 300 reads), TWO or FOUR lanes own a record between them
+// (SketchArgs::seg_sub, fh_device.h) and a tile is 32 or 16 records:
 //   * phase A: the wave loads the tile's 64 S + 96 bytes coalesced (16 bytes a lane a time, all loads in flight together),
 //     classifies them (fh_core.h classify_chunk) and leaves THREE tile-wide strings in its own LDS: the complemented 2-bit codes
 //     (a window's reverse complement is a bit field of it), the digit-reversed codes (the forward strand's windows) and the
@@ -89,7 +91,7 @@ __device__ __forceinline__ u32 lane_now() { // (recomputed where it is needed: a
     return l;
 }
 
-template <int K>
+template <int K, bool SEED0>
 __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArgs a) {
     constexpr int WPB = K2S_WPB, NTHR = 64 * WPB, R = k2s_round(K), PRE = pre_shift(K);
     constexpr bool LONG = k2s_long(K);
@@ -143,9 +145,16 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
     u32 *const Fc = (u32 *)(blob + K2S_TILE) + (u32)wave * K2S_WAVE_DW; // ~codes: chunk i at word 1 + i
     u32 *const Rv = Fc + K2S_FC_DW;                                      // digit-reversed codes: chunk i at word NCH - 1 - i
     u32 *const Gd = Rv + K2S_RV_DW;                                      // good bits: chunk i at half-word i
+    // A record of S start positions belongs to 1 << SH lanes: the first ones take H positions each, the last one the rest
+    // (LAST >= H: it holds the K positions behind the record's last window).  SH = 0: a lane per record, H = LAST = S.
     const u32 S = (u32)__builtin_amdgcn_readfirstlane((int)a.seg_stride);
-    const u32 NCH = 4u * S + 6u, NR = (S + (u32)RO - 1u) / (u32)RO;
-    const u32 tile_pos = 64u * S;
+    const u32 SH = (u32)__builtin_amdgcn_readfirstlane((int)(a.seg_sub >= 4u ? 2u : a.seg_sub >= 2u ? 1u : 0u));
+    const u32 SUBM = (1u << SH) - 1u;
+    const u32 H = SH ? (S - (u32)K + SUBM) >> SH : S, LAST = S - SUBM * H;
+    const u32 tile_pos = (64u >> SH) * S;
+    const u32 NCH = (tile_pos >> 4) + 6u, NR = (LAST + (u32)RO - 1u) / (u32)RO;
+    // where lane l's segment begins in the tile, and how long it is
+    auto seg_start = [&](u32 l) -> u32 { return S * (l >> SH) + (l & SUBM) * H; };
     u32 nvalid = 0;
 
 #define FLUSHS(ctl_, q_, qn_, shard_) ([&] { const u32 r_ = (u32)__builtin_amdgcn_readfirstlane((int)flush_queue(ctl_, q_, qn_, shard_)); want_refresh |= r_ >> 31; return r_ & 0x7FFFFFFFu; }())
@@ -255,14 +264,18 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
                 const u32 rc0 = (u32)RO * c; // the round's first segment offset (wave-uniform)
                 Win win;
                 Mask Wc;
-                u32 nmax = S - rc0 < (u32)RO ? S - rc0 : (u32)RO; // positions of the segment this round covers
+                u32 nmax = LAST - rc0 < (u32)RO ? LAST - rc0 : (u32)RO; // positions of the (longest) segment this round covers
                 {
                     const u32 lane = lane_now();
-                    const u32 p0 = S * lane + rc0; // the lane's view begins at this tile position
+                    const u32 p0 = seg_start(lane) + rc0; // the lane's view begins at this tile position
                     // which of its windows carry a k-mer: all K bases good, inside the segment, inside [p_begin, p_end)
                     const u64 g64 = seg_good_bits(Gd, p0);
                     u32 limit = __builtin_elementwise_sub_sat(tile_room, p0);
                     limit = limit < nmax ? limit : nmax; // <= RO
+                    if (SH) { // (wave-uniform: the lanes in front of a record's last one own H positions, not LAST)
+                        const u32 own = __builtin_elementwise_sub_sat((lane & SUBM) == SUBM ? LAST : H, rc0);
+                        limit = limit < own ? limit : own;
+                    }
                     if constexpr (LONG) Wc = window_valid_mask64<K>(g64) & ((1ull << limit) - 1ull); // (R <= 48)
                     else Wc = window_valid_mask<K>(g64) & (limit >= 32u ? 0xFFFFFFFFu : ((1u << limit) - 1u));
                     // a round whose windows reach the segment's last K bases may hold nothing, or nothing behind some position,
@@ -318,7 +331,7 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
                     }
                     const u64 cm = cm_cur;
                     const bool rc_loop = rc_cur;
-                    const HashParts hp = murmur_finish_parts<K, true>(kw_cur, 0ull);
+                    const HashParts hp = murmur_finish_parts<K, SEED0>(kw_cur, a.seed);
                     const bool cand = parts_hi_plus1(hp) <= tau_hi1;
                     if (__builtin_expect(__any(cand), 0)) { // wave-uniform branch
                         const bool take = cand && ((Wc >> j) & 1u);
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
                                 queue->ka[my] = hp.ka;
                                 queue->kb[my] = hp.kb;
                                 queue->k[my] = cm;
-                                const u64 pos = tile_stream_pos + (u64)(lane_now() * S + rc0 + (u32)(h * R + j));
+                                const u64 pos = tile_stream_pos + (u64)(seg_start(lane_now()) + rc0 + (u32)(h * R + j));
                                 bool is_rc = rc_loop;
                                 if constexpr (Win::MINF64) is_rc = win.strand_of(j);
                                 queue->p[my] = pos | ((u64)(is_rc ? 1u : 0u) << 63);
@@ -411,7 +424,8 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
 template <int K>
 static hipError_t launch_k2s_t(const SketchArgs &a, hipStream_t st) {
     const dim3 grid((a.n_waves + K2S_WPB - 1) / K2S_WPB), block(64 * K2S_WPB);
-    hipLaunchKernelGGL((k2_sketch_seg<K>), grid, block, 0, st, a);
+    if (a.seed == 0) hipLaunchKernelGGL((k2_sketch_seg<K, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k2_sketch_seg<K, false>), grid, block, 0, st, a);
     return hipGetLastError();
 }
 

@@ -20,8 +20,8 @@ hipError_t launch_k2_part0(int k, const SketchArgs &a, int blocks, hipStream_t s
 hipError_t launch_k2_part1(int k, const SketchArgs &a, int blocks, hipStream_t st);
 hipError_t launch_k2_part2(int k, const SketchArgs &a, int blocks, hipStream_t st);
 hipError_t launch_k2_part3(int k, const SketchArgs &a, int blocks, hipStream_t st);
-// fh_k2s.hip: the segment form of the sketch kernel (SketchArgs::seg_stride != 0; K = 1..32, seed 0, no test mask, no lower
-// threshold), sixteen waves per workgroup whatever K
+// fh_k2s.hip: the segment form of the sketch kernel (SketchArgs::seg_stride != 0; K = 1..32, any seed, no test mask, no lower
+// threshold; strides up to SEG_MAX_RECORD with seg_sub lanes per record), sixteen waves per workgroup whatever K
 hipError_t launch_k2s_part0(int k, const SketchArgs &a, hipStream_t st);
 hipError_t launch_k2s_part1(int k, const SketchArgs &a, hipStream_t st);
 hipError_t launch_k2s_part2(int k, const SketchArgs &a, hipStream_t st);
@@ -34,7 +34,7 @@ hipError_t launch_k2ws_part2(int k, const SketchArgs &a, hipStream_t st);
 hipError_t launch_k2ws_part3(int k, const SketchArgs &a, hipStream_t st);
 constexpr int seg_waves_per_block(int k) { return k > 32 ? WAVES_PER_BLOCK : K2S_WAVES_PER_BLOCK; }
 // Is the packed stream made of records of one length?  One wavefront looks at its first bytes and at records spread over
-// the block: out[0] = the records' stride (length + 1, within [SEG_MIN_STRIDE, SEG_MAX_STRIDE]) if every byte looked at where a
+// the block: out[0] = the records' stride (length + 1, within [SEG_MIN_STRIDE, SEG_MAX_RECORD]) if every byte looked at where a
 // breaker should be is one, else 0.  (A tuning hint only: the segment kernel is exact for any stride.)  `out`: device or pinned host memory.
 hipError_t launch_seg_probe(const uint8_t *seq, uint64_t len, uint32_t *out, hipStream_t st);
 // fh_k2w.hip: K = 33..64, again in FH_NPARTS translation units

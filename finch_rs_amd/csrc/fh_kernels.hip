@@ -21,7 +21,7 @@ hipError_t launch_k2(int k, const SketchArgs &a, int blocks, hipStream_t st) {
     static_assert(FH_NPARTS == 4, "dispatcher below is written for 4 parts");
     if (k < 1 || k > FH_MAX_K) return hipErrorInvalidValue;
     if (k > 32 && a.seg_stride) { // two-word k-mers, segment form (fh_k2ws.hip)
-        if (a.seg_stride < SEG_MIN_STRIDE || a.seg_stride > SEG_MAX_STRIDE) return hipErrorInvalidValue;
+        if (a.seg_stride < SEG_MIN_STRIDE || a.seg_stride > SEG_MAX_STRIDE || a.seg_sub > 1u) return hipErrorInvalidValue;
         switch ((k - 33) / (32 / FH_NPARTS)) {
         case 0: return launch_k2ws_part0(k, a, st);
         case 1: return launch_k2ws_part1(k, a, st);
@@ -38,7 +38,10 @@ hipError_t launch_k2(int k, const SketchArgs &a, int blocks, hipStream_t st) {
         }
     }
     if (a.seg_stride) { // the segment form (fh_k2s.hip)
-        if (a.seg_stride < SEG_MIN_STRIDE || a.seg_stride > SEG_MAX_STRIDE || a.tau_lo || a.seed || a.hash_mask != ~0ull) return hipErrorInvalidValue;
+        const uint32_t sub = a.seg_sub ? a.seg_sub : 1u;
+        if (a.seg_stride < SEG_MIN_STRIDE || (sub != 1u && sub != 2u && sub != 4u) || (a.seg_stride + sub - 1u) / sub > SEG_MAX_STRIDE || a.seg_stride <= (uint32_t)k ||
+            a.tau_lo || a.hash_mask != ~0ull)
+            return hipErrorInvalidValue;
         switch ((k - 1) / (32 / FH_NPARTS)) {
         case 0: return launch_k2s_part0(k, a, st);
         case 1: return launch_k2s_part1(k, a, st);
@@ -1048,9 +1051,9 @@ __global__ __launch_bounds__(64) void k_seg_probe(const uint8_t *seq, u64 len, u
         // the first four bytes that are no bases, within the longest record the segment kernel takes: one of them ends record 0
         // (the others are N's inside it).  Three bytes a lane, the lanes' verdicts as ballots.
         u32 n = 0;
-        for (u32 base = 0; base < 192u && n < 4u; base += 64u) { // (wave-uniform loop)
+        for (u32 base = 0; base < SEG_MAX_RECORD + 63u && n < 4u; base += 64u) { // (wave-uniform loop)
             const u32 i = base + lane;
-            const bool bad = i < SEG_MAX_STRIDE && (u64)i < len && !probe_is_base(seq[i]);
+            const bool bad = i < SEG_MAX_RECORD && (u64)i < len && !probe_is_base(seq[i]);
             u64 m = __builtin_amdgcn_ballot_w64(bad);
             while (m && n < 4u) {
                 const u32 b = (u32)__builtin_ctzll(m);
@@ -1066,7 +1069,7 @@ __global__ __launch_bounds__(64) void k_seg_probe(const uint8_t *seq, u64 len, u
     u32 found = 0u;
     for (int ci = 0; ci < 4 && !found; ++ci) {
         const u32 S = cand[ci];
-        if (S < SEG_MIN_STRIDE || S > SEG_MAX_STRIDE) continue;
+        if (S < SEG_MIN_STRIDE || S > SEG_MAX_RECORD) continue;
         const u64 nrec = len / S;
         if (nrec < 128ull || nrec * S != len) continue; // (a block of whole records)
         // the first 64 records, and 64 spread over the block: the byte where the breaker should be, and the one in front of

@@ -225,3 +225,52 @@ def test_strides_around_the_round_lengths(genome, k, stride):
     assert_same(sk, oracle_of(O.MASH, 1000, k, stream), "k=%d stride=%d" % (k, stride))
     sk, _ = sketch_on_device(F.SketchParams.scaled(100, k, 0.5, 0), stream, stride, max_launch=4096)
     assert_same(sk, oracle_of(O.SCALED, 100, k, stream, 0.5), "scaled k=%d stride=%d" % (k, stride))
+
+
+# --- records longer than a lane's segment: two or four lanes to a record (SketchArgs::seg_sub; strides 169..672) ---
+@pytest.mark.parametrize("L,k", [(168, 21), (200, 21), (250, 21), (250, 31), (300, 21), (300, 31), (335, 16), (336, 24), (400, 21), (500, 31),
+                                  (671, 21), (671, 32), (250, 1), (301, 27)])
+def test_long_records_two_and_four_lanes_each(L, k):
+    genome = S.synth_genome_host(400_000, 78)
+    rng = np.random.default_rng(6000 + L + k)
+    stream = packed(fixed_reads(rng, 1500 + k, L, genome))  # (a partial last tile)
+    sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, k, 0), stream, L + 1)
+    assert sk.debug_segments()[0] > 0 and sk.debug_segments()[2] == L + 1
+    assert_same(sk, oracle_of(O.MASH, 1000, k, stream), "L=%d k=%d" % (L, k))
+
+
+@pytest.mark.parametrize("stride", [169, 251, 252, 300, 336, 337, 499, 672])
+def test_long_strides_that_are_wrong_change_nothing(stride):
+    """strides of the two- and four-lane forms on streams they do not fit: reads of 150 and of 250 bases, ragged records, one long
+    record, breakers where bases should be -- the sketch never depends on what the stride says"""
+    genome = S.synth_genome_host(300_000, 79)
+    rng = np.random.default_rng(7000 + stride)
+    streams = {
+        "150s": packed(fixed_reads(rng, 2500, 150, genome)),
+        "250s": packed(fixed_reads(rng, 1500, 250, genome)),
+        "ragged": packed(random_reads(rng, 3000, 0, 420, p_n=0.01, genome=genome)),
+        "one": np.concatenate([genome[:250_000], np.zeros(1, np.uint8)]),
+    }
+    for name, stream in streams.items():
+        for k in (21, 31):
+            sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, k, 0), stream, stride)
+            assert sk.debug_segments()[0] > 0, (name, k)
+            assert_same(sk, oracle_of(O.MASH, 1000, k, stream), "%s k=%d stride=%d" % (name, k, stride))
+
+
+@pytest.mark.parametrize("k,seed", [(21, 42), (31, 2**63 + 11), (16, 1), (25, 7)])
+def test_seeds_go_through_the_segment_kernels(genome, k, seed):
+    """hash_seed != 0 (hashing.rs:10-12: murmurhash3_x64_128(kmer, seed)): the segment kernels take the seed like every other"""
+    rng = np.random.default_rng(8000 + k)
+    for L in (150, 250):
+        stream = packed(fixed_reads(rng, 2500, L, genome))
+        sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, k, seed), stream, L + 1)
+        assert sk.debug_segments()[0] > 0
+        ora = O.OracleSketcher(O.MASH, 1000, k, seed)
+        ora.process_packed(stream, 0)
+        assert_same(sk, ora, "L=%d k=%d seed=%d" % (L, k, seed))
+    sc = F.SketchParams.scaled(1000, k, 0.25, seed)
+    sk, _ = sketch_on_device(sc, stream, 251, max_launch=16384)  # few waves, loose threshold: waves stop inside tiles
+    ora = O.OracleSketcher(O.SCALED, 1000, k, seed, 0.25)
+    ora.process_packed(stream, 0)
+    assert_same(sk, ora, "scaled k=%d seed=%d" % (k, seed))
