@@ -2161,8 +2161,14 @@ int fh_push_staged(fh_sketcher *s, uint64_t len, uint32_t flags) {
     const uint64_t base = s->stream_off - carry_len;
     // the device buffer of this slot may still feed a pending range
     if (int rc = drain(s)) return rc;
-    HIP_TRY(hipMemcpyAsync(s->d_stage[b], src, m, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+    if (carry_len == 0 && s->stage_prefetched[b] == len) { // the filler's thread has the copy under way (fh_text_prefetch)
+        HIP_TRY(hipStreamWaitEvent(s->stream, s->stage_done[b], 0));
+    } else {
+        if (s->stage_prefetched[b]) HIP_TRY(hipEventSynchronize(s->stage_done[b])); // (a prefetch of something else: let it land first)
+        HIP_TRY(hipMemcpyAsync(s->d_stage[b], src, m, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipEventRecord(s->stage_done[b], s->stream));
+    }
+    s->stage_prefetched[b] = 0;
     s->stage_busy[b] = true;
     if (int rc = sketch_device_range(s, s->d_stage[b], m, base)) return rc;
     s->stream_off += len;

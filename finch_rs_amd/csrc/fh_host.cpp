@@ -24,6 +24,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <functional>
 #include <future>
 #include <thread>
 #include <vector>
@@ -33,6 +34,7 @@
 #include "fh_inflate.h"
 #include "fh_pargz.h"
 #include "fh_strip.h"
+#include "fh_fqstrip.h"
 
 // job(t) for t = 0 .. n - 1, one thread each (the caller's runs job(0)).  A thread that cannot be created (EAGAIN under a
 // thread limit) must not take the process down -- a vector of joinable threads that unwinds calls std::terminate -- so its
@@ -232,6 +234,8 @@ struct ByteSource {
     virtual bool rewind() { return false; }           // back to the first byte
     virtual unsigned threads_hint() const { return 1; } // host threads the reader of this source may use
     virtual uint64_t remaining_hint() const { return UINT64_MAX; } // bytes still to come, if the source knows (files, memory)
+    // the source's WHOLE content as one contiguous read-only range, if it is memory (wherever its read position is)
+    virtual bool whole_view(const uint8_t **, size_t *) const { return false; }
 };
 
 static unsigned read_threads_total(const char *env);
@@ -267,6 +271,11 @@ struct MemSource : ByteSource {
     }
     unsigned threads_hint() const override { return n_thr; }
     uint64_t remaining_hint() const override { return n - off; }
+    bool whole_view(const uint8_t **pp, size_t *nn) const override {
+        *pp = p;
+        *nn = n;
+        return true;
+    }
 };
 
 struct FileSource : ByteSource {
@@ -351,6 +360,7 @@ struct PrefixedSource : ByteSource {
         const uint64_t r = inner->remaining_hint();
         return r == UINT64_MAX ? r : r + (prefix.size() - std::min(off, prefix.size()));
     }
+    bool whole_view(const uint8_t **pp, size_t *nn) const override { return inner->whole_view(pp, nn); } // (the prefix is its first bytes)
 };
 
 struct GzSource : ByteSource {
@@ -1966,7 +1976,7 @@ static bool file_batch_enabled() {
     return !(e && e[0] == '0');
 }
 static std::atomic<uint64_t> g_ktimes_us{0}, g_ktimes_launches{0}, g_ktimes_positions{0};
-static int fastq_text_to_device(ByteSource &src, fh_sketcher *h, uint32_t k);
+static int fastq_text_to_device(ByteSource &src, fh_sketcher *h, uint32_t k, struct FastxStats *st_out, bool *host_counted);
 
 // Device-side FASTA (fh_push_fasta_text): the host reads raw file bytes into the pinned staging buffer, cuts chunks
 // after a newline and does the bookkeeping that needs no per-base work: the record count and total_bases =
@@ -2060,8 +2070,203 @@ struct FastaCounter {
 };
 
 static int fasta_text_to_device(ByteSource &src, fh_sketcher *h, FastxStats &st, uint32_t k) { return pump_text_to_device(src, h, false, k, st); }
-static int fastq_text_to_device(ByteSource &src, fh_sketcher *h, uint32_t k) {
+// FASTQ text that lies in host memory, with read threads to spare: the call's read threads drop headers, '+' lines and
+// quality strings on the HOST (fh_fqstrip.h) and only the packed sequence stream -- 1.007 bytes per base instead of the
+// text's 2.1 -- crosses the PCIe link (fh_push_staged; each chunk's copy starts the moment it is packed, fh_text_prefetch).
+// The device-side splitter stays what a call without threads to spare goes through (the workers of a many-file call have
+// one each), and what compressed and file input goes through (their reads already keep the threads busy).
+// -> FH_OK (st: records, total_bases), FH_ERR_STATE = does not apply (nothing consumed), FH_ERR_INVALID = not plain 4-line
+// FASTQ (the caller rewinds and lets the parser that is the judge of that read it), or an error.
+static std::atomic<uint64_t> g_fastq_host_strip{0};
+static int fastq_host_strip_to_device(ByteSource &src, fh_sketcher *h, FastxStats &st) {
+    const char *opt = cfg("fastq_host_strip"); // 0 = never, 1 = whatever the thread count (tests), default: from 8 read threads on
+    if (opt && opt[0] == '0') return FH_ERR_STATE;
+    const unsigned hint = src.threads_hint();
+    const bool forced = opt && opt[0] == '1';
+    if (!forced && hint < 8) return FH_ERR_STATE;
+    const unsigned T = std::max(2u, std::min(32u, hint));
+    const uint8_t *text = nullptr;
+    size_t n = 0;
+    if (!src.whole_view(&text, &n) || n == 0 || text[0] != '@') return FH_ERR_STATE;
+    uint8_t *stage[2] = {nullptr, nullptr};
+    uint64_t cap = 0;
+    int next = 0;
+    if (int rc = fh_text_buffers(h, stage, &cap, &next)) return hfail(rc, "%s", fh_last_error());
+    if (cap < (1u << 16)) return FH_ERR_STATE;
+    // a chunk of text whose packed stream fits a staging buffer whatever it holds (a record's sequence is less than half of it)
+    static const uint64_t chunk_opt = cfg("fastq_strip_chunk") ? strtoull(cfg("fastq_strip_chunk"), nullptr, 10) : 0; // (tests: many chunks)
+    const size_t CHUNK = (size_t)std::min<uint64_t>(chunk_opt ? std::max<uint64_t>(chunk_opt, 4096) : (128ull << 20), 2 * (cap - 4096));
+    struct Job {
+        int slot;
+        uint64_t m;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    bool is_free[2] = {true, true}, producer_done = false;
+    std::vector<Job> ready;
+    std::atomic<bool> abort{false};
+    int prc = FH_OK;
+    std::string pmsg;
+    uint64_t n_rec_total = 0, bases_total = 0;
+    // the team: T - 1 helpers parked between chunks, the producer is member 0
+    std::vector<fqstrip::Piece> pieces(T);
+    fqstrip::Barrier bar(T);
+    struct Work {
+        const uint8_t *text = nullptr;
+        size_t n = 0;
+        uint8_t *out = nullptr;
+        unsigned gen = 0;
+        bool quit = false;
+    } work;
+    std::mutex wmu;
+    std::condition_variable wcv;
+    bool ok = false;
+    uint64_t m_out = 0, rec_out = 0, bases_out = 0;
+    std::vector<std::thread> helpers;
+    auto helper_main = [&](unsigned t) {
+        unsigned seen = 0;
+        for (;;) {
+            Work w;
+            {
+                std::unique_lock<std::mutex> lk(wmu);
+                wcv.wait(lk, [&] { return work.gen != seen || work.quit; });
+                if (work.quit) return;
+                seen = work.gen;
+                w = work;
+            }
+            fqstrip::strip_chunk(t, T, w.text, w.n, w.out, pieces, bar, &ok, &m_out, &rec_out, &bases_out);
+        }
+    };
+    try {
+        for (unsigned t = 1; t < T; ++t) helpers.emplace_back(helper_main, t);
+    } catch (...) { // not enough threads: this path is not for now (the helpers that exist wait for a chunk that never comes)
+        {
+            std::lock_guard<std::mutex> g(wmu);
+            work.quit = true;
+        }
+        wcv.notify_all();
+        for (auto &x : helpers) x.join();
+        return FH_ERR_STATE;
+    }
+    auto stop_helpers = [&] {
+        {
+            std::lock_guard<std::mutex> g(wmu);
+            work.quit = true;
+        }
+        wcv.notify_all();
+        for (auto &x : helpers) x.join();
+    };
+    std::thread producer([&] {
+        int slot = next;
+        size_t off = 0;
+        while (off < n && !abort) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return is_free[slot] || abort.load(); });
+                if (abort) break;
+                is_free[slot] = false;
+            }
+            size_t len = std::min(CHUNK, n - off);
+            if (off + len < n) { // cut behind the last whole record: the last header line whose line two below is a '+' line
+                const uint8_t *buf = text + off;
+                size_t ls[16];
+                int nl = 0;
+                size_t pos = len;
+                while (nl < 16) {
+                    const uint8_t *q = pos > 0 ? (const uint8_t *)memrchr(buf, '\n', pos) : nullptr;
+                    const size_t start = q ? (size_t)(q - buf) + 1 : 0;
+                    if (start < len) ls[nl++] = start;
+                    if (!q) break;
+                    pos = (size_t)(q - buf);
+                }
+                size_t cut = 0;
+                for (int i = 2; i < nl && !cut; ++i)
+                    if (buf[ls[i]] == '@' && buf[ls[i - 2]] == '+') cut = ls[i];
+                if (!cut) {
+                    prc = FH_ERR_INVALID;
+                    pmsg = "no FASTQ record boundary found in a chunk";
+                    break;
+                }
+                len = cut;
+            }
+            {
+                std::lock_guard<std::mutex> g(wmu);
+                work.text = text + off;
+                work.n = len;
+                work.out = stage[slot];
+                ++work.gen;
+            }
+            wcv.notify_all();
+            fqstrip::strip_chunk(0, T, text + off, len, stage[slot], pieces, bar, &ok, &m_out, &rec_out, &bases_out);
+            if (!ok) {
+                prc = FH_ERR_INVALID;
+                pmsg = "not plain 4-line FASTQ";
+                break;
+            }
+            n_rec_total += rec_out;
+            bases_total += bases_out;
+            (void)fh_text_prefetch(h, slot, m_out); // the chunk's copy starts now, behind the previous chunk's
+            {
+                std::lock_guard<std::mutex> g(mu);
+                ready.push_back(Job{slot, m_out});
+            }
+            cv.notify_all();
+            off += len;
+            slot ^= 1;
+        }
+        std::lock_guard<std::mutex> g(mu);
+        producer_done = true;
+        cv.notify_all();
+    });
+    int rc = FH_OK;
+    std::string msg;
+    int prev_slot = -1;
+    for (;;) {
+        Job job;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !ready.empty() || producer_done; });
+            if (ready.empty()) break;
+            job = ready.front();
+            ready.erase(ready.begin());
+        }
+        if (rc == FH_OK) {
+            rc = fh_push_staged(h, job.m, 0u);
+            if (rc != FH_OK) {
+                msg = fh_last_error();
+                abort = true;
+            }
+        }
+        // the slot pushed BEFORE this one is free again: this push waited for its sketch launch (which had waited for its copy)
+        std::lock_guard<std::mutex> g(mu);
+        if (prev_slot >= 0) is_free[prev_slot] = true;
+        if (rc != FH_OK) is_free[0] = is_free[1] = true;
+        prev_slot = job.slot;
+        cv.notify_all();
+    }
+    producer.join();
+    stop_helpers();
+    if (rc != FH_OK) return hfail(rc, "%s", msg.c_str());
+    if (prc != FH_OK) return hfail(prc, "%s", pmsg.c_str());
+    st.total_bases = bases_total;
+    st.n_records = n_rec_total;
+    g_fastq_host_strip++;
+    return FH_OK;
+}
+
+// (host_counted: total_bases / n_records of st are the host's count; otherwise the device's, fh_text_bases)
+static int fastq_text_to_device(ByteSource &src, fh_sketcher *h, uint32_t k, FastxStats *st_out, bool *host_counted) {
     FastxStats st;
+    if (host_counted) *host_counted = false;
+    const int rc = fastq_host_strip_to_device(src, h, st);
+    if (rc != FH_ERR_STATE) {
+        if (rc == FH_OK && st_out && host_counted) {
+            st_out->total_bases = st.total_bases;
+            st_out->n_records = st.n_records;
+            *host_counted = true;
+        }
+        return rc;
+    }
     return pump_text_to_device(src, h, true, k, st);
 }
 
@@ -2106,6 +2311,74 @@ static void host_parallel(size_t n, F f) {
     fork_join(t_max, [=](unsigned t) { f(t, std::min(n, (size_t)t * per), std::min(n, ((size_t)t + 1) * per)); });
 }
 
+// Up to seven helper threads parked on a condition variable between teams.  run(n, job, mine): job(0..n-1) on n helpers while
+// the caller runs mine(); returns false -- nothing was run -- if the pool is in use or cannot have n threads (the caller then
+// starts threads of its own).  The helpers live as long as the process.
+class TeamPool {
+public:
+    static TeamPool &instance() {
+        static TeamPool *p = new TeamPool; // (never destroyed: its threads may outlive static destructors)
+        return *p;
+    }
+    template <class J, class M>
+    bool run(unsigned n, J job, M mine) {
+        if (n == 0 || n > MAX) return false;
+        if (!busy_.try_lock()) return false;
+        std::function<void(unsigned)> fn = job;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            try {
+                while (threads_ < n) {
+                    std::thread(&TeamPool::worker, this, threads_).detach();
+                    ++threads_;
+                }
+            } catch (...) {
+                busy_.unlock();
+                return false;
+            }
+            job_ = &fn;
+            want_ = n;
+            done_ = 0;
+            ++gen_;
+        }
+        cv_.notify_all();
+        mine();
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_done_.wait(lk, [&] { return done_ == want_; });
+            job_ = nullptr;
+        }
+        busy_.unlock();
+        return true;
+    }
+
+private:
+    static constexpr unsigned MAX = 7;
+    void worker(unsigned id) {
+        unsigned seen = 0;
+        for (;;) {
+            std::function<void(unsigned)> *j;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (id >= want_) continue; // (a smaller team than there are helpers)
+                j = job_;
+            }
+            (*j)(id);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                ++done_;
+            }
+            cv_done_.notify_one();
+        }
+    }
+    std::mutex busy_, mu_;
+    std::condition_variable cv_, cv_done_;
+    std::function<void(unsigned)> *job_ = nullptr;
+    unsigned threads_ = 0, want_ = 0, done_ = 0, gen_ = 0;
+};
+
 // the same team of threads for several passes in a row: starting and joining a std::thread costs 50-100 us, which for three
 // passes over a 2 M-hash oversketch was more than the passes themselves.  f(t, n_threads, barrier) runs on every thread;
 // barrier() returns once all of them have called it.
@@ -2133,6 +2406,10 @@ static bool host_team(size_t n, F f) {
             failed.store(true, std::memory_order_release);
         }
     };
+    // the team's threads are kept between calls (TeamPool): starting and joining seven std::threads was 0.5-1 ms of the 2-3 ms
+    // the three filter passes over configs[2]'s 2 M records took.  A second team at the same time (workers of a many-file
+    // call that filter large sketches side by side) starts threads of its own as before.
+    if (t_max > 1 && TeamPool::instance().run(t_max - 1, [&](unsigned i) { run(i + 1); }, [&] { run(0u); })) return !failed.load();
     std::vector<std::thread> th;
     th.reserve(t_max - 1);
     try {
@@ -2496,17 +2773,21 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
         if (int r2 = fh_reset(h)) return hfail(r2, "%s", fh_last_error());
     }
     bool device_parse = !dp_off && (first == '>' || first == '@');
+    bool fastq_host_counted = false; // the FASTQ text was stripped on the host (fastq_host_strip_to_device): st has the totals
     if (device_parse && first == '@' && !dp_on && !src->can_rewind()) device_parse = false; // no second chance: host parser
     if (device_parse && first == '@') {
         // FASTQ on the device has to be strictly 4-line.  Unless the caller insists (FINCH_DEVICE_PARSE=1: errors stay
         // loud), a file the device pass rejects is read again through the host parser, which is the judge of what
         // needletail accepts (blank lines between records, ...); sources that cannot rewind start on the host.
         st.format = 2;
-        const int rc = fastq_text_to_device(*src, h, sp.kmer_length);
+        const int rc = fastq_text_to_device(*src, h, sp.kmer_length, &st, &fastq_host_counted);
         if (rc != FH_OK) {
             if (dp_on || rc != FH_ERR_INVALID || !src->rewind()) return rc;
             if (int r2 = fh_reset(h)) return hfail(r2, "%s", fh_last_error());
             device_parse = false;
+            fastq_host_counted = false;
+            st = FastxStats{};
+            st.format = 2;
         }
     }
     if (device_parse && first == '>') {
@@ -2526,7 +2807,7 @@ static int sketch_stream(std::unique_ptr<ByteSource> raw, const std::string &nam
         if (int rc = parse_fastx(*src, sink, st)) return rc;
         if (int rc = sink.flush()) return rc;
     }
-    if (device_parse && st.format == 2) {
+    if (device_parse && st.format == 2 && !fastq_host_counted) {
         if (int rc = fh_text_bases(h, &st.total_bases)) return hfail(rc, "%s", fh_last_error());
     }
     return finish_sketch(h, name, sp, filters, st, out);
@@ -3501,6 +3782,25 @@ void finch_debug_kernel_times(int enable, double *kernel_ms, uint64_t *launches,
         if (enable) finch::g_ktimes_us = 0, finch::g_ktimes_launches = 0, finch::g_ktimes_positions = 0;
     }
 }
+
+uint64_t finch_debug_fastq_host_strip(void) { return finch::g_fastq_host_strip.load(); }
+
+// test hook: text[0, len) (whole records of plain 4-line FASTQ) through the host-side strip (fh_fqstrip.h) on `threads` threads
+int finch_fastq_strip_probe(const uint8_t *text, uint64_t len, uint32_t threads, uint8_t *out, uint64_t cap, uint64_t *packed,
+                            uint64_t *n_records, uint64_t *total_bases) try {
+    if ((!text && len) || !out || !packed || !n_records || !total_bases || threads < 1 || threads > 64) return hfail(FH_ERR_INVALID, "bad argument");
+    if (cap < len / 2 + 64) return hfail(FH_ERR_INVALID, "output needs len / 2 + 64 bytes");
+    std::vector<fqstrip::Piece> pieces(threads);
+    fqstrip::Barrier bar(threads);
+    bool ok = false;
+    uint64_t m = 0, nr = 0, nb = 0;
+    fork_join(threads, [&](unsigned t) { fqstrip::strip_chunk(t, threads, text, (size_t)len, out, pieces, bar, &ok, &m, &nr, &nb); });
+    if (!ok) return hfail(FH_ERR_INVALID, "not plain 4-line FASTQ");
+    *packed = m;
+    *n_records = nr;
+    *total_bases = nb;
+    return FH_OK;
+} FINCH_CATCH
 
 void finch_debug_file_batch(uint64_t *taken, uint64_t *not_taken) {
     if (taken) *taken = finch::g_batch_taken.load();

@@ -73,6 +73,9 @@ const OptDef DEFS[] = {
     {"no_small_sketcher", "no final_size-sized sketcher for unfiltered oversketched Mash input"},
     {"small_fasta_host", "0 = small FASTA files are split on the device, not packed by the worker"},
     {"file_batch", "0 = every file of a finch_sketch_files batch through a sketcher of its own (no many-per-launch groups)"},
+    // --- FASTQ text in host memory ---
+    {"fastq_host_strip", "0 = FASTQ text always goes to the device-side splitter; 1 = stripped on the host whatever the read threads (default: from 8 read threads on)"},
+    {"fastq_strip_chunk", "bytes of text per chunk of the host-side FASTQ strip (tests: many chunks)"},
 };
 constexpr int N_OPTS = (int)(sizeof(DEFS) / sizeof(DEFS[0]));
 

@@ -110,6 +110,9 @@ _SYMS = {
     "finch_debug_device_gzip": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "finch_debug_kernel_times": (None, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "finch_debug_file_batch": (None, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "finch_debug_fastq_host_strip": (C.c_uint64, []),
+    "finch_fastq_strip_probe": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                          C.POINTER(C.c_uint64)]),
     "finch_gzip_probe": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_uint32)]),
     "finch_bgzf_batch_probe": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64),
@@ -431,6 +434,19 @@ def debug_device_gzip():
     a, b = C.c_uint64(), C.c_uint64()
     lib().finch_debug_device_gzip(C.byref(a), C.byref(b))
     return a.value, b.value
+
+
+def fastq_strip_probe(text: bytes, threads: int):
+    """-> (packed stream, records, total_bases) of plain 4-line FASTQ text through the host-side strip; FinchError if it is not"""
+    src = np.frombuffer(text, dtype=np.uint8)
+    out = np.zeros(len(text) // 2 + 64, dtype=np.uint8)
+    m, nr, nb = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    _check(lib().finch_fastq_strip_probe(src.ctypes.data, len(text), threads, out.ctypes.data, len(out), C.byref(m), C.byref(nr), C.byref(nb)))
+    return out[:m.value].tobytes(), nr.value, nb.value
+
+
+def debug_fastq_host_strip() -> int:
+    return lib().finch_debug_fastq_host_strip()
 
 
 def debug_file_batch():

@@ -209,6 +209,14 @@ void finch_debug_kernel_times(int enable, double *kernel_ms, uint64_t *launches,
  * files the batch path handed to a sketcher of their own instead (not taken: too few distinct k-mers below the batch's
  * threshold, ...; files that never qualified -- FASTQ, compressed, stdin, huge -- count in neither) */
 void finch_debug_file_batch(uint64_t *taken, uint64_t *not_taken);
+/* inputs of this process whose FASTQ text was stripped to the packed sequence stream on the host (fh_fqstrip.h: text in host
+ * memory and >= 8 read threads -- headers, '+' lines and quality strings never cross the PCIe link) */
+uint64_t finch_debug_fastq_host_strip(void);
+/* test hook: text[0, len) -- whole records of plain 4-line FASTQ -- through that strip on `threads` threads: out (cap >= len / 2 + 64)
+ * receives the packed stream (each record's sequence, blanks dropped, one 0 byte behind it); FH_ERR_INVALID if the text is not
+ * plain 4-line FASTQ (what the caller then hands to the parser that is the judge of it) */
+int finch_fastq_strip_probe(const uint8_t *text, uint64_t len, uint32_t threads, uint8_t *out, uint64_t cap, uint64_t *packed,
+                            uint64_t *n_records, uint64_t *total_bases);
 
 #ifdef __cplusplus
 }

@@ -125,6 +125,7 @@ def test_long_records_span_blocks_and_staging_slices():
     code = r'''
 import numpy as np
 from finch_rs_amd import host as H, sketch_schemes as S
+import finch_rs_amd as F
 from oracle import oracle as O
 seq = bytes(S.synth_genome_host(300000, 9))
 data = b">chr1 long\n" + b"\n".join(seq[j:j+61] for j in range(0, len(seq), 61)) + b"\n>chr2\n" + seq[1000:9000] + b"\nNNNN\n" + seq[:500] + b"\n"
@@ -214,6 +215,7 @@ def test_device_side_fastq_parsing_matches_host_parser(tmp_path):
     code = r'''
 import os, sys, numpy as np
 from finch_rs_amd import host as H, sketch_schemes as S
+import finch_rs_amd as F
 from oracle import oracle as O
 def vs_oracle(b, data, p, tag):
     """the device-split sketch against the oracle's own parser + sketcher (returns False if the oracle's parser rejects the text)"""
@@ -340,6 +342,7 @@ def test_device_side_fasta_parsing_matches_host_parser(tmp_path):
     code = r'''
 import os, sys, numpy as np
 from finch_rs_amd import host as H, sketch_schemes as S
+import finch_rs_amd as F
 from oracle import oracle as O
 def vs_oracle(b, data, p, tag):
     """the device-split sketch against the oracle's own parser + sketcher (returns False if the oracle's parser rejects the text)"""
@@ -405,6 +408,7 @@ def test_device_side_fasta_parsing_random_text():
     code = r'''
 import os, numpy as np
 from finch_rs_amd import host as H, sketch_schemes as S
+import finch_rs_amd as F
 from oracle import oracle as O
 def vs_oracle(b, data, p, tag):
     """the device-split sketch against the oracle's own parser + sketcher (returns False if the oracle's parser rejects the text)"""
@@ -617,3 +621,46 @@ def test_one_input_across_several_device_handles(tmp_path):
         H.sketch_file_sharded(str(bad), SketchParams.mash(10, 10, True, 21, 0), H.FilterParams(False), [0, 0], 4096)
     with pytest.raises(FinchError, match="No such file"):
         H.sketch_file_sharded(str(tmp_path / "nope.fq"), SketchParams.default(), H.FilterParams(False), [0, 0], 0)
+
+
+def test_fastq_text_in_memory_is_stripped_on_the_host_and_matches_the_device_splitter():
+    """finch_sketch_buffer on FASTQ text with read threads to spare: headers, '+' lines and quality strings are dropped on the
+    host (fh_fqstrip.h) and only the packed stream crosses the link -- same Sketch as through the device-side splitter and as
+    the oracle's sketch_stream, for LF / CRLF text, a missing last newline, many small chunks; text that is not plain 4-line
+    FASTQ goes to the host parser as before"""
+    code = r'''
+import os, numpy as np
+import finch_rs_amd as F
+from finch_rs_amd import host as H, sketch_schemes as S
+from oracle import oracle as O
+g = S.synth_genome_host(200_000, 5)
+reads = S.synth_reads_host(g, 0, 30_000, 150, 3, 10000, 500).reshape(30_000, 151)[:, :150]
+def fq(eol=b"\n", last=True, blank_at=None):
+    recs = [b"@read%d extra" % i + eol + bytes(reads[i]) + eol + b"+" + eol + b"I" * 150 for i in range(len(reads))]
+    if blank_at is not None:
+        recs[blank_at] = recs[blank_at] + eol  # a blank line behind a record: needletail reads on, the strip must hand over
+    return eol.join(recs) + (eol if last else b"")
+p = S.SketchParams.mash(1000, 1000, False, 21, 0)
+for eol, last in ((b"\n", True), (b"\r\n", True), (b"\n", False)):
+    data = fq(eol, last)
+    o = O.OracleSketcher(O.MASH, 1000, 21, 0); o.sketch_stream(data); okc, okm = o.to_vec()
+    F.debug_set(fastq_host_strip="0")
+    a = H.sketch_stream(data, "mem", p, H.FilterParams(False)).sketch(0)
+    n0 = H.debug_fastq_host_strip()
+    F.debug_set(fastq_host_strip="1")
+    b = H.sketch_stream(data, "mem", p, H.FilterParams(False)).sketch(0)
+    assert H.debug_fastq_host_strip() == n0 + 1
+    for sk in (a, b):
+        assert np.array_equal(sk.arrays[0], okc) and np.array_equal(sk.arrays[1], okm)
+        assert (sk.seq_length, sk.num_valid_kmers) == o.total_bases_and_kmers()
+# not plain 4-line FASTQ: the strip refuses, the parser that is the judge of it reads the text
+data = fq(blank_at=777)
+o = O.OracleSketcher(O.MASH, 1000, 21, 0); o.sketch_stream(data); okc, okm = o.to_vec()
+n0 = H.debug_fastq_host_strip()
+c = H.sketch_stream(data, "mem", p, H.FilterParams(False)).sketch(0)
+assert H.debug_fastq_host_strip() == n0
+assert np.array_equal(c.arrays[0], okc) and np.array_equal(c.arrays[1], okm) and (c.seq_length, c.num_valid_kmers) == o.total_bases_and_kmers()
+print("child ok")
+'''
+    for env in ({}, {"fastq_strip_chunk": "70000"}, {"fastq_strip_chunk": "1000000", "read_threads": "3"}):
+        assert "child ok" in _run_child(code, env)

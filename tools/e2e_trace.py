@@ -10,6 +10,7 @@ import numpy as np
 import finch_rs_amd as F
 F.debug_set(trace="1")
 from finch_rs_amd import host as H, sketch_schemes as S
+import finch_rs_amd as F
 
 ns = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 RL, REC = 150, 151
