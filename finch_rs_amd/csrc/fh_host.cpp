@@ -53,6 +53,75 @@ static void fork_join(unsigned n, J job) {
     for (auto &x : th) x.join();
 }
 
+// Up to 31 helper threads parked on a condition variable between teams.  run(n, job, mine): job(0..n-1) on n helpers while
+// the caller runs mine(); returns false -- nothing was run -- if the pool is in use or cannot have n threads (the caller then
+// starts threads of its own).  The helpers live as long as the process.
+class TeamPool {
+public:
+    static TeamPool &instance() {
+        static TeamPool *p = new TeamPool; // (never destroyed: its threads may outlive static destructors)
+        return *p;
+    }
+    template <class J, class M>
+    bool run(unsigned n, J job, M mine) {
+        if (n == 0 || n > MAX) return false;
+        if (!busy_.try_lock()) return false;
+        std::function<void(unsigned)> fn = job;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            try {
+                while (threads_ < n) {
+                    std::thread(&TeamPool::worker, this, threads_).detach();
+                    ++threads_;
+                }
+            } catch (...) {
+                busy_.unlock();
+                return false;
+            }
+            job_ = &fn;
+            want_ = n;
+            done_ = 0;
+            ++gen_;
+        }
+        cv_.notify_all();
+        mine();
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_done_.wait(lk, [&] { return done_ == want_; });
+            job_ = nullptr;
+        }
+        busy_.unlock();
+        return true;
+    }
+
+private:
+    static constexpr unsigned MAX = 31;
+    void worker(unsigned id) {
+        unsigned seen = 0;
+        for (;;) {
+            std::function<void(unsigned)> *j;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (id >= want_) continue; // (a smaller team than there are helpers)
+                j = job_;
+            }
+            (*j)(id);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                ++done_;
+            }
+            cv_done_.notify_one();
+        }
+    }
+    std::mutex busy_, mu_;
+    std::condition_variable cv_, cv_done_;
+    std::function<void(unsigned)> *job_ = nullptr;
+    unsigned threads_ = 0, want_ = 0, done_ = 0, gen_ = 0;
+};
+
+
 namespace finch {
 using fh::cfg;
 
@@ -2122,7 +2191,6 @@ static int fastq_host_strip_to_device(ByteSource &src, fh_sketcher *h, FastxStat
     std::condition_variable wcv;
     bool ok = false;
     uint64_t m_out = 0, rec_out = 0, bases_out = 0;
-    std::vector<std::thread> helpers;
     auto helper_main = [&](unsigned t) {
         unsigned seen = 0;
         for (;;) {
@@ -2137,35 +2205,34 @@ static int fastq_host_strip_to_device(ByteSource &src, fh_sketcher *h, FastxStat
             fqstrip::strip_chunk(t, T, w.text, w.n, w.out, pieces, bar, &ok, &m_out, &rec_out, &bases_out);
         }
     };
-    try {
-        for (unsigned t = 1; t < T; ++t) helpers.emplace_back(helper_main, t);
-    } catch (...) { // not enough threads: this path is not for now (the helpers that exist wait for a chunk that never comes)
-        {
-            std::lock_guard<std::mutex> g(wmu);
-            work.quit = true;
-        }
-        wcv.notify_all();
-        for (auto &x : helpers) x.join();
-        return FH_ERR_STATE;
-    }
     auto stop_helpers = [&] {
         {
             std::lock_guard<std::mutex> g(wmu);
             work.quit = true;
         }
         wcv.notify_all();
-        for (auto &x : helpers) x.join();
     };
+    static const bool trace = cfg("trace") != nullptr;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now_s();
+    double t_wait_slot = 0, t_strip = 0, t_push = 0, t_wait_job = 0;
+    unsigned n_chunks = 0;
+    int rc = FH_OK;
+    std::string msg;
+    auto pipeline = [&] { // the reader (a thread of its own: member 0 of the team) and, on this thread, the pushes
     std::thread producer([&] {
         int slot = next;
         size_t off = 0;
         while (off < n && !abort) {
             {
+                const double w0 = trace ? now_s() : 0;
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return is_free[slot] || abort.load(); });
                 if (abort) break;
                 is_free[slot] = false;
+                if (trace) t_wait_slot += now_s() - w0;
             }
+            const double s0 = trace ? now_s() : 0;
             size_t len = std::min(CHUNK, n - off);
             if (off + len < n) { // cut behind the last whole record: the last header line whose line two below is a '+' line
                 const uint8_t *buf = text + off;
@@ -2205,6 +2272,7 @@ static int fastq_host_strip_to_device(ByteSource &src, fh_sketcher *h, FastxStat
             }
             n_rec_total += rec_out;
             bases_total += bases_out;
+            if (trace) t_strip += now_s() - s0, n_chunks++;
             (void)fh_text_prefetch(h, slot, m_out); // the chunk's copy starts now, behind the previous chunk's
             {
                 std::lock_guard<std::mutex> g(mu);
@@ -2218,11 +2286,10 @@ static int fastq_host_strip_to_device(ByteSource &src, fh_sketcher *h, FastxStat
         producer_done = true;
         cv.notify_all();
     });
-    int rc = FH_OK;
-    std::string msg;
     int prev_slot = -1;
     for (;;) {
         Job job;
+        const double j0 = trace ? now_s() : 0;
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return !ready.empty() || producer_done; });
@@ -2230,8 +2297,11 @@ static int fastq_host_strip_to_device(ByteSource &src, fh_sketcher *h, FastxStat
             job = ready.front();
             ready.erase(ready.begin());
         }
+        const double j1 = trace ? now_s() : 0;
+        t_wait_job += j1 - j0;
         if (rc == FH_OK) {
             rc = fh_push_staged(h, job.m, 0u);
+            if (trace) t_push += now_s() - j1;
             if (rc != FH_OK) {
                 msg = fh_last_error();
                 abort = true;
@@ -2246,6 +2316,25 @@ static int fastq_host_strip_to_device(ByteSource &src, fh_sketcher *h, FastxStat
     }
     producer.join();
     stop_helpers();
+    };
+    // the helpers are the process's parked team threads (TeamPool) where those are free -- starting fifteen threads per call is
+    // a millisecond of a 15 ms call, and threads that have just been created run slower than threads that have run -- else
+    // threads of this call's own
+    if (!TeamPool::instance().run(T - 1, [&](unsigned i) { helper_main(i + 1); }, pipeline)) {
+        std::vector<std::thread> helpers;
+        try {
+            for (unsigned t = 1; t < T; ++t) helpers.emplace_back(helper_main, t);
+        } catch (...) { // not enough threads: this path is not for now (the helpers that exist wait for a chunk that never comes)
+            stop_helpers();
+            for (auto &x : helpers) x.join();
+            return FH_ERR_STATE;
+        }
+        pipeline();
+        for (auto &x : helpers) x.join();
+    }
+    if (trace)
+        fprintf(stderr, "[finch] fastq host strip: %u chunks of <= %.0f MiB of text on %u threads in %.1f ms: strip %.1f ms, producer waited %.1f ms for a buffer, pushes took %.1f ms and waited %.1f ms for chunks\n",
+                n_chunks, CHUNK / 1048576.0, T, (now_s() - t_begin) * 1e3, t_strip * 1e3, t_wait_slot * 1e3, t_push * 1e3, t_wait_job * 1e3);
     if (rc != FH_OK) return hfail(rc, "%s", msg.c_str());
     if (prc != FH_OK) return hfail(prc, "%s", pmsg.c_str());
     st.total_bases = bases_total;
@@ -2310,74 +2399,6 @@ static void host_parallel(size_t n, F f) {
     const size_t per = (n + t_max - 1) / t_max;
     fork_join(t_max, [=](unsigned t) { f(t, std::min(n, (size_t)t * per), std::min(n, ((size_t)t + 1) * per)); });
 }
-
-// Up to seven helper threads parked on a condition variable between teams.  run(n, job, mine): job(0..n-1) on n helpers while
-// the caller runs mine(); returns false -- nothing was run -- if the pool is in use or cannot have n threads (the caller then
-// starts threads of its own).  The helpers live as long as the process.
-class TeamPool {
-public:
-    static TeamPool &instance() {
-        static TeamPool *p = new TeamPool; // (never destroyed: its threads may outlive static destructors)
-        return *p;
-    }
-    template <class J, class M>
-    bool run(unsigned n, J job, M mine) {
-        if (n == 0 || n > MAX) return false;
-        if (!busy_.try_lock()) return false;
-        std::function<void(unsigned)> fn = job;
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            try {
-                while (threads_ < n) {
-                    std::thread(&TeamPool::worker, this, threads_).detach();
-                    ++threads_;
-                }
-            } catch (...) {
-                busy_.unlock();
-                return false;
-            }
-            job_ = &fn;
-            want_ = n;
-            done_ = 0;
-            ++gen_;
-        }
-        cv_.notify_all();
-        mine();
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_done_.wait(lk, [&] { return done_ == want_; });
-            job_ = nullptr;
-        }
-        busy_.unlock();
-        return true;
-    }
-
-private:
-    static constexpr unsigned MAX = 7;
-    void worker(unsigned id) {
-        unsigned seen = 0;
-        for (;;) {
-            std::function<void(unsigned)> *j;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
-                if (id >= want_) continue; // (a smaller team than there are helpers)
-                j = job_;
-            }
-            (*j)(id);
-            {
-                std::lock_guard<std::mutex> g(mu_);
-                ++done_;
-            }
-            cv_done_.notify_one();
-        }
-    }
-    std::mutex busy_, mu_;
-    std::condition_variable cv_, cv_done_;
-    std::function<void(unsigned)> *job_ = nullptr;
-    unsigned threads_ = 0, want_ = 0, done_ = 0, gen_ = 0;
-};
 
 // the same team of threads for several passes in a row: starting and joining a std::thread costs 50-100 us, which for three
 // passes over a 2 M-hash oversketch was more than the passes themselves.  f(t, n_threads, barrier) runs on every thread;
