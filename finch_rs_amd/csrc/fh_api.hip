@@ -1105,7 +1105,9 @@ int sketch_positions(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_
         if (!s->open_loop) {
             // status of everything before this range is known (drained): decide whether the threshold is
             // tight enough to let launches run to completion on their own
-            const double inflight = (double)(s->max_waves * TILE_POS);
+            // (positions the resident waves hold at once: a tile each -- of the kernel that runs the block, s->gran: a segment tile is
+            // about five of k2_sketch's)
+            const double inflight = (double)(s->max_waves * std::max<uint64_t>(s->gran, (uint64_t)TILE_POS));
             const double room = (double)s->live_target -
                                 (double)std::min<uint64_t>(std::max<uint64_t>(s->p.size, s->last_live), s->live_target);
             if (s->positions_done > 0 && inflight * fill_rate(s) <= 0.25 * room) s->open_loop = true;
@@ -3303,8 +3305,15 @@ class BlockTeam {
     // changes if sysfs does not say (numa_node -1 or absent), and the caller's own thread is never touched.
     static void sit_near(int device) {
         static thread_local int sitting = -1;
+        // what the thread was allowed BEFORE its first pin: a later pin to another node is cut out of this mask, not out of the
+        // one the previous pin left (whose intersection with another node's CPUs is empty)
+        static thread_local cpu_set_t allowed;
+        static thread_local bool have_allowed = false;
         if (sitting == device || cfg("no_numa_pin")) return;
-        sitting = device;
+        if (!have_allowed) {
+            if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+            have_allowed = true;
+        }
         char bdf[32] = {0};
         if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) return;
         for (char *c = bdf; *c; ++c) *c = (char)tolower(*c);
@@ -3322,9 +3331,8 @@ class BlockTeam {
             if (!fgets(list, (int)sizeof(list), f)) list[0] = 0;
             fclose(f);
         }
-        cpu_set_t allowed, want;
+        cpu_set_t want;
         CPU_ZERO(&want);
-        if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
         int n = 0;
         for (char *p = list; *p;) { // "0-63,128-191"
             char *e;
@@ -3340,7 +3348,8 @@ class BlockTeam {
             p = (*e == ',') ? e + 1 : e;
             if (*e != ',') break;
         }
-        if (n > 0) (void)sched_setaffinity(0, sizeof(want), &want);
+        // (recorded only once the thread really sits there: a pin that did not happen is tried again at the next job)
+        if (n > 0 && sched_setaffinity(0, sizeof(want), &want) == 0) sitting = device;
     }
     static void run_one(Job &j) {
         int rc = fh_reset(j.h);

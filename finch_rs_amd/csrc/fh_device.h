@@ -112,7 +112,8 @@ constexpr int UNIT_TILES = FH_UNIT_TILES; // queue granularity (SketchArgs::unit
 constexpr int MAX_UNITS = FH_MAX_UNITS;   // (guided self-scheduling: big pulls first, single units at the end)
 // What a wave can insert between two looks at its budget: a tile's positions (k2_sketch, k2_sketch_w: 2048) or a round's (the
 // segment kernels: 64 lanes x up to 48 positions, fh_k2s.hip k2s_round).  Table, shard lists and budgets are sized with it.
-constexpr int WAVE_OVERSHOOT = 3072;
+// (+ QCAP = 64: up to QCAP / 2 - 1 candidates parked before the round are upserted after the wave last looked at its budget)
+constexpr int WAVE_OVERSHOOT = 3072 + 64;
 constexpr int WAVE_BUDGET = 2048; // + at most TILE_POS-1 overshoot inside the tile that crosses it   // tiles a wave pulls from the queue at a time (contiguous: halo reuse)
 
 // The segment kernel (fh_k2s.hip): a lane owns one SEGMENT of seg_stride consecutive k-mer start positions instead of 32, a

@@ -22,7 +22,8 @@
 //     k2_sketch would have admitted: the sketch never depends on S (tests/test_gpu_segments.py).
 // One workgroup of sixteen waves per CU (a wave's strings are 6.7 KB); a wave that uses up its insert budget stops at the
 // end of a ROUND and hands the rest of its range back as ONE leftover entry (first tile, end of the range, round to resume the
-// first tile at), so the table's guard is k2_sketch's: budget + at most 2047 new hashes per wave and launch.
+// first tile at), so the table's guard is k2_sketch's with a round in place of a tile: budget + at most 64 x 48 new hashes of the
+// round that crosses it + the candidates parked before it (WAVE_OVERSHOOT, fh_device.h) per wave and launch.
 //
 // Compiled FH_NPARTS times (-DFH_PART=i) like fh_k2.hip.
 #include <hip/hip_runtime.h>
@@ -51,7 +52,7 @@ constexpr int K2S_WPB = 16;
 // (fh_core.h: seg_round, seg_long, seg_doff and the cut of the views, shared with the host logic test)
 constexpr bool k2s_long(int K) { return seg_long(K); }
 constexpr int k2s_round(int K) { return seg_round(K); }
-static_assert(64 * 48 <= WAVE_OVERSHOOT, "a round's positions are what a wave may overshoot its insert budget by (fh_device.h)");
+static_assert(64 * 48 + QCAP <= WAVE_OVERSHOOT, "a round's positions are what a wave may overshoot its insert budget by (fh_device.h)");
 // LDS of the workgroup: lookup tables, admit queues, then a block per wave
 constexpr u32 K2S_A1 = 0, K2S_A2 = 4096, K2S_B1 = 8192, K2S_B2 = 10240, K2S_P = 12288, K2S_Q = 20480;
 constexpr u32 K2S_TILE = K2S_Q + K2S_WPB * (u32)sizeof(AdmitQueueT<false>);

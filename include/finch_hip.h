@@ -202,8 +202,11 @@ int fh_push_fasta_text(fh_sketcher *s, uint64_t len, uint32_t start_state, uint3
  * (fh_set_stream_offset).  Applies to one push; excludes FH_PUSH_CONTINUE. */
 int fh_set_text_halo(fh_sketcher *s, const uint8_t *halo, uint32_t n);
 /* Zero-copy form of fh_push_block_ex: the caller writes packed-stream bytes (sequence bytes + one breaker byte per
- * record, whitespace already removed) straight into the buffer handed out by fh_text_buffer and commits the first
- * `len` of them.  Same flags as fh_push_block_ex. */
+ * record, whitespace already removed) straight into the buffer handed out by fh_text_buffer / fh_text_buffers and commits
+ * the first `len` of them.  Same flags as fh_push_block_ex.  A filler thread that has called fh_text_prefetch(slot, len) on the
+ * buffer finds its copy honoured (a push without FH_PUSH_CONTINUE): the link works while the previous push is sketched.  The
+ * buffer of the push BEFORE the one that has just returned is free to be filled again (this push waited for that one's
+ * launches, which had waited for its copy). */
 int fh_push_staged(fh_sketcher *s, uint64_t len, uint32_t flags);
 /* sequence bytes seen by fh_push_fastq_text so far (what total_bases counts, mash.rs:72); valid after fh_finish */
 int fh_text_bases(fh_sketcher *s, uint64_t *total_bases);
@@ -215,11 +218,16 @@ int fh_push_device(fh_sketcher *s, const void *dev_bytes, uint64_t len);
 
 /* What the caller knows about the records of the packed streams it pushes (a property of its data: it survives fh_reset).
  * stride = record length + 1 (the breaker): every record of every block pushed from now on has that length -- reads of one
- * length, which is what sequencers write; 0 (the default) = not known: a block of 64 MiB or more is asked itself (one wavefront
- * and one host round trip per block); 1 = records are not of one length, do not ask.  With a stride the library sketches the
- * block with a kernel that does not hash the k positions of every record whose window crosses its breaker (fh_k2s.hip; the
- * reference's canonical_kmers yields len - k + 1 windows per record, mash.rs:76).  A TUNING hint: the sketch is the same bit
- * for bit whatever is said here, also when it is wrong (tests/test_gpu_segments.py).  Strides outside 40..168 are taken as 1. */
+ * length, which is what sequencers write; 1 = records are not of one length, do not look; 0 (the default) = not known: the
+ * library looks itself.  A block of 16 MiB or more is probed (one wavefront: its first bytes and 128 records spread over it)
+ * BEHIND its own launches, without a wait, and the NEXT block of the handle goes by the newest answer that has arrived (the
+ * blocks of one input and the passes over one buffer share their read length; an answer is read only once its probe's event
+ * has completed).  Only a handle that has no answer yet waits for one, and only for a block of 256 MiB or more (0.1-0.3 ms,
+ * once) -- so a handle's first block below 256 MiB runs the tile kernel.  With a stride the block is sketched by a kernel that
+ * does not hash the k positions of every record whose window crosses its breaker (fh_k2s.hip; the reference's canonical_kmers
+ * yields len - k + 1 windows per record, mash.rs:76): strides 40..168 one lane per record, 169..336 two, 337..672 four
+ * (k > 32: 40..168 only); any seed.  A TUNING hint: the sketch is the same bit for bit whatever is said here, also when it is
+ * wrong or stale (tests/test_gpu_segments.py).  Strides outside those ranges are taken as 1. */
 int fh_set_record_stride(fh_sketcher *s, uint32_t stride);
 /* debug / tests: launches of the segment kernel, blocks probed for a stride, the stride of the last block (0: none) */
 int fh_debug_segments(fh_sketcher *s, uint64_t *launches, uint64_t *probes, uint32_t *stride);

@@ -186,3 +186,62 @@ def test_sketch_device_blocks_rejects_what_it_cannot_merge():
         SH.sketch_device_blocks([a, a], [buf.ptr, buf.ptr], [1024, 1024], [0, 1024])
     a.close()
     b.close()
+
+
+def test_sketch_device_blocks_soak_500_calls_random_blocks_one_bad_block_mid_series():
+    """the N-device driver before its first real eight-GPU run: eight handles, 500 calls in a row with blocks of random sizes --
+    empty, one read, ends that are no multiple of anything -- every 25th call's merged sketch held against the oracle; in the
+    middle of the series one call gets a block that cannot be sketched (a pointer that is not 16-byte aligned): the call names the
+    block, the calls after it are as good as the ones before, and the caller's HIP device is the one it was after every return"""
+    import torch
+    N, CALLS = 8, 500
+    rng = np.random.default_rng(808)
+    n_reads = 60_000
+    data = _reads(n_reads, seed=12)
+    pool = F.DeviceBuffer(len(data) + 4096)
+    pool.upload(data)
+    params = F.SketchParams.default()
+    sks = [params.create_sketcher() for _ in range(N)]
+    torch.cuda.set_device(0)
+    checked = 0
+    for call in range(CALLS):
+        # read ranges of random sizes out of the resident reads: block i = reads [lo_i, hi_i); record starts are 151 bytes apart, so a
+        # block's start is 16-byte aligned only for lo_i a multiple of 16
+        los, his = [], []
+        for i in range(N):
+            kind = rng.integers(0, 6)
+            lo = int(rng.integers(0, n_reads // 16 - 1)) * 16
+            if kind == 0:
+                hi = lo                                             # an empty block
+            elif kind == 1:
+                hi = lo + 1                                         # one read
+            elif kind == 2:
+                hi = lo + int(rng.integers(2, 70))                  # less than a segment tile
+            else:
+                hi = min(n_reads, lo + int(rng.integers(100, 20_000)))
+            los.append(lo)
+            his.append(hi)
+        ptrs = [pool.ptr + lo * REC for lo in los]
+        lens = [(hi - lo) * REC for lo, hi in zip(los, his)]
+        offs = list(np.cumsum([0] + lens[:-1]))
+        if call == CALLS // 2:
+            bad = int(rng.integers(1, N))
+            ptrs[bad] += 8  # not 16-byte aligned: fh_push_device refuses it
+            lens[bad] = max(lens[bad], REC)
+            with pytest.raises(F.FinchHipError, match="block %d " % bad):
+                SH.sketch_device_blocks(sks, ptrs, lens, offs)
+            assert torch.cuda.current_device() == 0
+            continue
+        SH.sketch_device_blocks(sks, ptrs, lens, offs)
+        assert torch.cuda.current_device() == 0
+        if call % 25 == 0 or call == CALLS // 2 + 1:
+            union = np.concatenate([data[lo * REC:hi * REC] for lo, hi in zip(los, his)] + [np.zeros(0, np.uint8)])
+            ora = O.OracleSketcher(O.MASH, 1000, 21, 0)
+            if len(union):
+                ora.process_packed(union, 0)
+            kc, km, _ = sks[0].to_arrays()
+            _same(kc, km, sks[0].finish()[1], ora, "call %d" % call)
+            checked += 1
+    assert checked >= 20
+    for s in sks:
+        s.close()
