@@ -193,7 +193,13 @@ def test_sketch_device_blocks_soak_500_calls_random_blocks_one_bad_block_mid_ser
     empty, one read, ends that are no multiple of anything -- every 25th call's merged sketch held against the oracle; in the
     middle of the series one call gets a block that cannot be sketched (a pointer that is not 16-byte aligned): the call names the
     block, the calls after it are as good as the ones before, and the caller's HIP device is the one it was after every return"""
-    import torch
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")  # (the runtime the library is linked against: already loaded)
+
+    def current_device():
+        d = ctypes.c_int(-1)
+        assert hip.hipGetDevice(ctypes.byref(d)) == 0
+        return d.value
     N, CALLS = 8, 500
     rng = np.random.default_rng(808)
     n_reads = 60_000
@@ -202,7 +208,7 @@ def test_sketch_device_blocks_soak_500_calls_random_blocks_one_bad_block_mid_ser
     pool.upload(data)
     params = F.SketchParams.default()
     sks = [params.create_sketcher() for _ in range(N)]
-    torch.cuda.set_device(0)
+    assert hip.hipSetDevice(0) == 0
     checked = 0
     for call in range(CALLS):
         # read ranges of random sizes out of the resident reads: block i = reads [lo_i, hi_i); record starts are 151 bytes apart, so a
@@ -230,10 +236,10 @@ def test_sketch_device_blocks_soak_500_calls_random_blocks_one_bad_block_mid_ser
             lens[bad] = max(lens[bad], REC)
             with pytest.raises(F.FinchHipError, match="block %d " % bad):
                 SH.sketch_device_blocks(sks, ptrs, lens, offs)
-            assert torch.cuda.current_device() == 0
+            assert current_device() == 0
             continue
         SH.sketch_device_blocks(sks, ptrs, lens, offs)
-        assert torch.cuda.current_device() == 0
+        assert current_device() == 0
         if call % 25 == 0 or call == CALLS // 2 + 1:
             union = np.concatenate([data[lo * REC:hi * REC] for lo, hi in zip(los, his)] + [np.zeros(0, np.uint8)])
             ora = O.OracleSketcher(O.MASH, 1000, 21, 0)

@@ -180,9 +180,11 @@ def test_the_bench_line_collects_its_own_counters():
     d = _bench(["--workload", "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], 1)
     r = d["roofline"]
     assert r["traffic_source"].startswith("live"), r.get("traffic_source")
-    live = r["pmc_live"]
+    live = r["pmc"]  # (the per-wave-iteration block of the line is this run's own; the committed passes' sit under pmc_committed)
+    assert live["source"].startswith("live")
     assert 0.95 < live["hbm_bytes_per_position"] < 1.6, live
     assert 30.0 < live["valu_per_wave_iter"] < 80.0, live
+    assert live["lds_active_per_wave_iter"] is None or live["lds_active_per_wave_iter"] > 0
     assert r["traffic"] == int(live["hbm_bytes_per_position"] * r["alg_bytes_per_launch"])
     committed = _bench(["--workload", "c2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-live-pmc"], 1)
     assert committed["roofline"]["traffic_source"].startswith("committed")
