@@ -1075,7 +1075,9 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
     if (!sampled && s->positions_done == 0 && s->tau_lo == 0) {
         // a large first block speculates on its first 32 M positions only: a wrong guess then costs a second pass
         // over that prefix (0.1 ms), a right one replaces the ten closed-loop warm-up ranges and their round trips
-        const uint64_t spec_pos = n_pos <= SPEC_MAX_POS ? n_pos : SPEC_PREFIX_POS / s->gran * s->gran;
+        // (option spec_prefix_pos: the positions a large first block speculates on -- measurement knob)
+        static const uint64_t prefix_pos = cfg("spec_prefix_pos") ? std::max<uint64_t>(1ull << 20, strtoull(cfg("spec_prefix_pos"), nullptr, 10)) : SPEC_PREFIX_POS;
+        const uint64_t spec_pos = n_pos <= SPEC_MAX_POS ? n_pos : std::max<uint64_t>(prefix_pos / s->gran, 1) * s->gran;
         bool done = false;
         if (int rc = speculative_first_block(s, d_seq, len, base_pos, spec_pos, &done)) return rc;
         if (done) {

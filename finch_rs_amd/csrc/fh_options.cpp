@@ -37,6 +37,7 @@ const OptDef DEFS[] = {
     {"no_spec_rescale", "a failed speculation re-reads its block for everything above the guess at once"},
     {"no_reset_fold", "fh_finish's epilogue does not leave the handle reset"},
     {"max_range", "cap on k-mer start positions per range (tests: many ranges per push)"},
+    {"spec_prefix_pos", "positions of a large first block that are sketched at the speculative threshold (default 32 M)"},
     // --- large sketches ---
     {"no_sample", "no sampling pre-pass for large sketches"},
     {"sample_min_pos", "smallest first block that is sampled (tests)"},

@@ -109,3 +109,10 @@ def test_one_configuration_surface(built):
             os.environ.pop("FH_DEBUG", None)
         else:
             os.environ["FH_DEBUG"] = old
+
+
+def test_readme_lists_the_options_the_library_has(built):
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    table = readme[readme.index("| option | effect |"):]
+    listed = re.findall(r"^\| `([a-z0-9_]+)` \|", table, re.M)
+    assert listed == [n for n, _ in F.option_list()]
