@@ -192,12 +192,13 @@ struct fh_sketcher {
     // The segment kernel (fh_k2s.hip): seg_hint is what the caller said about the records (fh_set_record_stride: 0 = find out,
     // 1 = do not use it, else the stride), blk_seg the stride of the block being sketched (0: k2_sketch), gran what the block's
     // ranges are cut at (a tile of the kernel that runs it)
-    uint32_t seg_hint = 0, blk_seg = 0;
+    uint32_t seg_hint = 0, blk_seg = 0, blk_sub = 1; // (blk_sub: lanes per record, or SEG_RAGGED)
     uint64_t gran = TILE_POS;
     uint32_t *h_probe = nullptr; // pinned: launch_seg_probe's answer
     bool probe_seen = false;     // a block of this handle has been asked (probe_answer is its answer, or a later block's)
     hipEvent_t probe_ev = nullptr; // recorded behind the newest probe: h_probe[0] is read only once it has completed
     uint32_t probe_answer = 0;     // the newest answer read that way
+    uint32_t probe_breakers = 0;   // ... and how many of the 4096 bytes it looked at all over the block were no bases
     uint64_t n_seg_launches = 0, n_seg_probes = 0;
     uint64_t max_waves = 0;
     uint64_t max_range = 0; // test knob: cap on positions per range
@@ -672,7 +673,7 @@ int start_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint64_t bas
     // the segment kernel where the block has a stride and the launch is the plain one (any seed; no test mask, no lower threshold)
     // (K > 32: fh_k2ws.hip takes seed, mask and lower threshold at run time, as fh_k2w.hip does)
     r.seg = (s->blk_seg && (s->p.k > 32 || (!s->p.hash_mask && !s->tau_lo)) && pos % s->gran == 0) ? s->blk_seg : 0u;
-    r.seg_sub = r.seg ? seg_sub_for(r.seg) : 1u;
+    r.seg_sub = r.seg ? s->blk_sub : 1u;
     const uint64_t tile = r.seg ? (uint64_t)seg_tile_pos(r.seg, r.seg_sub) : (uint64_t)TILE_POS;
     const uint64_t tiles = (end - pos + tile - 1) / tile;
     if (tiles >= (1ull << 31)) return fail(FH_ERR_INVALID, "block too large for one range");
@@ -995,6 +996,7 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
     // caller may have said so (fh_set_record_stride); a large block is asked itself -- one wavefront, one round trip (~20 us:
     // worth it from a few milliseconds of sketching on).  The stride only decides how fast, never what comes out.
     s->blk_seg = 0;
+    s->blk_sub = 1;
     s->gran = TILE_POS;
     bool probe_behind = false;
     {
@@ -1026,7 +1028,7 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
                 if (s->probe_seen) {
                     // (the newest probe may still be running -- it sits behind its block's launches: its answer is taken once
                     // its event has completed, until then the one before it stands)
-                    if (s->probe_ev && hipEventQuery(s->probe_ev) == hipSuccess) s->probe_answer = s->h_probe[0];
+                    if (s->probe_ev && hipEventQuery(s->probe_ev) == hipSuccess) s->probe_answer = s->h_probe[0], s->probe_breakers = s->h_probe[1];
                     else (void)hipGetLastError();
                     S = s->probe_answer;
                 } else if (len >= probe_wait_min) {
@@ -1034,6 +1036,7 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
                     HIP_TRY(launch_seg_probe(d_seq, len, s->h_probe, s->stream));
                     HIP_TRY(hipStreamSynchronize(s->stream));
                     S = s->probe_answer = s->h_probe[0];
+                    s->probe_breakers = s->h_probe[1];
                     s->n_seg_probes++;
                     s->probe_seen = true;
                 }
@@ -1044,7 +1047,18 @@ int sketch_device_range(fh_sketcher *s, const uint8_t *d_seq, uint64_t len, uint
             const uint32_t s_max = s->p.k > 32 ? SEG_MAX_STRIDE : SEG_MAX_RECORD;
             if (S >= SEG_MIN_STRIDE && S <= s_max && S > s->p.k && n_pos >= 64ull * S) {
                 s->blk_seg = S;
-                s->gran = seg_tile_pos(S, seg_sub_for(S));
+                s->blk_sub = seg_sub_for(S);
+                s->gran = seg_tile_pos(S, s->blk_sub);
+            } else if (seg_ragged_k((int)s->p.k) && n_pos >= 64ull * SEG_RAGGED_STRIDE) {
+                // no one stride, but records of a few hundred bases at most (a breaker in every 256 bytes the probe looked at, or
+                // more): the work-item form.  Option seg_ragged: 0 = never, 1 = whatever the block holds (tests)
+                static const int rag_opt = cfg("seg_ragged") ? atoi(cfg("seg_ragged")) : -1;
+                const bool dense = S == 0 && s->seg_hint == 0 && probe_behind && s->probe_seen && s->probe_breakers >= 16u;
+                if (rag_opt == 1 || (rag_opt != 0 && dense)) {
+                    s->blk_seg = SEG_RAGGED_STRIDE;
+                    s->blk_sub = SEG_RAGGED;
+                    s->gran = seg_tile_pos(SEG_RAGGED_STRIDE, SEG_RAGGED);
+                }
             }
         }
     }
@@ -1572,6 +1586,7 @@ fh_sketcher *fh_new(const fh_params *params, int device) {
                 s->seg_hint = 0;
                 s->probe_seen = false; // (the previous owner's reads say nothing about the new one's)
                 s->probe_answer = 0;
+                s->probe_breakers = 0;
                 s->gz_no_feed = false; // (nor does a feed that timed out on its files)
                 {
                     const bool fast = !s->big_mode && cfg("no_fast") == nullptr;

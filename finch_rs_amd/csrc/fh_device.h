@@ -127,7 +127,14 @@ constexpr uint32_t SEG_MIN_STRIDE = 40, SEG_MAX_STRIDE = 168; // (what a wave's 
 // positions behind the last window -- so that every lane of the wave runs out of valid windows in the same round.
 constexpr uint32_t SEG_MAX_RECORD = 4 * SEG_MAX_STRIDE;
 constexpr uint32_t seg_sub_for(uint32_t stride) { return stride <= SEG_MAX_STRIDE ? 1u : stride <= 2 * SEG_MAX_STRIDE ? 2u : stride <= SEG_MAX_RECORD ? 4u : 0u; }
-constexpr uint32_t seg_tile_pos(uint32_t stride, uint32_t sub) { return (64u / sub) * stride; } // start positions of a tile (a multiple of 16)
+// RAGGED records (trimmed reads: no stride fits): SketchArgs::seg_sub == SEG_RAGGED with seg_stride == SEG_RAGGED_STRIDE.  A lane
+// looks at SEG_RAGGED_STRIDE positions of the tile in cells of 32; a cell that holds valid windows becomes a WORK ITEM (from its
+// first to its last valid window), the items are ordered by size class in the wave's LDS and dealt out 64 a round -- a round
+// ends behind the longest of its items, and cells without a window cost nothing (fh_k2s.hip).  K = 25, 27..32 only (rounds of 32
+// positions; the K that live off the LDS pipe, where every window not hashed is lookups saved: docs/MEASUREMENTS_r06.md 4).
+constexpr uint32_t SEG_RAGGED = 0x100u, SEG_RAGGED_STRIDE = 128u;
+constexpr bool seg_ragged_k(int k) { return k == 25 || (k >= 27 && k <= 32); }
+constexpr uint32_t seg_tile_pos(uint32_t stride, uint32_t sub) { return sub == SEG_RAGGED ? 64u * stride : (64u / sub) * stride; } // start positions of a tile (a multiple of 16)
 // (the segment kernels' leftover lists hold TRIPLES (t0, t1, c0): tiles [t0, t1), t0 from round c0 on -- a wave may stop inside a tile)
 
 struct SketchArgs {

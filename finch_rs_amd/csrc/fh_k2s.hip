@@ -149,13 +149,22 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
     // A record of S start positions belongs to 1 << SH lanes: the first ones take H positions each, the last one the rest
     // (LAST >= H: it holds the K positions behind the record's last window).  SH = 0: a lane per record, H = LAST = S.
     const u32 S = (u32)__builtin_amdgcn_readfirstlane((int)a.seg_stride);
-    const u32 SH = (u32)__builtin_amdgcn_readfirstlane((int)(a.seg_sub >= 4u ? 2u : a.seg_sub >= 2u ? 1u : 0u));
+    // RAG: records of many lengths -- the lanes' cells become work items, 64 a round (fh_device.h, SEG_RAGGED); not for the K whose
+    // rounds are longer than 32 positions
+    const bool RAG = !LONG && RO == 32 && (u32)__builtin_amdgcn_readfirstlane((int)a.seg_sub) == SEG_RAGGED;
+    const u32 SH = RAG ? 0u : (u32)__builtin_amdgcn_readfirstlane((int)(a.seg_sub >= 4u ? 2u : a.seg_sub >= 2u ? 1u : 0u));
     const u32 SUBM = (1u << SH) - 1u;
     const u32 H = SH ? (S - (u32)K + SUBM) >> SH : S, LAST = S - SUBM * H;
     const u32 tile_pos = (64u >> SH) * S;
     const u32 NCH = (tile_pos >> 4) + 6u, NR = (LAST + (u32)RO - 1u) / (u32)RO;
     // where lane l's segment begins in the tile, and how long it is
     auto seg_start = [&](u32 l) -> u32 { return S * (l >> SH) + (l & SUBM) * H; };
+    // RAG: the tile's work items (start position | windows << 16), at most 256, in the room the strings of a 128-position stride
+    // leave behind them (two halves: behind the complemented codes and behind the reversed ones; 8 words of zeroes stay between)
+    u32 *const ItA = Fc + (NCH + 8u), *const ItB = Rv + (NCH + 8u);
+    static_assert(4u * SEG_RAGGED_STRIDE + 6u + 8u + 128u <= K2S_RV_DW, "the item list fits behind the strings of a ragged tile");
+    auto item_ptr = [&](u32 i) -> u32 * { return i < 128u ? ItA + i : ItB + (i - 128u); };
+    u32 n_items = 0; // (wave-uniform)
     u32 nvalid = 0;
 
 #define FLUSHS(ctl_, q_, qn_, shard_) ([&] { const u32 r_ = (u32)__builtin_amdgcn_readfirstlane((int)flush_queue(ctl_, q_, qn_, shard_)); want_refresh |= r_ >> 31; return r_ & 0x7FFFFFFFu; }())
@@ -257,18 +266,59 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             const u64 tile_stream_pos = a.base_pos + tile_pos0;
+            u32 NRt = NR; // rounds of this tile
             // start positions from the tile's first one to the end of the launch's range, as far as 32 bits count (scalar: a lane's
             // share of it is one saturating subtraction per round instead of 64-bit arithmetic per lane)
             const u32 tile_room = a.p_end > tile_pos0 ? (u32)(a.p_end - tile_pos0 < 0x7FFFFFFFull ? a.p_end - tile_pos0 : 0x7FFFFFFFull) : 0u;
+            if constexpr (!LONG && RO == 32) {
+                if (RAG) {
+                    // ---- the tile's work items: every lane's four cells of 32 positions, trimmed to their valid windows ----
+                    const u32 lane = lane_now();
+                    u32 it[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const u32 p0 = S * lane + 32u * (u32)q;
+                        const u64 g64 = seg_good_bits(Gd, p0);
+                        u32 lim = __builtin_elementwise_sub_sat(tile_room, p0);
+                        lim = lim < 32u ? lim : 32u;
+                        const u32 W = window_valid_mask<K>(g64) & (lim >= 32u ? 0xFFFFFFFFu : ((1u << lim) - 1u));
+                        const u32 first = W ? (u32)__builtin_ctz(W) : 0u, last = W ? 31u - (u32)__builtin_clz(W) : 0u;
+                        it[q] = W ? ((p0 + first) | ((last - first + 1u) << 16)) : 0u;
+                    }
+                    // ordered by size class (25..32, 17..24, 9..16, 1..8 windows): a round's lanes then run about equally long
+                    n_items = 0;
 #pragma unroll 1
-            for (u32 c = c_first; c < NR; ++c) {
-                const u32 rc0 = (u32)RO * c; // the round's first segment offset (wave-uniform)
+                    for (u32 cls = 0; cls < 4u; ++cls) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const bool in = it[q] != 0u && ((32u - (it[q] >> 16)) >> 3) == cls;
+                            const u64 m = __builtin_amdgcn_ballot_w64(in);
+                            if (in) *item_ptr(n_items + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))) = it[q];
+                            n_items += (u32)__popcll(m);
+                        }
+                    }
+                    NRt = (n_items + 63u) >> 6;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+#pragma unroll 1
+            for (u32 c = c_first; c < NRt; ++c) {
+                const u32 rc0 = RAG ? 0u : (u32)RO * c; // the round's first segment offset (wave-uniform)
                 Win win;
                 Mask Wc;
-                u32 nmax = LAST - rc0 < (u32)RO ? LAST - rc0 : (u32)RO; // positions of the (longest) segment this round covers
+                u32 nmax = RAG ? (u32)RO : (LAST - rc0 < (u32)RO ? LAST - rc0 : (u32)RO); // positions of the (longest) segment this round covers
                 {
                     const u32 lane = lane_now();
-                    const u32 p0 = seg_start(lane) + rc0; // the lane's view begins at this tile position
+                    u32 p0 = seg_start(lane) + rc0; // the lane's view begins at this tile position
+                    u32 item_n = 0;
+                    if (RAG) { // the lane's work item of this round (none: no windows)
+                        const u32 ii = 64u * c + lane;
+                        const u32 itv = ii < n_items ? *item_ptr(ii) : 0u;
+                        p0 = itv & 0xFFFFu;
+                        item_n = itv >> 16;
+                    }
                     // which of its windows carry a k-mer: all K bases good, inside the segment, inside [p_begin, p_end)
                     const u64 g64 = seg_good_bits(Gd, p0);
                     u32 limit = __builtin_elementwise_sub_sat(tile_room, p0);
@@ -277,6 +327,7 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
                         const u32 own = __builtin_elementwise_sub_sat((lane & SUBM) == SUBM ? LAST : H, rc0);
                         limit = limit < own ? limit : own;
                     }
+                    if (RAG) limit = limit < item_n ? limit : item_n;
                     if constexpr (LONG) Wc = window_valid_mask64<K>(g64) & ((1ull << limit) - 1ull); // (R <= 48)
                     else Wc = window_valid_mask<K>(g64) & (limit >= 32u ? 0xFFFFFFFFu : ((1u << limit) - 1u));
                     // a round whose windows reach the segment's last K bases may hold nothing, or nothing behind some position,
@@ -348,7 +399,9 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
                                 queue->ka[my] = hp.ka;
                                 queue->kb[my] = hp.kb;
                                 queue->k[my] = cm;
-                                const u64 pos = tile_stream_pos + (u64)(seg_start(lane_now()) + rc0 + (u32)(h * R + j));
+                                u32 p_here = seg_start(lane_now()) + rc0;
+                                if (RAG) p_here = *item_ptr(64u * c + lane_now()) & 0xFFFFu; // (a candidate's lane has an item)
+                                const u64 pos = tile_stream_pos + (u64)(p_here + (u32)(h * R + j));
                                 bool is_rc = rc_loop;
                                 if constexpr (Win::MINF64) is_rc = win.strand_of(j);
                                 queue->p[my] = pos | ((u64)(is_rc ? 1u : 0u) << 63);
@@ -366,7 +419,7 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
                 step(step, std::integral_constant<int, 0>{});
                 }
                 __builtin_amdgcn_wave_barrier();
-                const bool last_round = c + 1u == NR;
+                const bool last_round = c + 1u == NRt;
                 if (qn >= (u32)(QCAP / 2)) { // drain when half full (and at the end of the pulled range, below)
                     wave_inserts += FLUSHS(a.ctl, queue, qn, shard);
                     qn = 0;

@@ -39,9 +39,12 @@ hipError_t launch_k2(int k, const SketchArgs &a, int blocks, hipStream_t st) {
     }
     if (a.seg_stride) { // the segment form (fh_k2s.hip)
         const uint32_t sub = a.seg_sub ? a.seg_sub : 1u;
-        if (a.seg_stride < SEG_MIN_STRIDE || (sub != 1u && sub != 2u && sub != 4u) || (a.seg_stride + sub - 1u) / sub > SEG_MAX_STRIDE || a.seg_stride <= (uint32_t)k ||
-            a.tau_lo || a.hash_mask != ~0ull)
+        if (sub == SEG_RAGGED) {
+            if (a.seg_stride != SEG_RAGGED_STRIDE || !seg_ragged_k(k) || a.tau_lo || a.hash_mask != ~0ull) return hipErrorInvalidValue;
+        } else if (a.seg_stride < SEG_MIN_STRIDE || (sub != 1u && sub != 2u && sub != 4u) || (a.seg_stride + sub - 1u) / sub > SEG_MAX_STRIDE ||
+                   a.seg_stride <= (uint32_t)k || a.tau_lo || a.hash_mask != ~0ull) {
             return hipErrorInvalidValue;
+        }
         switch ((k - 1) / (32 / FH_NPARTS)) {
         case 0: return launch_k2s_part0(k, a, st);
         case 1: return launch_k2s_part1(k, a, st);
@@ -1079,7 +1082,16 @@ __global__ __launch_bounds__(64) void k_seg_probe(const uint8_t *seq, u64 len, u
         const bool inner = probe_is_base(seq[r0 * S]) || probe_is_base(seq[r1 * S + S / 2u]);
         if (__builtin_amdgcn_ballot_w64(ok) == ~0ull && __popcll(__builtin_amdgcn_ballot_w64(inner)) >= 32) found = S;
     }
+    // how dense the record ends are: the bytes that are no bases among 64 x 64 looked at all over the block (out[1], of 4096) --
+    // records of many lengths but few hundred bases each are what the segment kernel's work-item form is for (SEG_RAGGED)
+    u32 nb = 0;
+    if (len >= 8192ull) {
+        const u64 at = (len - 64ull) * lane / 63ull;
+        for (u32 i = 0; i < 64u; ++i) nb += probe_is_base(seq[at + i]) ? 0u : 1u;
+    }
+    for (int off = 32; off > 0; off >>= 1) nb += __shfl_xor(nb, off);
     if (lane == 0) {
+        out[1] = nb;
         out[0] = found;
         __threadfence_system();
     }

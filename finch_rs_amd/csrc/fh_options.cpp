@@ -26,6 +26,7 @@ const OptDef DEFS[] = {
     {"seg_probe_min", "blocks from this many bytes on are probed for a record stride (default 16 MiB)"},
     {"seg_probe_wait_min", "a handle's first block of at least this many bytes waits for its probe (default 256 MiB)"},
     {"seg_pull_pos", "positions a segment-kernel pull takes at most (default 32 K)"},
+    {"seg_ragged", "0 = never the work-item form of the segment kernels (records of many lengths, k = 25, 27..32), 1 = for every block without a stride (tests); default: where the probe of a block finds a record end in every 256 bytes or more"},
     {"unit_tiles", "tiles per queue unit (0 = by size)"},
     {"no_static_units", "no statically dealt first units: every unit through the queue"},
     {"waves_per_cu", "persistent waves per compute unit (default 16)"},

@@ -274,3 +274,59 @@ def test_seeds_go_through_the_segment_kernels(genome, k, seed):
     ora = O.OracleSketcher(O.SCALED, 1000, k, seed, 0.25)
     ora.process_packed(stream, 0)
     assert_same(sk, ora, "scaled k=%d seed=%d" % (k, seed))
+
+
+def test_records_of_many_lengths_go_through_the_work_item_form():
+    """SEG_RAGGED (fh_k2s.hip; k = 25, 27..32): no stride fits, the lanes' cells of 32 positions become work items ordered by size
+    and dealt out 64 a round.  Forced on every block without a stride (option seg_ragged=1, read once per process: a child), on
+    ragged reads, trimmed mixes, one long record, all-N, tails of N, few waves with loose thresholds (waves stop inside tiles and
+    resume at a round of a rebuilt item list), seeds -- the sketch is the oracle's"""
+    code = r'''
+import numpy as np
+import finch_rs_amd as F
+from finch_rs_amd import sketch_schemes as S
+from oracle import oracle as O
+import sys
+sys.path.insert(0, "tests")
+from test_gpu_parity import assert_same, random_reads
+from test_gpu_segments import packed, fixed_reads, sketch_on_device, oracle_of
+genome = S.synth_genome_host(300_000, 77)
+rng = np.random.default_rng(99)
+streams = {
+    "ragged 0..220": packed(random_reads(rng, 6000, 0, 220, p_n=0.01, genome=genome)),
+    "trimmed 35..150": packed(random_reads(rng, 8000, 35, 150, p_n=0.002, genome=genome)),
+    "mostly 150": packed([r if i % 5 else r[:int(rng.integers(30, 150))] for i, r in enumerate(fixed_reads(rng, 6000, 150, genome))]),
+    "one record": np.concatenate([genome[:250_000], np.zeros(1, np.uint8)]),
+    "all N": packed([bytes(r) for r in np.full((3000, 150), ord("N"), np.uint8)]),
+    "tail N": packed([r[:120] + b"N" * 30 for r in fixed_reads(rng, 3000, 150, genome)]),
+}
+n_rag = 0
+for k in (25, 27, 28, 29, 30, 31, 32):
+    for name, stream in streams.items():
+        if k not in (25, 31) and name not in ("ragged 0..220", "trimmed 35..150"):
+            continue
+        sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, k, 0), stream, 0)
+        launches, _, stride = sk.debug_segments()
+        assert launches > 0 and stride == 128, (k, name, launches, stride)
+        n_rag += 1
+        assert_same(sk, oracle_of(O.MASH, 1000, k, stream), "%s k=%d" % (name, k))
+# the K whose rounds are longer than 32 positions keep the tile kernel
+sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, 21, 0), streams["trimmed 35..150"], 0)
+assert sk.debug_segments()[0] == 0
+assert_same(sk, oracle_of(O.MASH, 1000, 21, streams["trimmed 35..150"]), "k=21")
+# seeds, a scaled sketch that keeps half of all k-mers on few waves, several pushes
+stream = streams["trimmed 35..150"]
+for k, seed in ((31, 42), (27, 2**63 + 9)):
+    sk, _ = sketch_on_device(F.SketchParams.mash(500, 500, True, k, seed), stream, 0, pushes=3)
+    ora = O.OracleSketcher(O.MASH, 500, k, seed); ora.process_packed(stream, 0)
+    assert sk.debug_segments()[2] == 128
+    assert_same(sk, ora, "seed k=%d" % k)
+for ml in (4096, 16384, 0):
+    sk, _ = sketch_on_device(F.SketchParams.scaled(1000, 31, 0.5, 0), stream, 0, max_launch=ml)
+    assert sk.debug_segments()[2] == 128
+    assert_same(sk, oracle_of(O.SCALED, 1000, 31, stream, 0.5), "scaled max_launch=%d" % ml)
+print("child ok", n_rag)
+'''
+    r = subprocess.run([sys.executable, "-c", code], env=F.debug_env(seg_ragged="1"), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "child ok" in r.stdout, r.stdout[-3000:]

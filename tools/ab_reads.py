@@ -23,6 +23,7 @@ ap.add_argument("--n", type=int, default=1000)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--ragged", default="")
+ap.add_argument("--frac-full", type=float, default=0.0, help="--ragged: this fraction of the records has the full length HI")
 a = ap.parse_args()
 
 GL = 5_000_000
@@ -33,6 +34,7 @@ if a.ragged:
     rng = np.random.default_rng(1)
     nrec = int(a.gbases * 1e9 / ((lo + hi) / 2))
     lens = rng.integers(lo, hi + 1, size=nrec)
+    lens[rng.random(nrec) < a.frac_full] = hi
     # reads of `hi` bases from the device generator, cut to their lengths on the host (bounded: a few hundred Mbases)
     full = S.DeviceBuffer(nrec * (hi + 1) + 64)
     S.synth_reads_device(full, gen, GL, 0, nrec, hi, 20250620, 10000, 500)
@@ -47,7 +49,7 @@ if a.ragged:
     buf.upload(stream)
     bases = int(lens.sum())
     hints = (("tile kernels", 1), ("segment kernels (block asked)", 0))
-    what = "records of %d..%d bases (uniform), %.2f Gbases" % (lo, hi, bases / 1e9)
+    what = "records of %d..%d bases (uniform%s), %.2f Gbases" % (lo, hi, ", %.0f %% at %d" % (100 * a.frac_full, hi) if a.frac_full else "", bases / 1e9)
 else:
     L = a.len
     nrec = int(a.gbases * 1e9 / L)
