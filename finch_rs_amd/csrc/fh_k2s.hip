@@ -285,13 +285,16 @@ __global__ __launch_bounds__(64 * K2S_WPB, 4) void k2_sketch_seg(const SketchArg
                         const u32 first = W ? (u32)__builtin_ctz(W) : 0u, last = W ? 31u - (u32)__builtin_clz(W) : 0u;
                         it[q] = W ? ((p0 + first) | ((last - first + 1u) << 16)) : 0u;
                     }
-                    // ordered by size class (25..32, 17..24, 9..16, 1..8 windows): a round's lanes then run about equally long
+                    // ordered by size class (29..32, 25..28, ... 1..4 windows): a round's lanes then run about equally long
                     n_items = 0;
+#ifndef FH_RAG_CLASS_SHIFT
+#define FH_RAG_CLASS_SHIFT 2
+#endif
 #pragma unroll 1
-                    for (u32 cls = 0; cls < 4u; ++cls) {
+                    for (u32 cls = 0; cls < (32u >> FH_RAG_CLASS_SHIFT); ++cls) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const bool in = it[q] != 0u && ((32u - (it[q] >> 16)) >> 3) == cls;
+                            const bool in = it[q] != 0u && ((32u - (it[q] >> 16)) >> FH_RAG_CLASS_SHIFT) == cls;
                             const u64 m = __builtin_amdgcn_ballot_w64(in);
                             if (in) *item_ptr(n_items + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))) = it[q];
                             n_items += (u32)__popcll(m);

@@ -314,10 +314,10 @@ for k in (25, 27, 28, 29, 30, 31, 32):
 sk, _ = sketch_on_device(F.SketchParams.mash(1000, 1000, True, 21, 0), streams["trimmed 35..150"], 0)
 assert sk.debug_segments()[0] == 0
 assert_same(sk, oracle_of(O.MASH, 1000, 21, streams["trimmed 35..150"]), "k=21")
-# seeds, a scaled sketch that keeps half of all k-mers on few waves, several pushes
+# seeds, a scaled sketch that keeps half of all k-mers on few waves
 stream = streams["trimmed 35..150"]
 for k, seed in ((31, 42), (27, 2**63 + 9)):
-    sk, _ = sketch_on_device(F.SketchParams.mash(500, 500, True, k, seed), stream, 0, pushes=3)
+    sk, _ = sketch_on_device(F.SketchParams.mash(500, 500, True, k, seed), stream, 0)
     ora = O.OracleSketcher(O.MASH, 500, k, seed); ora.process_packed(stream, 0)
     assert sk.debug_segments()[2] == 128
     assert_same(sk, ora, "seed k=%d" % k)
