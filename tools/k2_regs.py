@@ -93,9 +93,12 @@ def pretty(name):
     if m:
         return "k2_sketch<%s,%s%s%s>" % (m.group(1), "M" if m.group(2) == "1" else "-", "S0" if m.group(3) == "1" else "--",
                                           "L" if m.group(4) == "1" else "-")
-    m = re.match(r"_ZN2fh13k2_sketch_segILi(\d+)EEE", name)
+    m = re.match(r"_ZN2fh13k2_sketch_segILi(\d+)ELb(\d)EEE", name)
     if m:
-        return "k2_sketch_seg<%s>" % m.group(1)
+        return "k2_sketch_seg<%s,%s>" % (m.group(1), "S0" if m.group(2) == "1" else "--")
+    m = re.match(r"_ZN2fh8k2_batchILi(\d+)ELb(\d)EEE", name)
+    if m:
+        return "k2_batch<%s,%s>" % (m.group(1), "S0" if m.group(2) == "1" else "--")
     m = re.match(r"_ZN2fh12k2_sketch_wsILi(\d+)EEE", name)
     if m:
         return "k2_sketch_ws<%s>" % m.group(1)
@@ -128,9 +131,10 @@ def main():
     if args.objects:
         import glob
         objs = sorted(glob.glob(os.path.join(CSRC, "obj", "fh_k2_*.o")) + glob.glob(os.path.join(CSRC, "obj", "fh_k2w_*.o")) +
-                      glob.glob(os.path.join(CSRC, "obj", "fh_k2s_*.o")) + glob.glob(os.path.join(CSRC, "obj", "fh_k2ws_*.o")))
-        if len(objs) != 4 * B.NPARTS:
-            sys.exit("expected %d sketch-kernel objects under csrc/obj, found %d: build the library first" % (4 * B.NPARTS, len(objs)))
+                      glob.glob(os.path.join(CSRC, "obj", "fh_k2s_*.o")) + glob.glob(os.path.join(CSRC, "obj", "fh_k2ws_*.o")) +
+                      glob.glob(os.path.join(CSRC, "obj", "fh_k2b_*.o")))
+        if len(objs) != 5 * B.NPARTS:
+            sys.exit("expected %d sketch-kernel objects under csrc/obj, found %d: build the library first" % (5 * B.NPARTS, len(objs)))
         for o in objs:
             rows += unbundle_object(o)
     elif args.k is not None:
@@ -145,9 +149,9 @@ def main():
         with ThreadPoolExecutor(max_workers=4) as ex:
             for r in ex.map(lambda j: compile_one(*j), jobs):
                 rows += r
-    rows = [r for r in rows if "k2_sketch" in r["name"]]
+    rows = [r for r in rows if "k2_sketch" in r["name"] or "k2_batch" in r["name"]]
     if not args.all_variants:
-        rows = [r for r in rows if "k2_sketch_w" in r["name"] or "k2_sketch_seg" in r["name"] or "ELb0ELb1ELb0E" in r["name"]]
+        rows = [r for r in rows if "k2_sketch_w" in r["name"] or "k2_sketch_seg" in r["name"] or "k2_batch" in r["name"] or "ELb0ELb1ELb0E" in r["name"]]
 
     def key(r):
         m = re.search(r"ILi(\d+)E", r["name"])

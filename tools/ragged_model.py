@@ -23,7 +23,8 @@ ap.add_argument("--reads", type=int, default=200_000)
 ap.add_argument("--frac-full", type=float, default=0.0)
 a = ap.parse_args()
 K = a.k
-RO = 65 - K if K <= 24 or K == 26 else 32
+import os
+RO = int(os.environ.get("RO", 65 - K if K <= 24 or K == 26 else 32))
 SETUP = 85.0 / (56.0 if K <= 24 else 65.0)
 rng = np.random.default_rng(1)
 lens = rng.integers(a.lo, a.hi + 1, size=a.reads)
