@@ -7,6 +7,7 @@
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -2147,6 +2148,58 @@ static int fasta_text_to_device(ByteSource &src, fh_sketcher *h, FastxStats &st,
 // -> FH_OK (st: records, total_bases), FH_ERR_STATE = does not apply (nothing consumed), FH_ERR_INVALID = not plain 4-line
 // FASTQ (the caller rewinds and lets the parser that is the judge of that read it), or an error.
 static std::atomic<uint64_t> g_fastq_host_strip{0};
+
+// The threads of a memory-bound pass over a buffer run next to the buffer: the CPUs of the NUMA node the buffer's pages are on,
+// as far as the thread is allowed on them (a strip whose threads sit on the other socket runs at half the rate: 18-21 ms
+// against 11 for 1.26 GB of FASTQ text on a two-socket box).  Restored when the object goes.  Nothing happens if the node
+// cannot be told (no NUMA, no sysfs), or with the option no_numa_pin.
+struct NearMemory {
+    cpu_set_t want;
+    bool have = false;
+    explicit NearMemory(const void *addr) {
+        if (cfg("no_numa_pin")) return;
+        int node = -1;
+#ifdef SYS_get_mempolicy
+        if (syscall(SYS_get_mempolicy, &node, nullptr, 0UL, addr, 3UL /* MPOL_F_NODE | MPOL_F_ADDR */) != 0) node = -1;
+#endif
+        if (node < 0) return;
+        char path[96], list[4096] = {0};
+        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+        if (FILE *f = fopen(path, "r")) {
+            if (!fgets(list, (int)sizeof list, f)) list[0] = 0;
+            fclose(f);
+        }
+        cpu_set_t allowed;
+        if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+        CPU_ZERO(&want);
+        int n = 0;
+        for (char *p = list; *p;) { // "0-63,128-191"
+            char *e;
+            const long a = strtol(p, &e, 10);
+            if (e == p) break;
+            long b = a;
+            if (*e == '-') b = strtol(e + 1, &e, 10);
+            for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+                if (CPU_ISSET((int)c, &allowed)) {
+                    CPU_SET((int)c, &want);
+                    ++n;
+                }
+            if (*e != ',') break;
+            p = e + 1;
+        }
+        have = n >= 8; // (fewer CPUs than the strip has threads: better spread out)
+    }
+    struct Seat { // one thread's stay
+        cpu_set_t old;
+        bool moved = false;
+        explicit Seat(const NearMemory &m) {
+            if (m.have && sched_getaffinity(0, sizeof old, &old) == 0 && sched_setaffinity(0, sizeof m.want, &m.want) == 0) moved = true;
+        }
+        ~Seat() {
+            if (moved) (void)sched_setaffinity(0, sizeof old, &old);
+        }
+    };
+};
 static int fastq_host_strip_to_device(ByteSource &src, fh_sketcher *h, FastxStats &st) {
     const char *opt = cfg("fastq_host_strip"); // 0 = never, 1 = whatever the thread count (tests), default: from 8 read threads on
     if (opt && opt[0] == '0') return FH_ERR_STATE;
@@ -2191,7 +2244,9 @@ static int fastq_host_strip_to_device(ByteSource &src, fh_sketcher *h, FastxStat
     std::condition_variable wcv;
     bool ok = false;
     uint64_t m_out = 0, rec_out = 0, bases_out = 0;
+    const NearMemory near_text(text + n / 2);
     auto helper_main = [&](unsigned t) {
+        NearMemory::Seat seat(near_text);
         unsigned seen = 0;
         for (;;) {
             Work w;
@@ -2221,6 +2276,7 @@ static int fastq_host_strip_to_device(ByteSource &src, fh_sketcher *h, FastxStat
     std::string msg;
     auto pipeline = [&] { // the reader (a thread of its own: member 0 of the team) and, on this thread, the pushes
     std::thread producer([&] {
+        NearMemory::Seat seat(near_text);
         int slot = next;
         size_t off = 0;
         while (off < n && !abort) {
@@ -4099,12 +4155,23 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
     {
         std::vector<std::thread> th;
         th.reserve(n_threads);
+        // (no exception leaves a worker's thread -- that would be std::terminate in the caller's process: a worker that runs out
+        // of memory reports it as the error of the call)
+        std::atomic<bool> worker_threw{false};
+        auto guarded = [&](uint32_t w) {
+            try {
+                worker(w);
+            } catch (...) {
+                worker_threw = true;
+            }
+        };
         try {
-            for (uint32_t w = 0; w < n_threads; ++w) th.emplace_back(worker, w);
+            for (uint32_t w = 0; w < n_threads; ++w) th.emplace_back(guarded, w);
         } catch (...) { // fewer workers than asked for: the files are pulled from one queue, those that started take them all
         }
-        if (th.empty()) worker(0u);
+        if (th.empty()) guarded(0u);
         for (auto &t : th) t.join();
+        if (worker_threw) return hfail(FH_ERR_CAPACITY, "out of host memory");
     }
     if (first_err_code != FH_OK) return hfail(first_err_code, "%s", first_err_msg.c_str());
     *out = res.release();
