@@ -79,6 +79,9 @@ SYMBOLS = {
     "fh_batch_free": (None, [_P]),
     "fh_batch_stage": (C.c_int, [_P, C.c_int, C.POINTER(_P), _U64P]),
     "fh_batch_submit": (C.c_int, [_P, C.c_int, _P, _P, C.c_uint32]),
+    "fh_batch_submit_packed": (C.c_int, [_P, C.c_int, _P, _P, C.c_uint32]),
+    "fh_batch_packed_bytes": (C.c_uint64, [C.c_uint64]),
+    "fh_batch_pack": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64]),
     "fh_batch_wait": (C.c_int, [_P, C.c_int, _P]),
     "fh_batch_result": (C.c_int, [_P, C.c_int, C.c_uint32, _U64P, _U64P]),
     "fh_batch_copy_out": (C.c_int, [_P, C.c_int, C.c_uint32, _P, _P, _P, _P, _P]),

@@ -28,6 +28,8 @@
 #include "fh_device.h"
 #include "fh_internal.h"
 #include "fh_kernels.h"
+#include "fh_options.h"
+#include "fh_pack2.h"
 
 using namespace fh;
 
@@ -291,19 +293,24 @@ int fh_batch_stage(fh_batch *b, int slot, uint8_t **buf, uint64_t *cap) {
     return FH_OK;
 }
 
-int fh_batch_submit(fh_batch *b, int slot, const uint64_t *offsets, const uint64_t *lens, uint32_t n_files) try {
+static int batch_submit(fh_batch *b, int slot, const uint64_t *offsets, const uint64_t *lens, uint32_t n_files, bool two_bit) try {
     if (!b || slot < 0 || slot > 1 || (n_files && (!offsets || !lens))) return api_fail(FH_ERR_INVALID, "bad argument");
     fh_batch::Slot &s = b->slot[slot];
     if (s.in_flight) return api_fail(FH_ERR_STATE, "slot %d is in flight: fh_batch_wait first", slot);
     if (n_files > b->max_files) return api_fail(FH_ERR_INVALID, "%u files in a batch of at most %u", n_files, b->max_files);
     BHIP_TRY(hipSetDevice(b->device));
     BatchFile *hd = reinterpret_cast<BatchFile *>(s.h_stage);
-    uint64_t end = 0, tiles = 0, positions = 0;
+    uint64_t end = 0, tiles = 0, positions = 0, prev_end = 0;
     for (uint32_t f = 0; f < n_files; ++f) {
-        if ((offsets[f] & 15u) || offsets[f] > b->data_bytes || lens[f] > b->data_bytes - offsets[f])
-            return api_fail(FH_ERR_INVALID, "file %u: [%llu, +%llu) is not a 16-byte aligned range of the staging buffer", f,
-                            (unsigned long long)offsets[f], (unsigned long long)lens[f]);
-        if (f && offsets[f] < offsets[f - 1] + lens[f - 1]) return api_fail(FH_ERR_INVALID, "file %u overlaps file %u (offsets ascend)", f, f - 1);
+        // bytes the file occupies in the staging buffer: its stream, or its region in the two-bit form (fh_pack2.h)
+        if (two_bit && lens[f] > (1ull << 40)) return api_fail(FH_ERR_INVALID, "file %u: %llu positions", f, (unsigned long long)lens[f]);
+        const uint64_t bytes = two_bit ? fh_pack2::region_bytes(lens[f]) : lens[f];
+        const uint64_t align = two_bit ? 63u : 15u;
+        if ((offsets[f] & align) || offsets[f] > b->data_bytes || bytes > b->data_bytes - offsets[f])
+            return api_fail(FH_ERR_INVALID, "file %u: [%llu, +%llu) is not a %u-byte aligned range of the staging buffer", f,
+                            (unsigned long long)offsets[f], (unsigned long long)bytes, (unsigned)align + 1u);
+        if (f && offsets[f] < prev_end) return api_fail(FH_ERR_INVALID, "file %u overlaps file %u (offsets ascend)", f, f - 1);
+        prev_end = offsets[f] + bytes;
         const uint64_t n_tiles = (lens[f] + TILE_POS - 1) / TILE_POS;
         if (tiles + n_tiles > 0xFFFFFFF0ull) return api_fail(FH_ERR_INVALID, "batch too large");
         BatchFile &d = hd[f];
@@ -324,7 +331,7 @@ int fh_batch_submit(fh_batch *b, int slot, const uint64_t *offsets, const uint64
         s.len[f] = lens[f];
         tiles += n_tiles;
         positions += lens[f];
-        end = std::max(end, offsets[f] + lens[f]);
+        end = std::max(end, prev_end);
     }
     s.n_files = n_files;
     s.positions = positions;
@@ -344,6 +351,7 @@ int fh_batch_submit(fh_batch *b, int slot, const uint64_t *offsets, const uint64
         a.tiles_per_wave = (uint32_t)std::max<uint64_t>(1, (tiles + BATCH_MAX_WAVES - 1) / BATCH_MAX_WAVES);
         const uint64_t waves = ((tiles + a.tiles_per_wave - 1) / a.tiles_per_wave + wpb - 1) / wpb * wpb;
         a.seed = b->p.seed;
+        a.two_bit = two_bit ? 1u : 0u;
         if (b->profiling) BHIP_TRY(hipEventRecord(s.k0, b->stream));
         BHIP_TRY(launch_k2b((int)b->p.k, a, (uint32_t)waves, b->stream));
         if (b->profiling) BHIP_TRY(hipEventRecord(s.k1, b->stream));
@@ -354,6 +362,40 @@ int fh_batch_submit(fh_batch *b, int slot, const uint64_t *offsets, const uint64
     return FH_OK;
 } catch (...) {
     return api_fail(FH_ERR_CAPACITY, "out of host memory");
+}
+
+int fh_batch_submit(fh_batch *b, int slot, const uint64_t *offsets, const uint64_t *lens, uint32_t n_files) {
+    return batch_submit(b, slot, offsets, lens, n_files, false);
+}
+
+int fh_batch_submit_packed(fh_batch *b, int slot, const uint64_t *offsets, const uint64_t *lens, uint32_t n_files) {
+    return batch_submit(b, slot, offsets, lens, n_files, true);
+}
+
+uint64_t fh_batch_packed_bytes(uint64_t len) { return fh_pack2::region_bytes(len); }
+
+int fh_batch_pack(const uint8_t *stream, uint64_t len, uint8_t *region, uint64_t region_cap) {
+    if ((len && !stream) || !region) return api_fail(FH_ERR_INVALID, "bad argument");
+    if (len > (1ull << 40) || fh_pack2::region_bytes(len) > region_cap)
+        return api_fail(FH_ERR_CAPACITY, "%llu positions take %llu bytes in the two-bit form, the region has %llu", (unsigned long long)len,
+                        (unsigned long long)fh_pack2::region_bytes(len), (unsigned long long)region_cap);
+    const bool avx2 = fh_pack2::have_avx2() && !cfg_on("pack_scalar");
+    const uint64_t whole = len / 32;
+    fh_pack2::pack_groups(stream, (size_t)whole, region, 0, avx2);
+    uint64_t groups = whole;
+    if (len & 31u) {
+        uint8_t last[32] = {0};
+        memcpy(last, stream + 32 * whole, (size_t)(len & 31u));
+        fh_pack2::pack_groups(last, 1, region, groups++, avx2);
+    }
+    const uint64_t n_tiles = (len + TILE_POS - 1) / TILE_POS;
+    for (uint64_t g = groups; g < n_tiles * 64; ++g) {
+        uint8_t *const tile = region + (g >> 6) * fh_pack2::TILE_BYTES;
+        memset(tile + 8 * (g & 63), 0, 8);
+        memset(tile + fh_pack2::CODES_BYTES + 4 * (g & 63), 0, 4);
+    }
+    memset(region + n_tiles * fh_pack2::TILE_BYTES, 0, fh_pack2::TILE_BYTES);
+    return FH_OK;
 }
 
 int fh_batch_wait(fh_batch *b, int slot, uint8_t *status) {

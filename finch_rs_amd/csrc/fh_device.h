@@ -170,8 +170,9 @@ struct SketchArgs {
 // table partition and shard lists of its own; the batch's tiles form one tile space that the launch's waves cut into equal
 // contiguous stretches.
 struct BatchFile {
-    const uint8_t *seq;  // the file's packed stream (device), 16-byte aligned; bytes behind `len` are never read as sequence
-    uint64_t len;        // bytes = k-mer start positions
+    const uint8_t *seq;  // the file's packed stream (device), 16-byte aligned; bytes behind `len` are never read as sequence.
+                         // BatchArgs.two_bit: the file's region in the two-bit form (fh_pack2.h), 64-byte aligned
+    uint64_t len;        // k-mer start positions (= bytes of the packed stream)
     Ctl *ctl;            // the file's control block
     uint64_t tau;        // the one threshold the file is sketched at (EMPTY64: everything is admitted)
     uint32_t tile0;      // first tile of the file in the batch's tile space
@@ -179,8 +180,10 @@ struct BatchFile {
 };
 struct BatchArgs {
     const BatchFile *files;
-    uint32_t n_files, tiles_total, tiles_per_wave, pad;
+    uint32_t n_files, tiles_total, tiles_per_wave;
+    uint32_t two_bit; // 1: the files are staged in the two-bit form (768 bytes per tile: phase A is two loads)
     uint64_t seed;
 };
+constexpr uint32_t TWO_BIT_TILE_BYTES = 768, TWO_BIT_CODES_BYTES = 512;
 
 } // namespace fh

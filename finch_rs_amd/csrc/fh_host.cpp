@@ -36,6 +36,7 @@
 #include "fh_pargz.h"
 #include "fh_strip.h"
 #include "fh_fqstrip.h"
+#include "fh_pack2.h"
 
 // job(t) for t = 0 .. n - 1, one thread each (the caller's runs job(0)).  A thread that cannot be created (EAGAIN under a
 // thread limit) must not take the process down -- a vector of joinable threads that unwinds calls std::terminate -- so its
@@ -125,6 +126,8 @@ private:
 
 namespace finch {
 using fh::cfg;
+using fh::cfg_on;
+using fh::cfg_u64;
 
 thread_local std::string g_host_err;
 
@@ -2711,6 +2714,74 @@ static bool pack_fasta_text(const uint8_t *raw, size_t n, uint8_t *dst, size_t c
     return true;
 }
 
+// The same walk with the sequence leaving in the batch sketcher's two-bit form (fh_pack2.h), and piece by piece: the worker
+// reads a file in pieces the core's L2 keeps and hands each on while it is there, so a genome's text is never written to
+// memory and read back (16 workers doing that moved four times the bytes the link does).  `region` has room for
+// fh_pack2::region_bytes(bytes of the file): a file never has more positions than bytes, a record's breaker stands where
+// its header stood.
+struct FastaTwoBit {
+    fh_pack2::Packer &pk;
+    FastxStats &st;
+    bool in_header = true;      // the text begins with a header line (the caller has seen its '>')
+    bool at_line_start = false; // the byte in front of the next piece was a line end
+    uint64_t region_len = 0;    // bytes of the current record's sequence region so far
+    uint8_t last1 = 0, last2 = 0; // ... its last and second-to-last byte
+    FastaTwoBit(fh_pack2::Packer &p, FastxStats &s, uint8_t *region) : pk(p), st(s) { pk.begin(region); }
+    void close_record() {
+        uint64_t trim = 0; // one trailing line end is not sequence (parse_fastx: the region ends in front of it)
+        if (region_len >= 1 && last1 == '\n') trim = (region_len >= 2 && last2 == '\r') ? 2 : 1;
+        else if (region_len >= 1 && last1 == '\r') trim = 1;
+        st.total_bases += region_len - trim;
+        st.n_records++;
+        pk.byte(0); // the record's breaker
+        region_len = 0; // (a header line the text ends in is a record of no bases)
+    }
+    void piece(const uint8_t *p, size_t n) {
+        const uint8_t *const e = p + n;
+        while (p < e) {
+            if (in_header) {
+                const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(e - p));
+                if (!nl) return; // (the header goes on in the next piece; at_line_start is not looked at inside one)
+                p = nl + 1;
+                in_header = false;
+                at_line_start = true;
+                region_len = 0;
+                continue;
+            }
+            // the sequence region runs to the next '>' at a line start
+            const uint8_t *stop = e;
+            bool header = false;
+            for (const uint8_t *q = p; q < e;) {
+                const uint8_t *g = (const uint8_t *)memchr(q, '>', (size_t)(e - q));
+                if (!g) break;
+                if (g == p ? at_line_start : g[-1] == '\n') {
+                    stop = g;
+                    header = true;
+                    break;
+                }
+                q = g + 1;
+            }
+            const size_t len = (size_t)(stop - p);
+            if (len) {
+                pk.text(p, len);
+                last2 = len >= 2 ? stop[-2] : last1;
+                last1 = stop[-1];
+                region_len += len;
+                at_line_start = last1 == '\n';
+            }
+            p = stop;
+            if (header) {
+                close_record();
+                in_header = true;
+            }
+        }
+    }
+    uint64_t finish() { // -> positions
+        close_record(); // (a header line without a sequence region behind it is a record of no bases)
+        return pk.finish();
+    }
+};
+
 // A plain FASTA file that fits the staging buffer twice over (a genome of a batch: configs[4]) is packed on the HOST, in
 // one pass, while it is staged: the file is read into the upper part of the sketcher's pinned staging buffer and its
 // sequence regions are copied to the front without their blanks (fh_strip.h), one breaker byte per record -- the packed
@@ -3879,6 +3950,22 @@ int finch_fastq_strip_probe(const uint8_t *text, uint64_t len, uint32_t threads,
     return FH_OK;
 } FINCH_CATCH
 
+// test hook: FASTA text through the workers' piecewise walk into the batch sketcher's two-bit form (FastaTwoBit), `piece` bytes at a time
+int finch_fasta_two_bit_probe(const uint8_t *text, uint64_t len, uint64_t piece, uint8_t *region, uint64_t cap, uint64_t *positions,
+                              uint64_t *n_records, uint64_t *total_bases) try {
+    if (!text || len < 1 || text[0] != '>' || piece < 1 || !region || !positions || !n_records || !total_bases) return hfail(FH_ERR_INVALID, "bad argument");
+    if (cap < fh_pack2::region_bytes(len)) return hfail(FH_ERR_INVALID, "the region needs fh_batch_packed_bytes(len) bytes");
+    std::unique_ptr<fh_pack2::Packer> pk(new fh_pack2::Packer);
+    if (cfg_on("pack_scalar")) pk->avx2 = false;
+    finch::FastxStats st;
+    finch::FastaTwoBit walk(*pk, st, region);
+    for (uint64_t o = 0; o < len; o += piece) walk.piece(text + o, (size_t)std::min<uint64_t>(piece, len - o));
+    *positions = walk.finish();
+    *n_records = st.n_records;
+    *total_bases = st.total_bases;
+    return FH_OK;
+} FINCH_CATCH
+
 void finch_debug_file_batch(uint64_t *taken, uint64_t *not_taken) {
     if (taken) *taken = finch::g_batch_taken.load();
     if (not_taken) *not_taken = finch::g_batch_not_taken.load();
@@ -3974,6 +4061,7 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
                           filters->filter_on <= 0 && file_batch_enabled();
     constexpr uint64_t GROUP_STAGE = 32ull << 20;
     constexpr uint32_t GROUP_FILES = 64;
+    const size_t READ_PIECE = std::max<uint64_t>(4096, cfg_u64("batch_read_piece", 256u << 10)); // bytes of a file read and packed at a time
     auto worker = [&](uint32_t w) {
         HandleSet handles;
         handles.full = to_fh(*sp, batch ? ml : single_ml, batch ? (16ull << 20) : single_stage);
@@ -4015,13 +4103,22 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
         uint8_t *stage[2] = {nullptr, nullptr};
         uint64_t stage_cap = 0;
         std::vector<uint8_t> raw; // a file's text as read
+        const bool two_bit = !(cfg("batch_two_bit") && cfg("batch_two_bit")[0] == '0'); // how a group's files cross the link
+        std::unique_ptr<fh_pack2::Packer> packer;
         std::vector<uint8_t> status;
+        static const bool trace = cfg("trace") != nullptr;
+        auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t_read = 0, t_pack = 0, t_submit = 0, t_wait = 0, t_collect = 0;
+        const double t_worker0 = now_s();
         auto collect = [&](int slot) { // wait for the group in `slot`, turn its results into Sketches
             Group &g = grp[slot];
             if (!g.in_flight) return;
             g.in_flight = false;
             status.assign(g.idx.size() + 1, 1);
+            const double w0 = trace ? now_s() : 0;
             int rc = fh_batch_wait(bt, slot, status.data());
+            const double w1 = trace ? now_s() : 0;
+            t_wait += w1 - w0;
             for (size_t j = 0; j < g.idx.size(); ++j) {
                 const uint32_t i = g.idx[j];
                 if (rc != FH_OK || status[j] != 0) { // not taken (or the batch failed as a whole): the long way, which is exact for anything
@@ -4063,11 +4160,16 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
             g.len.clear();
             g.st.clear();
             g.fill = 0;
+            if (trace) t_collect += now_s() - w1;
         };
         auto submit_cur = [&]() { // hand the current group to the device, go on in the other slot (its previous group collected)
             Group &g = grp[cur];
             if (g.idx.empty()) return;
-            if (fh_batch_submit(bt, cur, g.off.data(), g.len.data(), (uint32_t)g.idx.size()) != FH_OK) {
+            const double s0 = trace ? now_s() : 0;
+            const int src = two_bit ? fh_batch_submit_packed(bt, cur, g.off.data(), g.len.data(), (uint32_t)g.idx.size())
+                                    : fh_batch_submit(bt, cur, g.off.data(), g.len.data(), (uint32_t)g.idx.size());
+            if (trace) t_submit += now_s() - s0;
+            if (src != FH_OK) {
                 for (uint32_t i : g.idx) through_sketcher(i);
                 g.idx.clear(), g.off.clear(), g.len.clear(), g.st.clear();
                 g.fill = 0;
@@ -4104,29 +4206,68 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
                 }
                 if (g_ktimes_on.load(std::memory_order_relaxed)) fh_batch_set_profiling(bt, 1);
             }
-            if (grp[cur].idx.size() >= GROUP_FILES || grp[cur].fill + size + 64 > stage_cap) submit_cur();
-            if (raw.size() < size + 64) raw.resize(size + 64 + (size >> 2));
-            size_t got = 0;
-            while (got < size) {
-                const ssize_t r = pread(fd, raw.data() + got, size - got, (off_t)got);
-                if (r <= 0) break;
-                got += (size_t)r;
-            }
-            // one byte more than fstat said = the file grew: not for this path
-            uint8_t extra;
-            const bool grew = got == size && pread(fd, &extra, 1, (off_t)size) > 0;
-            close(fd);
-            if (got != size || grew || raw[0] != '>') return false;
+            const uint64_t room_needed = two_bit ? fh_pack2::region_bytes(size) + 64 : (uint64_t)size + 64;
+            if (grp[cur].idx.size() >= GROUP_FILES || grp[cur].fill + room_needed > stage_cap) submit_cur();
             Group &g = grp[cur];
             FastxStats st;
             st.format = 1;
             size_t m = 0;
-            if (!pack_fasta_text(raw.data(), size, stage[cur] + g.fill, (size_t)(stage_cap - g.fill), st, m)) return false;
+            uint64_t occupied;
+            const double r0 = trace ? now_s() : 0;
+            double r1 = r0;
+            if (two_bit) {
+                // piece by piece: read, strip, pack while the piece is in the core's cache
+                if (!packer) {
+                    packer.reset(new fh_pack2::Packer);
+                    if (cfg_on("pack_scalar")) packer->avx2 = false;
+                }
+                if (raw.size() < READ_PIECE + 64) raw.resize(READ_PIECE + 64);
+                FastaTwoBit walk(*packer, st, stage[cur] + g.fill);
+                size_t got = 0;
+                bool bad = false;
+                while (got < size) {
+                    const double p0 = trace ? now_s() : 0;
+                    const ssize_t r = pread(fd, raw.data(), std::min<size_t>(READ_PIECE, size - got), (off_t)got);
+                    if (r <= 0 || (got == 0 && raw[0] != '>')) {
+                        bad = true;
+                        break;
+                    }
+                    const double p1 = trace ? now_s() : 0;
+                    walk.piece(raw.data(), (size_t)r);
+                    got += (size_t)r;
+                    if (trace) t_read += p1 - p0, t_pack += now_s() - p1;
+                }
+                // one byte more than fstat said = the file grew: not for this path (its region is abandoned: g.fill stays)
+                uint8_t extra;
+                const bool grew = !bad && pread(fd, &extra, 1, (off_t)size) > 0;
+                close(fd);
+                if (bad || grew) return false;
+                m = (size_t)walk.finish();
+                occupied = fh_pack2::region_bytes(m);
+                r1 = trace ? now_s() : 0;
+            } else {
+                if (raw.size() < size + 64) raw.resize(size + 64 + (size >> 2));
+                size_t got = 0;
+                while (got < size) {
+                    const ssize_t r = pread(fd, raw.data() + got, size - got, (off_t)got);
+                    if (r <= 0) break;
+                    got += (size_t)r;
+                }
+                uint8_t extra;
+                const bool grew = got == size && pread(fd, &extra, 1, (off_t)size) > 0;
+                close(fd);
+                if (got != size || grew || raw[0] != '>') return false;
+                r1 = trace ? now_s() : 0;
+                t_read += r1 - r0;
+                if (!pack_fasta_text(raw.data(), size, stage[cur] + g.fill, (size_t)(stage_cap - g.fill), st, m)) return false;
+                occupied = m;
+            }
             g.idx.push_back(i);
             g.off.push_back(g.fill);
             g.len.push_back(m);
             g.st.push_back(st);
-            g.fill = (g.fill + m + 15) & ~15ull;
+            g.fill = (g.fill + occupied + 63) & ~63ull;
+            if (trace) t_pack += now_s() - r1;
             return true;
         };
         for (;;) {
@@ -4149,6 +4290,9 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
             }
             uint64_t tk = 0, nt = 0;
             if (fh_batch_counters(bt, &tk, &nt) == FH_OK) g_batch_taken += tk, g_batch_not_taken += nt;
+            if (trace && w == 0)
+                fprintf(stderr, "[finch] worker 0 of a batch: %.1f ms in all: reading %.1f, packing %.1f, submits %.1f, waiting for the device %.1f, results %.1f ms (%llu files taken)\n",
+                        (now_s() - t_worker0) * 1e3, t_read * 1e3, t_pack * 1e3, t_submit * 1e3, t_wait * 1e3, t_collect * 1e3, (unsigned long long)tk);
             fh_batch_free(bt);
         }
     };

@@ -61,6 +61,17 @@ __device__ __forceinline__ void classify_tile_b(const uint8_t *seq, u64 len, u64
     good_ring[par * 64u + (u32)lane] = g0 | (g1 << 16);
 }
 
+// ... and of a file staged in the two-bit form (fh_pack2.h): the host has done the classification, a tile is the 512 bytes of
+// codes and 256 bytes of base bits phase A would have produced, lane by lane; the tile behind a file's last is zeroes
+__device__ __forceinline__ void load_tile_two_bit(const uint8_t *region, u64 tile, int lane, u32 *codes_ring, u32 *good_ring) {
+    const uint8_t *const tb = region + tile * (u64)TWO_BIT_TILE_BYTES; // wave-uniform
+    const uint2 q = *reinterpret_cast<const uint2 *>(tb + 8u * (u32)lane);
+    const u32 g = *reinterpret_cast<const u32 *>(tb + TWO_BIT_CODES_BYTES + 4u * (u32)lane);
+    const u32 par = (u32)(tile & 1u);
+    *reinterpret_cast<uint2 *>(&codes_ring[par * 128u + 2u * (u32)lane]) = q;
+    good_ring[par * 64u + (u32)lane] = g;
+}
+
 template <int K, bool SEED0>
 __global__ __launch_bounds__(64 * k2_wpb_of(K), k2_min_waves(K)) void k2_batch(const BatchArgs a) {
     constexpr int WPB = k2_wpb_of(K), NTHR = 64 * WPB, REP = k2_a1_rep(K);
@@ -140,9 +151,12 @@ __global__ __launch_bounds__(64 * k2_wpb_of(K), k2_min_waves(K)) void k2_batch(c
         u32 nvalid = 0; // per lane
         u32 qn = 0;     // occupancy of the admit queue (wave-uniform)
 
-        classify_tile_b(f_seq, f_len, rt0, lane, codes_ring, good_ring);
+        if (a.two_bit) load_tile_two_bit(f_seq, rt0, lane, codes_ring, good_ring);
+        else classify_tile_b(f_seq, f_len, rt0, lane, codes_ring, good_ring);
         for (u64 tt = rt0; tt < rt1; ++tt) {
-            classify_tile_b(f_seq, f_len, tt + 1, lane, codes_ring, good_ring); // also provides the halo of lane 63
+            // (the tile behind: it also provides the halo of lane 63)
+            if (a.two_bit) load_tile_two_bit(f_seq, tt + 1, lane, codes_ring, good_ring);
+            else classify_tile_b(f_seq, f_len, tt + 1, lane, codes_ring, good_ring);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

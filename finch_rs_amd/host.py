@@ -113,6 +113,8 @@ _SYMS = {
     "finch_debug_fastq_host_strip": (C.c_uint64, []),
     "finch_fastq_strip_probe": (C.c_int, [_P, C.c_uint64, C.c_uint32, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                           C.POINTER(C.c_uint64)]),
+    "finch_fasta_two_bit_probe": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_uint64)]),
     "finch_gzip_probe": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_uint64),
                                    C.POINTER(C.c_uint32)]),
     "finch_bgzf_batch_probe": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _P, C.c_uint64, C.POINTER(C.c_uint64),
@@ -443,6 +445,17 @@ def fastq_strip_probe(text: bytes, threads: int):
     m, nr, nb = C.c_uint64(), C.c_uint64(), C.c_uint64()
     _check(lib().finch_fastq_strip_probe(src.ctypes.data, len(text), threads, out.ctypes.data, len(out), C.byref(m), C.byref(nr), C.byref(nb)))
     return out[:m.value].tobytes(), nr.value, nb.value
+
+
+def fasta_two_bit_probe(text: bytes, piece: int):
+    """-> (region, positions, records, total_bases): FASTA text through the workers' piecewise walk into the two-bit form"""
+    src = np.frombuffer(text, dtype=np.uint8)
+    cap = ((len(text) + 2047) // 2048 + 1) * 768
+    region = np.full(cap + 64, 0xA5, dtype=np.uint8)
+    m, nr, nb = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    _check(lib().finch_fasta_two_bit_probe(src.ctypes.data, len(text), piece, region.ctypes.data, cap, C.byref(m), C.byref(nr), C.byref(nb)))
+    assert np.all(region[cap:] == 0xA5)
+    return region[:((m.value + 2047) // 2048 + 1) * 768], m.value, nr.value, nb.value
 
 
 def debug_fastq_host_strip() -> int:

@@ -261,10 +261,20 @@ class BatchSketcher:
         check(self._L.fh_batch_stage(self._h, slot, C.byref(buf), C.byref(cap)))
         return np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(cap.value,))
 
-    def submit(self, slot: int, offsets, lens) -> None:
+    def submit(self, slot: int, offsets, lens, two_bit: bool = False) -> None:
         o = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = np.ascontiguousarray(lens, dtype=np.uint64)
-        check(self._L.fh_batch_submit(self._h, slot, o.ctypes.data, n.ctypes.data, len(o)))
+        fn = self._L.fh_batch_submit_packed if two_bit else self._L.fh_batch_submit
+        check(fn(self._h, slot, o.ctypes.data, n.ctypes.data, len(o)))
+
+    def packed_bytes(self, n_positions: int) -> int:
+        """bytes a file of n_positions occupies in the two-bit form (fh_batch_submit_packed)"""
+        return int(self._L.fh_batch_packed_bytes(n_positions))
+
+    def pack(self, block: np.ndarray, region: np.ndarray) -> None:
+        """write a packed byte stream's two-bit form into `region` (a slice of the staging buffer)"""
+        block = np.ascontiguousarray(block, dtype=np.uint8)
+        check(self._L.fh_batch_pack(block.ctypes.data, len(block), region.ctypes.data, len(region)))
 
     def wait(self, slot: int, n_files: int) -> np.ndarray:
         st = np.zeros(max(n_files, 1), dtype=np.uint8)
@@ -286,23 +296,30 @@ class BatchSketcher:
         assert np.array_equal(hs, kc["hash"]) and np.array_equal(cs, kc["count"]) and np.array_equal(es, kc["extra_count"]) and np.array_equal(km, km2)
         return kc, km, ps, tk.value
 
-    def sketch_many(self, blocks, slot: int = 0):
-        """blocks: packed streams (bytes / uint8 arrays) -> list of result tuples / None, in order; as many batches as it takes"""
+    def sketch_many(self, blocks, slot: int = 0, two_bit: bool = False):
+        """blocks: packed streams (bytes / uint8 arrays) -> list of result tuples / None, in order; as many batches as it takes.
+        two_bit: stage every block in the two-bit form (0.375 bytes per position on the link)"""
         out = []
         buf = self.stage(slot)
         i = 0
         blocks = [np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b for b in blocks]
         while i < len(blocks):
             offs, lens, pos = [], [], 0
-            while i < len(blocks) and len(offs) < self.max_files and pos + len(blocks[i]) <= len(buf):
-                buf[pos:pos + len(blocks[i])] = blocks[i]
+            while i < len(blocks) and len(offs) < self.max_files:
+                need = self.packed_bytes(len(blocks[i])) if two_bit else len(blocks[i])
+                if pos + need > len(buf):
+                    break
+                if two_bit:
+                    self.pack(blocks[i], buf[pos:pos + need])
+                else:
+                    buf[pos:pos + need] = blocks[i]
                 offs.append(pos)
                 lens.append(len(blocks[i]))
-                pos = (pos + len(blocks[i]) + 15) & ~15
+                pos = (pos + need + 63) & ~63
                 i += 1
             if not offs:
                 raise ValueError("block %d does not fit the staging buffer" % i)
-            self.submit(slot, offs, lens)
+            self.submit(slot, offs, lens, two_bit)
             st = self.wait(slot, len(offs))
             out += [self.result(slot, j) if st[j] == 0 else None for j in range(len(offs))]
         return out

@@ -66,7 +66,7 @@ typedef struct fh_sketcher fh_sketcher;
 /* number of visible HIP devices (0 if none / runtime unusable) */
 int fh_device_count(void);
 const char *fh_last_error(void);
-/* library/ABI version, bumped on any change of this header's functions (5: the batch sketcher, fh_set_option; the round-5
+/* library/ABI version, bumped on any change of this header's functions (5: the batch sketcher with its two-bit input form, fh_set_option; the round-5
  * additions fh_set_record_stride, fh_debug_segments, fh_process_records_in, fh_debug_add_counts, fh_debug_gzip_feed_timeouts) */
 #define FH_ABI_VERSION 5
 int fh_abi_version(void);
@@ -329,6 +329,17 @@ int fh_sketch_device_blocks(fh_sketcher *const *handles, const void *const *dev_
  *                                                          fh_sketcher, which handles all of that.  Never an approximate
  *                                                          sketch: a taken file's hashes, counts and k-mer bytes are the
  *                                                          reference's (mash.rs:34-63, 86-102), bit for bit.
+ *   fh_batch_submit_packed(b, slot, offsets, lens, n)      the same with every file staged in the TWO-BIT form: 0.375 bytes
+ *                                                          per position on the link instead of 1 (the link is what bounds a
+ *                                                          batch of genomes).  File i occupies fh_batch_packed_bytes(lens[i])
+ *                                                          bytes at the 64-byte aligned offsets[i]; lens[i] = its positions.
+ *                                                          Per tile of 2048 positions 768 bytes: 64 little-endian u64 of codes
+ *                                                          (position 32 g + i of the tile at bits [2 i, 2 i + 2) of word g:
+ *                                                          A 0, C 1, G 2, T/U 3, either case) and 64 u32 of "is a base" bits
+ *                                                          (bit i of word g; clear = the byte breaks k-mers, as every byte
+ *                                                          but ACGTUacgtu and every record's breaker does); positions behind
+ *                                                          the file's last are zero and one all-zero tile follows the last.
+ *                                                          fh_batch_pack writes that form from a packed byte stream.
  * The two slots alternate: fill slot 1 while slot 0 is in flight.  A batch handle is single-threaded like an fh_sketcher;
  * different handles are independent (one per worker thread). */
 typedef struct fh_batch fh_batch;
@@ -336,6 +347,9 @@ fh_batch *fh_batch_new(const fh_params *params, int device, uint32_t max_files, 
 void fh_batch_free(fh_batch *b);
 int fh_batch_stage(fh_batch *b, int slot, uint8_t **buf, uint64_t *cap);
 int fh_batch_submit(fh_batch *b, int slot, const uint64_t *offsets, const uint64_t *lens, uint32_t n_files);
+int fh_batch_submit_packed(fh_batch *b, int slot, const uint64_t *offsets, const uint64_t *lens, uint32_t n_files);
+uint64_t fh_batch_packed_bytes(uint64_t len);
+int fh_batch_pack(const uint8_t *stream, uint64_t len, uint8_t *region, uint64_t region_cap);
 int fh_batch_wait(fh_batch *b, int slot, uint8_t *status);
 /* file i of the batch last waited for in `slot`: hashes retained and valid k-mers seen (mash.rs:35); then the sketch,
  * ascending by hash, as fh_copy_out / fh_copy_out_records deliver it (any pointer may be NULL) */

@@ -218,6 +218,12 @@ uint64_t finch_debug_fastq_host_strip(void);
 int finch_fastq_strip_probe(const uint8_t *text, uint64_t len, uint32_t threads, uint8_t *out, uint64_t cap, uint64_t *packed,
                             uint64_t *n_records, uint64_t *total_bases);
 
+/* test hook: FASTA text (text[0] == '>') through the walk a worker of finch_sketch_files stages a genome with -- read in pieces,
+ * line ends stripped, records closed by a breaker, written in the batch sketcher's two-bit form (finch_hip.h
+ * fh_batch_submit_packed) -- `piece` bytes at a time; region: cap >= fh_batch_packed_bytes(len) */
+int finch_fasta_two_bit_probe(const uint8_t *text, uint64_t len, uint64_t piece, uint8_t *region, uint64_t cap, uint64_t *positions,
+                              uint64_t *n_records, uint64_t *total_bases);
+
 #ifdef __cplusplus
 }
 #endif

@@ -227,6 +227,20 @@ def test_sketch_files_groups_match_the_oracle_and_the_one_by_one_path(tmp_path, 
         assert a.filter_params == b.filter_params and a.sketch_params == b.sketch_params, i
         if i < len(datas) - 2:
             _same_as_oracle(a, d, 1000, 21)
+    # the groups with bytes on the link instead of the two-bit form (fh_batch_submit_packed is the default), and the two-bit
+    # form written by the packer's portable code: the same sketches, the same files taken
+    # ... and the files read in pieces of 4099 and 5000 bytes (header lines, line ends and CR LF pairs cut by piece ends)
+    for opts in (dict(batch_two_bit="0"), dict(pack_scalar="1"), dict(batch_read_piece="4099"), dict(batch_read_piece="5000")):
+        F.debug_set(file_batch=None, **opts)
+        t2, n2 = H.debug_file_batch()
+        alt = H.sketch_files(paths, params, H.FilterParams(None), n_threads=3)
+        t3, n3 = H.debug_file_batch()
+        assert (t3 - t2, n3 - n2) == (t1 - t0, n1 - n0), opts
+        for i in range(len(datas)):
+            a, b = res.sketch(i), alt.sketch(i)
+            assert np.array_equal(a.arrays[0], b.arrays[0]) and np.array_equal(a.arrays[1], b.arrays[1]), (opts, i)
+            assert (a.seq_length, a.num_valid_kmers) == (b.seq_length, b.num_valid_kmers), (opts, i)
+        F.debug_set(**{k: None for k in opts})
     # strict mode: the file with 680 k-mers is the reference's error (mod.rs:123-125), whichever path took it
     F.debug_set(file_batch=None)
     with pytest.raises(FinchError, match="had too few kmers \\(680\\) to sketch"):
