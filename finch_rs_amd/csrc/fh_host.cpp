@@ -3956,7 +3956,7 @@ int finch_fasta_two_bit_probe(const uint8_t *text, uint64_t len, uint64_t piece,
     if (!text || len < 1 || text[0] != '>' || piece < 1 || !region || !positions || !n_records || !total_bases) return hfail(FH_ERR_INVALID, "bad argument");
     if (cap < fh_pack2::region_bytes(len)) return hfail(FH_ERR_INVALID, "the region needs fh_batch_packed_bytes(len) bytes");
     std::unique_ptr<fh_pack2::Packer> pk(new fh_pack2::Packer);
-    if (cfg_on("pack_scalar")) pk->avx2 = false;
+    pk->force_form((unsigned)cfg_u64("pack_scalar", 0));
     finch::FastxStats st;
     finch::FastaTwoBit walk(*pk, st, region);
     for (uint64_t o = 0; o < len; o += piece) walk.piece(text + o, (size_t)std::min<uint64_t>(piece, len - o));
@@ -4219,7 +4219,7 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
                 // piece by piece: read, strip, pack while the piece is in the core's cache
                 if (!packer) {
                     packer.reset(new fh_pack2::Packer);
-                    if (cfg_on("pack_scalar")) packer->avx2 = false;
+                    packer->force_form((unsigned)cfg_u64("pack_scalar", 0));
                 }
                 if (raw.size() < READ_PIECE + 64) raw.resize(READ_PIECE + 64);
                 FastaTwoBit walk(*packer, st, stage[cur] + g.fill);

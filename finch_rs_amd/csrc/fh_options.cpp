@@ -77,7 +77,7 @@ const OptDef DEFS[] = {
     {"file_batch", "0 = every file of a finch_sketch_files batch through a sketcher of its own (no many-per-launch groups)"},
     {"batch_two_bit", "0 = a group's files cross the link as bytes, not in the two-bit form (fh_batch_submit_packed)"},
     {"batch_read_piece", "bytes of a file a worker reads and packs at a time (default 256 KiB: stays in the core's L2; tests: many pieces)"},
-    {"pack_scalar", "1 = the two-bit packer's portable form even where AVX2 is there (tests)"},
+    {"pack_scalar", "the two-bit packer's form (tests): 1 = portable, 2 = two passes with AVX2 (no BMI2); default: one pass with AVX2 + BMI2 where the CPU has them"},
     // --- FASTQ text in host memory ---
     {"fastq_host_strip", "0 = FASTQ text always goes to the device-side splitter; 1 = stripped on the host whatever the read threads (default: from 8 read threads on)"},
     {"fastq_strip_chunk", "bytes of text per chunk of the host-side FASTQ strip (tests: many chunks)"},

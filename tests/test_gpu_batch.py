@@ -230,7 +230,7 @@ def test_sketch_files_groups_match_the_oracle_and_the_one_by_one_path(tmp_path, 
     # the groups with bytes on the link instead of the two-bit form (fh_batch_submit_packed is the default), and the two-bit
     # form written by the packer's portable code: the same sketches, the same files taken
     # ... and the files read in pieces of 4099 and 5000 bytes (header lines, line ends and CR LF pairs cut by piece ends)
-    for opts in (dict(batch_two_bit="0"), dict(pack_scalar="1"), dict(batch_read_piece="4099"), dict(batch_read_piece="5000")):
+    for opts in (dict(batch_two_bit="0"), dict(pack_scalar="1"), dict(pack_scalar="2"), dict(batch_read_piece="4099"), dict(batch_read_piece="5000")):
         F.debug_set(file_batch=None, **opts)
         t2, n2 = H.debug_file_batch()
         alt = H.sketch_files(paths, params, H.FilterParams(None), n_threads=3)

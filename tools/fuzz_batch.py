@@ -60,7 +60,8 @@ def main():
         nf = int(rng.integers(1, 40))
         blocks = [make_file(rng) for _ in range(nf)]
         b = F.BatchSketcher(n, k, seed, max_files=int(rng.choice([1, 3, 8, 64])), stage_bytes=int(rng.choice([1 << 20, 4 << 20])))
-        res = b.sketch_many(blocks, slot=int(rng.integers(0, 2)))
+        two_bit = bool(rng.integers(0, 2))  # the link carries bytes, or the two-bit form (fh_batch_submit_packed)
+        res = b.sketch_many(blocks, slot=int(rng.integers(0, 2)), two_bit=two_bit)
         batches += 1
         for i, (r, blk) in enumerate(zip(res, blocks)):
             ora = O.OracleSketcher(O.MASH, n, k, seed)

@@ -21,4 +21,5 @@ echo "== fuzz_params" >> $O; timeout 600 python tools/fuzz_params.py 2>&1 | tail
 echo "== fuzz_device_text" >> $O; timeout 600 python tools/fuzz_device_text.py 2>&1 | tail -3 >> $O
 echo "== fuzz_gzip" >> $O; timeout 600 python tools/fuzz_gzip.py 2>&1 | tail -3 >> $O
 echo "== fuzz_batch" >> $O; timeout 900 python tools/fuzz_batch.py 2500 ${SO}7 2>&1 | tail -3 >> $O
+echo "== fuzz_files" >> $O; timeout 900 python tools/fuzz_files.py 2500 ${SO}9 2>&1 | tail -3 >> $O
 cat $O
