@@ -149,23 +149,39 @@ def _h2d_peak_gbs(dev=0, mib=32, reps=16):
         return None
 
 
-def c5_roofline(kernel_ms, launches, positions, wall_ms, n_gpus, batch=None, live=None, h2d=None):
+def c5_roofline(kernel_ms, launches, positions, wall_ms, n_gpus, batch=None, live=None, h2d=None, text_bytes=None):
     """the batch's roofline block: the sketch kernel over ALL files (sum of its launches' HIP-event times on the workers'
-    streams, finch_debug_kernel_times) against the HBM peak, how much of the call the GPU spent in it, and what binds the call:
-    the packed sequence bytes that cross the PCIe link (1 per k-mer start position) against the link's measured rate"""
+    streams, finch_debug_kernel_times) against the HBM peak -- algorithmic bytes as SURVEY 8d counts them, 1 per k-mer start
+    position --, how much of the call the GPU spent in it, and what the call's other two resources did: the bytes that cross the
+    PCIe link (0.375 per position in the two-bit form the workers stage the files in, 1 with option batch_two_bit=0) against
+    the link's measured rate, and the 16 host cores that read and pack the files"""
+    import finch_rs_amd as F
+    two_bit = F.get_option("batch_two_bit") != "0"
+    per_pos = 0.375 if two_bit else 1.0
     ach = positions / 1e9 / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
-    link = positions / 1e9 / (wall_ms / 1e3) / max(n_gpus, 1) if wall_ms > 0 else 0.0
+    link = per_pos * positions / 1e9 / (wall_ms / 1e3) / max(n_gpus, 1) if wall_ms > 0 else 0.0
     out = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
            "traffic": None if not live else round(live["hbm_bytes_per_position"] * positions / max(launches, 1), 1),
            "kernel": "k2_batch<21> (fh_k2b.hip: the files a worker has staged, sketched by ONE launch; finished by one k_batch_epilogue "
                      "launch, a workgroup per file)", "launches": int(launches),
            "avg_launch_ms": round(kernel_ms / max(launches, 1), 4), "alg_bytes_per_launch": int(positions / max(launches, 1)),
+           "input_bytes_per_position_in_hbm": per_pos,
            "kernel_ms_total": round(kernel_ms, 3), "call_ms_total": round(wall_ms, 3),
            "kernel_share_of_call": round(kernel_ms / max(wall_ms * n_gpus, 1e-9), 4),
            "pcie": {"h2d_peak_gbs": h2d, "achieved_gbs": round(link, 2), "frac": round(link / h2d, 3) if h2d else None,
-                    "bytes": "the files' packed streams, 1 byte per k-mer start position, in copies of up to 32 MiB per worker"},
-           "binding_resource": "one PCIe link per GPU: the packed streams of the files cross it at pcie.achieved_gbs of the pcie.h2d_peak_gbs "
-                               "this box's link copies (measured in this run); the sketch kernels take kernel_share_of_call of the call"}
+                    "bytes": ("the files in the two-bit form (fh_batch_submit_packed): 2 bits of code + 1 'is a base' bit per k-mer start "
+                              "position" if two_bit else "the files' packed streams, 1 byte per k-mer start position")
+                             + ", in copies of up to 32 MiB per worker"},
+           "binding_resource": ("the host: the workers (one per core the cgroup grants) read every file from the page cache and pack it into the "
+                                "two-bit form at text_gbs_per_worker each; the link carries pcie.frac of what it could, the sketch kernels "
+                                "take kernel_share_of_call of the call") if two_bit else
+                               ("one PCIe link per GPU: the packed streams of the files cross it at pcie.achieved_gbs of the pcie.h2d_peak_gbs "
+                                "this box's link copies (measured in this run); the sketch kernels take kernel_share_of_call of the call")}
+    if text_bytes and wall_ms > 0:
+        workers = max(1, min(_usable_cpus(), 16 * max(n_gpus, 1)))
+        out["host"] = {"workers": workers, "text_gbs_total": round(text_bytes / 1e9 / (wall_ms / 1e3), 2),
+                       "text_gbs_per_worker": round(text_bytes / 1e9 / (wall_ms / 1e3) / workers, 2),
+                       "what": "FASTA text read from the page cache (pread, 256 KiB pieces) and packed (line ends out, two-bit form) per second of the call"}
     if batch is not None:
         out["files_taken_many_per_launch"], out["files_through_own_sketcher"] = batch
     if live:
@@ -371,6 +387,8 @@ def main():
                          "c5: configs[4], batch of FASTA files through finch_sketch_files")
     ap.add_argument("--gbases", type=float, default=None, help="c2: Gbases per GPU (default 10); c4: Gbases in total (default 50)")
     ap.add_argument("--files", type=int, default=10000, help="c5: number of FASTA files")
+    ap.add_argument("--c5-dir", default=None, help="c5: sketch the files g00000.fa ... already in this directory (the live counter passes of a "
+                                                   "c5 run reuse their parent's files: a second set next to 40 GB of tmpfs is what the box's memory does not hold)")
     ap.add_argument("--k", type=int, default=21)
     ap.add_argument("--n", type=int, default=1000)
     ap.add_argument("--cpu-sample-mbases", type=float, default=600.0)  # ~11 s of one host core
@@ -675,8 +693,12 @@ def run_c5(args, F, S, dist, barrier, rank, world, my_devices, launched, gather_
             pass
     nf = max(1, min(args.files, int(0.8 * free / (3.95e6 * 1.015))))  # mean of the log-uniform lengths + newlines
     d = os.path.join(base, "finch_bench_c5_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
+    reuse = args.c5_dir is not None
+    if reuse:
+        d, nf = args.c5_dir, args.files
+        base = os.path.dirname(d)
     try:
-        if rank == 0:
+        if rank == 0 and not reuse:
             os.makedirs(d, exist_ok=True)
             with mp.get_context("fork").Pool(max(1, min(_usable_cpus(), 64))) as p2:
                 made = p2.map(_write_fasta_job, [(d, i) for i in range(nf)], chunksize=8)
@@ -739,8 +761,8 @@ def run_c5(args, F, S, dist, barrier, rank, world, my_devices, launched, gather_
                           "parallelism": "file -> GPU mapping x%d (%s)" % (world, "one call per rank" if launched and world > 1 else "one call, devices=[0..%d]" % (world - 1))},
                "roofline": c5_roofline(k_ms, k_launches, k_pos, elapsed * 1e3, world, batch=(fb1[0] - fb0[0], fb1[1] - fb0[1]),
                                        live=None if (args.no_live_pmc or world != 1) else
-                                       _live_pmc(["--workload", "c5", "--files", str(min(nf, 256))], timeout_s=240, kernels=("k2_batch", "k2_sketch")),
-                                       h2d=_h2d_peak_gbs(my_devices[0])),
+                                       _live_pmc(["--workload", "c5", "--files", str(min(nf, 256)), "--c5-dir", d], timeout_s=240, kernels=("k2_batch", "k2_sketch")),
+                                       h2d=_h2d_peak_gbs(my_devices[0]), text_bytes=sum(os.path.getsize(p) for p in paths) * args.steps),
                "cpu_baseline": None if args.no_cpu_baseline else c5_cpu_baseline(paths, lens), "sketch_check": fp}
         print(json.dumps(out), flush=True)
         return 0 if fp["matches_golden"] is not False else 3
@@ -748,7 +770,7 @@ def run_c5(args, F, S, dist, barrier, rank, world, my_devices, launched, gather_
         res = None
         if dist is not None:
             dist.barrier()
-        if rank == 0:
+        if rank == 0 and not reuse:
             shutil.rmtree(d, ignore_errors=True)
         if dist is not None:
             dist.destroy_process_group()
@@ -1025,7 +1047,7 @@ def measure_extras(F, S, dr, dg, n_reads, dev):
             return {"what": "ONE finch_sketch_files call over %d synthetic FASTA files (log-uniform 1-10 Mb, 70-column lines, "
                             "%.2f Gbases, page cache / tmpfs), library defaults (k=21 n=1000, up to 16 worker threads per GPU)" % (nf, tot / 1e9),
                     "seconds": round(best, 4), "files_per_s": round(nf / best, 1), "gbases_per_s": round(tot / best / 1e9, 2),
-                    "roofline": c5_roofline(kt[0], kt[1], kt[2], best * 1e3, 1, batch=fb, h2d=_h2d_peak_gbs(dev),
+                    "roofline": c5_roofline(kt[0], kt[1], kt[2], best * 1e3, 1, batch=fb, h2d=_h2d_peak_gbs(dev), text_bytes=sum(os.path.getsize(p) for p in paths),
                                             live=_live_pmc(["--workload", "c5", "--files", "256"], kernels=("k2_batch", "k2_sketch"))
                                             if LIVE_PMC_EXTRAS else None),
                     "cpu_baseline": c5_cpu_baseline(paths, [m[1] for m in made])}
