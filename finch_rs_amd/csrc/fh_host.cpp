@@ -2618,7 +2618,7 @@ static int finish_mash_in_place(fh_sketcher *h, const std::string &name, const f
     out.comment = "";
     out.hashes.resize(rows.size());
     for (size_t i = 0; i < rows.size(); ++i)
-        out.hashes[i] = KmerCount{recs[i].hash, std::string((const char *)km.get() + i * (size_t)k, k), recs[i].count, recs[i].extra_count};
+        out.hashes[i] = KmerCount{recs[i].hash, KmerBytes((const char *)km.get() + i * (size_t)k, (size_t)k), recs[i].count, recs[i].extra_count};
     out.filter_params = fp;
     out.sketch_params = sp;
     if (trace)
@@ -2671,7 +2671,7 @@ static int finish_sketch(fh_sketcher *h, const std::string &name, const finch_sk
     out.hashes.resize(filtered.size());
     for (size_t i = 0; i < filtered.size(); ++i) {
         const KmerRef &r = filtered[i];
-        out.hashes[i] = KmerCount{r.hash, std::string((const char *)km.get() + i * (size_t)k, k), r.count, r.extra_count};
+        out.hashes[i] = KmerCount{r.hash, KmerBytes((const char *)km.get() + i * (size_t)k, (size_t)k), r.count, r.extra_count};
     }
     out.filter_params = fp;
     out.sketch_params = sp;
@@ -3868,7 +3868,7 @@ static int to_json(const std::vector<Sketch> &sketches, std::string &o) {
         o += "],\"kmers\":[";
         for (size_t j = 0; j < s.hashes.size(); ++j) {
             if (j) o.push_back(',');
-            json_escape(o, s.hashes[j].kmer);
+            json_escape(o, s.hashes[j].kmer.str());
         }
         o += "],\"counts\":[";
         for (size_t j = 0; j < s.hashes.size(); ++j) {
@@ -4150,7 +4150,7 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
                 out.comment = "";
                 out.hashes.resize(keep);
                 for (size_t q = 0; q < keep; ++q)
-                    out.hashes[q] = KmerCount{recs[q].hash, std::string((const char *)km.get() + q * (size_t)k, k), recs[q].count, recs[q].extra_count};
+                    out.hashes[q] = KmerCount{recs[q].hash, KmerBytes((const char *)km.get() + q * (size_t)k, (size_t)k), recs[q].count, recs[q].extra_count};
                 out.filter_params = *filters;
                 out.filter_params.filter_on = 0; // lib.rs:70-76: FASTA defaults to no filtering (group_ok: not asked for either)
                 out.sketch_params = *sp;
@@ -4502,7 +4502,7 @@ int finch_sketches_from_arrays(const char *name, uint64_t seq_length, uint64_t n
     const size_t k = sp->kmer_length;
     s.hashes.resize(n);
     for (uint64_t i = 0; i < n; ++i)
-        s.hashes[i] = KmerCount{hashes[i], kmers ? std::string((const char *)kmers + i * k, k) : std::string(), counts[i],
+        s.hashes[i] = KmerCount{hashes[i], kmers ? KmerBytes((const char *)kmers + i * k, (size_t)k) : KmerBytes(), counts[i],
                                 extra_counts[i]};
     *out = res.release();
     return FH_OK;
@@ -4588,7 +4588,7 @@ uint32_t finch_guess_filter_threshold(const uint32_t *counts, uint64_t n, double
             return 0;
         }
     std::vector<KmerCount> v(n);
-    for (uint64_t i = 0; i < n; ++i) v[i] = KmerCount{i, std::string(), counts[i], 0};
+    for (uint64_t i = 0; i < n; ++i) v[i] = KmerCount{i, KmerBytes(), counts[i], 0};
     return guess_filter_threshold(v, filter_level);
 }
 

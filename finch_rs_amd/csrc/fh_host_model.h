@@ -6,8 +6,10 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <exception>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -27,12 +29,72 @@ int hfail(int code, const char *fmt, ...);
     catch (const std::exception &e) { return finch::hfail(FH_ERR_INVALID, "internal error: %s", e.what()); }    \
     catch (...) { return finch::hfail(FH_ERR_INVALID, "internal error"); }
 
+// The bytes of one k-mer.  A batch of 10 000 genomes returns ten million of them: as std::string (15 bytes inline) every k = 21
+// k-mer was a heap block of its own to build and to free.  44 bytes inline cover k <= 44 (a KmerCount is 80 bytes); longer ones
+// (and whatever a sketch file read from disk holds) go to the heap.
+class KmerBytes {
+    static constexpr uint32_t INL = 44;
+    uint32_t n_ = 0;
+    union {
+        char inl_[INL];
+        char *heap_;
+    };
+    void set(const char *p, size_t n) {
+        n_ = (uint32_t)n;
+        char *d = inl_;
+        if (n > INL) d = heap_ = (char *)::operator new(n);
+        if (n) memcpy(d, p, n);
+    }
+    void drop() {
+        if (n_ > INL) ::operator delete(heap_);
+        n_ = 0;
+    }
+
+  public:
+    KmerBytes() {}
+    KmerBytes(const char *p, size_t n) { set(p, n); }
+    KmerBytes(const std::string &s) { set(s.data(), s.size()); }
+    KmerBytes(const KmerBytes &o) { set(o.data(), o.size()); }
+    KmerBytes(KmerBytes &&o) noexcept {
+        n_ = o.n_;
+        if (n_ > INL) heap_ = o.heap_;
+        else memcpy(inl_, o.inl_, n_);
+        o.n_ = 0;
+    }
+    KmerBytes &operator=(const KmerBytes &o) {
+        if (this != &o) {
+            KmerBytes t(o);
+            drop();
+            new (this) KmerBytes(std::move(t));
+        }
+        return *this;
+    }
+    KmerBytes &operator=(KmerBytes &&o) noexcept {
+        if (this != &o) {
+            drop();
+            new (this) KmerBytes(std::move(o));
+        }
+        return *this;
+    }
+    KmerBytes &operator=(const std::string &s) {
+        drop();
+        set(s.data(), s.size());
+        return *this;
+    }
+    ~KmerBytes() { drop(); }
+    const char *data() const { return n_ > INL ? heap_ : inl_; }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    std::string str() const { return std::string(data(), n_); }
+    bool operator==(const KmerBytes &o) const { return n_ == o.n_ && memcmp(data(), o.data(), n_) == 0; }
+};
+
 struct KmerCount {
     uint64_t hash;
-    std::string kmer;
+    KmerBytes kmer;
     uint32_t count, extra_count;
-    bool has_label = false; // label: Option<Vec<u8>>; None for everything the sketchers emit, carried through the readers
-    std::string label;
+    // label: Option<Vec<u8>>; None (null) for everything the sketchers emit, carried through the readers
+    std::shared_ptr<const std::string> label;
 };
 
 // the same without the k-mer bytes (they stay in the copy-out array, `row` says where): what the filters work on when a

@@ -409,9 +409,9 @@ static int write_bsk(const std::vector<Sketch> &sketches, std::string &out) {
             const KmerCount &h = s.hashes[j];
             const size_t e = hl + 4 * j;
             b.w[e] = h.hash;
-            b.data(e + 2, h.kmer);
+            b.bytes(e + 2, h.kmer.data(), h.kmer.size(), false);
             b.w[e + 1] = (uint64_t)h.count | ((uint64_t)h.extra_count << 32);
-            if (h.has_label) b.data(e + 3, h.label);
+            if (h.label) b.data(e + 3, *h.label);
         }
         // FilterParams (finch_capnp.rs:80-97): bit 0 filtered, u32 field 1 lowAbunFilter, u32 field 2 highAbunFilter, f64
         // field 2 errFilter, f64 field 3 strandFilter; values as mod.rs:150-156 sets them
@@ -476,7 +476,12 @@ static int read_bsk(const uint8_t *data, uint64_t len, std::vector<Sketch> &out)
             h.hash = ch.word(0);
             h.count = ch.u32(2);
             h.extra_count = ch.u32(3);
-            if (!w.field_bytes(ch, 0, false, h.kmer) || !w.field_bytes(ch, 1, false, h.label, &h.has_label)) return bad();
+            std::string kmer_bytes;
+            std::string label_bytes;
+            bool has_label = false;
+            if (!w.field_bytes(ch, 0, false, kmer_bytes) || !w.field_bytes(ch, 1, false, label_bytes, &has_label)) return bad();
+            if (has_label) h.label = std::make_shared<const std::string>(std::move(label_bytes));
+            h.kmer = kmer_bytes;
         }
         capnp::StructR sp, fp;
         if (!w.field_struct(cs, 4, sp) || !w.field_struct(cs, 3, fp)) return bad();
@@ -600,10 +605,10 @@ static int read_msh(const uint8_t *data, uint64_t len, std::vector<Sketch> &out)
         s.hashes.resize(hs.size());
         // mash.rs:95-121: no counts -> (1, 0); else zip(hashes, counts) -> (c, c / 2)
         if (cs.empty()) {
-            for (size_t j = 0; j < hs.size(); ++j) s.hashes[j] = KmerCount{hs[j], std::string(), 1u, 0u};
+            for (size_t j = 0; j < hs.size(); ++j) s.hashes[j] = KmerCount{hs[j], KmerBytes(), 1u, 0u};
         } else {
             s.hashes.resize(std::min(hs.size(), cs.size()));
-            for (size_t j = 0; j < s.hashes.size(); ++j) s.hashes[j] = KmerCount{hs[j], std::string(), cs[j], cs[j] / 2};
+            for (size_t j = 0; j < s.hashes.size(); ++j) s.hashes[j] = KmerCount{hs[j], KmerBytes(), cs[j], cs[j] / 2};
         }
         if (!w.field_bytes(r, 2, true, s.name) || !w.field_bytes(r, 3, true, s.comment)) return bad();
         s.seq_length = r.word(1);

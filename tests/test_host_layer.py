@@ -749,3 +749,29 @@ def test_parallel_gzip_keeps_going_through_a_very_compressible_member(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.split() == [str(len(text)), hashlib.md5(text).hexdigest()]
     assert "parallel gzip" in r.stderr and "sequential reader took over" not in r.stderr, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("k", [15, 21, 44, 45, 64])
+def test_kmer_bytes_of_every_length_survive_the_three_formats(k):
+    """a k-mer's bytes live inline in its record up to 44 bytes and on the heap beyond (fh_host_model.h KmerBytes): both
+    kinds through finch_sketches_from_arrays, the .sk / .bsk / .msh writers and their readers, and the filters' reordering"""
+    rng = np.random.default_rng(k)
+    n = 300
+    counts = (rng.poisson(3, n) + 1).astype(np.uint32)
+    kc = kc_of(counts, (counts * rng.random(n)).astype(np.uint32))
+    kc["hash"] = np.sort(rng.integers(1, 2**62, n).astype(np.uint64))
+    km = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=(n, k))
+    params = SketchParams.mash(n, n, True, k, 0)
+    sk = H.sketches_from_arrays("long", 10, 20, kc, km, params, H.FilterParams(False))
+    got = sk.sketch(0)
+    assert np.array_equal(got.arrays[0], kc) and np.array_equal(got.arrays[1], km)
+    for back in (H.sketches_from_json(sk.to_json()), H.sketches_from_bsk(sk.to_bsk())):
+        g2 = back.sketch(0)
+        assert np.array_equal(g2.arrays[0]["hash"], kc["hash"]) and np.array_equal(g2.arrays[0]["count"], kc["count"])
+        assert np.array_equal(g2.arrays[1], km)
+    m = H.sketches_from_msh(sk.to_msh()).sketch(0)  # (.msh carries no k-mer bytes)
+    assert np.array_equal(m.arrays[0]["hash"], kc["hash"])
+    fp = sk.apply_filters(0, H.FilterParams(True, (2, None), 0.0, 0.0))
+    keep = kc["count"] >= 2
+    got = sk.sketch(0)
+    assert np.array_equal(got.arrays[0], kc[keep]) and np.array_equal(got.arrays[1], km[keep]) and fp.filter_on
