@@ -35,16 +35,24 @@ constexpr uint64_t TILE_POS = 2048, TILE_BYTES = 768, CODES_BYTES = 512;
 
 inline uint64_t region_bytes(uint64_t len) { return ((len + TILE_POS - 1) / TILE_POS + 1) * TILE_BYTES; }
 
-// 32 bytes -> their codes and base bits (fh_core.h classify4: the byte's low three bits pick the letter it has to be)
-inline void pack32_scalar(const uint8_t *p, uint64_t &codes, uint32_t &good) {
+// one byte -> its code and base bit (fh_core.h classify4: the byte's low three bits pick the letter it has to be)
+inline void classify1(uint8_t b, uint64_t &code, uint32_t &good) {
     static const uint8_t EXPECT[8] = {0xFF, 'A', 0xFF, 'C', 'T', 'U', 0xFF, 'G'};
     static const uint8_t CODE[8] = {0, 0, 0, 1, 3, 3, 0, 2};
+    code = CODE[b & 7];
+    good = (uint8_t)(b & 0xDF) == EXPECT[b & 7];
+}
+
+// 32 bytes -> their codes and base bits
+inline void pack32_scalar(const uint8_t *p, uint64_t &codes, uint32_t &good) {
     uint64_t c = 0;
     uint32_t g = 0;
     for (int i = 0; i < 32; ++i) {
-        const uint8_t b = p[i];
-        c |= (uint64_t)CODE[b & 7] << (2 * i);
-        g |= (uint32_t)((uint8_t)(b & 0xDF) == EXPECT[b & 7]) << i;
+        uint64_t ci;
+        uint32_t gi;
+        classify1(p[i], ci, gi);
+        c |= ci << (2 * i);
+        g |= gi << i;
     }
     codes = c;
     good = g;
@@ -156,7 +164,7 @@ struct Packer {
                                                     (char)0xFF, 'A', (char)0xFF, 'C', 'T', 'U', (char)0xFF, 'G', 0, 0, 0, 0, 0, 0, 0, 0);
         const __m256i seven = _mm256_set1_epi8(7), fold = _mm256_set1_epi8((char)0xDF);
         // (the accumulator lives in registers for the length of the call: as members every step would wait for the stores of the one before)
-        uint64_t lo = (uint64_t)acc_c, hi = (uint64_t)(acc_c >> 64), gg = acc_g, grp = groups;
+        uint64_t lo = (uint64_t)acc_c, gg = acc_g, grp = groups; // (acc_c holds fewer than 64 bits between calls: na < 32)
         unsigned a = na;
         uint8_t *const reg = region;
         size_t i = 0;
@@ -189,7 +197,7 @@ struct Packer {
             // append: a < 32 positions wait in (lo, gg); cc has at most 64 bits, so lo | cc << 2a spills into hi
             const unsigned sh = 2 * a;
             lo |= cc << sh;
-            hi = sh ? cc >> (64 - sh) : 0;
+            const uint64_t hi = sh ? cc >> (64 - sh) : 0; // what of cc does not fit the word
             gg |= gc << a;
             a += (unsigned)_mm_popcnt_u32(keep);
             if (a >= 32) {
@@ -202,7 +210,6 @@ struct Packer {
                 gg >>= 32;
                 a -= 32;
             }
-            hi = 0;
             i += 32;
         }
         acc_c = lo, acc_g = gg, na = a, groups = grp;
@@ -226,9 +233,8 @@ struct Packer {
         if (fused) {
             uint64_t c;
             uint32_t g;
-            uint8_t one[32] = {b};
-            pack32_scalar(one, c, g);
-            append(c & 3u, g & 1u, 1);
+            classify1(b, c, g);
+            append(c, g, 1);
             return;
         }
         if (fill >= PIECE) drain();
