@@ -2273,6 +2273,20 @@ static int fastq_host_strip_to_device(ByteSource &src, fh_sketcher *h, FastxStat
     static const bool trace = cfg("trace") != nullptr;
     auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now_s();
+    // (trace: how long the cgroup's CPU quota held this process's threads back meanwhile -- a team of as many threads as the
+    // quota has CPUs, next to the pushing thread and the runtime's, is throttled as soon as anything else runs)
+    auto throttled_us = [] {
+        unsigned long long v = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.stat", "r")) {
+            char key[64];
+            unsigned long long x;
+            while (fscanf(f, "%63s %llu", key, &x) == 2)
+                if (strcmp(key, "throttled_usec") == 0) v = x;
+            fclose(f);
+        }
+        return v;
+    };
+    const unsigned long long thr0 = trace ? throttled_us() : 0;
     double t_wait_slot = 0, t_strip = 0, t_push = 0, t_wait_job = 0;
     unsigned n_chunks = 0;
     int rc = FH_OK;
@@ -2392,8 +2406,9 @@ static int fastq_host_strip_to_device(ByteSource &src, fh_sketcher *h, FastxStat
         for (auto &x : helpers) x.join();
     }
     if (trace)
-        fprintf(stderr, "[finch] fastq host strip: %u chunks of <= %.0f MiB of text on %u threads in %.1f ms: strip %.1f ms, producer waited %.1f ms for a buffer, pushes took %.1f ms and waited %.1f ms for chunks\n",
-                n_chunks, CHUNK / 1048576.0, T, (now_s() - t_begin) * 1e3, t_strip * 1e3, t_wait_slot * 1e3, t_push * 1e3, t_wait_job * 1e3);
+        fprintf(stderr, "[finch] fastq host strip: %u chunks of <= %.0f MiB of text on %u threads in %.1f ms: strip %.1f ms, producer waited %.1f ms for a buffer, pushes took %.1f ms and waited %.1f ms for chunks; the cgroup throttled its threads for %.1f ms meanwhile\n",
+                n_chunks, CHUNK / 1048576.0, T, (now_s() - t_begin) * 1e3, t_strip * 1e3, t_wait_slot * 1e3, t_push * 1e3, t_wait_job * 1e3,
+                (throttled_us() - thr0) / 1e3);
     if (rc != FH_OK) return hfail(rc, "%s", msg.c_str());
     if (prc != FH_OK) return hfail(prc, "%s", pmsg.c_str());
     st.total_bases = bases_total;
