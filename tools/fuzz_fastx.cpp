@@ -1,7 +1,7 @@
 // Mutation fuzzer for the host reader stack (fh_host.cpp: format sniffing, gzip / BGZF containers, the serial and the
 // multi-threaded inflate sources, the FASTA / FASTQ parser) through its GPU-free entry points, under ASan + UBSan:
 //   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -Iinclude -Ifinch_rs_amd/csrc \
-//       tools/fuzz_fastx.cpp finch_rs_amd/csrc/fh_host.cpp finch_rs_amd/csrc/fh_serial.cpp \
+//       tools/fuzz_fastx.cpp finch_rs_amd/csrc/fh_host.cpp finch_rs_amd/csrc/fh_serial.cpp finch_rs_amd/csrc/fh_options.cpp \
 //       -Lfinch_rs_amd -lfinch_hip -Wl,-rpath,$PWD/finch_rs_amd -lz -ldl -lpthread -o /tmp/fuzz_fastx
 //   ASAN_OPTIONS=detect_leaks=0 /tmp/fuzz_fastx [iterations [seed]]
 // (the device engine's entry points come from libfinch_hip.so and are never reached: finch_fastx_scan only reads and
@@ -145,6 +145,8 @@ static void scan(const std::vector<uint8_t> &img, const Case *expect) {
     }
 }
 
+static uint64_t n_two_bit = 0;
+
 int main(int argc, char **argv) {
     const uint64_t iters = argc > 1 ? strtoull(argv[1], nullptr, 10) : 20000;
     const uint64_t seed = argc > 2 ? strtoull(argv[2], nullptr, 10) : 1;
@@ -177,8 +179,24 @@ int main(int argc, char **argv) {
         std::vector<uint8_t> d = c.image;
         mutate(rng, d);
         scan(d, nullptr);
+        // the batch path's FASTA walk into the two-bit form (FastaTwoBit, fh_pack2.h) on the same bytes, in pieces of a random size, in
+        // each of the packer's forms: the region it is given is EXACTLY as large as the header says it must be (ASan watches the end)
+        if (!d.empty() && d[0] == '>') {
+            const uint64_t cap = ((d.size() + 2047) / 2048 + 1) * 768;
+            std::vector<uint8_t> region(cap);
+            static const uint64_t pieces[] = {1, 7, 31, 32, 33, 64, 1000, 4096, 16384, 1 << 20};
+            static const char *forms[] = {"0", "1", "2"};
+            setenv("FH_DEBUG", (std::string("pack_scalar=") + forms[rng() % 3]).c_str(), 1);
+            uint64_t pos = 0, nr = 0, nb = 0;
+            if (finch_fasta_two_bit_probe(d.data(), d.size(), pieces[rng() % 10], region.data(), cap, &pos, &nr, &nb) != 0 || pos > d.size()) {
+                fprintf(stderr, "two-bit walk failed on a text of %zu bytes (positions %llu)\n", d.size(), (unsigned long long)pos);
+                return 1;
+            }
+            ++n_two_bit;
+        }
         if ((it + 1) % 2000 == 0) fprintf(stderr, "%llu mutated inputs\n", (unsigned long long)(it + 1));
     }
-    printf("done: %llu mutated inputs, %llu scanned, %llu refused\n", (unsigned long long)iters, (unsigned long long)n_ok, (unsigned long long)n_err);
+    printf("done: %llu mutated inputs, %llu scanned, %llu refused; %llu plain FASTA texts also walked into the two-bit form\n", (unsigned long long)iters,
+           (unsigned long long)n_ok, (unsigned long long)n_err, (unsigned long long)n_two_bit);
     return 0;
 }
