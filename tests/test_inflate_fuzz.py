@@ -30,7 +30,8 @@ def test_mutated_deflate_streams_under_sanitizers(tmp_path):
 
 def test_mutated_fastx_images_under_sanitizers(tmp_path):
     """tools/fuzz_fastx.cpp: the whole reader stack of fh_host.cpp (sniffing, gzip / BGZF containers, the serial and the
-    multi-threaded inflate sources, the FASTA / FASTQ parser) through finch_fastx_scan, rebuilt with ASan + UBSan; the
+    multi-threaded inflate sources, the FASTA / FASTQ parser) through finch_fastx_scan, and the batch path's FASTA walk into the
+    two-bit form (finch_fasta_two_bit_probe) on the mutated plain FASTA texts, rebuilt with ASan + UBSan; the
     device engine comes from libfinch_hip.so and is never called."""
     gxx = shutil.which("g++")
     if gxx is None:
@@ -53,3 +54,4 @@ def test_mutated_fastx_images_under_sanitizers(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
     assert "undamaged inputs scanned right with 1 and 4 inflate threads" in r.stdout
     assert "done: 400 mutated inputs" in r.stdout
+    assert "walked into the two-bit form" in r.stdout  # (the batch path's FASTA walk and packer, exact-size regions)
