@@ -131,6 +131,15 @@ def test_fasta_walk_in_pieces_matches_the_restatement(eol, piece, form):
         want, wrec, wbases = fasta_restated(t)
         region, m, nrec, bases = H.fasta_two_bit_probe(t, piece)
         assert (m, nrec, bases) == (len(want), wrec, wbases), (t[:40], piece)
+        if form == 0:  # ... and seq_length is what the oracle's parse_fastx restatement counts (lib.rs:51-94, mash.rs:72)
+            from oracle import oracle as O
+            o = O.OracleSketcher(O.MASH, 10, 3, 0)
+            o.sketch_stream(t)
+            assert o.total_bases_and_kmers()[0] == bases, (t[:40], piece)
+            # ... and the base bits of the region give the oracle's count of valid 3-mers (mash.rs:35: windows without a breaker)
+            good = np.unpackbits(region.reshape(-1, TILE_BYTES)[:, 512:].copy().reshape(-1), bitorder="little")[:m].astype(np.int64)
+            runs = good[:-2] + good[1:-1] + good[2:] if m >= 3 else np.zeros(0, np.int64)
+            assert int((runs == 3).sum()) == o.total_bases_and_kmers()[1], (t[:40], piece)
         assert np.array_equal(masked(region), masked(region_model(np.frombuffer(want, np.uint8)))), (t[:40], piece, form)
 
 
