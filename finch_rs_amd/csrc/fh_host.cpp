@@ -4034,11 +4034,13 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
     std::vector<int> devs;
     if (devices && n_devices) devs.assign(devices, devices + n_devices);
     else devs.push_back(0);
-    // host workers per GPU: a worker spends most of a small file staging it (page cache -> pinned memory, blanks dropped) and
-    // waits for the device once per file; 16 of them keep one GPU 85 % busy (9400 files/s against 8600 with 12 on a 16-core
-    // grant, profiles/r04_c5_threads.txt), more than the cores granted run slower than fewer (24: 5500)
+    // host workers per GPU: a worker's time is reading its files and packing them (page cache -> pinned memory, line ends out, the
+    // two-bit form), the device and the link have room to spare (docs/MEASUREMENTS_r06.md 1b); 16 is what the boxes so far grant,
+    // and more workers than cores granted run slower than fewer (24 on a 16-core grant: 5500 files/s, profiles/r04_c5_threads.txt)
     if (n_threads == 0) n_threads = std::min<uint32_t>(16u, std::max<uint32_t>(4u, usable_cpus() / (uint32_t)devs.size())) * (uint32_t)devs.size();
     n_threads = std::max<uint32_t>(1, std::min<uint32_t>(n_threads, std::max<uint32_t>(n_files, 1)));
+    static const bool trace_call = cfg("trace") != nullptr;
+    const auto call_t0 = std::chrono::steady_clock::now();
     auto res = std::make_unique<finch_sketches>();
     res->v.resize(n_files);
     std::atomic<uint32_t> next{0};
@@ -4329,7 +4331,12 @@ int finch_sketch_files(const char *const *filenames, uint32_t n_files, const fin
         } catch (...) { // fewer workers than asked for: the files are pulled from one queue, those that started take them all
         }
         if (th.empty()) guarded(0u);
+        const auto spawned = std::chrono::steady_clock::now();
         for (auto &t : th) t.join();
+        if (trace_call && n_files > 1)
+            fprintf(stderr, "[finch] sketch_files: %u files on %u workers: %.1f ms to the last worker's start, %.1f ms until all had ended\n", n_files, n_threads,
+                    std::chrono::duration<double, std::milli>(spawned - call_t0).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - call_t0).count());
         if (worker_threw) return hfail(FH_ERR_CAPACITY, "out of host memory");
     }
     if (first_err_code != FH_OK) return hfail(first_err_code, "%s", first_err_msg.c_str());
